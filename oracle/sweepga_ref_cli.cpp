@@ -1,0 +1,118 @@
+// TEST INFRASTRUCTURE ONLY -- `sweepga-ref`: the CPU oracle behind the reference's own
+// filter-path command line (`sweepga <paf> --output-file out.paf ...`), so that the inline
+// PAFs of the reference's binary-invoking tests can be replayed.  Flag names and defaults
+// follow src/cli.rs:204-288; flag -> FilterConfig mapping follows src/main.rs:3477-3568,
+// 3590-3619, 3689-3691.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "sweepga_oracle.h"
+
+using namespace orc;
+
+static void die(const std::string& msg) {
+  std::fprintf(stderr, "sweepga-ref: %s\n", msg.c_str());
+  std::exit(2);
+}
+
+int main(int argc, char** argv) {
+  std::string input, output_file;
+  std::string num_mappings = "many:many", scoring = "log-length-ani", min_identity = "0";
+  std::string scaffold_filter = "many:many", min_scaffold_identity = "0";
+  double overlap = 0.95, scaffold_overlap = 0.5;
+  uint64_t scaffold_jump = 50000, scaffold_mass = 10000, scaffold_dist = 0;
+  bool have_block_length = false;
+  uint64_t block_length = 0;
+  bool keep_self = false, no_filter = false, scaffolds_only = false;
+
+  auto need = [&](int& i) -> std::string {
+    if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]);
+    return argv[++i];
+  };
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    std::string val;
+    size_t eq = a.find('=');
+    bool has_eq = a.rfind("--", 0) == 0 && eq != std::string::npos;
+    if (has_eq) {
+      val = a.substr(eq + 1);
+      a = a.substr(0, eq);
+    }
+    auto value = [&]() { return has_eq ? val : need(i); };
+    if (a == "--output-file" || a == "-o") output_file = value();
+    else if (a == "--num-mappings") num_mappings = value();
+    else if (a == "--overlap") overlap = std::strtod(value().c_str(), nullptr);
+    else if (a == "--scoring") scoring = value();
+    else if (a == "--min-aln-identity") min_identity = value();
+    else if (a == "--min-aln-length") {
+      if (!parse_metric_number(value(), &block_length)) die("bad --min-aln-length");
+      have_block_length = true;
+    } else if (a == "--self") keep_self = true;
+    else if (a == "--no-filter") no_filter = true;
+    else if (a == "--scaffold-jump") {
+      if (!parse_metric_number(value(), &scaffold_jump)) die("bad --scaffold-jump");
+    } else if (a == "--scaffold-mass") {
+      if (!parse_metric_number(value(), &scaffold_mass)) die("bad --scaffold-mass");
+    } else if (a == "--scaffold-filter") scaffold_filter = value();
+    else if (a == "--scaffold-overlap") scaffold_overlap = std::strtod(value().c_str(), nullptr);
+    else if (a == "--scaffold-dist") {
+      if (!parse_metric_number(value(), &scaffold_dist)) die("bad --scaffold-dist");
+    } else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
+    else if (a == "--scaffolds-only") scaffolds_only = true;
+    else if (a == "--no-adaptive-scaffolds" || a == "--quiet" || a == "--paf") { /* no effect here */ }
+    else if (a == "--threads" || a == "-t") (void)value();
+    else if (a.rfind("-", 0) == 0 && a != "-") die("unknown flag " + a);
+    else input = a;
+  }
+  if (input.empty()) die("usage: sweepga-ref <in.paf> [--output-file out.paf] [filter flags]");
+
+  std::string out_path = output_file.empty() ? "/dev/stdout" : output_file;
+  if (no_filter) {  // main.rs:3461-3470
+    std::ifstream in(input, std::ios::binary);
+    std::ofstream out(out_path, std::ios::binary);
+    std::string line;
+    while (std::getline(in, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      out << line << "\n";
+    }
+    return 0;
+  }
+
+  FilterConfig cfg;
+  int mode;
+  uint64_t pq, pt;
+  if (!parse_filter_mode(num_mappings, &mode, &pq, &pt)) return 1;
+  cfg.mapping_filter_mode = mode;
+  cfg.mapping_max_per_query = pq;
+  cfg.mapping_max_per_target = pt;
+  if (!parse_filter_mode(scaffold_filter, &mode, &pq, &pt)) return 1;
+  cfg.scaffold_filter_mode = mode;
+  cfg.scaffold_max_per_query = pq;
+  cfg.scaffold_max_per_target = pt;
+  cfg.scoring_function = parse_scoring(scoring);
+  // clamp_scaffold_params is a no-op for PAF input (no .fai for a PAF): main.rs:3515-3527
+  cfg.min_block_length = have_block_length ? block_length : 0;
+  cfg.overlap_threshold = overlap;
+  cfg.scaffold_gap = scaffold_jump;
+  cfg.min_scaffold_length = scaffold_mass;
+  cfg.scaffold_overlap_threshold = scaffold_overlap;
+  cfg.scaffold_max_deviation = scaffold_dist;
+  if (!parse_identity_value(min_identity, &cfg.min_identity)) die("bad --min-aln-identity");
+  if (min_scaffold_identity.empty())
+    cfg.min_scaffold_identity = cfg.min_identity;
+  else if (!parse_identity_value(min_scaffold_identity, &cfg.min_scaffold_identity))
+    die("bad --min-scaffold-identity");
+  cfg.keep_self = keep_self;  // || no_filter, handled above
+  cfg.scaffolds_only = scaffolds_only;
+
+  try {
+    PafFilter(cfg).filter_paf(input, out_path);
+  } catch (const std::exception& e) {
+    die(e.what());
+  }
+  return 0;
+}

@@ -1,0 +1,25 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is the checker: build it once per session if its .so is missing/stale."""
+    odir = os.path.join(ROOT, "oracle")
+    so = os.path.join(odir, "liboracle.so")
+    srcs = [os.path.join(odir, f) for f in os.listdir(odir) if f.endswith((".cpp", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", odir, "-s"])
+    yield
