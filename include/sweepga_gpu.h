@@ -1,0 +1,191 @@
+/* sweepga_gpu.h -- C ABI of the MI355X plane-sweep / scaffold filter.
+ *
+ * Drop-in boundary for sweepga's filter path (`sweepga <paf> --output-file ...`).  The
+ * reference has no FFI layer; the seam this library replaces is
+ *
+ *     PafFilter::apply_filters(&self, Vec<RecordMeta>) -> Result<HashMap<usize, RecordMeta>>
+ *                                                         (src/paf_filter.rs:379-382)
+ *
+ * called from PafFilter::filter_paf (src/paf_filter.rs:283), unified_filter::filter_file
+ * (src/unified_filter.rs:316) and examples/compare_filter_outcomes.rs:62-63.  The host keeps
+ * CLI parsing, PAF/.1aln I/O and name -> id interning; everything between "records parsed" and
+ * "per-record status + chain id" runs in hand-written gfx950 kernels.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes; the library owns device
+ *     memory, streams and staging inside swg_ctx;
+ *   - every call returns SWG_OK (0) or a negative SWG_ERR_* code; swg_last_error() gives text;
+ *   - no exceptions, aborts or allocations cross the boundary;
+ *   - one swg_ctx is used by one host thread at a time; contexts are independent (one per GPU);
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     SWG_ERR_NO_DEVICE.
+ */
+#ifndef SWEEPGA_GPU_H
+#define SWEEPGA_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWG_ABI_VERSION 1
+
+/* error codes */
+#define SWG_OK 0
+#define SWG_ERR_INVALID (-1)     /* bad argument */
+#define SWG_ERR_NO_DEVICE (-2)   /* no HIP device / device init failed */
+#define SWG_ERR_HIP (-3)         /* a HIP runtime call or kernel failed */
+#define SWG_ERR_OOM (-4)         /* device or host allocation failed */
+#define SWG_ERR_RANGE (-5)       /* coordinate >= 2^32, or composite sort key wider than 64 bits */
+#define SWG_ERR_UNSUPPORTED (-6) /* valid in the reference, not implemented here (documented) */
+
+/* ScoringFunction, src/filter_types.rs:8-14 */
+#define SWG_SCORE_IDENTITY 0
+#define SWG_SCORE_LENGTH 1
+#define SWG_SCORE_LENGTH_IDENTITY 2
+#define SWG_SCORE_LOG_LENGTH_IDENTITY 3
+#define SWG_SCORE_MATCHES 4
+
+/* FilterMode, src/filter_types.rs:18-22 */
+#define SWG_MODE_ONE_TO_ONE 0
+#define SWG_MODE_ONE_TO_MANY 1
+#define SWG_MODE_MANY_TO_MANY 2
+
+/* per-record result, ChainStatus of src/mapping.rs:82-86 plus "dropped" */
+#define SWG_ST_DROPPED 0
+#define SWG_ST_SCAFFOLD 1   /* st:Z:scaffold   */
+#define SWG_ST_RESCUED 2    /* st:Z:rescued    */
+#define SWG_ST_UNASSIGNED 3 /* st:Z:unassigned */
+
+/* usize::MAX of the reference ("keep all") for the k arguments of the sweep entry points */
+#define SWG_K_INF UINT64_MAX
+
+typedef struct swg_ctx swg_ctx;
+
+/* The fields of FilterConfig (src/paf_filter.rs:20-49) that the filter reads, plus the two
+ * PafFilter builder switches (src/paf_filter.rs:267-275).  Limits: 0 means None. */
+typedef struct swg_config {
+  uint64_t min_block_length;         /* --min-aln-length        */
+  int32_t mapping_filter_mode;       /* --num-mappings (mode)   */
+  uint64_t mapping_max_per_query;    /*   per-query limit, 0 = None  */
+  uint64_t mapping_max_per_target;   /*   per-target limit, 0 = None */
+  int32_t scaffold_filter_mode;      /* --scaffold-filter       */
+  uint64_t scaffold_max_per_query;
+  uint64_t scaffold_max_per_target;
+  double overlap_threshold;          /* --overlap               */
+  uint64_t scaffold_gap;             /* --scaffold-jump; 0 disables scaffolding */
+  uint64_t min_scaffold_length;      /* --scaffold-mass         */
+  double scaffold_overlap_threshold; /* --scaffold-overlap      */
+  uint64_t scaffold_max_deviation;   /* --scaffold-dist         */
+  int32_t scoring_function;          /* --scoring               */
+  double min_identity;               /* --min-aln-identity      */
+  double min_scaffold_identity;      /* --min-scaffold-identity */
+  int32_t keep_self;                 /* --self                  */
+  int32_t scaffolds_only;            /* --scaffolds-only        */
+} swg_config;
+
+/* Column (SoA) form of Vec<RecordMeta> (src/paf_filter.rs:54-71), one entry per parsed PAF /
+ * .1aln record in input (rank) order.  Sequence names are interned by the host into one id
+ * space shared by queries and targets (the reference's SequenceIndex, src/sequence_index.rs:7-31);
+ * the two per-sequence tables give each sequence its genome under the two prefix rules the
+ * reference uses.  Pointers are host pointers for swg_filter and device pointers for
+ * swg_filter_device. */
+typedef struct swg_records {
+  uint64_t n;                /* number of records */
+  const uint32_t* q_id;      /* [n] sequence id of the query name  */
+  const uint32_t* t_id;      /* [n] sequence id of the target name */
+  const uint32_t* q_start;   /* [n] */
+  const uint32_t* q_end;     /* [n] */
+  const uint32_t* t_start;   /* [n] */
+  const uint32_t* t_end;     /* [n] */
+  const double* identity;    /* [n] RecordMeta.identity */
+  const uint32_t* matches;   /* [n] RecordMeta.matches */
+  const uint32_t* block_len; /* [n] RecordMeta.block_length */
+  const uint8_t* strand;     /* [n] 0 = '+', 1 = '-' */
+  uint32_t n_seq;            /* number of sequence ids */
+  const uint32_t* seq_genome_last; /* [n_seq] genome id, prefix = up to the LAST '#'
+                                      (src/paf_filter.rs:1022-1030) */
+  uint32_t n_genome_last;
+  const uint32_t* seq_genome_two;  /* [n_seq] genome id, prefix = first two '#' parts
+                                      (src/plane_sweep_scaffold.rs:13-22) */
+  uint32_t n_genome_two;
+} swg_records;
+
+/* Per-call timing/statistics (optional, may be NULL). */
+typedef struct swg_stats {
+  uint64_t n_in;          /* records in */
+  uint64_t n_retained;    /* after the step-1 retain (src/paf_filter.rs:384-388) */
+  uint64_t n_swept;       /* after the mapping plane sweep */
+  uint64_t n_chains;      /* chains built */
+  uint64_t n_chains_kept; /* chains after span/identity filter and scaffold sweep */
+  uint64_t n_out;         /* records kept */
+  double device_ms;       /* GPU time of the call measured with HIP events on the ctx stream */
+  double h2d_ms, d2h_ms;  /* copies (swg_filter only) */
+} swg_stats;
+
+/* ---- context ------------------------------------------------------------------------- */
+int swg_abi_version(void);
+/* device: HIP device ordinal.  On failure *out is NULL and the code says why. */
+int swg_create(int device, swg_ctx** out);
+void swg_destroy(swg_ctx* ctx);
+/* Text of the last error on this context (or of the last failed swg_create if ctx is NULL). */
+const char* swg_last_error(const swg_ctx* ctx);
+/* The HIP stream (hipStream_t) all work of this context is enqueued on. */
+void* swg_stream(swg_ctx* ctx);
+int swg_synchronize(swg_ctx* ctx);
+
+/* ---- the filter: PafFilter::apply_filters (src/paf_filter.rs:379-747) ----------------- */
+/* status_out[n]: SWG_ST_*; chain_out[n]: N of "ch:Z:chain_N", 0 = no ch:Z: tag.
+ * Host buffers in, host buffers out (copies included). */
+int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint8_t* status_out,
+               uint32_t* chain_out, swg_stats* stats);
+/* Same with every pointer of `rec`, status_out and chain_out in device memory of ctx's GPU.
+ * Asynchronous on swg_stream(ctx) except for the small read-backs the pipeline needs. */
+int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg,
+                      uint8_t* status_out, uint32_t* chain_out, swg_stats* stats);
+
+/* ---- lower public seams of the reference, exercised by its tests ---------------------- */
+/* plane_sweep_query / plane_sweep_target / plane_sweep_both (src/plane_sweep_exact.rs:268,
+ * 355, 436) on ONE segment of n mappings given as host arrays.  axis: 0 query, 1 target,
+ * 2 both.  keep_out[i] = 1 iff index i is in the returned Vec<usize>.  u64 coordinates as in
+ * PlaneSweepMapping; values >= 2^32 give SWG_ERR_RANGE. */
+int swg_plane_sweep(swg_ctx* ctx, int axis, uint64_t n, const uint64_t* q_start,
+                    const uint64_t* q_end, const uint64_t* t_start, const uint64_t* t_end,
+                    const double* identity, uint64_t k_query, uint64_t k_target,
+                    double overlap_threshold, int scoring, uint8_t* keep_out);
+
+/* plane_sweep_scaffolds (src/plane_sweep_scaffold.rs:47-94) on n chains; q_id/t_id are
+ * sequence ids, seq_genome_two as in swg_records.  order_out receives the kept indices in the
+ * reference's output order, *n_kept their number. */
+int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_t* q_id, const uint32_t* t_id,
+                              uint32_t n_seq, const uint32_t* seq_genome_two, uint32_t n_genome_two,
+                              const uint64_t* q_start, const uint64_t* q_end,
+                              const uint64_t* t_start, const uint64_t* t_end, const double* identity,
+                              int mode, uint64_t max_per_query, uint64_t max_per_target,
+                              double overlap_threshold, int scoring, uint64_t* order_out,
+                              uint64_t* n_kept);
+
+/* merge_mappings_into_chains (src/paf_filter.rs:750-933) on n records (no retain, no sweep).
+ * chain_of[i] = index of record i's chain in the reference's all_chains order; per-chain
+ * outputs hold *n_chains entries (buffers sized n). */
+int swg_merge_chains(swg_ctx* ctx, const swg_records* rec, uint64_t max_gap, uint32_t* chain_of,
+                     uint32_t* c_q_start, uint32_t* c_q_end, uint32_t* c_t_start,
+                     uint32_t* c_t_end, double* c_weighted_identity, uint64_t* n_chains);
+
+/* UnionFind::get_sets (src/union_find.rs:52-63) after union(xs[e], ys[e]) for e = 0..m-1:
+ * set_of[i] = position of i's set in get_sets() order (ascending smallest... see DESIGN.md). */
+int swg_union_find_sets(swg_ctx* ctx, uint64_t n, uint64_t m, const uint32_t* xs,
+                        const uint32_t* ys, uint32_t* set_of, uint64_t* n_sets);
+
+/* f64::ln as the reference evaluates it (glibc log) for n host doubles, computed on the GPU. */
+int swg_log(swg_ctx* ctx, uint64_t n, const double* x, double* y);
+/* ln(first + i * stride) for i in [0, n), compared on the device against nothing: returns the
+ * values so a test can compare them with the host libm. */
+int swg_log_range(swg_ctx* ctx, uint64_t first, uint64_t stride, uint64_t n, double* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWEEPGA_GPU_H */

@@ -1,0 +1,177 @@
+"""ctypes binding of include/sweepga_gpu.h.  There is no CPU fallback: if the HIP library is
+missing or no GPU is usable, every compute call raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsweepga_gpu.so")
+
+SWG_OK = 0
+ERR_NAMES = {-1: "SWG_ERR_INVALID", -2: "SWG_ERR_NO_DEVICE", -3: "SWG_ERR_HIP", -4: "SWG_ERR_OOM",
+             -5: "SWG_ERR_RANGE", -6: "SWG_ERR_UNSUPPORTED"}
+K_INF = 2**64 - 1
+
+# every symbol include/sweepga_gpu.h declares
+SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
+           "swg_filter", "swg_filter_device", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
+           "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range"]
+
+
+class SwgError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {text}")
+        self.code = code
+
+
+class SwgConfig(C.Structure):
+    _fields_ = [
+        ("min_block_length", C.c_uint64),
+        ("mapping_filter_mode", C.c_int32),
+        ("mapping_max_per_query", C.c_uint64),
+        ("mapping_max_per_target", C.c_uint64),
+        ("scaffold_filter_mode", C.c_int32),
+        ("scaffold_max_per_query", C.c_uint64),
+        ("scaffold_max_per_target", C.c_uint64),
+        ("overlap_threshold", C.c_double),
+        ("scaffold_gap", C.c_uint64),
+        ("min_scaffold_length", C.c_uint64),
+        ("scaffold_overlap_threshold", C.c_double),
+        ("scaffold_max_deviation", C.c_uint64),
+        ("scoring_function", C.c_int32),
+        ("min_identity", C.c_double),
+        ("min_scaffold_identity", C.c_double),
+        ("keep_self", C.c_int32),
+        ("scaffolds_only", C.c_int32),
+    ]
+
+
+class SwgRecords(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("q_id", C.c_void_p),
+        ("t_id", C.c_void_p),
+        ("q_start", C.c_void_p),
+        ("q_end", C.c_void_p),
+        ("t_start", C.c_void_p),
+        ("t_end", C.c_void_p),
+        ("identity", C.c_void_p),
+        ("matches", C.c_void_p),
+        ("block_len", C.c_void_p),
+        ("strand", C.c_void_p),
+        ("n_seq", C.c_uint32),
+        ("seq_genome_last", C.c_void_p),
+        ("n_genome_last", C.c_uint32),
+        ("seq_genome_two", C.c_void_p),
+        ("n_genome_two", C.c_uint32),
+    ]
+
+
+class SwgStats(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_uint64),
+        ("n_retained", C.c_uint64),
+        ("n_swept", C.c_uint64),
+        ("n_chains", C.c_uint64),
+        ("n_chains_kept", C.c_uint64),
+        ("n_out", C.c_uint64),
+        ("device_ms", C.c_double),
+        ("h2d_ms", C.c_double),
+        ("d2h_ms", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Loads libsweepga_gpu.so.  Raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built (run `python -m sweepga_amd.build` or "
+            "__graft_entry__.build()).  sweepga_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.swg_abi_version.restype = C.c_int
+    lib.swg_create.restype = C.c_int
+    lib.swg_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.swg_destroy.restype = None
+    lib.swg_destroy.argtypes = [C.c_void_p]
+    lib.swg_last_error.restype = C.c_char_p
+    lib.swg_last_error.argtypes = [C.c_void_p]
+    lib.swg_stream.restype = C.c_void_p
+    lib.swg_stream.argtypes = [C.c_void_p]
+    lib.swg_synchronize.restype = C.c_int
+    lib.swg_synchronize.argtypes = [C.c_void_p]
+    for name in ("swg_filter", "swg_filter_device"):
+        f = getattr(lib, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p, C.c_void_p,
+                      C.POINTER(SwgStats)]
+    lib.swg_plane_sweep.restype = C.c_int
+    lib.swg_plane_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int,
+                                    C.c_void_p]
+    lib.swg_plane_sweep_scaffolds.restype = C.c_int
+    lib.swg_plane_sweep_scaffolds.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64,
+                                              C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.swg_merge_chains.restype = C.c_int
+    lib.swg_merge_chains.argtypes = [C.c_void_p, C.POINTER(SwgRecords), C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.swg_union_find_sets.restype = C.c_int
+    lib.swg_union_find_sets.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_uint64)]
+    lib.swg_log.restype = C.c_int
+    lib.swg_log.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.swg_log_range.restype = C.c_int
+    lib.swg_log_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One swg_ctx (one GPU).  Not thread-safe, like the C object it wraps."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.swg_create(int(device), C.byref(h))
+        if rc != SWG_OK:
+            raise SwgError(rc, (self.lib.swg_last_error(None) or b"").decode())
+        self.handle = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != SWG_OK:
+            raise SwgError(rc, (self.lib.swg_last_error(self.handle) or b"").decode())
+
+    def synchronize(self):
+        self.check(self.lib.swg_synchronize(self.handle))
+
+    @property
+    def stream(self):
+        return self.lib.swg_stream(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.swg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,128 @@
+// Context, error text and the scratch arena of libsweepga_gpu.so.
+#include <cstdarg>
+#include <cstdio>
+
+#include "swg_internal.h"
+
+thread_local std::string swg_create_error;
+
+int swg_set_error(swg_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    swg_create_error = buf;
+  return code;
+}
+
+void* swg_arena_alloc(swg_ctx* ctx, size_t bytes) {
+  size_t aligned = (bytes + 255) & ~size_t(255);
+  size_t off = ctx->arena_off;
+  ctx->arena_off = off + aligned;
+  if (ctx->arena_off > ctx->arena_peak) ctx->arena_peak = ctx->arena_off;
+  if (ctx->arena_off > ctx->arena_cap) {
+    ctx->arena_overflow = true;
+    return nullptr;
+  }
+  return ctx->arena + off;
+}
+
+void swg_arena_reset(swg_ctx* ctx) {
+  ctx->arena_off = 0;
+  ctx->arena_peak = 0;
+  ctx->arena_overflow = false;
+}
+
+int swg_arena_reserve(swg_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->arena_cap) return SWG_OK;
+  SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->arena) {
+    SWG_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_cap = 0;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess)
+    return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu-byte scratch arena failed: %s", bytes,
+                         hipGetErrorString(e));
+  ctx->arena = static_cast<char*>(p);
+  ctx->arena_cap = bytes;
+  return SWG_OK;
+}
+
+int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count) {
+  if (count > 64) return swg_set_error(ctx, SWG_ERR_INVALID, "swg_read_scalars: count > 64");
+  SWG_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, d_src, sizeof(uint64_t) * count, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; ++i) h_dst[i] = ctx->h_scalars[i];
+  return SWG_OK;
+}
+
+extern "C" {
+
+int swg_abi_version(void) { return SWG_ABI_VERSION; }
+
+int swg_create(int device, swg_ctx** out) {
+  if (!out) return swg_set_error(nullptr, SWG_ERR_INVALID, "swg_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return swg_set_error(nullptr, SWG_ERR_NO_DEVICE,
+                         "no HIP device available (%s); libsweepga_gpu has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device < 0 || device >= count)
+    return swg_set_error(nullptr, SWG_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+  swg_ctx* ctx = new (std::nothrow) swg_ctx();
+  if (!ctx) return swg_set_error(nullptr, SWG_ERR_OOM, "host allocation failed");
+  ctx->device = device;
+  auto fail = [&](const char* what, hipError_t err) {
+    swg_set_error(nullptr, SWG_ERR_NO_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
+    swg_destroy(ctx);
+    return SWG_ERR_NO_DEVICE;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return fail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+  void* hp = nullptr;
+  if ((e = hipHostMalloc(&hp, 64 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+    return fail("hipHostMalloc", e);
+  ctx->h_scalars = static_cast<uint64_t*>(hp);
+  *out = ctx;
+  return SWG_OK;
+}
+
+void swg_destroy(swg_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* swg_last_error(const swg_ctx* ctx) { return ctx ? ctx->err.c_str() : swg_create_error.c_str(); }
+
+void* swg_stream(swg_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int swg_synchronize(swg_ctx* ctx) {
+  if (!ctx) return SWG_ERR_INVALID;
+  SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SWG_OK;
+}
+
+}  // extern "C"

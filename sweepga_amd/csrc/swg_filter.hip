@@ -1,0 +1,413 @@
+// The filter pipeline: PafFilter::apply_filters (src/paf_filter.rs:379-747) on the device, and
+// the host-array entry points of the C ABI.
+#include <vector>
+
+#include "swg_internal.h"
+#include "swg_log.h"
+#include "swg_pipeline.h"
+
+namespace {
+
+constexpr int EW = 256;
+inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
+
+// step 1 retain, src/paf_filter.rs:384-388.  NaN identity fails `>=`.
+__global__ __launch_bounds__(EW) void retain_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
+                                                    const uint32_t* __restrict__ t_id,
+                                                    const uint32_t* __restrict__ block_len,
+                                                    const double* __restrict__ identity, uint64_t min_block,
+                                                    int keep_self, double min_identity,
+                                                    uint8_t* __restrict__ alive) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  const bool ok = (uint64_t)block_len[i] >= min_block && (keep_self || q_id[i] != t_id[i]) &&
+                  identity[i] >= min_identity;
+  alive[i] = ok ? 1 : 0;
+}
+
+// scalars[0] = max coordinate over all four columns, scalars[1] = number of alive records
+__global__ __launch_bounds__(EW) void stats_kernel(uint64_t n, const uint32_t* __restrict__ a,
+                                                   const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+                                                   const uint32_t* __restrict__ d, const uint8_t* __restrict__ alive,
+                                                   unsigned long long* __restrict__ scalars) {
+  uint32_t mx = 0, cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW) {
+    uint32_t m1 = a[i] > b[i] ? a[i] : b[i];
+    uint32_t m2 = c[i] > d[i] ? c[i] : d[i];
+    uint32_t m = m1 > m2 ? m1 : m2;
+    if (m > mx) mx = m;
+    if (!alive || alive[i]) ++cnt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = __shfl_down(mx, o, 64);
+    if (t > mx) mx = t;
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&scalars[0], (unsigned long long)mx);
+    atomicAdd(&scalars[1], (unsigned long long)cnt);
+  }
+}
+
+// segment ids of the mapping-level sweep (src/paf_filter.rs:1037-1100):
+//   query axis : (query sequence, genome of the target)   target axis : (target sequence, genome of the query)
+__global__ __launch_bounds__(EW) void mapping_segments_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
+                                                              const uint32_t* __restrict__ t_id,
+                                                              const uint32_t* __restrict__ seq_genome,
+                                                              uint32_t n_genome, uint64_t* __restrict__ seg_q,
+                                                              uint64_t* __restrict__ seg_t) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t q = q_id[i], t = t_id[i];
+  seg_q[i] = (uint64_t)q * n_genome + seq_genome[t];
+  seg_t[i] = (uint64_t)t * n_genome + seq_genome[q];
+}
+
+__global__ __launch_bounds__(EW) void and_kernel(uint64_t n, const uint8_t* __restrict__ a,
+                                                 const uint8_t* __restrict__ b, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) out[i] = (a[i] && b[i]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(EW) void unassigned_status_kernel(uint64_t n, const uint8_t* __restrict__ keep,
+                                                               uint8_t* __restrict__ status,
+                                                               uint32_t* __restrict__ chain,
+                                                               unsigned long long* __restrict__ n_out) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint32_t k = 0;
+  if (i < n) {
+    k = keep[i] ? 1 : 0;
+    status[i] = k ? SWG_ST_UNASSIGNED : SWG_ST_DROPPED;
+    chain[i] = 0;
+  }
+  const uint64_t b = __ballot(k);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_out, (unsigned long long)__popcll(b));
+}
+
+__global__ __launch_bounds__(EW) void log_kernel(uint64_t n, const double* __restrict__ x, double* __restrict__ y) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) y[i] = swg_log_glibc(x[i]);
+}
+__global__ __launch_bounds__(EW) void log_range_kernel(uint64_t first, uint64_t stride, uint64_t n,
+                                                       double* __restrict__ y) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) y[i] = swg_log_glibc((double)(first + i * stride));
+}
+
+void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, uint64_t* kt) {
+  // src/paf_filter.rs:1004-1014
+  switch (mode) {
+    case SWG_MODE_ONE_TO_ONE:
+      *kq = 1;
+      *kt = 1;
+      break;
+    case SWG_MODE_ONE_TO_MANY:
+      *kq = max_q ? max_q : 1;
+      *kt = max_t ? max_t : SWG_K_INF;
+      break;
+    default:
+      *kq = max_q ? max_q : SWG_K_INF;
+      *kt = max_t ? max_t : SWG_K_INF;
+  }
+}
+
+}  // namespace
+
+// ---- mapping-level sweep ----------------------------------------------------------------------
+int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
+                      const uint64_t* score_key, int pos_bits, uint8_t* keep) {
+  const uint64_t n = r->n;
+  hipStream_t st = ctx->stream;
+  uint64_t kq, kt;
+  limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint64_t* seg_q = swg_alloc<uint64_t>(ctx, n);
+  uint64_t* seg_t = swg_alloc<uint64_t>(ctx, n);
+  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, n);
+  uint8_t* keep_t = swg_alloc<uint8_t>(ctx, n);
+  SWG_CHECK_ARENA(ctx);
+  mapping_segments_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->seq_genome_last, r->n_genome_last,
+                                                  seg_q, seg_t);
+  SWG_KERNEL_CHECK(ctx);
+  const int seg_bits = swg_bits_for((uint64_t)r->n_seq * r->n_genome_last);  // ids + 1 <= n_seq * n_genome
+  swg_axis_input ax;
+  ax.n = n;
+  ax.seg_bits = seg_bits;
+  ax.pos_bits = pos_bits;
+  ax.score_key = score_key;
+  ax.alive = alive;
+  ax.seg = seg_q;
+  ax.start = r->q_start;
+  ax.end = r->q_end;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
+  ax.seg = seg_t;
+  ax.start = r->t_start;
+  ax.end = r->t_end;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep_t));
+  and_kernel<<<nblk(n), EW, 0, st>>>(n, keep_q, keep_t, keep);  // intersection, src/paf_filter.rs:1105-1111
+  SWG_KERNEL_CHECK(ctx);
+  swg_arena_restore(ctx, mark);
+  return SWG_OK;
+}
+
+// ---- apply_filters on device-resident records ---------------------------------------------------
+static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* status_out,
+                              uint32_t* chain_out, swg_stats* stats) {
+  const uint64_t n = r->n;
+  hipStream_t st = ctx->stream;
+  if (stats) {
+    stats->n_in = n;
+    stats->n_retained = stats->n_swept = stats->n_chains = stats->n_chains_kept = stats->n_out = 0;
+  }
+  if (n == 0) return SWG_OK;
+  uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
+  uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
+  uint64_t* score_key = swg_alloc<uint64_t>(ctx, n);
+  unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
+  retain_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->block_len, r->identity, cfg->min_block_length,
+                                        cfg->keep_self, cfg->min_identity, alive);
+  SWG_KERNEL_CHECK(ctx);
+  stats_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, r->q_start, r->q_end, r->t_start, r->t_end, alive, scalars);
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_score_keys(ctx, n, r->q_start, r->q_end, r->identity, cfg->scoring_function, score_key));
+  uint64_t h[2];
+  SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 2));
+  const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
+  if (stats) stats->n_retained = h[1];
+
+  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, score_key, pos_bits, keep1));
+
+  if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
+    unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out, scalars + 2);
+    SWG_KERNEL_CHECK(ctx);
+    if (stats) {
+      uint64_t c;
+      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars + 2), &c, 1));
+      stats->n_swept = stats->n_out = c;
+    }
+    return SWG_OK;
+  }
+  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, score_key, pos_bits, status_out, chain_out, stats);
+}
+
+static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (!r || !cfg) return swg_set_error(ctx, SWG_ERR_INVALID, "records/config is NULL");
+  if (r->n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "more than 2^31-1 records");
+  if (r->n && (!r->q_id || !r->t_id || !r->q_start || !r->q_end || !r->t_start || !r->t_end || !r->identity ||
+               !r->matches || !r->block_len || !r->strand || !r->seq_genome_last || !r->seq_genome_two))
+    return swg_set_error(ctx, SWG_ERR_INVALID, "a record column is NULL");
+  if (r->n && (r->n_seq == 0 || r->n_genome_last == 0 || r->n_genome_two == 0))
+    return swg_set_error(ctx, SWG_ERR_INVALID, "n_seq / n_genome_* must be > 0");
+  if (cfg->scoring_function < 0 || cfg->scoring_function > 4)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "bad scoring_function");
+  if (cfg->mapping_filter_mode < 0 || cfg->mapping_filter_mode > 2 || cfg->scaffold_filter_mode < 0 ||
+      cfg->scaffold_filter_mode > 2)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "bad filter mode");
+  return SWG_OK;
+}
+
+extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg,
+                                 uint8_t* status_out, uint32_t* chain_out, swg_stats* stats) {
+  SWG_TRY(validate(ctx, rec, cfg));
+  if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)rec->n * 160 + (size_t(8) << 20)));
+  SWG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = swg_run_with_arena(ctx, [&]() { return filter_device_body(ctx, rec, cfg, status_out, chain_out, stats); });
+  if (rc != SWG_OK) return rc;
+  SWG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (stats) {
+    SWG_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    SWG_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->device_ms = ms;
+    stats->h2d_ms = stats->d2h_ms = 0.0;
+  }
+  return SWG_OK;
+}
+
+// Host buffers in / out: stage through device copies, then the device entry point.
+extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint8_t* status_out,
+                          uint32_t* chain_out, swg_stats* stats) {
+  SWG_TRY(validate(ctx, rec, cfg));
+  const uint64_t n = rec->n;
+  if (n == 0) {
+    if (stats) *stats = swg_stats{};
+    return SWG_OK;
+  }
+  if (!status_out || !chain_out) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // one device block for the inputs + outputs of this call (outside the scratch arena)
+  const size_t col4 = ((n * 4 + 255) & ~size_t(255)), col8 = ((n * 8 + 255) & ~size_t(255)),
+               col1 = ((n + 255) & ~size_t(255)), seqt = (((size_t)rec->n_seq * 4 + 255) & ~size_t(255));
+  const size_t total = col4 * 8 + col8 + col1 * 2 + seqt * 2 + col4;
+  char* blk = nullptr;
+  {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, total);
+    if (e != hipSuccess)
+      return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu bytes for record staging failed: %s", total,
+                           hipGetErrorString(e));
+    blk = static_cast<char*>(p);
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = blk + off;
+    off += bytes;
+    return p;
+  };
+  swg_records d = *rec;
+  hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+  int rc = SWG_OK;
+  float h2d = 0.f, d2h = 0.f;
+  auto up = [&](const void* src, size_t bytes, size_t slot) -> void* {
+    char* dst = take(slot);
+    if (rc == SWG_OK && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+      rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy failed");
+    return dst;
+  };
+  (void)hipEventRecord(e0, st);
+  d.q_id = (const uint32_t*)up(rec->q_id, n * 4, col4);
+  d.t_id = (const uint32_t*)up(rec->t_id, n * 4, col4);
+  d.q_start = (const uint32_t*)up(rec->q_start, n * 4, col4);
+  d.q_end = (const uint32_t*)up(rec->q_end, n * 4, col4);
+  d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4);
+  d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4);
+  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4);
+  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4);
+  d.identity = (const double*)up(rec->identity, n * 8, col8);
+  d.strand = (const uint8_t*)up(rec->strand, n, col1);
+  d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt);
+  d.seq_genome_two = (const uint32_t*)up(rec->seq_genome_two, (size_t)rec->n_seq * 4, seqt);
+  uint8_t* d_status = (uint8_t*)take(col1);
+  uint32_t* d_chain = (uint32_t*)take(col4);
+  (void)hipEventRecord(e1, st);
+  if (rc == SWG_OK && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&h2d, e0, e1);
+  swg_stats local{};
+  if (rc == SWG_OK) rc = swg_filter_device(ctx, &d, cfg, d_status, d_chain, &local);
+  if (rc == SWG_OK) {
+    (void)hipEventRecord(e0, st);
+    if (hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(chain_out, d_chain, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+      rc = swg_set_error(ctx, SWG_ERR_HIP, "D2H copy failed");
+    (void)hipEventRecord(e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == SWG_OK)
+      rc = swg_set_error(ctx, SWG_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == SWG_OK) (void)hipEventElapsedTime(&d2h, e0, e1);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  (void)hipFree(blk);
+  if (stats && rc == SWG_OK) {
+    *stats = local;
+    stats->h2d_ms = h2d;
+    stats->d2h_ms = d2h;
+  }
+  return rc;
+}
+
+// ---- plane_sweep_query / target / both on one segment of host arrays --------------------------------
+extern "C" int swg_plane_sweep(swg_ctx* ctx, int axis, uint64_t n, const uint64_t* q_start, const uint64_t* q_end,
+                               const uint64_t* t_start, const uint64_t* t_end, const double* identity,
+                               uint64_t k_query, uint64_t k_target, double thr, int scoring, uint8_t* keep_out) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (axis < 0 || axis > 2) return swg_set_error(ctx, SWG_ERR_INVALID, "axis must be 0, 1 or 2");
+  if (scoring < 0 || scoring > 4) return swg_set_error(ctx, SWG_ERR_INVALID, "bad scoring");
+  if (k_query == 0 || k_target == 0) return swg_set_error(ctx, SWG_ERR_INVALID, "k must be >= 1");
+  if (n == 0) return SWG_OK;
+  if (!q_start || !q_end || !t_start || !t_end || !identity || !keep_out)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many mappings");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> h(4 * n);
+  uint32_t mx = 0;
+  const uint64_t* src[4] = {q_start, q_end, t_start, t_end};
+  for (int c = 0; c < 4; ++c)
+    for (uint64_t i = 0; i < n; ++i) {
+      if (src[c][i] > 0xffffffffull)
+        return swg_set_error(ctx, SWG_ERR_RANGE, "coordinate %llu >= 2^32 is not supported by the device path",
+                             (unsigned long long)src[c][i]);
+      h[c * n + i] = (uint32_t)src[c][i];
+      if (h[c * n + i] > mx) mx = h[c * n + i];
+    }
+  const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
+  hipStream_t st = ctx->stream;
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 200 + (size_t(8) << 20)));
+  return swg_run_with_arena(ctx, [&]() -> int {
+    uint32_t* d_c = swg_alloc<uint32_t>(ctx, 4 * n);
+    double* d_id = swg_alloc<double>(ctx, n);
+    uint64_t* d_key = swg_alloc<uint64_t>(ctx, n);
+    uint64_t* d_seg = swg_alloc<uint64_t>(ctx, n);
+    uint8_t* d_kq = swg_alloc<uint8_t>(ctx, n);
+    uint8_t* d_kt = swg_alloc<uint8_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemcpyAsync(d_c, h.data(), 4 * n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(d_id, identity, n * sizeof(double), hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemsetAsync(d_seg, 0, n * sizeof(uint64_t), st));
+    SWG_TRY(swg_score_keys(ctx, n, d_c, d_c + n, d_id, scoring, d_key));
+    swg_axis_input ax;
+    ax.n = n;
+    ax.seg = d_seg;
+    ax.seg_bits = 1;
+    ax.pos_bits = pos_bits;
+    ax.score_key = d_key;
+    ax.alive = nullptr;
+    uint8_t* result = d_kq;
+    if (axis == 0 || axis == 2) {
+      ax.start = d_c;
+      ax.end = d_c + n;
+      SWG_TRY(swg_sweep_axis(ctx, ax, k_query, thr, d_kq));
+    }
+    if (axis == 1 || axis == 2) {
+      ax.start = d_c + 2 * n;
+      ax.end = d_c + 3 * n;
+      ax.alive = axis == 2 ? d_kq : nullptr;  // plane_sweep_both: target sweep over the query survivors
+      SWG_TRY(swg_sweep_axis(ctx, ax, k_target, thr, d_kt));
+      result = d_kt;
+    }
+    SWG_HIP(ctx, hipMemcpyAsync(keep_out, result, n, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipStreamSynchronize(st));
+    return SWG_OK;
+  });
+}
+
+extern "C" int swg_log(swg_ctx* ctx, uint64_t n, const double* x, double* y) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (n == 0) return SWG_OK;
+  if (!x || !y) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 16 + (size_t(8) << 20)));
+  return swg_run_with_arena(ctx, [&]() -> int {
+    double* dx = swg_alloc<double>(ctx, n);
+    double* dy = swg_alloc<double>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    log_kernel<<<nblk(n), EW, 0, ctx->stream>>>(n, dx, dy);
+    SWG_KERNEL_CHECK(ctx);
+    SWG_HIP(ctx, hipMemcpyAsync(y, dy, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWG_OK;
+  });
+}
+
+extern "C" int swg_log_range(swg_ctx* ctx, uint64_t first, uint64_t stride, uint64_t n, double* y) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (n == 0) return SWG_OK;
+  if (!y) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 8 + (size_t(8) << 20)));
+  return swg_run_with_arena(ctx, [&]() -> int {
+    double* dy = swg_alloc<double>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    log_range_kernel<<<nblk(n), EW, 0, ctx->stream>>>(first, stride, n, dy);
+    SWG_KERNEL_CHECK(ctx);
+    SWG_HIP(ctx, hipMemcpyAsync(y, dy, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SWG_OK;
+  });
+}

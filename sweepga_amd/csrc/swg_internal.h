@@ -1,0 +1,130 @@
+// Internal declarations shared by the HIP translation units of libsweepga_gpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/sweepga_gpu.h"
+
+// ---- error plumbing ---------------------------------------------------------------------
+struct swg_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // bump arena for per-call scratch; grown (never shrunk) between calls
+  char* arena = nullptr;
+  size_t arena_cap = 0;
+  size_t arena_off = 0;
+  size_t arena_peak = 0;   // high-water mark of the current call (may exceed cap -> retry)
+  bool arena_overflow = false;
+  // pinned host scratch for small read-backs
+  uint64_t* h_scalars = nullptr;  // 64 x u64
+  std::string err;
+  int num_cu = 256;
+};
+
+extern thread_local std::string swg_create_error;
+
+int swg_set_error(swg_ctx* ctx, int code, const char* fmt, ...);
+
+#define SWG_HIP(ctx, call)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return swg_set_error((ctx), e_ == hipErrorOutOfMemory ? SWG_ERR_OOM : SWG_ERR_HIP,        \
+                           "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                           __LINE__);                                                           \
+  } while (0)
+
+#define SWG_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != SWG_OK) return rc_; \
+  } while (0)
+
+#define SWG_KERNEL_CHECK(ctx) SWG_HIP((ctx), hipGetLastError())
+
+// ---- arena --------------------------------------------------------------------------------
+// Allocation never fails inside a pipeline: when the arena is too small the pointer returned is
+// NULL-safe garbage-free (nullptr) and arena_overflow is set; pipelines are written as
+// "plan, then run": run_with_arena() executes the pipeline body, and if it overflowed, grows the
+// arena to the recorded peak and runs it again.
+void* swg_arena_alloc(swg_ctx* ctx, size_t bytes);
+template <class T>
+static inline T* swg_alloc(swg_ctx* ctx, size_t n) {
+  return reinterpret_cast<T*>(swg_arena_alloc(ctx, n * sizeof(T)));
+}
+void swg_arena_reset(swg_ctx* ctx);
+int swg_arena_reserve(swg_ctx* ctx, size_t bytes);
+struct swg_arena_mark {
+  size_t off;
+};
+static inline swg_arena_mark swg_arena_save(swg_ctx* ctx) { return {ctx->arena_off}; }
+static inline void swg_arena_restore(swg_ctx* ctx, swg_arena_mark m) { ctx->arena_off = m.off; }
+
+// Runs body(ctx) with a fresh arena; on overflow grows the arena and runs it once more.
+template <class F>
+static inline int swg_run_with_arena(swg_ctx* ctx, F&& body) {
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    swg_arena_reset(ctx);
+    int rc = body();
+    if (!ctx->arena_overflow) return rc;
+    // overflow: the body saw a nullptr and bailed out with SWG_ERR_OOM before using it
+    size_t need = ctx->arena_peak + (ctx->arena_peak >> 1) + (size_t(1) << 20);
+    if (need < 2 * ctx->arena_cap) need = 2 * ctx->arena_cap;
+    int rc2 = swg_arena_reserve(ctx, need);
+    if (rc2 != SWG_OK) return rc2;
+  }
+  return swg_set_error(ctx, SWG_ERR_OOM, "scratch arena still too small after growing 8 times");
+}
+#define SWG_CHECK_ARENA(ctx)                                          \
+  do {                                                                \
+    if ((ctx)->arena_overflow) return SWG_ERR_OOM;                    \
+  } while (0)
+
+// ---- primitives (swg_sort.hip) ---------------------------------------------------------------
+// Exclusive prefix sum of n u32 values, in place allowed (out may equal in).  If total_out is
+// non-null it receives the grand total (device pointer, u32... as u64).
+int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n,
+                           uint64_t* d_total_out);
+// Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
+// Result is left in keys_a/vals_a; keys_b/vals_b are scratch of the same size.
+int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                         uint32_t* vals_b, uint64_t n, int begin_bit, int end_bit);
+// Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
+int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
+
+static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represent max_value
+  int b = 0;
+  while (max_value) {
+    ++b;
+    max_value >>= 1;
+  }
+  return b;
+}
+
+// ---- sweep (swg_sweep.hip) ---------------------------------------------------------------------
+// One axis of the plane sweep over n intervals that all live in one index space [0, n):
+//   seg[i]    dense-ish segment id (u64 composite already reduced to < 2^seg_bits)
+//   start/end axis coordinates; score_key[i] = sortable score (smaller = better); tie-break = i
+//   alive[i]  (optional) 0 = interval does not take part
+//   k         mappings_to_keep (SWG_K_INF = unbounded), thr = overlap threshold
+// Output keep[i] = 1 iff interval i is returned by plane_sweep_query/target on its segment
+// (src/plane_sweep_exact.rs:268-433); keep[i] = 0 for !alive.
+struct swg_axis_input {
+  uint64_t n;
+  const uint64_t* seg;       // [n] segment id
+  int seg_bits;              // ids < 2^seg_bits
+  const uint32_t* start;     // [n]
+  const uint32_t* end;       // [n]
+  int pos_bits;              // coordinates < 2^pos_bits
+  const uint64_t* score_key; // [n]
+  const uint8_t* alive;      // [n] or nullptr
+};
+int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
+
+// score keys: key[i] = order-preserving transform of -score so that smaller key = better
+// (src/plane_sweep_exact.rs:29-86, 183-193); length is always q_end - q_start.
+int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint32_t* q_end,
+                   const double* identity, int scoring, uint64_t* key_out);

@@ -1,0 +1,240 @@
+// Scan and radix-sort primitives for gfx950 (wave64).
+//
+//  * swg_exclusive_scan_u32 : reduce / recurse / down-sweep scan, 4096 elements per workgroup.
+//  * swg_radix_sort_pairs   : stable LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.
+//      per pass: (1) per-tile digit histogram, (2) exclusive scan of the digit-major histogram,
+//      (3) stable scatter: each tile re-reads its keys in 256-element rows, ranks every row with
+//      a wavefront match (8 x 64-bit ballots) + cross-wave prefix in LDS, and writes the pair to
+//      its final slot.  Stability is what makes the multi-word sorts of the pipeline compose and
+//      is what carries the reference's "ties fall to input order" rule (sort_by_key is stable,
+//      src/plane_sweep_exact.rs:300, src/paf_filter.rs:777).
+#include "swg_internal.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix and
+// the block total through *total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* lds_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = wave_inclusive_scan(v, lane);
+  if (lane == 63) lds_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    uint32_t s = lds_wave[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
+                                                                    uint32_t* __restrict__ block_sums,
+                                                                    uint64_t n) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint64_t i = base + j;
+    if (i < n) s += in[i];
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan(s, &tot, lds_wave);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// `in` and `out` may alias (in-place scan): every thread reads its 16 inputs before any write.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const uint32_t* in, uint32_t* out,
+                                                                  const uint32_t* __restrict__ block_offsets,
+                                                                  uint64_t n, uint64_t* __restrict__ total_out,
+                                                                  int write_total) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint64_t i = base + j;
+    v[j] = i < n ? in[i] : 0u;
+    s += v[j];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot, lds_wave);
+  uint32_t run = ex + (block_offsets ? block_offsets[blockIdx.x] : 0u);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    uint64_t i = base + j;
+    if (i < n) out[i] = run;
+    run += v[j];
+  }
+  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total_out = run;
+}
+
+}  // namespace
+
+int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n,
+                           uint64_t* d_total_out) {
+  if (n == 0) {
+    if (d_total_out) SWG_HIP(ctx, hipMemsetAsync(d_total_out, 0, sizeof(uint64_t), ctx->stream));
+    return SWG_OK;
+  }
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 1) {
+    scan_down_kernel<<<1, SCAN_THREADS, 0, ctx->stream>>>(in, out, nullptr, n, d_total_out,
+                                                          d_total_out ? 1 : 0);
+    SWG_KERNEL_CHECK(ctx);
+    return SWG_OK;
+  }
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* sums = swg_alloc<uint32_t>(ctx, nb);
+  SWG_CHECK_ARENA(ctx);
+  scan_reduce_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n);
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, sums, sums, nb, nullptr));
+  scan_down_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, out, sums, n, d_total_out,
+                                                                   d_total_out ? 1 : 0);
+  SWG_KERNEL_CHECK(ctx);
+  swg_arena_restore(ctx, mark);  // stream order keeps `sums` alive until the kernels above ran
+  return SWG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ROWS = 16;  // rows of 256 elements per tile
+constexpr int RS_TILE = RS_THREADS * RS_ROWS;
+constexpr int RS_RADIX = 256;
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                              int shift, uint32_t mask,
+                                                              uint32_t* __restrict__ hist, uint32_t ntiles) {
+  __shared__ uint32_t h[RS_RADIX];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int r = 0; r < RS_ROWS; ++r) {
+    uint64_t i = base + (uint64_t)r * RS_THREADS + threadIdx.x;
+    if (i < n) {
+      uint32_t d = (uint32_t)(keys[i] >> shift) & mask;
+      atomicAdd(&h[d], 1u);
+    }
+  }
+  __syncthreads();
+  hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, uint32_t mask,
+    const uint32_t* __restrict__ offsets, uint32_t ntiles) {
+  __shared__ uint32_t running[RS_RADIX];
+  __shared__ uint32_t wcnt[RS_THREADS / 64][RS_RADIX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = offsets[(uint64_t)threadIdx.x * ntiles + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < RS_THREADS / 64; ++w) wcnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const uint64_t i = base + (uint64_t)r * RS_THREADS + threadIdx.x;
+    const bool valid = i < n;
+    uint64_t key = 0;
+    uint32_t val = 0;
+    if (valid) {
+      key = keys_in[i];
+      val = vals_in[i];
+    }
+    const uint32_t d = (uint32_t)(key >> shift) & mask;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t rank_in_wave = __popcll(peers & lt_mask);
+    if (valid && rank_in_wave == 0) wcnt[wave][d] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = running[d] + rank_in_wave;
+#pragma unroll
+      for (int w = 0; w < RS_THREADS / 64; ++w)
+        if (w < wave) off += wcnt[w][d];
+      keys_out[off] = key;
+      vals_out[off] = val;
+    }
+    __syncthreads();
+    {
+      uint32_t add = 0;
+#pragma unroll
+      for (int w = 0; w < RS_THREADS / 64; ++w) {
+        add += wcnt[w][threadIdx.x];
+        wcnt[w][threadIdx.x] = 0;
+      }
+      running[threadIdx.x] += add;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                         uint32_t* vals_b, uint64_t n, int begin_bit, int end_bit) {
+  if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
+  if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
+  const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* hist = swg_alloc<uint32_t>(ctx, (size_t)RS_RADIX * ntiles);
+  SWG_CHECK_ARENA(ctx);
+  uint64_t* kin = keys_a;
+  uint32_t* vin = vals_a;
+  uint64_t* kout = keys_b;
+  uint32_t* vout = vals_b;
+  int passes = 0;
+  for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    const uint32_t mask = (1u << bits) - 1u;
+    rs_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, n, shift, mask, hist, ntiles);
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, hist, hist, (uint64_t)RS_RADIX * ntiles, nullptr));
+    rs_scatter_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift, mask, hist,
+                                                              ntiles);
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t* tk = kin;
+    kin = kout;
+    kout = tk;
+    uint32_t* tv = vin;
+    vin = vout;
+    vout = tv;
+    ++passes;
+  }
+  if (passes & 1) {  // result currently in the *_b buffers: move it home
+    SWG_HIP(ctx, hipMemcpyAsync(keys_a, keys_b, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    SWG_HIP(ctx, hipMemcpyAsync(vals_a, vals_b, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  swg_arena_restore(ctx, mark);
+  return SWG_OK;
+}

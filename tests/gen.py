@@ -1,0 +1,75 @@
+"""Seeded synthetic inputs for parity tests (numpy; small enough for the CPU oracle)."""
+import numpy as np
+
+from tests import orc
+
+
+def random_segment(rng, n, span=10_000, max_len=2_000, zero_frac=0.03, dup_frac=0.1, ident_levels=None):
+    """One sweep segment: (qs, qe, ts, te, identity) with ties, duplicates, zero-length and
+    zero-identity records mixed in."""
+    qs = rng.integers(0, span, n)
+    ql = rng.integers(1, max_len, n)
+    ts = rng.integers(0, span, n)
+    tl = rng.integers(1, max_len, n)
+    if ident_levels:
+        ident = rng.choice(np.asarray(ident_levels, dtype=np.float64), n)
+    else:
+        ident = np.round(rng.uniform(0.7, 1.0, n), 3)
+    z = rng.random(n) < zero_frac
+    ql[z] = 0
+    z2 = rng.random(n) < zero_frac
+    tl[z2] = 0
+    z3 = rng.random(n) < zero_frac / 2
+    ident[z3] = 0.0
+    # exact duplicates of earlier records (score + start ties -> index tie-break)
+    for i in range(1, n):
+        if rng.random() < dup_frac:
+            j = rng.integers(0, i)
+            qs[i], ql[i], ident[i] = qs[j], ql[j], ident[j]
+            if rng.random() < 0.5:
+                ts[i], tl[i] = ts[j], tl[j]
+    return (qs.astype(np.uint64), (qs + ql).astype(np.uint64), ts.astype(np.uint64), (ts + tl).astype(np.uint64),
+            ident.astype(np.float64))
+
+
+def random_records(rng, n, n_genomes=4, chrs_per_genome=3, span=200_000, max_len=8_000, pansn=True,
+                   self_frac=0.02, minus_frac=0.2, syntenic_frac=0.7, zero_frac=0.01):
+    """PAF-like records over several genomes/chromosomes -> orc.Records (names + columns)."""
+    def name(g, c):
+        return f"g{g}#1#chr{c}" if pansn else f"g{g}chr{c}"
+
+    gq = rng.integers(0, n_genomes, n)
+    gt = rng.integers(0, n_genomes, n)
+    cq = rng.integers(0, chrs_per_genome, n)
+    ct = np.where(rng.random(n) < 0.8, cq, rng.integers(0, chrs_per_genome, n))
+    same = rng.random(n) < self_frac
+    gt = np.where(same, gq, gt)
+    ct = np.where(same, cq, ct)
+    qs = rng.integers(0, span, n)
+    ln = np.minimum(np.exp(rng.normal(np.log(max_len / 8), 1.0, n)).astype(np.int64) + 50, max_len)
+    ln[rng.random(n) < zero_frac] = 0
+    syn = rng.random(n) < syntenic_frac
+    ts = np.where(syn, np.clip(qs + rng.normal(0, 2000, n).astype(np.int64), 0, span), rng.integers(0, span, n))
+    tl = np.maximum(ln + rng.integers(-20, 20, n), 0)
+    tl[ln == 0] = 0
+    ident = np.round(0.7 + 0.3 * rng.beta(5, 1.5, n), 4)
+    block = np.maximum(ln, tl).astype(np.uint64)
+    matches = np.floor(ident * block).astype(np.uint64)
+    ident = matches / np.maximum(block, 1)
+    strand = np.where(rng.random(n) < minus_frac, ord("-"), ord("+")).astype(np.uint8)
+    qn = [name(int(a), int(b)) for a, b in zip(gq, cq)]
+    tn = [name(int(a), int(b)) for a, b in zip(gt, ct)]
+    u = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+    return orc.Records(qn, tn, u(qs), u(qs + ln), u(ts), u(ts + tl), u(block), np.ascontiguousarray(ident, dtype=np.float64),
+                       u(matches), strand, u(np.arange(n)))
+
+
+def records_to_meta(rec):
+    """orc.Records -> list of sweepga_amd.RecordMeta (host mirror input)."""
+    from sweepga_amd import RecordMeta
+    out = []
+    for i in range(len(rec)):
+        out.append(RecordMeta(int(rec.rank[i]), rec.qname[i], rec.tname[i], int(rec.qs[i]), int(rec.qe[i]),
+                              int(rec.ts[i]), int(rec.te[i]), int(rec.block_length[i]), float(rec.identity[i]),
+                              int(rec.matches[i]), int(rec.block_length[i]), chr(int(rec.strand[i]))))
+    return out

@@ -1,0 +1,174 @@
+"""GPU parity: the HIP plane sweep (through the C ABI) against the CPU oracle, bit-exact.
+
+Runs on the MI355X box only (-m gpu).  Mismatches are dumped under gpurun_out/ for offline study.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import gen, orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _dump(name, payload):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(payload, f)
+
+
+@pytest.fixture(scope="module")
+def sw():
+    import sweepga_amd
+    sweepga_amd.default_context(0)  # fails loudly without the HIP library or a GPU
+    return sweepga_amd
+
+
+def test_device_log_equals_host_libm(sw):
+    """Device ln == glibc log bit for bit: all lengths < 2^22, then strided samples up to 2^40."""
+    import ctypes as C
+    ctx = sw.default_context(0)
+    for first, stride, n in ((1, 1, 1 << 22), (1 << 22, 977, 1 << 22), (1 << 32, 1_000_003, 1 << 20)):
+        dev = np.zeros(n, dtype=np.float64)
+        ctx.check(ctx.lib.swg_log_range(ctx.handle, first, stride, n, dev.ctypes.data_as(C.c_void_p)))
+        x = (first + stride * np.arange(n, dtype=np.uint64)).astype(np.float64)
+        host = np.zeros(n, dtype=np.float64)
+        orc.lib().orc_log_array(C.c_uint64(n), x.ctypes.data_as(C.c_void_p), host.ctypes.data_as(C.c_void_p))
+        bad = np.nonzero(dev.view(np.uint64) != host.view(np.uint64))[0]
+        assert bad.size == 0, f"{bad.size} log mismatches, first at x={x[bad[0]]}"
+
+
+KAT = [
+    # (maps, k, thr, scoring)  -- vectors of the reference's unit tests (see tests/test_oracle_kat.py)
+    ([(100, 200, 300, 400, 0.95)], 1, 0.95, 3),
+    ([(100, 200, 300, 400, 0.95), (300, 400, 500, 600, 0.90)], 1, 0.95, 3),
+    ([(100, 200, 300, 400, 0.95), (150, 250, 350, 450, 0.90)], 1, 0.95, 3),
+    ([(100, 200, 300, 400, 0.95), (100, 200, 500, 600, 0.90), (100, 200, 700, 800, 0.85)], 2, 0.95, 3),
+    ([(100, 200, 300, 400, 0.95), (100, 200, 500, 600, 0.90), (100, 200, 700, 800, 0.85)], 1, 1.0, 3),
+    ([(100, 200, 300, 400, 0.95), (100, 200, 500, 600, 0.90), (100, 200, 700, 800, 0.85)], 2, 0.5, 3),
+    ([(100, 200, 300, 400, 1.0), (100, 200, 500, 600, 1.0), (100, 200, 700, 800, 1.0)], 1, 0.95, 3),
+    ([(100, 200, 300, 400, 1.0), (100, 200, 500, 600, 1.0), (100, 200, 700, 800, 1.0)], orc.K_INF, 0.95, 3),
+    ([(100, 300, 400, 600, 1.0), (150, 180, 500, 530, 1.0)], 1, 0.95, 3),
+    ([(100, 300, 400, 600, 1.0), (100, 300, 700, 900, 1.0), (100, 300, 1000, 1200, 1.0), (100, 300, 1300, 1500, 1.0)], 2, 0.5, 3),
+    ([(0, 100, 0, 100, 1.0), (50, 150, 200, 300, 1.0), (120, 220, 400, 500, 1.0), (200, 300, 600, 700, 1.0), (280, 380, 800, 900, 1.0)], 1, 0.95, 3),
+    ([(100, 200, 300, 400, 1.0), (100, 190, 500, 590, 1.0), (100, 180, 700, 780, 1.0), (100, 170, 900, 970, 1.0), (100, 160, 1100, 1160, 1.0)], 3, 1.0, 3),
+    ([(100, 100, 300, 300, 1.0), (100, 200, 400, 500, 1.0), (100, 300, 600, 800, 1.0)], 1, 0.95, 3),
+    ([(1000, 2000, 5000, 6000, 1.0), (1500, 2500, 7000, 8000, 1.0), (3000, 4000, 9000, 10000, 1.0), (3200, 3800, 11000, 11600, 1.0),
+      (5000, 5500, 15000, 15500, 1.0), (5000, 5500, 16000, 16500, 1.0), (5000, 5500, 17000, 17500, 1.0), (5000, 5500, 18000, 18500, 1.0),
+      (8000, 12000, 20000, 24000, 1.0)], 2, 0.95, 3),
+    ([(100, 500, 1000, 1400, 0.70), (100, 200, 2000, 2100, 0.99), (100, 300, 3000, 3200, 0.85)], 1, 0.95, 0),
+    ([(100, 200, 1000, 1100, 0.99), (100, 600, 2000, 2500, 0.50), (100, 350, 3000, 3250, 0.75)], 1, 0.95, 1),
+    ([(100, 200, 1000, 1100, 0.95), (100, 400, 2000, 2300, 0.60), (100, 300, 3000, 3200, 0.80)], 1, 0.95, 2),
+    ([(100, 300, 1000, 1200, 0.90), (100, 280, 2000, 2180, 1.00), (100, 460, 3000, 3360, 0.50)], 1, 0.95, 2),
+    ([(100, 200, 1000, 1100, 0.70), (100, 250, 2000, 2150, 0.80), (100, 300, 3000, 3200, 0.90), (100, 180, 4000, 4080, 0.99), (100, 220, 5000, 5120, 0.60)], 2, 0.95, 2),
+    ([(100, 101, 1000, 1001, 1.00), (100, 100100, 2000, 102000, 0.01), (100, 1100, 3000, 4000, 0.50)], 1, 0.95, 4),
+]
+
+
+def _maps(sw, rows):
+    return [sw.PlaneSweepMapping(i, *r) for i, r in enumerate(rows)]
+
+
+@pytest.mark.parametrize("case", range(len(KAT)))
+def test_reference_vectors(sw, case):
+    rows, k, thr, scoring = KAT[case]
+    m = _maps(sw, rows)
+    for axis, fn_g, fn_o in ((0, sw.plane_sweep_query, orc.plane_sweep_query), (1, sw.plane_sweep_target, orc.plane_sweep_target)):
+        got = fn_g(m, k, thr, sw.ScoringFunction(scoring))
+        want = fn_o(rows, k, thr, scoring)
+        assert got == want, (axis, got, want)
+    assert sw.plane_sweep_both(m, k, k, thr, sw.ScoringFunction(scoring)) == orc.plane_sweep_both(rows, k, k, thr, scoring)
+
+
+def test_empty_and_range_errors(sw):
+    assert sw.plane_sweep_query([], 1, 0.95) == []
+    U = 2**64 - 1
+    with pytest.raises(sw.SwgError) as e:  # plane_sweep_exact.rs:804-826 uses u64::MAX: outside the u32 device layout
+        sw.plane_sweep_query(_maps(sw, [(0, 100, 0, 100, 0.95), (U - 100, U, 1000, 1100, 0.9)]), 1, 0.95)
+    assert e.value.code == -5
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_segments_bit_exact(sw, seed):
+    """Differential fuzz on single segments: k in {1,2,3,7,inf}, thr in {0,.5,.95,1}, all scorings."""
+    import ctypes as C
+    rng = np.random.default_rng(1000 + seed)
+    ctx = sw.default_context(0)
+    n = int(rng.choice([2, 3, 17, 64, 257, 600, 1500, 4000]))
+    span = int(rng.choice([500, 5_000, 100_000]))
+    levels = [0.9, 0.95] if seed % 3 == 0 else None  # force score ties
+    qs, qe, ts, te, ident = gen.random_segment(rng, n, span=span, max_len=max(2, span // 4), ident_levels=levels)
+    fails = []
+    for k in (1, 2, 3, 7, orc.K_INF):
+        for thr in (0.0, 0.5, 0.95, 1.0):
+            for scoring in range(5):
+                if (k, thr, scoring) != (1, 0.95, 3) and rng.random() < 0.6:
+                    continue
+                for axis in (0, 1, 2):
+                    want = np.zeros(n, dtype=np.uint8)
+                    want[orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k, k_t=k, thr=thr, scoring=scoring)] = 1
+                    got = np.zeros(n, dtype=np.uint8)
+                    ctx.check(ctx.lib.swg_plane_sweep(ctx.handle, axis, n, *(a.ctypes.data_as(C.c_void_p) for a in (qs, qe, ts, te, ident)),
+                                                      k, k, thr, scoring, got.ctypes.data_as(C.c_void_p)))
+                    if not np.array_equal(got, want):
+                        bad = np.nonzero(got != want)[0]
+                        fails.append(dict(k=int(min(k, 10**9)), thr=thr, scoring=scoring, axis=axis, n=n, nbad=int(bad.size),
+                                          first=[int(b) for b in bad[:10]], got=[int(got[b]) for b in bad[:10]]))
+    if fails:
+        _dump(f"sweep_fuzz_seed{seed}.json", dict(fails=fails, qs=qs.tolist(), qe=qe.tolist(), ts=ts.tolist(),
+                                                   te=te.tolist(), ident=ident.tolist()))
+    assert not fails, fails[:3]
+
+
+@pytest.mark.parametrize("seed,n", [(1, 20_000), (2, 60_000)])
+def test_large_single_segment(sw, seed, n):
+    """One deep segment (many carry-ins per tile) against the oracle, k = 1 and k = 2."""
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    ctx = sw.default_context(0)
+    qs, qe, ts, te, ident = gen.random_segment(rng, n, span=2_000_000, max_len=40_000, zero_frac=0.001, dup_frac=0.01)
+    for k, thr in ((1, 0.95), (2, 0.5)):
+        for axis in (0, 1):
+            want = np.zeros(n, dtype=np.uint8)
+            want[orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k, k_t=k, thr=thr)] = 1
+            got = np.zeros(n, dtype=np.uint8)
+            ctx.check(ctx.lib.swg_plane_sweep(ctx.handle, axis, n, *(a.ctypes.data_as(C.c_void_p) for a in (qs, qe, ts, te, ident)),
+                                              k, k, thr, 3, got.ctypes.data_as(C.c_void_p)))
+            bad = np.nonzero(got != want)[0]
+            if bad.size:
+                _dump(f"sweep_large_seed{seed}_k{k}_axis{axis}.json", dict(nbad=int(bad.size), first=bad[:50].tolist()))
+            assert bad.size == 0, (k, axis, bad.size)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mapping_filter_no_scaffold(sw, seed):
+    """apply_filters with scaffold_gap = 0 (plane sweep only) on multi-genome records."""
+    rng = np.random.default_rng(50 + seed)
+    n = int(rng.choice([1, 2, 50, 3000, 20_000]))
+    rec = gen.random_records(rng, n, n_genomes=int(rng.integers(1, 5)), chrs_per_genome=int(rng.integers(1, 4)),
+                             pansn=bool(seed % 2 == 0))
+    meta = gen.records_to_meta(rec)
+    modes = [(sw.FilterMode.OneToOne, None, None), (sw.FilterMode.OneToMany, 1, None), (sw.FilterMode.ManyToMany, 2, 3),
+             (sw.FilterMode.ManyToMany, None, None)]
+    for mode, mq, mt in modes:
+        for thr in (0.5, 0.95):
+            for keep_self in (False, True):
+                cfg = sw.FilterConfig(mapping_filter_mode=mode, mapping_max_per_query=mq, mapping_max_per_target=mt,
+                                      overlap_threshold=thr, scaffold_gap=0, min_block_length=100 if seed % 2 else 0,
+                                      min_identity=0.75 if seed % 3 == 0 else 0.0)
+                f = sw.PafFilter(cfg).with_keep_self(keep_self)
+                status, chain = f.filter_columns(sw.pack_records(meta))
+                ocfg = orc.Config(mapping_filter_mode=int(mode), mapping_max_per_query=mq or 0, mapping_max_per_target=mt or 0,
+                                  overlap_threshold=thr, scaffold_gap=0, min_block_length=cfg.min_block_length,
+                                  min_identity=cfg.min_identity, keep_self=keep_self)
+                ost, och = orc.apply_filters(ocfg, rec)
+                bad = np.nonzero(status != ost)[0]
+                if bad.size:
+                    _dump(f"mapfilter_seed{seed}.json", dict(mode=int(mode), mq=mq, mt=mt, thr=thr, keep_self=keep_self,
+                                                             nbad=int(bad.size), first=bad[:20].tolist()))
+                assert bad.size == 0, (int(mode), mq, mt, thr, keep_self, bad.size)
+                assert np.array_equal(chain, och)
