@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- PAF mappings/s through the MI355X plane-sweep (+scaffold) filter.
+
+One "step" = one pass of the whole filter (PafFilter::apply_filters, src/paf_filter.rs:379-747)
+over one synthetic PAF shard that is already resident in HBM as the SoA of include/sweepga_gpu.h.
+Workload (BASELINE.json configs[3], "S-pan"): 100 single-chromosome genomes, 9,900 ordered
+non-self genome pairs ("10 k groups"), 10^8 mappings per GPU, lognormal group sizes; flags
+`--num-mappings 1:1 --scaffold-jump 0` by default (the sort+sweep path), `--pipeline full` for
+1:1 + scaffold chaining + scaffold 1:1 filter + rescue.  Genome pairs are independent, so with
+N GPUs every rank filters its own shard (weak scaling, no collective on the data path).
+
+Prints ONE JSON line on rank 0 (see the field list at the bottom).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
+ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000):
+    """S-pan shard on the device: group-major order, as an aligner emits pairs."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    P = n_genomes * (n_genomes - 1)
+    w = torch.exp(0.5 * torch.randn(P, generator=g, device=device, dtype=torch.float64))
+    sizes = torch.floor(w / w.sum() * n).to(torch.int64)
+    sizes[0] += n - int(sizes.sum())
+    pair = torch.repeat_interleave(torch.arange(P, device=device, dtype=torch.int32), sizes)
+    q = torch.div(pair, n_genomes - 1, rounding_mode="floor")
+    t = pair - q * (n_genomes - 1)
+    t = t + (t >= q).to(torch.int32)
+    del pair
+    ln = torch.exp(7.6009 + 1.2 * torch.randn(n, generator=g, device=device)).clamp_(100, 500_000).to(torch.int32)
+    room = (chr_len - ln).to(torch.float32)
+    qs = (torch.rand(n, generator=g, device=device) * room).to(torch.int32)
+    syn = torch.rand(n, generator=g, device=device) < 0.7
+    ts_syn = (qs.to(torch.float32) + 50_000.0 * torch.randn(n, generator=g, device=device))
+    ts_syn = torch.minimum(ts_syn.clamp_(min=0), room).to(torch.int32)
+    ts_rep = (torch.rand(n, generator=g, device=device) * room).to(torch.int32)
+    ts = torch.where(syn, ts_syn, ts_rep)
+    del syn, ts_syn, ts_rep, room
+    a = torch._standard_gamma(torch.full((n,), 5.0, device=device))
+    b = torch._standard_gamma(torch.full((n,), 1.5, device=device))
+    ident = 0.70 + 0.30 * (a / (a + b))
+    del a, b
+    block = ln
+    matches = torch.floor(ident.to(torch.float64) * block.to(torch.float64)).to(torch.int32)
+    identity = matches.to(torch.float64) / block.to(torch.float64)
+    strand = (torch.rand(n, generator=g, device=device) < 0.1).to(torch.uint8)
+    table = torch.arange(n_genomes, device=device, dtype=torch.int32)
+    cols = dict(q_id=q.contiguous(), t_id=t.contiguous(), q_start=qs, q_end=qs + ln, t_start=ts, t_end=ts + ln,
+                identity=identity.contiguous(), matches=matches, block_len=block.contiguous(), strand=strand,
+                seq_genome_last=table, seq_genome_two=table.clone())
+    return cols, sizes
+
+
+def make_records(lib_mod, cols, n, n_genomes):
+    r = lib_mod.SwgRecords()
+    r.n = n
+    for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
+        setattr(r, k, cols[k].data_ptr())
+    r.n_seq = n_genomes
+    r.seq_genome_last = cols["seq_genome_last"].data_ptr()
+    r.n_genome_last = n_genomes
+    r.seq_genome_two = cols["seq_genome_two"].data_ptr()
+    r.n_genome_two = n_genomes
+    return r
+
+
+def make_config(sw, pipeline):
+    if pipeline == "sweep":   # --num-mappings 1:1 --scaffold-jump 0
+        return sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=0)
+    if pipeline == "full":    # --num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000 (jump 50k, mass 10k)
+        return sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_filter_mode=sw.FilterMode.OneToOne,
+                               scaffold_gap=50_000, min_scaffold_length=10_000, scaffold_max_deviation=20_000)
+    if pipeline == "default":  # all CLI defaults (many:many, jump 50k, mass 10k)
+        return sw.FilterConfig()
+    raise SystemExit(f"unknown --pipeline {pipeline}")
+
+
+def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev):
+    """The CPU oracle (port of the reference, 1 thread like the reference's filter) timed on a bounded
+    sample: the first whole genome-pair groups of this rank's shard.  Also the parity check."""
+    import numpy as np
+    from tests import orc
+    csum = sizes.cumsum(0).cpu().numpy()
+    g = int(np.searchsorted(csum, sample_target)) + 1
+    m = int(csum[min(g, len(csum)) - 1])
+    h = {k: cols[k][:m].cpu().numpy() for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity",
+                                                 "matches", "block_len", "strand")}
+    names = [f"g{i:03d}#1#chr1" for i in range(int(max(h["q_id"].max(), h["t_id"].max())) + 1)]
+    u = lambda a: np.ascontiguousarray(a.astype(np.uint64))
+    rec = orc.Records([names[i] for i in h["q_id"]], [names[i] for i in h["t_id"]], u(h["q_start"]), u(h["q_end"]),
+                      u(h["t_start"]), u(h["t_end"]), u(h["block_len"]), np.ascontiguousarray(h["identity"]),
+                      u(h["matches"]), np.where(h["strand"] == 0, ord("+"), ord("-")).astype(np.uint8),
+                      u(np.arange(m)))
+    ocfg = orc.Config(mapping_filter_mode=int(cfg.mapping_filter_mode), mapping_max_per_query=cfg.mapping_max_per_query or 0,
+                      mapping_max_per_target=cfg.mapping_max_per_target or 0,
+                      scaffold_filter_mode=int(cfg.scaffold_filter_mode), scaffold_max_per_query=cfg.scaffold_max_per_query or 0,
+                      scaffold_max_per_target=cfg.scaffold_max_per_target or 0, overlap_threshold=cfg.overlap_threshold,
+                      scaffold_gap=cfg.scaffold_gap, min_scaffold_length=cfg.min_scaffold_length,
+                      scaffold_overlap_threshold=cfg.scaffold_overlap_threshold,
+                      scaffold_max_deviation=cfg.scaffold_max_deviation, scoring_function=int(cfg.scoring_function),
+                      min_identity=cfg.min_identity, min_scaffold_identity=cfg.min_scaffold_identity)
+    ost, och, secs = orc.apply_filters(ocfg, rec, want_seconds=True)
+    gst = status_dev[:m].cpu().numpy()
+    parity = bool(np.array_equal(gst, ost))
+    if parity and cfg.scaffold_gap:
+        # chain numbers are global to a call; compare the partition they induce on the sample
+        gch = chain_dev[:m].cpu().numpy()
+        a = {}
+        for x, y in zip(gch.tolist(), och.tolist()):
+            if (x == 0) != (y == 0) or a.setdefault(x, y) != y:
+                parity = False
+                break
+    return dict(value=m / secs, unit="mappings/s", cores=1, kind="port",
+                sample=f"first {g} genome-pair groups of rank 0's shard = {m} mappings, oracle apply_filters {secs:.2f} s"), parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mappings", type=int, default=100_000_000, help="mappings per GPU")
+    ap.add_argument("--genomes", type=int, default=100)
+    ap.add_argument("--pipeline", default="sweep", choices=["sweep", "full", "default"])
+    ap.add_argument("--cpu-sample", type=int, default=300_000, help="mappings in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--seed", type=int, default=2025)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import sweepga_amd as sw
+    from sweepga_amd import _lib
+    ctx = sw.Context(local_rank)
+    n = args.mappings
+    cols, sizes = gen_shard(torch, n, args.genomes, args.seed + 7919 * rank, device)
+    torch.cuda.synchronize()
+    rec = make_records(_lib, cols, n, args.genomes)
+    cfg = make_config(sw, args.pipeline)
+    ccfg = cfg.to_c()
+    status = torch.zeros(n, dtype=torch.uint8, device=device)
+    chain = torch.zeros(n, dtype=torch.int32, device=device)
+    stats = _lib.SwgStats()
+
+    def step(with_stats=False):
+        ctx.check(ctx.lib.swg_filter_device(ctx.handle, C.byref(rec), C.byref(ccfg), status.data_ptr(), chain.data_ptr(),
+                                            C.byref(stats) if with_stats else None))
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_reset()
+    ctx.profile(True)   # HIP events around every kernel launch on the library's own stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ctx.profile(False)
+    prof = ctx.profile_table()
+    step(with_stats=True)  # untimed: counts for the report
+    ctx.synchronize()
+
+    if rank == 0:
+        algo = ALGO_BYTES_SWEEP if args.pipeline == "sweep" else ALGO_BYTES_FULL
+        ms_per_step = elapsed / args.steps * 1e3
+        total_kernel_ms = sum(ms for _, ms in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
+        dom_name, (dom_launches, dom_ms) = dom
+        dom_avg_ms = dom_ms / max(dom_launches, 1)
+        achieved = algo * n / (dom_avg_ms * 1e-3) / 1e9
+        pipe_achieved = algo * n / (ms_per_step * 1e-3) / 1e9
+        cpu, parity = (None, None)
+        if args.cpu_sample > 0:
+            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status, chain)
+        out = {
+            "metric": "PAF mappings/sec through plane-sweep+scaffold filter",
+            "value": n * world / (elapsed / args.steps),
+            "unit": "mappings/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 coordinates, f64 scores",
+            "data": "synthetic",
+            "config": {"workload": f"S-pan: {n} mappings per GPU over {args.genomes * (args.genomes - 1)} genome-pair groups "
+                                   f"({args.genomes} single-chromosome genomes), pipeline={args.pipeline}",
+                       "flags": {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
+                                 "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
+                                 "default": "(defaults)"}[args.pipeline],
+                       "mappings_per_gpu": n, "groups_per_gpu": args.genomes * (args.genomes - 1)},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
+                         "algorithmic_bytes_per_mapping": algo, "units_per_launch": n,
+                         "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
+                         "kernel_ms_per_step": total_kernel_ms / args.steps},
+            "cpu_baseline": cpu,
+            "parity_vs_oracle_on_sample": parity,
+            "counts": {"in": stats.n_in, "retained": stats.n_retained, "swept": stats.n_swept, "chains": stats.n_chains,
+                       "chains_kept": stats.n_chains_kept, "out": stats.n_out, "device_ms_last_step": stats.device_ms},
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,16 @@ int swg_log(swg_ctx* ctx, uint64_t n, const double* x, double* y);
  * values so a test can compare them with the host libm. */
 int swg_log_range(swg_ctx* ctx, uint64_t first, uint64_t stride, uint64_t n, double* y);
 
+/* ---- per-kernel timing (HIP events on swg_stream) ---------------------------------------- */
+/* When enabled, every kernel launch of later calls is bracketed by HIP events on the context's
+ * stream and its elapsed time accumulated per kernel name.  Costs two event records per launch. */
+int swg_profile_enable(swg_ctx* ctx, int on);
+int swg_profile_reset(swg_ctx* ctx);
+/* Number of distinct kernel names seen since the last reset. */
+int swg_profile_count(swg_ctx* ctx);
+/* Entry i: name (owned by ctx, valid until the next reset), launches, summed milliseconds. */
+int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

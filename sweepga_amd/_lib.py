@@ -14,7 +14,8 @@ K_INF = 2**64 - 1
 # every symbol include/sweepga_gpu.h declares
 SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
            "swg_filter", "swg_filter_device", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
-           "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range"]
+           "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range", "swg_profile_enable",
+           "swg_profile_reset", "swg_profile_count", "swg_profile_get"]
 
 
 class SwgError(RuntimeError):
@@ -128,6 +129,15 @@ def load():
     lib.swg_log.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.swg_log_range.restype = C.c_int
     lib.swg_log_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.swg_profile_enable.restype = C.c_int
+    lib.swg_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.swg_profile_reset.restype = C.c_int
+    lib.swg_profile_reset.argtypes = [C.c_void_p]
+    lib.swg_profile_count.restype = C.c_int
+    lib.swg_profile_count.argtypes = [C.c_void_p]
+    lib.swg_profile_get.restype = C.c_int
+    lib.swg_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -154,6 +164,26 @@ class Context:
     @property
     def stream(self):
         return self.lib.swg_stream(self.handle)
+
+    def profile(self, on=True):
+        self.check(self.lib.swg_profile_enable(self.handle, int(bool(on))))
+
+    def profile_reset(self):
+        self.check(self.lib.swg_profile_reset(self.handle))
+
+    def profile_table(self):
+        """{kernel name: (launches, total_ms)} accumulated since the last reset."""
+        n = self.lib.swg_profile_count(self.handle)
+        if n < 0:
+            self.check(n)
+        out = {}
+        for i in range(n):
+            name = C.c_char_p()
+            launches = C.c_uint64()
+            ms = C.c_double()
+            self.check(self.lib.swg_profile_get(self.handle, i, C.byref(name), C.byref(launches), C.byref(ms)))
+            out[name.value.decode()] = (launches.value, ms.value)
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

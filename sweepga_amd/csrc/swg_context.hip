@@ -64,7 +64,79 @@ int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int c
   return SWG_OK;
 }
 
+swg_prof_scope::swg_prof_scope(swg_ctx* c, const char* kernel_name) : ctx(c) {
+  if (!ctx || !ctx->prof_on) return;
+  for (size_t i = 0; i < ctx->prof_entries.size(); ++i)
+    if (ctx->prof_entries[i].name == kernel_name) name = (int)i;
+  if (name < 0) {
+    ctx->prof_entries.push_back({kernel_name, 0, 0.0});
+    name = (int)ctx->prof_entries.size() - 1;
+  }
+  auto get = [&]() -> hipEvent_t {
+    if (!ctx->prof_free_events.empty()) {
+      hipEvent_t e = ctx->prof_free_events.back();
+      ctx->prof_free_events.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  };
+  a = get();
+  b = get();
+  if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+swg_prof_scope::~swg_prof_scope() {
+  if (!ctx || name < 0) return;
+  if (a && b) {
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof_pending_list.push_back({name, a, b});
+  }
+}
+
+int swg_prof_collect(swg_ctx* ctx) {
+  if (ctx->prof_pending_list.empty()) return SWG_OK;
+  SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& p : ctx->prof_pending_list) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->prof_entries[p.name].launches += 1;
+      ctx->prof_entries[p.name].ms += ms;
+    }
+    ctx->prof_free_events.push_back(p.a);
+    ctx->prof_free_events.push_back(p.b);
+  }
+  ctx->prof_pending_list.clear();
+  return SWG_OK;
+}
+
 extern "C" {
+
+int swg_profile_enable(swg_ctx* ctx, int on) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (!on) SWG_TRY(swg_prof_collect(ctx));
+  ctx->prof_on = on != 0;
+  return SWG_OK;
+}
+int swg_profile_reset(swg_ctx* ctx) {
+  if (!ctx) return SWG_ERR_INVALID;
+  SWG_TRY(swg_prof_collect(ctx));
+  ctx->prof_entries.clear();
+  return SWG_OK;
+}
+int swg_profile_count(swg_ctx* ctx) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (swg_prof_collect(ctx) != SWG_OK) return SWG_ERR_HIP;
+  return (int)ctx->prof_entries.size();
+}
+int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms) {
+  if (!ctx || i < 0 || i >= (int)ctx->prof_entries.size()) return SWG_ERR_INVALID;
+  if (name) *name = ctx->prof_entries[i].name.c_str();
+  if (launches) *launches = ctx->prof_entries[i].launches;
+  if (total_ms) *total_ms = ctx->prof_entries[i].ms;
+  return SWG_OK;
+}
 
 int swg_abi_version(void) { return SWG_ABI_VERSION; }
 
@@ -111,6 +183,11 @@ void swg_destroy(swg_ctx* ctx) {
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (auto& p : ctx->prof_pending_list) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

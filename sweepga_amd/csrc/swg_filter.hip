@@ -127,8 +127,8 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep_t = swg_alloc<uint8_t>(ctx, n);
   SWG_CHECK_ARENA(ctx);
-  mapping_segments_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->seq_genome_last, r->n_genome_last,
-                                                  seg_q, seg_t);
+  SWG_LAUNCH(ctx, "mapping_segments", mapping_segments_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->seq_genome_last, r->n_genome_last,
+                                                  seg_q, seg_t));
   SWG_KERNEL_CHECK(ctx);
   const int seg_bits = swg_bits_for((uint64_t)r->n_seq * r->n_genome_last);  // ids + 1 <= n_seq * n_genome
   swg_axis_input ax;
@@ -145,7 +145,7 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   ax.start = r->t_start;
   ax.end = r->t_end;
   SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep_t));
-  and_kernel<<<nblk(n), EW, 0, st>>>(n, keep_q, keep_t, keep);  // intersection, src/paf_filter.rs:1105-1111
+  SWG_LAUNCH(ctx, "and", and_kernel<<<nblk(n), EW, 0, st>>>(n, keep_q, keep_t, keep));  // intersection, src/paf_filter.rs:1105-1111
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);
   return SWG_OK;
@@ -167,10 +167,10 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
-  retain_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->block_len, r->identity, cfg->min_block_length,
-                                        cfg->keep_self, cfg->min_identity, alive);
+  SWG_LAUNCH(ctx, "retain", retain_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->block_len, r->identity, cfg->min_block_length,
+                                        cfg->keep_self, cfg->min_identity, alive));
   SWG_KERNEL_CHECK(ctx);
-  stats_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, r->q_start, r->q_end, r->t_start, r->t_end, alive, scalars);
+  SWG_LAUNCH(ctx, "stats", stats_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, r->q_start, r->q_end, r->t_start, r->t_end, alive, scalars));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_score_keys(ctx, n, r->q_start, r->q_end, r->identity, cfg->scoring_function, score_key));
   uint64_t h[2];
@@ -181,7 +181,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, score_key, pos_bits, keep1));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
-    unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out, scalars + 2);
+    SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out, scalars + 2));
     SWG_KERNEL_CHECK(ctx);
     if (stats) {
       uint64_t c;
@@ -387,7 +387,7 @@ extern "C" int swg_log(swg_ctx* ctx, uint64_t n, const double* x, double* y) {
     double* dy = swg_alloc<double>(ctx, n);
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    log_kernel<<<nblk(n), EW, 0, ctx->stream>>>(n, dx, dy);
+    SWG_LAUNCH(ctx, "log", log_kernel<<<nblk(n), EW, 0, ctx->stream>>>(n, dx, dy));
     SWG_KERNEL_CHECK(ctx);
     SWG_HIP(ctx, hipMemcpyAsync(y, dy, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -404,7 +404,7 @@ extern "C" int swg_log_range(swg_ctx* ctx, uint64_t first, uint64_t stride, uint
   return swg_run_with_arena(ctx, [&]() -> int {
     double* dy = swg_alloc<double>(ctx, n);
     SWG_CHECK_ARENA(ctx);
-    log_range_kernel<<<nblk(n), EW, 0, ctx->stream>>>(first, stride, n, dy);
+    SWG_LAUNCH(ctx, "log_range", log_range_kernel<<<nblk(n), EW, 0, ctx->stream>>>(first, stride, n, dy));
     SWG_KERNEL_CHECK(ctx);
     SWG_HIP(ctx, hipMemcpyAsync(y, dy, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/sweepga_gpu.h"
 
@@ -22,7 +23,25 @@ struct swg_ctx {
   uint64_t* h_scalars = nullptr;  // 64 x u64
   std::string err;
   int num_cu = 256;
+  // per-kernel profiler (swg_profile_*)
+  bool prof_on = false;
+  struct prof_pending { int name; hipEvent_t a, b; };
+  struct prof_entry { std::string name; uint64_t launches = 0; double ms = 0.0; };
+  std::vector<prof_pending> prof_pending_list;
+  std::vector<hipEvent_t> prof_free_events;
+  std::vector<prof_entry> prof_entries;
 };
+
+// RAII bracket around one kernel launch (or a short run of launches of one kind).
+struct swg_prof_scope {
+  swg_ctx* ctx;
+  int name = -1;
+  hipEvent_t a = nullptr, b = nullptr;
+  swg_prof_scope(swg_ctx* c, const char* kernel_name);
+  ~swg_prof_scope();
+};
+// Resolves pending event pairs into the per-name table (synchronises the stream).
+int swg_prof_collect(swg_ctx* ctx);
 
 extern thread_local std::string swg_create_error;
 
@@ -44,6 +63,12 @@ int swg_set_error(swg_ctx* ctx, int code, const char* fmt, ...);
   } while (0)
 
 #define SWG_KERNEL_CHECK(ctx) SWG_HIP((ctx), hipGetLastError())
+// Launch bracket: `SWG_LAUNCH(ctx, "name", kernel<<<grid, block, 0, stream>>>(args));`
+#define SWG_LAUNCH(ctx, name, ...)        \
+  do {                                    \
+    swg_prof_scope prof_scope_(ctx, name); \
+    __VA_ARGS__;                          \
+  } while (0)
 
 // ---- arena --------------------------------------------------------------------------------
 // Allocation never fails inside a pipeline: when the arena is too small the pointer returned is

@@ -97,19 +97,19 @@ int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint
   }
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 1) {
-    scan_down_kernel<<<1, SCAN_THREADS, 0, ctx->stream>>>(in, out, nullptr, n, d_total_out,
-                                                          d_total_out ? 1 : 0);
+    SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<<<1, SCAN_THREADS, 0, ctx->stream>>>(in, out, nullptr, n, d_total_out,
+                                                          d_total_out ? 1 : 0));
     SWG_KERNEL_CHECK(ctx);
     return SWG_OK;
   }
   swg_arena_mark mark = swg_arena_save(ctx);
   uint32_t* sums = swg_alloc<uint32_t>(ctx, nb);
   SWG_CHECK_ARENA(ctx);
-  scan_reduce_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n);
+  SWG_LAUNCH(ctx, "scan_reduce", scan_reduce_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, sums, sums, nb, nullptr));
-  scan_down_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, out, sums, n, d_total_out,
-                                                                   d_total_out ? 1 : 0);
+  SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, out, sums, n, d_total_out,
+                                                                   d_total_out ? 1 : 0));
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);  // stream order keeps `sums` alive until the kernels above ran
   return SWG_OK;
@@ -217,11 +217,11 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint6
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    rs_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, n, shift, mask, hist, ntiles);
+    SWG_LAUNCH(ctx, "rs_hist", rs_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, n, shift, mask, hist, ntiles));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_exclusive_scan_u32(ctx, hist, hist, (uint64_t)RS_RADIX * ntiles, nullptr));
-    rs_scatter_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift, mask, hist,
-                                                              ntiles);
+    SWG_LAUNCH(ctx, "rs_scatter", rs_scatter_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift, mask, hist,
+                                                              ntiles));
     SWG_KERNEL_CHECK(ctx);
     uint64_t* tk = kin;
     kin = kout;

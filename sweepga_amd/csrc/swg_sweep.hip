@@ -457,8 +457,8 @@ inline unsigned blocks_for(uint64_t n, int threads) { return (unsigned)((n + thr
 int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint32_t* q_end,
                    const double* identity, int scoring, uint64_t* key_out) {
   if (n == 0) return SWG_OK;
-  score_key_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, ctx->stream>>>(n, q_start, q_end, identity,
-                                                                              scoring, key_out);
+  SWG_LAUNCH(ctx, "score_key", score_key_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, ctx->stream>>>(n, q_start, q_end, identity,
+                                                                              scoring, key_out));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
@@ -481,7 +481,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     uint32_t* n_zero = swg_alloc<uint32_t>(ctx, 2);
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemsetAsync(n_zero, 0, 8, st));
-    kinf_mark_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.start, in.end, in.alive, keep, n_zero);
+    SWG_LAUNCH(ctx, "kinf_mark", kinf_mark_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.start, in.end, in.alive, keep, n_zero));
     SWG_KERNEL_CHECK(ctx);
     uint64_t h = 0;
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(n_zero), &h, 1));
@@ -492,15 +492,15 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       uint32_t* ev_val2 = swg_alloc<uint32_t>(ctx, n_ev);
       uint8_t* single = swg_alloc<uint8_t>(ctx, n);
       SWG_CHECK_ARENA(ctx);
-      event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
-                                                                            in.pos_bits, ev_x, ev_val);
+      SWG_LAUNCH(ctx, "event_build", event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
+                                                                            in.pos_bits, ev_x, ev_val));
       SWG_KERNEL_CHECK(ctx);
       SWG_TRY(swg_radix_sort_pairs(ctx, ev_x, ev_val, ev_x2, ev_val2, n_ev, 0, key_bits));
       SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
-      single_segment_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.pos_bits,
-                                                                                  single);
+      SWG_LAUNCH(ctx, "single_segment", single_segment_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.pos_bits,
+                                                                                  single));
       SWG_KERNEL_CHECK(ctx);
-      kinf_single_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, single, keep);
+      SWG_LAUNCH(ctx, "kinf_single", kinf_single_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, single, keep));
       SWG_KERNEL_CHECK(ctx);
     }
     swg_arena_restore(ctx, mark);
@@ -523,8 +523,8 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint8_t* top = flags + n;
   uint8_t* ovl = flags + 2 * n;
 
-  event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
-                                                                        in.pos_bits, ev_x, ev_val);
+  SWG_LAUNCH(ctx, "event_build", event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
+                                                                        in.pos_bits, ev_x, ev_val));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_radix_sort_pairs(ctx, ev_x, ev_val, ev_x2, ev_val2, n_ev, 0, key_bits));
   uint64_t* ev_key = ev_x2;
@@ -532,14 +532,14 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 3 * n, st));
   SWG_HIP(ctx, hipMemsetAsync(tile_cnt, 0, sizeof(uint32_t) * ((size_t)ntiles + 1), st));
   SWG_HIP(ctx, hipMemsetAsync(tile_cur, 0, sizeof(uint32_t) * ((size_t)ntiles + 1), st));
-  event_gather_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.end,
+  SWG_LAUNCH(ctx, "event_gather", event_gather_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.end,
                                                                             in.score_key, pos_begin, pos_end,
-                                                                            ev_end, ev_key);
+                                                                            ev_end, ev_key));
   SWG_KERNEL_CHECK(ctx);
-  single_segment_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.pos_bits,
-                                                                              single);
+  SWG_LAUNCH(ctx, "single_segment", single_segment_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.pos_bits,
+                                                                              single));
   SWG_KERNEL_CHECK(ctx);
-  carry_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, pos_begin, pos_end, tile_cnt);
+  SWG_LAUNCH(ctx, "carry_count", carry_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, pos_begin, pos_end, tile_cnt));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, tile_cnt, tile_cnt, (uint64_t)ntiles + 1, d_total));
   uint64_t n_carry = 0;
@@ -550,9 +550,9 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* c_id = swg_alloc<uint32_t>(ctx, n_carry + 1);
   SWG_CHECK_ARENA(ctx);
   if (n_carry) {
-    carry_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+    SWG_LAUNCH(ctx, "carry_fill", carry_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
         n, in.alive, pos_begin, pos_end, in.seg, in.start, in.end, in.score_key, in.pos_bits, tile_cnt, tile_cur,
-        c_s, c_e, c_key, c_id);
+        c_s, c_e, c_key, c_id));
     SWG_KERNEL_CHECK(ctx);
   }
   TileArgs ta;
@@ -572,11 +572,11 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.top = top;
   ta.ovl = ovl;
   if (k == 1)
-    sweep_tile_kernel<true><<<ntiles, TE, 0, st>>>(ta);
+    SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_kernel<true><<<ntiles, TE, 0, st>>>(ta));
   else
-    sweep_tile_kernel<false><<<ntiles, TE, 0, st>>>(ta);
+    SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kernel<false><<<ntiles, TE, 0, st>>>(ta));
   SWG_KERNEL_CHECK(ctx);
-  combine_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, top, ovl, keep);
+  SWG_LAUNCH(ctx, "combine", combine_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, top, ovl, keep));
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);
   return SWG_OK;
