@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--mappings", type=int, default=100_000_000, help="mappings per GPU")
     ap.add_argument("--genomes", type=int, default=100)
     ap.add_argument("--pipeline", default="sweep", choices=["sweep", "full", "default"])
-    ap.add_argument("--cpu-sample", type=int, default=300_000, help="mappings in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="mappings in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=2025)
     args = ap.parse_args()
 

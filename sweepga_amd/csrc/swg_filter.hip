@@ -72,17 +72,22 @@ __global__ __launch_bounds__(EW) void and_kernel(uint64_t n, const uint8_t* __re
 
 __global__ __launch_bounds__(EW) void unassigned_status_kernel(uint64_t n, const uint8_t* __restrict__ keep,
                                                                uint8_t* __restrict__ status,
-                                                               uint32_t* __restrict__ chain,
-                                                               unsigned long long* __restrict__ n_out) {
+                                                               uint32_t* __restrict__ chain) {
   uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  uint32_t k = 0;
   if (i < n) {
-    k = keep[i] ? 1 : 0;
-    status[i] = k ? SWG_ST_UNASSIGNED : SWG_ST_DROPPED;
+    status[i] = keep[i] ? SWG_ST_UNASSIGNED : SWG_ST_DROPPED;
     chain[i] = 0;
   }
-  const uint64_t b = __ballot(k);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_out, (unsigned long long)__popcll(b));
+}
+
+// number of non-zero bytes (grid-stride, one atomic per wave of a small grid)
+__global__ __launch_bounds__(EW) void count_nonzero_kernel(uint64_t n, const uint8_t* __restrict__ v,
+                                                           unsigned long long* __restrict__ out) {
+  uint32_t cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW) cnt += v[i] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
 }
 
 __global__ __launch_bounds__(EW) void log_kernel(uint64_t n, const double* __restrict__ x, double* __restrict__ y) {
@@ -181,9 +186,11 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, score_key, pos_bits, keep1));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
-    SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out, scalars + 2));
+    SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out));
     SWG_KERNEL_CHECK(ctx);
     if (stats) {
+      SWG_LAUNCH(ctx, "count_nonzero", count_nonzero_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, keep1, scalars + 2));
+      SWG_KERNEL_CHECK(ctx);
       uint64_t c;
       SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars + 2), &c, 1));
       stats->n_swept = stats->n_out = c;

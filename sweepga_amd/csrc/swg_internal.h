@@ -113,6 +113,8 @@ static inline int swg_run_with_arena(swg_ctx* ctx, F&& body) {
 // non-null it receives the grand total (device pointer, u32... as u64).
 int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n,
                            uint64_t* d_total_out);
+// Inclusive running maximum of n u32 values (in place allowed).
+int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n);
 // Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
 // Result is left in keys_a/vals_a; keys_b/vals_b are scratch of the same size.
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,

@@ -1,22 +1,1285 @@
-// Scaffold stage -- under construction.
+// Scaffold stage of the filter (src/paf_filter.rs:436-747) on the device:
+//
+//   sort A      all step-1 survivors by (query seq, target seq, strand, q_start), stable
+//               (groups of merge_mappings_into_chains, paf_filter.rs:761-777; ties fall to input order)
+//   chaining    best-buddy predecessor selection (paf_filter.rs:784-851), one wavefront per
+//               (q, t, strand) group: sequential over i as the greedy demands, the j-window spread over
+//               the 64 lanes, minimum by wave reduction
+//   labelling   chains = paths of the predecessor forest; heads by pointer jumping -- the role of
+//               union_find.rs (every union joins a path's tail, so the union-find root is the path head)
+//   aggregates  bounding box, sum of matches / block lengths per chain (atomics keyed by the head)
+//   ordering    chains are put in the reference's `all_chains` order: groups by first appearance in the
+//               plane-swept metadata order (genome-pair-major, paf_filter.rs:1037-1046, 761-770), then
+//               by head position
+//   filter      span / identity (paf_filter.rs:449-455), weighted identity with glibc-exact ln
+//   sweep       plane_sweep_both per chromosome pair (plane_sweep_scaffold.rs:108-251) on the sweep kernels
+//   numbering   chain_N in plane_sweep_scaffolds' output order (genome pair -> chromosome pair -> index)
+//   anchors     members of kept chains; inversion capture (paf_filter.rs:535-597)
+//   rescue      per chromosome pair, anchors sorted by query centre, window search (paf_filter.rs:599-747)
+#include <vector>
+
+#include "swg_log.h"
 #include "swg_pipeline.h"
 
-int swg_scaffold_stage(swg_ctx* ctx, const swg_records*, const swg_config*, const uint8_t*, const uint8_t*,
-                       const uint64_t*, int, uint8_t*, uint32_t*, swg_stats*) {
-  return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "scaffold stage not built yet");
+namespace {
+
+constexpr int EW = 256;
+constexpr uint32_t NONE = 0xffffffffu;
+inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
+
+// ---- small generic kernels ------------------------------------------------------------------------
+__global__ __launch_bounds__(EW) void flags_to_u32_kernel(uint64_t n, const uint8_t* __restrict__ f,
+                                                          uint32_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) out[i] = f[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(EW) void fill_u32_kernel(uint64_t n, uint32_t* __restrict__ p, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(EW) void fill_u64_kernel(uint64_t n, uint64_t* __restrict__ p, uint64_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(EW) void iota_u32_kernel(uint64_t n, uint32_t* __restrict__ p) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+// out[pos[i]] = i for flagged i (stream compaction given the exclusive scan `pos` of the flags)
+__global__ __launch_bounds__(EW) void compact_indices_kernel(uint64_t n, const uint8_t* __restrict__ f,
+                                                             const uint32_t* __restrict__ pos,
+                                                             uint32_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n && f[i]) out[pos[i]] = (uint32_t)i;
 }
 
-extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t, const uint32_t*, const uint32_t*, uint32_t,
-                                         const uint32_t*, uint32_t, const uint64_t*, const uint64_t*,
-                                         const uint64_t*, const uint64_t*, const double*, int, uint64_t, uint64_t,
-                                         double, int, uint64_t*, uint64_t*) {
-  return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "not built yet");
+// ---- sort A -----------------------------------------------------------------------------------------
+// key = (((q * n_seq + t) * 2 + strand) << pos_bits) | q_start      value = original index
+__global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
+                                                        const uint32_t* __restrict__ q_id,
+                                                        const uint32_t* __restrict__ t_id,
+                                                        const uint8_t* __restrict__ strand,
+                                                        const uint32_t* __restrict__ q_start, uint32_t n_seq,
+                                                        int pos_bits, uint64_t* __restrict__ key) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint32_t i = a_idx[a];
+  const uint64_t g = ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
+  key[a] = (g << pos_bits) | q_start[i];
 }
-extern "C" int swg_merge_chains(swg_ctx* ctx, const swg_records*, uint64_t, uint32_t*, uint32_t*, uint32_t*,
-                                uint32_t*, uint32_t*, double*, uint64_t*) {
-  return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "not built yet");
+
+// After sort A: per A-position columns + pair boundaries.
+__global__ __launch_bounds__(EW) void gatherA_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
+                                                     const uint32_t* __restrict__ idxA,
+                                                     const uint32_t* __restrict__ q_end,
+                                                     const uint32_t* __restrict__ t_start,
+                                                     const uint32_t* __restrict__ t_end,
+                                                     const uint8_t* __restrict__ keep1, int pos_bits,
+                                                     uint32_t* __restrict__ a_qe, uint32_t* __restrict__ a_ts,
+                                                     uint32_t* __restrict__ a_te, uint8_t* __restrict__ a_keep,
+                                                     uint32_t* __restrict__ pair_flag) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint32_t i = idxA[a];
+  a_qe[a] = q_end[i];
+  a_ts[a] = t_start[i];
+  a_te[a] = t_end[i];
+  a_keep[a] = keep1[i] ? 1 : 0;
+  const uint64_t pair = keyA[a] >> (pos_bits + 1);
+  pair_flag[a] = (a == 0 || (keyA[a - 1] >> (pos_bits + 1)) != pair) ? 1u : 0u;
 }
-extern "C" int swg_union_find_sets(swg_ctx* ctx, uint64_t, uint64_t, const uint32_t*, const uint32_t*, uint32_t*,
-                                   uint64_t*) {
-  return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "not built yet");
+
+// dense pair id of every A position: inclusive count of pair heads - 1 (scan result is exclusive)
+__global__ __launch_bounds__(EW) void dense_from_scan_kernel(uint64_t M, const uint32_t* __restrict__ excl,
+                                                             const uint32_t* __restrict__ flag,
+                                                             uint32_t* __restrict__ dense) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a < M) dense[a] = excl[a] + flag[a] - 1;
+}
+
+// ---- survivors (mapping-sweep survivors in A order) -----------------------------------------------------
+__global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t* __restrict__ s_a,
+                                                     const uint64_t* __restrict__ keyA,
+                                                     const uint32_t* __restrict__ idxA,
+                                                     const uint32_t* __restrict__ a_qe,
+                                                     const uint32_t* __restrict__ a_ts,
+                                                     const uint32_t* __restrict__ a_te,
+                                                     const uint32_t* __restrict__ matches,
+                                                     const uint32_t* __restrict__ block_len, int pos_bits,
+                                                     uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
+                                                     uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
+                                                     uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
+                                                     uint32_t* __restrict__ s_idx, uint64_t* __restrict__ s_grp,
+                                                     uint32_t* __restrict__ head_flag) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t a = s_a[p];
+  const uint64_t k = keyA[a];
+  const uint32_t i = idxA[a];
+  s_qs[p] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
+  s_qe[p] = a_qe[a];
+  s_ts[p] = a_ts[a];
+  s_te[p] = a_te[a];
+  s_m[p] = matches[i];
+  s_b[p] = block_len[i];
+  s_idx[p] = i;
+  const uint64_t g = k >> pos_bits;
+  s_grp[p] = g;
+  bool head = p == 0;
+  if (!head) head = (keyA[s_a[p - 1]] >> pos_bits) != g;
+  head_flag[p] = head ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
+                                                          const uint32_t* __restrict__ gidx_excl,
+                                                          uint32_t* __restrict__ s_gidx,
+                                                          uint32_t* __restrict__ group_begin) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t g = gidx_excl[p] + head_flag[p] - 1;
+  s_gidx[p] = g;
+  if (head_flag[p]) group_begin[g] = (uint32_t)p;
+}
+
+// ---- best-buddy chaining (paf_filter.rs:784-851) -----------------------------------------------------------
+// One wavefront per (q, t, strand) group.  The outer loop over i is the reference's sequential greedy
+// (later i read best_pred_score[] written by earlier i); the inner loop over j runs on the 64 lanes.
+// best_pred_score lives in global memory: the single writer and all readers are lanes of this wavefront;
+// accesses are agent-scope atomics (served by the XCD's L2, never a stale L1 line) and each step's store is
+// drained (workgroup-scope release = s_waitcnt vmcnt(0)) before the next step's loads are issued.
+__global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                    uint32_t m, const uint64_t* __restrict__ s_grp,
+                                                    const uint32_t* __restrict__ s_qs,
+                                                    const uint32_t* __restrict__ s_qe,
+                                                    const uint32_t* __restrict__ s_ts,
+                                                    const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                    unsigned long long* bps, uint32_t* __restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * 256) >> 6;
+  const uint64_t INF = ~0ull;
+  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+    const uint32_t b = group_begin[g];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+    if (e - b < 2) continue;
+    const bool minus = (s_grp[b] & 1ull) != 0;
+    for (uint32_t i = b; i + 1 < e; ++i) {
+      const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
+      const uint64_t bound = qe_i + max_gap;  // u64, wraps like the reference only beyond 2^64
+      uint64_t best_d = INF;
+      uint32_t best_j = NONE;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        bool in = j < e;
+        uint64_t qs_j = 0;
+        if (in) {
+          qs_j = s_qs[j];
+          in = qs_j <= bound;
+        }
+        if (in) {
+          const uint64_t ts_j = s_ts[j], te_j = s_te[j];
+          uint64_t q_gap, r_gap;
+          if (qs_j >= qe_i) {
+            q_gap = qs_j - qe_i;
+          } else {
+            const uint64_t ov = qe_i - qs_j;
+            q_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
+          }
+          if (!minus) {
+            if (ts_j >= te_i) {
+              r_gap = ts_j - te_i;
+            } else {
+              const uint64_t ov = te_i - ts_j;
+              r_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
+            }
+          } else if (ts_i >= te_j) {
+            r_gap = ts_i - te_j;
+          } else {
+            const uint64_t ov = te_j - ts_i;
+            r_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
+          }
+          if (q_gap <= max_gap && r_gap <= max_gap) {
+            const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
+            // `d < best_score && d < best_pred_score[j]`, first minimum in j order wins
+            const uint64_t cur = __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d < cur && d < best_d) {
+              best_d = d;
+              best_j = j;
+            }
+          }
+        }
+        // sorted by q_start: a stripe with no lane inside the window ends the scan (paf_filter.rs:794-796)
+        if (!__any(in)) break;
+      }
+      // wave reduction: minimum d, ties to the smaller j (strict `<` in j order)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t od = __shfl_xor(best_d, o, 64);
+        const uint32_t oj = __shfl_xor(best_j, o, 64);
+        if (od < best_d || (od == best_d && oj < best_j)) {
+          best_d = od;
+          best_j = oj;
+        }
+      }
+      if (best_j != NONE && lane == 0) {
+        __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pred[best_j] = i;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+  }
+}
+
+// ---- chain labelling ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
+                                                       uint32_t* __restrict__ hd) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) hd[p] = pred[p] == NONE ? (uint32_t)p : pred[p];
+}
+// hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
+__global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t h = hd[p];
+  const uint32_t hh = hd[h];
+  if (hh != h) {
+    hd[p] = hh;
+    *changed = 1;
+  }
+}
+
+__global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                             const uint32_t* __restrict__ s_qe,
+                                                             const uint32_t* __restrict__ s_ts,
+                                                             const uint32_t* __restrict__ s_te,
+                                                             const uint32_t* __restrict__ s_m,
+                                                             const uint32_t* __restrict__ s_b,
+                                                             uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
+                                                             uint32_t* __restrict__ h_te,
+                                                             unsigned long long* __restrict__ h_sm,
+                                                             unsigned long long* __restrict__ h_sb,
+                                                             uint32_t* __restrict__ is_head) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t h = hd[p];
+  is_head[p] = h == p ? 1u : 0u;
+  atomicMax(&h_qe[h], s_qe[p]);
+  atomicMin(&h_ts[h], s_ts[p]);
+  atomicMax(&h_te[h], s_te[p]);
+  atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
+  atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+}
+
+// min original index per (q,t,strand) group, and per genome pair (prefix-last) over ALL alive records
+__global__ __launch_bounds__(EW) void group_first_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                         const uint32_t* __restrict__ s_idx,
+                                                         uint32_t* __restrict__ group_first) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) atomicMin(&group_first[s_gidx[p]], s_idx[p]);
+}
+__global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
+                                                               const uint32_t* __restrict__ q_id,
+                                                               const uint32_t* __restrict__ t_id,
+                                                               const uint32_t* __restrict__ seq_genome,
+                                                               uint32_t n_genome, uint32_t* __restrict__ table) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  const bool valid = a < M;
+  uint32_t i = 0xffffffffu, L = 0;
+  if (valid) {
+    i = idxA[a];
+    L = seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]];
+  }
+  // A order is pair-major, so a wave usually sees one genome pair: one atomic per wave then
+  const uint32_t L0 = __shfl(L, 0, 64);
+  const bool uniform = __all(!valid || L == L0) && __shfl((int)valid, 0, 64);
+  if (uniform) {
+    uint32_t v = i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(v, o, 64);
+      if (t < v) v = t;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(&table[L0], v);
+  } else if (valid) {
+    atomicMin(&table[L], i);
+  }
+}
+
+// chains in head-position order: sort key for the reference's all_chains order
+__global__ __launch_bounds__(EW) void chain_list_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
+                                                        const uint32_t* __restrict__ cpos_excl,
+                                                        const uint32_t* __restrict__ s_gidx,
+                                                        const uint32_t* __restrict__ s_idx,
+                                                        const uint32_t* __restrict__ group_first,
+                                                        const uint32_t* __restrict__ q_id,
+                                                        const uint32_t* __restrict__ t_id,
+                                                        const uint32_t* __restrict__ seq_genome, uint32_t n_genome,
+                                                        const uint32_t* __restrict__ gp_first, int idx_bits,
+                                                        uint32_t* __restrict__ ch_head, uint64_t* __restrict__ ch_key) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m || !is_head[p]) return;
+  const uint32_t c = cpos_excl[p];
+  ch_head[c] = (uint32_t)p;
+  const uint32_t i = s_idx[p];
+  const uint32_t L = seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]];
+  ch_key[c] = ((uint64_t)gp_first[L] << idx_bits) | group_first[s_gidx[p]];
+}
+
+// chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
+__global__ __launch_bounds__(EW) void chain_columns_kernel(
+    uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
+    const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
+    const uint32_t* __restrict__ h_te, const unsigned long long* __restrict__ h_sm,
+    const unsigned long long* __restrict__ h_sb, const uint64_t* __restrict__ s_grp, const uint32_t* __restrict__ s_a,
+    const uint32_t* __restrict__ a_dpair, uint32_t n_seq, uint64_t min_len, double min_ident,
+    uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
+    uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
+    double* __restrict__ C_wid, uint8_t* __restrict__ C_strand, uint32_t* __restrict__ C_dpair,
+    uint8_t* __restrict__ C_ok, uint32_t* __restrict__ rank_of_poschain) {
+  uint64_t c2 = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c2 >= nc) return;
+  const uint32_t c = order[c2];
+  rank_of_poschain[c] = (uint32_t)c2;
+  const uint32_t p = ch_head[c];
+  const uint64_t g = s_grp[p];
+  const uint64_t pair = g >> 1;
+  const uint32_t qs = s_qs[p], qe = h_qe[p], ts = h_ts[p], te = h_te[p];
+  C_qid[c2] = (uint32_t)(pair / n_seq);
+  C_tid[c2] = (uint32_t)(pair % n_seq);
+  C_strand[c2] = (uint8_t)(g & 1);
+  C_qs[c2] = qs;
+  C_qe[c2] = qe;
+  C_ts[c2] = ts;
+  C_te[c2] = te;
+  C_dpair[c2] = a_dpair[s_a[p]];
+  const uint64_t total_length = (uint64_t)qe - (uint64_t)qs;  // q_max - q_min
+  const uint64_t sm = h_sm[p], sb = h_sb[p];
+  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
+  double lcg = 0.0;
+  if (gap_length > 0) {
+    lcg = swg_log_glibc((double)gap_length);
+    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
+  }
+  const double eff = __dadd_rn((double)sb, lcg);
+  const double wid = eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
+  C_wid[c2] = wid;
+  C_ok[c2] = (total_length >= min_len && wid >= min_ident) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                            const uint32_t* __restrict__ cpos_excl,
+                                                            const uint32_t* __restrict__ rank_of_poschain,
+                                                            uint32_t* __restrict__ s_chain) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) s_chain[p] = rank_of_poschain[cpos_excl[hd[p]]];
+}
+
+// ---- scaffold sweep + numbering ------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW) void chain_seg_kernel(uint64_t nc, const uint32_t* __restrict__ C_qid,
+                                                       const uint32_t* __restrict__ C_tid, uint32_t n_seq,
+                                                       uint64_t* __restrict__ seg) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c < nc) seg[c] = (uint64_t)C_qid[c] * n_seq + C_tid[c];
+}
+// after the stable sort of chains by chromosome pair: run heads
+__global__ __launch_bounds__(EW) void run_flag_kernel(uint64_t nc, const uint64_t* __restrict__ sorted_seg,
+                                                      uint32_t* __restrict__ flag) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s < nc) flag[s] = (s == 0 || sorted_seg[s - 1] != sorted_seg[s]) ? 1u : 0u;
+}
+// pair_first[run] = min index over the span/identity-filtered chains of the chromosome pair;
+// gp2_first[genome pair (first two '#' parts)] likewise (plane_sweep_scaffold.rs:116-130 insertion order)
+__global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
+                                                              const uint32_t* __restrict__ run_excl,
+                                                              const uint32_t* __restrict__ run_flag,
+                                                              const uint8_t* __restrict__ C_ok,
+                                                              const uint32_t* __restrict__ C_qid,
+                                                              const uint32_t* __restrict__ C_tid,
+                                                              const uint32_t* __restrict__ seq_genome2, uint32_t n_g2,
+                                                              uint32_t* __restrict__ run_of_chain,
+                                                              uint32_t* __restrict__ pair_first,
+                                                              uint32_t* __restrict__ gp2_first) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s >= nc) return;
+  const uint32_t c = sorted_c[s];
+  const uint32_t run = run_excl[s] + run_flag[s] - 1;
+  run_of_chain[c] = run;
+  if (C_ok[c]) {
+    atomicMin(&pair_first[run], c);
+    atomicMin(&gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]], c);
+  }
+}
+__global__ __launch_bounds__(EW) void number_keys_kernel(uint64_t nk, const uint32_t* __restrict__ kept_list,
+                                                         const uint32_t* __restrict__ run_of_chain,
+                                                         const uint32_t* __restrict__ pair_first,
+                                                         const uint32_t* __restrict__ gp2_first,
+                                                         const uint32_t* __restrict__ C_qid,
+                                                         const uint32_t* __restrict__ C_tid,
+                                                         const uint32_t* __restrict__ seq_genome2, uint32_t n_g2,
+                                                         int c_bits, uint64_t* __restrict__ key) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= nk) return;
+  const uint32_t c = kept_list[j];
+  const uint32_t g2 = gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]];
+  key[j] = ((uint64_t)g2 << c_bits) | pair_first[run_of_chain[c]];
+}
+__global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const uint32_t* __restrict__ sorted_kept,
+                                                            uint32_t* __restrict__ C_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
+}
+
+struct ChainTable {
+  uint64_t nc = 0;
+  uint32_t *qid = nullptr, *tid = nullptr, *qs = nullptr, *qe = nullptr, *ts = nullptr, *te = nullptr;
+  double* wid = nullptr;
+  uint8_t* ok = nullptr;  // passes span/identity filter (input of the scaffold sweep)
+};
+
+// plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
+// reference's all_chains order (their index is the plane sweep's tie-break `idx`).
+// Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).
+int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
+                              uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
+                              int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out) {
+  const uint64_t nc = T.nc;
+  hipStream_t st = ctx->stream;
+  *n_kept_out = 0;
+  if (nc == 0) return SWG_OK;
+  if ((uint64_t)n_g2 * n_g2 > (uint64_t(1) << 28))
+    return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "more than 2^14 genomes (first-two-'#' prefix) is not supported");
+  uint64_t kq, kt;
+  if (mode == SWG_MODE_ONE_TO_ONE) {
+    kq = 1;
+    kt = 1;
+  } else {
+    kq = max_q ? max_q : SWG_K_INF;
+    kt = max_t ? max_t : SWG_K_INF;
+  }
+  uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
+  uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
+  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, T.qid, T.tid, n_seq, seg));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_score_keys(ctx, nc, T.qs, T.qe, T.wid, scoring, skey));
+  swg_axis_input ax;
+  ax.n = nc;
+  ax.seg = seg;
+  ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
+  ax.pos_bits = pos_bits;
+  ax.score_key = skey;
+  ax.alive = T.ok;
+  ax.start = T.qs;
+  ax.end = T.qe;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
+  ax.alive = keep_q;
+  ax.start = T.ts;
+  ax.end = T.te;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, C_kept));
+
+  // ---- numbering -------------------------------------------------------------------------------------
+  uint64_t* seg_sorted = swg_alloc<uint64_t>(ctx, nc);
+  uint64_t* seg_tmp = swg_alloc<uint64_t>(ctx, nc);
+  uint32_t* c_sorted = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* c_tmp = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_flag = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_excl = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* gp2_first = swg_alloc<uint32_t>(ctx, (size_t)n_g2 * n_g2);
+  uint32_t* kflag = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* kpos = swg_alloc<uint32_t>(ctx, nc);
+  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
+  SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, seg_sorted, c_sorted, seg_tmp, c_tmp, nc, 0, ax.seg_bits));
+  SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, pair_first, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk((uint64_t)n_g2 * n_g2), EW, 0, st>>>((uint64_t)n_g2 * n_g2, gp2_first, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(
+                                          nc, c_sorted, run_excl, run_flag, T.ok, T.qid, T.tid, seq_genome2, n_g2,
+                                          run_of_chain, pair_first, gp2_first));
+  SWG_KERNEL_CHECK(ctx);
+  // kept chains, in index order
+  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_kept, kflag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, kflag, kpos, nc, d_tot));
+  uint64_t nk = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
+  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, nc * sizeof(uint32_t), st));
+  *n_kept_out = nk;
+  if (nk == 0) return SWG_OK;
+  uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
+  uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
+  uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
+  uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_kept, kpos, kept_list));
+  SWG_KERNEL_CHECK(ctx);
+  const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
+  SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first,
+                                                                  T.qid, T.tid, seq_genome2, n_g2, c_bits, nkey));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, nkey, kept_list, nkey_tmp, kept_tmp, nk, 0, 2 * c_bits));
+  SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, C_num));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+// ---- chains from records ------------------------------------------------------------------------------------------
+struct ChainBuild {
+  // sort A (all `alive` records)
+  uint64_t M = 0;
+  uint64_t* keyA = nullptr;
+  uint32_t* idxA = nullptr;  // original index at A position
+  uint32_t *a_qe = nullptr, *a_ts = nullptr, *a_te = nullptr, *a_dpair = nullptr;
+  uint64_t n_pairs = 0;
+  // survivors (members of chains)
+  uint64_t m = 0;
+  uint32_t* s_a = nullptr;      // A position
+  uint32_t* s_idx = nullptr;    // original index
+  uint32_t* s_chain = nullptr;  // chain (all_chains index)
+  // chains, in all_chains order
+  ChainTable T;
+  uint8_t* C_strand = nullptr;
+  uint32_t* C_dpair = nullptr;
+};
+
+// merge_mappings_into_chains (paf_filter.rs:750-933) over the records with member[i] != 0, sorted
+// together with every alive[i] != 0 record (sort A is reused by the anchor / rescue steps).
+int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
+                 uint64_t min_len, double min_ident, int pos_bits, ChainBuild* out) {
+  const uint64_t n = r->n;
+  hipStream_t st = ctx->stream;
+  ChainBuild& B = *out;
+  if ((uint64_t)r->n_genome_last * r->n_genome_last > (uint64_t(1) << 28))
+    return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "more than 2^14 genomes (last-'#' prefix) is not supported");
+  const int pair_bits = swg_bits_for((uint64_t)r->n_seq * r->n_seq * 2);
+  if (pair_bits + pos_bits > 64)
+    return swg_set_error(ctx, SWG_ERR_RANGE, "chain sort key (%d pair bits + %d coordinate bits) exceeds 64 bits",
+                         pair_bits, pos_bits);
+  // ---- compaction of alive, sort A
+  uint32_t* f32 = swg_alloc<uint32_t>(ctx, n);
+  uint32_t* fpos = swg_alloc<uint32_t>(ctx, n);
+  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 4);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n), EW, 0, st>>>(n, alive, f32));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, f32, fpos, n, d_tot));
+  uint64_t M = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
+  B.M = M;
+  if (M == 0) return SWG_OK;
+  B.keyA = swg_alloc<uint64_t>(ctx, M);
+  B.idxA = swg_alloc<uint32_t>(ctx, M);
+  uint64_t* key_tmp = swg_alloc<uint64_t>(ctx, M);
+  uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
+  B.a_qe = swg_alloc<uint32_t>(ctx, M);
+  B.a_ts = swg_alloc<uint32_t>(ctx, M);
+  B.a_te = swg_alloc<uint32_t>(ctx, M);
+  B.a_dpair = swg_alloc<uint32_t>(ctx, M);
+  uint8_t* a_keep = swg_alloc<uint8_t>(ctx, M);
+  uint32_t* pair_flag = swg_alloc<uint32_t>(ctx, M);
+  uint32_t* pair_excl = swg_alloc<uint32_t>(ctx, M);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n), EW, 0, st>>>(n, alive, fpos, B.idxA));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
+                                                              r->n_seq, pos_bits, B.keyA));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, B.keyA, B.idxA, key_tmp, idx_tmp, M, 0, pair_bits + pos_bits));
+  SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
+                                                        pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, pair_excl, M, d_tot + 1));
+  SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
+  SWG_KERNEL_CHECK(ctx);
+  // ---- survivors in A order
+  uint32_t* spos = pair_excl;  // reuse
+  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(M), EW, 0, st>>>(M, a_keep, pair_flag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, spos, M, d_tot + 2));
+  uint64_t h3[3];
+  SWG_TRY(swg_read_scalars(ctx, d_tot, h3, 3));
+  B.n_pairs = h3[1];
+  const uint64_t m = h3[2];
+  B.m = m;
+  B.T.nc = 0;
+  if (m == 0) return SWG_OK;
+  if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
+  B.s_a = swg_alloc<uint32_t>(ctx, m);
+  B.s_idx = swg_alloc<uint32_t>(ctx, m);
+  B.s_chain = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_qs = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_qe = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_ts = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_te = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_m = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_b = swg_alloc<uint32_t>(ctx, m);
+  uint64_t* s_grp = swg_alloc<uint64_t>(ctx, m);
+  uint32_t* head_flag = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* gidx_excl = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* s_gidx = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* group_begin = swg_alloc<uint32_t>(ctx, m);
+  unsigned long long* bps = swg_alloc<unsigned long long>(ctx, m);
+  uint32_t* pred = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* hd = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_qe = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_ts = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_te = swg_alloc<uint32_t>(ctx, m);
+  unsigned long long* h_sm = swg_alloc<unsigned long long>(ctx, m);
+  unsigned long long* h_sb = swg_alloc<unsigned long long>(ctx, m);
+  uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* group_first = swg_alloc<uint32_t>(ctx, m);
+  const uint64_t n_gp = (uint64_t)r->n_genome_last * r->n_genome_last;
+  uint32_t* gp_first = swg_alloc<uint32_t>(ctx, n_gp);
+  uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(M), EW, 0, st>>>(M, a_keep, spos, B.s_a));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
+                                                        r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                        B.s_idx, s_grp, head_flag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, head_flag, gidx_excl, m, d_tot + 3));
+  SWG_LAUNCH(ctx, "group_bounds", group_bounds_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, gidx_excl, s_gidx, group_begin));
+  SWG_KERNEL_CHECK(ctx);
+  uint64_t n_groups = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot + 3, &n_groups, 1));
+  // ---- best-buddy chaining
+  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(bps), ~0ull));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  {
+    const uint64_t waves_needed = n_groups;
+    uint64_t blocks = (waves_needed + 3) / 4;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks == 0) blocks = 1;
+    SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp, s_qs,
+                                                                s_qe, s_ts, s_te, max_gap, bps, pred));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  // ---- labelling by pointer jumping
+  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<nblk(m), EW, 0, st>>>(m, pred, hd));
+  SWG_KERNEL_CHECK(ctx);
+  for (int round = 0; round < 64; ++round) {
+    SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
+    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t ch = 0;
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
+    if ((uint32_t)ch == 0) break;
+  }
+  // ---- aggregates
+  SWG_HIP(ctx, hipMemsetAsync(h_qe, 0, m * 4, st));
+  SWG_HIP(ctx, hipMemsetAsync(h_te, 0, m * 4, st));
+  SWG_HIP(ctx, hipMemsetAsync(h_ts, 0xff, m * 4, st));
+  SWG_HIP(ctx, hipMemsetAsync(h_sm, 0, m * 8, st));
+  SWG_HIP(ctx, hipMemsetAsync(h_sb, 0, m * 8, st));
+  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
+                                                                        h_sm, h_sb, is_head));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
+  uint64_t nc = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
+  // ---- all_chains order
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, group_first, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_gp), EW, 0, st>>>(n_gp, gp_first, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "group_first", group_first_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, B.s_idx, group_first));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->seq_genome_last,
+                                                                            r->n_genome_last, gp_first));
+  SWG_KERNEL_CHECK(ctx);
+  uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
+  uint64_t* ch_key = swg_alloc<uint64_t>(ctx, nc);
+  uint64_t* ch_key_tmp = swg_alloc<uint64_t>(ctx, nc);
+  uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* order_tmp = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
+  ChainTable& T = B.T;
+  T.nc = nc;
+  T.qid = swg_alloc<uint32_t>(ctx, nc);
+  T.tid = swg_alloc<uint32_t>(ctx, nc);
+  T.qs = swg_alloc<uint32_t>(ctx, nc);
+  T.qe = swg_alloc<uint32_t>(ctx, nc);
+  T.ts = swg_alloc<uint32_t>(ctx, nc);
+  T.te = swg_alloc<uint32_t>(ctx, nc);
+  T.wid = swg_alloc<double>(ctx, nc);
+  T.ok = swg_alloc<uint8_t>(ctx, nc);
+  B.C_strand = swg_alloc<uint8_t>(ctx, nc);
+  B.C_dpair = swg_alloc<uint32_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
+  SWG_LAUNCH(ctx, "chain_list", chain_list_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, B.s_idx, group_first, r->q_id,
+                                                              r->t_id, r->seq_genome_last, r->n_genome_last, gp_first,
+                                                              idx_bits, ch_head, ch_key));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, order));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, ch_key, order, ch_key_tmp, order_tmp, nc, 0, 2 * idx_bits));
+  SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
+                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
+                                       r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
+                                       B.C_strand, B.C_dpair, T.ok, rank_of));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, cpos, rank_of, B.s_chain));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+// ---- anchors, inversions, rescue -------------------------------------------------------------------------------------
+// anchor_num[i] = chain number of the kept chain record i belongs to (0 = not an anchor);
+// in_filtered[i] = 1 iff i is a member of a span/identity-filtered chain (pre_sweep_scaffold_members)
+__global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint32_t* __restrict__ s_idx,
+                                                          const uint32_t* __restrict__ s_chain,
+                                                          const uint8_t* __restrict__ C_ok,
+                                                          const uint32_t* __restrict__ C_num,
+                                                          uint32_t* __restrict__ anchor_num,
+                                                          uint8_t* __restrict__ in_filtered) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t c = s_chain[p], i = s_idx[p];
+  anchor_num[i] = C_num[c];
+  in_filtered[i] = C_ok[c];
+}
+
+// kept '+' chains per dense chromosome pair (CSR)
+__global__ __launch_bounds__(EW) void fwd_count_kernel(uint64_t nc, const uint32_t* __restrict__ C_num,
+                                                       const uint8_t* __restrict__ C_strand,
+                                                       const uint32_t* __restrict__ C_dpair,
+                                                       uint32_t* __restrict__ cnt) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c < nc && C_num[c] && C_strand[c] == 0) atomicAdd(&cnt[C_dpair[c]], 1u);
+}
+__global__ __launch_bounds__(EW) void fwd_fill_kernel(uint64_t nc, const uint32_t* __restrict__ C_num,
+                                                      const uint8_t* __restrict__ C_strand,
+                                                      const uint32_t* __restrict__ C_dpair,
+                                                      const uint32_t* __restrict__ off, uint32_t* __restrict__ cur,
+                                                      uint32_t* __restrict__ list) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c < nc && C_num[c] && C_strand[c] == 0) {
+    const uint32_t dp = C_dpair[c];
+    list[off[dp] + atomicAdd(&cur[dp], 1u)] = (uint32_t)c;
+  }
+}
+// paf_filter.rs:535-597: a '-' record joins the first (lowest-numbered) kept '+' chain of its pair whose
+// diagonal it sits on.
+__global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
+                                                       const uint32_t* __restrict__ idxA,
+                                                       const uint32_t* __restrict__ a_qe,
+                                                       const uint32_t* __restrict__ a_ts,
+                                                       const uint32_t* __restrict__ a_te,
+                                                       const uint32_t* __restrict__ a_dpair, int pos_bits,
+                                                       const uint32_t* __restrict__ off,
+                                                       const uint32_t* __restrict__ list,
+                                                       const uint32_t* __restrict__ C_qs,
+                                                       const uint32_t* __restrict__ C_qe,
+                                                       const uint32_t* __restrict__ C_ts,
+                                                       const uint32_t* __restrict__ C_num, uint64_t gap,
+                                                       uint32_t* anchor_num) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint64_t k = keyA[a];
+  if (((k >> pos_bits) & 1ull) == 0) return;  // only '-' records
+  const uint32_t i = idxA[a];
+  if (anchor_num[i]) return;
+  const uint32_t dp = a_dpair[a];
+  const uint32_t lb = off[dp], le = off[dp + 1];
+  if (lb == le) return;
+  const uint64_t qs = k & ((uint64_t(1) << pos_bits) - 1), qe = a_qe[a], ts = a_ts[a], te = a_te[a];
+  const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
+  uint32_t best = 0;
+  for (uint32_t s = lb; s < le; ++s) {
+    const uint32_t c = list[s];
+    const uint64_t cqs = C_qs[c], cqe = C_qe[c];
+    const uint64_t ext_start = cqs > gap ? cqs - gap : 0;                            // saturating_sub
+    const uint64_t ext_end = cqe > ~0ull - gap ? ~0ull : cqe + gap;                  // saturating_add
+    if (qe < ext_start || qs > ext_end) continue;
+    const int64_t diag = (int64_t)C_ts[c] - (int64_t)cqs;
+    const int64_t dev = (int64_t)tc - (int64_t)qc - diag;
+    const uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;
+    const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
+    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
+    if (perp <= gap) {
+      const uint32_t num = C_num[c];
+      if (best == 0 || num < best) best = num;
+    }
+  }
+  if (best) anchor_num[i] = best;
+}
+
+// anchors in A order -> keys (dense pair, query centre) for sort B
+__global__ __launch_bounds__(EW) void anchor_flag_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
+                                                         const uint32_t* __restrict__ anchor_num,
+                                                         uint8_t* __restrict__ flag) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a < M) flag[a] = anchor_num[idxA[a]] ? 1 : 0;
+}
+__global__ __launch_bounds__(EW) void anchor_keys_kernel(uint64_t na, const uint32_t* __restrict__ anchor_a,
+                                                         const uint64_t* __restrict__ keyA,
+                                                         const uint32_t* __restrict__ a_qe,
+                                                         const uint32_t* __restrict__ a_dpair, int pos_bits,
+                                                         uint64_t* __restrict__ key) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= na) return;
+  const uint32_t a = anchor_a[j];
+  const uint64_t qs = keyA[a] & ((uint64_t(1) << pos_bits) - 1);
+  const uint64_t qc = (qs + (uint64_t)a_qe[a]) / 2;
+  key[j] = ((uint64_t)a_dpair[a] << pos_bits) | qc;
+}
+__global__ __launch_bounds__(EW) void anchor_cols_kernel(uint64_t na, const uint32_t* __restrict__ sorted_a,
+                                                         const uint32_t* __restrict__ idxA,
+                                                         const uint32_t* __restrict__ a_ts,
+                                                         const uint32_t* __restrict__ a_te,
+                                                         const uint32_t* __restrict__ anchor_num,
+                                                         uint32_t* __restrict__ b_tc, uint32_t* __restrict__ b_idx,
+                                                         uint32_t* __restrict__ b_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= na) return;
+  const uint32_t a = sorted_a[j];
+  const uint32_t i = idxA[a];
+  b_tc[j] = (uint32_t)(((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2);
+  b_idx[j] = i;
+  b_num[j] = anchor_num[i];
+}
+
+// paf_filter.rs:656-732 per record.  Rescued records take the chain of the lowest-index anchor in range
+// (the reference iterates a HashSet here; ascending input order is the instance the oracle fixes).
+__global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
+                                                    const uint32_t* __restrict__ idxA,
+                                                    const uint32_t* __restrict__ a_qe,
+                                                    const uint32_t* __restrict__ a_ts,
+                                                    const uint32_t* __restrict__ a_te,
+                                                    const uint32_t* __restrict__ a_dpair, int pos_bits,
+                                                    const uint32_t* __restrict__ anchor_num,
+                                                    const uint8_t* __restrict__ in_filtered, uint64_t na,
+                                                    const uint64_t* __restrict__ b_key,
+                                                    const uint32_t* __restrict__ b_tc,
+                                                    const uint32_t* __restrict__ b_idx,
+                                                    const uint32_t* __restrict__ b_num, uint64_t D,
+                                                    uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint32_t i = idxA[a];
+  const uint32_t an = anchor_num[i];
+  if (an) {
+    status[i] = SWG_ST_SCAFFOLD;
+    chain[i] = an;
+    return;
+  }
+  if (in_filtered[i] || D == 0 || na == 0) return;  // status stays DROPPED
+  const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
+  const uint64_t qs = keyA[a] & posmask;
+  const uint64_t qc = (qs + (uint64_t)a_qe[a]) / 2, tc = ((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2;
+  const uint64_t hi_part = (uint64_t)a_dpair[a] << pos_bits;
+  const uint64_t lo = hi_part | (qc > D ? qc - D : 0);
+  const uint64_t hi_q = qc + D < qc ? ~0ull : qc + D;
+  const uint64_t hi = hi_part | (hi_q > posmask ? posmask : hi_q);
+  // lower_bound(b_key, lo)
+  uint64_t l = 0, r = na;
+  while (l < r) {
+    const uint64_t mid = (l + r) >> 1;
+    if (b_key[mid] < lo)
+      l = mid + 1;
+    else
+      r = mid;
+  }
+  uint32_t best_idx = NONE, best_num = 0;
+  for (uint64_t j = l; j < na; ++j) {
+    const uint64_t bk = b_key[j];
+    if (bk > hi) break;
+    const uint64_t aq = bk & posmask;
+    const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+    if (q_diff > D) continue;
+    const uint64_t at = b_tc[j];
+    const uint64_t t_diff = tc > at ? tc - at : at - tc;
+    const double dd = __dsqrt_rn((double)(q_diff * q_diff + t_diff * t_diff));
+    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
+    if (dist <= D && b_idx[j] < best_idx) {
+      best_idx = b_idx[j];
+      best_num = b_num[j];
+    }
+  }
+  if (best_idx != NONE) {
+    status[i] = SWG_ST_RESCUED;
+    chain[i] = best_num;
+  }
+}
+
+__global__ __launch_bounds__(EW) void scaffolds_only_kernel(uint64_t n, const uint32_t* __restrict__ anchor_num,
+                                                            uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t an = anchor_num[i];
+  status[i] = an ? SWG_ST_SCAFFOLD : SWG_ST_DROPPED;
+  chain[i] = an;
+}
+
+__global__ __launch_bounds__(EW) void count_status_kernel(uint64_t n, const uint8_t* __restrict__ status,
+                                                          unsigned long long* __restrict__ out) {
+  uint32_t cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW) cnt += status[i] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, (unsigned long long)cnt);
+}
+
+}  // namespace
+
+int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
+                       const uint8_t* keep1, const uint64_t* score_key, int pos_bits, uint8_t* status_out,
+                       uint32_t* chain_out, swg_stats* stats) {
+  (void)score_key;
+  const uint64_t n = r->n;
+  hipStream_t st = ctx->stream;
+  SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+  SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, n * sizeof(uint32_t), st));
+  ChainBuild B;
+  SWG_TRY(build_chains(ctx, r, alive, keep1, cfg->scaffold_gap, cfg->min_scaffold_length, cfg->min_scaffold_identity,
+                       pos_bits, &B));
+  if (stats) {
+    stats->n_swept = B.m;
+    stats->n_chains = B.T.nc;
+  }
+  if (B.M == 0 || B.m == 0 || B.T.nc == 0) return SWG_OK;  // nothing can be an anchor: everything is dropped
+  const uint64_t nc = B.T.nc, M = B.M, m = B.m;
+  uint8_t* C_kept = swg_alloc<uint8_t>(ctx, nc);
+  uint32_t* C_num = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* anchor_num = swg_alloc<uint32_t>(ctx, n);
+  uint8_t* in_filtered = swg_alloc<uint8_t>(ctx, n);
+  unsigned long long* d_cnt = swg_alloc<unsigned long long>(ctx, 2);
+  SWG_CHECK_ARENA(ctx);
+  uint64_t n_kept = 0;
+  SWG_TRY(scaffold_sweep_and_number(ctx, B.T, r->n_seq, r->seq_genome_two, r->n_genome_two, cfg->scaffold_filter_mode,
+                                    cfg->scaffold_max_per_query, cfg->scaffold_max_per_target,
+                                    cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, C_kept, C_num,
+                                    &n_kept));
+  if (stats) stats->n_chains_kept = n_kept;
+  SWG_HIP(ctx, hipMemsetAsync(anchor_num, 0, n * sizeof(uint32_t), st));
+  SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
+  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.s_chain, B.T.ok, C_num, anchor_num, in_filtered));
+  SWG_KERNEL_CHECK(ctx);
+
+  auto finish_counts = [&]() -> int {
+    if (!stats) return SWG_OK;
+    SWG_HIP(ctx, hipMemsetAsync(d_cnt, 0, 16, st));
+    SWG_LAUNCH(ctx, "count_status", count_status_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, status_out, d_cnt));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t c = 0;
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(d_cnt), &c, 1));
+    stats->n_out = c;
+    return SWG_OK;
+  };
+
+  if (cfg->scaffolds_only) {  // paf_filter.rs:486-513
+    SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
+    SWG_KERNEL_CHECK(ctx);
+    return finish_counts();
+  }
+  if (n_kept == 0) return finish_counts();  // no anchors anywhere: every pair is skipped (paf_filter.rs:658-660)
+
+  // ---- inversion capture
+  {
+    const uint64_t np = B.n_pairs;
+    uint32_t* cnt = swg_alloc<uint32_t>(ctx, np + 1);
+    uint32_t* cur = swg_alloc<uint32_t>(ctx, np + 1);
+    uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(cnt, 0, (np + 1) * 4, st));
+    SWG_HIP(ctx, hipMemsetAsync(cur, 0, (np + 1) * 4, st));
+    SWG_LAUNCH(ctx, "fwd_count", fwd_count_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, B.C_dpair, cnt));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, cnt, cnt, np + 1, d_tot));
+    uint64_t nf = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_tot, &nf, 1));
+    if (nf) {
+      uint32_t* list = swg_alloc<uint32_t>(ctx, nf);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "fwd_fill", fwd_fill_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, B.C_dpair, cnt, cur, list));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "inversion", inversion_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits,
+                                                                cnt, list, B.T.qs, B.T.qe, B.T.ts, C_num, cfg->scaffold_gap,
+                                                                anchor_num));
+      SWG_KERNEL_CHECK(ctx);
+    }
+  }
+  // ---- rescue
+  {
+    uint8_t* aflag = swg_alloc<uint8_t>(ctx, M);
+    uint32_t* aflag32 = swg_alloc<uint32_t>(ctx, M);
+    uint32_t* apos = swg_alloc<uint32_t>(ctx, M);
+    uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "anchor_flag", anchor_flag_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, anchor_num, aflag));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(M), EW, 0, st>>>(M, aflag, aflag32));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, aflag32, apos, M, d_tot));
+    uint64_t na = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_tot, &na, 1));
+    uint32_t* anchor_a = swg_alloc<uint32_t>(ctx, na + 1);
+    uint32_t* anchor_tmp = swg_alloc<uint32_t>(ctx, na + 1);
+    uint64_t* b_key = swg_alloc<uint64_t>(ctx, na + 1);
+    uint64_t* b_key_tmp = swg_alloc<uint64_t>(ctx, na + 1);
+    uint32_t* b_tc = swg_alloc<uint32_t>(ctx, na + 1);
+    uint32_t* b_idx = swg_alloc<uint32_t>(ctx, na + 1);
+    uint32_t* b_num = swg_alloc<uint32_t>(ctx, na + 1);
+    SWG_CHECK_ARENA(ctx);
+    if (na) {
+      SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(M), EW, 0, st>>>(M, aflag, apos, anchor_a));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "anchor_keys", anchor_keys_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.keyA, B.a_qe, B.a_dpair, pos_bits, b_key));
+      SWG_KERNEL_CHECK(ctx);
+      const int dp_bits = swg_bits_for(B.n_pairs) ? swg_bits_for(B.n_pairs) : 1;
+      if (dp_bits + pos_bits > 64) return swg_set_error(ctx, SWG_ERR_RANGE, "anchor sort key exceeds 64 bits");
+      SWG_TRY(swg_radix_sort_pairs(ctx, b_key, anchor_a, b_key_tmp, anchor_tmp, na, 0, dp_bits + pos_bits));
+      SWG_LAUNCH(ctx, "anchor_cols", anchor_cols_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.idxA, B.a_ts, B.a_te, anchor_num, b_tc, b_idx,
+                                                                     b_num));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, anchor_num,
+                                                        in_filtered, na, b_key, b_tc, b_idx, b_num,
+                                                        cfg->scaffold_max_deviation, status_out, chain_out));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  return finish_counts();
+}
+
+// ---- public seams -----------------------------------------------------------------------------------------------------
+extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_t* q_id, const uint32_t* t_id,
+                                         uint32_t n_seq, const uint32_t* seq_genome_two, uint32_t n_genome_two,
+                                         const uint64_t* q_start, const uint64_t* q_end, const uint64_t* t_start,
+                                         const uint64_t* t_end, const double* identity, int mode,
+                                         uint64_t max_per_query, uint64_t max_per_target, double thr, int scoring,
+                                         uint64_t* order_out, uint64_t* n_kept) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (n_kept) *n_kept = 0;
+  if (n == 0) return SWG_OK;
+  if (!q_id || !t_id || !seq_genome_two || !q_start || !q_end || !t_start || !t_end || !identity || !order_out ||
+      !n_kept)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  if (mode < 0 || mode > 2 || scoring < 0 || scoring > 4 || n_seq == 0 || n_genome_two == 0)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "bad mode / scoring / table size");
+  if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chains");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> h(4 * n);
+  uint32_t mx = 0;
+  const uint64_t* src[4] = {q_start, q_end, t_start, t_end};
+  for (int c = 0; c < 4; ++c)
+    for (uint64_t i = 0; i < n; ++i) {
+      if (src[c][i] > 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "coordinate >= 2^32");
+      h[c * n + i] = (uint32_t)src[c][i];
+      if (h[c * n + i] > mx) mx = h[c * n + i];
+    }
+  for (uint64_t i = 0; i < n; ++i)
+    if (q_id[i] >= n_seq || t_id[i] >= n_seq) return swg_set_error(ctx, SWG_ERR_INVALID, "sequence id out of range");
+  const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
+  hipStream_t st = ctx->stream;
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 400 + (size_t(16) << 20)));
+  std::vector<uint32_t> num(n);
+  int rc = swg_run_with_arena(ctx, [&]() -> int {
+    ChainTable T;
+    T.nc = n;
+    uint32_t* d_c = swg_alloc<uint32_t>(ctx, 4 * n);
+    T.qid = swg_alloc<uint32_t>(ctx, n);
+    T.tid = swg_alloc<uint32_t>(ctx, n);
+    T.wid = swg_alloc<double>(ctx, n);
+    T.ok = swg_alloc<uint8_t>(ctx, n);
+    uint32_t* d_g2 = swg_alloc<uint32_t>(ctx, n_seq);
+    uint8_t* C_kept = swg_alloc<uint8_t>(ctx, n);
+    uint32_t* C_num = swg_alloc<uint32_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    T.qs = d_c;
+    T.qe = d_c + n;
+    T.ts = d_c + 2 * n;
+    T.te = d_c + 3 * n;
+    SWG_HIP(ctx, hipMemcpyAsync(d_c, h.data(), 4 * n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.qid, q_id, n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.tid, t_id, n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.wid, identity, n * 8, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(d_g2, seq_genome_two, (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemsetAsync(T.ok, 1, n, st));
+    uint64_t nk = 0;
+    SWG_TRY(scaffold_sweep_and_number(ctx, T, n_seq, d_g2, n_genome_two, mode, max_per_query, max_per_target, thr,
+                                      scoring, pos_bits, C_kept, C_num, &nk));
+    SWG_HIP(ctx, hipMemcpyAsync(num.data(), C_num, n * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipStreamSynchronize(st));
+    *n_kept = nk;
+    return SWG_OK;
+  });
+  if (rc != SWG_OK) return rc;
+  for (uint64_t i = 0; i < n; ++i)
+    if (num[i]) order_out[num[i] - 1] = i;
+  return SWG_OK;
+}
+
+extern "C" int swg_merge_chains(swg_ctx* ctx, const swg_records* rec, uint64_t max_gap, uint32_t* chain_of,
+                                uint32_t* c_q_start, uint32_t* c_q_end, uint32_t* c_t_start, uint32_t* c_t_end,
+                                double* c_weighted_identity, uint64_t* n_chains) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (!rec || !n_chains) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL argument");
+  *n_chains = 0;
+  const uint64_t n = rec->n;
+  if (n == 0) return SWG_OK;
+  if (!chain_of || !c_q_start || !c_q_end || !c_t_start || !c_t_end || !c_weighted_identity)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "NULL output");
+  if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many records");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 400 + (size_t(16) << 20)));
+  uint32_t mx = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t v[4] = {rec->q_start[i], rec->q_end[i], rec->t_start[i], rec->t_end[i]};
+    for (uint32_t x : v)
+      if (x > mx) mx = x;
+  }
+  const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
+  return swg_run_with_arena(ctx, [&]() -> int {
+    swg_records d = *rec;
+    auto up32 = [&](const uint32_t* src, uint64_t cnt) -> uint32_t* {
+      uint32_t* p = swg_alloc<uint32_t>(ctx, cnt);
+      if (p) (void)hipMemcpyAsync(p, src, cnt * 4, hipMemcpyHostToDevice, st);
+      return p;
+    };
+    d.q_id = up32(rec->q_id, n);
+    d.t_id = up32(rec->t_id, n);
+    d.q_start = up32(rec->q_start, n);
+    d.q_end = up32(rec->q_end, n);
+    d.t_start = up32(rec->t_start, n);
+    d.t_end = up32(rec->t_end, n);
+    d.matches = up32(rec->matches, n);
+    d.block_len = up32(rec->block_len, n);
+    d.seq_genome_last = up32(rec->seq_genome_last, rec->n_seq);
+    d.seq_genome_two = up32(rec->seq_genome_two, rec->n_seq);
+    uint8_t* d_strand = swg_alloc<uint8_t>(ctx, n);
+    uint8_t* ones = swg_alloc<uint8_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemcpyAsync(d_strand, rec->strand, n, hipMemcpyHostToDevice, st));
+    d.strand = d_strand;
+    d.identity = nullptr;
+    SWG_HIP(ctx, hipMemsetAsync(ones, 1, n, st));
+    ChainBuild B;
+    SWG_TRY(build_chains(ctx, &d, ones, ones, max_gap, 0, 0.0, pos_bits, &B));
+    const uint64_t nc = B.T.nc;
+    // chain_of[original index] via the survivor list (every record is a survivor here)
+    std::vector<uint32_t> s_idx(B.m), s_chain(B.m);
+    SWG_HIP(ctx, hipMemcpyAsync(s_idx.data(), B.s_idx, B.m * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(s_chain.data(), B.s_chain, B.m * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(c_q_start, B.T.qs, nc * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(c_q_end, B.T.qe, nc * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(c_t_start, B.T.ts, nc * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(c_t_end, B.T.te, nc * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipMemcpyAsync(c_weighted_identity, B.T.wid, nc * 8, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipStreamSynchronize(st));
+    for (uint64_t p = 0; p < B.m; ++p) chain_of[s_idx[p]] = s_chain[p];
+    *n_chains = nc;
+    return SWG_OK;
+  });
+}
+
+// Connected components standing in for UnionFind::get_sets (src/union_find.rs:52-63).  Sets are returned in
+// ascending order of their smallest member, members ascending -- identical to the reference's root order
+// whenever every union(x, y) joins a fresh singleton y > x to x's set (how the filter uses it,
+// paf_filter.rs:854-859); for arbitrary union orders the reference's order depends on union-by-rank history.
+namespace {
+__global__ __launch_bounds__(EW) void cc_hook_kernel(uint64_t m, const uint32_t* __restrict__ xs,
+                                                     const uint32_t* __restrict__ ys, uint32_t* label,
+                                                     uint32_t* __restrict__ changed) {
+  uint64_t e = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (e >= m) return;
+  const uint32_t lx = label[xs[e]], ly = label[ys[e]];
+  if (lx == ly) return;
+  const uint32_t lo = lx < ly ? lx : ly, hi = lx < ly ? ly : lx;
+  atomicMin(&label[hi], lo);
+  *changed = 1;
+}
+__global__ __launch_bounds__(EW) void cc_compress_kernel(uint64_t n, uint32_t* label, uint32_t* __restrict__ changed) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  uint32_t l = label[i];
+  uint32_t ll = label[l];
+  if (ll != l) {
+    label[i] = ll;
+    *changed = 1;
+  }
+}
+__global__ __launch_bounds__(EW) void cc_root_flag_kernel(uint64_t n, const uint32_t* __restrict__ label,
+                                                          uint32_t* __restrict__ flag) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) flag[i] = label[i] == i ? 1u : 0u;
+}
+__global__ __launch_bounds__(EW) void cc_set_of_kernel(uint64_t n, const uint32_t* __restrict__ label,
+                                                       const uint32_t* __restrict__ root_excl,
+                                                       uint32_t* __restrict__ set_of) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) set_of[i] = root_excl[label[i]];
+}
+}  // namespace
+
+extern "C" int swg_union_find_sets(swg_ctx* ctx, uint64_t n, uint64_t m, const uint32_t* xs, const uint32_t* ys,
+                                   uint32_t* set_of, uint64_t* n_sets) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (!n_sets) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL argument");
+  *n_sets = 0;
+  if (n == 0) return SWG_OK;
+  if (!set_of || (m && (!xs || !ys))) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many elements");
+  for (uint64_t e = 0; e < m; ++e)
+    if (xs[e] >= n || ys[e] >= n) return swg_set_error(ctx, SWG_ERR_INVALID, "element out of range");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)(n + m) * 32 + (size_t(8) << 20)));
+  return swg_run_with_arena(ctx, [&]() -> int {
+    uint32_t* label = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* flag = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* excl = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* d_set = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* dx = swg_alloc<uint32_t>(ctx, m + 1);
+    uint32_t* dy = swg_alloc<uint32_t>(ctx, m + 1);
+    uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
+    uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    if (m) {
+      SWG_HIP(ctx, hipMemcpyAsync(dx, xs, m * 4, hipMemcpyHostToDevice, st));
+      SWG_HIP(ctx, hipMemcpyAsync(dy, ys, m * 4, hipMemcpyHostToDevice, st));
+    }
+    SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(n), EW, 0, st>>>(n, label));
+    SWG_KERNEL_CHECK(ctx);
+    for (int round = 0; round < 100000 && m; ++round) {
+      SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
+      SWG_LAUNCH(ctx, "cc_hook", cc_hook_kernel<<<nblk(m), EW, 0, st>>>(m, dx, dy, label, changed));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "cc_compress", cc_compress_kernel<<<nblk(n), EW, 0, st>>>(n, label, changed));
+      SWG_KERNEL_CHECK(ctx);
+      uint64_t ch = 0;
+      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
+      if ((uint32_t)ch == 0) break;
+    }
+    SWG_LAUNCH(ctx, "cc_root_flag", cc_root_flag_kernel<<<nblk(n), EW, 0, st>>>(n, label, flag));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, flag, excl, n, d_tot));
+    SWG_LAUNCH(ctx, "cc_set_of", cc_set_of_kernel<<<nblk(n), EW, 0, st>>>(n, label, excl, d_set));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t ns = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_tot, &ns, 1));
+    SWG_HIP(ctx, hipMemcpyAsync(set_of, d_set, n * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipStreamSynchronize(st));
+    *n_sets = ns;
+    return SWG_OK;
+  });
 }

@@ -409,3 +409,78 @@ class PafFilter:
         metadata = self.extract_metadata(input_path)
         passing = self.apply_filters(metadata)
         self.write_filtered_output(input_path, output_path, passing)
+
+
+def plane_sweep_scaffolds(chains, filter_mode, max_per_query, max_per_target, overlap_threshold,
+                          scoring_function=ScoringFunction.LogLengthIdentity, ctx=None) -> List[int]:
+    """src/plane_sweep_scaffold.rs:47-94.  chains: objects/tuples exposing the ScaffoldLike accessors
+    (query_name, target_name, query_start, query_end, target_start, target_end, identity).
+    Returns the kept indices in the reference's output order."""
+    ctx = ctx or default_context()
+    n = len(chains)
+    if n == 0:
+        return []
+
+    def get(c, k, pos):
+        return getattr(c, k) if hasattr(c, k) else c[pos]
+
+    idx = SequenceIndex()
+    q_id = np.fromiter((idx.get_or_insert(get(c, "query_name", 0)) for c in chains), dtype=np.uint32, count=n)
+    t_id = np.fromiter((idx.get_or_insert(get(c, "target_name", 1)) for c in chains), dtype=np.uint32, count=n)
+    _, _, two, n_two = idx.genome_tables()
+    qs = _u64([get(c, "query_start", 2) for c in chains])
+    qe = _u64([get(c, "query_end", 3) for c in chains])
+    ts = _u64([get(c, "target_start", 4) for c in chains])
+    te = _u64([get(c, "target_end", 5) for c in chains])
+    ident = np.ascontiguousarray(np.asarray([get(c, "identity", 6) for c in chains], dtype=np.float64))
+    order = np.zeros(n, dtype=np.uint64)
+    nk = C.c_uint64(0)
+    ctx.check(ctx.lib.swg_plane_sweep_scaffolds(ctx.handle, n, _ptr(q_id), _ptr(t_id), len(idx), _ptr(two), n_two,
+                                                _ptr(qs), _ptr(qe), _ptr(ts), _ptr(te), _ptr(ident), int(filter_mode),
+                                                max_per_query or 0, max_per_target or 0, float(overlap_threshold),
+                                                int(scoring_function), _ptr(order), C.byref(nk)))
+    return [int(x) for x in order[: nk.value]]
+
+
+def merge_mappings_into_chains(metadata: List[RecordMeta], max_gap: int, ctx=None):
+    """src/paf_filter.rs:750-933 -> (chain_of[n] in all_chains order, dict of per-chain columns)."""
+    ctx = ctx or default_context()
+    packed = pack_records(metadata)
+    n = packed.n
+    chain_of = np.zeros(max(n, 1), dtype=np.uint32)
+    cols = [np.zeros(max(n, 1), dtype=np.uint32) for _ in range(4)]
+    wid = np.zeros(max(n, 1), dtype=np.float64)
+    nc = C.c_uint64(0)
+    rec = packed.to_c()
+    ctx.check(ctx.lib.swg_merge_chains(ctx.handle, C.byref(rec), int(max_gap), _ptr(chain_of), _ptr(cols[0]),
+                                       _ptr(cols[1]), _ptr(cols[2]), _ptr(cols[3]), _ptr(wid), C.byref(nc)))
+    k = nc.value
+    return chain_of[:n], dict(query_start=cols[0][:k], query_end=cols[1][:k], target_start=cols[2][:k],
+                              target_end=cols[3][:k], weighted_identity=wid[:k])
+
+
+class UnionFind:
+    """src/union_find.rs over the device: unions are recorded and get_sets() labels connected components on
+    the GPU.  Sets come back ordered by their smallest member (== the reference's root order for the union
+    sequences the filter produces; see include/sweepga_gpu.h)."""
+
+    def __init__(self, n, ctx=None):
+        self.n = n
+        self.edges = []
+        self._ctx = ctx
+
+    def union(self, x, y):
+        self.edges.append((x, y))
+
+    def get_sets(self):
+        ctx = self._ctx or default_context()
+        xs = np.ascontiguousarray(np.asarray([e[0] for e in self.edges], dtype=np.uint32))
+        ys = np.ascontiguousarray(np.asarray([e[1] for e in self.edges], dtype=np.uint32))
+        set_of = np.zeros(max(self.n, 1), dtype=np.uint32)
+        ns = C.c_uint64(0)
+        ctx.check(ctx.lib.swg_union_find_sets(ctx.handle, self.n, len(self.edges), _ptr(xs), _ptr(ys), _ptr(set_of),
+                                              C.byref(ns)))
+        sets = [[] for _ in range(ns.value)]
+        for i in range(self.n):
+            sets[int(set_of[i])].append(i)
+        return sets
