@@ -322,8 +322,12 @@ __global__ __launch_bounds__(EW) void chain_list_kernel(uint64_t m, const uint32
   const uint32_t c = cpos_excl[p];
   ch_head[c] = (uint32_t)p;
   const uint32_t i = s_idx[p];
-  const uint32_t L = seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]];
-  ch_key[c] = ((uint64_t)gp_first[L] << idx_bits) | group_first[s_gidx[p]];
+  // gp_first == nullptr: groups in plain first-appearance order of the records as given
+  // (merge_mappings_into_chains called on its own); otherwise genome-pair-major, which is the order
+  // apply_plane_sweep_to_mappings leaves the metadata in (paf_filter.rs:1037-1046, 1117-1120).
+  uint64_t hi = 0;
+  if (gp_first) hi = gp_first[seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]]];
+  ch_key[c] = (hi << idx_bits) | group_first[s_gidx[p]];
 }
 
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
@@ -556,7 +560,7 @@ struct ChainBuild {
 // merge_mappings_into_chains (paf_filter.rs:750-933) over the records with member[i] != 0, sorted
 // together with every alive[i] != 0 record (sort A is reused by the anchor / rescue steps).
 int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                 uint64_t min_len, double min_ident, int pos_bits, ChainBuild* out) {
+                 uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   ChainBuild& B = *out;
@@ -726,8 +730,9 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_CHECK_ARENA(ctx);
   const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
   SWG_LAUNCH(ctx, "chain_list", chain_list_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, B.s_idx, group_first, r->q_id,
-                                                              r->t_id, r->seq_genome_last, r->n_genome_last, gp_first,
-                                                              idx_bits, ch_head, ch_key));
+                                                              r->t_id, r->seq_genome_last, r->n_genome_last,
+                                                              genome_pair_major ? gp_first : nullptr, idx_bits, ch_head,
+                                                              ch_key));
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, order));
   SWG_KERNEL_CHECK(ctx);
@@ -951,7 +956,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, n * sizeof(uint32_t), st));
   ChainBuild B;
   SWG_TRY(build_chains(ctx, r, alive, keep1, cfg->scaffold_gap, cfg->min_scaffold_length, cfg->min_scaffold_identity,
-                       pos_bits, &B));
+                       pos_bits, true, &B));
   if (stats) {
     stats->n_swept = B.m;
     stats->n_chains = B.T.nc;
@@ -1174,7 +1179,7 @@ extern "C" int swg_merge_chains(swg_ctx* ctx, const swg_records* rec, uint64_t m
     d.identity = nullptr;
     SWG_HIP(ctx, hipMemsetAsync(ones, 1, n, st));
     ChainBuild B;
-    SWG_TRY(build_chains(ctx, &d, ones, ones, max_gap, 0, 0.0, pos_bits, &B));
+    SWG_TRY(build_chains(ctx, &d, ones, ones, max_gap, 0, 0.0, pos_bits, false, &B));
     const uint64_t nc = B.T.nc;
     // chain_of[original index] via the survivor list (every record is a survivor here)
     std::vector<uint32_t> s_idx(B.m), s_chain(B.m);
