@@ -116,9 +116,11 @@ int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint
 // Inclusive running maximum of n u32 values (in place allowed).
 int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n);
 // Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
-// Result is left in keys_a/vals_a; keys_b/vals_b are scratch of the same size.
-int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
-                         uint32_t* vals_b, uint64_t n, int begin_bit, int end_bit);
+// *keys / *vals hold the input; the *_alt buffers are scratch of the same size.  Passes ping-pong
+// between the two pairs of buffers and the POINTERS are swapped so that on return *keys / *vals
+// address the sorted data (no copy-back pass).
+int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
+                         uint64_t n, int begin_bit, int end_bit);
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
 

@@ -144,9 +144,20 @@ __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint
 // ---- best-buddy chaining (paf_filter.rs:784-851) -----------------------------------------------------------
 // One wavefront per (q, t, strand) group.  The outer loop over i is the reference's sequential greedy
 // (later i read best_pred_score[] written by earlier i); the inner loop over j runs on the 64 lanes.
-// best_pred_score lives in global memory: the single writer and all readers are lanes of this wavefront;
-// accesses are agent-scope atomics (served by the XCD's L2, never a stale L1 line) and each step's store is
-// drained (workgroup-scope release = s_waitcnt vmcnt(0)) before the next step's loads are issued.
+// The next 128 elements after the block start live in registers (two 64-element blocks, one element per
+// lane and block, including their best_pred_score), so a step is: read lane i's row with v_readlane,
+// evaluate the two blocks, wave-min, update one lane's register.  Only windows reaching past those 128
+// elements touch memory: their best_pred_score entries are read/written in global memory with agent-scope
+// atomics (served by the XCD's L2, never a stale L1 line), the store drained before the next step.
+struct ChainBlock {
+  uint32_t qs, qe, ts, te;
+  uint64_t bps;
+};
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
 __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
                                                     uint32_t m, const uint64_t* __restrict__ s_grp,
                                                     const uint32_t* __restrict__ s_qs,
@@ -158,60 +169,95 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
   const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
+  const uint64_t fifth = max_gap / 5;
   for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
     const uint32_t b = group_begin[g];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
     if (e - b < 2) continue;
     const bool minus = (s_grp[b] & 1ull) != 0;
+    auto load_block = [&](uint32_t pos) {
+      ChainBlock k;
+      const uint32_t p = pos + lane;
+      if (p < e) {
+        k.qs = s_qs[p];
+        k.qe = s_qe[p];
+        k.ts = s_ts[p];
+        k.te = s_te[p];
+        k.bps = __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        k.qs = k.qe = k.ts = k.te = 0;
+        k.bps = 0;  // never a candidate (j < e fails first)
+      }
+      return k;
+    };
+    uint32_t base = b;
+    ChainBlock A = load_block(base), B = load_block(base + 64);
     for (uint32_t i = b; i + 1 < e; ++i) {
-      const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
-      const uint64_t bound = qe_i + max_gap;  // u64, wraps like the reference only beyond 2^64
+      if (i - base == 64) {
+        A = B;
+        base += 64;
+        B = load_block(base + 64);
+      }
+      const int li = (int)(i - base);
+      const uint64_t qe_i = readlane_u32(A.qe, li), ts_i = readlane_u32(A.ts, li), te_i = readlane_u32(A.te, li);
+      const uint64_t bound = qe_i + max_gap;
       uint64_t best_d = INF;
       uint32_t best_j = NONE;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        bool in = j < e;
-        uint64_t qs_j = 0;
-        if (in) {
-          qs_j = s_qs[j];
-          in = qs_j <= bound;
+      // d(i, j) for one candidate; returns false when j is outside the window
+      auto consider = [&](uint32_t j, uint64_t qs_j, uint64_t ts_j, uint64_t te_j, uint64_t cur) {
+        uint64_t q_gap, r_gap;
+        if (qs_j >= qe_i) {
+          q_gap = qs_j - qe_i;
+        } else {
+          const uint64_t ov = qe_i - qs_j;
+          q_gap = ov <= fifth ? ov : max_gap + 1;
         }
-        if (in) {
-          const uint64_t ts_j = s_ts[j], te_j = s_te[j];
-          uint64_t q_gap, r_gap;
-          if (qs_j >= qe_i) {
-            q_gap = qs_j - qe_i;
+        if (!minus) {
+          if (ts_j >= te_i) {
+            r_gap = ts_j - te_i;
           } else {
-            const uint64_t ov = qe_i - qs_j;
-            q_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
+            const uint64_t ov = te_i - ts_j;
+            r_gap = ov <= fifth ? ov : max_gap + 1;
           }
-          if (!minus) {
-            if (ts_j >= te_i) {
-              r_gap = ts_j - te_i;
-            } else {
-              const uint64_t ov = te_i - ts_j;
-              r_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
-            }
-          } else if (ts_i >= te_j) {
-            r_gap = ts_i - te_j;
-          } else {
-            const uint64_t ov = te_j - ts_i;
-            r_gap = ov <= max_gap / 5 ? ov : max_gap + 1;
-          }
-          if (q_gap <= max_gap && r_gap <= max_gap) {
-            const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
-            // `d < best_score && d < best_pred_score[j]`, first minimum in j order wins
-            const uint64_t cur = __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d < cur && d < best_d) {
-              best_d = d;
-              best_j = j;
-            }
+        } else if (ts_i >= te_j) {
+          r_gap = ts_i - te_j;
+        } else {
+          const uint64_t ov = te_j - ts_i;
+          r_gap = ov <= fifth ? ov : max_gap + 1;
+        }
+        if (q_gap <= max_gap && r_gap <= max_gap) {
+          const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
+          // `d < best_score && d < best_pred_score[j]`; per lane j ascends, so strict `<` keeps the first
+          if (d < cur && d < best_d) {
+            best_d = d;
+            best_j = j;
           }
         }
-        // sorted by q_start: a stripe with no lane inside the window ends the scan (paf_filter.rs:794-796)
-        if (!__any(in)) break;
+      };
+      {
+        const uint32_t j = base + lane;
+        if (lane > li && j < e && (uint64_t)A.qs <= bound) consider(j, A.qs, A.ts, A.te, A.bps);
       }
+      {
+        const uint32_t j = base + 64 + lane;
+        if (j < e && (uint64_t)B.qs <= bound) consider(j, B.qs, B.ts, B.te, B.bps);
+      }
+      // window reaching past the register blocks (dense groups only)
+      if (base + 128 < e && (uint64_t)readlane_u32(B.qs, 63) <= bound) {
+        for (uint32_t j0 = base + 128; j0 < e; j0 += 64) {
+          const uint32_t j = j0 + lane;
+          bool in = j < e;
+          uint64_t qs_j = 0;
+          if (in) {
+            qs_j = s_qs[j];
+            in = qs_j <= bound;
+          }
+          if (in)
+            consider(j, qs_j, s_ts[j], s_te[j], __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (!__any(in)) break;  // sorted by q_start (paf_filter.rs:794-796)
+        }
+      }
+      if (!__any(best_j != NONE)) continue;
       // wave reduction: minimum d, ties to the smaller j (strict `<` in j order)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -222,11 +268,16 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
           best_j = oj;
         }
       }
-      if (best_j != NONE && lane == 0) {
-        __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pred[best_j] = i;
+      const uint32_t lj = best_j - base;
+      if (lj < 64) {
+        if ((uint32_t)lane == lj) A.bps = best_d;
+      } else if (lj < 128) {
+        if ((uint32_t)lane == lj - 64) B.bps = best_d;
+      } else {
+        if (lane == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) pred[best_j] = i;
     }
   }
 }
@@ -272,11 +323,28 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
 }
 
 // min original index per (q,t,strand) group, and per genome pair (prefix-last) over ALL alive records
-__global__ __launch_bounds__(EW) void group_first_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                         const uint32_t* __restrict__ s_idx,
+__global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                         uint32_t m, const uint32_t* __restrict__ s_idx,
                                                          uint32_t* __restrict__ group_first) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) atomicMin(&group_first[s_gidx[p]], s_idx[p]);
+  // one wavefront per (q,t,strand) group: members are contiguous in survivor order
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * EW) >> 6;
+  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+    const uint32_t b = group_begin[g];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+    uint32_t v = 0xffffffffu;
+    for (uint32_t p = b + lane; p < e; p += 64) {
+      const uint32_t x = s_idx[p];
+      if (x < v) v = x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(v, o, 64);
+      if (t < v) v = t;
+    }
+    if (lane == 0) group_first[g] = v;
+  }
 }
 __global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
                                                                const uint32_t* __restrict__ q_id,
@@ -409,7 +477,9 @@ __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const
   const uint32_t c = sorted_c[s];
   const uint32_t run = run_excl[s] + run_flag[s] - 1;
   run_of_chain[c] = run;
-  if (C_ok[c]) {
+  // the sort is stable, so inside a run c ascends: the minimum is the first ok chain of the run.  Only an ok
+  // chain whose predecessor in the run is not ok (or that opens the run) can be that one -> few atomics.
+  if (C_ok[c] && (run_flag[s] || !C_ok[sorted_c[s - 1]])) {
     atomicMin(&pair_first[run], c);
     atomicMin(&gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]], c);
   }
@@ -500,7 +570,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, seg_sorted, c_sorted, seg_tmp, c_tmp, nc, 0, ax.seg_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, ax.seg_bits));
   SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
@@ -532,7 +602,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first,
                                                                   T.qid, T.tid, seq_genome2, n_g2, c_bits, nkey));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, nkey, kept_list, nkey_tmp, kept_tmp, nk, 0, 2 * c_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
   SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, C_num));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
@@ -599,7 +669,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
                                                               r->n_seq, pos_bits, B.keyA));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, B.keyA, B.idxA, key_tmp, idx_tmp, M, 0, pair_bits + pos_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
   SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
                                                         pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
   SWG_KERNEL_CHECK(ctx);
@@ -704,7 +774,13 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_gp), EW, 0, st>>>(n_gp, gp_first, NONE));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "group_first", group_first_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, B.s_idx, group_first));
+  {
+    uint64_t blocks = (n_groups + 3) / 4;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+    if (blocks > max_blocks) blocks = max_blocks;
+    SWG_LAUNCH(ctx, "group_first", group_first_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m,
+                                                                               B.s_idx, group_first));
+  }
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->seq_genome_last,
                                                                             r->n_genome_last, gp_first));
@@ -736,7 +812,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, order));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, ch_key, order, ch_key_tmp, order_tmp, nc, 0, 2 * idx_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &ch_key, &order, &ch_key_tmp, &order_tmp, nc, 0, 2 * idx_bits));
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
                                        nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
                                        r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
@@ -1052,7 +1128,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_KERNEL_CHECK(ctx);
       const int dp_bits = swg_bits_for(B.n_pairs) ? swg_bits_for(B.n_pairs) : 1;
       if (dp_bits + pos_bits > 64) return swg_set_error(ctx, SWG_ERR_RANGE, "anchor sort key exceeds 64 bits");
-      SWG_TRY(swg_radix_sort_pairs(ctx, b_key, anchor_a, b_key_tmp, anchor_tmp, na, 0, dp_bits + pos_bits));
+      SWG_TRY(swg_radix_sort_pairs(ctx, &b_key, &anchor_a, &b_key_tmp, &anchor_tmp, na, 0, dp_bits + pos_bits));
       SWG_LAUNCH(ctx, "anchor_cols", anchor_cols_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.idxA, B.a_ts, B.a_te, anchor_num, b_tc, b_idx,
                                                                      b_num));
       SWG_KERNEL_CHECK(ctx);

@@ -224,39 +224,248 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 
 }  // namespace
 
-int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
-                         uint32_t* vals_b, uint64_t n, int begin_bit, int end_bit) {
-  if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
-  if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
+// ---------------------------------------------------------------------------------------------
+// "onesweep" pass: one kernel per digit, read once / write once.
+//   * digit histograms of every pass come from one upfront sweep over the keys;
+//   * a tile (4096 pairs) ranks its keys with wavefront match + per-wave LDS counters, learns the
+//     number of equal-digit keys in all earlier tiles by decoupled look-back over per-tile status
+//     words (count | flag in one 32-bit word, agent-scope relaxed atomics: single-word hand-off),
+//     reorders the tile in LDS and writes digit runs with consecutive lanes on consecutive addresses.
+//   Tiles take their index from an atomic ticket so that every tile a block waits on has started.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int OS_THREADS = 256;
+constexpr int OS_ITEMS = 16;
+constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
+constexpr int OS_WAVES = OS_THREADS / 64;
+constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_GLOBAL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
+constexpr int OS_MAX_PASSES = 8;
+
+__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                              int begin_bit, int end_bit, int npasses,
+                                                              uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t h[OS_MAX_PASSES][RS_RADIX];
+  for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t base = (uint64_t)blockIdx.x * OS_TILE; base < n; base += (uint64_t)gridDim.x * OS_TILE) {
+#pragma unroll 4
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint64_t i = base + (uint64_t)r * OS_THREADS + threadIdx.x;
+      if (i < n) {
+        const uint64_t k = keys[i];
+        for (int p = 0; p < npasses; ++p) {
+          const int shift = begin_bit + 8 * p;
+          const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+          atomicAdd(&h[p][(uint32_t)(k >> shift) & ((1u << bits) - 1u)], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < npasses; ++p) {
+    const uint32_t c = h[p][threadIdx.x];
+    if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
+  }
+}
+
+// one block per pass: exclusive scan of its 256 bins, in place
+__global__ __launch_bounds__(RS_RADIX) void os_scan_hist_kernel(uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t lds_wave[RS_RADIX / 64];
+  __shared__ uint32_t lds_prev[RS_RADIX];
+  uint32_t* row = ghist + (size_t)blockIdx.x * RS_RADIX;
+  const uint32_t v = row[threadIdx.x];
+  uint32_t tot;
+  const uint32_t ex = block_exclusive_scan<0>(v, &tot, lds_wave, lds_prev);
+  row[threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in,
+                                                              uint64_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, uint64_t n, int shift,
+                                                              uint32_t mask, const uint32_t* __restrict__ gbase,
+                                                              uint32_t* status, uint32_t* ticket) {
+  __shared__ uint64_t lkeys[OS_TILE];
+  __shared__ uint32_t lvals[OS_TILE];
+  __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
+  __shared__ uint32_t tile_excl[RS_RADIX];
+  __shared__ uint32_t dst_base[RS_RADIX];
+  __shared__ uint32_t lds_wave[OS_THREADS / 64];
+  __shared__ uint32_t lds_prev[OS_THREADS];
+  __shared__ uint32_t s_tile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t tile_base = (uint64_t)tile * OS_TILE;
+  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+  uint64_t key[OS_ITEMS];
+  uint32_t val[OS_ITEMS];
+  uint32_t rank[OS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    key[r] = i < n ? keys_in[i] : ~0ull;
+    val[r] = i < n ? vals_in[i] : 0u;
+  }
+  // ---- rank inside the wave (stable): match + per-wave running digit counters in LDS
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t prev = 0;
+    int leader = 0;
+    if (valid) {
+      leader = __builtin_ctzll(peers);
+      if (lane == leader) {
+        prev = cnt[wave][d];
+        cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+      }
+    }
+    prev = __shfl(prev, leader, 64);
+    rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
+  }
+  __syncthreads();
+  // ---- per digit (thread = digit): tile count, wave offsets, tile-exclusive prefix, look-back
+  {
+    uint32_t c[OS_WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < OS_WAVES; ++w) {
+      c[w] = cnt[w][tid];
+      cnt[w][tid] = tot;  // exclusive over waves
+      tot += c[w];
+    }
+    uint32_t block_total;
+    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
+    tile_excl[tid] = ex;
+    uint32_t excl = 0;
+    uint32_t* my = status + (size_t)tile * RS_RADIX + tid;
+    if (tile == 0) {
+      __hip_atomic_store(my, OS_FLAG_GLOBAL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my, OS_FLAG_LOCAL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t tt = tile - 1;
+      while (true) {
+        const uint32_t sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = sv & ~OS_VALUE_MASK;
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += sv & OS_VALUE_MASK;
+        if (f == OS_FLAG_GLOBAL) break;
+        --tt;  // LOCAL: keep looking back (tile 0 always publishes GLOBAL)
+      }
+      __hip_atomic_store(my, OS_FLAG_GLOBAL | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    dst_base[tid] = gbase[tid] + excl - ex;
+  }
+  __syncthreads();
+  // ---- reorder the tile in LDS
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+      const uint32_t pos = tile_excl[d] + cnt[wave][d] + rank[r];
+      lkeys[pos] = key[r];
+      lvals[pos] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    if (p < tile_n) {
+      const uint64_t k = lkeys[p];
+      const uint32_t d = (uint32_t)(k >> shift) & mask;
+      const uint32_t o = dst_base[d] + p;
+      keys_out[o] = k;
+      vals_out[o] = lvals[p];
+    }
+  }
+}
+
+// Fallback (n >= 2^30): histogram / scan / scatter per pass.
+int radix_sort_three_kernel(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
+                            uint64_t n, int begin_bit, int end_bit) {
   const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
   uint32_t* hist = swg_alloc<uint32_t>(ctx, (size_t)RS_RADIX * ntiles);
   SWG_CHECK_ARENA(ctx);
-  uint64_t* kin = keys_a;
-  uint32_t* vin = vals_a;
-  uint64_t* kout = keys_b;
-  uint32_t* vout = vals_b;
-  int passes = 0;
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    SWG_LAUNCH(ctx, "rs_hist", rs_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, n, shift, mask, hist, ntiles));
+    SWG_LAUNCH(ctx, "rs_hist", rs_hist_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(*keys, n, shift, mask, hist, ntiles));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_exclusive_scan_u32(ctx, hist, hist, (uint64_t)RS_RADIX * ntiles, nullptr));
-    SWG_LAUNCH(ctx, "rs_scatter", rs_scatter_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, shift, mask, hist,
-                                                              ntiles));
+    SWG_LAUNCH(ctx, "rs_scatter", rs_scatter_kernel<<<ntiles, RS_THREADS, 0, ctx->stream>>>(*keys, *vals, *keys_alt, *vals_alt, n, shift,
+                                                                                 mask, hist, ntiles));
     SWG_KERNEL_CHECK(ctx);
-    uint64_t* tk = kin;
-    kin = kout;
-    kout = tk;
-    uint32_t* tv = vin;
-    vin = vout;
-    vout = tv;
-    ++passes;
+    uint64_t* tk = *keys;
+    *keys = *keys_alt;
+    *keys_alt = tk;
+    uint32_t* tv = *vals;
+    *vals = *vals_alt;
+    *vals_alt = tv;
   }
-  if (passes & 1) {  // result currently in the *_b buffers: move it home
-    SWG_HIP(ctx, hipMemcpyAsync(keys_a, keys_b, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
-    SWG_HIP(ctx, hipMemcpyAsync(vals_a, vals_b, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  swg_arena_restore(ctx, mark);
+  return SWG_OK;
+}
+
+}  // namespace
+
+int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
+                         uint64_t n, int begin_bit, int end_bit) {
+  if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
+  if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
+  const int npasses = (end_bit - begin_bit + 7) / 8;
+  if (n >= (uint64_t(1) << 30) || npasses > OS_MAX_PASSES)
+    return radix_sort_three_kernel(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit);
+  const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* ghist = swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
+  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * RS_RADIX);
+  uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
+  SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
+  {
+    uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
+    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, begin_bit, end_bit, npasses, ghist));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, RS_RADIX, 0, ctx->stream>>>(ghist));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  for (int p = 0; p < npasses; ++p) {
+    const int shift = begin_bit + 8 * p;
+    const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    const uint32_t mask = (1u << bits) - 1u;
+    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * RS_RADIX, ctx->stream));
+    SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<<<ntiles, OS_THREADS, 0, ctx->stream>>>(*keys, *vals, *keys_alt, *vals_alt, n, shift, mask,
+                                                                          ghist + (size_t)p * RS_RADIX, status, tickets + p));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t* tk = *keys;
+    *keys = *keys_alt;
+    *keys_alt = tk;
+    uint32_t* tv = *vals;
+    *vals = *vals_alt;
+    *vals_alt = tv;
   }
   swg_arena_restore(ctx, mark);
   return SWG_OK;

@@ -495,7 +495,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_LAUNCH(ctx, "event_build", event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
                                                                             in.pos_bits, ev_x, ev_val));
       SWG_KERNEL_CHECK(ctx);
-      SWG_TRY(swg_radix_sort_pairs(ctx, ev_x, ev_val, ev_x2, ev_val2, n_ev, 0, key_bits));
+      SWG_TRY(swg_radix_sort_pairs(ctx, &ev_x, &ev_val, &ev_x2, &ev_val2, n_ev, 0, key_bits));
       SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
       SWG_LAUNCH(ctx, "single_segment", single_segment_kernel<<<blocks_for(n_ev, EW_THREADS), EW_THREADS, 0, st>>>(n_ev, ev_x, ev_val, in.pos_bits,
                                                                                   single));
@@ -526,7 +526,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   SWG_LAUNCH(ctx, "event_build", event_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.seg, in.start, in.end, in.alive,
                                                                         in.pos_bits, ev_x, ev_val));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, ev_x, ev_val, ev_x2, ev_val2, n_ev, 0, key_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &ev_x, &ev_val, &ev_x2, &ev_val2, n_ev, 0, key_bits));
   uint64_t* ev_key = ev_x2;
   uint32_t* ev_end = ev_val2;
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 3 * n, st));
