@@ -238,35 +238,47 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
         const uint32_t j = base + lane;
         if (lane > li && j < e && (uint64_t)A.qs <= bound) consider(j, A.qs, A.ts, A.te, A.bps);
       }
-      {
+      // block B (and beyond) only when its first element is inside the window: q_start is sorted
+      if (base + 64 < e && (uint64_t)readlane_u32(B.qs, 0) <= bound) {
         const uint32_t j = base + 64 + lane;
         if (j < e && (uint64_t)B.qs <= bound) consider(j, B.qs, B.ts, B.te, B.bps);
-      }
-      // window reaching past the register blocks (dense groups only)
-      if (base + 128 < e && (uint64_t)readlane_u32(B.qs, 63) <= bound) {
-        for (uint32_t j0 = base + 128; j0 < e; j0 += 64) {
-          const uint32_t j = j0 + lane;
-          bool in = j < e;
-          uint64_t qs_j = 0;
-          if (in) {
-            qs_j = s_qs[j];
-            in = qs_j <= bound;
+        // window reaching past the register blocks (dense groups only)
+        if (base + 128 < e && (uint64_t)readlane_u32(B.qs, 63) <= bound) {
+          for (uint32_t j0 = base + 128; j0 < e; j0 += 64) {
+            const uint32_t jj = j0 + lane;
+            bool in = jj < e;
+            uint64_t qs_j = 0;
+            if (in) {
+              qs_j = s_qs[jj];
+              in = qs_j <= bound;
+            }
+            if (in)
+              consider(jj, qs_j, s_ts[jj], s_te[jj],
+                       __hip_atomic_load(&bps[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (!__any(in)) break;  // sorted by q_start (paf_filter.rs:794-796)
           }
-          if (in)
-            consider(j, qs_j, s_ts[j], s_te[j], __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (!__any(in)) break;  // sorted by q_start (paf_filter.rs:794-796)
         }
       }
-      if (!__any(best_j != NONE)) continue;
-      // wave reduction: minimum d, ties to the smaller j (strict `<` in j order)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t od = __shfl_xor(best_d, o, 64);
-        const uint32_t oj = __shfl_xor(best_j, o, 64);
-        if (od < best_d || (od == best_d && oj < best_j)) {
-          best_d = od;
-          best_j = oj;
+      // minimum d, ties to the smaller j (strict `<` in j order).  Few lanes hold a candidate, so walk the
+      // ballot with scalar compares instead of a 6-step butterfly.
+      uint64_t cand = __ballot(best_j != NONE);
+      if (!cand) continue;
+      {
+        uint64_t bd = INF;
+        uint32_t bj = NONE;
+        while (cand) {
+          const int l = __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const uint32_t dlo = readlane_u32((uint32_t)best_d, l), dhi = readlane_u32((uint32_t)(best_d >> 32), l);
+          const uint64_t d = ((uint64_t)dhi << 32) | dlo;
+          const uint32_t j = readlane_u32(best_j, l);
+          if (d < bd || (d == bd && j < bj)) {
+            bd = d;
+            bj = j;
+          }
         }
+        best_d = bd;
+        best_j = bj;
       }
       const uint32_t lj = best_j - base;
       if (lj < 64) {
@@ -839,39 +851,77 @@ __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint
   in_filtered[i] = C_ok[c];
 }
 
-// kept '+' chains per dense chromosome pair (CSR)
-__global__ __launch_bounds__(EW) void fwd_count_kernel(uint64_t nc, const uint32_t* __restrict__ C_num,
-                                                       const uint8_t* __restrict__ C_strand,
-                                                       const uint32_t* __restrict__ C_dpair,
-                                                       uint32_t* __restrict__ cnt) {
+// Kept '+' chains compacted in all_chains order.  A chromosome pair's '+' group is contiguous in that order and
+// sorted by chain q_start (head position order), so per pair the list is a q_start-sorted range: no CSR, no atomics.
+__global__ __launch_bounds__(EW) void fwd_flag_kernel(uint64_t nc, const uint32_t* __restrict__ C_num,
+                                                      const uint8_t* __restrict__ C_strand, uint8_t* __restrict__ flag) {
   uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (c < nc && C_num[c] && C_strand[c] == 0) atomicAdd(&cnt[C_dpair[c]], 1u);
+  if (c < nc) flag[c] = (C_num[c] && C_strand[c] == 0) ? 1 : 0;
 }
-__global__ __launch_bounds__(EW) void fwd_fill_kernel(uint64_t nc, const uint32_t* __restrict__ C_num,
-                                                      const uint8_t* __restrict__ C_strand,
-                                                      const uint32_t* __restrict__ C_dpair,
-                                                      const uint32_t* __restrict__ off, uint32_t* __restrict__ cur,
-                                                      uint32_t* __restrict__ list) {
-  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (c < nc && C_num[c] && C_strand[c] == 0) {
-    const uint32_t dp = C_dpair[c];
-    list[off[dp] + atomicAdd(&cur[dp], 1u)] = (uint32_t)c;
+__global__ __launch_bounds__(EW) void fwd_cols_kernel(uint64_t nf, const uint32_t* __restrict__ f_c,
+                                                      const uint32_t* __restrict__ C_qs, const uint32_t* __restrict__ C_qe,
+                                                      const uint32_t* __restrict__ C_ts, const uint32_t* __restrict__ C_num,
+                                                      const uint32_t* __restrict__ C_dpair, uint32_t* __restrict__ f_qs,
+                                                      uint32_t* __restrict__ f_qe, uint32_t* __restrict__ f_ts,
+                                                      uint32_t* __restrict__ f_num, uint32_t* __restrict__ f_dp) {
+  uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (k >= nf) return;
+  const uint32_t c = f_c[k];
+  f_qs[k] = C_qs[c];
+  f_qe[k] = C_qe[c];
+  f_ts[k] = C_ts[c];
+  f_num[k] = C_num[c];
+  f_dp[k] = C_dpair[c];
+}
+// range of each pair in the list; one thread per list entry looks at its neighbours
+__global__ __launch_bounds__(EW) void fwd_ranges_kernel(uint64_t nf, const uint32_t* __restrict__ f_dp,
+                                                        uint32_t* __restrict__ pair_lo, uint32_t* __restrict__ pair_hi) {
+  uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (k >= nf) return;
+  const uint32_t dp = f_dp[k];
+  if (k == 0 || f_dp[k - 1] != dp) pair_lo[dp] = (uint32_t)k;
+  if (k + 1 == nf || f_dp[k + 1] != dp) pair_hi[dp] = (uint32_t)k + 1;
+}
+// running maximum of chain q_end inside each pair range (one wavefront per pair)
+__global__ __launch_bounds__(EW) void fwd_prefmax_kernel(uint32_t n_pairs, const uint32_t* __restrict__ pair_lo,
+                                                         const uint32_t* __restrict__ pair_hi,
+                                                         const uint32_t* __restrict__ f_qe, uint32_t* __restrict__ f_pm) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * EW) >> 6;
+  for (uint32_t dp = wave_global; dp < n_pairs; dp += n_waves) {
+    const uint32_t lo = pair_lo[dp], hi = pair_hi[dp];
+    uint32_t carry = 0;
+    for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      uint32_t v = k < hi ? f_qe[k] : 0u;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d && t > v) v = t;
+      }
+      if (carry > v) v = carry;
+      if (k < hi) f_pm[k] = v;
+      carry = __shfl(v, 63, 64);
+    }
   }
 }
 // paf_filter.rs:535-597: a '-' record joins the first (lowest-numbered) kept '+' chain of its pair whose
-// diagonal it sits on.
+// diagonal it sits on.  Candidates: chains with q_start <= q_end(rec) + gap (binary search) and
+// q_end + gap >= q_start(rec) (backward scan, stopped by the running maximum).
 __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
                                                        const uint32_t* __restrict__ idxA,
                                                        const uint32_t* __restrict__ a_qe,
                                                        const uint32_t* __restrict__ a_ts,
                                                        const uint32_t* __restrict__ a_te,
                                                        const uint32_t* __restrict__ a_dpair, int pos_bits,
-                                                       const uint32_t* __restrict__ off,
-                                                       const uint32_t* __restrict__ list,
-                                                       const uint32_t* __restrict__ C_qs,
-                                                       const uint32_t* __restrict__ C_qe,
-                                                       const uint32_t* __restrict__ C_ts,
-                                                       const uint32_t* __restrict__ C_num, uint64_t gap,
+                                                       const uint32_t* __restrict__ pair_lo,
+                                                       const uint32_t* __restrict__ pair_hi,
+                                                       const uint32_t* __restrict__ f_qs,
+                                                       const uint32_t* __restrict__ f_qe,
+                                                       const uint32_t* __restrict__ f_pm,
+                                                       const uint32_t* __restrict__ f_ts,
+                                                       const uint32_t* __restrict__ f_num, uint64_t gap,
                                                        uint32_t* anchor_num) {
   uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (a >= M) return;
@@ -880,24 +930,34 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
   const uint32_t i = idxA[a];
   if (anchor_num[i]) return;
   const uint32_t dp = a_dpair[a];
-  const uint32_t lb = off[dp], le = off[dp + 1];
-  if (lb == le) return;
+  const uint32_t lb = pair_lo[dp], le = pair_hi[dp];
+  if (lb >= le) return;
   const uint64_t qs = k & ((uint64_t(1) << pos_bits) - 1), qe = a_qe[a], ts = a_ts[a], te = a_te[a];
   const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
+  // chain.query_start.saturating_sub(gap) <= qe  <=>  chain.query_start <= qe + gap
+  const uint64_t lim = qe > ~0ull - gap ? ~0ull : qe + gap;
+  uint32_t l = lb, r = le;  // upper bound: first chain with q_start > lim
+  while (l < r) {
+    const uint32_t mid = l + ((r - l) >> 1);
+    if ((uint64_t)f_qs[mid] <= lim)
+      l = mid + 1;
+    else
+      r = mid;
+  }
   uint32_t best = 0;
-  for (uint32_t s = lb; s < le; ++s) {
-    const uint32_t c = list[s];
-    const uint64_t cqs = C_qs[c], cqe = C_qe[c];
-    const uint64_t ext_start = cqs > gap ? cqs - gap : 0;                            // saturating_sub
-    const uint64_t ext_end = cqe > ~0ull - gap ? ~0ull : cqe + gap;                  // saturating_add
-    if (qe < ext_start || qs > ext_end) continue;
-    const int64_t diag = (int64_t)C_ts[c] - (int64_t)cqs;
+  for (uint32_t s = l; s > lb; --s) {
+    const uint32_t c = s - 1;
+    const uint64_t pm = f_pm[c];
+    if ((pm > ~0ull - gap ? ~0ull : pm + gap) < qs) break;  // no earlier chain reaches the record
+    const uint64_t cqe = f_qe[c];
+    if ((cqe > ~0ull - gap ? ~0ull : cqe + gap) < qs) continue;  // mapping.query_start > extended_query_end
+    const int64_t diag = (int64_t)f_ts[c] - (int64_t)f_qs[c];
     const int64_t dev = (int64_t)tc - (int64_t)qc - diag;
     const uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;
     const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
     const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
     if (perp <= gap) {
-      const uint32_t num = C_num[c];
+      const uint32_t num = f_num[c];
       if (best == 0 || num < best) best = num;
     }
   }
@@ -1077,25 +1137,48 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   // ---- inversion capture
   {
     const uint64_t np = B.n_pairs;
-    uint32_t* cnt = swg_alloc<uint32_t>(ctx, np + 1);
-    uint32_t* cur = swg_alloc<uint32_t>(ctx, np + 1);
+    uint8_t* fflag = swg_alloc<uint8_t>(ctx, nc);
+    uint32_t* fflag32 = swg_alloc<uint32_t>(ctx, nc);
+    uint32_t* fpos = swg_alloc<uint32_t>(ctx, nc);
+    uint32_t* pair_lo = swg_alloc<uint32_t>(ctx, np + 1);
+    uint32_t* pair_hi = swg_alloc<uint32_t>(ctx, np + 1);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
-    SWG_HIP(ctx, hipMemsetAsync(cnt, 0, (np + 1) * 4, st));
-    SWG_HIP(ctx, hipMemsetAsync(cur, 0, (np + 1) * 4, st));
-    SWG_LAUNCH(ctx, "fwd_count", fwd_count_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, B.C_dpair, cnt));
+    SWG_LAUNCH(ctx, "fwd_flag", fwd_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, fflag));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, cnt, cnt, np + 1, d_tot));
+    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, fflag, fflag32));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, fflag32, fpos, nc, d_tot));
     uint64_t nf = 0;
     SWG_TRY(swg_read_scalars(ctx, d_tot, &nf, 1));
     if (nf) {
-      uint32_t* list = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_c = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_qs = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_qe = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_pm = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_ts = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_num = swg_alloc<uint32_t>(ctx, nf);
+      uint32_t* f_dp = swg_alloc<uint32_t>(ctx, nf);
       SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "fwd_fill", fwd_fill_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, B.C_dpair, cnt, cur, list));
+      SWG_HIP(ctx, hipMemsetAsync(pair_lo, 0, (np + 1) * 4, st));
+      SWG_HIP(ctx, hipMemsetAsync(pair_hi, 0, (np + 1) * 4, st));
+      SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, fflag, fpos, f_c));
       SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "fwd_cols", fwd_cols_kernel<<<nblk(nf), EW, 0, st>>>(nf, f_c, B.T.qs, B.T.qe, B.T.ts, C_num, B.C_dpair, f_qs, f_qe,
+                                                                f_ts, f_num, f_dp));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "fwd_ranges", fwd_ranges_kernel<<<nblk(nf), EW, 0, st>>>(nf, f_dp, pair_lo, pair_hi));
+      SWG_KERNEL_CHECK(ctx);
+      {
+        uint64_t blocks = (np + 3) / 4;
+        const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+        if (blocks > max_blocks) blocks = max_blocks;
+        SWG_LAUNCH(ctx, "fwd_prefmax", fwd_prefmax_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)np, pair_lo, pair_hi, f_qe, f_pm));
+        SWG_KERNEL_CHECK(ctx);
+      }
       SWG_LAUNCH(ctx, "inversion", inversion_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits,
-                                                                cnt, list, B.T.qs, B.T.qe, B.T.ts, C_num, cfg->scaffold_gap,
-                                                                anchor_num));
+                                                                pair_lo, pair_hi, f_qs, f_qe, f_pm, f_ts, f_num,
+                                                                cfg->scaffold_gap, anchor_num));
       SWG_KERNEL_CHECK(ctx);
     }
   }
