@@ -15,11 +15,14 @@
 //   2. the sorted begins are cut into tiles of TB = 256.  With X_b the first key of tile b:
 //        - an interval that begins before tile b and ends after X_b is a *carry-in* of b;
 //        - an interval's end coordinate E is an evaluation point of the last tile with X_b < E
-//          (unless E coincides with the next tile's first key, which is evaluated as a start).
-//      Both per-tile lists are built once (exponential + binary search over the tile-start array,
-//      count, scan, fill); carry-in entries carry {start, end, score key, index} inline.
+//          (unless E coincides with the next tile's first key, which is evaluated as a start);
+//          that tile holds the interval either as one of its own begins or as a carry-in, so
+//          end points need no list of their own.
+//      Carry-in lists are built once (exponential + binary search over the tile-start array,
+//      count, scan, fill); entries carry {start, end, score key, index} inline.
 //   3. one work-group per tile.  Evaluation points are processed in batches of 256 (one per
-//      thread): the tile's own start coordinates, then its routed end coordinates.  For a point x
+//      thread): the tile's own start coordinates, the ends of its own begins, then the ends of
+//      its carry-ins chunk by chunk (only ends before the next tile's first key).  For a point x
 //      the candidates are the tile's own begins at or before x (backward scan in LDS from the
 //      last begin <= x, cut short by a prefix maximum of interval ends) and the carry-ins
 //      (streamed through LDS in chunks).  Pass 1 finds T(x), pass 2 marks `ever-top` for its
@@ -42,7 +45,6 @@ namespace {
 constexpr int TB = 256;  // begins per tile == threads per workgroup
 constexpr int CC = 256;  // carry-in entries staged per LDS chunk
 constexpr int EW_THREADS = 256;
-constexpr uint32_t NO_TILE = 0xffffffffu;
 
 __device__ __forceinline__ bool prio_less(uint64_t ak, uint64_t as, uint32_t ai, uint64_t bk, uint64_t bs,
                                           uint32_t bi) {
@@ -153,48 +155,38 @@ __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, con
                                                                  const uint64_t* __restrict__ E,
                                                                  const uint64_t* __restrict__ tile_x, uint32_t ntiles,
                                                                  uint32_t* __restrict__ te_out,
-                                                                 uint32_t* __restrict__ carry_cnt,
-                                                                 uint32_t* __restrict__ ep_cnt) {
+                                                                 uint32_t* __restrict__ carry_cnt) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
   const uint64_t s = S[p], e = E[p];
-  if (s == 0 || e <= s) {  // dead, or zero-length: never active, its end equals its own start coordinate
-    te_out[p] = NO_TILE;
-    return;
-  }
   const uint32_t tb = (uint32_t)(p / TB);
-  const uint32_t te = last_tile_below(tile_x, ntiles, tb, e);
-  for (uint32_t b = tb + 1; b <= te; ++b) atomicAdd(&carry_cnt[b], 1u);
-  const bool ep = !(te + 1 < ntiles && tile_x[te + 1] == e);  // otherwise evaluated as a start coordinate
-  if (ep) atomicAdd(&ep_cnt[te], 1u);
-  te_out[p] = te | (ep ? 0x80000000u : 0u);
+  uint32_t te = tb;
+  if (s != 0 && e > s) {  // live and not zero-length
+    te = last_tile_below(tile_x, ntiles, tb, e);
+    for (uint32_t b = tb + 1; b <= te; ++b) atomicAdd(&carry_cnt[b], 1u);
+  }
+  te_out[p] = te;
 }
 
 __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
     uint64_t n, const uint64_t* __restrict__ S, const uint64_t* __restrict__ E, const uint64_t* __restrict__ KEY,
     const uint32_t* __restrict__ I, const uint32_t* __restrict__ te_in, const uint32_t* __restrict__ carry_off,
-    uint32_t* __restrict__ carry_cur, const uint32_t* __restrict__ ep_off, uint32_t* __restrict__ ep_cur,
-    uint64_t* __restrict__ c_s, uint64_t* __restrict__ c_e, uint64_t* __restrict__ c_key, uint32_t* __restrict__ c_id,
-    uint64_t* __restrict__ ep_x) {
+    uint32_t* __restrict__ carry_cur, uint64_t* __restrict__ c_s, uint64_t* __restrict__ c_e,
+    uint64_t* __restrict__ c_key, uint32_t* __restrict__ c_id) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
-  const uint32_t t = te_in[p];
-  if (t == NO_TILE) return;
-  const uint32_t te = t & 0x7fffffffu;
+  const uint32_t te = te_in[p];
   const uint32_t tb = (uint32_t)(p / TB);
-  const uint64_t e = E[p];
-  if (te > tb) {
-    const uint64_t s = S[p], k = KEY[p];
-    const uint32_t id = I[p];
-    for (uint32_t b = tb + 1; b <= te; ++b) {
-      const uint32_t slot = carry_off[b] + atomicAdd(&carry_cur[b], 1u);
-      c_s[slot] = s;
-      c_e[slot] = e;
-      c_key[slot] = k;
-      c_id[slot] = id;
-    }
+  if (te <= tb) return;
+  const uint64_t s = S[p], e = E[p], k = KEY[p];
+  const uint32_t id = I[p];
+  for (uint32_t b = tb + 1; b <= te; ++b) {
+    const uint32_t slot = carry_off[b] + atomicAdd(&carry_cur[b], 1u);
+    c_s[slot] = s;
+    c_e[slot] = e;
+    c_key[slot] = k;
+    c_id[slot] = id;
   }
-  if (t & 0x80000000u) ep_x[ep_off[te] + atomicAdd(&ep_cur[te], 1u)] = e;
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------------
@@ -211,8 +203,6 @@ struct TileArgs {
   const uint64_t* c_e;
   const uint64_t* c_key;
   const uint32_t* c_id;
-  const uint32_t* ep_off;  // [ntiles + 1]
-  const uint64_t* ep_x;
   uint64_t k;
   double thr;
   uint8_t* top;
@@ -273,8 +263,8 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
   __syncthreads();
 
   const uint32_t c_begin = a.carry_off[blockIdx.x], c_end = a.carry_off[blockIdx.x + 1];
-  const uint32_t e_begin = a.ep_off[blockIdx.x], e_end = a.ep_off[blockIdx.x + 1];
-  const uint32_t n_batches = 1 + (e_end - e_begin + TB - 1) / TB;
+  const uint32_t n_chunks = (c_end - c_begin + CC - 1) / CC;
+  const uint32_t n_batches = 2 + n_chunks;
 
   for (uint32_t batch = 0; batch < n_batches; ++batch) {
     // ---- this thread's evaluation point: coordinate PX, last own begin at or before it Q0
@@ -285,10 +275,19 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
       eval = valid && X != 0 && (tid == TB - 1 || sx[tid + 1] != X) && X != x_next;
       PX = X;
       Q0 = tid;
-    } else {  // routed end coordinates: X_b < PX < X_{b+1}
-      const uint32_t ei = e_begin + (batch - 1) * TB + tid;
-      eval = ei < e_end;
-      PX = eval ? a.ep_x[ei] : 0;
+    } else {
+      // end coordinates that fall inside this tile's range (X_b < PX < X_{b+1}): batch 1 = ends of the
+      // tile's own begins, batch 2+j = ends of the carry-ins of chunk j.  An end equal to the next
+      // tile's first key is evaluated there as a start coordinate.
+      if (batch == 1) {
+        eval = valid && X != 0 && EE > X && EE < x_next;
+        PX = EE;
+      } else {
+        const uint32_t ci = c_begin + (batch - 2) * CC + tid;
+        eval = ci < c_end;
+        PX = eval ? a.c_e[ci] : 0;
+        eval = eval && PX < x_next;
+      }
       int l = 0, r = TB;  // upper_bound(sx, PX) - 1; sx is ~0 past the end of a short last tile
       while (l < r) {
         const int mid = (l + r) >> 1;
@@ -549,34 +548,28 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   SWG_TRY(sort_begins());
   uint32_t* te = swg_alloc<uint32_t>(ctx, n);
   uint8_t* flags = swg_alloc<uint8_t>(ctx, 2 * n);  // top | ovl
-  uint32_t* cnts = swg_alloc<uint32_t>(ctx, 4 * ((size_t)ntiles + 1));  // carry_cnt | ep_cnt | carry_cur | ep_cur
+  uint32_t* cnts = swg_alloc<uint32_t>(ctx, 2 * ((size_t)ntiles + 1));  // carry_cnt | carry_cur
   uint64_t* d_total = swg_alloc<uint64_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   uint8_t* top = flags;
   uint8_t* ovl = flags + n;
   uint32_t* carry_cnt = cnts;
-  uint32_t* ep_cnt = cnts + ((size_t)ntiles + 1);
-  uint32_t* carry_cur = cnts + 2 * ((size_t)ntiles + 1);
-  uint32_t* ep_cur = cnts + 3 * ((size_t)ntiles + 1);
+  uint32_t* carry_cur = cnts + ((size_t)ntiles + 1);
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 2 * n, st));
-  SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 4 * ((size_t)ntiles + 1), st));
-  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, tile_x, ntiles, te, carry_cnt,
-                                                                                          ep_cnt));
+  SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 2 * ((size_t)ntiles + 1), st));
+  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, tile_x, ntiles, te, carry_cnt));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)ntiles + 1, d_total));
-  SWG_TRY(swg_exclusive_scan_u32(ctx, ep_cnt, ep_cnt, (uint64_t)ntiles + 1, d_total + 1));
-  uint64_t tot[2] = {0, 0};
-  SWG_TRY(swg_read_scalars(ctx, d_total, tot, 2));
-  const uint64_t n_carry = tot[0], n_ep = tot[1];
+  uint64_t n_carry = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_total, &n_carry, 1));
   uint64_t* c_s = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_e = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_key = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint32_t* c_id = swg_alloc<uint32_t>(ctx, n_carry + 1);
-  uint64_t* ep_x = swg_alloc<uint64_t>(ctx, n_ep + 1);
   SWG_CHECK_ARENA(ctx);
-  if (n_carry || n_ep) {
+  if (n_carry) {
     SWG_LAUNCH(ctx, "route_fill", route_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                      n, S, E, KEY, I, te, carry_cnt, carry_cur, ep_cnt, ep_cur, c_s, c_e, c_key, c_id, ep_x));
+                                      n, S, E, KEY, I, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
     SWG_KERNEL_CHECK(ctx);
   }
   TileArgs ta;
@@ -592,8 +585,6 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.c_e = c_e;
   ta.c_key = c_key;
   ta.c_id = c_id;
-  ta.ep_off = ep_cnt;
-  ta.ep_x = ep_x;
   ta.k = k;
   ta.thr = thr;
   ta.top = top;
