@@ -386,28 +386,62 @@ __global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t M, const
   }
 }
 
-// chains in head-position order: sort key for the reference's all_chains order
-__global__ __launch_bounds__(EW) void chain_list_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
-                                                        const uint32_t* __restrict__ cpos_excl,
-                                                        const uint32_t* __restrict__ s_gidx,
+// all_chains order = (q,t,strand) groups by first appearance, chains of a group by head position.  Chains in
+// head-position order are already contiguous per group, so only the GROUPS are sorted; a chain's place is its
+// group's base plus its rank inside the group.
+__global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                        uint32_t m, const uint32_t* __restrict__ cpos_excl, uint32_t nc,
                                                         const uint32_t* __restrict__ s_idx,
                                                         const uint32_t* __restrict__ group_first,
                                                         const uint32_t* __restrict__ q_id,
                                                         const uint32_t* __restrict__ t_id,
                                                         const uint32_t* __restrict__ seq_genome, uint32_t n_genome,
                                                         const uint32_t* __restrict__ gp_first, int idx_bits,
-                                                        uint32_t* __restrict__ ch_head, uint64_t* __restrict__ ch_key) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m || !is_head[p]) return;
-  const uint32_t c = cpos_excl[p];
-  ch_head[c] = (uint32_t)p;
-  const uint32_t i = s_idx[p];
+                                                        uint64_t* __restrict__ g_key, uint32_t* __restrict__ g_val,
+                                                        uint32_t* __restrict__ g_first_chain,
+                                                        uint32_t* __restrict__ g_nchains) {
+  uint32_t g = blockIdx.x * EW + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t b = group_begin[g];
+  const uint32_t first = cpos_excl[b];  // a group's first member is always a chain head
+  const uint32_t next = (g + 1 < n_groups) ? cpos_excl[group_begin[g + 1]] : nc;
+  (void)m;
+  g_first_chain[g] = first;
+  g_nchains[g] = next - first;
+  const uint32_t i = s_idx[b];
   // gp_first == nullptr: groups in plain first-appearance order of the records as given
   // (merge_mappings_into_chains called on its own); otherwise genome-pair-major, which is the order
   // apply_plane_sweep_to_mappings leaves the metadata in (paf_filter.rs:1037-1046, 1117-1120).
   uint64_t hi = 0;
   if (gp_first) hi = gp_first[seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]]];
-  ch_key[c] = (hi << idx_bits) | group_first[s_gidx[p]];
+  g_key[g] = (hi << idx_bits) | group_first[g];
+  g_val[g] = g;
+}
+__global__ __launch_bounds__(EW) void group_sizes_sorted_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
+                                                                const uint32_t* __restrict__ g_nchains,
+                                                                uint32_t* __restrict__ sizes) {
+  uint32_t r = blockIdx.x * EW + threadIdx.x;
+  if (r < n_groups) sizes[r] = g_nchains[g_sorted[r]];
+}
+__global__ __launch_bounds__(EW) void group_base_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
+                                                        const uint32_t* __restrict__ base_sorted,
+                                                        uint32_t* __restrict__ g_base) {
+  uint32_t r = blockIdx.x * EW + threadIdx.x;
+  if (r < n_groups) g_base[g_sorted[r]] = base_sorted[r];
+}
+// per chain head: position-order ordinal c -> all_chains index c2 (and the inverse)
+__global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
+                                                         const uint32_t* __restrict__ cpos_excl,
+                                                         const uint32_t* __restrict__ s_gidx,
+                                                         const uint32_t* __restrict__ g_first_chain,
+                                                         const uint32_t* __restrict__ g_base,
+                                                         uint32_t* __restrict__ ch_head, uint32_t* __restrict__ order) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m || !is_head[p]) return;
+  const uint32_t c = cpos_excl[p];
+  const uint32_t g = s_gidx[p];
+  ch_head[c] = (uint32_t)p;
+  order[g_base[g] + (c - g_first_chain[g])] = c;
 }
 
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
@@ -472,12 +506,12 @@ __global__ __launch_bounds__(EW) void run_flag_kernel(uint64_t nc, const uint64_
   uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (s < nc) flag[s] = (s == 0 || sorted_seg[s - 1] != sorted_seg[s]) ? 1u : 0u;
 }
-// pair_first[run] = min index over the span/identity-filtered chains of the chromosome pair;
-// gp2_first[genome pair (first two '#' parts)] likewise (plane_sweep_scaffold.rs:116-130 insertion order)
+// Chains here are already the span/identity-filtered ones, in index order, and the sort by chromosome pair is
+// stable: the first chain of a run is the pair's first appearance (plane_sweep_scaffold.rs:116-130 insertion
+// order), and the genome pair's (first two '#' parts) first appearance is the minimum over its runs' heads.
 __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
                                                               const uint32_t* __restrict__ run_excl,
                                                               const uint32_t* __restrict__ run_flag,
-                                                              const uint8_t* __restrict__ C_ok,
                                                               const uint32_t* __restrict__ C_qid,
                                                               const uint32_t* __restrict__ C_tid,
                                                               const uint32_t* __restrict__ seq_genome2, uint32_t n_g2,
@@ -489,10 +523,8 @@ __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const
   const uint32_t c = sorted_c[s];
   const uint32_t run = run_excl[s] + run_flag[s] - 1;
   run_of_chain[c] = run;
-  // the sort is stable, so inside a run c ascends: the minimum is the first ok chain of the run.  Only an ok
-  // chain whose predecessor in the run is not ok (or that opens the run) can be that one -> few atomics.
-  if (C_ok[c] && (run_flag[s] || !C_ok[sorted_c[s - 1]])) {
-    atomicMin(&pair_first[run], c);
+  if (run_flag[s]) {
+    pair_first[run] = c;
     atomicMin(&gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]], c);
   }
 }
@@ -516,6 +548,36 @@ __global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const u
   if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
 }
 
+__global__ __launch_bounds__(EW) void chain_compact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
+                                                           const uint32_t* __restrict__ qid, const uint32_t* __restrict__ tid,
+                                                           const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
+                                                           const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
+                                                           const double* __restrict__ wid, uint32_t* __restrict__ o_qid,
+                                                           uint32_t* __restrict__ o_tid, uint32_t* __restrict__ o_qs,
+                                                           uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts,
+                                                           uint32_t* __restrict__ o_te, double* __restrict__ o_wid) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= no) return;
+  const uint32_t c = ok_idx[j];
+  o_qid[j] = qid[c];
+  o_tid[j] = tid[c];
+  o_qs[j] = qs[c];
+  o_qe[j] = qe[c];
+  o_ts[j] = ts[c];
+  o_te[j] = te[c];
+  o_wid[j] = wid[c];
+}
+__global__ __launch_bounds__(EW) void chain_uncompact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
+                                                             const uint8_t* __restrict__ kept_j,
+                                                             const uint32_t* __restrict__ num_j,
+                                                             uint8_t* __restrict__ C_kept, uint32_t* __restrict__ C_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= no) return;
+  const uint32_t c = ok_idx[j];
+  C_kept[c] = kept_j[j];
+  C_num[c] = num_j[j];
+}
+
 struct ChainTable {
   uint64_t nc = 0;
   uint32_t *qid = nullptr, *tid = nullptr, *qs = nullptr, *qe = nullptr, *ts = nullptr, *te = nullptr;
@@ -529,10 +591,9 @@ struct ChainTable {
 int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
                               uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
                               int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out) {
-  const uint64_t nc = T.nc;
   hipStream_t st = ctx->stream;
   *n_kept_out = 0;
-  if (nc == 0) return SWG_OK;
+  if (T.nc == 0) return SWG_OK;
   if ((uint64_t)n_g2 * n_g2 > (uint64_t(1) << 28))
     return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "more than 2^14 genomes (first-two-'#' prefix) is not supported");
   uint64_t kq, kt;
@@ -543,27 +604,56 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
     kq = max_q ? max_q : SWG_K_INF;
     kt = max_t ? max_t : SWG_K_INF;
   }
+  SWG_HIP(ctx, hipMemsetAsync(C_kept, 0, T.nc, st));
+  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, T.nc * sizeof(uint32_t), st));
+  // ---- only the span/identity-filtered chains take part (compaction keeps their relative order, which is
+  //      all the plane sweep's index tie-break needs)
+  uint32_t* okf = swg_alloc<uint32_t>(ctx, T.nc);
+  uint32_t* okpos = swg_alloc<uint32_t>(ctx, T.nc);
+  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(T.nc), EW, 0, st>>>(T.nc, T.ok, okf));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, okf, okpos, T.nc, d_tot));
+  uint64_t nc = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
+  if (nc == 0) return SWG_OK;
+  uint32_t* ok_idx = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qid = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* tid = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qs = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qe = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* ts = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* te = swg_alloc<uint32_t>(ctx, nc);
+  double* wid = swg_alloc<double>(ctx, nc);
   uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
   uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
+  uint8_t* kept = swg_alloc<uint8_t>(ctx, nc);
+  uint32_t* num = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, T.qid, T.tid, n_seq, seg));
+  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(T.nc), EW, 0, st>>>(T.nc, T.ok, okpos, ok_idx));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_score_keys(ctx, nc, T.qs, T.qe, T.wid, scoring, skey));
+  SWG_LAUNCH(ctx, "chain_compact", chain_compact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, qid,
+                                                                     tid, qs, qe, ts, te, wid));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, qid, tid, n_seq, seg));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
   swg_axis_input ax;
   ax.n = nc;
   ax.seg = seg;
   ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
   ax.pos_bits = pos_bits;
   ax.score_key = skey;
-  ax.alive = T.ok;
-  ax.start = T.qs;
-  ax.end = T.qe;
+  ax.alive = nullptr;
+  ax.start = qs;
+  ax.end = qe;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
-  ax.alive = keep_q;
-  ax.start = T.ts;
-  ax.end = T.te;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, C_kept));
+  ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
+  ax.start = ts;
+  ax.end = te;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
 
   // ---- numbering -------------------------------------------------------------------------------------
   uint64_t* seg_sorted = swg_alloc<uint64_t>(ctx, nc);
@@ -577,7 +667,6 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   uint32_t* gp2_first = swg_alloc<uint32_t>(ctx, (size_t)n_g2 * n_g2);
   uint32_t* kflag = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* kpos = swg_alloc<uint32_t>(ctx, nc);
-  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
@@ -586,36 +675,36 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, pair_first, NONE));
-  SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk((uint64_t)n_g2 * n_g2), EW, 0, st>>>((uint64_t)n_g2 * n_g2, gp2_first, NONE));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(
-                                          nc, c_sorted, run_excl, run_flag, T.ok, T.qid, T.tid, seq_genome2, n_g2,
-                                          run_of_chain, pair_first, gp2_first));
+  SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, run_excl, run_flag, qid, tid, seq_genome2,
+                                                                           n_g2, run_of_chain, pair_first, gp2_first));
   SWG_KERNEL_CHECK(ctx);
   // kept chains, in index order
-  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_kept, kflag));
+  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, kept, kflag));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, kflag, kpos, nc, d_tot));
   uint64_t nk = 0;
   SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
-  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, nc * sizeof(uint32_t), st));
+  SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
   *n_kept_out = nk;
-  if (nk == 0) return SWG_OK;
-  uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
-  uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
-  uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
-  uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
-  SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_kept, kpos, kept_list));
-  SWG_KERNEL_CHECK(ctx);
-  const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
-  SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first,
-                                                                  T.qid, T.tid, seq_genome2, n_g2, c_bits, nkey));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
-  SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, C_num));
+  if (nk) {
+    uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
+    uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
+    uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
+    uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, kept, kpos, kept_list));
+    SWG_KERNEL_CHECK(ctx);
+    const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
+    SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
+                                                                    seq_genome2, n_g2, c_bits, nkey));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
+    SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  SWG_LAUNCH(ctx, "chain_uncompact", chain_uncompact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, kept, num, C_kept, C_num));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
@@ -798,11 +887,16 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                                                                             r->n_genome_last, gp_first));
   SWG_KERNEL_CHECK(ctx);
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
-  uint64_t* ch_key = swg_alloc<uint64_t>(ctx, nc);
-  uint64_t* ch_key_tmp = swg_alloc<uint64_t>(ctx, nc);
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* order_tmp = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
+  uint64_t* g_key = swg_alloc<uint64_t>(ctx, n_groups);
+  uint64_t* g_key_tmp = swg_alloc<uint64_t>(ctx, n_groups);
+  uint32_t* g_sorted = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_sorted_tmp = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_first_chain = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_nchains = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_sizes = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_base = swg_alloc<uint32_t>(ctx, n_groups);
   ChainTable& T = B.T;
   T.nc = nc;
   T.qid = swg_alloc<uint32_t>(ctx, nc);
@@ -817,14 +911,20 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   B.C_dpair = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
   const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
-  SWG_LAUNCH(ctx, "chain_list", chain_list_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, B.s_idx, group_first, r->q_id,
-                                                              r->t_id, r->seq_genome_last, r->n_genome_last,
-                                                              genome_pair_major ? gp_first : nullptr, idx_bits, ch_head,
-                                                              ch_key));
+  const unsigned gblk = nblk(n_groups);
+  SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, cpos, (uint32_t)nc,
+                                                           B.s_idx, group_first, r->q_id, r->t_id, r->seq_genome_last,
+                                                           r->n_genome_last, genome_pair_major ? gp_first : nullptr,
+                                                           idx_bits, g_key, g_sorted, g_first_chain, g_nchains));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, order));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &g_key, &g_sorted, &g_key_tmp, &g_sorted_tmp, n_groups, 0, 2 * idx_bits));
+  SWG_LAUNCH(ctx, "group_sizes_sorted", group_sizes_sorted_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_nchains, g_sizes));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &ch_key, &order, &ch_key_tmp, &order_tmp, nc, 0, 2 * idx_bits));
+  SWG_TRY(swg_exclusive_scan_u32(ctx, g_sizes, g_sizes, n_groups, nullptr));
+  SWG_LAUNCH(ctx, "group_base", group_base_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_sizes, g_base));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
+  SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
                                        nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
                                        r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
