@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--pipeline", default="sweep", choices=["sweep", "full", "default"])
     ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="mappings in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=2025)
+    ap.add_argument("--others", type=int, default=2, help="timed steps for the other two flag sets (0 = skip them)")
+    ap.add_argument("--pcie", action="store_true", help="also time swg_filter (host buffers in/out, PCIe included)")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +197,56 @@ def main():
     prof = ctx.profile_table()
     step(with_stats=True)  # untimed: counts for the report
     ctx.synchronize()
+    main_counts = {"in": stats.n_in, "retained": stats.n_retained, "swept": stats.n_swept, "chains": stats.n_chains,
+                   "chains_kept": stats.n_chains_kept, "out": stats.n_out, "device_ms_last_step": stats.device_ms}
+    status_main, chain_main = status.clone(), chain.clone()
+
+    # the other flag sets of the same workload (shorter, same timing discipline), for the record
+    others = {}
+    if args.others > 0:
+        for name in ("sweep", "full", "default"):
+            if name == args.pipeline:
+                continue
+            ocfg = make_config(sw, name).to_c()
+
+            def ostep(with_stats=False):
+                ctx.check(ctx.lib.swg_filter_device(ctx.handle, C.byref(rec), C.byref(ocfg), status.data_ptr(),
+                                                    chain.data_ptr(), C.byref(stats) if with_stats else None))
+            ostep()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.others):
+                ostep()
+            ctx.synchronize()
+            dt = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            ostep(with_stats=True)
+            ctx.synchronize()
+            others[name] = {"value": n * world / (dt / args.others), "unit": "mappings/s", "ms_per_step": dt / args.others * 1e3,
+                            "steps": args.others, "out": stats.n_out, "chains": stats.n_chains, "chains_kept": stats.n_chains_kept}
+
+    pcie = None
+    if args.pcie and rank == 0:
+        import numpy as np
+        host = {k: v.cpu().numpy() for k, v in cols.items()}
+        hrec = _lib.SwgRecords()
+        hrec.n = n
+        for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand",
+                  "seq_genome_last", "seq_genome_two"):
+            setattr(hrec, k, host[k].ctypes.data)
+        hrec.n_seq = hrec.n_genome_last = hrec.n_genome_two = args.genomes
+        hst = np.zeros(n, dtype=np.uint8)
+        hch = np.zeros(n, dtype=np.uint32)
+        hs = _lib.SwgStats()
+        for _ in range(2):
+            t1 = time.perf_counter()
+            ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(hrec), C.byref(ccfg), hst.ctypes.data, hch.ctypes.data, C.byref(hs)))
+            dt = time.perf_counter() - t1
+        pcie = {"value": n / dt, "unit": "mappings/s", "ms": dt * 1e3, "h2d_ms": hs.h2d_ms, "d2h_ms": hs.d2h_ms,
+                "device_ms": hs.device_ms, "note": "swg_filter: pageable host buffers in and out, second call"}
 
     if rank == 0:
         algo = ALGO_BYTES_SWEEP if args.pipeline == "sweep" else ALGO_BYTES_FULL
@@ -207,7 +259,7 @@ def main():
         pipe_achieved = algo * n / (ms_per_step * 1e-3) / 1e9
         cpu, parity = (None, None)
         if args.cpu_sample > 0:
-            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status, chain)
+            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main)
         out = {
             "metric": "PAF mappings/sec through plane-sweep+scaffold filter",
             "value": n * world / (elapsed / args.steps),
@@ -235,8 +287,9 @@ def main():
                          "kernel_ms_per_step": total_kernel_ms / args.steps},
             "cpu_baseline": cpu,
             "parity_vs_oracle_on_sample": parity,
-            "counts": {"in": stats.n_in, "retained": stats.n_retained, "swept": stats.n_swept, "chains": stats.n_chains,
-                       "chains_kept": stats.n_chains_kept, "out": stats.n_out, "device_ms_last_step": stats.device_ms},
+            "counts": main_counts,
+            "other_pipelines": others,
+            "pcie_inclusive": pcie,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
         print(json.dumps(out))

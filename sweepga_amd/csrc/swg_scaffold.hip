@@ -53,6 +53,15 @@ __global__ __launch_bounds__(EW) void compact_indices_kernel(uint64_t n, const u
   if (i < n && f[i]) out[pos[i]] = (uint32_t)i;
 }
 
+__global__ __launch_bounds__(EW) void invert_flags_kernel(uint64_t n, const uint8_t* __restrict__ f, uint8_t* __restrict__ inv,
+                                                          uint32_t* __restrict__ inv32) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) {
+    inv[i] = f[i] ? 0 : 1;
+    inv32[i] = f[i] ? 0u : 1u;
+  }
+}
+
 // ---- sort A -----------------------------------------------------------------------------------------
 // key = (((q * n_seq + t) * 2 + strand) << pos_bits) | q_start      value = original index
 __global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
@@ -164,13 +173,16 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
                                                     const uint32_t* __restrict__ s_qe,
                                                     const uint32_t* __restrict__ s_ts,
                                                     const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                    const uint32_t* __restrict__ dense_list, uint32_t n_dense,
                                                     unsigned long long* bps, uint32_t* __restrict__ pred) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
-  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+  (void)n_groups;
+  for (uint32_t gi = wave_global; gi < n_dense; gi += n_waves) {
+    const uint32_t g = dense_list[gi];
     const uint32_t b = group_begin[g];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
     if (e - b < 2) continue;
@@ -290,6 +302,184 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
       }
       if (lane == 0) pred[best_j] = i;
+    }
+  }
+}
+
+// Groups whose windows are expected to be short (<= 2 * 16 elements) are chained four at a time per wavefront:
+// each 16-lane slice owns one group, with two 16-element register blocks.  Same arithmetic, same order of
+// evaluation as chain_kernel; only the lane layout differs.  The slices of a wavefront advance in lock step,
+// each through its own group.
+constexpr int SL = 16;
+
+__global__ __launch_bounds__(EW) void chain_classify_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                            uint32_t m, const uint32_t* __restrict__ s_qs,
+                                                            const uint32_t* __restrict__ s_qe, uint64_t max_gap,
+                                                            uint8_t* __restrict__ is_dense) {
+  uint32_t g = blockIdx.x * EW + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t b = group_begin[g];
+  const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+  const uint64_t size = e - b;
+  uint8_t dense = 0;
+  if (size >= 2) {
+    // expected window = (typical length + gap) * density; lengths sampled at the group's ends and middle
+    const uint64_t span = (uint64_t)s_qs[e - 1] - (uint64_t)s_qs[b] + 1;
+    const uint32_t mid = b + (uint32_t)(size / 2);
+    const uint64_t len = ((uint64_t)(s_qe[b] - s_qs[b]) + (uint64_t)(s_qe[mid] - s_qs[mid]) + (uint64_t)(s_qe[e - 1] - s_qs[e - 1])) / 3;
+    const double w = (double)size * (double)(len + max_gap) / (double)span;
+    dense = w > (double)SL ? 1 : 0;
+  }
+  is_dense[g] = dense;
+}
+
+__global__ __launch_bounds__(256) void chain_sliced_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                           uint32_t m, const uint64_t* __restrict__ s_grp,
+                                                           const uint32_t* __restrict__ s_qs,
+                                                           const uint32_t* __restrict__ s_qe,
+                                                           const uint32_t* __restrict__ s_ts,
+                                                           const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                           const uint32_t* __restrict__ sparse_list, uint32_t n_sparse,
+                                                           unsigned long long* bps, uint32_t* __restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const int sl = lane & (SL - 1);
+  const int slice_lane0 = lane & ~(SL - 1);
+  const uint32_t slice_global = (blockIdx.x * 256 + threadIdx.x) / SL;
+  const uint32_t n_slices = (gridDim.x * 256) / SL;
+  const uint64_t INF = ~0ull;
+  const uint64_t fifth = max_gap / 5;
+  (void)n_groups;
+  // per-slice state, replicated in the slice's 16 lanes
+  uint32_t gi = slice_global, b = 0, e = 0, i = 0, base = 0;
+  bool minus = false, active = false;
+  ChainBlock A = {0, 0, 0, 0, 0}, B = {0, 0, 0, 0, 0};
+  auto load_block = [&](uint32_t pos) {
+    ChainBlock k;
+    const uint32_t p = pos + sl;
+    if (p < e) {
+      k.qs = s_qs[p];
+      k.qe = s_qe[p];
+      k.ts = s_ts[p];
+      k.te = s_te[p];
+      k.bps = __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      k.qs = k.qe = k.ts = k.te = 0;
+      k.bps = 0;
+    }
+    return k;
+  };
+  auto next_group = [&]() {
+    active = false;
+    while (gi < n_sparse) {
+      const uint32_t g = sparse_list[gi];
+      b = group_begin[g];
+      e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+      if (e - b >= 2) {
+        minus = (s_grp[b] & 1ull) != 0;
+        i = b;
+        base = b;
+        A = load_block(base);
+        B = load_block(base + SL);
+        active = true;
+        return;
+      }
+      gi += n_slices;
+    }
+  };
+  next_group();
+  while (__any(active)) {
+    if (active) {
+      if (i - base == SL) {
+        A = B;
+        base += SL;
+        B = load_block(base + SL);
+      }
+      const int li = (int)(i - base);
+      const int src = slice_lane0 + li;
+      const uint64_t qe_i = __shfl(A.qe, src, 64), ts_i = __shfl(A.ts, src, 64), te_i = __shfl(A.te, src, 64);
+      const uint64_t bound = qe_i + max_gap;
+      uint64_t best_d = INF;
+      uint32_t best_j = NONE;
+      auto consider = [&](uint32_t j, uint64_t qs_j, uint64_t ts_j, uint64_t te_j, uint64_t cur) {
+        uint64_t q_gap, r_gap;
+        if (qs_j >= qe_i) {
+          q_gap = qs_j - qe_i;
+        } else {
+          const uint64_t ov = qe_i - qs_j;
+          q_gap = ov <= fifth ? ov : max_gap + 1;
+        }
+        if (!minus) {
+          if (ts_j >= te_i) {
+            r_gap = ts_j - te_i;
+          } else {
+            const uint64_t ov = te_i - ts_j;
+            r_gap = ov <= fifth ? ov : max_gap + 1;
+          }
+        } else if (ts_i >= te_j) {
+          r_gap = ts_i - te_j;
+        } else {
+          const uint64_t ov = te_j - ts_i;
+          r_gap = ov <= fifth ? ov : max_gap + 1;
+        }
+        if (q_gap <= max_gap && r_gap <= max_gap) {
+          const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
+          if (d < cur && d < best_d) {
+            best_d = d;
+            best_j = j;
+          }
+        }
+      };
+      {
+        const uint32_t j = base + sl;
+        if (sl > li && j < e && (uint64_t)A.qs <= bound) consider(j, A.qs, A.ts, A.te, A.bps);
+      }
+      {
+        const uint32_t j = base + SL + sl;
+        if (j < e && (uint64_t)B.qs <= bound) consider(j, B.qs, B.ts, B.te, B.bps);
+      }
+      // window past the two register blocks: global memory, 16 lanes at a time
+      if (base + 2 * SL < e && (uint64_t)__shfl(B.qs, slice_lane0 + SL - 1, 64) <= bound) {
+        for (uint32_t j0 = base + 2 * SL; j0 < e; j0 += SL) {
+          const uint32_t jj = j0 + sl;
+          bool in = jj < e;
+          uint64_t qs_j = 0;
+          if (in) {
+            qs_j = s_qs[jj];
+            in = qs_j <= bound;
+          }
+          if (in)
+            consider(jj, qs_j, s_ts[jj], s_te[jj], __hip_atomic_load(&bps[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          const uint64_t bal = __ballot(in);
+          if (((bal >> slice_lane0) & ((1ull << SL) - 1)) == 0) break;  // sorted by q_start (paf_filter.rs:794-796)
+        }
+      }
+      // slice minimum: d, ties to the smaller j
+#pragma unroll
+      for (int o = SL / 2; o > 0; o >>= 1) {
+        const uint64_t od = __shfl_xor(best_d, o, 64);
+        const uint32_t oj = __shfl_xor(best_j, o, 64);
+        if (od < best_d || (od == best_d && oj < best_j)) {
+          best_d = od;
+          best_j = oj;
+        }
+      }
+      if (best_j != NONE) {
+        const uint32_t lj = best_j - base;
+        if (lj < (uint32_t)SL) {
+          if ((uint32_t)sl == lj) A.bps = best_d;
+        } else if (lj < 2u * SL) {
+          if ((uint32_t)sl == lj - SL) B.bps = best_d;
+        } else {
+          if (sl == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
+        }
+        if (sl == 0) pred[best_j] = i;
+      }
+      ++i;
+      if (i + 1 >= e) {
+        gi += n_slices;
+        next_group();
+      }
     }
   }
 }
@@ -836,14 +1026,47 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
   SWG_KERNEL_CHECK(ctx);
   {
-    const uint64_t waves_needed = n_groups;
-    uint64_t blocks = (waves_needed + 3) / 4;
-    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-    if (blocks > max_blocks) blocks = max_blocks;
-    if (blocks == 0) blocks = 1;
-    SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp, s_qs,
-                                                                s_qe, s_ts, s_te, max_gap, bps, pred));
+    // short-window groups: four per wavefront (16-lane slices); the rest: one wavefront each
+    uint8_t* is_dense = swg_alloc<uint8_t>(ctx, n_groups);
+    uint8_t* is_sparse = swg_alloc<uint8_t>(ctx, n_groups);
+    uint32_t* cf32 = swg_alloc<uint32_t>(ctx, n_groups);
+    uint32_t* cpos_d = swg_alloc<uint32_t>(ctx, n_groups);
+    uint32_t* dense_list = swg_alloc<uint32_t>(ctx, n_groups);
+    uint32_t* sparse_list = swg_alloc<uint32_t>(ctx, n_groups);
+    uint64_t* d_nd = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "chain_classify", chain_classify_kernel<<<nblk(n_groups), EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs,
+                                                                               s_qe, max_gap, is_dense));
     SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, cf32));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_groups, d_nd));
+    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, cpos_d, dense_list));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t n_dense = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_nd, &n_dense, 1));
+    const uint64_t n_sparse = n_groups - n_dense;
+    SWG_LAUNCH(ctx, "invert_flags", invert_flags_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, is_sparse, cf32));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_groups, nullptr));
+    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_sparse, cpos_d, sparse_list));
+    SWG_KERNEL_CHECK(ctx);
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (n_sparse) {
+      uint64_t blocks = (n_sparse + 15) / 16;
+      if (blocks > max_blocks) blocks = max_blocks;
+      SWG_LAUNCH(ctx, "chain_sliced", chain_sliced_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp,
+                                                                                s_qs, s_qe, s_ts, s_te, max_gap, sparse_list,
+                                                                                (uint32_t)n_sparse, bps, pred));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    if (n_dense) {
+      uint64_t blocks = (n_dense + 3) / 4;
+      if (blocks > max_blocks) blocks = max_blocks;
+      SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp, s_qs, s_qe,
+                                                                  s_ts, s_te, max_gap, dense_list, (uint32_t)n_dense, bps, pred));
+      SWG_KERNEL_CHECK(ctx);
+    }
   }
   // ---- labelling by pointer jumping
   SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<nblk(m), EW, 0, st>>>(m, pred, hd));
