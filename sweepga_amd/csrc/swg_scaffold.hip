@@ -310,6 +310,48 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
 // each 16-lane slice owns one group, with two 16-element register blocks.  Same arithmetic, same order of
 // evaluation as chain_kernel; only the lane layout differs.  The slices of a wavefront advance in lock step,
 // each through its own group.
+// Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
+// q_end of the group by more than the gap -- no (i, j) pair of the reference's window test
+// (`q_start[j] <= q_end[i] + gap`, paf_filter.rs:786-796) can then straddle p, so the greedy on either side is
+// independent.  One wavefront per group, 64 elements per step, running maximum carried along.
+__global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                        uint32_t m, const uint32_t* __restrict__ s_qs,
+                                                        const uint32_t* __restrict__ s_qe, uint64_t max_gap,
+                                                        uint32_t* __restrict__ unit_flag) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * EW) >> 6;
+  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+    const uint32_t b = group_begin[g];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+    uint32_t carry = 0;  // max q_end over [b, p0)
+    for (uint32_t p0 = b; p0 < e; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      const uint32_t qe = p < e ? s_qe[p] : 0u;
+      uint32_t inc = qe;  // inclusive running max inside the stripe
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d && t > inc) inc = t;
+      }
+      uint32_t before = __shfl_up(inc, 1, 64);  // max over earlier lanes of the stripe
+      if (lane == 0) before = 0;
+      if (carry > before) before = carry;
+      uint64_t lim = (uint64_t)before + max_gap;
+      if (lim < max_gap) lim = ~0ull;  // saturate
+      if (p < e) unit_flag[p] = (p == b || (uint64_t)s_qs[p] > lim) ? 1u : 0u;
+      const uint32_t last = __shfl(inc, 63, 64);
+      if (last > carry) carry = last;
+    }
+  }
+}
+__global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
+                                                        const uint32_t* __restrict__ unit_excl,
+                                                        uint32_t* __restrict__ unit_begin) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m && unit_flag[p]) unit_begin[unit_excl[p]] = (uint32_t)p;
+}
+
 constexpr int SL = 16;
 
 __global__ __launch_bounds__(EW) void chain_classify_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
@@ -1026,36 +1068,56 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
   SWG_KERNEL_CHECK(ctx);
   {
-    // short-window groups: four per wavefront (16-lane slices); the rest: one wavefront each
-    uint8_t* is_dense = swg_alloc<uint8_t>(ctx, n_groups);
-    uint8_t* is_sparse = swg_alloc<uint8_t>(ctx, n_groups);
-    uint32_t* cf32 = swg_alloc<uint32_t>(ctx, n_groups);
-    uint32_t* cpos_d = swg_alloc<uint32_t>(ctx, n_groups);
-    uint32_t* dense_list = swg_alloc<uint32_t>(ctx, n_groups);
-    uint32_t* sparse_list = swg_alloc<uint32_t>(ctx, n_groups);
+    // units = groups cut where no window can straddle; short-window units go four per wavefront (16-lane
+    // slices), the rest one wavefront each
+    uint32_t* unit_flag = swg_alloc<uint32_t>(ctx, m);
+    uint32_t* unit_excl = swg_alloc<uint32_t>(ctx, m);
+    uint64_t* d_nu = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    {
+      uint64_t blocks = (n_groups + 3) / 4;
+      const uint64_t mb = (uint64_t)ctx->num_cu * 16;
+      if (blocks > mb) blocks = mb;
+      SWG_LAUNCH(ctx, "chain_cuts", chain_cuts_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs, s_qe,
+                                                                           max_gap, unit_flag));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    SWG_TRY(swg_exclusive_scan_u32(ctx, unit_flag, unit_excl, m, d_nu));
+    uint64_t n_units = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_nu, &n_units, 1));
+    uint32_t* unit_begin = swg_alloc<uint32_t>(ctx, n_units);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
+    SWG_KERNEL_CHECK(ctx);
+    uint8_t* is_dense = swg_alloc<uint8_t>(ctx, n_units);
+    uint8_t* is_sparse = swg_alloc<uint8_t>(ctx, n_units);
+    uint32_t* cf32 = swg_alloc<uint32_t>(ctx, n_units);
+    uint32_t* cpos_d = swg_alloc<uint32_t>(ctx, n_units);
+    uint32_t* dense_list = swg_alloc<uint32_t>(ctx, n_units);
+    uint32_t* sparse_list = swg_alloc<uint32_t>(ctx, n_units);
     uint64_t* d_nd = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "chain_classify", chain_classify_kernel<<<nblk(n_groups), EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs,
+    SWG_LAUNCH(ctx, "chain_classify", chain_classify_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_qs,
                                                                                s_qe, max_gap, is_dense));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, cf32));
+    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, cf32));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_groups, d_nd));
-    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, cpos_d, dense_list));
+    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_units, d_nd));
+    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, cpos_d, dense_list));
     SWG_KERNEL_CHECK(ctx);
     uint64_t n_dense = 0;
     SWG_TRY(swg_read_scalars(ctx, d_nd, &n_dense, 1));
-    const uint64_t n_sparse = n_groups - n_dense;
-    SWG_LAUNCH(ctx, "invert_flags", invert_flags_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_dense, is_sparse, cf32));
+    const uint64_t n_sparse = n_units - n_dense;
+    SWG_LAUNCH(ctx, "invert_flags", invert_flags_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, is_sparse, cf32));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_groups, nullptr));
-    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, is_sparse, cpos_d, sparse_list));
+    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_units, nullptr));
+    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_sparse, cpos_d, sparse_list));
     SWG_KERNEL_CHECK(ctx);
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
     if (n_sparse) {
       uint64_t blocks = (n_sparse + 15) / 16;
       if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain_sliced", chain_sliced_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp,
+      SWG_LAUNCH(ctx, "chain_sliced", chain_sliced_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
                                                                                 s_qs, s_qe, s_ts, s_te, max_gap, sparse_list,
                                                                                 (uint32_t)n_sparse, bps, pred));
       SWG_KERNEL_CHECK(ctx);
@@ -1063,7 +1125,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if (n_dense) {
       uint64_t blocks = (n_dense + 3) / 4;
       if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_grp, s_qs, s_qe,
+      SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp, s_qs, s_qe,
                                                                   s_ts, s_te, max_gap, dense_list, (uint32_t)n_dense, bps, pred));
       SWG_KERNEL_CHECK(ctx);
     }
