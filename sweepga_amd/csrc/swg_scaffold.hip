@@ -16,6 +16,8 @@
 //   numbering   chain_N in plane_sweep_scaffolds' output order (genome pair -> chromosome pair -> index)
 //   anchors     members of kept chains; inversion capture (paf_filter.rs:535-597)
 //   rescue      per chromosome pair, anchors sorted by query centre, window search (paf_filter.rs:599-747)
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "swg_log.h"
@@ -357,7 +359,7 @@ constexpr int SL = 16;
 __global__ __launch_bounds__(EW) void chain_classify_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
                                                             uint32_t m, const uint32_t* __restrict__ s_qs,
                                                             const uint32_t* __restrict__ s_qe, uint64_t max_gap,
-                                                            uint8_t* __restrict__ is_dense) {
+                                                            int force_mode, uint8_t* __restrict__ is_dense) {
   uint32_t g = blockIdx.x * EW + threadIdx.x;
   if (g >= n_groups) return;
   const uint32_t b = group_begin[g];
@@ -370,7 +372,9 @@ __global__ __launch_bounds__(EW) void chain_classify_kernel(uint32_t n_groups, c
     const uint32_t mid = b + (uint32_t)(size / 2);
     const uint64_t len = ((uint64_t)(s_qe[b] - s_qs[b]) + (uint64_t)(s_qe[mid] - s_qs[mid]) + (uint64_t)(s_qe[e - 1] - s_qs[e - 1])) / 3;
     const double w = (double)size * (double)(len + max_gap) / (double)span;
-    dense = w > (double)SL ? 1 : 0;
+    dense = (w > (double)SL || size > 1024) ? 1 : 0;  // long units: one wavefront each (128-element register window)
+    if (force_mode == 1) dense = 1;
+    if (force_mode == 2) dense = 0;
   }
   is_dense[g] = dense;
 }
@@ -1098,7 +1102,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     uint64_t* d_nd = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "chain_classify", chain_classify_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_qs,
-                                                                               s_qe, max_gap, is_dense));
+                                                                               s_qe, max_gap, getenv("SWG_CHAIN_MODE") ? atoi(getenv("SWG_CHAIN_MODE")) : 0, is_dense));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, cf32));
     SWG_KERNEL_CHECK(ctx);
@@ -1108,6 +1112,10 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     uint64_t n_dense = 0;
     SWG_TRY(swg_read_scalars(ctx, d_nd, &n_dense, 1));
     const uint64_t n_sparse = n_units - n_dense;
+    if (getenv("SWG_DEBUG"))
+      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu dense=%llu sparse=%llu\n", (unsigned long long)m,
+              (unsigned long long)n_groups, (unsigned long long)n_units, (unsigned long long)n_dense,
+              (unsigned long long)n_sparse);
     SWG_LAUNCH(ctx, "invert_flags", invert_flags_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, is_sparse, cf32));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_units, nullptr));
