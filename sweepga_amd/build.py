@@ -21,17 +21,35 @@ def stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sweepga_gpu.h")]
+    deps = [d for d in deps if not os.path.isdir(d)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+CLI_SRC = os.path.join(CSRC, "host", "sweepga_gpu_cli.cpp")
+CLI = os.path.join(HERE, "bin", "sweepga-gpu")
+
+
+def build_cli(force=False, verbose=False):
+    """The C++ host (reference-compatible command line) linked against libsweepga_gpu.so."""
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(LIB)):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", CLI, CLI_SRC, "-L", HERE, "-lsweepga_gpu",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    return CLI
+
+
+def build(force=False, verbose=False):
+    if force or stale():
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
+        cmd += [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    build_cli(force=force, verbose=verbose)
     return LIB
 
 

@@ -73,3 +73,23 @@ def records_to_meta(rec):
                               int(rec.ts[i]), int(rec.te[i]), int(rec.block_length[i]), float(rec.identity[i]),
                               int(rec.matches[i]), int(rec.block_length[i]), chr(int(rec.strand[i]))))
     return out
+
+
+def records_to_paf(rng, rec, junk_lines=True):
+    """orc.Records -> PAF text.  Identity is carried the way real PAFs do it: a third of the lines by the
+    matches/block columns only, a third with an extended CIGAR (cg:Z:<m>=<x>X, which overrides column 10),
+    a third with a dv:f: tag; plus a few malformed / short lines that must be skipped but still counted."""
+    out = []
+    for i in range(len(rec)):
+        m, b = int(rec.matches[i]), int(rec.block_length[i])
+        line = [rec.qname[i], "1000000", str(int(rec.qs[i])), str(int(rec.qe[i])), chr(int(rec.strand[i])), rec.tname[i],
+                "1000000", str(int(rec.ts[i])), str(int(rec.te[i])), str(m), str(b), "60"]
+        k = int(rng.integers(0, 3))
+        if k == 1 and m > 0:
+            line += ["NM:i:%d" % (b - m), "cg:Z:%d=%dX" % (m, b - m)]
+        elif k == 2:
+            line += ["dv:f:%.4f" % (1.0 - m / max(b, 1)), "tp:A:P"]
+        out.append("\t".join(line))
+        if junk_lines and rng.random() < 0.01:
+            out.append(rng.choice(["", "# comment", "too\tfew\tfields", "q\t1\tx\ty\t+\tt\t1\t0\t0\tz\t\t0"]))
+    return "\n".join(out) + "\n"

@@ -1,0 +1,48 @@
+"""End to end through the C++ host: `sweepga-gpu <paf> --output-file ...` must write byte-for-byte what the
+oracle's `sweepga-ref` (CPU restatement of the reference binary's filter path) writes, for the same flags."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import gen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FLAG_SETS = [
+    [],                                                                   # CLI defaults
+    ["--num-mappings", "1:1", "--scaffold-jump", "0"],                    # BASELINE config "sweep"
+    ["--num-mappings", "1:1", "--scaffold-filter", "1:1", "--scaffold-dist", "20000"],   # "full"
+    ["--num-mappings", "1", "--overlap", "0.5", "--scaffold-jump", "10k", "--scaffold-mass", "2k", "--scaffold-dist", "5k"],
+    ["--num-mappings", "2:3", "--scoring", "length-ani", "--scaffold-jump", "20000", "--scaffold-mass", "1000",
+     "--scaffold-filter", "2:1", "--scaffold-overlap", "0.3", "--min-aln-length", "200", "--min-aln-identity", "80"],
+    ["--self", "--scaffolds-only", "--scaffold-jump", "30k", "--scaffold-mass", "5k", "--scoring", "matches"],
+    ["--scoring", "ani", "--num-mappings", "1:many", "--scaffold-jump", "0", "--min-aln-identity", "0.9"],
+]
+
+
+@pytest.fixture(scope="module")
+def bins():
+    from sweepga_amd import build
+    return build.CLI, os.path.join(ROOT, "oracle", "sweepga-ref")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cli_output_byte_identical(bins, tmp_path, seed):
+    cli, ref = bins
+    rng = np.random.default_rng(4242 + seed)
+    n = int(rng.choice([300, 5000, 40_000]))
+    rec = gen.random_records(rng, n, n_genomes=int(rng.integers(2, 5)), chrs_per_genome=int(rng.integers(1, 4)),
+                             span=int(rng.choice([200_000, 2_000_000])), pansn=bool(seed % 2 == 0))
+    paf = tmp_path / "in.paf"
+    paf.write_text(gen.records_to_paf(rng, rec))
+    for k, flags in enumerate(FLAG_SETS):
+        o1, o2 = tmp_path / f"gpu{k}.paf", tmp_path / f"ref{k}.paf"
+        r = subprocess.run([cli, str(paf), "--output-file", str(o1), "--quiet", *flags], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        subprocess.check_call([ref, str(paf), "--output-file", str(o2), *flags])
+        a, b = o1.read_bytes(), o2.read_bytes()
+        assert a == b, (flags, len(a), len(b))
+    assert os.path.getsize(tmp_path / "gpu0.paf") > 0
