@@ -153,59 +153,169 @@ __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint
 }
 
 // ---- best-buddy chaining (paf_filter.rs:784-851) -----------------------------------------------------------
-// One wavefront per (q, t, strand) group.  The outer loop over i is the reference's sequential greedy
-// (later i read best_pred_score[] written by earlier i); the inner loop over j runs on the 64 lanes.
-// The next 128 elements after the block start live in registers (two 64-element blocks, one element per
-// lane and block, including their best_pred_score), so a step is: read lane i's row with v_readlane,
-// evaluate the two blocks, wave-min, update one lane's register.  Only windows reaching past those 128
-// elements touch memory: their best_pred_score entries are read/written in global memory with agent-scope
-// atomics (served by the XCD's L2, never a stale L1 line), the store drained before the next step.
-struct ChainBlock {
-  uint32_t qs, qe, ts, te;
-  uint64_t bps;
-};
+// The reference's greedy is sequential in i (later i read best_pred_score[] written by earlier i), but the
+// expensive part of a step -- the distance d(i, j) to every j of the window -- does not depend on that state.
+// So the work is split:
+//   chain_candidates : parallel, one thread per i: the KC smallest (d, j) over the valid j of i's window
+//                      (both gaps within the limit), sorted by (d, j); plus how many valid j there were.
+//   chain_select     : one wavefront per unit (a group cut where no window can straddle, chain_cuts), sequential
+//                      in i: i takes the first of its candidates with d < best_pred_score[j] -- which is the
+//                      reference's choice, because any valid j outside the list is worse than every listed one.
+//                      best_pred_score of the next 128 elements lives in registers (one element per lane and
+//                      block); a step is a handful of v_readlane + scalar compares.  Only when all KC listed
+//                      candidates are blocked AND the window held more than KC valid j is the window
+//                      re-evaluated in full (wave-parallel, global memory).
+constexpr int KC = 4;
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+  return ((uint64_t)readlane_u32((uint32_t)(v >> 32), l) << 32) | readlane_u32((uint32_t)v, l);
+}
 
-__global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                    uint32_t m, const uint64_t* __restrict__ s_grp,
-                                                    const uint32_t* __restrict__ s_qs,
-                                                    const uint32_t* __restrict__ s_qe,
-                                                    const uint32_t* __restrict__ s_ts,
-                                                    const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                    const uint32_t* __restrict__ dense_list, uint32_t n_dense,
-                                                    unsigned long long* bps, uint32_t* __restrict__ pred) {
+// d(i, j) of paf_filter.rs:798-836; returns false when a gap exceeds the limit
+__device__ __forceinline__ bool chain_dist(bool minus, uint64_t qe_i, uint64_t ts_i, uint64_t te_i, uint64_t qs_j,
+                                           uint64_t ts_j, uint64_t te_j, uint64_t max_gap, uint64_t fifth, uint64_t* d) {
+  uint64_t q_gap, r_gap;
+  if (qs_j >= qe_i) {
+    q_gap = qs_j - qe_i;
+  } else {
+    const uint64_t ov = qe_i - qs_j;
+    q_gap = ov <= fifth ? ov : max_gap + 1;
+  }
+  if (!minus) {
+    if (ts_j >= te_i) {
+      r_gap = ts_j - te_i;
+    } else {
+      const uint64_t ov = te_i - ts_j;
+      r_gap = ov <= fifth ? ov : max_gap + 1;
+    }
+  } else if (ts_i >= te_j) {
+    r_gap = ts_i - te_j;
+  } else {
+    const uint64_t ov = te_j - ts_i;
+    r_gap = ov <= fifth ? ov : max_gap + 1;
+  }
+  if (q_gap > max_gap || r_gap > max_gap) return false;
+  *d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
+  return true;
+}
+
+__global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                              const uint32_t* __restrict__ group_begin,
+                                                              uint32_t n_groups, const uint64_t* __restrict__ s_grp,
+                                                              const uint32_t* __restrict__ s_qs,
+                                                              const uint32_t* __restrict__ s_qe,
+                                                              const uint32_t* __restrict__ s_ts,
+                                                              const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                              unsigned long long* __restrict__ c_d,  // [KC][m]
+                                                              uint32_t* __restrict__ c_j,            // [KC][m]
+                                                              uint32_t* __restrict__ c_n) {          // valid count (saturating)
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t g = s_gidx[p];
+  const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
+  const bool minus = (s_grp[p] & 1ull) != 0;
+  const uint64_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
+  const uint64_t bound = qe_i + max_gap, fifth = max_gap / 5;
+  uint64_t bd[KC];
+  uint32_t bj[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    bd[k] = ~0ull;
+    bj[k] = NONE;
+  }
+  uint32_t count = 0;
+  for (uint32_t j = (uint32_t)p + 1; j < e; ++j) {
+    const uint64_t qs_j = s_qs[j];
+    if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
+    uint64_t d;
+    if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
+    if (count < 0xffffffffu) ++count;
+    // insert (d, j) keeping (d asc, j asc); j only grows, so strict `<` keeps earlier j first on ties
+    if (d < bd[KC - 1]) {
+      uint64_t cd = d;
+      uint32_t cj = j;
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        if (cd < bd[k]) {
+          const uint64_t td = bd[k];
+          const uint32_t tj = bj[k];
+          bd[k] = cd;
+          bj[k] = cj;
+          cd = td;
+          cj = tj;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    c_d[(uint64_t)k * m + p] = bd[k];
+    c_j[(uint64_t)k * m + p] = bj[k];
+  }
+  c_n[p] = count;
+}
+
+struct SelBlock {
+  uint64_t d[KC];
+  uint32_t j[KC];
+  uint32_t n;
+  uint64_t bps;
+};
+
+__global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                           uint32_t m, const uint64_t* __restrict__ s_grp,
+                                                           const uint32_t* __restrict__ s_qs,
+                                                           const uint32_t* __restrict__ s_qe,
+                                                           const uint32_t* __restrict__ s_ts,
+                                                           const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                           const unsigned long long* __restrict__ c_d,
+                                                           const uint32_t* __restrict__ c_j,
+                                                           const uint32_t* __restrict__ c_n, unsigned long long* bps,
+                                                           uint32_t* __restrict__ pred) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
-  (void)n_groups;
-  for (uint32_t gi = wave_global; gi < n_dense; gi += n_waves) {
-    const uint32_t g = dense_list[gi];
-    const uint32_t b = group_begin[g];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+  for (uint32_t u = wave_global; u < n_units; u += n_waves) {
+    const uint32_t b = unit_begin[u];
+    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
     if (e - b < 2) continue;
     const bool minus = (s_grp[b] & 1ull) != 0;
     auto load_block = [&](uint32_t pos) {
-      ChainBlock k;
+      SelBlock k;
       const uint32_t p = pos + lane;
       if (p < e) {
-        k.qs = s_qs[p];
-        k.qe = s_qe[p];
-        k.ts = s_ts[p];
-        k.te = s_te[p];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          k.d[c] = c_d[(uint64_t)c * m + p];
+          k.j[c] = c_j[(uint64_t)c * m + p];
+        }
+        k.n = c_n[p];
         k.bps = __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        k.qs = k.qe = k.ts = k.te = 0;
-        k.bps = 0;  // never a candidate (j < e fails first)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          k.d[c] = INF;
+          k.j[c] = NONE;
+        }
+        k.n = 0;
+        k.bps = 0;
       }
       return k;
     };
     uint32_t base = b;
-    ChainBlock A = load_block(base), B = load_block(base + 64);
+    SelBlock A = load_block(base), B = load_block(base + 64);
+    // best_pred_score[j] as the sequential loop sees it now (wave-uniform j)
+    auto current = [&](uint32_t j) -> uint64_t {
+      const uint32_t lj = j - base;
+      if (lj < 64) return readlane_u64(A.bps, (int)lj);
+      if (lj < 128) return readlane_u64(B.bps, (int)(lj - 64));
+      return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     for (uint32_t i = b; i + 1 < e; ++i) {
       if (i - base == 64) {
         A = B;
@@ -213,87 +323,66 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
         B = load_block(base + 64);
       }
       const int li = (int)(i - base);
-      const uint64_t qe_i = readlane_u32(A.qe, li), ts_i = readlane_u32(A.ts, li), te_i = readlane_u32(A.te, li);
-      const uint64_t bound = qe_i + max_gap;
+      const uint32_t nvalid = readlane_u32(A.n, li);
+      if (nvalid == 0) continue;
       uint64_t best_d = INF;
       uint32_t best_j = NONE;
-      // d(i, j) for one candidate; returns false when j is outside the window
-      auto consider = [&](uint32_t j, uint64_t qs_j, uint64_t ts_j, uint64_t te_j, uint64_t cur) {
-        uint64_t q_gap, r_gap;
-        if (qs_j >= qe_i) {
-          q_gap = qs_j - qe_i;
-        } else {
-          const uint64_t ov = qe_i - qs_j;
-          q_gap = ov <= fifth ? ov : max_gap + 1;
-        }
-        if (!minus) {
-          if (ts_j >= te_i) {
-            r_gap = ts_j - te_i;
-          } else {
-            const uint64_t ov = te_i - ts_j;
-            r_gap = ov <= fifth ? ov : max_gap + 1;
-          }
-        } else if (ts_i >= te_j) {
-          r_gap = ts_i - te_j;
-        } else {
-          const uint64_t ov = te_j - ts_i;
-          r_gap = ov <= fifth ? ov : max_gap + 1;
-        }
-        if (q_gap <= max_gap && r_gap <= max_gap) {
-          const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
-          // `d < best_score && d < best_pred_score[j]`; per lane j ascends, so strict `<` keeps the first
-          if (d < cur && d < best_d) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (best_j == NONE && (uint32_t)c < nvalid) {
+          const uint64_t d = readlane_u64(A.d[c], li);
+          const uint32_t j = readlane_u32(A.j[c], li);
+          if (d < current(j)) {
             best_d = d;
             best_j = j;
           }
         }
-      };
-      {
-        const uint32_t j = base + lane;
-        if (lane > li && j < e && (uint64_t)A.qs <= bound) consider(j, A.qs, A.ts, A.te, A.bps);
       }
-      // block B (and beyond) only when its first element is inside the window: q_start is sorted
-      if (base + 64 < e && (uint64_t)readlane_u32(B.qs, 0) <= bound) {
-        const uint32_t j = base + 64 + lane;
-        if (j < e && (uint64_t)B.qs <= bound) consider(j, B.qs, B.ts, B.te, B.bps);
-        // window reaching past the register blocks (dense groups only)
-        if (base + 128 < e && (uint64_t)readlane_u32(B.qs, 63) <= bound) {
-          for (uint32_t j0 = base + 128; j0 < e; j0 += 64) {
-            const uint32_t jj = j0 + lane;
-            bool in = jj < e;
-            uint64_t qs_j = 0;
-            if (in) {
-              qs_j = s_qs[jj];
-              in = qs_j <= bound;
-            }
-            if (in)
-              consider(jj, qs_j, s_ts[jj], s_te[jj],
-                       __hip_atomic_load(&bps[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (!__any(in)) break;  // sorted by q_start (paf_filter.rs:794-796)
+      if (best_j == NONE && nvalid > (uint32_t)KC) {
+        // every listed candidate is blocked and the window held more: evaluate it in full (rare)
+        const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
+        const uint64_t bound = qe_i + max_gap;
+        uint64_t ld = INF;
+        uint32_t lj2 = NONE;
+        for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+          const uint32_t j = j0 + lane;
+          bool in = j < e;
+          uint64_t qs_j = 0;
+          if (in) {
+            qs_j = s_qs[j];
+            in = qs_j <= bound;
           }
+          // this lane's own view of best_pred_score[j] (j differs per lane here); the cross-lane reads are
+          // done by all lanes before any branch
+          const uint32_t rel = in ? j - base : 0u;
+          const uint64_t va = __shfl(A.bps, (int)(rel & 63), 64), vb = __shfl(B.bps, (int)(rel & 63), 64);
+          if (in) {
+            uint64_t d;
+            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) {
+              const uint64_t cur = rel < 64 ? va
+                                   : rel < 128 ? vb
+                                               : __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (d < cur && d < ld) {
+                ld = d;
+                lj2 = j;
+              }
+            }
+          }
+          if (!__any(in)) break;
         }
-      }
-      // minimum d, ties to the smaller j (strict `<` in j order).  Few lanes hold a candidate, so walk the
-      // ballot with scalar compares instead of a 6-step butterfly.
-      uint64_t cand = __ballot(best_j != NONE);
-      if (!cand) continue;
-      {
-        uint64_t bd = INF;
-        uint32_t bj = NONE;
+        uint64_t cand = __ballot(lj2 != NONE);
         while (cand) {
           const int l = __builtin_ctzll(cand);
           cand &= cand - 1;
-          const uint32_t dlo = readlane_u32((uint32_t)best_d, l), dhi = readlane_u32((uint32_t)(best_d >> 32), l);
-          const uint64_t d = ((uint64_t)dhi << 32) | dlo;
-          const uint32_t j = readlane_u32(best_j, l);
-          if (d < bd || (d == bd && j < bj)) {
-            bd = d;
-            bj = j;
+          const uint64_t d = readlane_u64(ld, l);
+          const uint32_t j = readlane_u32(lj2, l);
+          if (d < best_d || (d == best_d && j < best_j)) {
+            best_d = d;
+            best_j = j;
           }
         }
-        best_d = bd;
-        best_j = bj;
       }
+      if (best_j == NONE) continue;
       const uint32_t lj = best_j - base;
       if (lj < 64) {
         if ((uint32_t)lane == lj) A.bps = best_d;
@@ -308,10 +397,6 @@ __global__ __launch_bounds__(256) void chain_kernel(uint32_t n_groups, const uin
   }
 }
 
-// Groups whose windows are expected to be short (<= 2 * 16 elements) are chained four at a time per wavefront:
-// each 16-lane slice owns one group, with two 16-element register blocks.  Same arithmetic, same order of
-// evaluation as chain_kernel; only the lane layout differs.  The slices of a wavefront advance in lock step,
-// each through its own group.
 // Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
 // q_end of the group by more than the gap -- no (i, j) pair of the reference's window test
 // (`q_start[j] <= q_end[i] + gap`, paf_filter.rs:786-796) can then straddle p, so the greedy on either side is
@@ -352,182 +437,6 @@ __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32
                                                         uint32_t* __restrict__ unit_begin) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p < m && unit_flag[p]) unit_begin[unit_excl[p]] = (uint32_t)p;
-}
-
-constexpr int SL = 16;
-
-__global__ __launch_bounds__(EW) void chain_classify_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                            uint32_t m, const uint32_t* __restrict__ s_qs,
-                                                            const uint32_t* __restrict__ s_qe, uint64_t max_gap,
-                                                            int force_mode, uint8_t* __restrict__ is_dense) {
-  uint32_t g = blockIdx.x * EW + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint32_t b = group_begin[g];
-  const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
-  const uint64_t size = e - b;
-  uint8_t dense = 0;
-  if (size >= 2) {
-    // expected window = (typical length + gap) * density; lengths sampled at the group's ends and middle
-    const uint64_t span = (uint64_t)s_qs[e - 1] - (uint64_t)s_qs[b] + 1;
-    const uint32_t mid = b + (uint32_t)(size / 2);
-    const uint64_t len = ((uint64_t)(s_qe[b] - s_qs[b]) + (uint64_t)(s_qe[mid] - s_qs[mid]) + (uint64_t)(s_qe[e - 1] - s_qs[e - 1])) / 3;
-    const double w = (double)size * (double)(len + max_gap) / (double)span;
-    dense = (w > (double)SL || size > 1024) ? 1 : 0;  // long units: one wavefront each (128-element register window)
-    if (force_mode == 1) dense = 1;
-    if (force_mode == 2) dense = 0;
-  }
-  is_dense[g] = dense;
-}
-
-__global__ __launch_bounds__(256) void chain_sliced_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                           uint32_t m, const uint64_t* __restrict__ s_grp,
-                                                           const uint32_t* __restrict__ s_qs,
-                                                           const uint32_t* __restrict__ s_qe,
-                                                           const uint32_t* __restrict__ s_ts,
-                                                           const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                           const uint32_t* __restrict__ sparse_list, uint32_t n_sparse,
-                                                           unsigned long long* bps, uint32_t* __restrict__ pred) {
-  const int lane = threadIdx.x & 63;
-  const int sl = lane & (SL - 1);
-  const int slice_lane0 = lane & ~(SL - 1);
-  const uint32_t slice_global = (blockIdx.x * 256 + threadIdx.x) / SL;
-  const uint32_t n_slices = (gridDim.x * 256) / SL;
-  const uint64_t INF = ~0ull;
-  const uint64_t fifth = max_gap / 5;
-  (void)n_groups;
-  // per-slice state, replicated in the slice's 16 lanes
-  uint32_t gi = slice_global, b = 0, e = 0, i = 0, base = 0;
-  bool minus = false, active = false;
-  ChainBlock A = {0, 0, 0, 0, 0}, B = {0, 0, 0, 0, 0};
-  auto load_block = [&](uint32_t pos) {
-    ChainBlock k;
-    const uint32_t p = pos + sl;
-    if (p < e) {
-      k.qs = s_qs[p];
-      k.qe = s_qe[p];
-      k.ts = s_ts[p];
-      k.te = s_te[p];
-      k.bps = __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      k.qs = k.qe = k.ts = k.te = 0;
-      k.bps = 0;
-    }
-    return k;
-  };
-  auto next_group = [&]() {
-    active = false;
-    while (gi < n_sparse) {
-      const uint32_t g = sparse_list[gi];
-      b = group_begin[g];
-      e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
-      if (e - b >= 2) {
-        minus = (s_grp[b] & 1ull) != 0;
-        i = b;
-        base = b;
-        A = load_block(base);
-        B = load_block(base + SL);
-        active = true;
-        return;
-      }
-      gi += n_slices;
-    }
-  };
-  next_group();
-  while (__any(active)) {
-    if (active) {
-      if (i - base == SL) {
-        A = B;
-        base += SL;
-        B = load_block(base + SL);
-      }
-      const int li = (int)(i - base);
-      const int src = slice_lane0 + li;
-      const uint64_t qe_i = __shfl(A.qe, src, 64), ts_i = __shfl(A.ts, src, 64), te_i = __shfl(A.te, src, 64);
-      const uint64_t bound = qe_i + max_gap;
-      uint64_t best_d = INF;
-      uint32_t best_j = NONE;
-      auto consider = [&](uint32_t j, uint64_t qs_j, uint64_t ts_j, uint64_t te_j, uint64_t cur) {
-        uint64_t q_gap, r_gap;
-        if (qs_j >= qe_i) {
-          q_gap = qs_j - qe_i;
-        } else {
-          const uint64_t ov = qe_i - qs_j;
-          q_gap = ov <= fifth ? ov : max_gap + 1;
-        }
-        if (!minus) {
-          if (ts_j >= te_i) {
-            r_gap = ts_j - te_i;
-          } else {
-            const uint64_t ov = te_i - ts_j;
-            r_gap = ov <= fifth ? ov : max_gap + 1;
-          }
-        } else if (ts_i >= te_j) {
-          r_gap = ts_i - te_j;
-        } else {
-          const uint64_t ov = te_j - ts_i;
-          r_gap = ov <= fifth ? ov : max_gap + 1;
-        }
-        if (q_gap <= max_gap && r_gap <= max_gap) {
-          const uint64_t d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
-          if (d < cur && d < best_d) {
-            best_d = d;
-            best_j = j;
-          }
-        }
-      };
-      {
-        const uint32_t j = base + sl;
-        if (sl > li && j < e && (uint64_t)A.qs <= bound) consider(j, A.qs, A.ts, A.te, A.bps);
-      }
-      {
-        const uint32_t j = base + SL + sl;
-        if (j < e && (uint64_t)B.qs <= bound) consider(j, B.qs, B.ts, B.te, B.bps);
-      }
-      // window past the two register blocks: global memory, 16 lanes at a time
-      if (base + 2 * SL < e && (uint64_t)__shfl(B.qs, slice_lane0 + SL - 1, 64) <= bound) {
-        for (uint32_t j0 = base + 2 * SL; j0 < e; j0 += SL) {
-          const uint32_t jj = j0 + sl;
-          bool in = jj < e;
-          uint64_t qs_j = 0;
-          if (in) {
-            qs_j = s_qs[jj];
-            in = qs_j <= bound;
-          }
-          if (in)
-            consider(jj, qs_j, s_ts[jj], s_te[jj], __hip_atomic_load(&bps[jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          const uint64_t bal = __ballot(in);
-          if (((bal >> slice_lane0) & ((1ull << SL) - 1)) == 0) break;  // sorted by q_start (paf_filter.rs:794-796)
-        }
-      }
-      // slice minimum: d, ties to the smaller j
-#pragma unroll
-      for (int o = SL / 2; o > 0; o >>= 1) {
-        const uint64_t od = __shfl_xor(best_d, o, 64);
-        const uint32_t oj = __shfl_xor(best_j, o, 64);
-        if (od < best_d || (od == best_d && oj < best_j)) {
-          best_d = od;
-          best_j = oj;
-        }
-      }
-      if (best_j != NONE) {
-        const uint32_t lj = best_j - base;
-        if (lj < (uint32_t)SL) {
-          if ((uint32_t)sl == lj) A.bps = best_d;
-        } else if (lj < 2u * SL) {
-          if ((uint32_t)sl == lj - SL) B.bps = best_d;
-        } else {
-          if (sl == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
-        }
-        if (sl == 0) pred[best_j] = i;
-      }
-      ++i;
-      if (i + 1 >= e) {
-        gi += n_slices;
-        next_group();
-      }
-    }
-  }
 }
 
 // ---- chain labelling ---------------------------------------------------------------------------------------
@@ -1093,48 +1002,23 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
     SWG_KERNEL_CHECK(ctx);
-    uint8_t* is_dense = swg_alloc<uint8_t>(ctx, n_units);
-    uint8_t* is_sparse = swg_alloc<uint8_t>(ctx, n_units);
-    uint32_t* cf32 = swg_alloc<uint32_t>(ctx, n_units);
-    uint32_t* cpos_d = swg_alloc<uint32_t>(ctx, n_units);
-    uint32_t* dense_list = swg_alloc<uint32_t>(ctx, n_units);
-    uint32_t* sparse_list = swg_alloc<uint32_t>(ctx, n_units);
-    uint64_t* d_nd = swg_alloc<uint64_t>(ctx, 1);
+    unsigned long long* c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
+    uint32_t* c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
+    uint32_t* c_n = swg_alloc<uint32_t>(ctx, m);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "chain_classify", chain_classify_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_qs,
-                                                                               s_qe, max_gap, getenv("SWG_CHAIN_MODE") ? atoi(getenv("SWG_CHAIN_MODE")) : 0, is_dense));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, cf32));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_units, d_nd));
-    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, cpos_d, dense_list));
-    SWG_KERNEL_CHECK(ctx);
-    uint64_t n_dense = 0;
-    SWG_TRY(swg_read_scalars(ctx, d_nd, &n_dense, 1));
-    const uint64_t n_sparse = n_units - n_dense;
     if (getenv("SWG_DEBUG"))
-      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu dense=%llu sparse=%llu\n", (unsigned long long)m,
-              (unsigned long long)n_groups, (unsigned long long)n_units, (unsigned long long)n_dense,
-              (unsigned long long)n_sparse);
-    SWG_LAUNCH(ctx, "invert_flags", invert_flags_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_dense, is_sparse, cf32));
+      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
+              (unsigned long long)n_groups, (unsigned long long)n_units);
+    SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
+                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, cf32, cpos_d, n_units, nullptr));
-    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_sparse, cpos_d, sparse_list));
-    SWG_KERNEL_CHECK(ctx);
-    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-    if (n_sparse) {
-      uint64_t blocks = (n_sparse + 15) / 16;
+    {
+      uint64_t blocks = (n_units + 3) / 4;
+      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
       if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain_sliced", chain_sliced_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
-                                                                                s_qs, s_qe, s_ts, s_te, max_gap, sparse_list,
-                                                                                (uint32_t)n_sparse, bps, pred));
-      SWG_KERNEL_CHECK(ctx);
-    }
-    if (n_dense) {
-      uint64_t blocks = (n_dense + 3) / 4;
-      if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain", chain_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp, s_qs, s_qe,
-                                                                  s_ts, s_te, max_gap, dense_list, (uint32_t)n_dense, bps, pred));
+      SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
+                                                                                s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n,
+                                                                                bps, pred));
       SWG_KERNEL_CHECK(ctx);
     }
   }
