@@ -252,12 +252,21 @@ __global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __r
 #pragma unroll 4
     for (int r = 0; r < OS_ITEMS; ++r) {
       const uint64_t i = base + (uint64_t)r * OS_THREADS + threadIdx.x;
-      if (i < n) {
-        const uint64_t k = keys[i];
-        for (int p = 0; p < npasses; ++p) {
-          const int shift = begin_bit + 8 * p;
-          const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
-          atomicAdd(&h[p][(uint32_t)(k >> shift) & ((1u << bits) - 1u)], 1u);
+      const bool valid = i < n;
+      const uint64_t k = valid ? keys[i] : 0ull;
+      const uint64_t vmask = __ballot(valid);
+      for (int p = 0; p < npasses; ++p) {
+        const int shift = begin_bit + 8 * p;
+        const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+        const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
+        // high digits are usually the same for a whole wavefront (sorted-ish / segment bits): one add then,
+        // instead of 64 serialised LDS atomics on one bin
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        const bool uniform = __ballot(valid && d != d0) == 0 && (vmask & 1ull);
+        if (uniform) {
+          if ((threadIdx.x & 63) == 0) atomicAdd(&h[p][d0], (uint32_t)__popcll(vmask));
+        } else if (valid) {
+          atomicAdd(&h[p][d], 1u);
         }
       }
     }
@@ -286,8 +295,7 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
                                                               uint32_t* __restrict__ vals_out, uint64_t n, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ gbase,
                                                               uint32_t* status, uint32_t* ticket) {
-  __shared__ uint64_t lkeys[OS_TILE];
-  __shared__ uint32_t lvals[OS_TILE];
+  __shared__ uint64_t lkeys[OS_TILE];  // staging for the keys, then reused (as u32) for the values
   __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
   __shared__ uint32_t tile_excl[RS_RADIX];
   __shared__ uint32_t dst_base[RS_RADIX];
@@ -375,29 +383,41 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
     dst_base[tid] = gbase[tid] + excl - ex;
   }
   __syncthreads();
-  // ---- reorder the tile in LDS
+  // ---- reorder the tile in LDS: keys first, then the values through the same buffer
+  uint32_t pos[OS_ITEMS];
 #pragma unroll
   for (int r = 0; r < OS_ITEMS; ++r) {
     const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (i < n) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-      const uint32_t pos = tile_excl[d] + cnt[wave][d] + rank[r];
-      lkeys[pos] = key[r];
-      lvals[pos] = val[r];
-    }
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    pos[r] = tile_excl[d] + cnt[wave][d] + rank[r];
+    if (i < n) lkeys[pos[r]] = key[r];
   }
   __syncthreads();
   const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+  uint32_t dst[OS_ITEMS];
 #pragma unroll
   for (int r = 0; r < OS_ITEMS; ++r) {
     const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    dst[r] = 0;
     if (p < tile_n) {
       const uint64_t k = lkeys[p];
       const uint32_t d = (uint32_t)(k >> shift) & mask;
-      const uint32_t o = dst_base[d] + p;
-      keys_out[o] = k;
-      vals_out[o] = lvals[p];
+      dst[r] = dst_base[d] + p;
+      keys_out[dst[r]] = k;
     }
+  }
+  __syncthreads();
+  uint32_t* lvals = reinterpret_cast<uint32_t*>(lkeys);
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (i < n) lvals[pos[r]] = val[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    if (p < tile_n) vals_out[dst[r]] = lvals[p];
   }
 }
 
