@@ -166,6 +166,7 @@ __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint
 //                      candidates are blocked AND the window held more than KC valid j is the window
 //                      re-evaluated in full (wave-parallel, global memory).
 constexpr int KC = 4;
+constexpr uint32_t BIG_UNIT = 2048;  // units at least this long take chain_select_big_kernel
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
   for (uint32_t u = wave_global; u < n_units; u += n_waves) {
     const uint32_t b = unit_begin[u];
     const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-    if (e - b < 2) continue;
+    if (e - b < 2 || e - b >= BIG_UNIT) continue;  // long units: chain_select_big_kernel
     const bool minus = (s_grp[b] & 1ull) != 0;
     auto load_block = [&](uint32_t pos) {
       SelBlock k;
@@ -395,6 +396,155 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
       if (lane == 0) pred[best_j] = i;
     }
   }
+}
+
+// Long units (dense data: windows of thousands of elements) keep best_pred_score of the next BIGW positions in an
+// LDS ring instead of registers, so a candidate's score is one LDS read instead of a global round trip.  One
+// wavefront per block; positions beyond the ring still go through global memory (agent-scope atomics), and every
+// time the ring advances by 64 positions the 64 entering slots are loaded from there.
+constexpr int BIGW = 4096;
+
+__global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
+                                                              uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                              uint32_t m, const uint64_t* __restrict__ s_grp,
+                                                              const uint32_t* __restrict__ s_qs,
+                                                              const uint32_t* __restrict__ s_qe,
+                                                              const uint32_t* __restrict__ s_ts,
+                                                              const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                              const unsigned long long* __restrict__ c_d,
+                                                              const uint32_t* __restrict__ c_j,
+                                                              const uint32_t* __restrict__ c_n, unsigned long long* bps,
+                                                              uint32_t* __restrict__ pred) {
+  __shared__ unsigned long long ring[BIGW];
+  const int lane = threadIdx.x;
+  const uint64_t INF = ~0ull;
+  const uint64_t fifth = max_gap / 5;
+  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    const uint32_t u = big_list[bi];
+    const uint32_t b = unit_begin[u];
+    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+    if (e - b < 2) continue;
+    const bool minus = (s_grp[b] & 1ull) != 0;
+    // ring covers positions [base, base + BIGW); slot of position p is p % BIGW
+    uint32_t base = b;
+    for (uint32_t p = b + lane; p < b + BIGW; p += 64)
+      ring[p % BIGW] = p < e ? __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+    __syncthreads();
+    // candidate lists of the 64 elements [base, base + 64), one per lane
+    uint64_t cd[KC];
+    uint32_t cj[KC];
+    uint32_t cn;
+    auto load_cands = [&](uint32_t pos) {
+      const uint32_t p = pos + lane;
+      if (p < e) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          cd[c] = c_d[(uint64_t)c * m + p];
+          cj[c] = c_j[(uint64_t)c * m + p];
+        }
+        cn = c_n[p];
+      } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          cd[c] = INF;
+          cj[c] = NONE;
+        }
+        cn = 0;
+      }
+    };
+    load_cands(base);
+    auto current = [&](uint32_t j) -> uint64_t {
+      if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
+      return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (uint32_t i = b; i + 1 < e; ++i) {
+      if (i - base == 64) {
+        // advance: positions [base, base+64) leave the ring, [base+BIGW, base+BIGW+64) enter it
+        const uint32_t pn = base + BIGW + lane;
+        __syncthreads();
+        ring[pn % BIGW] = pn < e ? __hip_atomic_load(&bps[pn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+        base += 64;
+        load_cands(base);
+        __syncthreads();
+      }
+      const int li = (int)(i - base);
+      const uint32_t nvalid = readlane_u32(cn, li);
+      if (nvalid == 0) continue;
+      uint64_t best_d = INF;
+      uint32_t best_j = NONE;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        if (best_j == NONE && (uint32_t)c < nvalid) {
+          const uint64_t d = readlane_u64(cd[c], li);
+          const uint32_t j = readlane_u32(cj[c], li);
+          if (d < current(j)) {
+            best_d = d;
+            best_j = j;
+          }
+        }
+      }
+      if (best_j == NONE && nvalid > (uint32_t)KC) {
+        // every listed candidate is blocked and the window held more: evaluate it in full
+        const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
+        const uint64_t bound = qe_i + max_gap;
+        uint64_t ld = INF;
+        uint32_t lj2 = NONE;
+        for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+          const uint32_t j = j0 + lane;
+          bool in = j < e;
+          uint64_t qs_j = 0;
+          if (in) {
+            qs_j = s_qs[j];
+            in = qs_j <= bound;
+          }
+          if (in) {
+            uint64_t d;
+            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) {
+              const uint64_t cur = current(j);
+              if (d < cur && d < ld) {
+                ld = d;
+                lj2 = j;
+              }
+            }
+          }
+          if (!__any(in)) break;
+        }
+        uint64_t cand = __ballot(lj2 != NONE);
+        while (cand) {
+          const int l = __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const uint64_t d = readlane_u64(ld, l);
+          const uint32_t j = readlane_u32(lj2, l);
+          if (d < best_d || (d == best_d && j < best_j)) {
+            best_d = d;
+            best_j = j;
+          }
+        }
+      }
+      if (best_j == NONE) continue;
+      if (best_j - base < (uint32_t)BIGW) {
+        if (lane == 0) ring[best_j % BIGW] = best_d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      } else {
+        if (lane == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
+      }
+      if (lane == 0) pred[best_j] = i;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                           uint32_t m, uint8_t* __restrict__ is_big,
+                                                           uint32_t* __restrict__ is_big32) {
+  uint32_t u = blockIdx.x * EW + threadIdx.x;
+  if (u >= n_units) return;
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  const uint8_t f = (e - unit_begin[u]) >= BIG_UNIT ? 1 : 0;
+  is_big[u] = f;
+  is_big32[u] = f;
 }
 
 // Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
@@ -1020,6 +1170,29 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                                                                                 s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n,
                                                                                 bps, pred));
       SWG_KERNEL_CHECK(ctx);
+    }
+    {
+      uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
+      uint32_t* is_big32 = swg_alloc<uint32_t>(ctx, n_units);
+      uint32_t* big_pos = swg_alloc<uint32_t>(ctx, n_units);
+      uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 1);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "unit_big_flag", unit_big_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_big, is_big32));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_exclusive_scan_u32(ctx, is_big32, big_pos, n_units, d_nb));
+      uint64_t n_big = 0;
+      SWG_TRY(swg_read_scalars(ctx, d_nb, &n_big, 1));
+      if (n_big) {
+        uint32_t* big_list = swg_alloc<uint32_t>(ctx, n_big);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_big, big_pos, big_list));
+        SWG_KERNEL_CHECK(ctx);
+        uint64_t blocks = n_big < (uint64_t)ctx->num_cu * 4 ? n_big : (uint64_t)ctx->num_cu * 4;
+        SWG_LAUNCH(ctx, "chain_select_big", chain_select_big_kernel<<<(unsigned)blocks, 64, 0, st>>>(
+                                                (uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin, (uint32_t)m, s_grp, s_qs, s_qe, s_ts,
+                                                s_te, max_gap, c_d, c_j, c_n, bps, pred));
+        SWG_KERNEL_CHECK(ctx);
+      }
     }
   }
   // ---- labelling by pointer jumping

@@ -236,7 +236,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 namespace {
 
 constexpr int OS_THREADS = 256;
-constexpr int OS_ITEMS = 16;
+#ifndef SWG_OS_ITEMS
+#define SWG_OS_ITEMS 16
+#endif
+constexpr int OS_ITEMS = SWG_OS_ITEMS;
 constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
 constexpr int OS_WAVES = OS_THREADS / 64;
 constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_GLOBAL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;

@@ -110,6 +110,27 @@ def test_merge_chains(sw, seed):
         assert np.array_equal(got["weighted_identity"].view(np.uint64), want_wid.view(np.uint64))  # bit-exact f64
 
 
+@pytest.mark.parametrize("seed,n,span,gap", [(1, 20_000, 400_000, 60_000), (2, 30_000, 3_000_000, 50_000), (3, 9_000, 100_000, 5_000)])
+def test_merge_chains_long_dense_units(sw, seed, n, span, gap):
+    """One chromosome pair, windows of hundreds to thousands of elements and no cuts: the long-unit path
+    (LDS ring, full-window fallback when the 4 listed candidates are all blocked)."""
+    rng = np.random.default_rng(seed)
+    rec = gen.random_records(rng, n, n_genomes=2, chrs_per_genome=1, span=span, max_len=6000, self_frac=0.0,
+                             syntenic_frac=0.9)
+    # keep one ordered genome pair only
+    keep = [i for i in range(len(rec)) if rec.qname[i].startswith("g0") and rec.tname[i].startswith("g1")]
+    import dataclasses
+    sub = orc.Records([rec.qname[i] for i in keep], [rec.tname[i] for i in keep],
+                      *(np.ascontiguousarray(getattr(rec, f)[keep]) for f in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")),
+                      np.arange(len(keep), dtype=np.uint64))
+    meta = gen.records_to_meta(sub)
+    got_of, got = sw.merge_mappings_into_chains(meta, gap)
+    want_of, want_cols, want_wid = orc.merge_chains(sub, gap)
+    assert np.array_equal(got_of, want_of), int((got_of != want_of).sum())
+    assert np.array_equal(got["query_end"], want_cols[1]) and np.array_equal(got["target_start"], want_cols[2])
+    assert np.array_equal(got["weighted_identity"].view(np.uint64), want_wid.view(np.uint64))
+
+
 SCAFFOLD_CFGS = [
     dict(),  # CLI defaults: many:many, jump 50k, mass 10k
     dict(scaffold_gap=20_000, min_scaffold_length=3_000, scaffold_filter_mode=0, scaffold_max_deviation=15_000),
