@@ -415,7 +415,8 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
                                                               const uint32_t* __restrict__ c_j,
                                                               const uint32_t* __restrict__ c_n, unsigned long long* bps,
                                                               uint32_t* __restrict__ pred) {
-  __shared__ unsigned long long ring[BIGW];
+  __shared__ unsigned long long ring[BIGW];             // best_pred_score of positions [base, base + BIGW)
+  __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];     // their q_start, t_start, t_end (for full-window passes)
   const int lane = threadIdx.x;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
@@ -427,8 +428,13 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
     const bool minus = (s_grp[b] & 1ull) != 0;
     // ring covers positions [base, base + BIGW); slot of position p is p % BIGW
     uint32_t base = b;
-    for (uint32_t p = b + lane; p < b + BIGW; p += 64)
-      ring[p % BIGW] = p < e ? __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+    for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
+      const bool ok = p < e;
+      ring[p % BIGW] = ok ? __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+      rq[p % BIGW] = ok ? s_qs[p] : 0xffffffffu;
+      rt[p % BIGW] = ok ? s_ts[p] : 0u;
+      re[p % BIGW] = ok ? s_te[p] : 0u;
+    }
     __syncthreads();
     // candidate lists of the 64 elements [base, base + 64), one per lane
     uint64_t cd[KC];
@@ -462,7 +468,13 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
         // advance: positions [base, base+64) leave the ring, [base+BIGW, base+BIGW+64) enter it
         const uint32_t pn = base + BIGW + lane;
         __syncthreads();
-        ring[pn % BIGW] = pn < e ? __hip_atomic_load(&bps[pn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+        {
+          const bool ok = pn < e;
+          ring[pn % BIGW] = ok ? __hip_atomic_load(&bps[pn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+          rq[pn % BIGW] = ok ? s_qs[pn] : 0xffffffffu;
+          rt[pn % BIGW] = ok ? s_ts[pn] : 0u;
+          re[pn % BIGW] = ok ? s_te[pn] : 0u;
+        }
         base += 64;
         load_cands(base);
         __syncthreads();
@@ -492,14 +504,16 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
         for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
           const uint32_t j = j0 + lane;
           bool in = j < e;
+          const bool inring = in && (j - base) < (uint32_t)BIGW;
           uint64_t qs_j = 0;
           if (in) {
-            qs_j = s_qs[j];
+            qs_j = inring ? rq[j % BIGW] : s_qs[j];
             in = qs_j <= bound;
           }
           if (in) {
             uint64_t d;
-            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) {
+            const uint64_t ts_j = inring ? rt[j % BIGW] : s_ts[j], te_j = inring ? re[j % BIGW] : s_te[j];
+            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) {
               const uint64_t cur = current(j);
               if (d < cur && d < ld) {
                 ld = d;
@@ -523,9 +537,9 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
       }
       if (best_j == NONE) continue;
       if (best_j - base < (uint32_t)BIGW) {
+        // one wavefront, program order: the next step's LDS reads follow this write (no fence -- a fence would
+        // also wait for the pred[] store below, a full memory round trip per step)
         if (lane == 0) ring[best_j % BIGW] = best_d;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       } else {
         if (lane == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
