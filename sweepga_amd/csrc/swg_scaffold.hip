@@ -55,15 +55,6 @@ __global__ __launch_bounds__(EW) void compact_indices_kernel(uint64_t n, const u
   if (i < n && f[i]) out[pos[i]] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(EW) void invert_flags_kernel(uint64_t n, const uint8_t* __restrict__ f, uint8_t* __restrict__ inv,
-                                                          uint32_t* __restrict__ inv32) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) {
-    inv[i] = f[i] ? 0 : 1;
-    inv32[i] = f[i] ? 0u : 1u;
-  }
-}
-
 // ---- sort A -----------------------------------------------------------------------------------------
 // key = (((q * n_seq + t) * 2 + strand) << pos_bits) | q_start      value = original index
 __global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
@@ -166,7 +157,7 @@ __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint
 //                      candidates are blocked AND the window held more than KC valid j is the window
 //                      re-evaluated in full (wave-parallel, global memory).
 constexpr int KC = 4;
-constexpr uint32_t BIG_UNIT = 2048;  // units at least this long take chain_select_big_kernel
+constexpr uint32_t BIG_UNIT = 2048;  // units at least this long take the block-speculative path (spec_round_kernel)
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
@@ -212,7 +203,8 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
                                                               const uint32_t* __restrict__ s_te, uint64_t max_gap,
                                                               unsigned long long* __restrict__ c_d,  // [KC][m]
                                                               uint32_t* __restrict__ c_j,            // [KC][m]
-                                                              uint32_t* __restrict__ c_n) {          // valid count (saturating)
+                                                              uint32_t* __restrict__ c_n,            // valid count (saturating)
+                                                              uint32_t* __restrict__ c_ext) {        // window extent in elements
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
   const uint32_t g = s_gidx[p];
@@ -227,10 +219,11 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
     bd[k] = ~0ull;
     bj[k] = NONE;
   }
-  uint32_t count = 0;
+  uint32_t count = 0, ext = 0;
   for (uint32_t j = (uint32_t)p + 1; j < e; ++j) {
     const uint64_t qs_j = s_qs[j];
     if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
+    ext = j - (uint32_t)p;
     uint64_t d;
     if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
     if (count < 0xffffffffu) ++count;
@@ -257,6 +250,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
     c_j[(uint64_t)k * m + p] = bj[k];
   }
   c_n[p] = count;
+  c_ext[p] = ext;
 }
 
 struct SelBlock {
@@ -284,7 +278,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
   for (uint32_t u = wave_global; u < n_units; u += n_waves) {
     const uint32_t b = unit_begin[u];
     const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-    if (e - b < 2 || e - b >= BIG_UNIT) continue;  // long units: chain_select_big_kernel
+    if (e - b < 2 || e - b >= BIG_UNIT) continue;  // long units: spec_round_kernel
     const bool minus = (s_grp[b] & 1ull) != 0;
     auto load_block = [&](uint32_t pos) {
       SelBlock k;
@@ -398,51 +392,157 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
   }
 }
 
-// Long units (dense data: windows of thousands of elements) keep best_pred_score of the next BIGW positions in an
-// LDS ring instead of registers, so a candidate's score is one LDS read instead of a global round trip.  One
-// wavefront per block; positions beyond the ring still go through global memory (agent-scope atomics), and every
-// time the ring advances by 64 positions the 64 entering slots are loaded from there.
+// Long units (>= BIG_UNIT elements; dense data, or a few per genome pair in sparse data) would pin one wavefront
+// for their whole length.  They are cut into blocks of S elements, S >= the longest window of the unit, and all
+// blocks run in parallel, round after round, until nothing changes:
+//   * a predecessor i of j lies in j's block or in the block before it (windows are shorter than a block), so the
+//     only state a block needs from outside is, for each of its own j, the best distance offered by the previous
+//     block (`ext[j]`); it starts from the previous round's value, the previous block publishes this round's;
+//   * inside a block the reference's sequential greedy runs unchanged (candidate lists, LDS ring of scores);
+//   * block 0 of a unit needs nothing from outside, so after round r the first r blocks are final: the loop ends
+//     when a round reproduces `ext` (by then every block has run on the inputs its predecessor's final choices
+//     imply).  In practice two or three rounds.
+// Two views keep the rounds apart: own[j] is what j's block sees (starts at ext[j]), prev[j] what the previous
+// block sees (starts at infinity); each has its own predecessor array.
 constexpr int BIGW = 4096;
 
-__global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
-                                                              uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                              uint32_t m, const uint64_t* __restrict__ s_grp,
-                                                              const uint32_t* __restrict__ s_qs,
-                                                              const uint32_t* __restrict__ s_qe,
-                                                              const uint32_t* __restrict__ s_ts,
-                                                              const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                              const unsigned long long* __restrict__ c_d,
-                                                              const uint32_t* __restrict__ c_j,
-                                                              const uint32_t* __restrict__ c_n, unsigned long long* bps,
-                                                              uint32_t* __restrict__ pred) {
-  __shared__ unsigned long long ring[BIGW];             // best_pred_score of positions [base, base + BIGW)
-  __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];     // their q_start, t_start, t_end (for full-window passes)
+struct SpecBlock {
+  uint32_t ue;  // end of the unit
+  uint32_t bb;  // block begin
+  uint32_t be;  // block end
+  uint32_t pad;
+};
+
+// per long unit: block size S (multiple of 64, >= longest window + 1, >= 512) and number of blocks
+__global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
+                                                       uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                       uint32_t m, const uint32_t* __restrict__ c_ext,
+                                                       uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out) {
+  __shared__ uint32_t wmaxs[EW / 64];
+  const uint32_t bi = blockIdx.x;
+  if (bi >= n_big) return;
+  const uint32_t u = big_list[bi];
+  const uint32_t b = unit_begin[u];
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  uint32_t w = 0;
+  for (uint32_t p = b + threadIdx.x; p < e; p += EW) {
+    const uint32_t x = c_ext[p];
+    if (x > w) w = x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_xor(w, o, 64);
+    if (t > w) w = t;
+  }
+  if ((threadIdx.x & 63) == 0) wmaxs[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < EW / 64; ++k)
+      if (wmaxs[k] > w) w = wmaxs[k];
+    uint32_t S = ((w + 1 + 63) / 64) * 64;
+    if (S < 512) S = 512;
+    S_out[bi] = S;
+    nblk_out[bi] = (e - b + S - 1) / S;
+  }
+}
+__global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
+                                                       uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                       uint32_t m, const uint32_t* __restrict__ S_in,
+                                                       const uint32_t* __restrict__ nblk_in,
+                                                       const uint32_t* __restrict__ blk_off, SpecBlock* __restrict__ desc) {
+  // one thread per (unit, block) pair would need a search; units are few, blocks per unit can be many: one
+  // work-group per unit, threads stride over its blocks
+  const uint32_t bi = blockIdx.x;
+  if (bi >= n_big) return;
+  const uint32_t u = big_list[bi];
+  const uint32_t b = unit_begin[u];
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  const uint32_t S = S_in[bi], nb = nblk_in[bi], off = blk_off[bi];
+  for (uint32_t k = threadIdx.x; k < nb; k += EW) {
+    SpecBlock d;
+    d.ue = e;
+    d.bb = b + k * S;
+    d.be = d.bb + S < e ? d.bb + S : e;
+    d.pad = 0;
+    desc[off + k] = d;
+  }
+}
+__global__ __launch_bounds__(EW) void spec_init_kernel(uint64_t m, const unsigned long long* __restrict__ ext,
+                                                       unsigned long long* __restrict__ own,
+                                                       unsigned long long* __restrict__ prev,
+                                                       uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  own[p] = ext[p];
+  prev[p] = ~0ull;
+  pred_own[p] = NONE;
+  pred_prev[p] = NONE;
+}
+__global__ __launch_bounds__(EW) void spec_check_kernel(uint64_t m, const unsigned long long* __restrict__ prev,
+                                                        unsigned long long* __restrict__ ext,
+                                                        uint32_t* __restrict__ changed) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const unsigned long long v = prev[p];
+  if (v != ext[p]) {
+    ext[p] = v;
+    *changed = 1;
+  }
+}
+__global__ __launch_bounds__(EW) void spec_final_kernel(uint64_t m, const uint32_t* __restrict__ pred_own,
+                                                        const uint32_t* __restrict__ pred_prev,
+                                                        uint32_t* __restrict__ pred) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t a = pred_own[p], b = pred_prev[p];
+  // own-block choosers come later in the sequence and had to beat the previous block's offer
+  if (a != NONE)
+    pred[p] = a;
+  else if (b != NONE)
+    pred[p] = b;
+}
+
+__global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
+                                                        const uint64_t* __restrict__ s_grp,
+                                                        const uint32_t* __restrict__ s_qs,
+                                                        const uint32_t* __restrict__ s_qe,
+                                                        const uint32_t* __restrict__ s_ts,
+                                                        const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                        const unsigned long long* __restrict__ c_d,
+                                                        const uint32_t* __restrict__ c_j,
+                                                        const uint32_t* __restrict__ c_n, unsigned long long* own,
+                                                        unsigned long long* prev, uint32_t* __restrict__ pred_own,
+                                                        uint32_t* __restrict__ pred_prev) {
+  __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this block sees them
+  __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end (for full-window passes)
   const int lane = threadIdx.x;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
-  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
-    const uint32_t u = big_list[bi];
-    const uint32_t b = unit_begin[u];
-    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-    if (e - b < 2) continue;
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    const uint32_t b = D.bb, be = D.be, e = D.ue;  // i runs over [b, be), j may reach into the next block (< e)
+    if (be - b < 1 || e - b < 2) continue;
     const bool minus = (s_grp[b] & 1ull) != 0;
-    // ring covers positions [base, base + BIGW); slot of position p is p % BIGW
+    // this block's view of position p: its own elements start from ext (in `own`), later ones from infinity (`prev`)
+    auto view_load = [&](uint32_t p) -> uint64_t {
+      return __hip_atomic_load(p < be ? &own[p] : &prev[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     uint32_t base = b;
+    __syncthreads();
     for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
       const bool ok = p < e;
-      ring[p % BIGW] = ok ? __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+      ring[p % BIGW] = ok ? view_load(p) : INF;
       rq[p % BIGW] = ok ? s_qs[p] : 0xffffffffu;
       rt[p % BIGW] = ok ? s_ts[p] : 0u;
       re[p % BIGW] = ok ? s_te[p] : 0u;
     }
     __syncthreads();
-    // candidate lists of the 64 elements [base, base + 64), one per lane
     uint64_t cd[KC];
     uint32_t cj[KC];
     uint32_t cn;
     auto load_cands = [&](uint32_t pos) {
       const uint32_t p = pos + lane;
-      if (p < e) {
+      if (p < be) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
           cd[c] = c_d[(uint64_t)c * m + p];
@@ -461,16 +561,15 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
     load_cands(base);
     auto current = [&](uint32_t j) -> uint64_t {
       if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
-      return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return view_load(j);
     };
-    for (uint32_t i = b; i + 1 < e; ++i) {
+    for (uint32_t i = b; i < be && i + 1 < e; ++i) {
       if (i - base == 64) {
-        // advance: positions [base, base+64) leave the ring, [base+BIGW, base+BIGW+64) enter it
         const uint32_t pn = base + BIGW + lane;
         __syncthreads();
         {
           const bool ok = pn < e;
-          ring[pn % BIGW] = ok ? __hip_atomic_load(&bps[pn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INF;
+          ring[pn % BIGW] = ok ? view_load(pn) : INF;
           rq[pn % BIGW] = ok ? s_qs[pn] : 0xffffffffu;
           rt[pn % BIGW] = ok ? s_ts[pn] : 0u;
           re[pn % BIGW] = ok ? s_te[pn] : 0u;
@@ -536,17 +635,15 @@ __global__ __launch_bounds__(64) void chain_select_big_kernel(uint32_t n_big, co
         }
       }
       if (best_j == NONE) continue;
-      if (best_j - base < (uint32_t)BIGW) {
-        // one wavefront, program order: the next step's LDS reads follow this write (no fence -- a fence would
-        // also wait for the pred[] store below, a full memory round trip per step)
-        if (lane == 0) ring[best_j % BIGW] = best_d;
-      } else {
-        if (lane == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
+      const bool in_ring = best_j - base < (uint32_t)BIGW;
+      if (lane == 0) {
+        if (in_ring) ring[best_j % BIGW] = best_d;  // read back by this wavefront in program order
+        // write-through: the views are what the check / final kernels (and the ring refill) read
+        __hip_atomic_store(best_j < be ? &own[best_j] : &prev[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (best_j < be ? pred_own : pred_prev)[best_j] = i;
       }
-      if (lane == 0) pred[best_j] = i;
+      if (!in_ring) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before a later global read of it
     }
-    __syncthreads();
   }
 }
 
@@ -1169,12 +1266,13 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     unsigned long long* c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
     uint32_t* c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
     uint32_t* c_n = swg_alloc<uint32_t>(ctx, m);
+    uint32_t* c_ext = swg_alloc<uint32_t>(ctx, m);
     SWG_CHECK_ARENA(ctx);
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
               (unsigned long long)n_groups, (unsigned long long)n_units);
     SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n));
+                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
     {
       uint64_t blocks = (n_units + 3) / 4;
@@ -1201,10 +1299,52 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         SWG_CHECK_ARENA(ctx);
         SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_big, big_pos, big_list));
         SWG_KERNEL_CHECK(ctx);
-        uint64_t blocks = n_big < (uint64_t)ctx->num_cu * 4 ? n_big : (uint64_t)ctx->num_cu * 4;
-        SWG_LAUNCH(ctx, "chain_select_big", chain_select_big_kernel<<<(unsigned)blocks, 64, 0, st>>>(
-                                                (uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin, (uint32_t)m, s_grp, s_qs, s_qe, s_ts,
-                                                s_te, max_gap, c_d, c_j, c_n, bps, pred));
+        // ---- block-speculative selection of the long units
+        uint32_t* S_u = swg_alloc<uint32_t>(ctx, n_big);
+        uint32_t* nblk_u = swg_alloc<uint32_t>(ctx, n_big);
+        uint32_t* blk_off = swg_alloc<uint32_t>(ctx, n_big);
+        uint64_t* d_nblk = swg_alloc<uint64_t>(ctx, 1);
+        unsigned long long* ext = swg_alloc<unsigned long long>(ctx, m);
+        unsigned long long* v_own = swg_alloc<unsigned long long>(ctx, m);
+        unsigned long long* v_prev = swg_alloc<unsigned long long>(ctx, m);
+        uint32_t* p_own = swg_alloc<uint32_t>(ctx, m);
+        uint32_t* p_prev = swg_alloc<uint32_t>(ctx, m);
+        uint32_t* spec_changed = swg_alloc<uint32_t>(ctx, 2);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                        (uint32_t)m, c_ext, S_u, nblk_u));
+        SWG_KERNEL_CHECK(ctx);
+        SWG_TRY(swg_exclusive_scan_u32(ctx, nblk_u, blk_off, n_big, d_nblk));
+        uint64_t n_spec = 0;
+        SWG_TRY(swg_read_scalars(ctx, d_nblk, &n_spec, 1));
+        SpecBlock* desc = swg_alloc<SpecBlock>(ctx, n_spec);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "spec_desc", spec_desc_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                        (uint32_t)m, S_u, nblk_u, blk_off, desc));
+        SWG_KERNEL_CHECK(ctx);
+        SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(ext), ~0ull));
+        SWG_KERNEL_CHECK(ctx);
+        const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
+        int rounds = 0;
+        for (uint64_t round = 0; round <= n_spec + 1; ++round) {
+          SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<nblk(m), EW, 0, st>>>(m, ext, v_own, v_prev, p_own, p_prev));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<<<(unsigned)rblocks, 64, 0, st>>>((uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe,
+                                                                              s_ts, s_te, max_gap, c_d, c_j, c_n, v_own, v_prev, p_own,
+                                                                              p_prev));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_HIP(ctx, hipMemsetAsync(spec_changed, 0, 8, st));
+          SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<nblk(m), EW, 0, st>>>(m, v_prev, ext, spec_changed));
+          SWG_KERNEL_CHECK(ctx);
+          uint64_t ch = 0;
+          SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(spec_changed), &ch, 1));
+          ++rounds;
+          if ((uint32_t)ch == 0) break;
+        }
+        if (getenv("SWG_DEBUG"))
+          fprintf(stderr, "[swg] long units: %llu, blocks %llu, rounds %d\n", (unsigned long long)n_big,
+                  (unsigned long long)n_spec, rounds);
+        SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<nblk(m), EW, 0, st>>>(m, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
       }
     }
