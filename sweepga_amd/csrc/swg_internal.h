@@ -115,6 +115,7 @@ int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint
                            uint64_t* d_total_out);
 // Inclusive running maximum of n u32 values (in place allowed).
 int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n);
+int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n);
 // Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
 // *keys / *vals hold the input; the *_alt buffers are scratch of the same size.  Passes ping-pong
 // between the two pairs of buffers and the POINTERS are swapped so that on return *keys / *vals

@@ -404,7 +404,6 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
 //     imply).  In practice two or three rounds.
 // Two views keep the rounds apart: own[j] is what j's block sees (starts at ext[j]), prev[j] what the previous
 // block sees (starts at infinity); each has its own predecessor array.
-constexpr int BIGW = 4096;
 
 struct SpecBlock {
   uint32_t ue;  // end of the unit
@@ -417,7 +416,8 @@ struct SpecBlock {
 __global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
                                                        uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                        uint32_t m, const uint32_t* __restrict__ c_ext,
-                                                       uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out) {
+                                                       uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out,
+                                                       uint32_t* __restrict__ s_max) {
   __shared__ uint32_t wmaxs[EW / 64];
   const uint32_t bi = blockIdx.x;
   if (bi >= n_big) return;
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uin
     if (S < 512) S = 512;
     S_out[bi] = S;
     nblk_out[bi] = (e - b + S - 1) / S;
+    atomicMax(s_max, S);
   }
 }
 __global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
@@ -467,41 +468,55 @@ __global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uin
     desc[off + k] = d;
   }
 }
-__global__ __launch_bounds__(EW) void spec_init_kernel(uint64_t m, const unsigned long long* __restrict__ ext,
+// The three per-round passes touch only the elements of long units: one work-group per block descriptor.
+__global__ __launch_bounds__(EW) void spec_init_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
+                                                       const unsigned long long* __restrict__ ext,
                                                        unsigned long long* __restrict__ own,
                                                        unsigned long long* __restrict__ prev,
                                                        uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  own[p] = ext[p];
-  prev[p] = ~0ull;
-  pred_own[p] = NONE;
-  pred_prev[p] = NONE;
-}
-__global__ __launch_bounds__(EW) void spec_check_kernel(uint64_t m, const unsigned long long* __restrict__ prev,
-                                                        unsigned long long* __restrict__ ext,
-                                                        uint32_t* __restrict__ changed) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const unsigned long long v = prev[p];
-  if (v != ext[p]) {
-    ext[p] = v;
-    *changed = 1;
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
+      own[p] = ext[p];
+      prev[p] = ~0ull;
+      pred_own[p] = NONE;
+      pred_prev[p] = NONE;
+    }
   }
 }
-__global__ __launch_bounds__(EW) void spec_final_kernel(uint64_t m, const uint32_t* __restrict__ pred_own,
+__global__ __launch_bounds__(EW) void spec_check_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
+                                                        const unsigned long long* __restrict__ prev,
+                                                        unsigned long long* __restrict__ ext,
+                                                        uint32_t* __restrict__ changed) {
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
+      const unsigned long long v = prev[p];
+      if (v != ext[p]) {
+        ext[p] = v;
+        *changed = 1;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(EW) void spec_final_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
+                                                        const uint32_t* __restrict__ pred_own,
                                                         const uint32_t* __restrict__ pred_prev,
                                                         uint32_t* __restrict__ pred) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t a = pred_own[p], b = pred_prev[p];
-  // own-block choosers come later in the sequence and had to beat the previous block's offer
-  if (a != NONE)
-    pred[p] = a;
-  else if (b != NONE)
-    pred[p] = b;
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
+      const uint32_t a = pred_own[p], b = pred_prev[p];
+      // own-block choosers come later in the sequence and had to beat the previous block's offer
+      if (a != NONE)
+        pred[p] = a;
+      else if (b != NONE)
+        pred[p] = b;
+    }
+  }
 }
 
+template <int BIGW>
 __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
                                                         const uint64_t* __restrict__ s_grp,
                                                         const uint32_t* __restrict__ s_qs,
@@ -693,6 +708,40 @@ __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const
     }
   }
 }
+// The same two per-group reductions for inputs with few, very long groups (one wavefront per group would crawl):
+// a running maximum over the composite (group index << 32 | value) is a segmented running maximum, because the
+// group index never decreases along the survivor order.
+__global__ __launch_bounds__(EW) void seg_compose_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                         const uint32_t* __restrict__ v, int complement,
+                                                         uint64_t* __restrict__ out) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) out[p] = ((uint64_t)s_gidx[p] << 32) | (complement ? 0xffffffffu - v[p] : v[p]);
+}
+__global__ __launch_bounds__(EW) void cuts_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
+                                                            const uint64_t* __restrict__ run_max,
+                                                            const uint32_t* __restrict__ s_qs, uint64_t max_gap,
+                                                            uint32_t* __restrict__ unit_flag) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  uint32_t f = 1;
+  if (!head_flag[p]) {  // p > 0 and p - 1 is in the same group
+    uint64_t lim = (run_max[p - 1] & 0xffffffffull) + max_gap;
+    if (lim < max_gap) lim = ~0ull;
+    f = (uint64_t)s_qs[p] > lim ? 1u : 0u;
+  }
+  unit_flag[p] = f;
+}
+__global__ __launch_bounds__(EW) void group_first_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
+                                                                   const uint64_t* __restrict__ run_max,
+                                                                   uint32_t* __restrict__ group_first) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  if (p + 1 == m || head_flag[p + 1]) {  // last member of its group
+    const uint64_t v = run_max[p];
+    group_first[(uint32_t)(v >> 32)] = 0xffffffffu - (uint32_t)v;
+  }
+}
+
 __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
                                                         const uint32_t* __restrict__ unit_excl,
                                                         uint32_t* __restrict__ unit_begin) {
@@ -1248,7 +1297,18 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     uint32_t* unit_excl = swg_alloc<uint32_t>(ctx, m);
     uint64_t* d_nu = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
-    {
+    const bool long_groups = m / n_groups > 8192;  // few, long groups: scan-based reductions
+    if (long_groups) {
+      swg_arena_mark mk = swg_arena_save(ctx);
+      uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, s_qe, 0, comp));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
+      SWG_LAUNCH(ctx, "cuts_from_scan", cuts_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, s_qs, max_gap, unit_flag));
+      SWG_KERNEL_CHECK(ctx);
+      swg_arena_restore(ctx, mk);
+    } else {
       uint64_t blocks = (n_groups + 3) / 4;
       const uint64_t mb = (uint64_t)ctx->num_cu * 16;
       if (blocks > mb) blocks = mb;
@@ -1310,13 +1370,18 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         uint32_t* p_own = swg_alloc<uint32_t>(ctx, m);
         uint32_t* p_prev = swg_alloc<uint32_t>(ctx, m);
         uint32_t* spec_changed = swg_alloc<uint32_t>(ctx, 2);
+        uint64_t* d_smax = swg_alloc<uint64_t>(ctx, 1);  // adjacent to d_nblk: read back together
         SWG_CHECK_ARENA(ctx);
+        SWG_HIP(ctx, hipMemsetAsync(d_smax, 0, 8, st));
         SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                        (uint32_t)m, c_ext, S_u, nblk_u));
+                                                                        (uint32_t)m, c_ext, S_u, nblk_u,
+                                                                        reinterpret_cast<uint32_t*>(d_smax)));
         SWG_KERNEL_CHECK(ctx);
         SWG_TRY(swg_exclusive_scan_u32(ctx, nblk_u, blk_off, n_big, d_nblk));
-        uint64_t n_spec = 0;
+        uint64_t n_spec = 0, s_max = 0;
         SWG_TRY(swg_read_scalars(ctx, d_nblk, &n_spec, 1));
+        SWG_TRY(swg_read_scalars(ctx, d_smax, &s_max, 1));
+        s_max &= 0xffffffffull;
         SpecBlock* desc = swg_alloc<SpecBlock>(ctx, n_spec);
         SWG_CHECK_ARENA(ctx);
         SWG_LAUNCH(ctx, "spec_desc", spec_desc_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
@@ -1325,16 +1390,22 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(ext), ~0ull));
         SWG_KERNEL_CHECK(ctx);
         const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
+        const bool small_ring = s_max + 64 <= 1024;  // every window fits a 1024-slot ring: 20 KB of LDS instead of 80
         int rounds = 0;
         for (uint64_t round = 0; round <= n_spec + 1; ++round) {
-          SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<nblk(m), EW, 0, st>>>(m, ext, v_own, v_prev, p_own, p_prev));
+          SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
           SWG_KERNEL_CHECK(ctx);
-          SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<<<(unsigned)rblocks, 64, 0, st>>>((uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe,
-                                                                              s_ts, s_te, max_gap, c_d, c_j, c_n, v_own, v_prev, p_own,
-                                                                              p_prev));
+          if (small_ring)
+            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<1024><<<(unsigned)rblocks, 64, 0, st>>>(
+                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
+                                              v_prev, p_own, p_prev));
+          else
+            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<4096><<<(unsigned)rblocks, 64, 0, st>>>(
+                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
+                                              v_prev, p_own, p_prev));
           SWG_KERNEL_CHECK(ctx);
           SWG_HIP(ctx, hipMemsetAsync(spec_changed, 0, 8, st));
-          SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<nblk(m), EW, 0, st>>>(m, v_prev, ext, spec_changed));
+          SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, v_prev, ext, spec_changed));
           SWG_KERNEL_CHECK(ctx);
           uint64_t ch = 0;
           SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(spec_changed), &ch, 1));
@@ -1344,7 +1415,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         if (getenv("SWG_DEBUG"))
           fprintf(stderr, "[swg] long units: %llu, blocks %llu, rounds %d\n", (unsigned long long)n_big,
                   (unsigned long long)n_spec, rounds);
-        SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<nblk(m), EW, 0, st>>>(m, p_own, p_prev, pred));
+        SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
       }
     }
@@ -1379,7 +1450,16 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_gp), EW, 0, st>>>(n_gp, gp_first, NONE));
   SWG_KERNEL_CHECK(ctx);
-  {
+  if (m / n_groups > 8192) {
+    swg_arena_mark mk = swg_arena_save(ctx);
+    uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, B.s_idx, 1, comp));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
+    SWG_LAUNCH(ctx, "group_first_from_scan", group_first_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, group_first));
+    swg_arena_restore(ctx, mk);
+  } else {
     uint64_t blocks = (n_groups + 3) / 4;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
     if (blocks > max_blocks) blocks = max_blocks;

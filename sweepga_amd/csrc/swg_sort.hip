@@ -16,17 +16,17 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
-// OP: 0 = add, 1 = max.  Identity is 0 for both (u32).
-template <int OP>
-__device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) {
+// OP: 0 = add, 1 = max.  Identity is 0 for both.  T = uint32_t or uint64_t.
+template <int OP, typename T>
+__device__ __forceinline__ T scan_op(T a, T b) {
   return OP == 0 ? a + b : (a > b ? a : b);
 }
 
-template <int OP>
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+template <int OP, typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
+    T t = __shfl_up(v, d, 64);
     if (lane >= d) v = scan_op<OP>(t, v);
   }
   return v;
@@ -34,65 +34,62 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 
 // Block-wide scan of one value per thread (256 threads); returns the EXCLUSIVE prefix (identity for
 // the first thread) and the block total through *total.
-template <int OP>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* lds_wave,
-                                                         uint32_t* lds_prev) {
+template <int OP, typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* total, T* lds_wave, T* lds_prev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = wave_inclusive_scan<OP>(v, lane);
+  T inc = wave_inclusive_scan<OP>(v, lane);
   if (lane == 63) lds_wave[wave] = inc;
   lds_prev[threadIdx.x] = inc;
   __syncthreads();
-  uint32_t base = 0, tot = 0;
+  T base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-    uint32_t s = lds_wave[w];
+    T s = lds_wave[w];
     if (w < wave) base = scan_op<OP>(base, s);
     tot = scan_op<OP>(tot, s);
   }
-  const uint32_t prev_in_wave = lane ? lds_prev[threadIdx.x - 1] : 0u;
+  const T prev_in_wave = lane ? lds_prev[threadIdx.x - 1] : (T)0;
   __syncthreads();
   *total = tot;
   return scan_op<OP>(base, prev_in_wave);
 }
 
-template <int OP>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in,
-                                                                    uint32_t* __restrict__ block_sums,
+template <int OP, typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const T* __restrict__ in, T* __restrict__ block_sums,
                                                                     uint64_t n) {
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  __shared__ uint32_t lds_prev[SCAN_THREADS];
+  __shared__ T lds_wave[SCAN_THREADS / 64];
+  __shared__ T lds_prev[SCAN_THREADS];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t s = 0;
+  T s = 0;
 #pragma unroll
   for (int j = 0; j < SCAN_ITEMS; ++j) {
     uint64_t i = base + j;
     if (i < n) s = scan_op<OP>(s, in[i]);
   }
-  uint32_t tot;
+  T tot;
   (void)block_exclusive_scan<OP>(s, &tot, lds_wave, lds_prev);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
 // `in` and `out` may alias (in-place scan): every thread reads its 16 inputs before any write.
-template <int OP, bool INCLUSIVE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const uint32_t* in, uint32_t* out,
-                                                                  const uint32_t* __restrict__ block_offsets,
+template <int OP, bool INCLUSIVE, typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const T* in, T* out, const T* __restrict__ block_offsets,
                                                                   uint64_t n, uint64_t* __restrict__ total_out,
                                                                   int write_total) {
-  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
-  __shared__ uint32_t lds_prev[SCAN_THREADS];
+  __shared__ T lds_wave[SCAN_THREADS / 64];
+  __shared__ T lds_prev[SCAN_THREADS];
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS];
-  uint32_t s = 0;
+  T v[SCAN_ITEMS];
+  T s = 0;
 #pragma unroll
   for (int j = 0; j < SCAN_ITEMS; ++j) {
     uint64_t i = base + j;
-    v[j] = i < n ? in[i] : 0u;
+    v[j] = i < n ? in[i] : (T)0;
     s = scan_op<OP>(s, v[j]);
   }
-  uint32_t tot;
-  uint32_t ex = block_exclusive_scan<OP>(s, &tot, lds_wave, lds_prev);
-  uint32_t run = scan_op<OP>(ex, block_offsets ? block_offsets[blockIdx.x] : 0u);
+  T tot;
+  T ex = block_exclusive_scan<OP>(s, &tot, lds_wave, lds_prev);
+  T run = scan_op<OP>(ex, block_offsets ? block_offsets[blockIdx.x] : (T)0);
 #pragma unroll
   for (int j = 0; j < SCAN_ITEMS; ++j) {
     uint64_t i = base + j;
@@ -100,30 +97,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const uint32_t*
     if (i < n) out[i] = run;
     if (!INCLUSIVE) run = scan_op<OP>(run, v[j]);
   }
-  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total_out = run;
+  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total_out = (uint64_t)run;
 }
 
-template <int OP, bool INCLUSIVE>
-int scan_impl(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* d_total_out) {
+template <int OP, bool INCLUSIVE, typename T>
+int scan_impl(swg_ctx* ctx, const T* in, T* out, uint64_t n, uint64_t* d_total_out) {
   if (n == 0) {
     if (d_total_out) SWG_HIP(ctx, hipMemsetAsync(d_total_out, 0, sizeof(uint64_t), ctx->stream));
     return SWG_OK;
   }
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 1) {
-    SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE><<<1, SCAN_THREADS, 0, ctx->stream>>>(
-                                     in, out, nullptr, n, d_total_out, d_total_out ? 1 : 0));
+    SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE, T><<<1, SCAN_THREADS, 0, ctx->stream>>>(
+                                     in, out, (const T*)nullptr, n, d_total_out, d_total_out ? 1 : 0));
     SWG_KERNEL_CHECK(ctx);
     return SWG_OK;
   }
   swg_arena_mark mark = swg_arena_save(ctx);
-  uint32_t* sums = swg_alloc<uint32_t>(ctx, nb);
+  T* sums = swg_alloc<T>(ctx, nb);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "scan_reduce", scan_reduce_kernel<OP><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n));
+  SWG_LAUNCH(ctx, "scan_reduce", scan_reduce_kernel<OP, T><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY((scan_impl<OP, false>(ctx, sums, sums, nb, nullptr)));  // block offsets are always exclusive
-  SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(
-                                   in, out, sums, n, d_total_out, d_total_out ? 1 : 0));
+  SWG_TRY((scan_impl<OP, false, T>(ctx, sums, sums, nb, nullptr)));  // block offsets are always exclusive
+  SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE, T><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(
+                                   in, out, (const T*)sums, n, d_total_out, d_total_out ? 1 : 0));
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);  // stream order keeps `sums` alive until the kernels above ran
   return SWG_OK;
@@ -132,10 +129,13 @@ int scan_impl(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n, uint6
 }  // namespace
 
 int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n, uint64_t* d_total_out) {
-  return scan_impl<0, false>(ctx, in, out, n, d_total_out);
+  return scan_impl<0, false, uint32_t>(ctx, in, out, n, d_total_out);
 }
 int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n) {
-  return scan_impl<1, true>(ctx, in, out, n, nullptr);
+  return scan_impl<1, true, uint32_t>(ctx, in, out, n, nullptr);
+}
+int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n) {
+  return scan_impl<1, true, uint64_t>(ctx, in, out, n, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
