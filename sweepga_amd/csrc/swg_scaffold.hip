@@ -260,6 +260,46 @@ struct SelBlock {
   uint64_t bps;
 };
 
+// Work items are *chunks*: runs of whole units of about CHUNK elements.  Windows never cross a unit boundary, so
+// running the sequential greedy straight through a run of units is the same as running it unit by unit, and a
+// wavefront pays its start-up loads once per ~CHUNK steps instead of once per (often tiny) unit.  Elements of
+// long units (handled by the block-speculative path) have had their candidate count zeroed and are stepped over.
+constexpr uint32_t CHUNK = 1024;
+
+struct SpecBlock {
+  uint32_t ue;  // end of the unit
+  uint32_t bb;  // block begin
+  uint32_t be;  // block end
+  uint32_t pad;
+};
+
+__global__ __launch_bounds__(EW) void chunk_begin_kernel(uint32_t n_chunks, const uint32_t* __restrict__ unit_begin,
+                                                         uint32_t n_units, uint32_t m, uint32_t* __restrict__ chunk_begin) {
+  uint32_t k = blockIdx.x * EW + threadIdx.x;
+  if (k > n_chunks) return;
+  if (k == n_chunks) {
+    chunk_begin[k] = m;
+    return;
+  }
+  const uint32_t x = k * CHUNK;  // first unit that begins at or after x
+  uint32_t l = 0, r = n_units;
+  while (l < r) {
+    const uint32_t mid = l + ((r - l) >> 1);
+    if (unit_begin[mid] < x)
+      l = mid + 1;
+    else
+      r = mid;
+  }
+  chunk_begin[k] = l < n_units ? unit_begin[l] : m;
+}
+__global__ __launch_bounds__(EW) void zero_long_counts_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
+                                                              uint32_t* __restrict__ c_n) {
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) c_n[p] = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                            uint32_t m, const uint64_t* __restrict__ s_grp,
                                                            const uint32_t* __restrict__ s_qs,
@@ -268,18 +308,20 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
                                                            const uint32_t* __restrict__ s_te, uint64_t max_gap,
                                                            const unsigned long long* __restrict__ c_d,
                                                            const uint32_t* __restrict__ c_j,
-                                                           const uint32_t* __restrict__ c_n, unsigned long long* bps,
-                                                           uint32_t* __restrict__ pred) {
+                                                           const uint32_t* __restrict__ c_n,
+                                                           const uint32_t* __restrict__ s_gidx,
+                                                           const uint32_t* __restrict__ group_begin, uint32_t n_groups,
+                                                           unsigned long long* bps, uint32_t* __restrict__ pred) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
+  // (n_units, unit_begin) are (n_chunks, chunk_begin) here: every chunk is a run of whole units
   for (uint32_t u = wave_global; u < n_units; u += n_waves) {
     const uint32_t b = unit_begin[u];
-    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-    if (e - b < 2 || e - b >= BIG_UNIT) continue;  // long units: spec_round_kernel
-    const bool minus = (s_grp[b] & 1ull) != 0;
+    const uint32_t e = unit_begin[u + 1];
+    if (e - b < 2) continue;
     auto load_block = [&](uint32_t pos) {
       SelBlock k;
       const uint32_t p = pos + lane;
@@ -336,12 +378,16 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
       if (best_j == NONE && nvalid > (uint32_t)KC) {
         // every listed candidate is blocked and the window held more: evaluate it in full (rare)
         const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
+        const bool minus = (s_grp[i] & 1ull) != 0;
         const uint64_t bound = qe_i + max_gap;
+        // the window ends with i's (q, t, strand) group at the latest (the chunk may hold several groups)
+        const uint32_t gi = s_gidx[i];
+        const uint32_t ge = (gi + 1 < n_groups) ? group_begin[gi + 1] : m;
         uint64_t ld = INF;
         uint32_t lj2 = NONE;
-        for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+        for (uint32_t j0 = i + 1; j0 < ge; j0 += 64) {
           const uint32_t j = j0 + lane;
-          bool in = j < e;
+          bool in = j < ge;
           uint64_t qs_j = 0;
           if (in) {
             qs_j = s_qs[j];
@@ -405,12 +451,6 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
 // Two views keep the rounds apart: own[j] is what j's block sees (starts at ext[j]), prev[j] what the previous
 // block sees (starts at infinity); each has its own predecessor array.
 
-struct SpecBlock {
-  uint32_t ue;  // end of the unit
-  uint32_t bb;  // block begin
-  uint32_t be;  // block end
-  uint32_t pad;
-};
 
 // per long unit: block size S (multiple of 64, >= longest window + 1, >= 512) and number of blocks
 __global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
@@ -1335,15 +1375,6 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                                                                             s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
     {
-      uint64_t blocks = (n_units + 3) / 4;
-      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-      if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
-                                                                                s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n,
-                                                                                bps, pred));
-      SWG_KERNEL_CHECK(ctx);
-    }
-    {
       uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
       uint32_t* is_big32 = swg_alloc<uint32_t>(ctx, n_units);
       uint32_t* big_pos = swg_alloc<uint32_t>(ctx, n_units);
@@ -1417,7 +1448,25 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                   (unsigned long long)n_spec, rounds);
         SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
+        // the long units are done: take them out of the chunked pass below
+        SWG_LAUNCH(ctx, "zero_long_counts", zero_long_counts_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, c_n));
+        SWG_KERNEL_CHECK(ctx);
       }
+    }
+    {
+      const uint32_t n_chunks = (uint32_t)((m + CHUNK - 1) / CHUNK);
+      uint32_t* chunk_begin = swg_alloc<uint32_t>(ctx, (size_t)n_chunks + 1);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "chunk_begin", chunk_begin_kernel<<<nblk((uint64_t)n_chunks + 1), EW, 0, st>>>(n_chunks, unit_begin, (uint32_t)n_units,
+                                                                                       (uint32_t)m, chunk_begin));
+      SWG_KERNEL_CHECK(ctx);
+      uint64_t blocks = ((uint64_t)n_chunks + 3) / 4;
+      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+      if (blocks > max_blocks) blocks = max_blocks;
+      SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>(n_chunks, chunk_begin, (uint32_t)m, s_grp, s_qs, s_qe,
+                                                                                s_ts, s_te, max_gap, c_d, c_j, c_n, s_gidx, group_begin,
+                                                                                (uint32_t)n_groups, bps, pred));
+      SWG_KERNEL_CHECK(ctx);
     }
   }
   // ---- labelling by pointer jumping
