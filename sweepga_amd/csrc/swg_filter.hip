@@ -11,65 +11,6 @@ namespace {
 constexpr int EW = 256;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
 
-// step 1 retain, src/paf_filter.rs:384-388.  NaN identity fails `>=`.
-__global__ __launch_bounds__(EW) void retain_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
-                                                    const uint32_t* __restrict__ t_id,
-                                                    const uint32_t* __restrict__ block_len,
-                                                    const double* __restrict__ identity, uint64_t min_block,
-                                                    int keep_self, double min_identity,
-                                                    uint8_t* __restrict__ alive) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i >= n) return;
-  const bool ok = (uint64_t)block_len[i] >= min_block && (keep_self || q_id[i] != t_id[i]) &&
-                  identity[i] >= min_identity;
-  alive[i] = ok ? 1 : 0;
-}
-
-// scalars[0] = max coordinate over all four columns, scalars[1] = number of alive records
-__global__ __launch_bounds__(EW) void stats_kernel(uint64_t n, const uint32_t* __restrict__ a,
-                                                   const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
-                                                   const uint32_t* __restrict__ d, const uint8_t* __restrict__ alive,
-                                                   unsigned long long* __restrict__ scalars) {
-  uint32_t mx = 0, cnt = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW) {
-    uint32_t m1 = a[i] > b[i] ? a[i] : b[i];
-    uint32_t m2 = c[i] > d[i] ? c[i] : d[i];
-    uint32_t m = m1 > m2 ? m1 : m2;
-    if (m > mx) mx = m;
-    if (!alive || alive[i]) ++cnt;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t t = __shfl_down(mx, o, 64);
-    if (t > mx) mx = t;
-    cnt += __shfl_down(cnt, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(&scalars[0], (unsigned long long)mx);
-    atomicAdd(&scalars[1], (unsigned long long)cnt);
-  }
-}
-
-// segment ids of the mapping-level sweep (src/paf_filter.rs:1037-1100):
-//   query axis : (query sequence, genome of the target)   target axis : (target sequence, genome of the query)
-__global__ __launch_bounds__(EW) void mapping_segments_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
-                                                              const uint32_t* __restrict__ t_id,
-                                                              const uint32_t* __restrict__ seq_genome,
-                                                              uint32_t n_genome, uint64_t* __restrict__ seg_q,
-                                                              uint64_t* __restrict__ seg_t) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t q = q_id[i], t = t_id[i];
-  seg_q[i] = (uint64_t)q * n_genome + seq_genome[t];
-  seg_t[i] = (uint64_t)t * n_genome + seq_genome[q];
-}
-
-__global__ __launch_bounds__(EW) void and_kernel(uint64_t n, const uint8_t* __restrict__ a,
-                                                 const uint8_t* __restrict__ b, uint8_t* __restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) out[i] = (a[i] && b[i]) ? 1 : 0;
-}
-
 __global__ __launch_bounds__(EW) void unassigned_status_kernel(uint64_t n, const uint8_t* __restrict__ keep,
                                                                uint8_t* __restrict__ status,
                                                                uint32_t* __restrict__ chain) {
@@ -123,35 +64,32 @@ void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, ui
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                       const uint64_t* score_key, int pos_bits, uint8_t* keep) {
   const uint64_t n = r->n;
-  hipStream_t st = ctx->stream;
   uint64_t kq, kt;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
   swg_arena_mark mark = swg_arena_save(ctx);
-  uint64_t* seg_q = swg_alloc<uint64_t>(ctx, n);
-  uint64_t* seg_t = swg_alloc<uint64_t>(ctx, n);
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, n);
-  uint8_t* keep_t = swg_alloc<uint8_t>(ctx, n);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "mapping_segments", mapping_segments_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->seq_genome_last, r->n_genome_last,
-                                                  seg_q, seg_t));
-  SWG_KERNEL_CHECK(ctx);
-  const int seg_bits = swg_bits_for((uint64_t)r->n_seq * r->n_genome_last);  // ids + 1 <= n_seq * n_genome
+  // segment ids of the mapping-level sweep (src/paf_filter.rs:1037-1100), computed where they are used:
+  //   query axis : (query sequence, genome of the target)   target axis : (target sequence, genome of the query)
   swg_axis_input ax;
   ax.n = n;
-  ax.seg_bits = seg_bits;
+  ax.seg_bits = swg_bits_for((uint64_t)r->n_seq * r->n_genome_last);  // ids + 1 <= n_seq * n_genome
+  ax.seg_mul = r->n_genome_last;
+  ax.seg_table = r->seq_genome_last;
   ax.pos_bits = pos_bits;
   ax.score_key = score_key;
   ax.alive = alive;
-  ax.seg = seg_q;
+  ax.seg_a = r->q_id;
+  ax.seg_b = r->t_id;
   ax.start = r->q_start;
   ax.end = r->q_end;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
-  ax.seg = seg_t;
+  ax.seg_a = r->t_id;
+  ax.seg_b = r->q_id;
   ax.start = r->t_start;
   ax.end = r->t_end;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep_t));
-  SWG_LAUNCH(ctx, "and", and_kernel<<<nblk(n), EW, 0, st>>>(n, keep_q, keep_t, keep));  // intersection, src/paf_filter.rs:1105-1111
-  SWG_KERNEL_CHECK(ctx);
+  ax.and_with = keep_q;  // intersection of the two axes, src/paf_filter.rs:1105-1111
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep));
   swg_arena_restore(ctx, mark);
   return SWG_OK;
 }
@@ -172,12 +110,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
-  SWG_LAUNCH(ctx, "retain", retain_kernel<<<nblk(n), EW, 0, st>>>(n, r->q_id, r->t_id, r->block_len, r->identity, cfg->min_block_length,
-                                        cfg->keep_self, cfg->min_identity, alive));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "stats", stats_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, r->q_start, r->q_end, r->t_start, r->t_end, alive, scalars));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_score_keys(ctx, n, r->q_start, r->q_end, r->identity, cfg->scoring_function, score_key));
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, score_key, scalars));
   uint64_t h[2];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 2));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;

@@ -144,13 +144,19 @@ static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represen
 // (src/plane_sweep_exact.rs:268-433); keep[i] = 0 for !alive.
 struct swg_axis_input {
   uint64_t n;
-  const uint64_t* seg;       // [n] segment id
+  const uint64_t* seg = nullptr;  // [n] explicit segment ids, or nullptr: computed on the fly as
+                                  //   seg_a[i] * seg_mul + (seg_table ? seg_table[seg_b[i]] : seg_b[i])
+  const uint32_t* seg_a = nullptr;
+  const uint32_t* seg_b = nullptr;
+  const uint32_t* seg_table = nullptr;
+  uint32_t seg_mul = 0;
   int seg_bits;              // ids < 2^seg_bits
   const uint32_t* start;     // [n]
   const uint32_t* end;       // [n]
   int pos_bits;              // coordinates < 2^pos_bits
   const uint64_t* score_key; // [n]
   const uint8_t* alive;      // [n] or nullptr
+  const uint8_t* and_with = nullptr;  // optional: keep[i] &= and_with[i] (intersection with another axis' result)
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
 
@@ -158,3 +164,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
 // (src/plane_sweep_exact.rs:29-86, 183-193); length is always q_end - q_start.
 int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint32_t* q_end,
                    const double* identity, int scoring, uint64_t* key_out);
+// Step-1 retain (src/paf_filter.rs:384-388), score keys and the two scalars the pipeline needs, in one pass over
+// the records: scalars[0] = max coordinate, scalars[1] = number of retained records (device u64, pre-zeroed).
+int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, uint64_t* score_key,
+                unsigned long long* scalars);

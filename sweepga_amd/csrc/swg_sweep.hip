@@ -64,16 +64,10 @@ __device__ __forceinline__ uint64_t sortable_desc(double score) {
   return ~asc;
 }
 
-__global__ __launch_bounds__(EW_THREADS) void score_key_kernel(uint64_t n, const uint32_t* __restrict__ qs,
-                                                               const uint32_t* __restrict__ qe,
-                                                               const double* __restrict__ identity, int scoring,
-                                                               uint64_t* __restrict__ key) {
-  uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ uint64_t score_key_of(uint32_t qs, uint32_t qe, double id, int scoring) {
   const double NEG_INF = -__longlong_as_double(0x7ff0000000000000ll);
-  const uint64_t len_u = (uint64_t)qe[i] - (uint64_t)qs[i];  // u64 wrapping subtraction as in the reference
+  const uint64_t len_u = (uint64_t)qe - (uint64_t)qs;  // u64 wrapping subtraction as in the reference
   const double length = (double)len_u;
-  const double id = identity[i];
   double score;
   switch (scoring) {
     case SWG_SCORE_IDENTITY: score = id <= 0.0 ? NEG_INF : id; break;
@@ -82,11 +76,57 @@ __global__ __launch_bounds__(EW_THREADS) void score_key_kernel(uint64_t n, const
     case SWG_SCORE_MATCHES: score = (length <= 0.0 || id <= 0.0) ? NEG_INF : __dmul_rn(length, id); break;
     default: score = (length <= 0.0 || id <= 0.0) ? NEG_INF : __dmul_rn(id, swg_log_glibc(length)); break;
   }
-  key[i] = sortable_desc(score);
+  return sortable_desc(score);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void score_key_kernel(uint64_t n, const uint32_t* __restrict__ qs,
+                                                               const uint32_t* __restrict__ qe,
+                                                               const double* __restrict__ identity, int scoring,
+                                                               uint64_t* __restrict__ key) {
+  uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i < n) key[i] = score_key_of(qs[i], qe[i], identity[i], scoring);
+}
+
+// retain + score key + max coordinate + retained count in one pass (grid-stride, one atomic pair per wave)
+__global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
+                                                             const uint32_t* __restrict__ t_id,
+                                                             const uint32_t* __restrict__ block_len,
+                                                             const double* __restrict__ identity,
+                                                             const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
+                                                             const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
+                                                             uint64_t min_block, int keep_self, double min_identity,
+                                                             int scoring, uint8_t* __restrict__ alive,
+                                                             uint64_t* __restrict__ key,
+                                                             unsigned long long* __restrict__ scalars) {
+  uint32_t mx = 0, cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
+    const double id = identity[i];
+    const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
+    const bool ok = (uint64_t)block_len[i] >= min_block && (keep_self || q_id[i] != t_id[i]) && id >= min_identity;
+    alive[i] = ok ? 1 : 0;
+    key[i] = score_key_of(a, b, id, scoring);
+    const uint32_t m1 = a > b ? a : b, m2 = c > d ? c : d;
+    const uint32_t m = m1 > m2 ? m1 : m2;
+    if (m > mx) mx = m;
+    cnt += ok ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_down(mx, o, 64);
+    if (t > mx) mx = t;
+    cnt += __shfl_down(cnt, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&scalars[0], (unsigned long long)mx);
+    atomicAdd(&scalars[1], (unsigned long long)cnt);
+  }
 }
 
 // ---- begins ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, const uint64_t* __restrict__ seg,
+                                                                 const uint32_t* __restrict__ seg_a,
+                                                                 const uint32_t* __restrict__ seg_b,
+                                                                 const uint32_t* __restrict__ seg_table, uint32_t seg_mul,
                                                                  const uint32_t* __restrict__ start,
                                                                  const uint8_t* __restrict__ alive, int pos_bits,
                                                                  uint64_t* __restrict__ key,
@@ -94,7 +134,18 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
   uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= n) return;
   const bool live = alive ? alive[i] != 0 : true;
-  key[i] = live ? (((seg[i] + 1) << pos_bits) | start[i]) : 0ull;
+  uint64_t k = 0;
+  if (live) {
+    uint64_t sg;
+    if (seg) {
+      sg = seg[i];
+    } else {
+      const uint32_t b = seg_b[i];
+      sg = (uint64_t)seg_a[i] * seg_mul + (seg_table ? seg_table[b] : b);
+    }
+    k = ((sg + 1) << pos_bits) | start[i];
+  }
+  key[i] = k;
   val[i] = (uint32_t)i;
 }
 
@@ -445,6 +496,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
 __global__ __launch_bounds__(EW_THREADS) void kinf_mark_kernel(uint64_t n, const uint32_t* __restrict__ start,
                                                                const uint32_t* __restrict__ end,
                                                                const uint8_t* __restrict__ alive,
+                                                               const uint8_t* __restrict__ and_with,
                                                                uint8_t* __restrict__ keep,
                                                                uint32_t* __restrict__ n_zero) {
   uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -453,27 +505,29 @@ __global__ __launch_bounds__(EW_THREADS) void kinf_mark_kernel(uint64_t n, const
   uint8_t kf = 0;
   if (live) {
     if (start[i] < end[i])
-      kf = 1;
+      kf = (!and_with || and_with[i]) ? 1 : 0;
     else
       atomicAdd(n_zero, 1u);
   }
   keep[i] = kf;
 }
 __global__ __launch_bounds__(EW_THREADS) void kinf_single_kernel(uint64_t n, const uint8_t* __restrict__ single,
+                                                                 const uint8_t* __restrict__ and_with,
                                                                  uint8_t* __restrict__ keep) {
   uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
-  if (i < n && single[i]) keep[i] = 1;
+  if (i < n && single[i] && (!and_with || and_with[i])) keep[i] = 1;
 }
 
 __global__ __launch_bounds__(EW_THREADS) void combine_kernel(uint64_t n, const uint8_t* __restrict__ alive,
                                                              const uint8_t* __restrict__ single,
                                                              const uint8_t* __restrict__ top,
                                                              const uint8_t* __restrict__ ovl,
+                                                             const uint8_t* __restrict__ and_with,
                                                              uint8_t* __restrict__ keep) {
   uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (i >= n) return;
   const bool live = alive ? alive[i] != 0 : true;
-  keep[i] = (live && (single[i] || (top[i] && !ovl[i]))) ? 1 : 0;
+  keep[i] = (live && (single[i] || (top[i] && !ovl[i])) && (!and_with || and_with[i])) ? 1 : 0;
 }
 
 inline unsigned blocks_for(uint64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -485,6 +539,17 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
   if (n == 0) return SWG_OK;
   SWG_LAUNCH(ctx, "score_key", score_key_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, ctx->stream>>>(
                                    n, q_start, q_end, identity, scoring, key_out));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, uint64_t* score_key,
+                unsigned long long* scalars) {
+  if (r->n == 0) return SWG_OK;
+  SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
+                                 r->n, r->q_id, r->t_id, r->block_len, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
+                                 cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, score_key,
+                                 scalars));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
@@ -516,7 +581,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     single = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                       n, in.seg, in.start, in.alive, in.pos_bits, S, I));
+                                       n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits));
     E = S2;  // the sort's scratch key buffer is free again
@@ -531,14 +596,14 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     uint32_t* n_zero = swg_alloc<uint32_t>(ctx, 2);
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemsetAsync(n_zero, 0, 8, st));
-    SWG_LAUNCH(ctx, "kinf_mark", kinf_mark_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.start, in.end, in.alive, keep,
-                                                                                        n_zero));
+    SWG_LAUNCH(ctx, "kinf_mark", kinf_mark_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.start, in.end, in.alive, in.and_with,
+                                                                                        keep, n_zero));
     SWG_KERNEL_CHECK(ctx);
     uint64_t h = 0;
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(n_zero), &h, 1));
     if ((uint32_t)h != 0) {  // zero-length intervals exist: need segment sizes -> sort the begins once
       SWG_TRY(sort_begins());
-      SWG_LAUNCH(ctx, "kinf_single", kinf_single_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, single, keep));
+      SWG_LAUNCH(ctx, "kinf_single", kinf_single_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, single, in.and_with, keep));
       SWG_KERNEL_CHECK(ctx);
     }
     swg_arena_restore(ctx, mark);
@@ -594,7 +659,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   else
     SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kernel<false><<<ntiles, TB, 0, st>>>(ta));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "combine", combine_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, top, ovl, keep));
+  SWG_LAUNCH(ctx, "combine", combine_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, top, ovl, in.and_with, keep));
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);
   return SWG_OK;
