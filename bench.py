@@ -127,6 +127,61 @@ def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev):
                 sample=f"first {g} genome-pair groups of rank 0's shard = {m} mappings, oracle apply_filters {secs:.2f} s"), parity
 
 
+def end_to_end(n_lines, ref_lines, threads):
+    """PAF file -> PAF file through the C++ host (native ingest, swg_filter, native egress), default flags, next to
+    the oracle's CLI on a prefix of the same file; outputs compared byte for byte on that prefix."""
+    import hashlib
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from sweepga_amd import build as _build
+    ref_bin = os.path.join(ROOT, "oracle", "sweepga-ref")
+    work = tempfile.mkdtemp(prefix="swg_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        paf = os.path.join(work, "in.paf")
+        with open(paf, "wb") as f:
+            subprocess.check_call([_build.SYNTH, str(n_lines)], stdout=f)
+        size = os.path.getsize(paf)
+        targ = ["--threads", str(threads)] if threads else []
+        best = None
+        for _ in range(2):  # second run: page cache warm, as for the CPU side
+            t0 = time.perf_counter()
+            r = subprocess.run([_build.CLI, paf, "--output-file", os.path.join(work, "gpu.paf"), *targ],
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr.strip()[-300:]}
+            best = wall if best is None else min(best, wall)
+        m = re.search(r"read ([\d.]+) ms \(load ([\d.]+), parse ([\d.]+)\), filter ([\d.]+) ms \(device ([\d.]+), h2d ([\d.]+), "
+                      r"d2h ([\d.]+)\), write ([\d.]+) ms", r.stderr)
+        phases = dict(zip(("read_ms", "load_ms", "parse_ms", "filter_ms", "device_ms", "h2d_ms", "d2h_ms", "write_ms"),
+                          map(float, m.groups()))) if m else None
+        out = {"lines": n_lines, "input_bytes": size, "flags": "(defaults)", "host_threads": threads or os.cpu_count(),
+               "wall_s": best, "value": n_lines / best, "unit": "mappings/s (process start to exit, page cache warm)",
+               "phases": phases}
+        if ref_lines > 0 and os.path.exists(ref_bin):
+            sub = os.path.join(work, "sub.paf")
+            with open(paf, "rb") as f, open(sub, "wb") as g:
+                k = 0
+                for line in f:
+                    if k >= ref_lines:
+                        break
+                    g.write(line)
+                    k += 1
+            t0 = time.perf_counter()
+            subprocess.check_call([ref_bin, sub, "--output-file", os.path.join(work, "ref.paf")])
+            ref_wall = time.perf_counter() - t0
+            subprocess.check_call([_build.CLI, sub, "--output-file", os.path.join(work, "gpu_sub.paf"), "--quiet", *targ])
+            sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+            out["cpu_reference_cli"] = {"lines": k, "wall_s": ref_wall, "value": k / ref_wall, "unit": "mappings/s",
+                                        "kind": "port", "cores": 1}
+            out["byte_identical_on_prefix"] = sha(os.path.join(work, "ref.paf")) == sha(os.path.join(work, "gpu_sub.paf"))
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +194,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--others", type=int, default=2, help="timed steps for the other two flag sets (0 = skip them)")
     ap.add_argument("--pcie", action="store_true", help="also time swg_filter (host buffers in/out, PCIe included)")
+    ap.add_argument("--e2e", type=int, default=0, help="lines of synthetic PAF for the file->file leg (0 = skip)")
+    ap.add_argument("--e2e-ref", type=int, default=1_000_000, help="prefix of that file the oracle CLI is timed on")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the e2e leg (0 = all cores)")
     args = ap.parse_args()
 
     import torch
@@ -249,6 +307,8 @@ def main():
         pcie = {"value": n / dt, "unit": "mappings/s", "ms": dt * 1e3, "h2d_ms": hs.h2d_ms, "d2h_ms": hs.d2h_ms,
                 "device_ms": hs.device_ms, "note": "swg_filter: pageable host buffers in and out, second call"}
 
+    e2e = end_to_end(args.e2e, args.e2e_ref, args.threads) if (args.e2e > 0 and rank == 0 and world == 1) else None
+
     if rank == 0:
         algo = ALGO_BYTES_SWEEP if args.pipeline == "sweep" else ALGO_BYTES_FULL
         ms_per_step = elapsed / args.steps * 1e3
@@ -300,6 +360,7 @@ def main():
             "counts": main_counts,
             "other_pipelines": others,
             "pcie_inclusive": pcie,
+            "end_to_end": e2e,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
         print(json.dumps(out))

@@ -195,6 +195,38 @@ int swg_profile_count(swg_ctx* ctx);
 /* Entry i: name (owned by ctx, valid until the next reset), launches, summed milliseconds. */
 int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
 
+/* ---- PAF ingest / egress (host side; no GPU needed for open/write) ----------------------------------------
+ * The reference reads the PAF twice (extract_metadata, then write_filtered_output re-reads it).  A swg_paf
+ * handle keeps the mapped text, the SoA columns swg_filter() takes and each record's (offset,length), so the
+ * writer does not parse again.  `threads` <= 0 means "all host cores".  Errors: negative code, message from
+ * swg_paf_last_error() (thread-local).
+ */
+typedef struct swg_paf swg_paf;
+/* open_paf_input (src/paf.rs:10-30: .gz/.bgz -> BGZF, blocks inflated in parallel; "-" = stdin) +
+ * PafFilter::extract_metadata (src/paf_filter.rs:292-376) + SequenceIndex (src/sequence_index.rs:7-31). */
+int swg_paf_open(const char* path, int threads, swg_paf** out);
+/* same, over PAF text already in memory (copied) */
+int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** out);
+void swg_paf_close(swg_paf* p);
+/* records in input order; pointers are owned by the handle */
+const swg_records* swg_paf_records(const swg_paf* p);
+/* physical line count (incl. skipped lines) and each record's rank = 0-based line index (src/paf_filter.rs:298) */
+uint64_t swg_paf_num_lines(const swg_paf* p);
+const uint64_t* swg_paf_ranks(const swg_paf* p);
+uint32_t swg_paf_num_sequences(const swg_paf* p);
+const char* swg_paf_sequence_name(const swg_paf* p, uint32_t id);
+void swg_paf_timing(const swg_paf* p, double* load_ms, double* parse_ms);
+int swg_paf_text(const swg_paf* p, const char** text, uint64_t* len);
+/* PafFilter::write_filtered_output (src/paf_filter.rs:1689-1726): records with status != 0, input order,
+ * original bytes + "\tch:Z:chain_<N>" (chain != 0) + "\tst:Z:<status>".  out_path "-" = stdout. */
+int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status, const uint32_t* chain, int threads,
+                  uint64_t* n_written);
+/* PafFilter::filter_paf (src/paf_filter.rs:278-289): open -> swg_filter -> write.
+ * timing_ms (optional) = {load, parse, filter (incl. PCIe), write}. */
+int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, const swg_config* cfg, int threads,
+                   swg_stats* stats, double timing_ms[4]);
+const char* swg_paf_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

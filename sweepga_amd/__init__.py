@@ -7,5 +7,6 @@ from ._lib import Context, SwgError, K_INF, default_context, load  # noqa: F401
 from .filter import (ChainStatus, FilterConfig, FilterMode, PafFilter, PlaneSweepMapping, RecordMeta,  # noqa: F401
                      ScoringFunction, SequenceIndex, pack_records, plane_sweep_both, plane_sweep_query,
                      plane_sweep_target, USIZE_MAX, UnionFind, merge_mappings_into_chains, plane_sweep_scaffolds)
+from .paf import PafFile  # noqa: F401
 
 __version__ = "0.1.0"

@@ -15,7 +15,10 @@ K_INF = 2**64 - 1
 SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
            "swg_filter", "swg_filter_device", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
            "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range", "swg_profile_enable",
-           "swg_profile_reset", "swg_profile_count", "swg_profile_get"]
+           "swg_profile_reset", "swg_profile_count", "swg_profile_get",
+           "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
+           "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
+           "swg_paf_write", "swg_filter_paf", "swg_paf_last_error"]
 
 
 class SwgError(RuntimeError):
@@ -138,6 +141,33 @@ def load():
     lib.swg_profile_get.restype = C.c_int
     lib.swg_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_double)]
+    lib.swg_paf_open.restype = C.c_int
+    lib.swg_paf_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.swg_paf_open_buffer.restype = C.c_int
+    lib.swg_paf_open_buffer.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
+    lib.swg_paf_close.restype = None
+    lib.swg_paf_close.argtypes = [C.c_void_p]
+    lib.swg_paf_records.restype = C.POINTER(SwgRecords)
+    lib.swg_paf_records.argtypes = [C.c_void_p]
+    lib.swg_paf_num_lines.restype = C.c_uint64
+    lib.swg_paf_num_lines.argtypes = [C.c_void_p]
+    lib.swg_paf_ranks.restype = C.c_void_p
+    lib.swg_paf_ranks.argtypes = [C.c_void_p]
+    lib.swg_paf_num_sequences.restype = C.c_uint32
+    lib.swg_paf_num_sequences.argtypes = [C.c_void_p]
+    lib.swg_paf_sequence_name.restype = C.c_char_p
+    lib.swg_paf_sequence_name.argtypes = [C.c_void_p, C.c_uint32]
+    lib.swg_paf_timing.restype = None
+    lib.swg_paf_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.swg_paf_text.restype = C.c_int
+    lib.swg_paf_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.swg_paf_write.restype = C.c_int
+    lib.swg_paf_write.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    lib.swg_filter_paf.restype = C.c_int
+    lib.swg_filter_paf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SwgConfig), C.c_int,
+                                   C.POINTER(SwgStats), C.POINTER(C.c_double)]
+    lib.swg_paf_last_error.restype = C.c_char_p
+    lib.swg_paf_last_error.argtypes = []
     _lib = lib
     return lib
 

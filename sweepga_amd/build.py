@@ -6,7 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsweepga_gpu.so")
-SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip"]
+SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip",
+           os.path.join("host", "paf_io.cpp")]
 
 
 def _hipcc():
@@ -21,6 +22,7 @@ def stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sweepga_gpu.h")]
+    deps += [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
     deps = [d for d in deps if not os.path.isdir(d)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
@@ -42,14 +44,31 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+SYNTH_SRC = os.path.join(CSRC, "host", "paf_synth.cpp")
+SYNTH = os.path.join(HERE, "bin", "paf-synth")
+
+
+def build_synth(force=False, verbose=False):
+    """Synthetic PAF generator used by bench.py's end-to-end leg."""
+    if not force and os.path.exists(SYNTH) and os.path.getmtime(SYNTH) >= os.path.getmtime(SYNTH_SRC):
+        return SYNTH
+    os.makedirs(os.path.dirname(SYNTH), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", SYNTH, SYNTH_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SYNTH
+
+
 def build(force=False, verbose=False):
     if force or stale():
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
-        cmd += [os.path.join(CSRC, s) for s in SOURCES]
+        cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_cli(force=force, verbose=verbose)
+    build_synth(force=force, verbose=verbose)
     return LIB
 
 

@@ -1,0 +1,787 @@
+// PAF ingest / egress for the filter path (host side, no HIP calls in this file).
+//
+//   open_paf_input ............ src/paf.rs:10-30        (.gz / .bgz by extension -> BGZF reader; else plain file)
+//   extract_metadata .......... src/paf_filter.rs:292-376 (rank = physical line index; < 11 fields skipped but counted;
+//                                identity = matches / max(block_len,1); dv:f: and cg:Z: overrides, last writer wins)
+//   parse_cigar_counts ........ src/paf.rs:32-64        (only the '=' total matters to the filter)
+//   SequenceIndex ............. src/sequence_index.rs:7-31 (ids in first-appearance order, query before target)
+//   genome prefixes ........... src/paf_filter.rs:1022-1030, src/plane_sweep_scaffold.rs:13-22
+//   write_filtered_output ..... src/paf_filter.rs:1689-1726 (input order, original bytes + ch:Z / st:Z tags)
+//   filter_paf ................ src/paf_filter.rs:278-289
+//
+// The reference makes two sequential passes over the text with one String allocation per line and per field
+// vector.  Here the file is mapped once, split at line boundaries into one slice per host thread, counted,
+// parsed straight into the SoA columns swg_filter() takes, and the writer reuses the (offset,length) of every
+// record instead of re-reading the input.  BGZF blocks are inflated in parallel.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/sweepga_gpu.h"
+
+namespace {
+
+thread_local std::string g_paf_error;
+
+int paf_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_paf_error = buf;
+  return code;
+}
+
+int pick_threads(int threads) {
+  if (threads > 0) return threads > 256 ? 256 : threads;
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc ? (int)(hc > 64 ? 64 : hc) : 1;
+}
+
+template <class F>
+void parallel_for(int threads, F&& body) {  // body(thread_index)
+  if (threads <= 1) {
+    body(0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(threads - 1);
+  for (int t = 1; t < threads; ++t) pool.emplace_back([&body, t] { body(t); });
+  body(0);
+  for (auto& th : pool) th.join();
+}
+
+// ---- Rust-compatible scalar parsers (str::parse::<u64>, str::parse::<f64>) ---------------------------
+inline bool parse_u64(const char* s, size_t n, uint64_t* out) {
+  size_t i = 0;
+  if (n == 0) return false;
+  if (s[0] == '+') i = 1;
+  if (i >= n) return false;
+  uint64_t v = 0;
+  for (; i < n; ++i) {
+    const unsigned d = (unsigned)(s[i] - '0');
+    if (d > 9) return false;
+    if (v > (UINT64_MAX - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  *out = v;
+  return true;
+}
+inline bool parse_f64(const char* s, size_t n, double* out) {  // no whitespace, no hex floats, no "nan(...)"
+  if (n == 0 || n > 400) return false;
+  char buf[401];
+  for (size_t i = 0; i < n; ++i) {
+    const char c = s[i];
+    if (c == 'x' || c == 'X' || c == ' ' || c == '\t' || c == '\n' || c == '(' || c == '\0') return false;
+    buf[i] = c;
+  }
+  buf[n] = '\0';
+  char* e = nullptr;
+  const double v = std::strtod(buf, &e);
+  if (e == buf || *e != '\0') return false;
+  *out = v;
+  return true;
+}
+// src/paf.rs:32-64: total of '=' run lengths; false when a run length does not parse
+inline bool cigar_eq_total(const char* s, size_t n, uint64_t* matches) {
+  uint64_t m = 0, cur = 0;
+  bool have = false, overflow = false;
+  for (size_t i = 0; i < n; ++i) {
+    const char ch = s[i];
+    const unsigned d = (unsigned)(ch - '0');
+    if (d <= 9) {
+      if (cur > (UINT64_MAX - d) / 10) overflow = true;
+      cur = cur * 10 + d;
+      have = true;
+    } else {
+      if (!have || overflow) return false;
+      if (ch == '=') m += cur;
+      cur = 0;
+      have = false;
+      overflow = false;
+    }
+  }
+  *matches = m;
+  return true;
+}
+
+// ---- input bytes ------------------------------------------------------------------------------------------
+struct Text {
+  const char* data = nullptr;
+  size_t len = 0;
+  void* map = nullptr;  // munmap(map, map_len) when set
+  size_t map_len = 0;
+  std::vector<char> owned;
+  ~Text() {
+    if (map) munmap(map, map_len);
+  }
+};
+
+bool has_gz_ext(const char* path) {  // src/paf.rs:15-19
+  const char* dot = std::strrchr(path, '.');
+  const char* slash = std::strrchr(path, '/');
+  if (!dot || (slash && dot < slash)) return false;
+  return !std::strcmp(dot + 1, "gz") || !std::strcmp(dot + 1, "bgz");
+}
+
+struct BgzfBlock {
+  size_t cdata, clen, out, isize;
+  uint32_t crc;
+};
+
+// BGZF: every member carries BSIZE in a 'B','C' extra subfield -> blocks can be located without inflating.
+bool bgzf_index(const unsigned char* p, size_t n, std::vector<BgzfBlock>* blocks, size_t* total) {
+  size_t pos = 0, out = 0;
+  while (pos < n) {
+    if (n - pos < 18 || p[pos] != 0x1f || p[pos + 1] != 0x8b || p[pos + 2] != 8 || !(p[pos + 3] & 4)) return false;
+    const size_t xlen = p[pos + 10] | (size_t)p[pos + 11] << 8;
+    if (n - pos < 12 + xlen + 8) return false;
+    size_t bsize = 0;
+    for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen;) {
+      const size_t slen = p[x + 2] | (size_t)p[x + 3] << 8;
+      if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= pos + 12 + xlen) bsize = (p[x + 4] | (size_t)p[x + 5] << 8) + 1;
+      x += 4 + slen;
+    }
+    if (!bsize || bsize < 12 + xlen + 8 || n - pos < bsize) return false;
+    const unsigned char* tail = p + pos + bsize - 4;
+    const size_t isize = tail[0] | (size_t)tail[1] << 8 | (size_t)tail[2] << 16 | (size_t)tail[3] << 24;
+    const uint32_t crc = tail[-4] | (uint32_t)tail[-3] << 8 | (uint32_t)tail[-2] << 16 | (uint32_t)tail[-1] << 24;
+    blocks->push_back({pos + 12 + xlen, bsize - 12 - xlen - 8, out, isize, crc});
+    out += isize;
+    pos += bsize;
+  }
+  *total = out;
+  return true;
+}
+
+int gunzip_all(const unsigned char* p, size_t n, int threads, std::vector<char>* out) {
+  std::vector<BgzfBlock> blocks;
+  size_t total = 0;
+  if (bgzf_index(p, n, &blocks, &total)) {
+    out->resize(total);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    parallel_for(threads, [&](int) {
+      z_stream z{};
+      if (inflateInit2(&z, -15) != Z_OK) {
+        bad = 1;
+        return;
+      }
+      for (;;) {
+        const size_t b = next.fetch_add(1);
+        if (b >= blocks.size()) break;
+        const BgzfBlock& k = blocks[b];
+        unsigned char none;
+        unsigned char* dst = k.isize ? reinterpret_cast<unsigned char*>(out->data() + k.out) : &none;
+        inflateReset(&z);
+        z.next_in = const_cast<unsigned char*>(p + k.cdata);
+        z.avail_in = (uInt)k.clen;
+        z.next_out = dst;
+        z.avail_out = (uInt)(k.isize ? k.isize : 1);
+        if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.total_out != k.isize ||
+            (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, (uInt)k.isize) != k.crc)
+          bad = 1;
+      }
+      inflateEnd(&z);
+    });
+    if (bad) return paf_error(SWG_ERR_INVALID, "corrupt BGZF block");
+    return SWG_OK;
+  }
+  // plain (possibly multi-member) gzip: sequential
+  z_stream z{};
+  if (inflateInit2(&z, 15 + 16) != Z_OK) return paf_error(SWG_ERR_OOM, "inflateInit2 failed");
+  out->clear();
+  std::vector<unsigned char> buf(1 << 20);
+  size_t pos = 0;
+  bool complete = true;  // the input must end exactly at a member end
+  while (pos < n) {
+    z.next_in = const_cast<unsigned char*>(p + pos);
+    z.avail_in = (uInt)((n - pos) > (1u << 30) ? (1u << 30) : (n - pos));
+    const size_t fed = z.avail_in;
+    int rc;
+    do {
+      z.next_out = buf.data();
+      z.avail_out = (uInt)buf.size();
+      rc = inflate(&z, Z_NO_FLUSH);
+      if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+        inflateEnd(&z);
+        return paf_error(SWG_ERR_INVALID, "gzip stream is corrupt (zlib error %d)", rc);
+      }
+      out->insert(out->end(), buf.data(), buf.data() + (buf.size() - z.avail_out));
+    } while (rc == Z_OK && (z.avail_in > 0 || z.avail_out == 0));
+    pos += fed - z.avail_in;
+    complete = rc == Z_STREAM_END;
+    if (rc == Z_STREAM_END) {
+      if (pos < n) inflateReset(&z);
+    } else if (fed - z.avail_in == 0) {
+      break;  // no progress: truncated
+    }
+  }
+  inflateEnd(&z);
+  if (!complete) return paf_error(SWG_ERR_INVALID, "gzip stream is truncated");
+  return SWG_OK;
+}
+
+int load_text(const char* path, int threads, Text* t) {
+  const bool is_stdin = !std::strcmp(path, "-");
+  int fd = is_stdin ? 0 : open(path, O_RDONLY);
+  if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot open %s: %s", path, std::strerror(errno));
+  struct stat st {};
+  const bool regular = !is_stdin && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+  const unsigned char* raw = nullptr;
+  size_t raw_len = 0;
+  std::vector<char> slurp;
+  void* map = nullptr;
+  if (regular && st.st_size > 0) {
+    map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) map = nullptr;
+  }
+  if (map) {
+    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL | MADV_WILLNEED);
+    raw = static_cast<const unsigned char*>(map);
+    raw_len = (size_t)st.st_size;
+  } else {
+    char buf[1 << 16];
+    ssize_t k;
+    while ((k = read(fd, buf, sizeof buf)) > 0) slurp.insert(slurp.end(), buf, buf + k);
+    if (k < 0) {
+      if (!is_stdin) close(fd);
+      return paf_error(SWG_ERR_INVALID, "read error on %s: %s", path, std::strerror(errno));
+    }
+    raw = reinterpret_cast<const unsigned char*>(slurp.data());
+    raw_len = slurp.size();
+  }
+  if (!is_stdin) close(fd);
+  const bool gz = has_gz_ext(path) || (raw_len >= 2 && raw[0] == 0x1f && raw[1] == 0x8b);
+  if (gz && raw_len) {
+    const int rc = gunzip_all(raw, raw_len, threads, &t->owned);
+    if (map) munmap(map, raw_len);
+    if (rc != SWG_OK) return rc;
+    t->data = t->owned.data();
+    t->len = t->owned.size();
+    return SWG_OK;
+  }
+  if (map) {
+    t->map = map;
+    t->map_len = raw_len;
+    t->data = static_cast<const char*>(map);
+    t->len = raw_len;
+  } else {
+    t->owned.swap(slurp);
+    t->data = t->owned.data();
+    t->len = t->owned.size();
+  }
+  return SWG_OK;
+}
+
+// ---- name interning -----------------------------------------------------------------------------------
+struct Interner {  // string_view keys point into the (immutable) input text
+  std::unordered_map<std::string_view, uint32_t> ids;
+  std::vector<std::string_view> names;
+  std::string_view last[2];
+  uint32_t last_id[2] = {0, 0};
+  uint32_t get(std::string_view nm, int slot) {  // slot 0 = query column, 1 = target column (one-entry caches)
+    if (!last[slot].empty() && last[slot] == nm) return last_id[slot];
+    uint32_t id;
+    auto it = ids.find(nm);
+    if (it != ids.end()) {
+      id = it->second;
+    } else {
+      id = (uint32_t)names.size();
+      names.push_back(nm);
+      ids.emplace(nm, id);
+    }
+    last[slot] = nm;
+    last_id[slot] = id;
+    return id;
+  }
+};
+
+std::string prefix_last(std::string_view n) {  // src/paf_filter.rs:1022-1030
+  const size_t p = n.rfind('#');
+  return std::string(p == std::string_view::npos ? n : n.substr(0, p + 1));
+}
+std::string prefix_two(std::string_view n) {  // src/plane_sweep_scaffold.rs:13-22
+  const size_t p1 = n.find('#');
+  if (p1 == std::string_view::npos) return std::string(n);
+  const size_t p2 = n.find('#', p1 + 1);
+  std::string r(n.substr(0, p1));
+  r += '#';
+  r += p2 == std::string_view::npos ? n.substr(p1 + 1) : n.substr(p1 + 1, p2 - p1 - 1);
+  r += '#';
+  return r;
+}
+uint32_t genome_table(const std::vector<std::string>& names, std::string (*fn)(std::string_view), std::vector<uint32_t>* out) {
+  std::unordered_map<std::string, uint32_t> g;
+  out->assign(names.empty() ? 1 : names.size(), 0);
+  for (size_t i = 0; i < names.size(); ++i) (*out)[i] = g.emplace(fn(names[i]), (uint32_t)g.size()).first->second;
+  return g.empty() ? 1u : (uint32_t)g.size();
+}
+
+struct Slice {
+  size_t begin = 0, end = 0;     // byte range, whole lines
+  uint64_t lines = 0, recs = 0;  // counted in pass 1
+  uint64_t line_base = 0, rec_base = 0;
+  Interner names;
+  std::vector<uint32_t> remap;   // local id -> global id
+  int err = SWG_OK;
+  uint64_t err_line = 0;
+  const char* err_what = nullptr;
+};
+
+}  // namespace
+
+struct swg_paf {
+  Text text;
+  uint64_t n_lines = 0;
+  std::vector<uint32_t> q_id, t_id, qs, qe, ts, te, matches, block;
+  std::vector<double> identity;
+  std::vector<uint8_t> strand;
+  std::vector<uint64_t> rank, rec_off;
+  std::vector<uint32_t> rec_len;
+  std::vector<std::string> names;
+  std::vector<uint32_t> g_last, g_two;
+  swg_records rec{};
+  double load_ms = 0, parse_ms = 0;
+};
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
+
+// One line [p, e) without its "\n"; returns false when it has fewer than 11 tab-separated fields.
+inline bool split11(const char* p, const char* e, const char* f[12]) {
+  f[0] = p;
+  for (int k = 1; k <= 10; ++k) {
+    const char* t = static_cast<const char*>(std::memchr(f[k - 1], '\t', (size_t)(e - f[k - 1])));
+    if (!t) return false;
+    f[k] = t + 1;
+  }
+  const char* t = static_cast<const char*>(std::memchr(f[10], '\t', (size_t)(e - f[10])));
+  f[11] = t ? t + 1 : e + 1;  // start of the tag area (one past the separator), e + 1 = none
+  return true;
+}
+
+int parse_text(swg_paf* p, int threads) {
+  const char* text = p->text.data;
+  const size_t len = p->text.len;
+  if (threads > 1 && len < (size_t)threads * 65536) threads = (int)(len / 65536) ? (int)(len / 65536) : 1;
+  std::vector<Slice> sl(threads);
+  for (int t = 0; t < threads; ++t) {
+    size_t b = len / threads * t;
+    if (t > 0 && b > 0) {
+      const void* nl = std::memchr(text + b - 1, '\n', len - (b - 1));
+      b = nl ? (size_t)(static_cast<const char*>(nl) - text) + 1 : len;
+    }
+    sl[t].begin = b;
+    if (t > 0) sl[t - 1].end = b;
+  }
+  sl[threads - 1].end = len;
+
+  // pass 1: lines and records per slice
+  parallel_for(threads, [&](int t) {
+    Slice& s = sl[t];
+    uint64_t lines = 0, recs = 0;
+    for (size_t pos = s.begin; pos < s.end;) {
+      const void* nl = std::memchr(text + pos, '\n', s.end - pos);
+      const size_t end = nl ? (size_t)(static_cast<const char*>(nl) - text) : s.end;
+      int tabs = 0;
+      for (const char* q = text + pos; tabs < 10;) {
+        q = static_cast<const char*>(std::memchr(q, '\t', (size_t)(text + end - q)));
+        if (!q) break;
+        ++tabs;
+        ++q;
+      }
+      recs += tabs >= 10;
+      ++lines;
+      pos = end + 1;
+    }
+    s.lines = lines;
+    s.recs = recs;
+  });
+  uint64_t n_lines = 0, n = 0;
+  for (auto& s : sl) {
+    s.line_base = n_lines;
+    s.rec_base = n;
+    n_lines += s.lines;
+    n += s.recs;
+  }
+  p->n_lines = n_lines;
+  if (n >= (uint64_t(1) << 31)) return paf_error(SWG_ERR_RANGE, "more than 2^31-1 records");
+  const size_t cap = n ? n : 1;
+  for (auto* v : {&p->q_id, &p->t_id, &p->qs, &p->qe, &p->ts, &p->te, &p->matches, &p->block, &p->rec_len}) v->resize(cap);
+  p->identity.resize(cap);
+  p->strand.resize(cap);
+  p->rank.resize(cap);
+  p->rec_off.resize(cap);
+
+  // pass 2: parse into the columns
+  parallel_for(threads, [&](int t) {
+    Slice& s = sl[t];
+    uint64_t line = s.line_base, k = s.rec_base;
+    const char* f[12];
+    auto fail = [&](const char* what) {
+      if (s.err == SWG_OK) {
+        s.err = SWG_ERR_RANGE;
+        s.err_line = line;
+        s.err_what = what;
+      }
+      return 0u;
+    };
+    for (size_t pos = s.begin; pos < s.end; ++line) {
+      const void* nl = std::memchr(text + pos, '\n', s.end - pos);
+      const size_t end = nl ? (size_t)(static_cast<const char*>(nl) - text) : s.end;
+      size_t ll = end - pos;
+      if (ll && text[pos + ll - 1] == '\r') --ll;  // BufRead::lines strips "\r\n"
+      const char* b = text + pos;
+      const char* e = b + ll;
+      pos = end + 1;
+      if (!split11(b, e, f)) continue;
+      auto fld = [&](int i) { return std::string_view(f[i], (size_t)(f[i + 1] - 1 - f[i])); };
+      auto u64_or = [&](int i, uint64_t d) {
+        uint64_t v;
+        return parse_u64(f[i], (size_t)(f[i + 1] - 1 - f[i]), &v) ? v : d;
+      };
+      auto narrow = [&](uint64_t v, const char* what) { return v > 0xffffffffull ? fail(what) : (uint32_t)v; };
+      uint64_t matches = u64_or(9, 0);
+      const uint64_t block = u64_or(10, 1);
+      const double denom = (double)(block > 1 ? block : 1);
+      double identity = (double)matches / denom;
+      for (const char* tg = f[11]; tg <= e;) {  // tags, in order; last writer wins
+        const char* te = static_cast<const char*>(std::memchr(tg, '\t', (size_t)(e - tg)));
+        if (!te) te = e;
+        const size_t tl = (size_t)(te - tg);
+        if (tl >= 5 && tg[2] == ':' && tg[4] == ':') {
+          if (tg[0] == 'd' && tg[1] == 'v' && tg[3] == 'f') {
+            double dv;
+            if (parse_f64(tg + 5, tl - 5, &dv)) identity = 1.0 - dv;
+          } else if (tg[0] == 'c' && tg[1] == 'g' && tg[3] == 'Z') {
+            uint64_t cm;
+            if (cigar_eq_total(tg + 5, tl - 5, &cm) && cm > 0) {
+              matches = cm;
+              identity = (double)cm / denom;
+            }
+          }
+        }
+        tg = te + 1;
+      }
+      p->q_id[k] = s.names.get(fld(0), 0);
+      p->t_id[k] = s.names.get(fld(5), 1);
+      p->qs[k] = narrow(u64_or(2, 0), "query_start");
+      p->qe[k] = narrow(u64_or(3, 0), "query_end");
+      p->ts[k] = narrow(u64_or(7, 0), "target_start");
+      p->te[k] = narrow(u64_or(8, 0), "target_end");
+      p->matches[k] = narrow(matches, "matches");
+      p->block[k] = narrow(block, "block_length");
+      p->identity[k] = identity;
+      p->strand[k] = (f[5] - 1 - f[4] == 1 && *f[4] == '+') ? 0 : 1;
+      p->rank[k] = line;
+      p->rec_off[k] = (uint64_t)(b - text);
+      p->rec_len[k] = (uint32_t)ll;
+      if (ll > 0xffffffffull) fail("line length");
+      ++k;
+    }
+  });
+  for (auto& s : sl)
+    if (s.err != SWG_OK)
+      return paf_error(s.err, "%s >= 2^32 on line %llu is not supported by the GPU layout", s.err_what,
+                       (unsigned long long)(s.err_line + 1));
+
+  // global ids: slices in file order, each slice's names in its own first-appearance order
+  {
+    std::unordered_map<std::string_view, uint32_t> ids;
+    for (auto& s : sl) {
+      s.remap.resize(s.names.names.size());
+      for (size_t i = 0; i < s.names.names.size(); ++i) {
+        auto it = ids.find(s.names.names[i]);
+        if (it == ids.end()) {
+          it = ids.emplace(s.names.names[i], (uint32_t)p->names.size()).first;
+          p->names.emplace_back(s.names.names[i]);
+        }
+        s.remap[i] = it->second;
+      }
+    }
+  }
+  parallel_for(threads, [&](int t) {
+    Slice& s = sl[t];
+    if (t == 0) return;  // slice 0's local ids are already global
+    for (uint64_t k = s.rec_base; k < s.rec_base + s.recs; ++k) {
+      p->q_id[k] = s.remap[p->q_id[k]];
+      p->t_id[k] = s.remap[p->t_id[k]];
+    }
+  });
+  const uint32_t n_last = genome_table(p->names, prefix_last, &p->g_last);
+  const uint32_t n_two = genome_table(p->names, prefix_two, &p->g_two);
+  swg_records& r = p->rec;
+  r.n = n;
+  r.q_id = p->q_id.data();
+  r.t_id = p->t_id.data();
+  r.q_start = p->qs.data();
+  r.q_end = p->qe.data();
+  r.t_start = p->ts.data();
+  r.t_end = p->te.data();
+  r.identity = p->identity.data();
+  r.matches = p->matches.data();
+  r.block_len = p->block.data();
+  r.strand = p->strand.data();
+  r.n_seq = (uint32_t)(p->names.empty() ? 1 : p->names.size());
+  r.seq_genome_last = p->g_last.data();
+  r.n_genome_last = n_last;
+  r.seq_genome_two = p->g_two.data();
+  r.n_genome_two = n_two;
+  return SWG_OK;
+}
+
+const char* const STATUS_TAG[4] = {"", "scaffold", "rescued", "unassigned"};  // src/paf_filter.rs:1708-1718
+const size_t STATUS_TAG_LEN[4] = {0, 8, 7, 10};
+
+inline size_t dec_digits(uint32_t v) {
+  size_t d = 1;
+  while (v >= 10) {
+    v /= 10;
+    ++d;
+  }
+  return d;
+}
+inline size_t out_len(const swg_paf* p, uint64_t k, uint8_t st, uint32_t ch) {
+  return (size_t)p->rec_len[k] + (ch ? 12 + dec_digits(ch) : 0) + 6 + STATUS_TAG_LEN[st & 3] + 1;
+}
+inline char* emit(const swg_paf* p, uint64_t k, uint8_t st, uint32_t ch, char* o) {
+  std::memcpy(o, p->text.data + p->rec_off[k], p->rec_len[k]);
+  o += p->rec_len[k];
+  if (ch) {
+    std::memcpy(o, "\tch:Z:chain_", 12);
+    o += 12;
+    const size_t d = dec_digits(ch);
+    for (size_t i = d; i-- > 0; ch /= 10) o[i] = (char)('0' + ch % 10);
+    o += d;
+  }
+  std::memcpy(o, "\tst:Z:", 6);
+  o += 6;
+  std::memcpy(o, STATUS_TAG[st & 3], STATUS_TAG_LEN[st & 3]);
+  o += STATUS_TAG_LEN[st & 3];
+  *o++ = '\n';
+  return o;
+}
+
+bool write_all(int fd, const char* b, size_t n) {
+  while (n) {
+    const ssize_t w = write(fd, b, n);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    b += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+bool pwrite_all(int fd, const char* b, size_t n, off_t at) {
+  while (n) {
+    const ssize_t w = pwrite(fd, b, n, at);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return false;
+    }
+    b += w;
+    n -= (size_t)w;
+    at += w;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* swg_paf_last_error(void) { return g_paf_error.c_str(); }
+
+int swg_paf_open(const char* path, int threads, swg_paf** out) {
+  if (!path || !out) return paf_error(SWG_ERR_INVALID, "swg_paf_open: NULL argument");
+  *out = nullptr;
+  threads = pick_threads(threads);
+  swg_paf* p = new (std::nothrow) swg_paf;
+  if (!p) return paf_error(SWG_ERR_OOM, "host allocation failed");
+  int rc;
+  try {
+    auto t0 = clk::now();
+    rc = load_text(path, threads, &p->text);
+    p->load_ms = ms_since(t0);
+    if (rc == SWG_OK) {
+      t0 = clk::now();
+      rc = parse_text(p, threads);
+      p->parse_ms = ms_since(t0);
+    }
+  } catch (const std::bad_alloc&) {
+    rc = paf_error(SWG_ERR_OOM, "out of host memory while reading %s", path);
+  }
+  if (rc != SWG_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SWG_OK;
+}
+
+int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** out) {
+  if ((!text && len) || !out) return paf_error(SWG_ERR_INVALID, "swg_paf_open_buffer: NULL argument");
+  *out = nullptr;
+  threads = pick_threads(threads);
+  swg_paf* p = new (std::nothrow) swg_paf;
+  if (!p) return paf_error(SWG_ERR_OOM, "host allocation failed");
+  int rc;
+  try {
+    p->text.owned.assign(text, text + len);  // the handle outlives the caller's buffer
+    p->text.data = p->text.owned.data();
+    p->text.len = (size_t)len;
+    const auto t0 = clk::now();
+    rc = parse_text(p, threads);
+    p->parse_ms = ms_since(t0);
+  } catch (const std::bad_alloc&) {
+    rc = paf_error(SWG_ERR_OOM, "out of host memory");
+  }
+  if (rc != SWG_OK) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SWG_OK;
+}
+
+void swg_paf_close(swg_paf* p) { delete p; }
+const swg_records* swg_paf_records(const swg_paf* p) { return p ? &p->rec : nullptr; }
+uint64_t swg_paf_num_lines(const swg_paf* p) { return p ? p->n_lines : 0; }
+const uint64_t* swg_paf_ranks(const swg_paf* p) { return p ? p->rank.data() : nullptr; }
+uint32_t swg_paf_num_sequences(const swg_paf* p) { return p ? (uint32_t)p->names.size() : 0; }
+const char* swg_paf_sequence_name(const swg_paf* p, uint32_t id) {
+  return (p && id < p->names.size()) ? p->names[id].c_str() : nullptr;
+}
+void swg_paf_timing(const swg_paf* p, double* load_ms, double* parse_ms) {
+  if (load_ms) *load_ms = p ? p->load_ms : 0;
+  if (parse_ms) *parse_ms = p ? p->parse_ms : 0;
+}
+int swg_paf_text(const swg_paf* p, const char** text, uint64_t* len) {
+  if (!p || !text || !len) return paf_error(SWG_ERR_INVALID, "swg_paf_text: NULL argument");
+  *text = p->text.data;
+  *len = p->text.len;
+  return SWG_OK;
+}
+
+int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status, const uint32_t* chain, int threads,
+                  uint64_t* n_written) {
+  if (!p || !out_path) return paf_error(SWG_ERR_INVALID, "swg_paf_write: NULL argument");
+  const uint64_t n = p->rec.n;
+  if (n && !status) return paf_error(SWG_ERR_INVALID, "swg_paf_write: status is NULL");
+  threads = pick_threads(threads);
+  if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
+  const bool to_stdout = !std::strcmp(out_path, "-");
+  const int fd = to_stdout ? 1 : open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot create %s: %s", out_path, std::strerror(errno));
+  // sizes per thread range
+  std::vector<uint64_t> bytes(threads + 1, 0), kept(threads, 0);
+  auto lo = [&](int t) { return n / threads * t + (uint64_t)std::min<uint64_t>(t, n % threads); };
+  parallel_for(threads, [&](int t) {
+    uint64_t b = 0, c = 0;
+    for (uint64_t k = lo(t); k < lo(t + 1); ++k)
+      if (status[k]) {
+        b += out_len(p, k, status[k], chain ? chain[k] : 0);
+        ++c;
+      }
+    bytes[t + 1] = b;
+    kept[t] = c;
+  });
+  for (int t = 0; t < threads; ++t) bytes[t + 1] += bytes[t];
+  uint64_t total_kept = 0;
+  for (auto c : kept) total_kept += c;
+  if (n_written) *n_written = total_kept;
+  const bool seekable = !to_stdout && lseek(fd, 0, SEEK_CUR) != (off_t)-1;
+  std::atomic<int> bad{0};
+  constexpr size_t BUF = size_t(8) << 20;
+  if (seekable) {
+    parallel_for(threads, [&](int t) {
+      std::vector<char> buf(BUF + (size_t(1) << 16));
+      off_t at = (off_t)bytes[t];
+      char* o = buf.data();
+      for (uint64_t k = lo(t); k < lo(t + 1); ++k) {
+        if (!status[k]) continue;
+        const size_t need = out_len(p, k, status[k], chain ? chain[k] : 0);
+        if ((size_t)(o - buf.data()) + need > buf.size()) {
+          if (!pwrite_all(fd, buf.data(), (size_t)(o - buf.data()), at)) bad = errno ? errno : EIO;
+          at += o - buf.data();
+          o = buf.data();
+          if (need > buf.size()) buf.resize(need);
+          o = buf.data();
+        }
+        o = emit(p, k, status[k], chain ? chain[k] : 0, o);
+      }
+      if (o != buf.data() && !pwrite_all(fd, buf.data(), (size_t)(o - buf.data()), at)) bad = errno ? errno : EIO;
+    });
+  } else {
+    std::vector<char> buf(BUF + (size_t(1) << 16));
+    char* o = buf.data();
+    for (uint64_t k = 0; k < n && !bad; ++k) {
+      if (!status[k]) continue;
+      const size_t need = out_len(p, k, status[k], chain ? chain[k] : 0);
+      if ((size_t)(o - buf.data()) + need > buf.size()) {
+        if (!write_all(fd, buf.data(), (size_t)(o - buf.data()))) bad = errno ? errno : EIO;
+        if (need > buf.size()) buf.resize(need);
+        o = buf.data();
+      }
+      o = emit(p, k, status[k], chain ? chain[k] : 0, o);
+    }
+    if (!bad && o != buf.data() && !write_all(fd, buf.data(), (size_t)(o - buf.data()))) bad = errno ? errno : EIO;
+  }
+  if (!to_stdout && close(fd) != 0 && !bad) bad = errno ? errno : EIO;
+  if (bad) return paf_error(SWG_ERR_INVALID, "write to %s failed: %s", out_path, std::strerror(bad));
+  return SWG_OK;
+}
+
+int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, const swg_config* cfg, int threads,
+                   swg_stats* stats, double timing_ms[4]) {
+  if (!ctx) return paf_error(SWG_ERR_INVALID, "swg_filter_paf: ctx is NULL");
+  swg_paf* p = nullptr;
+  int rc = swg_paf_open(in_path, threads, &p);
+  if (rc != SWG_OK) return rc;
+  const uint64_t n = p->rec.n;
+  std::vector<uint8_t> status(n ? n : 1, 0);
+  std::vector<uint32_t> chain(n ? n : 1, 0);
+  auto t0 = clk::now();
+  if (n) rc = swg_filter(ctx, &p->rec, cfg, status.data(), chain.data(), stats);
+  const double filter_ms = ms_since(t0);
+  if (rc != SWG_OK) {
+    paf_error(rc, "%s", swg_last_error(ctx));
+    swg_paf_close(p);
+    return rc;
+  }
+  t0 = clk::now();
+  rc = swg_paf_write(p, out_path, status.data(), chain.data(), threads, nullptr);
+  if (timing_ms) {
+    timing_ms[0] = p->load_ms;
+    timing_ms[1] = p->parse_ms;
+    timing_ms[2] = filter_ms;
+    timing_ms[3] = ms_since(t0);
+  }
+  swg_paf_close(p);
+  return rc;
+}
+
+}  // extern "C"

@@ -19,7 +19,6 @@
 #include <cstring>
 #include <string>
 #include <string_view>
-#include <unordered_map>
 #include <vector>
 
 #include "../../../include/sweepga_gpu.h"
@@ -137,74 +136,6 @@ bool parse_filter_mode(const std::string& mode, int32_t* fmode, uint64_t* pq, ui
   }
   return set(SWG_MODE_ONE_TO_ONE, 1, 1);
 }
-// paf.rs:32-64: sum of '=' lengths; false on a number parse error
-bool cigar_matches(std::string_view cigar, uint64_t* matches) {
-  uint64_t m = 0, cur = 0;
-  bool have = false, overflow = false;
-  for (char ch : cigar) {
-    if (ch >= '0' && ch <= '9') {
-      const uint64_t d = (uint64_t)(ch - '0');
-      if (cur > (UINT64_MAX - d) / 10) overflow = true;
-      cur = cur * 10 + d;
-      have = true;
-    } else {
-      if (!have || overflow) return false;
-      if (ch == '=') m += cur;
-      cur = 0;
-      have = false;
-      overflow = false;
-    }
-  }
-  *matches = m;
-  return true;
-}
-
-// ---- sequence index ---------------------------------------------------------------------------------------
-struct SequenceIndex {
-  std::unordered_map<std::string, uint32_t> ids;
-  std::vector<std::string> names;
-  uint32_t get_or_insert(std::string_view nm) {
-    auto it = ids.find(std::string(nm));
-    if (it != ids.end()) return it->second;
-    const uint32_t id = (uint32_t)names.size();
-    names.emplace_back(nm);
-    ids.emplace(names.back(), id);
-    return id;
-  }
-};
-std::string prefix_last(const std::string& n) {  // paf_filter.rs:1022-1030
-  const size_t p = n.rfind('#');
-  return p == std::string::npos ? n : n.substr(0, p + 1);
-}
-std::string prefix_two(const std::string& n) {  // plane_sweep_scaffold.rs:13-22
-  const size_t p1 = n.find('#');
-  if (p1 == std::string::npos) return n;
-  const size_t p2 = n.find('#', p1 + 1);
-  return n.substr(0, p1) + "#" + (p2 == std::string::npos ? n.substr(p1 + 1) : n.substr(p1 + 1, p2 - p1 - 1)) + "#";
-}
-uint32_t genome_table(const SequenceIndex& idx, std::string (*fn)(const std::string&), std::vector<uint32_t>* out) {
-  std::unordered_map<std::string, uint32_t> g;
-  out->resize(idx.names.empty() ? 1 : idx.names.size(), 0);
-  for (size_t i = 0; i < idx.names.size(); ++i) {
-    auto it = g.emplace(fn(idx.names[i]), (uint32_t)g.size()).first;
-    (*out)[i] = it->second;
-  }
-  return g.empty() ? 1u : (uint32_t)g.size();
-}
-
-struct Columns {
-  std::vector<uint32_t> q_id, t_id, qs, qe, ts, te, matches, block;
-  std::vector<double> identity;
-  std::vector<uint8_t> strand;
-  std::vector<uint64_t> rank;  // line index of each record
-};
-
-uint32_t narrow(uint64_t v, const char* what, size_t line) {
-  if (v > 0xffffffffull)
-    die(2, std::string(what) + " >= 2^32 on line " + std::to_string(line + 1) + " is not supported by the GPU layout");
-  return (uint32_t)v;
-}
-
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -214,7 +145,7 @@ int main(int argc, char** argv) {
   double overlap = 0.95, scaffold_overlap = 0.5;
   uint64_t scaffold_jump = 50000, scaffold_mass = 10000, scaffold_dist = 0, block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false, quiet = false;
-  int device = 0;
+  int device = 0, threads = 0;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], val;
     const size_t eq = a.find('=');
@@ -246,7 +177,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::atoi(value().c_str());
     else if (a == "--quiet") quiet = true;
     else if (a == "--no-adaptive-scaffolds" || a == "--paf") { /* no effect for PAF input (main.rs:3515-3527) */ }
-    else if (a == "--threads" || a == "-t") (void)value();
+    else if (a == "--threads" || a == "-t") threads = std::atoi(value().c_str());
     else if (a == "--help" || a == "-h") {
       std::puts("usage: sweepga-gpu <in.paf> [--output-file out.paf] [--num-mappings M] [--overlap F] [--scoring S]\n"
                 "         [--min-aln-identity I] [--min-aln-length N] [--self] [--no-filter] [--scaffold-jump N]\n"
@@ -275,91 +206,34 @@ int main(int argc, char** argv) {
   cfg.keep_self = keep_self;
   cfg.scaffolds_only = scaffolds_only;
 
-  // ---- read the whole input; line table (BufRead::lines: split on '\n', strip one '\r')
+  // ---- open_paf_input + extract_metadata (paf_filter.rs:292-376), multi-threaded in libsweepga_gpu.so
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
-  std::string text;
-  {
-    FILE* f = std::fopen(input.c_str(), "rb");
-    if (!f) die(2, "cannot open " + input + ": " + std::strerror(errno));
-    char buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
-    std::fclose(f);
-  }
-  std::vector<std::pair<size_t, size_t>> lines;  // (offset, length) without "\n" / "\r\n"
-  for (size_t pos = 0; pos < text.size();) {
-    const void* nl = std::memchr(text.data() + pos, '\n', text.size() - pos);
-    const size_t end = nl ? (size_t)((const char*)nl - text.data()) : text.size();
-    size_t len = end - pos;
-    if (len && text[pos + len - 1] == '\r') --len;
-    lines.emplace_back(pos, len);
-    pos = end + 1;
-  }
-  FILE* out = output_file.empty() ? stdout : std::fopen(output_file.c_str(), "wb");
-  if (!out) die(2, "cannot create " + output_file + ": " + std::strerror(errno));
-  if (no_filter) {  // main.rs:3461-3470
-    for (auto& ln : lines) {
-      std::fwrite(text.data() + ln.first, 1, ln.second, out);
+  swg_paf* paf = nullptr;
+  if (swg_paf_open(input.c_str(), threads, &paf) != SWG_OK) die(2, swg_paf_last_error());
+  const std::string out_path = output_file.empty() ? "-" : output_file;
+  const swg_records* r = swg_paf_records(paf);
+  const uint64_t n = r->n;
+  if (no_filter) {  // main.rs:3461-3470: every line, newline-normalised
+    const char* text;
+    uint64_t len;
+    swg_paf_text(paf, &text, &len);
+    FILE* out = output_file.empty() ? stdout : std::fopen(output_file.c_str(), "wb");
+    if (!out) die(2, "cannot create " + output_file + ": " + std::strerror(errno));
+    for (uint64_t pos = 0; pos < len;) {
+      const void* nl = std::memchr(text + pos, '\n', len - pos);
+      const uint64_t end = nl ? (uint64_t)((const char*)nl - text) : len;
+      uint64_t ll = end - pos;
+      if (ll && text[pos + ll - 1] == '\r') --ll;
+      std::fwrite(text + pos, 1, ll, out);
       std::fputc('\n', out);
+      pos = end + 1;
     }
     if (out != stdout) std::fclose(out);
+    swg_paf_close(paf);
     return 0;
   }
-
-  // ---- extract_metadata (paf_filter.rs:298-373)
-  SequenceIndex idx;
-  Columns c;
-  std::vector<std::string_view> f;
-  for (size_t li = 0; li < lines.size(); ++li) {
-    const std::string_view line(text.data() + lines[li].first, lines[li].second);
-    f.clear();
-    for (size_t s = 0;;) {
-      const size_t t = line.find('\t', s);
-      if (t == std::string_view::npos) {
-        f.push_back(line.substr(s));
-        break;
-      }
-      f.push_back(line.substr(s, t - s));
-      s = t + 1;
-    }
-    if (f.size() < 11) continue;
-    auto u64_or = [](std::string_view s, uint64_t d) {
-      uint64_t v;
-      return parse_u64(s, &v) ? v : d;
-    };
-    uint64_t matches = u64_or(f[9], 0);
-    const uint64_t block = u64_or(f[10], 1);
-    const double denom = (double)(block > 1 ? block : 1);
-    double identity = (double)matches / denom;
-    for (size_t k = 11; k < f.size(); ++k) {
-      if (f[k].substr(0, 5) == "dv:f:") {
-        double dv;
-        if (parse_f64(f[k].substr(5), &dv)) identity = 1.0 - dv;
-      } else if (f[k].substr(0, 5) == "cg:Z:") {
-        uint64_t cm;
-        if (cigar_matches(f[k].substr(5), &cm) && cm > 0) {
-          matches = cm;
-          identity = (double)cm / denom;
-        }
-      }
-    }
-    c.q_id.push_back(idx.get_or_insert(f[0]));
-    c.t_id.push_back(idx.get_or_insert(f[5]));
-    c.qs.push_back(narrow(u64_or(f[2], 0), "query_start", li));
-    c.qe.push_back(narrow(u64_or(f[3], 0), "query_end", li));
-    c.ts.push_back(narrow(u64_or(f[7], 0), "target_start", li));
-    c.te.push_back(narrow(u64_or(f[8], 0), "target_end", li));
-    c.matches.push_back(narrow(matches, "matches", li));
-    c.block.push_back(narrow(block, "block_length", li));
-    c.identity.push_back(identity);
-    c.strand.push_back(f[4] == "+" ? 0 : 1);
-    c.rank.push_back(li);
-  }
   const auto t1 = clk::now();
-  const uint64_t n = c.rank.size();
-  std::vector<uint32_t> g_last, g_two;
-  const uint32_t n_last = genome_table(idx, prefix_last, &g_last), n_two = genome_table(idx, prefix_two, &g_two);
 
   // ---- apply_filters on the GPU
   std::vector<uint8_t> status(n ? n : 1, 0);
@@ -369,60 +243,26 @@ int main(int argc, char** argv) {
     swg_ctx* ctx = nullptr;
     int rc = swg_create(device, &ctx);
     if (rc != SWG_OK) die(3, std::string("no usable GPU: ") + swg_last_error(nullptr));
-    swg_records r{};
-    r.n = n;
-    r.q_id = c.q_id.data();
-    r.t_id = c.t_id.data();
-    r.q_start = c.qs.data();
-    r.q_end = c.qe.data();
-    r.t_start = c.ts.data();
-    r.t_end = c.te.data();
-    r.identity = c.identity.data();
-    r.matches = c.matches.data();
-    r.block_len = c.block.data();
-    r.strand = c.strand.data();
-    r.n_seq = (uint32_t)(idx.names.empty() ? 1 : idx.names.size());
-    r.seq_genome_last = g_last.data();
-    r.n_genome_last = n_last;
-    r.seq_genome_two = g_two.data();
-    r.n_genome_two = n_two;
-    rc = swg_filter(ctx, &r, &cfg, status.data(), chain.data(), &st);
+    rc = swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
     if (rc != SWG_OK) die(3, std::string("filter failed: ") + swg_last_error(ctx));
     swg_destroy(ctx);
   }
   const auto t2 = clk::now();
 
   // ---- write_filtered_output (paf_filter.rs:1689-1726): input order, original bytes + tags
-  static const char* TAG[4] = {"", "scaffold", "rescued", "unassigned"};
-  std::string buf;
-  buf.reserve(1 << 20);
   uint64_t kept = 0;
-  for (uint64_t k = 0; k < n; ++k) {
-    if (!status[k]) continue;
-    ++kept;
-    const auto& ln = lines[c.rank[k]];
-    buf.append(text.data() + ln.first, ln.second);
-    if (chain[k]) {
-      buf += "\tch:Z:chain_";
-      buf += std::to_string(chain[k]);
-    }
-    buf += "\tst:Z:";
-    buf += TAG[status[k] & 3];
-    buf += '\n';
-    if (buf.size() > (1 << 20) - 4096) {
-      std::fwrite(buf.data(), 1, buf.size(), out);
-      buf.clear();
-    }
-  }
-  std::fwrite(buf.data(), 1, buf.size(), out);
-  if (out != stdout) std::fclose(out);
+  if (swg_paf_write(paf, out_path.c_str(), status.data(), chain.data(), threads, &kept) != SWG_OK) die(2, swg_paf_last_error());
   const auto t3 = clk::now();
   if (!quiet) {
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double load_ms, parse_ms;
+    swg_paf_timing(paf, &load_ms, &parse_ms);
     std::fprintf(stderr,
-                 "[sweepga-gpu] %llu records -> %llu kept | parse %.1f ms, filter %.1f ms (device %.1f, h2d %.1f, d2h %.1f), write %.1f ms\n",
-                 (unsigned long long)n, (unsigned long long)kept, ms(t0, t1), ms(t1, t2), st.device_ms, st.h2d_ms, st.d2h_ms,
-                 ms(t2, t3));
+                 "[sweepga-gpu] %llu records -> %llu kept | read %.1f ms (load %.1f, parse %.1f), filter %.1f ms (device %.1f, h2d %.1f, "
+                 "d2h %.1f), write %.1f ms\n",
+                 (unsigned long long)n, (unsigned long long)kept, ms(t0, t1), load_ms, parse_ms, ms(t1, t2), st.device_ms, st.h2d_ms,
+                 st.d2h_ms, ms(t2, t3));
   }
+  swg_paf_close(paf);
   return 0;
 }

@@ -10,13 +10,14 @@ All compute goes through libsweepga_gpu.so; nothing here evaluates the filter on
 """
 import ctypes as C
 import enum
+import os
 from dataclasses import dataclass, field
 from typing import List, NamedTuple, Optional
 
 import numpy as np
 
 from . import _lib
-from ._lib import K_INF, SwgConfig, SwgRecords, SwgStats, default_context
+from ._lib import K_INF, SwgConfig, SwgError, SwgRecords, SwgStats, default_context
 
 USIZE_MAX = K_INF
 
@@ -404,8 +405,23 @@ class PafFilter:
                 line += f"\tst:Z:{STATUS_TAG[meta.chain_status]}"
                 out.write(line.encode("utf-8", errors="surrogateescape") + b"\n")
 
-    def filter_paf(self, input_path, output_path):
-        """src/paf_filter.rs:278-289"""
+    def filter_paf(self, input_path, output_path, threads=0):
+        """src/paf_filter.rs:278-289.  Ingest, filter and egress all run in the native library
+        (host threads for the text, the GPU for apply_filters); returns {"load","parse","filter","write"} ms."""
+        cfg = self.config.to_c(self.keep_self, self.scaffolds_only)
+        stats = SwgStats()
+        timing = (C.c_double * 4)()
+        ctx = self.ctx
+        rc = ctx.lib.swg_filter_paf(ctx.handle, os.fsencode(input_path), os.fsencode(output_path), C.byref(cfg),
+                                    int(threads), C.byref(stats), timing)
+        if rc != 0:
+            raise SwgError(rc, (ctx.lib.swg_paf_last_error() or b"").decode())
+        self.last_stats = stats
+        return dict(zip(("load", "parse", "filter", "write"), timing))
+
+    def filter_paf_python(self, input_path, output_path):
+        """The same three steps through the Python mirrors of extract_metadata / write_filtered_output
+        (kept for API parity and as a cross-check of the native ingest)."""
         metadata = self.extract_metadata(input_path)
         passing = self.apply_filters(metadata)
         self.write_filtered_output(input_path, output_path, passing)

@@ -1,0 +1,108 @@
+"""Native PAF ingest/egress (sweepga_amd/csrc/host/paf_io.cpp) seen from Python.
+
+`PafFile` is the host-side half of PafFilter::filter_paf (src/paf_filter.rs:278-289): it owns the mapped
+text, the SoA columns swg_filter() takes and the line table the writer reuses.  Parsing and writing run on
+host threads in C++; nothing here needs a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._lib import SWG_OK, SwgError, load
+
+
+def _err(lib, rc):
+    raise SwgError(rc, (lib.swg_paf_last_error() or b"").decode())
+
+
+class PafFile:
+    """open_paf_input + extract_metadata (src/paf.rs:10-30, src/paf_filter.rs:292-376)."""
+
+    def __init__(self, path=None, text=None, threads=0):
+        self.lib = load()
+        h = C.c_void_p()
+        if text is not None:
+            if isinstance(text, str):
+                text = text.encode("utf-8", errors="surrogateescape")
+            rc = self.lib.swg_paf_open_buffer(text, len(text), int(threads), C.byref(h))
+        else:
+            rc = self.lib.swg_paf_open(os.fsencode(path), int(threads), C.byref(h))
+        if rc != SWG_OK:
+            _err(self.lib, rc)
+        self.handle = h
+        self.threads = int(threads)
+        self.records = self.lib.swg_paf_records(h).contents  # SwgRecords, pointers owned by the handle
+        self.n = int(self.records.n)
+        self.n_lines = int(self.lib.swg_paf_num_lines(h))
+
+    def _view(self, addr, dtype, n):
+        if n == 0 or not addr:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+        a = np.frombuffer(buf, dtype=dtype, count=n)
+        a.flags.writeable = False
+        return a
+
+    def column(self, name):
+        """Read-only numpy view of one record column (valid while the PafFile is open)."""
+        dtype = {"identity": np.float64, "strand": np.uint8}.get(name, np.uint32)
+        return self._view(getattr(self.records, name), dtype, self.n)
+
+    @property
+    def ranks(self):
+        return self._view(self.lib.swg_paf_ranks(self.handle), np.uint64, self.n)
+
+    @property
+    def names(self):
+        k = self.lib.swg_paf_num_sequences(self.handle)
+        return [self.lib.swg_paf_sequence_name(self.handle, i).decode("utf-8", errors="surrogateescape")
+                for i in range(k)]
+
+    @property
+    def seq_genome_last(self):
+        return self._view(self.records.seq_genome_last, np.uint32, max(int(self.records.n_seq), 1))
+
+    @property
+    def seq_genome_two(self):
+        return self._view(self.records.seq_genome_two, np.uint32, max(int(self.records.n_seq), 1))
+
+    @property
+    def timing_ms(self):
+        a, b = C.c_double(), C.c_double()
+        self.lib.swg_paf_timing(self.handle, C.byref(a), C.byref(b))
+        return {"load": a.value, "parse": b.value}
+
+    def write(self, out_path, status, chain=None, threads=None):
+        """write_filtered_output (src/paf_filter.rs:1689-1726) -> number of records written."""
+        status = np.ascontiguousarray(status, dtype=np.uint8)
+        if status.size < self.n:
+            raise ValueError("status has fewer entries than records")
+        if chain is not None:
+            chain = np.ascontiguousarray(chain, dtype=np.uint32)
+            if chain.size < self.n:
+                raise ValueError("chain has fewer entries than records")
+        kept = C.c_uint64()
+        rc = self.lib.swg_paf_write(self.handle, os.fsencode(out_path), status.ctypes.data if status.size else None,
+                                    chain.ctypes.data if chain is not None and chain.size else None,
+                                    self.threads if threads is None else int(threads), C.byref(kept))
+        if rc != SWG_OK:
+            _err(self.lib, rc)
+        return kept.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.records = None
+            self.lib.swg_paf_close(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

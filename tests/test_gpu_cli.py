@@ -46,3 +46,32 @@ def test_cli_output_byte_identical(bins, tmp_path, seed):
         a, b = o1.read_bytes(), o2.read_bytes()
         assert a == b, (flags, len(a), len(b))
     assert os.path.getsize(tmp_path / "gpu0.paf") > 0
+
+
+@pytest.mark.parametrize("suffix,threads", [(".paf", 1), (".paf", 7), (".paf.gz", 3)])
+def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, threads):
+    """PafFilter.filter_paf = swg_filter_paf (native ingest -> GPU filter -> native egress), against the oracle's
+    filter_paf (paf_filter.rs:278-289) and the Python extract/apply/write mirror."""
+    import gzip
+    from sweepga_amd import FilterConfig, FilterMode, PafFilter
+    from tests import orc
+    rng = np.random.default_rng(77)
+    rec = gen.random_records(rng, 30_000, n_genomes=4, chrs_per_genome=3)
+    text = gen.records_to_paf(rng, rec)
+    plain = tmp_path / "in.paf"
+    plain.write_text(text)
+    src = tmp_path / ("in2" + suffix)
+    src.write_bytes(gzip.compress(text.encode()) if suffix.endswith(".gz") else text.encode())
+    cfg = FilterConfig(scaffold_gap=20_000, min_scaffold_length=5_000, scaffold_max_deviation=10_000,
+                       mapping_filter_mode=FilterMode.OneToOne, mapping_max_per_query=1, mapping_max_per_target=1)
+    f = PafFilter(cfg)
+    timing = f.filter_paf(src, tmp_path / "native.paf", threads=threads)
+    assert set(timing) == {"load", "parse", "filter", "write"} and f.last_stats.n_in == f.last_stats.n_retained > 0
+    f.filter_paf_python(plain, tmp_path / "py.paf")
+    ocfg = orc.Config(scaffold_gap=20_000, min_scaffold_length=5_000, scaffold_max_deviation=10_000,
+                      mapping_filter_mode=orc.ONE_TO_ONE, mapping_max_per_query=1, mapping_max_per_target=1)
+    orc.filter_paf(ocfg, str(plain), str(tmp_path / "orc.paf"))
+    want = (tmp_path / "orc.paf").read_bytes()
+    assert len(want) > 0
+    assert (tmp_path / "native.paf").read_bytes() == want
+    assert (tmp_path / "py.paf").read_bytes() == want
