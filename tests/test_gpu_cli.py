@@ -66,7 +66,7 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
                        mapping_filter_mode=FilterMode.OneToOne, mapping_max_per_query=1, mapping_max_per_target=1)
     f = PafFilter(cfg)
     timing = f.filter_paf(src, tmp_path / "native.paf", threads=threads)
-    assert set(timing) == {"load", "parse", "filter", "write"} and f.last_stats.n_in == f.last_stats.n_retained > 0
+    assert set(timing) == {"load", "parse", "filter", "write"} and f.last_stats.n_in >= f.last_stats.n_retained > 0
     f.filter_paf_python(plain, tmp_path / "py.paf")
     ocfg = orc.Config(scaffold_gap=20_000, min_scaffold_length=5_000, scaffold_max_deviation=10_000,
                       mapping_filter_mode=orc.ONE_TO_ONE, mapping_max_per_query=1, mapping_max_per_target=1)
