@@ -115,6 +115,16 @@ int swg_exclusive_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint
                            uint64_t* d_total_out);
 // Inclusive running maximum of n u32 values (in place allowed).
 int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n);
+// Stream compaction from byte flags (non-zero = set) without a position array:
+//   swg_flags_count  : per-4096-tile counts + their exclusive scan (tile_off, from the arena), total -> *d_total
+//   swg_flags_compact: list[rank of i among set flags] = i, ascending
+struct swg_flag_scan {
+  const uint8_t* flags;
+  uint64_t n;
+  uint32_t* tile_off;
+};
+int swg_flags_count(swg_ctx* ctx, const uint8_t* flags, uint64_t n, swg_flag_scan* fs, uint64_t* d_total);
+int swg_flags_compact(swg_ctx* ctx, const swg_flag_scan& fs, uint32_t* list);
 int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n);
 // Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
 // *keys / *vals hold the input; the *_alt buffers are scratch of the same size.  Passes ping-pong

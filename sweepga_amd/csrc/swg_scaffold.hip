@@ -29,12 +29,6 @@ constexpr int EW = 256;
 constexpr uint32_t NONE = 0xffffffffu;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
 
-// ---- small generic kernels ------------------------------------------------------------------------
-__global__ __launch_bounds__(EW) void flags_to_u32_kernel(uint64_t n, const uint8_t* __restrict__ f,
-                                                          uint32_t* __restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) out[i] = f[i] ? 1u : 0u;
-}
 __global__ __launch_bounds__(EW) void fill_u32_kernel(uint64_t n, uint32_t* __restrict__ p, uint32_t v) {
   uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (i < n) p[i] = v;
@@ -46,13 +40,6 @@ __global__ __launch_bounds__(EW) void fill_u64_kernel(uint64_t n, uint64_t* __re
 __global__ __launch_bounds__(EW) void iota_u32_kernel(uint64_t n, uint32_t* __restrict__ p) {
   uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
-}
-// out[pos[i]] = i for flagged i (stream compaction given the exclusive scan `pos` of the flags)
-__global__ __launch_bounds__(EW) void compact_indices_kernel(uint64_t n, const uint8_t* __restrict__ f,
-                                                             const uint32_t* __restrict__ pos,
-                                                             uint32_t* __restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n && f[i]) out[pos[i]] = (uint32_t)i;
 }
 
 // ---- sort A -----------------------------------------------------------------------------------------
@@ -703,14 +690,12 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
 }
 
 __global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                           uint32_t m, uint8_t* __restrict__ is_big,
-                                                           uint32_t* __restrict__ is_big32) {
+                                                           uint32_t m, uint8_t* __restrict__ is_big) {
   uint32_t u = blockIdx.x * EW + threadIdx.x;
   if (u >= n_units) return;
   const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
   const uint8_t f = (e - unit_begin[u]) >= BIG_UNIT ? 1 : 0;
   is_big[u] = f;
-  is_big32[u] = f;
 }
 
 // Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
@@ -807,6 +792,29 @@ __global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd,
   }
 }
 
+// Chain aggregates live at the head's slot.  Pass 1 seeds every slot with the element's own values (plain
+// stores, this is also the initialisation); pass 2 folds the non-head members into their head with atomics.
+// Most chains are singletons, so most elements never issue an atomic.
+__global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                                  const uint32_t* __restrict__ s_qe,
+                                                                  const uint32_t* __restrict__ s_ts,
+                                                                  const uint32_t* __restrict__ s_te,
+                                                                  const uint32_t* __restrict__ s_m,
+                                                                  const uint32_t* __restrict__ s_b,
+                                                                  uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
+                                                                  uint32_t* __restrict__ h_te,
+                                                                  unsigned long long* __restrict__ h_sm,
+                                                                  unsigned long long* __restrict__ h_sb,
+                                                                  uint32_t* __restrict__ is_head) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  is_head[p] = hd[p] == p ? 1u : 0u;
+  h_qe[p] = s_qe[p];
+  h_ts[p] = s_ts[p];
+  h_te[p] = s_te[p];
+  h_sm[p] = s_m[p];
+  h_sb[p] = s_b[p];
+}
 __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const uint32_t* __restrict__ hd,
                                                              const uint32_t* __restrict__ s_qe,
                                                              const uint32_t* __restrict__ s_ts,
@@ -816,12 +824,11 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
                                                              uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
                                                              uint32_t* __restrict__ h_te,
                                                              unsigned long long* __restrict__ h_sm,
-                                                             unsigned long long* __restrict__ h_sb,
-                                                             uint32_t* __restrict__ is_head) {
+                                                             unsigned long long* __restrict__ h_sb) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
   const uint32_t h = hd[p];
-  is_head[p] = h == p ? 1u : 0u;
+  if (h == p) return;
   atomicMax(&h_qe[h], s_qe[p]);
   atomicMin(&h_ts[h], s_ts[p]);
   atomicMax(&h_te[h], s_te[p]);
@@ -1103,13 +1110,10 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_HIP(ctx, hipMemsetAsync(C_num, 0, T.nc * sizeof(uint32_t), st));
   // ---- only the span/identity-filtered chains take part (compaction keeps their relative order, which is
   //      all the plane sweep's index tie-break needs)
-  uint32_t* okf = swg_alloc<uint32_t>(ctx, T.nc);
-  uint32_t* okpos = swg_alloc<uint32_t>(ctx, T.nc);
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(T.nc), EW, 0, st>>>(T.nc, T.ok, okf));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, okf, okpos, T.nc, d_tot));
+  swg_flag_scan ok_scan;
+  SWG_TRY(swg_flags_count(ctx, T.ok, T.nc, &ok_scan, d_tot));
   uint64_t nc = 0;
   SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
   if (nc == 0) return SWG_OK;
@@ -1127,8 +1131,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   uint8_t* kept = swg_alloc<uint8_t>(ctx, nc);
   uint32_t* num = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(T.nc), EW, 0, st>>>(T.nc, T.ok, okpos, ok_idx));
-  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_flags_compact(ctx, ok_scan, ok_idx));
   SWG_LAUNCH(ctx, "chain_compact", chain_compact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, qid,
                                                                      tid, qs, qe, ts, te, wid));
   SWG_KERNEL_CHECK(ctx);
@@ -1160,8 +1163,6 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* gp2_first = swg_alloc<uint32_t>(ctx, (size_t)n_g2 * n_g2);
-  uint32_t* kflag = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* kpos = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
@@ -1176,9 +1177,8 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
                                                                            n_g2, run_of_chain, pair_first, gp2_first));
   SWG_KERNEL_CHECK(ctx);
   // kept chains, in index order
-  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, kept, kflag));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, kflag, kpos, nc, d_tot));
+  swg_flag_scan kept_scan;
+  SWG_TRY(swg_flags_count(ctx, kept, nc, &kept_scan, d_tot));
   uint64_t nk = 0;
   SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
   SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
@@ -1189,8 +1189,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
     uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
     uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, kept, kpos, kept_list));
-    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_flags_compact(ctx, kept_scan, kept_list));
     const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
     SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
                                                                     seq_genome2, n_g2, c_bits, nkey));
@@ -1237,13 +1236,10 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     return swg_set_error(ctx, SWG_ERR_RANGE, "chain sort key (%d pair bits + %d coordinate bits) exceeds 64 bits",
                          pair_bits, pos_bits);
   // ---- compaction of alive, sort A
-  uint32_t* f32 = swg_alloc<uint32_t>(ctx, n);
-  uint32_t* fpos = swg_alloc<uint32_t>(ctx, n);
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 4);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(n), EW, 0, st>>>(n, alive, f32));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, f32, fpos, n, d_tot));
+  swg_flag_scan alive_scan;
+  SWG_TRY(swg_flags_count(ctx, alive, n, &alive_scan, d_tot));
   uint64_t M = 0;
   SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
   B.M = M;
@@ -1260,8 +1256,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   uint32_t* pair_flag = swg_alloc<uint32_t>(ctx, M);
   uint32_t* pair_excl = swg_alloc<uint32_t>(ctx, M);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n), EW, 0, st>>>(n, alive, fpos, B.idxA));
-  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
   SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
                                                               r->n_seq, pos_bits, B.keyA));
   SWG_KERNEL_CHECK(ctx);
@@ -1273,10 +1268,8 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
   SWG_KERNEL_CHECK(ctx);
   // ---- survivors in A order
-  uint32_t* spos = pair_excl;  // reuse
-  SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(M), EW, 0, st>>>(M, a_keep, pair_flag));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, spos, M, d_tot + 2));
+  swg_flag_scan keep_scan;
+  SWG_TRY(swg_flags_count(ctx, a_keep, M, &keep_scan, d_tot + 2));
   uint64_t h3[3];
   SWG_TRY(swg_read_scalars(ctx, d_tot, h3, 3));
   B.n_pairs = h3[1];
@@ -1314,8 +1307,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   uint32_t* gp_first = swg_alloc<uint32_t>(ctx, n_gp);
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(M), EW, 0, st>>>(M, a_keep, spos, B.s_a));
-  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
   SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
                                                         r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
                                                         B.s_idx, s_grp, head_flag));
@@ -1376,20 +1368,18 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     SWG_KERNEL_CHECK(ctx);
     {
       uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
-      uint32_t* is_big32 = swg_alloc<uint32_t>(ctx, n_units);
-      uint32_t* big_pos = swg_alloc<uint32_t>(ctx, n_units);
       uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 1);
       SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "unit_big_flag", unit_big_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_big, is_big32));
+      SWG_LAUNCH(ctx, "unit_big_flag", unit_big_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_big));
       SWG_KERNEL_CHECK(ctx);
-      SWG_TRY(swg_exclusive_scan_u32(ctx, is_big32, big_pos, n_units, d_nb));
+      swg_flag_scan big_scan;
+      SWG_TRY(swg_flags_count(ctx, is_big, n_units, &big_scan, d_nb));
       uint64_t n_big = 0;
       SWG_TRY(swg_read_scalars(ctx, d_nb, &n_big, 1));
       if (n_big) {
         uint32_t* big_list = swg_alloc<uint32_t>(ctx, n_big);
         SWG_CHECK_ARENA(ctx);
-        SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(n_units), EW, 0, st>>>(n_units, is_big, big_pos, big_list));
-        SWG_KERNEL_CHECK(ctx);
+        SWG_TRY(swg_flags_compact(ctx, big_scan, big_list));
         // ---- block-speculative selection of the long units
         uint32_t* S_u = swg_alloc<uint32_t>(ctx, n_big);
         uint32_t* nblk_u = swg_alloc<uint32_t>(ctx, n_big);
@@ -1483,13 +1473,11 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if ((uint32_t)ch == 0) break;
   }
   // ---- aggregates
-  SWG_HIP(ctx, hipMemsetAsync(h_qe, 0, m * 4, st));
-  SWG_HIP(ctx, hipMemsetAsync(h_te, 0, m * 4, st));
-  SWG_HIP(ctx, hipMemsetAsync(h_ts, 0xff, m * 4, st));
-  SWG_HIP(ctx, hipMemsetAsync(h_sm, 0, m * 8, st));
-  SWG_HIP(ctx, hipMemsetAsync(h_sb, 0, m * 8, st));
+  SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
+                                                                                  h_te, h_sm, h_sb, is_head));
+  SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
-                                                                        h_sm, h_sb, is_head));
+                                                                        h_sm, h_sb));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
   uint64_t nc = 0;
@@ -1871,17 +1859,14 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   {
     const uint64_t np = B.n_pairs;
     uint8_t* fflag = swg_alloc<uint8_t>(ctx, nc);
-    uint32_t* fflag32 = swg_alloc<uint32_t>(ctx, nc);
-    uint32_t* fpos = swg_alloc<uint32_t>(ctx, nc);
     uint32_t* pair_lo = swg_alloc<uint32_t>(ctx, np + 1);
     uint32_t* pair_hi = swg_alloc<uint32_t>(ctx, np + 1);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "fwd_flag", fwd_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, C_num, B.C_strand, fflag));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, fflag, fflag32));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, fflag32, fpos, nc, d_tot));
+    swg_flag_scan fwd_scan;
+    SWG_TRY(swg_flags_count(ctx, fflag, nc, &fwd_scan, d_tot));
     uint64_t nf = 0;
     SWG_TRY(swg_read_scalars(ctx, d_tot, &nf, 1));
     if (nf) {
@@ -1895,8 +1880,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_CHECK_ARENA(ctx);
       SWG_HIP(ctx, hipMemsetAsync(pair_lo, 0, (np + 1) * 4, st));
       SWG_HIP(ctx, hipMemsetAsync(pair_hi, 0, (np + 1) * 4, st));
-      SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(nc), EW, 0, st>>>(nc, fflag, fpos, f_c));
-      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_flags_compact(ctx, fwd_scan, f_c));
       SWG_LAUNCH(ctx, "fwd_cols", fwd_cols_kernel<<<nblk(nf), EW, 0, st>>>(nf, f_c, B.T.qs, B.T.qe, B.T.ts, C_num, B.C_dpair, f_qs, f_qe,
                                                                 f_ts, f_num, f_dp));
       SWG_KERNEL_CHECK(ctx);
@@ -1918,15 +1902,12 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   // ---- rescue
   {
     uint8_t* aflag = swg_alloc<uint8_t>(ctx, M);
-    uint32_t* aflag32 = swg_alloc<uint32_t>(ctx, M);
-    uint32_t* apos = swg_alloc<uint32_t>(ctx, M);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "anchor_flag", anchor_flag_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, anchor_num, aflag));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "flags_to_u32", flags_to_u32_kernel<<<nblk(M), EW, 0, st>>>(M, aflag, aflag32));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, aflag32, apos, M, d_tot));
+    swg_flag_scan anchor_scan;
+    SWG_TRY(swg_flags_count(ctx, aflag, M, &anchor_scan, d_tot));
     uint64_t na = 0;
     SWG_TRY(swg_read_scalars(ctx, d_tot, &na, 1));
     uint32_t* anchor_a = swg_alloc<uint32_t>(ctx, na + 1);
@@ -1938,8 +1919,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     uint32_t* b_num = swg_alloc<uint32_t>(ctx, na + 1);
     SWG_CHECK_ARENA(ctx);
     if (na) {
-      SWG_LAUNCH(ctx, "compact_indices", compact_indices_kernel<<<nblk(M), EW, 0, st>>>(M, aflag, apos, anchor_a));
-      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_flags_compact(ctx, anchor_scan, anchor_a));
       SWG_LAUNCH(ctx, "anchor_keys", anchor_keys_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.keyA, B.a_qe, B.a_dpair, pos_bits, b_key));
       SWG_KERNEL_CHECK(ctx);
       const int dp_bits = swg_bits_for(B.n_pairs) ? swg_bits_for(B.n_pairs) : 1;

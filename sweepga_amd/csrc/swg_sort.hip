@@ -54,50 +54,117 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* total, T* lds_wave, T*
   return scan_op<OP>(base, prev_in_wave);
 }
 
-template <int OP, typename T>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const T* __restrict__ in, T* __restrict__ block_sums,
-                                                                    uint64_t n) {
-  __shared__ T lds_wave[SCAN_THREADS / 64];
-  __shared__ T lds_prev[SCAN_THREADS];
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  T s = 0;
+// Tile layout of the scans: 4096 elements per workgroup; wave w owns the contiguous 1024 elements
+// [w*1024, (w+1)*1024) as SCAN_ROWS rows of 256, lane l holding 4 consecutive elements of each row
+// (one 16-byte load per row for 32-bit elements -> every row is one fully coalesced 1 KB access).
+constexpr int SCAN_VEC = 4;
+constexpr int SCAN_ROWS = SCAN_ITEMS / SCAN_VEC;
+constexpr int SCAN_WAVE_SPAN = 64 * SCAN_ITEMS;
+
+template <typename T>
+__device__ __forceinline__ void load_vec4(const T* in, uint64_t i, uint64_t n, bool aligned, T v[SCAN_VEC]) {
+  if (aligned && i + SCAN_VEC <= n) {
+    if constexpr (sizeof(T) == 4) {
+      const uint4 q = *reinterpret_cast<const uint4*>(in + i);
+      v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+    } else {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(in + i);
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(in + i + 2);
+      v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+    }
+  } else {
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    uint64_t i = base + j;
-    if (i < n) s = scan_op<OP>(s, in[i]);
+    for (int j = 0; j < SCAN_VEC; ++j) v[j] = i + j < n ? in[i + j] : (T)0;
   }
-  T tot;
-  (void)block_exclusive_scan<OP>(s, &tot, lds_wave, lds_prev);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+template <typename T>
+__device__ __forceinline__ void store_vec4(T* out, uint64_t i, uint64_t n, bool aligned, const T v[SCAN_VEC]) {
+  if (aligned && i + SCAN_VEC <= n) {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<uint4*>(out + i) = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+      *reinterpret_cast<ulonglong2*>(out + i) = make_ulonglong2(v[0], v[1]);
+      *reinterpret_cast<ulonglong2*>(out + i + 2) = make_ulonglong2(v[2], v[3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SCAN_VEC; ++j)
+      if (i + j < n) out[i + j] = v[j];
+  }
 }
 
-// `in` and `out` may alias (in-place scan): every thread reads its 16 inputs before any write.
+template <int OP, typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const T* __restrict__ in, T* __restrict__ block_sums,
+                                                                    uint64_t n, int aligned) {
+  __shared__ T lds_wave[SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t wbase = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)wave * SCAN_WAVE_SPAN;
+  T s = 0;
+#pragma unroll
+  for (int r = 0; r < SCAN_ROWS; ++r) {
+    T v[SCAN_VEC];
+    load_vec4(in, wbase + (uint64_t)r * 256 + (uint64_t)lane * SCAN_VEC, n, aligned != 0, v);
+#pragma unroll
+    for (int j = 0; j < SCAN_VEC; ++j) s = scan_op<OP>(s, v[j]);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s = scan_op<OP>(s, (T)__shfl_xor(s, d, 64));
+  if (lane == 0) lds_wave[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T t = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t = scan_op<OP>(t, lds_wave[w]);
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// `in` and `out` may alias (in-place scan): a lane only ever writes elements it has read itself.
 template <int OP, bool INCLUSIVE, typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_down_kernel(const T* in, T* out, const T* __restrict__ block_offsets,
                                                                   uint64_t n, uint64_t* __restrict__ total_out,
-                                                                  int write_total) {
+                                                                  int write_total, int aligned) {
   __shared__ T lds_wave[SCAN_THREADS / 64];
-  __shared__ T lds_prev[SCAN_THREADS];
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  T v[SCAN_ITEMS];
-  T s = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t wbase = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)wave * SCAN_WAVE_SPAN;
+  T v[SCAN_ROWS][SCAN_VEC];
+  T ex[SCAN_ROWS];  // exclusive prefix of the lane's 4-element group inside the wave's span
+  T carry = 0;
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    uint64_t i = base + j;
-    v[j] = i < n ? in[i] : (T)0;
-    s = scan_op<OP>(s, v[j]);
-  }
-  T tot;
-  T ex = block_exclusive_scan<OP>(s, &tot, lds_wave, lds_prev);
-  T run = scan_op<OP>(ex, block_offsets ? block_offsets[blockIdx.x] : (T)0);
+  for (int r = 0; r < SCAN_ROWS; ++r) {
+    load_vec4(in, wbase + (uint64_t)r * 256 + (uint64_t)lane * SCAN_VEC, n, aligned != 0, v[r]);
+    T s = 0;
 #pragma unroll
-  for (int j = 0; j < SCAN_ITEMS; ++j) {
-    uint64_t i = base + j;
-    if (INCLUSIVE) run = scan_op<OP>(run, v[j]);
-    if (i < n) out[i] = run;
-    if (!INCLUSIVE) run = scan_op<OP>(run, v[j]);
+    for (int j = 0; j < SCAN_VEC; ++j) s = scan_op<OP>(s, v[r][j]);
+    const T inc = wave_inclusive_scan<OP>(s, lane);
+    T prev = (T)__shfl_up(inc, 1, 64);
+    if (lane == 0) prev = 0;
+    ex[r] = scan_op<OP>(carry, prev);
+    carry = scan_op<OP>(carry, (T)__shfl(inc, 63, 64));
   }
-  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) *total_out = (uint64_t)run;
+  if (lane == 0) lds_wave[wave] = carry;
+  __syncthreads();
+  T base = block_offsets ? block_offsets[blockIdx.x] : (T)0;
+  T tot = base;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    const T s = lds_wave[w];
+    if (w < wave) base = scan_op<OP>(base, s);
+    tot = scan_op<OP>(tot, s);
+  }
+#pragma unroll
+  for (int r = 0; r < SCAN_ROWS; ++r) {
+    T run = scan_op<OP>(base, ex[r]);
+    T o[SCAN_VEC];
+#pragma unroll
+    for (int j = 0; j < SCAN_VEC; ++j) {
+      if (INCLUSIVE) run = scan_op<OP>(run, v[r][j]);
+      o[j] = run;
+      if (!INCLUSIVE) run = scan_op<OP>(run, v[r][j]);
+    }
+    store_vec4(out, wbase + (uint64_t)r * 256 + (uint64_t)lane * SCAN_VEC, n, aligned != 0, o);
+  }
+  if (write_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (uint64_t)tot;
 }
 
 template <int OP, bool INCLUSIVE, typename T>
@@ -106,24 +173,88 @@ int scan_impl(swg_ctx* ctx, const T* in, T* out, uint64_t n, uint64_t* d_total_o
     if (d_total_out) SWG_HIP(ctx, hipMemsetAsync(d_total_out, 0, sizeof(uint64_t), ctx->stream));
     return SWG_OK;
   }
+  const int aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nb == 1) {
     SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE, T><<<1, SCAN_THREADS, 0, ctx->stream>>>(
-                                     in, out, (const T*)nullptr, n, d_total_out, d_total_out ? 1 : 0));
+                                     in, out, (const T*)nullptr, n, d_total_out, d_total_out ? 1 : 0, aligned));
     SWG_KERNEL_CHECK(ctx);
     return SWG_OK;
   }
   swg_arena_mark mark = swg_arena_save(ctx);
   T* sums = swg_alloc<T>(ctx, nb);
   SWG_CHECK_ARENA(ctx);
-  SWG_LAUNCH(ctx, "scan_reduce", scan_reduce_kernel<OP, T><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n));
+  SWG_LAUNCH(ctx, "scan_reduce", scan_reduce_kernel<OP, T><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(in, sums, n, aligned));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY((scan_impl<OP, false, T>(ctx, sums, sums, nb, nullptr)));  // block offsets are always exclusive
   SWG_LAUNCH(ctx, "scan_down", scan_down_kernel<OP, INCLUSIVE, T><<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(
-                                   in, out, (const T*)sums, n, d_total_out, d_total_out ? 1 : 0));
+                                   in, out, (const T*)sums, n, d_total_out, d_total_out ? 1 : 0, aligned));
   SWG_KERNEL_CHECK(ctx);
   swg_arena_restore(ctx, mark);  // stream order keeps `sums` alive until the kernels above ran
   return SWG_OK;
+}
+
+// ---- stream compaction straight from byte flags ------------------------------------------------------
+// Tile = 4096 flags; wave w owns 1024 of them, lane l 16 consecutive bytes (one 16-byte load).
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // 0x80 in every byte of w that is != 0
+  return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+}
+__device__ __forceinline__ void load_flags16(const uint8_t* __restrict__ f, uint64_t i, uint64_t n, bool aligned, uint32_t nz[4]) {
+  if (aligned && i + 16 <= n) {
+    const uint4 q = *reinterpret_cast<const uint4*>(f + i);
+    nz[0] = nonzero_bytes(q.x), nz[1] = nonzero_bytes(q.y), nz[2] = nonzero_bytes(q.z), nz[3] = nonzero_bytes(q.w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint64_t j = i + (uint64_t)k * 4 + b;
+        if (j < n && f[j]) m |= 0x80u << (8 * b);
+      }
+      nz[k] = m;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void flag_count_kernel(const uint8_t* __restrict__ f, uint64_t n, int aligned,
+                                                                   uint32_t* __restrict__ tile_cnt) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t nz[4];
+  load_flags16(f, (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16, n, aligned != 0, nz);
+  uint32_t c = __popc(nz[0]) + __popc(nz[1]) + __popc(nz[2]) + __popc(nz[3]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+  if (lane == 0) lds_wave[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+}
+
+// list[rank of i among the set flags] = i
+__global__ __launch_bounds__(SCAN_THREADS) void flag_compact_kernel(const uint8_t* __restrict__ f, uint64_t n, int aligned,
+                                                                     const uint32_t* __restrict__ tile_off,
+                                                                     uint32_t* __restrict__ list) {
+  __shared__ uint32_t lds_wave[SCAN_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 16;
+  uint32_t nz[4];
+  load_flags16(f, i0, n, aligned != 0, nz);
+  const uint32_t c = __popc(nz[0]) + __popc(nz[1]) + __popc(nz[2]) + __popc(nz[3]);
+  const uint32_t inc = wave_inclusive_scan<0>(c, lane);
+  if (lane == 63) lds_wave[wave] = inc;
+  __syncthreads();
+  uint32_t pos = tile_off[blockIdx.x] + inc - c;
+  for (int w = 0; w < wave; ++w) pos += lds_wave[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t m = nz[k];
+    while (m) {
+      const int b = __builtin_ctz(m) >> 3;
+      list[pos++] = (uint32_t)(i0 + (uint64_t)k * 4 + b);
+      m &= m - 1;
+    }
+  }
 }
 
 }  // namespace
@@ -136,6 +267,33 @@ int swg_inclusive_max_scan_u32(swg_ctx* ctx, const uint32_t* in, uint32_t* out, 
 }
 int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n) {
   return scan_impl<1, true, uint64_t>(ctx, in, out, n, nullptr);
+}
+
+int swg_flags_count(swg_ctx* ctx, const uint8_t* flags, uint64_t n, swg_flag_scan* fs, uint64_t* d_total) {
+  fs->flags = flags;
+  fs->n = n;
+  fs->tile_off = nullptr;
+  if (n == 0) {
+    if (d_total) SWG_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
+    return SWG_OK;
+  }
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  fs->tile_off = swg_alloc<uint32_t>(ctx, nb);
+  SWG_CHECK_ARENA(ctx);
+  const int aligned = (reinterpret_cast<uintptr_t>(flags) & 15) == 0;
+  SWG_LAUNCH(ctx, "flag_count", flag_count_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(flags, n, aligned, fs->tile_off));
+  SWG_KERNEL_CHECK(ctx);
+  return scan_impl<0, false, uint32_t>(ctx, fs->tile_off, fs->tile_off, nb, d_total);
+}
+
+int swg_flags_compact(swg_ctx* ctx, const swg_flag_scan& fs, uint32_t* list) {
+  if (fs.n == 0) return SWG_OK;
+  const uint64_t nb = (fs.n + SCAN_TILE - 1) / SCAN_TILE;
+  const int aligned = (reinterpret_cast<uintptr_t>(fs.flags) & 15) == 0;
+  SWG_LAUNCH(ctx, "flag_compact", flag_compact_kernel<<<(unsigned)nb, SCAN_THREADS, 0, ctx->stream>>>(fs.flags, fs.n, aligned,
+                                                                                            fs.tile_off, list));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
