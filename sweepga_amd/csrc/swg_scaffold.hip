@@ -860,31 +860,54 @@ __global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, cons
     if (lane == 0) group_first[g] = v;
   }
 }
-__global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
+// First (lowest) original index of every genome pair over the alive records, in ORIGINAL order (coalesced
+// reads).  Two filters keep the atomics rare: (1) a wavefront whose 256 records all belong to one pair (inputs
+// grouped by pair) reduces to one atomic; (2) otherwise (interleaved pairs) a plain cached read of the table --
+// it only ever decreases, so a stale value is merely conservative -- drops every record that cannot lower it.
+__global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const uint8_t* __restrict__ alive,
                                                                const uint32_t* __restrict__ q_id,
                                                                const uint32_t* __restrict__ t_id,
                                                                const uint32_t* __restrict__ seq_genome,
-                                                               uint32_t n_genome, uint32_t* __restrict__ table) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  const bool valid = a < M;
-  uint32_t i = 0xffffffffu, L = 0;
-  if (valid) {
-    i = idxA[a];
-    L = seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]];
-  }
-  // A order is pair-major, so a wave usually sees one genome pair: one atomic per wave then
-  const uint32_t L0 = __shfl(L, 0, 64);
-  const bool uniform = __all(!valid || L == L0) && __shfl((int)valid, 0, 64);
-  if (uniform) {
-    uint32_t v = i;
+                                                               uint32_t n_genome, uint32_t* table) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const uint64_t stride = (uint64_t)gridDim.x * EW * U;
+  // whole waves stay in the loop together (the bound is wave-uniform), so the cross-lane ops are safe
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * EW + (threadIdx.x & ~63)) * U; w0 < n; w0 += stride) {
+    const uint64_t i0 = w0 + (uint64_t)lane * U;
+    uint32_t L[U];
+    bool live[U];
+    uint32_t first_i = 0xffffffffu, first_L = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + u;
+      live[u] = i < n && alive[i] != 0;
+      L[u] = live[u] ? seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]] : 0u;
+      if (live[u] && first_i == 0xffffffffu) {
+        first_i = (uint32_t)i;
+        first_L = L[u];
+      }
+    }
+    // wave minimum of first_i, and the pair of the lane holding it
+    uint32_t vmin = first_i;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t t = __shfl_xor(v, o, 64);
-      if (t < v) v = t;
+      const uint32_t x = __shfl_xor(vmin, o, 64);
+      if (x < vmin) vmin = x;
     }
-    if ((threadIdx.x & 63) == 0) atomicMin(&table[L0], v);
-  } else if (valid) {
-    atomicMin(&table[L], i);
+    if (vmin == 0xffffffffu) continue;  // no live record in this wave's span
+    const uint64_t holder = __ballot(first_i == vmin);
+    const uint32_t L0 = __shfl(first_L, __builtin_ctzll(holder), 64);
+    bool same = true;
+#pragma unroll
+    for (int u = 0; u < U; ++u) same = same && (!live[u] || L[u] == L0);
+    if (__all(same)) {
+      if (lane == 0 && table[L0] > vmin) atomicMin(&table[L0], vmin);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (live[u] && table[L[u]] > (uint32_t)(i0 + u)) atomicMin(&table[L[u]], (uint32_t)(i0 + u));
+    }
   }
 }
 
@@ -1504,8 +1527,8 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                                                                                B.s_idx, group_first));
   }
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->seq_genome_last,
-                                                                            r->n_genome_last, gp_first));
+  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
+                                                                                    r->seq_genome_last, r->n_genome_last, gp_first));
   SWG_KERNEL_CHECK(ctx);
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
