@@ -88,23 +88,22 @@ def make_config(sw, pipeline):
     raise SystemExit(f"unknown --pipeline {pipeline}")
 
 
-def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev):
-    """The CPU oracle (port of the reference, 1 thread like the reference's filter) timed on a bounded
-    sample: the first whole genome-pair groups of this rank's shard.  Also the parity check."""
+def _oracle_records(cols, lo, hi, n_names):
     import numpy as np
     from tests import orc
-    csum = sizes.cumsum(0).cpu().numpy()
-    g = int(np.searchsorted(csum, sample_target)) + 1
-    m = int(csum[min(g, len(csum)) - 1])
-    h = {k: cols[k][:m].cpu().numpy() for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity",
-                                                 "matches", "block_len", "strand")}
-    names = [f"g{i:03d}#1#chr1" for i in range(int(max(h["q_id"].max(), h["t_id"].max())) + 1)]
+    h = {k: cols[k][lo:hi].cpu().numpy() for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity",
+                                                   "matches", "block_len", "strand")}
+    names = [f"g{i:03d}#1#chr1" for i in range(n_names)]
     u = lambda a: np.ascontiguousarray(a.astype(np.uint64))
-    rec = orc.Records([names[i] for i in h["q_id"]], [names[i] for i in h["t_id"]], u(h["q_start"]), u(h["q_end"]),
-                      u(h["t_start"]), u(h["t_end"]), u(h["block_len"]), np.ascontiguousarray(h["identity"]),
-                      u(h["matches"]), np.where(h["strand"] == 0, ord("+"), ord("-")).astype(np.uint8),
-                      u(np.arange(m)))
-    ocfg = orc.Config(mapping_filter_mode=int(cfg.mapping_filter_mode), mapping_max_per_query=cfg.mapping_max_per_query or 0,
+    return orc.Records([names[i] for i in h["q_id"]], [names[i] for i in h["t_id"]], u(h["q_start"]), u(h["q_end"]),
+                       u(h["t_start"]), u(h["t_end"]), u(h["block_len"]), np.ascontiguousarray(h["identity"]),
+                       u(h["matches"]), np.where(h["strand"] == 0, ord("+"), ord("-")).astype(np.uint8),
+                       u(np.arange(hi - lo)))
+
+
+def _oracle_config(cfg):
+    from tests import orc
+    return orc.Config(mapping_filter_mode=int(cfg.mapping_filter_mode), mapping_max_per_query=cfg.mapping_max_per_query or 0,
                       mapping_max_per_target=cfg.mapping_max_per_target or 0,
                       scaffold_filter_mode=int(cfg.scaffold_filter_mode), scaffold_max_per_query=cfg.scaffold_max_per_query or 0,
                       scaffold_max_per_target=cfg.scaffold_max_per_target or 0, overlap_threshold=cfg.overlap_threshold,
@@ -112,6 +111,51 @@ def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev):
                       scaffold_overlap_threshold=cfg.scaffold_overlap_threshold,
                       scaffold_max_deviation=cfg.scaffold_max_deviation, scoring_function=int(cfg.scoring_function),
                       min_identity=cfg.min_identity, min_scaffold_identity=cfg.min_scaffold_identity)
+
+
+def cpu_baseline_all_cores(cols, sizes, cfg, n_names, first_group, per_thread=150_000, max_threads=32):
+    """'What a group-parallel CPU filter would give' (SURVEY.md 8d-ii): the same oracle on T host threads at once,
+    every thread on its own whole genome-pair groups (the reference itself filters on one thread)."""
+    import threading
+    import numpy as np
+    from tests import orc
+    csum = np.concatenate([[0], sizes.cumsum(0).cpu().numpy()])
+    T = max(1, min(os.cpu_count() or 1, max_threads))
+    ocfg = _oracle_config(cfg)
+    jobs, g = [], first_group
+    for _ in range(T):
+        g2 = int(np.searchsorted(csum, csum[g] + per_thread)) if g < len(csum) - 1 else g
+        g2 = min(max(g2, g + 1), len(csum) - 1)
+        if g2 <= g:
+            break
+        jobs.append(_oracle_records(cols, int(csum[g]), int(csum[g2]), n_names))
+        g = g2
+    if not jobs:
+        return None
+    bar = threading.Barrier(len(jobs) + 1)
+    th = [threading.Thread(target=orc.apply_filters, args=(ocfg, r), kwargs={"barrier": bar}) for r in jobs]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    m = sum(len(r) for r in jobs)
+    return dict(value=m / wall, unit="mappings/s", cores=len(jobs), kind="port",
+                sample=f"{len(jobs)} threads x ~{per_thread} mappings (whole groups), all started together, wall {wall:.2f} s")
+
+
+def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev, n_names):
+    """The CPU oracle (port of the reference, 1 thread like the reference's filter) timed on a bounded
+    sample: the first whole genome-pair groups of this rank's shard.  Also the parity check."""
+    import numpy as np
+    from tests import orc
+    csum = sizes.cumsum(0).cpu().numpy()
+    g = int(np.searchsorted(csum, sample_target)) + 1
+    m = int(csum[min(g, len(csum)) - 1])
+    rec = _oracle_records(cols, 0, m, n_names)
+    ocfg = _oracle_config(cfg)
     ost, och, secs = orc.apply_filters(ocfg, rec, want_seconds=True)
     gst = status_dev[:m].cpu().numpy()
     parity = bool(np.array_equal(gst, ost))
@@ -326,9 +370,10 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         pipe_achieved = algo * n / (ms_per_step * 1e-3) / 1e9
-        cpu, parity = (None, None)
+        cpu, parity, cpu_mt = (None, None, None)
         if args.cpu_sample > 0:
-            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main)
+            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main, args.genomes)
+            cpu_mt = cpu_baseline_all_cores(cols, sizes, cfg, args.genomes, 0)
         out = {
             "metric": "PAF mappings/sec through plane-sweep+scaffold filter",
             "value": n * world / (elapsed / args.steps),
@@ -356,6 +401,7 @@ def main():
                          "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
                          "kernel_ms_per_step": total_kernel_ms / args.steps},
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_mt,
             "parity_vs_oracle_on_sample": parity,
             "counts": main_counts,
             "other_pipelines": others,

@@ -230,8 +230,10 @@ def parse_paf_text(text):
                    np.asarray(a[5], dtype=np.float64), _u64(a[6]), np.asarray(a[7], dtype=np.uint8), _u64(ranks))
 
 
-def apply_filters(cfg: Config, rec: Records, want_seconds=False):
-    """PafFilter::apply_filters -> (status[n], chain[n]) aligned with rec rows."""
+def apply_filters(cfg: Config, rec: Records, want_seconds=False, barrier=None):
+    """PafFilter::apply_filters -> (status[n], chain[n]) aligned with rec rows.
+    `barrier` (threading.Barrier): waited on right before the C call, so several threads can start together
+    (ctypes releases the GIL during the call)."""
     n = len(rec)
     status = np.zeros(max(n, 1), dtype=np.uint8)
     chain = np.zeros(max(n, 1), dtype=np.uint32)
@@ -239,7 +241,10 @@ def apply_filters(cfg: Config, rec: Records, want_seconds=False):
     cc = cfg.c()
     strand = np.ascontiguousarray(rec.strand)
     ident = np.ascontiguousarray(rec.identity)
-    r = lib().orc_apply_filters(C.byref(cc), C.c_uint64(n), _p(rec.rank), _names(rec.qname), _names(rec.tname),
+    qn, tn = _names(rec.qname), _names(rec.tname)
+    if barrier is not None:
+        barrier.wait()
+    r = lib().orc_apply_filters(C.byref(cc), C.c_uint64(n), _p(rec.rank), qn, tn,
                                 _p(rec.qs), _p(rec.qe), _p(rec.ts), _p(rec.te), _p(rec.block_length),
                                 _p(ident), _p(rec.matches), _p(strand), _p(status), _p(chain), C.byref(secs))
     assert r >= 0, "oracle apply_filters failed"
