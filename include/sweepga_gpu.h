@@ -227,6 +227,40 @@ int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, cons
                    swg_stats* stats, double timing_ms[4]);
 const char* swg_paf_last_error(void);
 
+/* ---- ANI pre-pass for "aniN" identity thresholds (src/main.rs:296-688, src/cli.rs:76-130) -------------------
+ * calculate_ani_stats: median over genome pairs (last-'#' prefixes, unordered) of Σmatches / Σblock_len, over
+ *   SWG_ANI_ALL         every inter-genome line                                   main.rs:339-342, 392-498
+ *   SWG_ANI_ORTHOGONAL  the survivors of a fixed 1:1 / >= 1 kb / matches-scored filter   main.rs:343-382
+ *   SWG_ANI_NPERCENTILE lines taken in descending length / identity / identity*max(ln len,1) order (stable)
+ *                       until their block lengths cover `percentile` % of the total sequence size   main.rs:500-688
+ * Host threads parse the ANI view of each line (f64 matches/block length, first valid dv:f:, sequence lengths);
+ * the GPU does the key sort, the prefix cut and the per-pair sums (each pair summed in reference order, so the
+ * f64 sums are bit-identical); the 1:1 filter of ORTHOGONAL is swg_filter.  The reference panics on NaN keys
+ * (partial_cmp().unwrap()); here that is SWG_ERR_INVALID.  Non-integral block lengths: SWG_ERR_UNSUPPORTED. */
+enum { SWG_ANI_ALL = 0, SWG_ANI_ORTHOGONAL = 1, SWG_ANI_NPERCENTILE = 2 };
+enum { SWG_NSORT_LENGTH = 0, SWG_NSORT_IDENTITY = 1, SWG_NSORT_SCORE = 2 };
+typedef struct swg_ani_input {
+  uint64_t n;               /* records of the swg_paf handle */
+  const uint8_t* eligible;  /* [n] line takes part (not '#'-led, genomes differ)         main.rs:406-432 */
+  const uint32_t* pair;     /* [n] unordered genome-pair id < n_pairs */
+  uint64_t n_pairs;
+  const double* matches;    /* [n] final_matches: column 10, or (1-dv)*block_len          main.rs:435-446 */
+  const double* block_len;  /* [n] column 11 as f64 (default 1.0) */
+  double total_genome_size; /* Σ first-seen length of every sequence on an eligible line  main.rs:560-572, 626 */
+} swg_ani_input;
+/* parse_ani_method (main.rs:296-330): returns 1 and fills the outputs, 0 for None */
+int swg_parse_ani_method(const char* s, int* kind, double* percentile, int* sort);
+/* parse_identity_value (cli.rs:76-130): ani_percentile < 0 means None.  Returns SWG_OK or SWG_ERR_INVALID. */
+int swg_parse_identity_value(const char* s, double ani_percentile, double* out);
+/* host side: the ANI view of the records (arrays owned by the handle, valid until swg_paf_close) */
+int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out);
+/* device side: median per-pair ANI.  `select` (optional, [n]) further restricts the lines (ORTHOGONAL survivors);
+ * kind ALL/ORTHOGONAL = file order, no cut.  0.0 when no line takes part (main.rs:448-451, 604-607). */
+int swg_ani_median(swg_ctx* ctx, const swg_ani_input* in, const uint8_t* select, int kind, double percentile, int sort,
+                   double* ani50);
+/* calculate_ani_stats over an open PAF (runs the ORTHOGONAL filter itself) */
+int swg_paf_ani_stats(swg_ctx* ctx, swg_paf* p, int kind, double percentile, int sort, int threads, double* ani50);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,6 +249,32 @@ int orc_parse_filter_mode(const char* s, int32_t* mode, uint64_t* pq, uint64_t* 
 }
 int orc_parse_metric_number(const char* s, uint64_t* out) { return parse_metric_number(s, out) ? 1 : 0; }
 int orc_parse_identity_value(const char* s, double* out) { return parse_identity_value(s, out) ? 1 : 0; }
+// ani_percentile < 0 = None
+int orc_parse_identity_value_ani(const char* s, double ani_percentile, double* out) {
+  return parse_identity_value(s, out, ani_percentile) ? 1 : 0;
+}
+// main.rs:296-330 ; returns 0 for None
+int orc_parse_ani_method(const char* s, int* kind, double* percentile, int* sort) {
+  AniMethod m;
+  if (!parse_ani_method(s, &m)) return 0;
+  *kind = m.kind;
+  *percentile = m.percentile;
+  *sort = m.sort;
+  return 1;
+}
+// main.rs:334-688 ; returns 0 on success, -1 on error (I/O, NaN where the reference panics)
+int orc_calculate_ani_stats(const char* path, int kind, double percentile, int sort, double* out) {
+  try {
+    AniMethod m;
+    m.kind = kind;
+    m.percentile = percentile;
+    m.sort = sort;
+    *out = calculate_ani_stats(path, m);
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
 int orc_parse_scoring(const char* s) { return parse_scoring(s); }
 uint64_t orc_round_nice(uint64_t v) { return round_nice(v); }
 void orc_clamp_scaffold_params(uint64_t j, uint64_t m, int have_avg, uint64_t avg, int adaptive,

@@ -24,6 +24,7 @@
 #include <stdexcept>
 #include <tuple>
 #include <unordered_set>
+#include <unistd.h>
 
 namespace orc {
 
@@ -461,11 +462,46 @@ bool parse_metric_number(const std::string& s, uint64_t* out) {
   return true;
 }
 
-// cli.rs:76-130 (non-ANI forms)
-bool parse_identity_value(const std::string& s, double* out) {
+// cli.rs:76-130
+bool parse_identity_value(const std::string& s, double* out, double ani_percentile) {
   std::string lower = s;
   for (auto& c : lower) c = (char)std::tolower((unsigned char)c);
-  if (lower.rfind("ani", 0) == 0) return false;  // needs the ANI pre-pass
+  if (lower.rfind("ani", 0) == 0) {
+    if (ani_percentile < 0.0) return false;  // "Cannot use ANI-based threshold without input alignments"
+    const std::string rem = lower.substr(3);
+    if (rem.empty()) {
+      *out = ani_percentile;
+      return true;
+    }
+    // aniN, aniN+X, aniN-X: the percentile number is parsed away and ignored (only the median is honoured)
+    char sign = 0;
+    std::string off;
+    const size_t plus = rem.find('+');
+    if (plus != std::string::npos) {
+      sign = '+';
+      off = rem.substr(plus + 1);
+    } else {
+      const size_t minus = rem.find('-');
+      if (minus != std::string::npos) {
+        sign = '-';
+        off = rem.substr(minus + 1);
+      }
+    }
+    if (!sign) {
+      *out = ani_percentile;
+      return true;
+    }
+    double offset;
+    if (!rust_parse_f64(off, &offset)) return false;  // "Invalid ANI offset"
+    if (sign == '+') {
+      const double v = ani_percentile + offset / 100.0;
+      *out = v < 1.0 ? v : 1.0;  // f64::min(1.0) (NaN -> 1.0)
+    } else {
+      const double v = ani_percentile - offset / 100.0;
+      *out = v > 0.0 ? v : 0.0;  // f64::max(0.0)
+    }
+    return true;
+  }
   double v;
   if (!rust_parse_f64(s, &v)) return false;
   *out = v > 1.0 ? v / 100.0 : v;
@@ -1043,6 +1079,215 @@ void PafFilter::filter_paf(const std::string& in, const std::string& out) const 
   std::vector<RecordMeta> md = extract_metadata(in);
   auto passing = apply_filters(std::move(md));
   write_filtered_output(in, out, passing);
+}
+
+// ---------------------------------------------------------------------------------------
+// ANI pre-pass (src/main.rs:296-688)
+// ---------------------------------------------------------------------------------------
+bool parse_ani_method(const std::string& method_str, AniMethod* out) {  // main.rs:296-330
+  const std::string lower = ascii_lower(method_str);
+  if (lower == "all") {
+    out->kind = ANI_ALL;
+    return true;
+  }
+  if (lower == "orthogonal" || lower == "1:1") {
+    out->kind = ANI_ORTHOGONAL;
+    return true;
+  }
+  if (lower.empty() || lower[0] != 'n') return false;
+  const std::string rest = lower.substr(1);
+  std::vector<std::string> parts;
+  for (size_t s0 = 0;;) {
+    const size_t d = rest.find('-', s0);
+    if (d == std::string::npos) {
+      parts.push_back(rest.substr(s0));
+      break;
+    }
+    parts.push_back(rest.substr(s0, d - s0));
+    s0 = d + 1;
+  }
+  double pct;
+  if (!rust_parse_f64(parts[0], &pct)) return false;
+  if (!(pct > 0.0 && pct <= 100.0)) return false;
+  int sort = NSORT_IDENTITY;
+  if (parts.size() > 1) {
+    if (parts[1] == "length") sort = NSORT_LENGTH;
+    else if (parts[1] == "identity") sort = NSORT_IDENTITY;
+    else if (parts[1] == "score") sort = NSORT_SCORE;
+    else return false;
+  }
+  out->kind = ANI_NPERCENTILE;
+  out->percentile = pct;
+  out->sort = sort;
+  return true;
+}
+
+namespace {
+
+std::string genome_prefix_last(const std::string& name) {  // main.rs:416-425
+  const size_t p = name.rfind('#');
+  return p == std::string::npos ? name : name.substr(0, p + 1);
+}
+
+struct AniLine {
+  std::string query_genome, target_genome;
+  double matches, block_length, identity;
+  uint64_t query_length, target_length;
+};
+
+// The per-line part shared by both passes (main.rs:405-446 and 531-586).  False = line skipped.
+bool parse_ani_line(const std::string& line, std::vector<std::string>* fields, AniLine* a) {
+  if (line.empty() || line[0] == '#') return false;
+  fields->clear();
+  for (size_t s0 = 0;;) {
+    const size_t t = line.find('\t', s0);
+    if (t == std::string::npos) {
+      fields->push_back(line.substr(s0));
+      break;
+    }
+    fields->push_back(line.substr(s0, t - s0));
+    s0 = t + 1;
+  }
+  const auto& f = *fields;
+  if (f.size() < 11) return false;
+  a->query_genome = genome_prefix_last(f[0]);
+  a->target_genome = genome_prefix_last(f[5]);
+  if (a->query_genome == a->target_genome) return false;
+  if (!rust_parse_u64(f[1], &a->query_length)) a->query_length = 0;
+  if (!rust_parse_u64(f[6], &a->target_length)) a->target_length = 0;
+  double matches, block_len;
+  if (!rust_parse_f64(f[9], &matches)) matches = 0.0;
+  if (!rust_parse_f64(f[10], &block_len)) block_len = 1.0;
+  double final_matches = matches;
+  for (size_t k = 11; k < f.size(); ++k) {
+    if (f[k].compare(0, 5, "dv:f:") == 0) {
+      double div;
+      if (rust_parse_f64(f[k].substr(5), &div)) {
+        final_matches = (1.0 - div) * block_len;
+        break;
+      }
+    }
+  }
+  a->matches = final_matches;
+  a->block_length = block_len;
+  a->identity = final_matches / (block_len > 1.0 ? block_len : 1.0);  // block_len.max(1.0): NaN -> 1.0
+  return true;
+}
+
+using PairSums = std::map<std::pair<std::string, std::string>, std::pair<double, double>>;
+
+void add_pair(PairSums* pairs, const AniLine& a) {
+  auto key = a.query_genome < a.target_genome ? std::make_pair(a.query_genome, a.target_genome)
+                                              : std::make_pair(a.target_genome, a.query_genome);
+  auto& e = (*pairs)[key];
+  e.first += a.matches;
+  e.second += a.block_length;
+}
+
+double median_pair_ani(const PairSums& pairs) {  // main.rs:461-498 / 660-686
+  std::vector<double> v;
+  for (const auto& kv : pairs) v.push_back(kv.second.second > 0.0 ? kv.second.first / kv.second.second : 0.0);
+  for (double x : v)
+    if (x != x) throw std::runtime_error("NaN in ANI values (the reference panics in partial_cmp().unwrap())");
+  std::sort(v.begin(), v.end());
+  const size_t mid = v.size() / 2;
+  return (v.size() % 2 == 0 && v.size() > 1) ? (v[mid - 1] + v[mid]) / 2.0 : v[mid];
+}
+
+std::vector<std::string> read_lines_lossless(const std::string& path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("cannot open " + path);
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(in, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    lines.push_back(line);
+  }
+  return lines;
+}
+
+double ani_n_percentile(const std::string& path, double percentile, int sort_method) {  // main.rs:500-688
+  std::vector<AniLine> al;
+  std::map<std::string, uint64_t> genome_sizes;  // key -> first-seen length (entry().or_insert)
+  std::vector<std::string> fields;
+  for (const std::string& line : read_lines_lossless(path)) {
+    AniLine a;
+    if (!parse_ani_line(line, &fields, &a)) continue;
+    auto last_part = [](const std::string& n) {
+      const size_t p = n.rfind('#');
+      return p == std::string::npos ? n : n.substr(p + 1);
+    };
+    genome_sizes.emplace(a.query_genome + last_part(fields[0]), a.query_length);
+    genome_sizes.emplace(a.target_genome + last_part(fields[5]), a.target_length);
+    al.push_back(a);
+  }
+  if (al.empty()) return 0.0;
+  auto key_of = [&](const AniLine& a) {
+    if (sort_method == NSORT_LENGTH) return a.block_length;
+    if (sort_method == NSORT_IDENTITY) return a.identity;
+    double l = std::log(a.block_length);
+    if (!(l > 1.0)) l = 1.0;  // ln().max(1.0); NaN -> 1.0
+    return a.identity * l;
+  };
+  for (const auto& a : al) {
+    const double k = key_of(a);
+    if (k != k) throw std::runtime_error("NaN sort key (the reference panics in partial_cmp().unwrap())");
+  }
+  std::stable_sort(al.begin(), al.end(), [&](const AniLine& x, const AniLine& y) { return key_of(x) > key_of(y); });
+  double total_genome_size = 0.0;
+  for (const auto& kv : genome_sizes) total_genome_size += (double)kv.second;
+  const double n_threshold = total_genome_size * (percentile / 100.0);
+  double cumulative = 0.0;
+  PairSums pairs;
+  for (const auto& a : al) {
+    cumulative += a.block_length;
+    add_pair(&pairs, a);
+    if (cumulative >= n_threshold) break;
+  }
+  return median_pair_ani(pairs);
+}
+
+}  // namespace
+
+double calculate_ani_stats(const std::string& input_path, const AniMethod& method) {  // main.rs:334-498
+  std::string final_input = input_path;
+  std::string tmp;
+  if (method.kind == ANI_ORTHOGONAL) {  // main.rs:343-382: best 1:1 mappings, >= 1 kb, scored by matches
+    FilterConfig c;
+    c.min_block_length = 1000;
+    c.mapping_filter_mode = ONE_TO_ONE;
+    c.mapping_max_per_query = 1;
+    c.mapping_max_per_target = 1;
+    c.scaffold_filter_mode = ONE_TO_ONE;
+    c.scaffold_max_per_query = 1;
+    c.scaffold_max_per_target = 1;
+    c.overlap_threshold = 0.95;
+    c.scaffold_gap = 10000;
+    c.min_scaffold_length = 0;
+    c.scaffold_overlap_threshold = 0.95;
+    c.scaffold_max_deviation = 0;
+    c.scoring_function = SCORE_MATCHES;
+    c.min_identity = 0.0;
+    c.min_scaffold_identity = 0.0;
+    char name[] = "/tmp/orc_ani_XXXXXX";
+    const int fd = mkstemp(name);
+    if (fd < 0) throw std::runtime_error("mkstemp failed");
+    close(fd);
+    tmp = name;
+    PafFilter(c).filter_paf(input_path, tmp);
+    final_input = tmp;
+  } else if (method.kind == ANI_NPERCENTILE) {
+    return ani_n_percentile(input_path, method.percentile, method.sort);
+  }
+  PairSums pairs;
+  std::vector<std::string> fields;
+  for (const std::string& line : read_lines_lossless(final_input)) {
+    AniLine a;
+    if (parse_ani_line(line, &fields, &a)) add_pair(&pairs, a);
+  }
+  if (!tmp.empty()) std::remove(tmp.c_str());
+  if (pairs.empty()) return 0.0;
+  return median_pair_ani(pairs);
 }
 
 }  // namespace orc

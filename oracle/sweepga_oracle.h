@@ -157,8 +157,21 @@ bool parse_filter_mode(const std::string& mode, int* fmode, uint64_t* per_query,
                        uint64_t* per_target);
 // src/cli.rs:26-61
 bool parse_metric_number(const std::string& s, uint64_t* out);
-// src/cli.rs:76-130 (numeric forms only; "aniN" needs the ANI pre-pass, out of scope)
-bool parse_identity_value(const std::string& s, double* out);
+// src/cli.rs:76-130.  `ani_percentile` < 0 means None ("aniN" forms then fail, as in the reference).
+bool parse_identity_value(const std::string& s, double* out, double ani_percentile = -1.0);
+
+// ---- ANI pre-pass (src/main.rs:172-188, 296-688) ----
+enum AniMethodKind { ANI_ALL = 0, ANI_ORTHOGONAL = 1, ANI_NPERCENTILE = 2 };
+enum NSort { NSORT_LENGTH = 0, NSORT_IDENTITY = 1, NSORT_SCORE = 2 };
+struct AniMethod {
+  int kind = ANI_NPERCENTILE;
+  double percentile = 50.0;
+  int sort = NSORT_IDENTITY;
+};
+// src/main.rs:296-330 ; false = None
+bool parse_ani_method(const std::string& s, AniMethod* out);
+// src/main.rs:334-498 (All / Orthogonal) and 500-688 (N-percentile).  Returns the median per-genome-pair ANI.
+double calculate_ani_stats(const std::string& input_path, const AniMethod& method);
 // src/main.rs:3485-3492
 int parse_scoring(const std::string& s);
 // src/pansn.rs:176-225

@@ -22,7 +22,7 @@ static void die(const std::string& msg) {
 int main(int argc, char** argv) {
   std::string input, output_file;
   std::string num_mappings = "many:many", scoring = "log-length-ani", min_identity = "0";
-  std::string scaffold_filter = "many:many", min_scaffold_identity = "0";
+  std::string scaffold_filter = "many:many", min_scaffold_identity = "0", ani_method_s = "n100";
   double overlap = 0.95, scaffold_overlap = 0.5;
   uint64_t scaffold_jump = 50000, scaffold_mass = 10000, scaffold_dist = 0;
   bool have_block_length = false;
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
       if (!parse_metric_number(value(), &scaffold_dist)) die("bad --scaffold-dist");
     } else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
     else if (a == "--scaffolds-only") scaffolds_only = true;
+    else if (a == "--ani-method") ani_method_s = value();
     else if (a == "--no-adaptive-scaffolds" || a == "--quiet" || a == "--paf") { /* no effect here */ }
     else if (a == "--threads" || a == "-t") (void)value();
     else if (a.rfind("-", 0) == 0 && a != "-") die("unknown flag " + a);
@@ -101,10 +102,29 @@ int main(int argc, char** argv) {
   cfg.min_scaffold_length = scaffold_mass;
   cfg.scaffold_overlap_threshold = scaffold_overlap;
   cfg.scaffold_max_deviation = scaffold_dist;
-  if (!parse_identity_value(min_identity, &cfg.min_identity)) die("bad --min-aln-identity");
+  // main.rs:3571-3595: ANI pre-pass only when a threshold mentions "ani"
+  AniMethod ani_method;
+  if (!parse_ani_method(ani_method_s, &ani_method)) {
+    ani_method.kind = ANI_NPERCENTILE;
+    ani_method.percentile = 50.0;
+    ani_method.sort = NSORT_IDENTITY;
+  }
+  auto lower = [](std::string v) {
+    for (auto& c : v)
+      if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+    return v;
+  };
+  double ani_percentile = -1.0;
+  try {
+    if (lower(min_identity).find("ani") != std::string::npos || lower(min_scaffold_identity).find("ani") != std::string::npos)
+      ani_percentile = calculate_ani_stats(input, ani_method);
+  } catch (const std::exception& e) {
+    die(e.what());
+  }
+  if (!parse_identity_value(min_identity, &cfg.min_identity, ani_percentile)) die("bad --min-aln-identity");
   if (min_scaffold_identity.empty())
     cfg.min_scaffold_identity = cfg.min_identity;
-  else if (!parse_identity_value(min_scaffold_identity, &cfg.min_scaffold_identity))
+  else if (!parse_identity_value(min_scaffold_identity, &cfg.min_scaffold_identity, ani_percentile))
     die("bad --min-scaffold-identity");
   cfg.keep_self = keep_self;  // || no_filter, handled above
   cfg.scaffolds_only = scaffolds_only;

@@ -18,7 +18,8 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_profile_reset", "swg_profile_count", "swg_profile_get",
            "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
-           "swg_paf_write", "swg_filter_paf", "swg_paf_last_error"]
+           "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
+           "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats"]
 
 
 class SwgError(RuntimeError):
@@ -81,6 +82,18 @@ class SwgStats(C.Structure):
         ("device_ms", C.c_double),
         ("h2d_ms", C.c_double),
         ("d2h_ms", C.c_double),
+    ]
+
+
+class SwgAniInput(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("eligible", C.c_void_p),
+        ("pair", C.c_void_p),
+        ("n_pairs", C.c_uint64),
+        ("matches", C.c_void_p),
+        ("block_len", C.c_void_p),
+        ("total_genome_size", C.c_double),
     ]
 
 
@@ -168,6 +181,17 @@ def load():
                                    C.POINTER(SwgStats), C.POINTER(C.c_double)]
     lib.swg_paf_last_error.restype = C.c_char_p
     lib.swg_paf_last_error.argtypes = []
+    lib.swg_parse_ani_method.restype = C.c_int
+    lib.swg_parse_ani_method.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.swg_parse_identity_value.restype = C.c_int
+    lib.swg_parse_identity_value.argtypes = [C.c_char_p, C.c_double, C.POINTER(C.c_double)]
+    lib.swg_paf_ani_input.restype = C.c_int
+    lib.swg_paf_ani_input.argtypes = [C.c_void_p, C.c_int, C.POINTER(SwgAniInput)]
+    lib.swg_ani_median.restype = C.c_int
+    lib.swg_ani_median.argtypes = [C.c_void_p, C.POINTER(SwgAniInput), C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                   C.POINTER(C.c_double)]
+    lib.swg_paf_ani_stats.restype = C.c_int
+    lib.swg_paf_ani_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _lib = lib
     return lib
 

@@ -361,6 +361,12 @@ struct swg_paf {
   std::vector<uint32_t> g_last, g_two;
   swg_records rec{};
   double load_ms = 0, parse_ms = 0;
+  // ANI view (filled by swg_paf_ani_input)
+  bool have_ani = false;
+  std::vector<uint8_t> ani_eligible;
+  std::vector<uint32_t> ani_pair;
+  std::vector<double> ani_matches, ani_block;
+  swg_ani_input ani{};
 };
 
 namespace {
@@ -752,6 +758,202 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   }
   if (!to_stdout && close(fd) != 0 && !bad) bad = errno ? errno : EIO;
   if (bad) return paf_error(SWG_ERR_INVALID, "write to %s failed: %s", out_path, std::strerror(bad));
+  return SWG_OK;
+}
+
+// ---- ANI pre-pass, host part (src/main.rs:405-446, 531-586) ----------------------------------------------
+int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out) {
+  if (!p || !out) return paf_error(SWG_ERR_INVALID, "swg_paf_ani_input: NULL argument");
+  if (p->have_ani) {
+    *out = p->ani;
+    return SWG_OK;
+  }
+  const uint64_t n = p->rec.n;
+  const uint64_t G = p->rec.n_genome_last;
+  if (G * G > 0xffffffffull) return paf_error(SWG_ERR_UNSUPPORTED, "more than 65535 genomes in the ANI pass");
+  threads = pick_threads(threads);
+  if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
+  const size_t cap = n ? n : 1;
+  p->ani_eligible.assign(cap, 0);
+  p->ani_pair.assign(cap, 0);
+  p->ani_matches.assign(cap, 0.0);
+  p->ani_block.assign(cap, 0.0);
+  const size_t n_seq = p->names.size();
+  // first-seen sequence length per thread range: (record index of first sighting, length)
+  struct Seen {
+    std::vector<uint8_t> has;
+    std::vector<uint64_t> len;
+  };
+  std::vector<Seen> seen(threads);
+  const char* text = p->text.data;
+  auto lo = [&](int t) { return n / threads * t + (uint64_t)std::min<uint64_t>(t, n % threads); };
+  parallel_for(threads, [&](int t) {
+    Seen& sn = seen[t];
+    sn.has.assign(n_seq ? n_seq : 1, 0);
+    sn.len.assign(n_seq ? n_seq : 1, 0);
+    const char* f[12];
+    for (uint64_t k = lo(t); k < lo(t + 1); ++k) {
+      const char* b = text + p->rec_off[k];
+      const char* e = b + p->rec_len[k];
+      const uint32_t q = p->q_id[k], tg = p->t_id[k];
+      if (b == e || *b == '#') continue;                       // main.rs:406-408
+      if (p->g_last[q] == p->g_last[tg]) continue;             // main.rs:429-432
+      if (!split11(b, e, f)) continue;                         // cannot happen for a record
+      auto len = [&](int i) { return (size_t)(f[i + 1] - 1 - f[i]); };
+      uint64_t ql = 0, tl = 0;
+      if (!parse_u64(f[1], len(1), &ql)) ql = 0;
+      if (!parse_u64(f[6], len(6), &tl)) tl = 0;
+      double matches, block;
+      if (!parse_f64(f[9], len(9), &matches)) matches = 0.0;
+      if (!parse_f64(f[10], len(10), &block)) block = 1.0;
+      double final_matches = matches;
+      for (const char* tgp = f[11]; tgp <= e;) {               // first dv:f: that parses wins (break)
+        const char* te = static_cast<const char*>(std::memchr(tgp, '\t', (size_t)(e - tgp)));
+        if (!te) te = e;
+        const size_t tl2 = (size_t)(te - tgp);
+        if (tl2 >= 5 && !std::memcmp(tgp, "dv:f:", 5)) {
+          double dv;
+          if (parse_f64(tgp + 5, tl2 - 5, &dv)) {
+            final_matches = (1.0 - dv) * block;
+            break;
+          }
+        }
+        tgp = te + 1;
+      }
+      p->ani_eligible[k] = 1;
+      const uint32_t ga = p->g_last[q], gb = p->g_last[tg];
+      p->ani_pair[k] = (uint32_t)((uint64_t)std::min(ga, gb) * G + std::max(ga, gb));
+      p->ani_matches[k] = final_matches;
+      p->ani_block[k] = block;
+      if (!sn.has[q]) {  // genome_sizes.entry(key).or_insert(len): query first, then target
+        sn.has[q] = 1;
+        sn.len[q] = ql;
+      }
+      if (!sn.has[tg]) {
+        sn.has[tg] = 1;
+        sn.len[tg] = tl;
+      }
+    }
+  });
+  double total = 0.0;
+  for (size_t sq = 0; sq < n_seq; ++sq)
+    for (int t = 0; t < threads; ++t)
+      if (seen[t].has[sq]) {
+        total += (double)seen[t].len[sq];
+        break;
+      }
+  p->ani.n = n;
+  p->ani.eligible = p->ani_eligible.data();
+  p->ani.pair = p->ani_pair.data();
+  p->ani.n_pairs = G * G;
+  p->ani.matches = p->ani_matches.data();
+  p->ani.block_len = p->ani_block.data();
+  p->ani.total_genome_size = total;
+  p->have_ani = true;
+  *out = p->ani;
+  return SWG_OK;
+}
+
+int swg_paf_ani_stats(swg_ctx* ctx, swg_paf* p, int kind, double percentile, int sort, int threads, double* ani50) {
+  if (!ctx || !p || !ani50) return paf_error(SWG_ERR_INVALID, "swg_paf_ani_stats: NULL argument");
+  swg_ani_input in;
+  int rc = swg_paf_ani_input(p, threads, &in);
+  if (rc != SWG_OK) return rc;
+  std::vector<uint8_t> status;
+  const uint8_t* select = nullptr;
+  if (kind == SWG_ANI_ORTHOGONAL) {  // main.rs:343-382: the fixed 1:1 filter, then the ALL pass over its survivors
+    swg_config c{};
+    c.min_block_length = 1000;
+    c.mapping_filter_mode = SWG_MODE_ONE_TO_ONE;
+    c.mapping_max_per_query = 1;
+    c.mapping_max_per_target = 1;
+    c.scaffold_filter_mode = SWG_MODE_ONE_TO_ONE;
+    c.scaffold_max_per_query = 1;
+    c.scaffold_max_per_target = 1;
+    c.overlap_threshold = 0.95;
+    c.scaffold_gap = 10000;
+    c.min_scaffold_length = 0;
+    c.scaffold_overlap_threshold = 0.95;
+    c.scaffold_max_deviation = 0;
+    c.scoring_function = SWG_SCORE_MATCHES;
+    const uint64_t n = p->rec.n;
+    status.assign(n ? n : 1, 0);
+    std::vector<uint32_t> chain(n ? n : 1, 0);
+    if (n) rc = swg_filter(ctx, &p->rec, &c, status.data(), chain.data(), nullptr);
+    if (rc != SWG_OK) return paf_error(rc, "%s", swg_last_error(ctx));
+    select = status.data();
+  }
+  rc = swg_ani_median(ctx, &in, select, kind, percentile, sort, ani50);
+  if (rc != SWG_OK) return paf_error(rc, "%s", swg_last_error(ctx));
+  return SWG_OK;
+}
+
+// parse_ani_method, src/main.rs:296-330
+int swg_parse_ani_method(const char* s, int* kind, double* percentile, int* sort) {
+  if (!s || !kind || !percentile || !sort) return 0;
+  std::string lower(s);
+  for (auto& c : lower)
+    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+  if (lower == "all") {
+    *kind = SWG_ANI_ALL;
+    return 1;
+  }
+  if (lower == "orthogonal" || lower == "1:1") {
+    *kind = SWG_ANI_ORTHOGONAL;
+    return 1;
+  }
+  if (lower.empty() || lower[0] != 'n') return 0;
+  const std::string rest = lower.substr(1);
+  const size_t d1 = rest.find('-');
+  const std::string num = rest.substr(0, d1);
+  double pct;
+  if (!parse_f64(num.data(), num.size(), &pct) || !(pct > 0.0 && pct <= 100.0)) return 0;
+  int so = SWG_NSORT_IDENTITY;
+  if (d1 != std::string::npos) {
+    const size_t d2 = rest.find('-', d1 + 1);
+    const std::string part = rest.substr(d1 + 1, d2 == std::string::npos ? std::string::npos : d2 - d1 - 1);
+    if (part == "length") so = SWG_NSORT_LENGTH;
+    else if (part == "identity") so = SWG_NSORT_IDENTITY;
+    else if (part == "score") so = SWG_NSORT_SCORE;
+    else return 0;
+  }
+  *kind = SWG_ANI_NPERCENTILE;
+  *percentile = pct;
+  *sort = so;
+  return 1;
+}
+
+// parse_identity_value, src/cli.rs:76-130
+int swg_parse_identity_value(const char* s, double ani_percentile, double* out) {
+  if (!s || !out) return paf_error(SWG_ERR_INVALID, "swg_parse_identity_value: NULL argument");
+  const std::string value(s);
+  std::string lower = value;
+  for (auto& c : lower)
+    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+  if (lower.rfind("ani", 0) == 0) {
+    if (ani_percentile < 0.0) return paf_error(SWG_ERR_INVALID, "Cannot use ANI-based threshold without input alignments");
+    const std::string rem = lower.substr(3);
+    const size_t plus = rem.find('+');
+    const size_t cut = plus != std::string::npos ? plus : rem.find('-');
+    if (rem.empty() || cut == std::string::npos) {  // the percentile number itself is ignored: only the median is honoured
+      *out = ani_percentile;
+      return SWG_OK;
+    }
+    const std::string off = rem.substr(cut + 1);
+    double offset;
+    if (!parse_f64(off.data(), off.size(), &offset)) return paf_error(SWG_ERR_INVALID, "Invalid ANI offset: %s", off.c_str());
+    if (rem[cut] == '+') {
+      const double v = ani_percentile + offset / 100.0;
+      *out = v < 1.0 ? v : 1.0;
+    } else {
+      const double v = ani_percentile - offset / 100.0;
+      *out = v > 0.0 ? v : 0.0;
+    }
+    return SWG_OK;
+  }
+  double v;
+  if (!parse_f64(value.data(), value.size(), &v)) return paf_error(SWG_ERR_INVALID, "Invalid identity value: %s", s);
+  *out = v > 1.0 ? v / 100.0 : v;
   return SWG_OK;
 }
 

@@ -82,16 +82,6 @@ bool parse_metric_number(const std::string& s, uint64_t* out) {  // cli.rs:26-61
   *out = !(r > 0.0) ? 0 : (r >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)r);
   return true;
 }
-bool parse_identity_value(const std::string& s, double* out) {  // cli.rs:76-130, numeric forms
-  std::string lower = s;
-  for (auto& c : lower)
-    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
-  if (lower.rfind("ani", 0) == 0) return false;  // needs the ANI pre-pass (main.rs:334-688), out of scope
-  double v;
-  if (!parse_f64(s, &v)) return false;
-  *out = v > 1.0 ? v / 100.0 : v;
-  return true;
-}
 int parse_scoring(const std::string& s) {  // main.rs:3485-3492
   if (s == "ani" || s == "identity") return SWG_SCORE_IDENTITY;
   if (s == "length") return SWG_SCORE_LENGTH;
@@ -141,7 +131,7 @@ bool parse_filter_mode(const std::string& mode, int32_t* fmode, uint64_t* pq, ui
 int main(int argc, char** argv) {
   std::string input, output_file;
   std::string num_mappings = "many:many", scoring = "log-length-ani", min_identity = "0";
-  std::string scaffold_filter = "many:many", min_scaffold_identity = "0";
+  std::string scaffold_filter = "many:many", min_scaffold_identity = "0", ani_method_s = "n100";
   double overlap = 0.95, scaffold_overlap = 0.5;
   uint64_t scaffold_jump = 50000, scaffold_mass = 10000, scaffold_dist = 0, block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false, quiet = false;
@@ -174,6 +164,7 @@ int main(int argc, char** argv) {
     else if (a == "--scaffold-dist") { if (!parse_metric_number(value(), &scaffold_dist)) die(2, "bad --scaffold-dist"); }
     else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
     else if (a == "--scaffolds-only") scaffolds_only = true;
+    else if (a == "--ani-method") ani_method_s = value();
     else if (a == "--device") device = std::atoi(value().c_str());
     else if (a == "--quiet") quiet = true;
     else if (a == "--no-adaptive-scaffolds" || a == "--paf") { /* no effect for PAF input (main.rs:3515-3527) */ }
@@ -200,11 +191,23 @@ int main(int argc, char** argv) {
   cfg.min_scaffold_length = scaffold_mass;
   cfg.scaffold_overlap_threshold = scaffold_overlap;
   cfg.scaffold_max_deviation = scaffold_dist;
-  if (!parse_identity_value(min_identity, &cfg.min_identity)) die(2, "bad --min-aln-identity (aniN presets need the ANI pre-pass)");
-  if (min_scaffold_identity.empty()) cfg.min_scaffold_identity = cfg.min_identity;
-  else if (!parse_identity_value(min_scaffold_identity, &cfg.min_scaffold_identity)) die(2, "bad --min-scaffold-identity");
   cfg.keep_self = keep_self;
   cfg.scaffolds_only = scaffolds_only;
+  // identity thresholds: plain numbers are checked now, "aniN" forms after the ANI pre-pass (main.rs:3571-3595)
+  auto lower = [](std::string v) {
+    for (auto& c : v)
+      if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+    return v;
+  };
+  const bool need_ani = lower(min_identity).find("ani") != std::string::npos || lower(min_scaffold_identity).find("ani") != std::string::npos;
+  auto set_identities = [&](double ani_percentile) {
+    if (swg_parse_identity_value(min_identity.c_str(), ani_percentile, &cfg.min_identity) != SWG_OK)
+      die(2, std::string("bad --min-aln-identity: ") + swg_paf_last_error());
+    if (min_scaffold_identity.empty()) cfg.min_scaffold_identity = cfg.min_identity;
+    else if (swg_parse_identity_value(min_scaffold_identity.c_str(), ani_percentile, &cfg.min_scaffold_identity) != SWG_OK)
+      die(2, std::string("bad --min-scaffold-identity: ") + swg_paf_last_error());
+  };
+  if (!need_ani) set_identities(-1.0);
 
   // ---- open_paf_input + extract_metadata (paf_filter.rs:292-376), multi-threaded in libsweepga_gpu.so
   using clk = std::chrono::steady_clock;
@@ -235,18 +238,36 @@ int main(int argc, char** argv) {
   }
   const auto t1 = clk::now();
 
+  // ---- ANI pre-pass over the input when a threshold asks for it
+  swg_ctx* ctx = nullptr;
+  if (n || need_ani) {
+    if (swg_create(device, &ctx) != SWG_OK) die(3, std::string("no usable GPU: ") + swg_last_error(nullptr));
+  }
+  double ani_percentile = -1.0, ani_ms = 0.0;
+  if (need_ani) {
+    int kind = SWG_ANI_NPERCENTILE, nsort = SWG_NSORT_IDENTITY;
+    double pct = 50.0;
+    if (!swg_parse_ani_method(ani_method_s.c_str(), &kind, &pct, &nsort)) {  // unknown method: n50-identity
+      kind = SWG_ANI_NPERCENTILE;
+      pct = 50.0;
+      nsort = SWG_NSORT_IDENTITY;
+    }
+    const auto ta = clk::now();
+    if (swg_paf_ani_stats(ctx, paf, kind, pct, nsort, threads, &ani_percentile) != SWG_OK) die(3, std::string("ANI pre-pass failed: ") + swg_paf_last_error());
+    ani_ms = std::chrono::duration<double, std::milli>(clk::now() - ta).count();
+  }
+  if (need_ani) set_identities(ani_percentile);
+  if (need_ani && !quiet) std::fprintf(stderr, "[sweepga-gpu] ANI pre-pass (%s): median %.6f in %.1f ms\n", ani_method_s.c_str(), ani_percentile, ani_ms);
+
   // ---- apply_filters on the GPU
   std::vector<uint8_t> status(n ? n : 1, 0);
   std::vector<uint32_t> chain(n ? n : 1, 0);
   swg_stats st{};
   if (n) {
-    swg_ctx* ctx = nullptr;
-    int rc = swg_create(device, &ctx);
-    if (rc != SWG_OK) die(3, std::string("no usable GPU: ") + swg_last_error(nullptr));
-    rc = swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
+    int rc = swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
     if (rc != SWG_OK) die(3, std::string("filter failed: ") + swg_last_error(ctx));
-    swg_destroy(ctx);
   }
+  if (ctx) swg_destroy(ctx);
   const auto t2 = clk::now();
 
   // ---- write_filtered_output (paf_filter.rs:1689-1726): input order, original bytes + tags

@@ -126,6 +126,7 @@ struct swg_flag_scan {
 int swg_flags_count(swg_ctx* ctx, const uint8_t* flags, uint64_t n, swg_flag_scan* fs, uint64_t* d_total);
 int swg_flags_compact(swg_ctx* ctx, const swg_flag_scan& fs, uint32_t* list);
 int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n);
+int swg_inclusive_sum_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n);
 // Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key.
 // *keys / *vals hold the input; the *_alt buffers are scratch of the same size.  Passes ping-pong
 // between the two pairs of buffers and the POINTERS are swapped so that on return *keys / *vals

@@ -269,6 +269,10 @@ int swg_inclusive_max_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, 
   return scan_impl<1, true, uint64_t>(ctx, in, out, n, nullptr);
 }
 
+int swg_inclusive_sum_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n) {
+  return scan_impl<0, true, uint64_t>(ctx, in, out, n, nullptr);
+}
+
 int swg_flags_count(swg_ctx* ctx, const uint8_t* flags, uint64_t n, swg_flag_scan* fs, uint64_t* d_total) {
   fs->flags = flags;
   fs->n = n;

@@ -285,9 +285,32 @@ def parse_metric_number(s):
     return o.value if lib().orc_parse_metric_number(s.encode(), C.byref(o)) else None
 
 
-def parse_identity_value(s):
+def parse_identity_value(s, ani_percentile=None):
     o = C.c_double()
-    return o.value if lib().orc_parse_identity_value(s.encode(), C.byref(o)) else None
+    if ani_percentile is None:
+        return o.value if lib().orc_parse_identity_value(s.encode(), C.byref(o)) else None
+    return o.value if lib().orc_parse_identity_value_ani(s.encode(), C.c_double(ani_percentile), C.byref(o)) else None
+
+
+ANI_ALL, ANI_ORTHOGONAL, ANI_NPERCENTILE = range(3)
+NSORT_LENGTH, NSORT_IDENTITY, NSORT_SCORE = range(3)
+
+
+def parse_ani_method(s):
+    """main.rs:296-330 -> (kind, percentile, sort) or None"""
+    k, p, so = C.c_int(), C.c_double(), C.c_int()
+    if not lib().orc_parse_ani_method(s.encode(), C.byref(k), C.byref(p), C.byref(so)):
+        return None
+    return k.value, p.value, so.value
+
+
+def calculate_ani_stats(path, kind, percentile=50.0, sort=NSORT_IDENTITY):
+    """main.rs:334-688 -> median per-genome-pair ANI"""
+    o = C.c_double()
+    r = lib().orc_calculate_ani_stats(str(path).encode(), C.c_int(kind), C.c_double(percentile), C.c_int(sort), C.byref(o))
+    if r != 0:
+        raise RuntimeError("oracle calculate_ani_stats failed")
+    return o.value
 
 
 def clamp_scaffold_params(jump, mass, avg, adaptive):

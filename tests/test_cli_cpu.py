@@ -27,7 +27,9 @@ def test_help_and_flag_errors(cli, tmp_path):
     r = subprocess.run([cli, str(p), "--num-mappings", "0"], capture_output=True, text=True)
     assert r.returncode == 1  # the reference exits(1) on a bare 0 (main.rs:281-288)
     r = subprocess.run([cli, str(p), "--min-aln-identity", "ani50"], capture_output=True, text=True)
-    assert r.returncode == 2
+    assert r.returncode == 3 and "no usable GPU" in r.stderr  # the ANI pre-pass runs on the device
+    r = subprocess.run([cli, str(p), "--min-aln-identity", "ninety"], capture_output=True, text=True)
+    assert r.returncode == 2 and "Invalid identity value" in r.stderr
 
 
 def test_no_filter_copies_input(cli, tmp_path):  # main.rs:3461-3470
