@@ -195,6 +195,16 @@ int swg_profile_count(swg_ctx* ctx);
 /* Entry i: name (owned by ctx, valid until the next reset), launches, summed milliseconds. */
 int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
 
+/* ---- several devices of one node ---------------------------------------------------------------
+ * swg_filter over n_ctx contexts (one per device, created by the caller): records are partitioned by genome pair
+ * (first-two-'#'-parts prefix), pairs are bin-packed onto the contexts by mapping count, every context filters its
+ * part on its own host thread, and chain numbers are made global again on the host (the reference numbers kept
+ * chains genome pair by genome pair in first-appearance order, src/paf_filter.rs:517-521).  No collective.  Falls
+ * back to ctxs[0] alone when the two genome-prefix rules of the reference partition the sequences differently.
+ * Results are identical to swg_filter(ctxs[0], ...).  Errors are reported on ctxs[0]. */
+int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_records* records, const swg_config* cfg, uint8_t* status_out,
+                     uint32_t* chain_out, swg_stats* stats);
+
 /* ---- PAF ingest / egress (host side; no GPU needed for open/write) ----------------------------------------
  * The reference reads the PAF twice (extract_metadata, then write_filtered_output re-reads it).  A swg_paf
  * handle keeps the mapped text, the SoA columns swg_filter() takes and each record's (offset,length), so the

@@ -19,7 +19,8 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
-           "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats"]
+           "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
+           "swg_filter_multi"]
 
 
 class SwgError(RuntimeError):
@@ -190,6 +191,9 @@ def load():
     lib.swg_ani_median.restype = C.c_int
     lib.swg_ani_median.argtypes = [C.c_void_p, C.POINTER(SwgAniInput), C.c_void_p, C.c_int, C.c_double, C.c_int,
                                    C.POINTER(C.c_double)]
+    lib.swg_filter_multi.restype = C.c_int
+    lib.swg_filter_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p,
+                                     C.c_void_p, C.POINTER(SwgStats)]
     lib.swg_paf_ani_stats.restype = C.c_int
     lib.swg_paf_ani_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _lib = lib

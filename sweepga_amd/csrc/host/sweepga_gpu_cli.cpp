@@ -136,6 +136,7 @@ int main(int argc, char** argv) {
   uint64_t scaffold_jump = 50000, scaffold_mass = 10000, scaffold_dist = 0, block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false, quiet = false;
   int device = 0, threads = 0;
+  std::vector<int> devices;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], val;
     const size_t eq = a.find('=');
@@ -166,6 +167,17 @@ int main(int argc, char** argv) {
     else if (a == "--scaffolds-only") scaffolds_only = true;
     else if (a == "--ani-method") ani_method_s = value();
     else if (a == "--device") device = std::atoi(value().c_str());
+    else if (a == "--devices") {  // comma-separated: shard the genome pairs over several GPUs of the node
+      const std::string v = value();
+      for (size_t s0 = 0; s0 <= v.size();) {
+        const size_t c = v.find(',', s0);
+        const std::string tok = v.substr(s0, c == std::string::npos ? std::string::npos : c - s0);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) die(2, "bad --devices");
+        devices.push_back(std::atoi(tok.c_str()));
+        if (c == std::string::npos) break;
+        s0 = c + 1;
+      }
+    }
     else if (a == "--quiet") quiet = true;
     else if (a == "--no-adaptive-scaffolds" || a == "--paf") { /* no effect for PAF input (main.rs:3515-3527) */ }
     else if (a == "--threads" || a == "-t") threads = std::atoi(value().c_str());
@@ -173,7 +185,8 @@ int main(int argc, char** argv) {
       std::puts("usage: sweepga-gpu <in.paf> [--output-file out.paf] [--num-mappings M] [--overlap F] [--scoring S]\n"
                 "         [--min-aln-identity I] [--min-aln-length N] [--self] [--no-filter] [--scaffold-jump N]\n"
                 "         [--scaffold-mass N] [--scaffold-filter M] [--scaffold-overlap F] [--scaffold-dist N]\n"
-                "         [--min-scaffold-identity I] [--scaffolds-only] [--device D] [--quiet]\n"
+                "         [--min-scaffold-identity I] [--scaffolds-only] [--ani-method M]\n"
+                "         [--device D | --devices D0,D1,...] [--threads T] [--quiet]\n"
                 "Filter path of pangenome/sweepga on an MI355X (libsweepga_gpu.so).  No CPU fallback.");
       return 0;
     } else if (a.rfind("-", 0) == 0 && a != "-") die(2, "unknown flag " + a);
@@ -239,10 +252,15 @@ int main(int argc, char** argv) {
   const auto t1 = clk::now();
 
   // ---- ANI pre-pass over the input when a threshold asks for it
-  swg_ctx* ctx = nullptr;
-  if (n || need_ani) {
-    if (swg_create(device, &ctx) != SWG_OK) die(3, std::string("no usable GPU: ") + swg_last_error(nullptr));
-  }
+  if (devices.empty()) devices.push_back(device);
+  std::vector<swg_ctx*> ctxs;
+  if (n || need_ani)
+    for (int d : devices) {
+      swg_ctx* c = nullptr;
+      if (swg_create(d, &c) != SWG_OK) die(3, std::string("no usable GPU: ") + swg_last_error(nullptr));
+      ctxs.push_back(c);
+    }
+  swg_ctx* ctx = ctxs.empty() ? nullptr : ctxs[0];
   double ani_percentile = -1.0, ani_ms = 0.0;
   if (need_ani) {
     int kind = SWG_ANI_NPERCENTILE, nsort = SWG_NSORT_IDENTITY;
@@ -264,10 +282,11 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> chain(n ? n : 1, 0);
   swg_stats st{};
   if (n) {
-    int rc = swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
+    const int rc = ctxs.size() > 1 ? swg_filter_multi(ctxs.data(), (int)ctxs.size(), r, &cfg, status.data(), chain.data(), &st)
+                                   : swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
     if (rc != SWG_OK) die(3, std::string("filter failed: ") + swg_last_error(ctx));
   }
-  if (ctx) swg_destroy(ctx);
+  for (swg_ctx* c : ctxs) swg_destroy(c);
   const auto t2 = clk::now();
 
   // ---- write_filtered_output (paf_filter.rs:1689-1726): input order, original bytes + tags

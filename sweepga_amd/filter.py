@@ -379,6 +379,21 @@ class PafFilter:
         self.last_stats = stats
         return status[:n], chain[:n]
 
+    def filter_columns_multi(self, packed: PackedRecords, contexts):
+        """The same over several contexts (one per GPU of the node): swg_filter_multi shards the genome pairs over
+        them and makes the chain numbers global again; results are identical to filter_columns."""
+        n = packed.n
+        status = np.zeros(max(n, 1), dtype=np.uint8)
+        chain = np.zeros(max(n, 1), dtype=np.uint32)
+        stats = SwgStats()
+        rec = packed.to_c()
+        cfg = self.config.to_c(self.keep_self, self.scaffolds_only)
+        handles = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+        contexts[0].check(contexts[0].lib.swg_filter_multi(handles, len(contexts), C.byref(rec), C.byref(cfg), _ptr(status),
+                                                           _ptr(chain), C.byref(stats)))
+        self.last_stats = stats
+        return status[:n], chain[:n]
+
     def apply_filters(self, metadata: List[RecordMeta]):
         """src/paf_filter.rs:379-747 -> {rank: RecordMeta} with chain_id / chain_status set."""
         packed = pack_records(metadata)
