@@ -62,7 +62,7 @@ void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, ui
 
 // ---- mapping-level sweep ----------------------------------------------------------------------
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
-                      const uint64_t* score_key, int pos_bits, uint8_t* keep) {
+                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep) {
   const uint64_t n = r->n;
   uint64_t kq, kt;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
@@ -77,17 +77,20 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   ax.seg_mul = r->n_genome_last;
   ax.seg_table = r->seq_genome_last;
   ax.pos_bits = pos_bits;
-  ax.score_key = score_key;
+  ax.score_key = nullptr;
+  ax.packed = key_ends;
   ax.alive = alive;
   ax.seg_a = r->q_id;
   ax.seg_b = r->t_id;
   ax.start = r->q_start;
   ax.end = r->q_end;
+  ax.packed_end = 0;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
   ax.seg_a = r->t_id;
   ax.seg_b = r->q_id;
   ax.start = r->t_start;
   ax.end = r->t_end;
+  ax.packed_end = 1;
   ax.and_with = keep_q;  // intersection of the two axes, src/paf_filter.rs:1105-1111
   SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep));
   swg_arena_restore(ctx, mark);
@@ -106,17 +109,17 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   if (n == 0) return SWG_OK;
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
-  uint64_t* score_key = swg_alloc<uint64_t>(ctx, n);
+  swg_key_ends* key_ends = swg_alloc<swg_key_ends>(ctx, n);
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
-  SWG_TRY(swg_prepare(ctx, r, cfg, alive, score_key, scalars));
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, scalars));
   uint64_t h[2];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 2));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
   if (stats) stats->n_retained = h[1];
 
-  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, score_key, pos_bits, keep1));
+  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
     SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out));
@@ -130,7 +133,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, score_key, pos_bits, status_out, chain_out, stats);
+  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats);
 }
 
 static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {

@@ -153,6 +153,13 @@ static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represen
 //   k         mappings_to_keep (SWG_K_INF = unbounded), thr = overlap threshold
 // Output keep[i] = 1 iff interval i is returned by plane_sweep_query/target on its segment
 // (src/plane_sweep_exact.rs:268-433); keep[i] = 0 for !alive.
+// Score key and both end coordinates of a record in one 16-byte slot: the sweep's post-sort gather then costs one
+// random sector per begin instead of two.
+struct __attribute__((aligned(16))) swg_key_ends {
+  uint64_t key;
+  uint32_t end[2];  // [0] query end, [1] target end
+};
+
 struct swg_axis_input {
   uint64_t n;
   const uint64_t* seg = nullptr;  // [n] explicit segment ids, or nullptr: computed on the fly as
@@ -168,6 +175,8 @@ struct swg_axis_input {
   const uint64_t* score_key; // [n]
   const uint8_t* alive;      // [n] or nullptr
   const uint8_t* and_with = nullptr;  // optional: keep[i] &= and_with[i] (intersection with another axis' result)
+  const swg_key_ends* packed = nullptr;  // optional: replaces score_key / end in the post-sort gather
+  int packed_end = 0;                    //   which end of `packed` is this axis' end
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
 
@@ -177,5 +186,5 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
                    const double* identity, int scoring, uint64_t* key_out);
 // Step-1 retain (src/paf_filter.rs:384-388), score keys and the two scalars the pipeline needs, in one pass over
 // the records: scalars[0] = max coordinate, scalars[1] = number of retained records (device u64, pre-zeroed).
-int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, uint64_t* score_key,
+int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends,
                 unsigned long long* scalars);

@@ -1827,9 +1827,8 @@ __global__ __launch_bounds__(EW) void count_status_kernel(uint64_t n, const uint
 }  // namespace
 
 int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
-                       const uint8_t* keep1, const uint64_t* score_key, int pos_bits, uint8_t* status_out,
+                       const uint8_t* keep1, int pos_bits, uint8_t* status_out,
                        uint32_t* chain_out, swg_stats* stats) {
-  (void)score_key;
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
                                                              uint64_t min_block, int keep_self, double min_identity,
                                                              int scoring, uint8_t* __restrict__ alive,
-                                                             uint64_t* __restrict__ key,
+                                                             swg_key_ends* __restrict__ key_ends,
                                                              unsigned long long* __restrict__ scalars) {
   uint32_t mx = 0, cnt = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
     const bool ok = (uint64_t)block_len[i] >= min_block && (keep_self || q_id[i] != t_id[i]) && id >= min_identity;
     alive[i] = ok ? 1 : 0;
-    key[i] = score_key_of(a, b, id, scoring);
+    swg_key_ends ke;
+    ke.key = score_key_of(a, b, id, scoring);
+    ke.end[0] = b;
+    ke.end[1] = d;
+    key_ends[i] = ke;
     const uint32_t m1 = a > b ? a : b, m2 = c > d ? c : d;
     const uint32_t m = m1 > m2 ? m1 : m2;
     if (m > mx) mx = m;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
                                                                   const uint32_t* __restrict__ I,
                                                                   const uint32_t* __restrict__ end,
                                                                   const uint64_t* __restrict__ score_key,
+                                                                  const swg_key_ends* __restrict__ packed, int packed_end,
                                                                   int pos_bits, uint64_t* __restrict__ E,
                                                                   uint64_t* __restrict__ KEY,
                                                                   uint64_t* __restrict__ tile_x,
@@ -167,8 +172,14 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
   if (s != 0) {
     const uint32_t id = I[p];
     const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
-    e = (s & ~posmask) | end[id];
-    k = score_key[id];
+    if (packed) {
+      const swg_key_ends ke = packed[id];
+      e = (s & ~posmask) | ke.end[packed_end];
+      k = ke.key;
+    } else {
+      e = (s & ~posmask) | end[id];
+      k = score_key[id];
+    }
     const uint64_t sg = s >> pos_bits;
     const bool prev_same = p > 0 && (S[p - 1] >> pos_bits) == sg;
     const bool next_same = p + 1 < n && (S[p + 1] >> pos_bits) == sg;
@@ -543,12 +554,12 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
   return SWG_OK;
 }
 
-int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, uint64_t* score_key,
+int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends,
                 unsigned long long* scalars) {
   if (r->n == 0) return SWG_OK;
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
                                  r->n, r->q_id, r->t_id, r->block_len, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
-                                 cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, score_key,
+                                 cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
                                  scalars));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
@@ -587,7 +598,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     E = S2;  // the sort's scratch key buffer is free again
     SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
     SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                        n, S, I, in.end, in.score_key, in.pos_bits, E, KEY, tile_x, single));
+                                        n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_x, single));
     SWG_KERNEL_CHECK(ctx);
     return SWG_OK;
   };
