@@ -8,6 +8,8 @@
 //      its final slot.  Stability is what makes the multi-word sorts of the pipeline compose and
 //      is what carries the reference's "ties fall to input order" rule (sort_by_key is stable,
 //      src/plane_sweep_exact.rs:300, src/paf_filter.rs:777).
+#include <cstdlib>
+
 #include "swg_internal.h"
 
 namespace {
@@ -620,7 +622,10 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
   if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
   const int npasses = (end_bit - begin_bit + 7) / 8;
-  if (n >= (uint64_t(1) << 30) || npasses > OS_MAX_PASSES)
+  // SWG_SORT_FALLBACK=1 forces the histogram/scan/scatter path (otherwise only reached for n >= 2^30) so that the
+  // tests can exercise it at small sizes
+  static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
+  if (force_fallback || n >= (uint64_t(1) << 30) || npasses > OS_MAX_PASSES)
     return radix_sort_three_kernel(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit);
   const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
