@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC runs (FETCH_SIZE and WRITE_SIZE collected in SEPARATE passes,
+as /opt/skills/guides/MI355X_MICROARCH.md prescribes) -> the JSON bench.py reads for `roofline.traffic`.
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --others 0
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --others 0
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write 100000000 > profiles/rNN_vMM_hbm_traffic_sweep_100m.json
+
+Both counters are in KB per dispatch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (the gfx950 FETCH_SIZE x2
+correction, calibrated on os_pass which reads exactly 12 B per pair)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short_name(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([A-Za-z0-9_:]+)(<[^(]*>)?", n)
+    base, targs = (m.group(1), m.group(2) or "") if m else (n, "")
+    base = base.split("::")[-1]
+    if base.endswith("_kernel"):
+        base = base[:-7]
+    if base == "sweep_tile":
+        base += "_k1" if "true" in targs else "_kn"
+    return base
+
+
+def collect(d, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            a = acc[short_name(row["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        f = fe[k][1] / fe[k][0] if fe[k][0] else 0.0
+        w = wr[k][1] / wr[k][0] if wr[k][0] else 0.0
+        kernels[k] = {"launches_profiled": max(fe[k][0], wr[k][0]), "fetch_size_kb_per_launch": f,
+                      "write_size_kb_per_launch": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
