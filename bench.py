@@ -146,6 +146,32 @@ def cpu_baseline_all_cores(cols, sizes, cfg, n_names, first_group, per_thread=15
                 sample=f"{len(jobs)} threads x ~{per_thread} mappings (whole groups), all started together, wall {wall:.2f} s")
 
 
+def full_parity(cols, sizes, cfg, n_names, status_dev, chain_dev, target, max_threads=64, groups_per_job=25):
+    """Parity beyond the single-thread sample: the oracle over whole genome-pair groups on all host threads (groups
+    are independent units of the filter), compared record by record with the device results of the timed workload."""
+    import numpy as np
+    from tests import orc
+    T = max(1, min(os.cpu_count() or 1, max_threads))
+    csum = np.concatenate([[0], sizes.cumsum(0).cpu().numpy()]).astype(np.int64)
+    g_hi = int(np.searchsorted(csum, min(int(target), int(csum[-1])), side="left"))
+    g_hi = max(1, min(g_hi, len(csum) - 1))
+    bounds = np.unique(np.concatenate([csum[0:g_hi:groups_per_job], [csum[g_hi]]]))
+    m = int(bounds[-1])
+    h = {k: np.ascontiguousarray(cols[k][:m].cpu().numpy()) for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end",
+                                                                       "identity", "matches", "block_len", "strand")}
+    names = [f"g{i:03d}#1#chr1" for i in range(n_names)]
+    ost, och, wall = orc.apply_filters_by_groups(_oracle_config(cfg), h, names, bounds, T)
+    gst = status_dev[:m].cpu().numpy()
+    status_equal = bool(np.array_equal(gst, ost))
+    chain_equal = None
+    if cfg.scaffold_gap:
+        job = np.searchsorted(bounds, np.arange(m), side="right").astype(np.int64)
+        lab = np.where(och != 0, (job << 32) | och.astype(np.int64), 0)
+        chain_equal = bool(orc.same_chain_partition(chain_dev[:m].cpu().numpy(), lab))
+    return {"mappings_checked": m, "groups_checked": g_hi, "status_equal": status_equal, "chain_partition_equal": chain_equal,
+            "oracle_threads": T, "oracle_wall_s": wall, "oracle_value": m / wall, "unit": "mappings/s"}
+
+
 def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev, n_names):
     """The CPU oracle (port of the reference, 1 thread like the reference's filter) timed on a bounded
     sample: the first whole genome-pair groups of this rank's shard.  Also the parity check."""
@@ -238,6 +264,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--others", type=int, default=2, help="timed steps for the other two flag sets (0 = skip them)")
     ap.add_argument("--pcie", action="store_true", help="also time swg_filter (host buffers in/out, PCIe included)")
+    ap.add_argument("--parity-mappings", type=int, default=-1,
+                    help="mappings of the timed workload checked against the oracle on all host threads "
+                         "(-1 = auto: 2M (sweep) / 0.5M (scaffold pipelines) per host thread, up to the whole shard; 0 = skip)")
     ap.add_argument("--e2e", type=int, default=0, help="lines of synthetic PAF for the file->file leg (0 = skip)")
     ap.add_argument("--e2e-ref", type=int, default=1_000_000, help="prefix of that file the oracle CLI is timed on")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the e2e leg (0 = all cores)")
@@ -374,6 +403,13 @@ def main():
         if args.cpu_sample > 0:
             cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main, args.genomes)
             cpu_mt = cpu_baseline_all_cores(cols, sizes, cfg, args.genomes, 0)
+        parity_full = None
+        pm = args.parity_mappings
+        if pm < 0:
+            per_thread = 2_000_000 if args.pipeline == "sweep" else 500_000  # ~10 s of oracle time either way
+            pm = min(n, per_thread * min(os.cpu_count() or 1, 64)) if args.cpu_sample > 0 else 0
+        if pm > 0:
+            parity_full = full_parity(cols, sizes, cfg, args.genomes, status_main, chain_main, pm)
         out = {
             "metric": "PAF mappings/sec through plane-sweep+scaffold filter",
             "value": n * world / (elapsed / args.steps),
@@ -403,6 +439,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_mt,
             "parity_vs_oracle_on_sample": parity,
+            "parity_all_threads": parity_full,
             "counts": main_counts,
             "other_pipelines": others,
             "pcie_inclusive": pcie,

@@ -177,6 +177,54 @@ int64_t orc_apply_filters(const orc_config* cfg, uint64_t n, const uint64_t* ran
   }
 }
 
+// The same over SoA columns with integer sequence ids (u32 coordinates, strand 0 = '+'), the layout the device
+// library takes: lets the checker run on millions of records without a Python string per record.  The records
+// are [lo, hi) of the columns; rank = index - lo.
+int64_t orc_apply_filters_ids(const orc_config* cfg, uint64_t lo, uint64_t hi, const uint32_t* q_id, const uint32_t* t_id,
+                              const char* const* names, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts,
+                              const uint32_t* te, const uint32_t* block_length, const double* identity,
+                              const uint32_t* matches, const uint8_t* strand, uint8_t* status_out, uint32_t* chain_out,
+                              double* seconds_out) {
+  try {
+    const uint64_t n = hi - lo;
+    std::vector<RecordMeta> md(n);
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint64_t i = lo + k;
+      RecordMeta& m = md[k];
+      m.rank = k;
+      m.query_name = names[q_id[i]];
+      m.target_name = names[t_id[i]];
+      m.query_start = qs[i];
+      m.query_end = qe[i];
+      m.target_start = ts[i];
+      m.target_end = te[i];
+      m.block_length = block_length[i];
+      m.identity = identity[i];
+      m.matches = matches[i];
+      m.alignment_length = block_length[i];
+      m.strand = strand[i] ? '-' : '+';
+    }
+    PafFilter f(to_cfg(cfg));
+    auto t0 = std::chrono::steady_clock::now();
+    auto passing = f.apply_filters(std::move(md));
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(t1 - t0).count();
+    for (uint64_t k = 0; k < n; ++k) {
+      auto it = passing.find(k);
+      if (it == passing.end()) {
+        status_out[k] = 0;
+        chain_out[k] = 0;
+      } else {
+        status_out[k] = (uint8_t)it->second.chain_status;
+        chain_out[k] = it->second.has_chain_id ? (uint32_t)std::stoul(it->second.chain_id.substr(6)) : 0u;
+      }
+    }
+    return (int64_t)passing.size();
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 // merge_mappings_into_chains on the given records (no retain, no sweep).  chain_of[i] = index
 // of record i's chain in all_chains order.  Per-chain outputs are sized n.  Returns #chains.
 int64_t orc_merge_chains(uint64_t n, const char* const* qnames, const char* const* tnames,

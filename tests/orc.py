@@ -253,6 +253,74 @@ def apply_filters(cfg: Config, rec: Records, want_seconds=False, barrier=None):
     return status[:n], chain[:n]
 
 
+def apply_filters_ids(cfg: Config, cols, names, lo, hi, status_out, chain_out):
+    """apply_filters over rows [lo, hi) of SoA columns with integer sequence ids (numpy arrays: q_id, t_id, q_start,
+    q_end, t_start, t_end, matches, block_len as uint32, identity float64, strand uint8 with 0 = '+').
+    Writes status_out[lo:hi] / chain_out[lo:hi]; returns the C-side seconds.  Releases the GIL while running."""
+    cc = cfg.c()
+    arr = (C.c_char_p * len(names))()
+    arr[:] = [n.encode() for n in names]
+    secs = C.c_double(0.0)
+    st = status_out[lo:hi]
+    ch = chain_out[lo:hi]
+    f = lib().orc_apply_filters_ids
+    f.restype = C.c_int64
+    r = f(C.byref(cc), C.c_uint64(lo), C.c_uint64(hi), _p(cols["q_id"]), _p(cols["t_id"]), arr, _p(cols["q_start"]),
+          _p(cols["q_end"]), _p(cols["t_start"]), _p(cols["t_end"]), _p(cols["block_len"]), _p(cols["identity"]),
+          _p(cols["matches"]), _p(cols["strand"]), _p(st), _p(ch), C.byref(secs))
+    assert r >= 0, "oracle apply_filters failed"
+    return secs.value
+
+
+def apply_filters_by_groups(cfg: Config, cols, names, bounds, threads):
+    """The oracle over consecutive row ranges bounds[j]..bounds[j+1] (each a union of whole genome-pair groups,
+    i.e. independent units of the filter), `threads` ranges at a time.  Returns (status, chain, wall seconds);
+    chain numbers are local to each range."""
+    import threading
+    import time
+    n = int(bounds[-1])
+    status = np.zeros(max(n, 1), dtype=np.uint8)
+    chain = np.zeros(max(n, 1), dtype=np.uint32)
+    jobs = list(zip(bounds[:-1], bounds[1:]))
+    lock = threading.Lock()
+    err = []
+
+    def worker():
+        while True:
+            with lock:
+                if not jobs:
+                    return
+                lo, hi = jobs.pop()
+            try:
+                apply_filters_ids(cfg, cols, names, int(lo), int(hi), status, chain)
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                return
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker) for _ in range(max(1, threads))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return status[:n], chain[:n], time.perf_counter() - t0
+
+
+def same_chain_partition(a, b):
+    """Chain ids are arbitrary labels: two labelings agree iff they induce the same partition (0 = no chain)."""
+    a = np.asarray(a, dtype=np.int64)
+    b = np.asarray(b, dtype=np.int64)
+    if not np.array_equal(a == 0, b == 0):
+        return False
+    m = a != 0
+    if not m.any():
+        return True
+    pairs = np.unique(np.stack([a[m], b[m]], axis=1), axis=0)
+    return len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+
+
 def merge_chains(rec: Records, max_gap):
     n = len(rec)
     chain_of = np.zeros(max(n, 1), dtype=np.uint32)
