@@ -336,6 +336,28 @@ uint32_t genome_table(const std::vector<std::string>& names, std::string (*fn)(s
   return g.empty() ? 1u : (uint32_t)g.size();
 }
 
+// Column storage without value-initialisation: the first touch of every page happens in the parsing threads
+// (a std::vector would zero-fill ~70 B per record on the calling thread before the parallel part starts).
+template <class T>
+struct Buf {
+  T* p = nullptr;
+  size_t n = 0;
+  Buf() = default;
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  ~Buf() { std::free(p); }
+  void alloc(size_t k) {
+    std::free(p);
+    p = static_cast<T*>(std::malloc((k ? k : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    n = k;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct Slice {
   size_t begin = 0, end = 0;     // byte range, whole lines
   uint64_t lines = 0, recs = 0;  // counted in pass 1
@@ -352,20 +374,20 @@ struct Slice {
 struct swg_paf {
   Text text;
   uint64_t n_lines = 0;
-  std::vector<uint32_t> q_id, t_id, qs, qe, ts, te, matches, block;
-  std::vector<double> identity;
-  std::vector<uint8_t> strand;
-  std::vector<uint64_t> rank, rec_off;
-  std::vector<uint32_t> rec_len;
+  Buf<uint32_t> q_id, t_id, qs, qe, ts, te, matches, block;
+  Buf<double> identity;
+  Buf<uint8_t> strand;
+  Buf<uint64_t> rank, rec_off;
+  Buf<uint32_t> rec_len;
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
   swg_records rec{};
   double load_ms = 0, parse_ms = 0;
   // ANI view (filled by swg_paf_ani_input)
   bool have_ani = false;
-  std::vector<uint8_t> ani_eligible;
-  std::vector<uint32_t> ani_pair;
-  std::vector<double> ani_matches, ani_block;
+  Buf<uint8_t> ani_eligible;
+  Buf<uint32_t> ani_pair;
+  Buf<double> ani_matches, ani_block;
   swg_ani_input ani{};
 };
 
@@ -434,11 +456,11 @@ int parse_text(swg_paf* p, int threads) {
   p->n_lines = n_lines;
   if (n >= (uint64_t(1) << 31)) return paf_error(SWG_ERR_RANGE, "more than 2^31-1 records");
   const size_t cap = n ? n : 1;
-  for (auto* v : {&p->q_id, &p->t_id, &p->qs, &p->qe, &p->ts, &p->te, &p->matches, &p->block, &p->rec_len}) v->resize(cap);
-  p->identity.resize(cap);
-  p->strand.resize(cap);
-  p->rank.resize(cap);
-  p->rec_off.resize(cap);
+  for (auto* v : {&p->q_id, &p->t_id, &p->qs, &p->qe, &p->ts, &p->te, &p->matches, &p->block, &p->rec_len}) v->alloc(cap);
+  p->identity.alloc(cap);
+  p->strand.alloc(cap);
+  p->rank.alloc(cap);
+  p->rec_off.alloc(cap);
 
   // pass 2: parse into the columns
   parallel_for(threads, [&](int t) {
@@ -698,6 +720,7 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   const uint64_t n = p->rec.n;
   if (n && !status) return paf_error(SWG_ERR_INVALID, "swg_paf_write: status is NULL");
   threads = pick_threads(threads);
+  if (threads > 16) threads = 16;  // concurrent pwrite()s into one file stop scaling (and then degrade) beyond this
   if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
   const bool to_stdout = !std::strcmp(out_path, "-");
   const int fd = to_stdout ? 1 : open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -774,10 +797,10 @@ int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out) {
   threads = pick_threads(threads);
   if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
   const size_t cap = n ? n : 1;
-  p->ani_eligible.assign(cap, 0);
-  p->ani_pair.assign(cap, 0);
-  p->ani_matches.assign(cap, 0.0);
-  p->ani_block.assign(cap, 0.0);
+  p->ani_eligible.alloc(cap);
+  p->ani_pair.alloc(cap);
+  p->ani_matches.alloc(cap);
+  p->ani_block.alloc(cap);
   const size_t n_seq = p->names.size();
   // first-seen sequence length per thread range: (record index of first sighting, length)
   struct Seen {
@@ -796,6 +819,10 @@ int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out) {
       const char* b = text + p->rec_off[k];
       const char* e = b + p->rec_len[k];
       const uint32_t q = p->q_id[k], tg = p->t_id[k];
+      p->ani_eligible[k] = 0;
+      p->ani_pair[k] = 0;
+      p->ani_matches[k] = 0.0;
+      p->ani_block[k] = 0.0;
       if (b == e || *b == '#') continue;                       // main.rs:406-408
       if (p->g_last[q] == p->g_last[tg]) continue;             // main.rs:429-432
       if (!split11(b, e, f)) continue;                         // cannot happen for a record
