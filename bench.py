@@ -444,6 +444,7 @@ def main():
             "other_pipelines": others,
             "pcie_inclusive": pcie,
             "end_to_end": e2e,
+            "arena_bytes_per_mapping": {"capacity": ctx.memory_info()[0] / n, "peak_last_call": ctx.memory_info()[1] / n},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
         }
         print(json.dumps(out))

@@ -195,6 +195,12 @@ int swg_profile_count(swg_ctx* ctx);
 /* Entry i: name (owned by ctx, valid until the next reset), launches, summed milliseconds. */
 int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
 
+/* Device scratch of this context: capacity of the arena (kept between calls, grown on demand) and the high-water
+ * mark of the last call.  A call whose scratch does not fit grows the arena and runs once more, so a host that
+ * knows its sizes can avoid that by one warm-up call or by swg_reserve(). */
+int swg_memory_info(const swg_ctx* ctx, uint64_t* arena_capacity, uint64_t* arena_peak_last_call);
+int swg_reserve(swg_ctx* ctx, uint64_t arena_bytes);
+
 /* ---- several devices of one node ---------------------------------------------------------------
  * swg_filter over n_ctx contexts (one per device, created by the caller): records are partitioned by genome pair
  * (first-two-'#'-parts prefix), pairs are bin-packed onto the contexts by mapping count, every context filters its

@@ -20,7 +20,7 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
-           "swg_filter_multi"]
+           "swg_filter_multi", "swg_memory_info", "swg_reserve"]
 
 
 class SwgError(RuntimeError):
@@ -194,6 +194,10 @@ def load():
     lib.swg_filter_multi.restype = C.c_int
     lib.swg_filter_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p,
                                      C.c_void_p, C.POINTER(SwgStats)]
+    lib.swg_memory_info.restype = C.c_int
+    lib.swg_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.swg_reserve.restype = C.c_int
+    lib.swg_reserve.argtypes = [C.c_void_p, C.c_uint64]
     lib.swg_paf_ani_stats.restype = C.c_int
     lib.swg_paf_ani_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _lib = lib
@@ -242,6 +246,15 @@ class Context:
             self.check(self.lib.swg_profile_get(self.handle, i, C.byref(name), C.byref(launches), C.byref(ms)))
             out[name.value.decode()] = (launches.value, ms.value)
         return out
+
+    def memory_info(self):
+        """(arena capacity, high-water mark of the last call) in bytes."""
+        cap, peak = C.c_uint64(), C.c_uint64()
+        self.check(self.lib.swg_memory_info(self.handle, C.byref(cap), C.byref(peak)))
+        return cap.value, peak.value
+
+    def reserve(self, arena_bytes):
+        self.check(self.lib.swg_reserve(self.handle, int(arena_bytes)))
 
     def close(self):
         if getattr(self, "handle", None):

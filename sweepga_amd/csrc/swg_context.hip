@@ -192,6 +192,18 @@ void swg_destroy(swg_ctx* ctx) {
   delete ctx;
 }
 
+int swg_memory_info(const swg_ctx* ctx, uint64_t* arena_capacity, uint64_t* arena_peak_last_call) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (arena_capacity) *arena_capacity = ctx->arena_cap;
+  if (arena_peak_last_call) *arena_peak_last_call = ctx->arena_peak;
+  return SWG_OK;
+}
+int swg_reserve(swg_ctx* ctx, uint64_t arena_bytes) {
+  if (!ctx) return SWG_ERR_INVALID;
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  return swg_arena_reserve(ctx, (size_t)arena_bytes);
+}
+
 const char* swg_last_error(const swg_ctx* ctx) { return ctx ? ctx->err.c_str() : swg_create_error.c_str(); }
 
 void* swg_stream(swg_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
