@@ -11,11 +11,22 @@ namespace {
 constexpr int EW = 256;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
 
+// 16 records per thread (16-byte flag load, 16-byte status store, four 16-byte chain stores)
 __global__ __launch_bounds__(EW) void unassigned_status_kernel(uint64_t n, const uint8_t* __restrict__ keep,
                                                                uint8_t* __restrict__ status,
-                                                               uint32_t* __restrict__ chain) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) {
+                                                               uint32_t* __restrict__ chain, int aligned) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * EW + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  if (aligned && i0 + 16 <= n) {
+    const uint4 k = *reinterpret_cast<const uint4*>(keep + i0);
+    auto f = [](uint32_t w) { return (((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u) * (uint32_t)SWG_ST_UNASSIGNED; };
+    *reinterpret_cast<uint4*>(status + i0) = make_uint4(f(k.x), f(k.y), f(k.z), f(k.w));
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(chain + i0 + 4 * j) = z;
+    return;
+  }
+  for (uint64_t i = i0; i < i0 + 16 && i < n; ++i) {
     status[i] = keep[i] ? SWG_ST_UNASSIGNED : SWG_ST_DROPPED;
     chain[i] = 0;
   }
@@ -122,7 +133,9 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
-    SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk(n), EW, 0, st>>>(n, keep1, status_out, chain_out));
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(keep1) | reinterpret_cast<uintptr_t>(status_out) | reinterpret_cast<uintptr_t>(chain_out);
+    SWG_LAUNCH(ctx, "unassigned_status", unassigned_status_kernel<<<nblk((n + 15) / 16), EW, 0, st>>>(n, keep1, status_out, chain_out,
+                                                                                            (ptrs & 15) == 0));
     SWG_KERNEL_CHECK(ctx);
     if (stats) {
       SWG_LAUNCH(ctx, "count_nonzero", count_nonzero_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, keep1, scalars + 2));
