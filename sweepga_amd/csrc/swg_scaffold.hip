@@ -1743,6 +1743,16 @@ __global__ __launch_bounds__(EW) void anchor_cols_kernel(uint64_t na, const uint
   b_num[j] = anchor_num[i];
 }
 
+// [lo, hi) of every dense pair in the sorted anchor table (pairs without anchors keep the zero-initialised empty range)
+__global__ __launch_bounds__(EW) void anchor_ranges_kernel(uint64_t na, const uint64_t* __restrict__ b_key, int pos_bits,
+                                                           uint32_t* __restrict__ pair_lo, uint32_t* __restrict__ pair_hi) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= na) return;
+  const uint64_t dp = b_key[j] >> pos_bits;
+  if (j == 0 || (b_key[j - 1] >> pos_bits) != dp) pair_lo[dp] = (uint32_t)j;
+  if (j + 1 == na || (b_key[j + 1] >> pos_bits) != dp) pair_hi[dp] = (uint32_t)(j + 1);
+}
+
 // paf_filter.rs:656-732 per record.  Rescued records take the chain of the lowest-index anchor in range
 // (the reference iterates a HashSet here; ascending input order is the instance the oracle fixes).
 __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
@@ -1751,8 +1761,10 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     const uint32_t* __restrict__ a_ts,
                                                     const uint32_t* __restrict__ a_te,
                                                     const uint32_t* __restrict__ a_dpair, int pos_bits,
-                                                    const uint32_t* __restrict__ anchor_num,
+                                                    const uint8_t* __restrict__ a_is_anchor,
                                                     const uint8_t* __restrict__ in_filtered, uint64_t na,
+                                                    const uint32_t* __restrict__ pair_lo,
+                                                    const uint32_t* __restrict__ pair_hi,
                                                     const uint64_t* __restrict__ b_key,
                                                     const uint32_t* __restrict__ b_tc,
                                                     const uint32_t* __restrict__ b_idx,
@@ -1760,14 +1772,9 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
   uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (a >= M) return;
+  if (a_is_anchor[a]) return;  // anchors got their status from the coalesced pass in input order
   const uint32_t i = idxA[a];
-  const uint32_t an = anchor_num[i];
-  if (an) {
-    status[i] = SWG_ST_SCAFFOLD;
-    chain[i] = an;
-    return;
-  }
-  if (in_filtered[i] || D == 0 || na == 0) return;  // status stays DROPPED
+  if (in_filtered[i]) return;  // status stays DROPPED
   const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
   const uint64_t qs = keyA[a] & posmask;
   const uint64_t qc = (qs + (uint64_t)a_qe[a]) / 2, tc = ((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2;
@@ -1775,8 +1782,9 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
   const uint64_t lo = hi_part | (qc > D ? qc - D : 0);
   const uint64_t hi_q = qc + D < qc ? ~0ull : qc + D;
   const uint64_t hi = hi_part | (hi_q > posmask ? posmask : hi_q);
-  // lower_bound(b_key, lo)
-  uint64_t l = 0, r = na;
+  // lower_bound(b_key, lo) inside the pair's own slice of the anchor table
+  const uint64_t slice_end = pair_hi[a_dpair[a]];
+  uint64_t l = pair_lo[a_dpair[a]], r = slice_end;
   while (l < r) {
     const uint64_t mid = (l + r) >> 1;
     if (b_key[mid] < lo)
@@ -1785,7 +1793,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
       r = mid;
   }
   uint32_t best_idx = NONE, best_num = 0;
-  for (uint64_t j = l; j < na; ++j) {
+  for (uint64_t j = l; j < slice_end; ++j) {
     const uint64_t bk = b_key[j];
     if (bk > hi) break;
     const uint64_t aq = bk & posmask;
@@ -1951,10 +1959,24 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
                                                                      b_num));
       SWG_KERNEL_CHECK(ctx);
     }
-    SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, anchor_num,
-                                                        in_filtered, na, b_key, b_tc, b_idx, b_num,
-                                                        cfg->scaffold_max_deviation, status_out, chain_out));
+    uint32_t* a_pair_lo = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
+    uint32_t* a_pair_hi = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(a_pair_lo, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
+    SWG_HIP(ctx, hipMemsetAsync(a_pair_hi, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
+    if (na) {
+      SWG_LAUNCH(ctx, "anchor_ranges", anchor_ranges_kernel<<<nblk(na), EW, 0, st>>>(na, b_key, pos_bits, a_pair_lo, a_pair_hi));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    // anchors: status + chain in input order (coalesced); everything else starts as dropped
+    SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
     SWG_KERNEL_CHECK(ctx);
+    if (cfg->scaffold_max_deviation != 0 && na != 0) {
+      SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, aflag,
+                                                          in_filtered, na, a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
+                                                          cfg->scaffold_max_deviation, status_out, chain_out));
+      SWG_KERNEL_CHECK(ctx);
+    }
   }
   return finish_counts();
 }
