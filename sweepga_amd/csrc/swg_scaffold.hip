@@ -214,13 +214,16 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
     uint64_t d;
     if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
     if (count < 0xffffffffu) ++count;
-    // insert (d, j) keeping (d asc, j asc); j only grows, so strict `<` keeps earlier j first on ties
+    // insert (d, j) keeping (d asc, j asc): j only grows, so the new entry goes after every entry with d' <= d
+    // (strict `<` finds that slot); from there on every entry moves down one slot, equal distances included
     if (d < bd[KC - 1]) {
       uint64_t cd = d;
       uint32_t cj = j;
+      bool placed = false;
 #pragma unroll
       for (int k = 0; k < KC; ++k) {
-        if (cd < bd[k]) {
+        if (placed || cd < bd[k]) {
+          placed = true;
           const uint64_t td = bd[k];
           const uint32_t tj = bj[k];
           bd[k] = cd;

@@ -222,3 +222,30 @@ def test_filter_paf_byte_identical(sw, name):
         a, b = open(o1, "rb").read(), open(o2, "rb").read()
         assert a == b, (a.decode(), b.decode())
         assert a  # every fixture keeps something
+
+
+def test_chaining_equal_distance_candidates(sw):
+    """Found by tools/fuzz_gpu.py: B's candidates arrive as C (d), D (d, duplicate of C), E (smaller d but already
+    taken by A).  The candidate list must keep C before D when E is inserted in front of them; the chain must then
+    be B-C-D, not C-D alone (paf_filter.rs:839: strict `<`, the first minimum wins)."""
+    rows = [(700, 750, 0, 50), (600, 750, 0, 150), (850, 950, 100, 150), (600, 700, 150, 250), (700, 750, 0, 50)]
+    u = lambda k: np.array([r[k] for r in rows], dtype=np.uint64)
+    n = len(rows)
+    rec = orc.Records(["q"] * n, ["t"] * n, u(0), u(1), u(2), u(3), u(1) - u(0), np.full(n, 0.9), (u(1) - u(0)) * 9 // 10,
+                      np.full(n, ord("+"), dtype=np.uint8), np.arange(n, dtype=np.uint64))
+    got_of, _ = sw.merge_mappings_into_chains(gen.records_to_meta(rec), 50_000)
+    want_of, _, _ = orc.merge_chains(rec, 50_000)
+    assert want_of.tolist() == [1, 0, 0, 1, 1]
+    assert got_of.tolist() == want_of.tolist()
+
+
+@pytest.mark.parametrize("first_seed", [0, 400, 3100, 5500])
+def test_fuzz_slice(sw, first_seed):
+    """A slice of tools/fuzz_gpu.py (random record sets x random configurations, exact status and chain numbers);
+    the ranges include seeds that failed before the candidate-list tie fix."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_gpu import run_case
+    for seed in range(first_seed, first_seed + 100):
+        ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed)
+        assert ok, (seed, n, bs, bc, kw, keep_self, scaffolds_only)

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the whole filter on the GPU against the CPU oracle, beyond the fixed seeds of tests/:
+random record sets (sizes 1 .. 60k, 1-6 genomes, sparse to very dense, ties and duplicates, zero-length and
+zero-identity records, PanSN and plain names) x random configurations (filter modes and k, overlap thresholds,
+scorings, gaps, masses, deviations, identity / length cut-offs, self, scaffolds-only).  Exact equality of status
+and chain numbers is required.  A failing case is written to gpurun_out/fuzz_fail_<seed>.json for replay.
+
+    python tools/fuzz_gpu.py --minutes 5 [--seed 0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import sweepga_amd as sw  # noqa: E402
+from tests import gen, orc  # noqa: E402
+
+
+def random_case(rng):
+    n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 20000, 60000],
+                       p=[.03, .03, .03, .05, .05, .05, .05, .15, .05, .05, .05, .15, .16, .10]))
+    span = int(rng.choice([2_000, 50_000, 400_000, 3_000_000]))
+    max_len = int(rng.choice([300, 3_000, 20_000]))
+    rec = gen.random_records(rng, n, n_genomes=int(rng.integers(1, 7)), chrs_per_genome=int(rng.integers(1, 4)), span=span,
+                             max_len=min(max_len, max(span // 2, 60)), pansn=bool(rng.integers(0, 2)),
+                             self_frac=float(rng.choice([0.0, 0.02, 0.3])), minus_frac=float(rng.choice([0.0, 0.2, 0.5, 1.0])),
+                             syntenic_frac=float(rng.choice([0.0, 0.7, 0.98])), zero_frac=float(rng.choice([0.0, 0.01, 0.1])))
+    if rng.random() < 0.3:  # heavy ties: few identity levels, coordinates on a coarse grid
+        g = int(rng.choice([50, 500]))
+        for a in (rec.qs, rec.qe, rec.ts, rec.te):
+            a[:] = a // g * g
+        rec.identity[:] = rng.choice([0.8, 0.9, 0.95], len(rec))
+        rec.matches[:] = np.floor(rec.identity * rec.block_length).astype(np.uint64)
+    modes = [sw.FilterMode.OneToOne, sw.FilterMode.OneToMany, sw.FilterMode.ManyToMany]
+    kq = rng.choice([None, 1, 2, 5])
+    kt = rng.choice([None, 1, 3])
+    kw = dict(
+        mapping_filter_mode=modes[int(rng.integers(0, 3))],
+        mapping_max_per_query=None if kq is None else int(kq), mapping_max_per_target=None if kt is None else int(kt),
+        scaffold_filter_mode=modes[int(rng.integers(0, 3))],
+        scaffold_max_per_query=None if rng.random() < 0.5 else int(rng.integers(1, 4)),
+        scaffold_max_per_target=None if rng.random() < 0.5 else int(rng.integers(1, 4)),
+        overlap_threshold=float(rng.choice([0.0, 0.3, 0.95, 1.0])),
+        scaffold_gap=int(rng.choice([0, 1, 500, 10_000, 50_000, 10_000_000])),
+        min_scaffold_length=int(rng.choice([0, 1_000, 10_000])),
+        scaffold_overlap_threshold=float(rng.choice([0.0, 0.5, 1.0])),
+        scaffold_max_deviation=int(rng.choice([0, 1, 2_000, 100_000])),
+        scoring_function=sw.ScoringFunction(int(rng.integers(0, 5))),
+        min_identity=float(rng.choice([0.0, 0.8, 0.97])),
+        min_scaffold_identity=float(rng.choice([0.0, 0.85])),
+        min_block_length=int(rng.choice([0, 100, 2_000])),
+    )
+    return rec, kw, bool(rng.random() < 0.3), bool(rng.random() < 0.15)
+
+
+def run_case(seed):
+    rng = np.random.default_rng(seed)
+    rec, kw, keep_self, scaffolds_only = random_case(rng)
+    cfg = sw.FilterConfig(**kw)
+    ocfg = orc.Config(**{k: (int(v) if hasattr(v, "value") else (0 if v is None else v)) for k, v in kw.items()})
+    ocfg.keep_self, ocfg.scaffolds_only = keep_self, scaffolds_only
+    f = sw.PafFilter(cfg).with_keep_self(keep_self).with_scaffolds_only(scaffolds_only)
+    status, chain = f.filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+    ost, och = orc.apply_filters(ocfg, rec)
+    ok = np.array_equal(status, ost) and np.array_equal(chain, och)
+    return ok, len(rec), kw, keep_self, scaffolds_only, int((status != ost).sum()), int((chain != och).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    t0 = time.time()
+    seed, cases, records, fails = args.seed, 0, 0, 0
+    while time.time() - t0 < args.minutes * 60:
+        ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed)
+        cases += 1
+        records += n
+        if not ok:
+            fails += 1
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}.json"), "w") as fh:
+                json.dump(dict(seed=seed, n=n, keep_self=keep_self, scaffolds_only=scaffolds_only, bad_status=bs, bad_chain=bc,
+                               cfg={k: (int(v) if hasattr(v, "value") else v) for k, v in kw.items()}), fh)
+            print("FAIL seed", seed, "n", n, "bad status", bs, "bad chain", bc, flush=True)
+        seed += 1
+    print(json.dumps(dict(cases=cases, records=records, failures=fails, first_seed=args.seed, next_seed=seed,
+                          minutes=(time.time() - t0) / 60)))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
