@@ -239,13 +239,14 @@ def test_chaining_equal_distance_candidates(sw):
     assert got_of.tolist() == want_of.tolist()
 
 
-@pytest.mark.parametrize("first_seed", [0, 400, 3100, 5500])
-def test_fuzz_slice(sw, first_seed):
-    """A slice of tools/fuzz_gpu.py (random record sets x random configurations, exact status and chain numbers);
-    the ranges include seeds that failed before the candidate-list tie fix."""
+@pytest.mark.parametrize("first_seed,extras", [(450, False), (3150, False), (5500, False), (0, True), (100_000, True)])
+def test_fuzz_slice(sw, first_seed, extras):
+    """Slices of tools/fuzz_gpu.py (random record sets x random configurations, exact status and chain numbers, every
+    8th case also through swg_filter_multi).  The extras=False ranges contain seeds 477, 3190 and 5535, which failed
+    before the candidate-list tie fix."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from fuzz_gpu import run_case
-    for seed in range(first_seed, first_seed + 100):
-        ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed)
+    for seed in range(first_seed, first_seed + 60):
+        ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed, extras)
         assert ok, (seed, n, bs, bc, kw, keep_self, scaffolds_only)

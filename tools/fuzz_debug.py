@@ -24,7 +24,7 @@ def sub_records(rec, keep):
 
 for seed in map(int, sys.argv[1:]):
     rng = np.random.default_rng(seed)
-    rec, kw, keep_self, scaffolds_only = random_case(rng)
+    rec, kw, keep_self, scaffolds_only = random_case(rng, extras=False)
     okw = {k: (int(v) if hasattr(v, "value") else (0 if v is None else v)) for k, v in kw.items()}
     print("== seed", seed, "n", len(rec), "keep_self", keep_self, "scaffolds_only", scaffolds_only, okw)
     # 1. mapping sweep alone

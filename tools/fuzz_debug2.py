@@ -30,7 +30,7 @@ def take(rec, keep):
 
 seed = int(sys.argv[1])
 rng = np.random.default_rng(seed)
-rec, kw, keep_self, _ = random_case(rng)
+rec, kw, keep_self, _ = random_case(rng, extras=False)
 okw = {k: (int(v) if hasattr(v, "value") else (0 if v is None else v)) for k, v in kw.items()}
 oc0 = orc.Config(**dict(okw, scaffold_gap=0))
 oc0.keep_self = keep_self

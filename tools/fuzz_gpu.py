@@ -22,7 +22,7 @@ import sweepga_amd as sw  # noqa: E402
 from tests import gen, orc  # noqa: E402
 
 
-def random_case(rng):
+def random_case(rng, extras=True):
     n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 1000, 4095, 4096, 4097, 9000, 20000, 60000],
                        p=[.03, .03, .03, .05, .05, .05, .05, .15, .05, .05, .05, .15, .16, .10]))
     span = int(rng.choice([2_000, 50_000, 400_000, 3_000_000]))
@@ -37,6 +37,13 @@ def random_case(rng):
             a[:] = a // g * g
         rec.identity[:] = rng.choice([0.8, 0.9, 0.95], len(rec))
         rec.matches[:] = np.floor(rec.identity * rec.block_length).astype(np.uint64)
+    if extras and rng.random() < 0.1:  # coordinates up against the 32-bit limit of the device layout
+        off = np.uint64(2**32 - 1 - int(max(rec.qe.max(), rec.te.max())))
+        for a in (rec.qs, rec.qe, rec.ts, rec.te):
+            a += off
+    if extras and rng.random() < 0.15:  # identity outliers (dv:f: can produce values outside [0, 1])
+        k = rng.random(len(rec)) < 0.05
+        rec.identity[k] = rng.choice([-0.5, 0.0, 1.0, 1.5], int(k.sum()))
     modes = [sw.FilterMode.OneToOne, sw.FilterMode.OneToMany, sw.FilterMode.ManyToMany]
     kq = rng.choice([None, 1, 2, 5])
     kt = rng.choice([None, 1, 3])
@@ -59,16 +66,31 @@ def random_case(rng):
     return rec, kw, bool(rng.random() < 0.3), bool(rng.random() < 0.15)
 
 
-def run_case(seed):
+_CTXS = []
+
+
+def contexts(k):
+    while len(_CTXS) < k:
+        _CTXS.append(sw.Context(0))
+    return _CTXS[:k]
+
+
+def run_case(seed, extras=True):
+    """extras=False reproduces the generator of the first campaign (the one that found the candidate-list tie bug)."""
     rng = np.random.default_rng(seed)
-    rec, kw, keep_self, scaffolds_only = random_case(rng)
+    rec, kw, keep_self, scaffolds_only = random_case(rng, extras)
     cfg = sw.FilterConfig(**kw)
     ocfg = orc.Config(**{k: (int(v) if hasattr(v, "value") else (0 if v is None else v)) for k, v in kw.items()})
     ocfg.keep_self, ocfg.scaffolds_only = keep_self, scaffolds_only
     f = sw.PafFilter(cfg).with_keep_self(keep_self).with_scaffolds_only(scaffolds_only)
-    status, chain = f.filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    status, chain = f.filter_columns(packed)
     ost, och = orc.apply_filters(ocfg, rec)
     ok = np.array_equal(status, ost) and np.array_equal(chain, och)
+    if ok and seed % 8 == 0:  # the sharded entry point must give the same answer
+        st2, ch2 = f.filter_columns_multi(packed, contexts(2 + seed % 3))
+        ok = np.array_equal(st2, ost) and np.array_equal(ch2, och)
+        status, chain = st2, ch2
     return ok, len(rec), kw, keep_self, scaffolds_only, int((status != ost).sum()), int((chain != och).sum())
 
 
