@@ -175,3 +175,14 @@ def test_open_buffer_and_errors(tmp_path):
             pf.write(tmp_path / "o", np.zeros(3, dtype=np.uint8))
         with pytest.raises(SwgError, match="cannot create"):
             pf.write(tmp_path / "no_such_dir" / "o", np.ones(9, dtype=np.uint8))
+
+
+def test_fuzz_slice_against_oracle(tmp_path):
+    """A slice of tools/fuzz_paf_io.py: hostile field values and tag soups, native ingest == oracle extract_metadata."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paf_io.py"), "--minutes", "0.1", "--seed", "500000"],
+                       capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0 and "'failures': 0" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
