@@ -250,11 +250,10 @@ struct SelBlock {
   uint64_t bps;
 };
 
-// Work items are *chunks*: runs of whole units of about CHUNK elements.  Windows never cross a unit boundary, so
-// running the sequential greedy straight through a run of units is the same as running it unit by unit, and a
-// wavefront pays its start-up loads once per ~CHUNK steps instead of once per (often tiny) unit.  Elements of
-// long units (handled by the block-speculative path) have had their candidate count zeroed and are stepped over.
-constexpr uint32_t CHUNK = 1024;
+// Units come in three sizes.  Short ones (<= SMALL_UNIT elements: nearly all of them in sparse data) are walked one per
+// LANE (chain_select_lanes_kernel); the longest (>= BIG_UNIT) are cut into blocks that run speculatively in parallel
+// (spec_round_kernel); the middle ones get one wavefront each (chain_select_kernel), which keeps the scores of the
+// next 128 elements in registers.
 
 struct SpecBlock {
   uint32_t ue;  // end of the unit
@@ -263,34 +262,8 @@ struct SpecBlock {
   uint32_t pad;
 };
 
-__global__ __launch_bounds__(EW) void chunk_begin_kernel(uint32_t n_chunks, const uint32_t* __restrict__ unit_begin,
-                                                         uint32_t n_units, uint32_t m, uint32_t* __restrict__ chunk_begin) {
-  uint32_t k = blockIdx.x * EW + threadIdx.x;
-  if (k > n_chunks) return;
-  if (k == n_chunks) {
-    chunk_begin[k] = m;
-    return;
-  }
-  const uint32_t x = k * CHUNK;  // first unit that begins at or after x
-  uint32_t l = 0, r = n_units;
-  while (l < r) {
-    const uint32_t mid = l + ((r - l) >> 1);
-    if (unit_begin[mid] < x)
-      l = mid + 1;
-    else
-      r = mid;
-  }
-  chunk_begin[k] = l < n_units ? unit_begin[l] : m;
-}
-__global__ __launch_bounds__(EW) void zero_long_counts_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
-                                                              uint32_t* __restrict__ c_n) {
-  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
-    const SpecBlock D = desc[bk];
-    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) c_n[p] = 0;
-  }
-}
-
-__global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+__global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, const uint32_t* __restrict__ unit_list,
+                                                           uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                            uint32_t m, const uint64_t* __restrict__ s_grp,
                                                            const uint32_t* __restrict__ s_qs,
                                                            const uint32_t* __restrict__ s_qe,
@@ -307,10 +280,11 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
-  // (n_units, unit_begin) are (n_chunks, chunk_begin) here: every chunk is a run of whole units
-  for (uint32_t u = wave_global; u < n_units; u += n_waves) {
+  // one wavefront per listed unit (the middle-sized ones: longer than a lane should walk, shorter than BIG_UNIT)
+  for (uint32_t k = wave_global; k < n_list; k += n_waves) {
+    const uint32_t u = unit_list[k];
     const uint32_t b = unit_begin[u];
-    const uint32_t e = unit_begin[u + 1];
+    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
     if (e - b < 2) continue;
     auto load_block = [&](uint32_t pos) {
       SelBlock k;
@@ -425,6 +399,66 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_units, con
       }
       if (lane == 0) pred[best_j] = i;
     }
+  }
+}
+
+// Short units -- the bulk of sparse data, where a gap larger than max_gap cuts a group every few dozen elements --
+// are the opposite case: a wavefront per chunk spends 64 lanes on one sequential walk.  Here every LANE walks its own
+// unit: the reference's greedy unchanged (listed candidates in (d, j) order against best_pred_score, full window when
+// all of them are blocked and the window held more), state in global memory but private to the lane, since windows
+// never leave a unit.
+constexpr uint32_t SMALL_UNIT = 96;
+
+__global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin, uint32_t m,
+                                                                const uint64_t* __restrict__ s_grp,
+                                                                const uint32_t* __restrict__ s_qs,
+                                                                const uint32_t* __restrict__ s_qe,
+                                                                const uint32_t* __restrict__ s_ts,
+                                                                const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                                const unsigned long long* __restrict__ c_d,
+                                                                const uint32_t* __restrict__ c_j,
+                                                                const uint32_t* __restrict__ c_n,
+                                                                const uint32_t* __restrict__ c_ext, unsigned long long* bps,
+                                                                uint32_t* pred) {
+  const uint32_t u = blockIdx.x * EW + threadIdx.x;
+  if (u >= n_units) return;
+  const uint32_t b = unit_begin[u];
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  const uint32_t len = e - b;
+  if (len > SMALL_UNIT) return;
+  const uint64_t fifth = max_gap / 5;
+  for (uint32_t i = b; i < e; ++i) {
+    const uint32_t nvalid = c_n[i];
+    if (nvalid == 0) continue;
+    uint64_t best_d = ~0ull;
+    uint32_t best_j = NONE;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (best_j == NONE && (uint32_t)c < nvalid) {
+        const uint64_t d = c_d[(uint64_t)c * m + i];
+        const uint32_t j = c_j[(uint64_t)c * m + i];
+        if (d < bps[j]) {
+          best_d = d;
+          best_j = j;
+        }
+      }
+    }
+    if (best_j == NONE && nvalid > (uint32_t)KC) {  // paf_filter.rs:794-840 over the whole window
+      const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
+      const bool minus = (s_grp[i] & 1ull) != 0;
+      const uint32_t last = i + c_ext[i];  // last element with q_start <= q_end[i] + max_gap (inside the unit)
+      for (uint32_t j = i + 1; j <= last && j < e; ++j) {
+        uint64_t d;
+        if (!chain_dist(minus, qe_i, ts_i, te_i, s_qs[j], s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
+        if (d < best_d && d < bps[j]) {
+          best_d = d;
+          best_j = j;
+        }
+      }
+    }
+    if (best_j == NONE) continue;
+    bps[best_j] = best_d;
+    pred[best_j] = i;
   }
 }
 
@@ -699,6 +733,15 @@ __global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, con
   const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
   const uint8_t f = (e - unit_begin[u]) >= BIG_UNIT ? 1 : 0;
   is_big[u] = f;
+}
+
+__global__ __launch_bounds__(EW) void unit_mid_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                           uint32_t m, uint8_t* __restrict__ is_mid) {
+  uint32_t u = blockIdx.x * EW + threadIdx.x;
+  if (u >= n_units) return;
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  const uint32_t len = e - unit_begin[u];
+  is_mid[u] = (len > SMALL_UNIT && len < BIG_UNIT) ? 1 : 0;
 }
 
 // Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
@@ -1392,6 +1435,10 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
                                                                             s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "chain_select_lanes", chain_select_lanes_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
+                                                                                    s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, bps,
+                                                                                    pred));
+    SWG_KERNEL_CHECK(ctx);
     {
       uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
       uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 1);
@@ -1464,25 +1511,31 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
                   (unsigned long long)n_spec, rounds);
         SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
-        // the long units are done: take them out of the chunked pass below
-        SWG_LAUNCH(ctx, "zero_long_counts", zero_long_counts_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, c_n));
-        SWG_KERNEL_CHECK(ctx);
       }
     }
     {
-      const uint32_t n_chunks = (uint32_t)((m + CHUNK - 1) / CHUNK);
-      uint32_t* chunk_begin = swg_alloc<uint32_t>(ctx, (size_t)n_chunks + 1);
+      // what is left: units longer than a lane should walk and shorter than BIG_UNIT, one wavefront each
+      uint8_t* is_mid = swg_alloc<uint8_t>(ctx, n_units);
+      uint64_t* d_nm = swg_alloc<uint64_t>(ctx, 1);
       SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "chunk_begin", chunk_begin_kernel<<<nblk((uint64_t)n_chunks + 1), EW, 0, st>>>(n_chunks, unit_begin, (uint32_t)n_units,
-                                                                                       (uint32_t)m, chunk_begin));
+      SWG_LAUNCH(ctx, "unit_mid_flag", unit_mid_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_mid));
       SWG_KERNEL_CHECK(ctx);
-      uint64_t blocks = ((uint64_t)n_chunks + 3) / 4;
-      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-      if (blocks > max_blocks) blocks = max_blocks;
-      SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>(n_chunks, chunk_begin, (uint32_t)m, s_grp, s_qs, s_qe,
-                                                                                s_ts, s_te, max_gap, c_d, c_j, c_n, s_gidx, group_begin,
-                                                                                (uint32_t)n_groups, bps, pred));
-      SWG_KERNEL_CHECK(ctx);
+      swg_flag_scan mid_scan;
+      SWG_TRY(swg_flags_count(ctx, is_mid, n_units, &mid_scan, d_nm));
+      uint64_t n_mid = 0;
+      SWG_TRY(swg_read_scalars(ctx, d_nm, &n_mid, 1));
+      if (n_mid) {
+        uint32_t* mid_list = swg_alloc<uint32_t>(ctx, n_mid);
+        SWG_CHECK_ARENA(ctx);
+        SWG_TRY(swg_flags_compact(ctx, mid_scan, mid_list));
+        uint64_t blocks = (n_mid + 3) / 4;
+        const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+        if (blocks > max_blocks) blocks = max_blocks;
+        SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_mid, mid_list, (uint32_t)n_units, unit_begin,
+                                                                                  (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j,
+                                                                                  c_n, s_gidx, group_begin, (uint32_t)n_groups, bps, pred));
+        SWG_KERNEL_CHECK(ctx);
+      }
     }
   }
   // ---- labelling by pointer jumping
