@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
 // unit: the reference's greedy unchanged (listed candidates in (d, j) order against best_pred_score, full window when
 // all of them are blocked and the window held more), state in global memory but private to the lane, since windows
 // never leave a unit.
-constexpr uint32_t SMALL_UNIT = 96;
+constexpr uint32_t SMALL_UNIT = 256;
 
 __global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin, uint32_t m,
                                                                 const uint64_t* __restrict__ s_grp,
