@@ -861,6 +861,11 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
   h_sm[p] = s_m[p];
   h_sb[p] = s_b[p];
 }
+// A member is usually a few positions after its head, so a block first folds the members whose head lies inside its
+// own 1024-element range into LDS (LDS atomics), then merges each touched partial aggregate into the head's seeded
+// global slot with one set of atomics per chain instead of one per member; members whose head lies before the range
+// go to global memory directly.
+constexpr int AGG_SPAN = 1024;
 __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const uint32_t* __restrict__ hd,
                                                              const uint32_t* __restrict__ s_qe,
                                                              const uint32_t* __restrict__ s_ts,
@@ -871,15 +876,49 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
                                                              uint32_t* __restrict__ h_te,
                                                              unsigned long long* __restrict__ h_sm,
                                                              unsigned long long* __restrict__ h_sb) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t h = hd[p];
-  if (h == p) return;
-  atomicMax(&h_qe[h], s_qe[p]);
-  atomicMin(&h_ts[h], s_ts[p]);
-  atomicMax(&h_te[h], s_te[p]);
-  atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
-  atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+  __shared__ uint32_t l_qe[AGG_SPAN], l_ts[AGG_SPAN], l_te[AGG_SPAN], l_cnt[AGG_SPAN];
+  __shared__ unsigned long long l_sm[AGG_SPAN], l_sb[AGG_SPAN];
+  const uint64_t base = (uint64_t)blockIdx.x * AGG_SPAN;
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    l_qe[k] = 0;
+    l_ts[k] = 0xffffffffu;
+    l_te[k] = 0;
+    l_cnt[k] = 0;
+    l_sm[k] = 0;
+    l_sb[k] = 0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p >= m) break;
+    const uint32_t h = hd[p];
+    if (h == p) continue;
+    if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
+      const uint32_t l = (uint32_t)(h - base);
+      atomicMax(&l_qe[l], s_qe[p]);
+      atomicMin(&l_ts[l], s_ts[p]);
+      atomicMax(&l_te[l], s_te[p]);
+      atomicAdd(&l_sm[l], (unsigned long long)s_m[p]);
+      atomicAdd(&l_sb[l], (unsigned long long)s_b[p]);
+      l_cnt[l] = 1;
+    } else {
+      atomicMax(&h_qe[h], s_qe[p]);
+      atomicMin(&h_ts[h], s_ts[p]);
+      atomicMax(&h_te[h], s_te[p]);
+      atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
+      atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    if (!l_cnt[k]) continue;
+    const uint64_t h = base + k;  // a head of this range with members in it; members of later ranges use atomics too
+    atomicMax(&h_qe[h], l_qe[k]);
+    atomicMin(&h_ts[h], l_ts[k]);
+    atomicMax(&h_te[h], l_te[k]);
+    atomicAdd(&h_sm[h], l_sm[k]);
+    atomicAdd(&h_sb[h], l_sb[k]);
+  }
 }
 
 // min original index per (q,t,strand) group, and per genome pair (prefix-last) over ALL alive records
@@ -1555,7 +1594,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
                                                                                   h_te, h_sm, h_sb, is_head));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
+  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
                                                                         h_sm, h_sb));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
