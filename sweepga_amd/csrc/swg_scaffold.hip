@@ -821,10 +821,30 @@ __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32
 }
 
 // ---- chain labelling ---------------------------------------------------------------------------------------
+// hd[p] = pred[p] (or p), then followed through LDS as far as the block's own 1024-element range goes: predecessors
+// precede their successors and are usually close, so most elements reach their head here and the global pointer
+// jumping below only has to connect chains across ranges.
+constexpr int HEAD_SPAN = 1024;
 __global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
                                                        uint32_t* __restrict__ hd) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) hd[p] = pred[p] == NONE ? (uint32_t)p : pred[p];
+  __shared__ uint32_t l[HEAD_SPAN];
+  const uint64_t base = (uint64_t)blockIdx.x * HEAD_SPAN;
+  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p < m) l[k] = pred[p] == NONE ? (uint32_t)p : pred[p];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p >= m) break;
+    uint32_t h = l[k];
+    while (h >= base) {  // h <= p < base + HEAD_SPAN
+      const uint32_t hh = l[h - base];
+      if (hh == h) break;
+      h = hh;
+    }
+    hd[p] = h;
+  }
 }
 // hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
 __global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed) {
@@ -1578,7 +1598,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     }
   }
   // ---- labelling by pointer jumping
-  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<nblk(m), EW, 0, st>>>(m, pred, hd));
+  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd));
   SWG_KERNEL_CHECK(ctx);
   for (int round = 0; round < 64; ++round) {
     SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
