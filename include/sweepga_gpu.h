@@ -150,7 +150,9 @@ int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cf
 /* plane_sweep_query / plane_sweep_target / plane_sweep_both (src/plane_sweep_exact.rs:268,
  * 355, 436) on ONE segment of n mappings given as host arrays.  axis: 0 query, 1 target,
  * 2 both.  keep_out[i] = 1 iff index i is in the returned Vec<usize>.  u64 coordinates as in
- * PlaneSweepMapping; values >= 2^32 give SWG_ERR_RANGE. */
+ * PlaneSweepMapping: values >= 2^32 are handled by shrinking the stretches no interval covers (exact for a
+ * sweep; the reference's u64::MAX test runs this way); SWG_ERR_RANGE only if the covered span of an axis
+ * itself does not fit 32 bits.  The same holds for swg_plane_sweep_scaffolds. */
 int swg_plane_sweep(swg_ctx* ctx, int axis, uint64_t n, const uint64_t* q_start,
                     const uint64_t* q_end, const uint64_t* t_start, const uint64_t* t_end,
                     const double* identity, uint64_t k_query, uint64_t k_target,

@@ -2,6 +2,9 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include <algorithm>
+#include <vector>
+
 #include "swg_internal.h"
 
 thread_local std::string swg_create_error;
@@ -52,6 +55,52 @@ int swg_arena_reserve(swg_ctx* ctx, size_t bytes) {
                          hipGetErrorString(e));
   ctx->arena = static_cast<char*>(p);
   ctx->arena_cap = bytes;
+  return SWG_OK;
+}
+
+// u64 interval coordinates of one axis -> u32.  Values below 2^32 pass through.  Otherwise (the reference's own test
+// puts a mapping at u64::MAX, plane_sweep_exact.rs:804-826) every stretch that no interval covers is shrunk to 1: a
+// plane sweep only depends on the order of the event coordinates and on lengths inside covered stretches, so this
+// is exact for the sweep seams.  Chaining measures uncovered gaps and never goes through here.
+int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64_t* e0, uint32_t* out_s, uint32_t* out_e,
+                      const char* axis) {
+  bool wide = false;
+  for (uint64_t i = 0; i < n && !wide; ++i) wide = s0[i] > 0xffffffffull || e0[i] > 0xffffffffull;
+  if (!wide) {
+    for (uint64_t i = 0; i < n; ++i) {
+      out_s[i] = (uint32_t)s0[i];
+      out_e[i] = (uint32_t)e0[i];
+    }
+    return SWG_OK;
+  }
+  std::vector<uint64_t> c;
+  c.reserve(2 * n);
+  for (uint64_t i = 0; i < n; ++i) {
+    c.push_back(s0[i]);
+    c.push_back(e0[i]);
+  }
+  std::sort(c.begin(), c.end());
+  c.erase(std::unique(c.begin(), c.end()), c.end());
+  auto rank = [&](uint64_t v) { return (size_t)(std::lower_bound(c.begin(), c.end(), v) - c.begin()); };
+  std::vector<int64_t> cover(c.size() + 1, 0);
+  for (uint64_t i = 0; i < n; ++i)
+    if (e0[i] > s0[i]) {
+      ++cover[rank(s0[i])];
+      --cover[rank(e0[i])];
+    }
+  std::vector<uint64_t> x(c.size(), 0);
+  int64_t depth = 0;
+  for (size_t k = 0; k + 1 < c.size(); ++k) {
+    depth += cover[k];
+    const uint64_t step = depth > 0 ? c[k + 1] - c[k] : 1;
+    x[k + 1] = x[k] + step;
+    if (x[k + 1] > 0xffffffffull || x[k + 1] < x[k])
+      return swg_set_error(ctx, SWG_ERR_RANGE, "covered span of the %s axis does not fit 32 bits", axis);
+  }
+  for (uint64_t i = 0; i < n; ++i) {
+    out_s[i] = (uint32_t)x[rank(s0[i])];
+    out_e[i] = (uint32_t)x[rank(e0[i])];
+  }
   return SWG_OK;
 }
 

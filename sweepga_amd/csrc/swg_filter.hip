@@ -2,6 +2,8 @@
 // the host-array entry points of the C ABI.
 #include <vector>
 
+#include <algorithm>
+
 #include "swg_internal.h"
 #include "swg_log.h"
 #include "swg_pipeline.h"
@@ -293,15 +295,10 @@ extern "C" int swg_plane_sweep(swg_ctx* ctx, int axis, uint64_t n, const uint64_
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> h(4 * n);
   uint32_t mx = 0;
-  const uint64_t* src[4] = {q_start, q_end, t_start, t_end};
-  for (int c = 0; c < 4; ++c)
-    for (uint64_t i = 0; i < n; ++i) {
-      if (src[c][i] > 0xffffffffull)
-        return swg_set_error(ctx, SWG_ERR_RANGE, "coordinate %llu >= 2^32 is not supported by the device path",
-                             (unsigned long long)src[c][i]);
-      h[c * n + i] = (uint32_t)src[c][i];
-      if (h[c * n + i] > mx) mx = h[c * n + i];
-    }
+  SWG_TRY(swg_narrow_coords(ctx, n, q_start, q_end, h.data(), h.data() + n, "query"));
+  SWG_TRY(swg_narrow_coords(ctx, n, t_start, t_end, h.data() + 2 * n, h.data() + 3 * n, "target"));
+  for (uint64_t i = 0; i < 4 * n; ++i)
+    if (h[i] > mx) mx = h[i];
   const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
   hipStream_t st = ctx->stream;
   if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 200 + (size_t(8) << 20)));

@@ -134,6 +134,8 @@ int swg_inclusive_sum_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, 
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                          uint64_t n, int begin_bit, int end_bit);
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
+int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64_t* e0, uint32_t* out_s, uint32_t* out_e,
+                      const char* axis);
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
 
 static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represent max_value

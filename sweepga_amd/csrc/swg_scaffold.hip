@@ -2115,13 +2115,10 @@ extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> h(4 * n);
   uint32_t mx = 0;
-  const uint64_t* src[4] = {q_start, q_end, t_start, t_end};
-  for (int c = 0; c < 4; ++c)
-    for (uint64_t i = 0; i < n; ++i) {
-      if (src[c][i] > 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "coordinate >= 2^32");
-      h[c * n + i] = (uint32_t)src[c][i];
-      if (h[c * n + i] > mx) mx = h[c * n + i];
-    }
+  SWG_TRY(swg_narrow_coords(ctx, n, q_start, q_end, h.data(), h.data() + n, "query"));
+  SWG_TRY(swg_narrow_coords(ctx, n, t_start, t_end, h.data() + 2 * n, h.data() + 3 * n, "target"));
+  for (uint64_t i = 0; i < 4 * n; ++i)
+    if (h[i] > mx) mx = h[i];
   for (uint64_t i = 0; i < n; ++i)
     if (q_id[i] >= n_seq || t_id[i] >= n_seq) return swg_set_error(ctx, SWG_ERR_INVALID, "sequence id out of range");
   const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;

@@ -84,12 +84,38 @@ def test_reference_vectors(sw, case):
     assert sw.plane_sweep_both(m, k, k, thr, sw.ScoringFunction(scoring)) == orc.plane_sweep_both(rows, k, k, thr, scoring)
 
 
-def test_empty_and_range_errors(sw):
+def test_empty_and_u64_coordinates(sw):
     assert sw.plane_sweep_query([], 1, 0.95) == []
     U = 2**64 - 1
-    with pytest.raises(sw.SwgError) as e:  # plane_sweep_exact.rs:804-826 uses u64::MAX: outside the u32 device layout
-        sw.plane_sweep_query(_maps(sw, [(0, 100, 0, 100, 0.95), (U - 100, U, 1000, 1100, 0.9)]), 1, 0.95)
+    # plane_sweep_exact.rs:804-826: a mapping at u64::MAX.  The seam shrinks uncovered stretches, so this runs on the
+    # u32 device layout and keeps both, like the reference.
+    assert sw.plane_sweep_query(_maps(sw, [(0, 100, 0, 100, 0.95), (U - 100, U, 1000, 1100, 0.9)]), 1, 0.95) == [0, 1]
+    # a covered stretch wider than 32 bits cannot be represented: refused, not wrapped
+    with pytest.raises(sw.SwgError) as e:
+        sw.plane_sweep_query(_maps(sw, [(0, 2**33, 0, 100, 0.95), (5, 2**33 + 7, 1000, 1100, 0.9)]), 1, 0.95)
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_u64_coordinates_match_oracle(sw, seed):
+    """Segments scattered over the whole u64 range (clusters of overlapping intervals separated by huge gaps), both
+    axes, against the oracle on the original coordinates."""
+    import ctypes as C
+    rng = np.random.default_rng(7000 + seed)
+    ctx = sw.default_context(0)
+    n = int(rng.choice([5, 60, 700, 3000]))
+    qs, qe, ts, te, ident = gen.random_segment(rng, n, span=int(rng.choice([2_000, 200_000])), max_len=500)
+    off_q = rng.integers(0, 2**62, n, dtype=np.uint64) // np.uint64(2**40) * np.uint64(2**40) * np.uint64(rng.integers(0, 4))
+    off_t = np.uint64(2**64 - 1 - int(te.max())) if seed % 2 else np.uint64(0)
+    qs, qe = qs + off_q, qe + off_q
+    ts, te = ts + off_t, te + off_t
+    for k, thr, scoring, axis in ((1, 0.95, 4, 0), (2, 0.5, 3, 1), (1, 0.0, 1, 2), (orc.K_INF, 1.0, 0, 2), (3, 0.95, 2, 0)):
+        want = np.zeros(n, dtype=np.uint8)
+        want[orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k, k_t=k, thr=thr, scoring=scoring)] = 1
+        got = np.zeros(n, dtype=np.uint8)
+        ctx.check(ctx.lib.swg_plane_sweep(ctx.handle, axis, n, *(a.ctypes.data_as(C.c_void_p) for a in (qs, qe, ts, te, ident)),
+                                          k, k, thr, scoring, got.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(got, want), (k, thr, scoring, axis, int((got != want).sum()))
 
 
 @pytest.mark.parametrize("seed", range(12))
