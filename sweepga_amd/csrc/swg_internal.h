@@ -155,6 +155,16 @@ static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represen
 //   k         mappings_to_keep (SWG_K_INF = unbounded), thr = overlap threshold
 // Output keep[i] = 1 iff interval i is returned by plane_sweep_query/target on its segment
 // (src/plane_sweep_exact.rs:268-433); keep[i] = 0 for !alive.
+// XCD-aware block index: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so the blocks one
+// XCD runs are spread over the whole grid.  Kernels that gather by original record index (neighbouring sorted
+// positions point into the same region of the input when the input is grouped) want neighbouring blocks on the SAME
+// L2 instead: logical block = a contiguous eighth of the grid per XCD.  Bijective for any grid size; a speed choice
+// only (placement is not a contract).
+__device__ __forceinline__ uint32_t swg_xcd_block(uint32_t bid, uint32_t nwg) {
+  const uint32_t q = nwg >> 3, r = nwg & 7u, x = bid & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 // Score key and both end coordinates of a record in one 16-byte slot: the sweep's post-sort gather then costs one
 // random sector per begin instead of two.
 struct __attribute__((aligned(16))) swg_key_ends {

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(EW) void gatherA_kernel(uint64_t M, const uint64_t*
                                                      uint32_t* __restrict__ a_qe, uint32_t* __restrict__ a_ts,
                                                      uint32_t* __restrict__ a_te, uint8_t* __restrict__ a_keep,
                                                      uint32_t* __restrict__ pair_flag) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (a >= M) return;
   const uint32_t i = idxA[a];
   a_qe[a] = q_end[i];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t*
                                                      uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
                                                      uint32_t* __restrict__ s_idx, uint64_t* __restrict__ s_grp,
                                                      uint32_t* __restrict__ head_flag) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
   const uint32_t a = s_a[p];
   const uint64_t k = keyA[a];
@@ -1703,7 +1703,7 @@ __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint
                                                           const uint32_t* __restrict__ C_num,
                                                           uint32_t* __restrict__ anchor_num,
                                                           uint8_t* __restrict__ in_filtered) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
   const uint32_t c = s_chain[p], i = s_idx[p];
   anchor_num[i] = C_num[c];
@@ -1827,7 +1827,7 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
 __global__ __launch_bounds__(EW) void anchor_flag_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
                                                          const uint32_t* __restrict__ anchor_num,
                                                          uint8_t* __restrict__ flag) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (a < M) flag[a] = anchor_num[idxA[a]] ? 1 : 0;
 }
 __global__ __launch_bounds__(EW) void anchor_keys_kernel(uint64_t na, const uint32_t* __restrict__ anchor_a,
@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     const uint32_t* __restrict__ b_idx,
                                                     const uint32_t* __restrict__ b_num, uint64_t D,
                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (a >= M) return;
   if (a_is_anchor[a]) return;  // anchors got their status from the coalesced pass in input order
   const uint32_t i = idxA[a];

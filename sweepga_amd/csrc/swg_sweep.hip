@@ -165,7 +165,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
                                                                   uint64_t* __restrict__ KEY,
                                                                   uint64_t* __restrict__ tile_x,
                                                                   uint8_t* __restrict__ single) {
-  uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW_THREADS + threadIdx.x;
   if (p >= n) return;
   const uint64_t s = S[p];
   uint64_t e = 0, k = 0;
