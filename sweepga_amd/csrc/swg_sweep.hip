@@ -293,8 +293,9 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
   __shared__ uint64_t cs[CC], ce[CC], ckey[CC];
   __shared__ uint32_t cid[CC];
 
+  const uint32_t tile_id = swg_xcd_block(blockIdx.x, gridDim.x);  // neighbouring tiles share an L2: their flag scatters meet there
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t p0 = (uint64_t)blockIdx.x * TB;
+  const uint64_t p0 = (uint64_t)tile_id * TB;
   const uint64_t p = p0 + tid;
   const bool valid = p < a.n;
   uint64_t X = ~0ull, EE = 0, KEY = 0;
@@ -321,10 +322,10 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
   for (int w = 0; w < TB / 64; ++w)
     if (w < wave && wmax[w] > m) m = wmax[w];
   spm[tid] = m;
-  const uint64_t x_next = (blockIdx.x + 1 < a.ntiles) ? a.tile_x[blockIdx.x + 1] : ~0ull;
+  const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
   __syncthreads();
 
-  const uint32_t c_begin = a.carry_off[blockIdx.x], c_end = a.carry_off[blockIdx.x + 1];
+  const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
   const uint32_t n_chunks = (c_end - c_begin + CC - 1) / CC;
   const uint32_t n_batches = 2 + n_chunks;
 
