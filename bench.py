@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--others", type=int, default=2, help="timed steps for the other two flag sets (0 = skip them)")
     ap.add_argument("--pcie", action="store_true", help="also time swg_filter (host buffers in/out, PCIe included)")
+    ap.add_argument("--shuffle", action="store_true",
+                    help="random record order instead of group-major (no locality for the gathers; implies no CPU legs)")
     ap.add_argument("--parity-mappings", type=int, default=-1,
                     help="mappings of the timed workload checked against the oracle on all host threads "
                          "(-1 = auto: 2M (sweep) / 0.5M (scaffold pipelines) per host thread, up to the whole shard; 0 = skip)")
@@ -292,6 +294,13 @@ def main():
     ctx = sw.Context(local_rank)
     n = args.mappings
     cols, sizes = gen_shard(torch, n, args.genomes, args.seed + 7919 * rank, device)
+    if args.shuffle:  # the CPU legs index whole groups by position, so they are skipped for a shuffled shard
+        perm = torch.randperm(n, device=device)
+        for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
+            cols[k] = cols[k][perm].contiguous()
+        del perm
+        args.cpu_sample = 0
+        args.parity_mappings = 0
     torch.cuda.synchronize()
     rec = make_records(_lib, cols, n, args.genomes)
     cfg = make_config(sw, args.pipeline)
