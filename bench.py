@@ -409,6 +409,10 @@ def main():
             traffic = None
         pipe_achieved = algo * n / (ms_per_step * 1e-3) / 1e9
         cpu, parity, cpu_mt = (None, None, None)
+        if world > 1:  # the CPU legs belong to the N=1 run (rank 0 would keep the other ranks waiting at the last barrier)
+            args.cpu_sample = 0
+            if args.parity_mappings < 0:
+                args.parity_mappings = 0
         if args.cpu_sample > 0:
             cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main, args.genomes)
             cpu_mt = cpu_baseline_all_cores(cols, sizes, cfg, args.genomes, 0)
