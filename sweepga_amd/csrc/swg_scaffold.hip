@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     const uint32_t* __restrict__ a_te,
                                                     const uint32_t* __restrict__ a_dpair, int pos_bits,
                                                     const uint8_t* __restrict__ a_is_anchor,
-                                                    const uint8_t* __restrict__ in_filtered, uint64_t na,
+                                                    const uint8_t* __restrict__ in_filtered,
                                                     const uint32_t* __restrict__ pair_lo,
                                                     const uint32_t* __restrict__ pair_hi,
                                                     const uint64_t* __restrict__ b_key,
@@ -2088,7 +2088,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     SWG_KERNEL_CHECK(ctx);
     if (cfg->scaffold_max_deviation != 0 && na != 0) {
       SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, aflag,
-                                                          in_filtered, na, a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
+                                                          in_filtered, a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
                                                           cfg->scaffold_max_deviation, status_out, chain_out));
       SWG_KERNEL_CHECK(ctx);
     }
