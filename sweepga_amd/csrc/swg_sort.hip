@@ -406,7 +406,14 @@ constexpr int OS_THREADS = 256;
 constexpr int OS_ITEMS = SWG_OS_ITEMS;
 constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
 constexpr int OS_WAVES = OS_THREADS / 64;
-constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_GLOBAL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
+// look-back word: flag in the top two bits, count below.  32-bit words hold prefixes < 2^30; inputs of 2^30 .. 2^32-1
+// pairs use 64-bit words (same protocol, one relaxed 8-byte access instead of a 4-byte one).
+template <typename ST>
+struct os_word {
+  static constexpr ST LOCAL = ST(1) << (sizeof(ST) * 8 - 2);
+  static constexpr ST GLOBAL = ST(2) << (sizeof(ST) * 8 - 2);
+  static constexpr ST MASK = LOCAL - 1;
+};
 constexpr int OS_MAX_PASSES = 8;
 
 __global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n,
@@ -456,12 +463,13 @@ __global__ __launch_bounds__(RS_RADIX) void os_scan_hist_kernel(uint32_t* __rest
   row[threadIdx.x] = ex;
 }
 
+template <typename ST>
 __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint64_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, uint64_t n, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ gbase,
-                                                              uint32_t* status, uint32_t* ticket) {
+                                                              ST* status, uint32_t* ticket) {
   __shared__ uint64_t lkeys[OS_TILE];  // staging for the keys, then reused (as u32) for the values
   __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
   __shared__ uint32_t tile_excl[RS_RADIX];
@@ -526,28 +534,28 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
     uint32_t block_total;
     const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
     tile_excl[tid] = ex;
-    uint32_t excl = 0;
-    uint32_t* my = status + (size_t)tile * RS_RADIX + tid;
+    using W = os_word<ST>;
+    ST excl = 0;
+    ST* my = status + (size_t)tile * RS_RADIX + tid;
     if (tile == 0) {
-      __hip_atomic_store(my, OS_FLAG_GLOBAL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      __hip_atomic_store(my, OS_FLAG_LOCAL | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(my, W::LOCAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t tt = tile - 1;
       while (true) {
-        const uint32_t sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t f = sv & ~OS_VALUE_MASK;
+        const ST sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const ST f = sv & ~W::MASK;
         if (f == 0) {
           __builtin_amdgcn_s_sleep(1);
           continue;
         }
-        excl += sv & OS_VALUE_MASK;
-        if (f == OS_FLAG_GLOBAL) break;
+        excl += sv & W::MASK;
+        if (f == W::GLOBAL) break;
         --tt;  // LOCAL: keep looking back (tile 0 always publishes GLOBAL)
       }
-      __hip_atomic_store(my, OS_FLAG_GLOBAL | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(my, W::GLOBAL | (excl + (ST)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    dst_base[tid] = gbase[tid] + excl - ex;
+    dst_base[tid] = gbase[tid] + (uint32_t)excl - ex;
   }
   __syncthreads();
   // ---- reorder the tile in LDS: keys first, then the values through the same buffer
@@ -624,13 +632,17 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   const int npasses = (end_bit - begin_bit + 7) / 8;
   // SWG_SORT_FALLBACK=1 forces the histogram/scan/scatter path (otherwise only reached for n >= 2^30) so that the
   // tests can exercise it at small sizes
+  // SWG_SORT_WIDE=1 forces the 64-bit look-back words (otherwise only used for n >= 2^30)
   static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
-  if (force_fallback || n >= (uint64_t(1) << 30) || npasses > OS_MAX_PASSES)
+  static const bool force_wide = getenv("SWG_SORT_WIDE") != nullptr;
+  if (force_fallback || npasses > OS_MAX_PASSES)
     return radix_sort_three_kernel(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit);
+  const bool wide = force_wide || n >= (uint64_t(1) << 30);
+  const size_t word = wide ? sizeof(uint64_t) : sizeof(uint32_t);
   const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
   uint32_t* ghist = swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
-  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * RS_RADIX);
+  void* status = swg_arena_alloc(ctx, (size_t)ntiles * RS_RADIX * word);
   uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
@@ -646,9 +658,15 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     const int shift = begin_bit + 8 * p;
     const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * RS_RADIX, ctx->stream));
-    SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<<<ntiles, OS_THREADS, 0, ctx->stream>>>(*keys, *vals, *keys_alt, *vals_alt, n, shift, mask,
-                                                                          ghist + (size_t)p * RS_RADIX, status, tickets + p));
+    SWG_HIP(ctx, hipMemsetAsync(status, 0, word * (size_t)ntiles * RS_RADIX, ctx->stream));
+    if (wide)
+      SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<uint64_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
+                                     static_cast<uint64_t*>(status), tickets + p));
+    else
+      SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<uint32_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
+                                     static_cast<uint32_t*>(status), tickets + p));
     SWG_KERNEL_CHECK(ctx);
     uint64_t* tk = *keys;
     *keys = *keys_alt;
