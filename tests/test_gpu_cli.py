@@ -77,8 +77,10 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-def test_cli_with_fallback_sort_path(bins, tmp_path):
-    """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort (otherwise only used for n >= 2^30)."""
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE"])
+def test_cli_with_other_sort_paths(bins, tmp_path, knob):
+    """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
+    onesweep pass (otherwise only used for n >= 2^30)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
@@ -87,7 +89,7 @@ def test_cli_with_fallback_sort_path(bins, tmp_path):
     for k, flags in enumerate(FLAG_SETS[:4]):
         o1, o2 = tmp_path / f"gpu{k}.paf", tmp_path / f"ref{k}.paf"
         r = subprocess.run([cli, str(paf), "--output-file", str(o1), "--quiet", *flags], capture_output=True, text=True,
-                           env={**os.environ, "SWG_SORT_FALLBACK": "1"})
+                           env={**os.environ, knob: "1"})
         assert r.returncode == 0, r.stderr
         subprocess.check_call([ref, str(paf), "--output-file", str(o2), *flags])
         assert o1.read_bytes() == o2.read_bytes(), flags
