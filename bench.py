@@ -402,7 +402,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC run (same command, same n)
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_v28_hbm_traffic_sweep_100m.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_v30_hbm_traffic_sweep_100m.json")))
             if tj.get("n_mappings") == n and args.pipeline == "sweep" and dom_name in tj["kernels"]:
                 traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
@@ -444,7 +444,7 @@ def main():
                        "mappings_per_gpu": n, "groups_per_gpu": args.genomes * (args.genomes - 1)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_v28_hbm_traffic_sweep_100m.json)",
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_v30_hbm_traffic_sweep_100m.json)",
                          "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
                          "algorithmic_bytes_per_mapping": algo, "units_per_launch": n,
                          "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
