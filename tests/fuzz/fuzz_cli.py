@@ -2,7 +2,7 @@
 """End-to-end differential fuzz of the two command lines: sweepga-gpu (native ingest, GPU filter, ANI pre-pass,
 native egress) against oracle/sweepga-ref on random PAF texts and random flag sets (including aniN thresholds,
 --ani-method, --self, --scaffolds-only, --devices).  Outputs must be byte-identical.
-    python tools/fuzz_cli.py --minutes 5"""
+    python tests/fuzz/fuzz_cli.py --minutes 5"""
 import argparse
 import os
 import subprocess
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from sweepga_amd import build  # noqa: E402

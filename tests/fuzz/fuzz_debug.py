@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""Replays failing seeds of tools/fuzz_gpu.py seam by seam: mapping sweep alone, merge_mappings_into_chains on the
+"""Replays failing seeds of tests/fuzz/fuzz_gpu.py seam by seam: mapping sweep alone, merge_mappings_into_chains on the
 sweep survivors, plane_sweep_scaffolds on the filtered chains, then the whole pipeline.
-    python tools/fuzz_debug.py 477 581 ..."""
+    python tests/fuzz/fuzz_debug.py 477 581 ..."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 
 import sweepga_amd as sw  # noqa: E402
 from fuzz_gpu import random_case  # noqa: E402

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Shrinks a failing chaining case: isolates the (q,t,strand) group of the first differing record, then greedily
-drops records while the GPU/oracle chain assignments still differ.  python tools/fuzz_debug2.py <seed>"""
+drops records while the GPU/oracle chain assignments still differ.  python tests/fuzz/fuzz_debug2.py <seed>"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 
 import sweepga_amd as sw  # noqa: E402
 from fuzz_debug import sub_records  # noqa: E402,F401

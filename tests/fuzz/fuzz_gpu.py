@@ -5,7 +5,7 @@ zero-identity records, PanSN and plain names) x random configurations (filter mo
 scorings, gaps, masses, deviations, identity / length cut-offs, self, scaffolds-only).  Exact equality of status
 and chain numbers is required.  A failing case is written to gpurun_out/fuzz_fail_<seed>.json for replay.
 
-    python tools/fuzz_gpu.py --minutes 5 [--seed 0]
+    python tests/fuzz/fuzz_gpu.py --minutes 5 [--seed 0]
 """
 import argparse
 import json
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sweepga_amd as sw  # noqa: E402

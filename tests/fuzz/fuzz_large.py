@@ -2,7 +2,7 @@
 """Million-record shapes the bench workload does not have, GPU vs oracle (exact status and chain numbers):
 single giant chromosome pair at high depth, many chromosomes per genome (segments spanning several target sequences),
 thousands of tiny genome pairs, heavy coordinate ties, minus-strand only.  Oracle runs are spread over host threads.
-    python tools/fuzz_large.py [--records 1500000]"""
+    python tests/fuzz/fuzz_large.py [--records 1500000]"""
 import argparse
 import json
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sweepga_amd as sw  # noqa: E402

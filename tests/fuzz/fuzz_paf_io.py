@@ -2,7 +2,7 @@
 """CPU-only differential fuzz of the native PAF ingest (paf_io.cpp) against the oracle's extract_metadata:
 lines assembled from hostile field values (empty, signed, huge, fractional, hex, spaces), random tag soups
 (dv:f: / cg:Z: in any order and number, malformed ones), short lines, comment lines, CRLF, missing final newline.
-    python tools/fuzz_paf_io.py --minutes 2"""
+    python tests/fuzz/fuzz_paf_io.py --minutes 2"""
 import argparse
 import ctypes as C
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from sweepga_amd import PafFile, SwgError  # noqa: E402

@@ -3,7 +3,7 @@
   swg_plane_sweep (query / target / both; k from 1 to huge and infinity; any threshold and scoring; deep single
   segments with ties, duplicates, zero-length and zero-identity records), swg_plane_sweep_scaffolds and
   swg_merge_chains (dense groups, tiny to huge gaps, both strands).
-    python tools/fuzz_seams.py --minutes 5"""
+    python tests/fuzz/fuzz_seams.py --minutes 5"""
 import argparse
 import ctypes as C
 import json
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import sweepga_amd as sw  # noqa: E402

@@ -225,7 +225,7 @@ def test_filter_paf_byte_identical(sw, name):
 
 
 def test_chaining_equal_distance_candidates(sw):
-    """Found by tools/fuzz_gpu.py: B's candidates arrive as C (d), D (d, duplicate of C), E (smaller d but already
+    """Found by tests/fuzz/fuzz_gpu.py: B's candidates arrive as C (d), D (d, duplicate of C), E (smaller d but already
     taken by A).  The candidate list must keep C before D when E is inserted in front of them; the chain must then
     be B-C-D, not C-D alone (paf_filter.rs:839: strict `<`, the first minimum wins)."""
     rows = [(700, 750, 0, 50), (600, 750, 0, 150), (850, 950, 100, 150), (600, 700, 150, 250), (700, 750, 0, 50)]
@@ -241,11 +241,11 @@ def test_chaining_equal_distance_candidates(sw):
 
 @pytest.mark.parametrize("first_seed,extras", [(450, False), (3150, False), (5500, False), (0, True), (100_000, True)])
 def test_fuzz_slice(sw, first_seed, extras):
-    """Slices of tools/fuzz_gpu.py (random record sets x random configurations, exact status and chain numbers, every
+    """Slices of tests/fuzz/fuzz_gpu.py (random record sets x random configurations, exact status and chain numbers, every
     8th case also through swg_filter_multi).  The extras=False ranges contain seeds 477, 3190 and 5535, which failed
     before the candidate-list tie fix."""
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     from fuzz_gpu import run_case
     for seed in range(first_seed, first_seed + 60):
         ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed, extras)

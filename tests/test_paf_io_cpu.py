@@ -178,11 +178,11 @@ def test_open_buffer_and_errors(tmp_path):
 
 
 def test_fuzz_slice_against_oracle(tmp_path):
-    """A slice of tools/fuzz_paf_io.py: hostile field values and tag soups, native ingest == oracle extract_metadata."""
+    """A slice of tests/fuzz/fuzz_paf_io.py: hostile field values and tag soups, native ingest == oracle extract_metadata."""
     import subprocess
     import sys
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_paf_io.py"), "--minutes", "0.1", "--seed", "500000"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_paf_io.py"), "--minutes", "0.1", "--seed", "500000"],
                        capture_output=True, text=True, cwd=root)
     assert r.returncode == 0 and "'failures': 0" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
