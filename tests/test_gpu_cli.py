@@ -93,3 +93,29 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
         assert r.returncode == 0, r.stderr
         subprocess.check_call([ref, str(paf), "--output-file", str(o2), *flags])
         assert o1.read_bytes() == o2.read_bytes(), flags
+
+
+def test_memory_info_reserve_and_filter_paf_errors(tmp_path):
+    """swg_memory_info / swg_reserve, and error propagation of swg_filter_paf (missing input, unwritable output)."""
+    import sweepga_amd as sw
+    ctx = sw.Context(0)
+    try:
+        assert ctx.memory_info() == (0, 0)
+        ctx.reserve(64 << 20)
+        cap, _ = ctx.memory_info()
+        assert cap >= 64 << 20
+        rng = np.random.default_rng(3)
+        paf = tmp_path / "in.paf"
+        paf.write_text(gen.records_to_paf(rng, gen.random_records(rng, 2000)))
+        f = sw.PafFilter(sw.FilterConfig(), ctx=ctx)
+        f.filter_paf(paf, tmp_path / "out.paf")
+        cap2, peak = ctx.memory_info()
+        assert cap2 >= cap and 0 < peak <= cap2          # the reserved arena was enough: no grow-and-rerun
+        with pytest.raises(sw.SwgError, match="cannot open"):
+            f.filter_paf(tmp_path / "missing.paf", tmp_path / "o.paf")
+        with pytest.raises(sw.SwgError, match="cannot create"):
+            f.filter_paf(paf, tmp_path / "no_such_dir" / "o.paf")
+        f.filter_paf(paf, tmp_path / "out2.paf")           # the context is still usable after the errors
+        assert (tmp_path / "out2.paf").read_bytes() == (tmp_path / "out.paf").read_bytes()
+    finally:
+        ctx.close()
