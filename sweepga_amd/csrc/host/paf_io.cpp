@@ -255,7 +255,8 @@ int load_text(const char* path, int threads, Text* t) {
     if (map == MAP_FAILED) map = nullptr;
   }
   if (map) {
-    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL | MADV_WILLNEED);
+    madvise(map, (size_t)st.st_size, MADV_WILLNEED);  // advice values are not flags: one call per hint
+    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
     raw = static_cast<const unsigned char*>(map);
     raw_len = (size_t)st.st_size;
   } else {
