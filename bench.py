@@ -27,6 +27,10 @@ ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+# BASELINE.json's metric, verbatim
+BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
+
+
 def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000):
     """S-pan shard on the device: group-major order, as an aligner emits pairs."""
     g = torch.Generator(device=device)
@@ -424,7 +428,7 @@ def main():
         if pm > 0:
             parity_full = full_parity(cols, sizes, cfg, args.genomes, status_main, chain_main, pm)
         out = {
-            "metric": "PAF mappings/sec through plane-sweep+scaffold filter",
+            "metric": BASELINE_METRIC,
             "value": n * world / (elapsed / args.steps),
             "unit": "mappings/s",
             "n_gpus": world,
@@ -436,8 +440,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 coordinates, f64 scores",
             "data": "synthetic",
-            "config": {"workload": f"S-pan: {n} mappings per GPU over {args.genomes * (args.genomes - 1)} genome-pair groups "
-                                   f"({args.genomes} single-chromosome genomes), pipeline={args.pipeline}",
+            "config": {"workload": f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
+                                   f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {args.genomes * (args.genomes - 1)} "
+                                   f"genome-pair groups ({args.genomes} single-chromosome genomes), pipeline={args.pipeline}",
                        "flags": {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
                                  "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
                                  "default": "(defaults)"}[args.pipeline],
