@@ -11,7 +11,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 
 import sweepga_amd as sw  # noqa: E402
-from fuzz_debug import sub_records  # noqa: E402,F401
 from fuzz_gpu import random_case  # noqa: E402
 from tests import gen, orc  # noqa: E402
 

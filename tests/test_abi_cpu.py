@@ -3,7 +3,6 @@ header declares; the host mirror's pure-host logic (interning, PAF parsing, conf
 import os
 import re
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,6 @@
 CPU oracle: status AND chain numbers must match exactly.  -m gpu only."""
 import json
 import os
-import subprocess
 import tempfile
 
 import numpy as np
@@ -119,7 +118,6 @@ def test_merge_chains_long_dense_units(sw, seed, n, span, gap):
                              syntenic_frac=0.9)
     # keep one ordered genome pair only
     keep = [i for i in range(len(rec)) if rec.qname[i].startswith("g0") and rec.tname[i].startswith("g1")]
-    import dataclasses
     sub = orc.Records([rec.qname[i] for i in keep], [rec.tname[i] for i in keep],
                       *(np.ascontiguousarray(getattr(rec, f)[keep]) for f in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")),
                       np.arange(len(keep), dtype=np.uint64))
