@@ -19,6 +19,56 @@ static void die(const std::string& msg) {
   std::exit(2);
 }
 
+static // --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509): on the PAF path the value is only validated -- the
+// filter never reads FilterConfig.sparsity and no tree filter is applied to a PAF.  0 = fine (no effect),
+// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable.
+int check_sparsify(const std::string& v) {
+  auto frac_ok = [](const std::string& t, bool open_top) {
+    char* e = nullptr;
+    const double f = std::strtod(t.c_str(), &e);
+    if (t.empty() || e == t.c_str() || *e) return false;
+    return f > 0.0 && (open_top ? f < 1.0 : f <= 1.0);
+  };
+  {
+    char* e = nullptr;
+    const double f = std::strtod(v.c_str(), &e);
+    if (!v.empty() && e != v.c_str() && !*e) return (f > 0.0 && f <= 1.0) ? 0 : 2;
+  }
+  if (v == "none" || v == "all") return 0;
+  if (v == "auto") return 1;
+  if (v.rfind("random:", 0) == 0) return frac_ok(v.substr(7), false) ? 0 : 2;
+  if (v.rfind("giant:", 0) == 0 || v.rfind("connectivity:", 0) == 0) return frac_ok(v.substr(v.find(':') + 1), true) ? 1 : 2;
+  if (v.rfind("wfmash:", 0) == 0) return (v.substr(7) == "auto" || frac_ok(v.substr(7), false)) ? 1 : 2;
+  if (v.rfind("tree:", 0) == 0 || v.rfind("knn:", 0) == 0) {
+    const std::string body = v.substr(v.find(':') + 1);
+    unsigned long kn = 0, kf = 0;
+    double rf = 0.0;
+    int parts = 0;
+    for (size_t s0 = 0; s0 <= body.size(); ++parts) {
+      const size_t c = body.find(':', s0);
+      const std::string tok = body.substr(s0, c == std::string::npos ? std::string::npos : c - s0);
+      char* e = nullptr;
+      if (parts < 2) {
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) return 2;
+        (parts == 0 ? kn : kf) = std::strtoul(tok.c_str(), &e, 10);
+      } else if (parts == 2) {
+        rf = std::strtod(tok.c_str(), &e);
+        if (tok.empty() || e == tok.c_str() || *e) return 2;
+      } else {
+        return 2;
+      }
+      if (c == std::string::npos) {
+        ++parts;
+        break;
+      }
+      s0 = c + 1;
+    }
+    if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
+    return 0;
+  }
+  return 2;
+}
+
 int main(int argc, char** argv) {
   std::string input, output_file;
   std::string num_mappings = "many:many", scoring = "log-length-ani", min_identity = "0";
@@ -28,6 +78,7 @@ int main(int argc, char** argv) {
   bool have_block_length = false;
   uint64_t block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false;
+  std::string bad_sparsify;
 
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]);
@@ -64,6 +115,12 @@ int main(int argc, char** argv) {
     } else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
     else if (a == "--scaffolds-only") scaffolds_only = true;
     else if (a == "--ani-method") ani_method_s = value();
+    else if (a == "--sparsify") {
+      const std::string v = value();
+      const int rc = check_sparsify(v);
+      if (rc == 2) die("invalid value for --sparsify");
+      if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
+    }
     else if (a == "--no-adaptive-scaffolds" || a == "--quiet" || a == "--paf") { /* no effect here */ }
     else if (a == "--threads" || a == "-t") (void)value();
     else if (a.rfind("-", 0) == 0 && a != "-") die("unknown flag " + a);
@@ -83,6 +140,10 @@ int main(int argc, char** argv) {
     return 0;
   }
 
+  if (!bad_sparsify.empty()) {
+    std::fprintf(stderr, "sweepga-ref: --sparsify '%s' is not valid for post-alignment PAF/1aln filtering\n", bad_sparsify.c_str());
+    return 1;
+  }
   FilterConfig cfg;
   int mode;
   uint64_t pq, pt;

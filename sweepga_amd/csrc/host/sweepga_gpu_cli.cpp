@@ -129,6 +129,56 @@ bool parse_filter_mode(const std::string& mode, int32_t* fmode, uint64_t* pq, ui
   }
   return set(SWG_MODE_ONE_TO_ONE, 1, 1);
 }
+// --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509): on the PAF path the value is only validated -- the
+// filter never reads FilterConfig.sparsity and no tree filter is applied to a PAF.  0 = fine (no effect),
+// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable.
+int check_sparsify(const std::string& v) {
+  auto frac_ok = [](const std::string& t, bool open_top) {
+    char* e = nullptr;
+    const double f = std::strtod(t.c_str(), &e);
+    if (t.empty() || e == t.c_str() || *e) return false;
+    return f > 0.0 && (open_top ? f < 1.0 : f <= 1.0);
+  };
+  {
+    char* e = nullptr;
+    const double f = std::strtod(v.c_str(), &e);
+    if (!v.empty() && e != v.c_str() && !*e) return (f > 0.0 && f <= 1.0) ? 0 : 2;
+  }
+  if (v == "none" || v == "all") return 0;
+  if (v == "auto") return 1;
+  if (v.rfind("random:", 0) == 0) return frac_ok(v.substr(7), false) ? 0 : 2;
+  if (v.rfind("giant:", 0) == 0 || v.rfind("connectivity:", 0) == 0) return frac_ok(v.substr(v.find(':') + 1), true) ? 1 : 2;
+  if (v.rfind("wfmash:", 0) == 0) return (v.substr(7) == "auto" || frac_ok(v.substr(7), false)) ? 1 : 2;
+  if (v.rfind("tree:", 0) == 0 || v.rfind("knn:", 0) == 0) {
+    const std::string body = v.substr(v.find(':') + 1);
+    unsigned long kn = 0, kf = 0;
+    double rf = 0.0;
+    int parts = 0;
+    for (size_t s0 = 0; s0 <= body.size(); ++parts) {
+      const size_t c = body.find(':', s0);
+      const std::string tok = body.substr(s0, c == std::string::npos ? std::string::npos : c - s0);
+      char* e = nullptr;
+      if (parts < 2) {
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) return 2;
+        (parts == 0 ? kn : kf) = std::strtoul(tok.c_str(), &e, 10);
+      } else if (parts == 2) {
+        rf = std::strtod(tok.c_str(), &e);
+        if (tok.empty() || e == tok.c_str() || *e) return 2;
+      } else {
+        return 2;
+      }
+      if (c == std::string::npos) {
+        ++parts;
+        break;
+      }
+      s0 = c + 1;
+    }
+    if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
+    return 0;
+  }
+  return 2;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -141,6 +191,7 @@ int main(int argc, char** argv) {
   bool keep_self = false, no_filter = false, scaffolds_only = false, quiet = false;
   int device = 0, threads = 0;
   std::vector<int> devices;
+  std::string bad_sparsify;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], val;
     const size_t eq = a.find('=');
@@ -170,6 +221,12 @@ int main(int argc, char** argv) {
     else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
     else if (a == "--scaffolds-only") scaffolds_only = true;
     else if (a == "--ani-method") ani_method_s = value();
+    else if (a == "--sparsify") {
+      const std::string v = value();
+      const int rc = check_sparsify(v);
+      if (rc == 2) die(2, "invalid value for --sparsify");
+      if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
+    }
     else if (a == "--device") device = std::atoi(value().c_str());
     else if (a == "--devices") {  // comma-separated: shard the genome pairs over several GPUs of the node
       const std::string v = value();
@@ -198,6 +255,7 @@ int main(int argc, char** argv) {
   }
   if (input.empty()) die(2, "usage: sweepga-gpu <in.paf> [--output-file out.paf] [filter flags]   (--help)");
 
+  if (!no_filter && !bad_sparsify.empty()) die(1, "--sparsify '" + bad_sparsify + "' is not valid for post-alignment PAF/1aln filtering");
   swg_config cfg{};
   if (!parse_filter_mode(num_mappings, &cfg.mapping_filter_mode, &cfg.mapping_max_per_query, &cfg.mapping_max_per_target)) return 1;
   if (!parse_filter_mode(scaffold_filter, &cfg.scaffold_filter_mode, &cfg.scaffold_max_per_query, &cfg.scaffold_max_per_target)) return 1;

@@ -49,3 +49,21 @@ def test_without_gpu_exits_loudly(cli, tmp_path):
     p.write_text("a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\n")
     r = subprocess.run([cli, str(p)], capture_output=True, text=True)
     assert r.returncode == 3 and "no CPU fallback" in r.stderr and r.stdout == ""
+
+
+def test_sparsify_flag_is_validated_only(cli, tmp_path):
+    """--sparsify on the PAF path (src/knn_graph.rs:59-160, src/main.rs:3494-3509): accepted values have no effect on
+    the filter, pre-alignment strategies are refused after the --no-filter shortcut, garbage is a usage error."""
+    import os
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "sweepga-ref")
+    p = tmp_path / "a.paf"
+    p.write_text("a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\n")
+    for v, want in (("none", 0), ("all", 0), ("0.5", 0), ("random:0.3", 0), ("tree:2:1:0.1", 0), ("knn:3", 0), ("auto", 0),
+                    ("1.5", 2), ("tree:0", 2), ("random:2", 2), ("bogus", 2)):
+        for exe in (cli, ref):
+            r = subprocess.run([exe, str(p), "--no-filter", "--sparsify", v], capture_output=True, text=True)
+            assert r.returncode == want, (exe, v, r.returncode, r.stderr)
+    for v in ("auto", "giant:0.9", "connectivity:0.5", "wfmash:auto", "wfmash:0.2"):
+        for exe in (cli, ref):
+            r = subprocess.run([exe, str(p), "--sparsify", v], capture_output=True, text=True)
+            assert r.returncode == 1 and "not valid for post-alignment" in r.stderr, (exe, v, r.returncode, r.stderr)
