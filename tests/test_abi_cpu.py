@@ -26,17 +26,18 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_struct_layouts_match_header(lib, tmp_path):
-    """ctypes mirrors of swg_config / swg_records / swg_stats have the C compiler's sizes."""
+    """ctypes mirrors of swg_config / swg_records / swg_stats / swg_ani_input have the C compiler's sizes; the header
+    is plain C (compiled with gcc, not g++)."""
     import ctypes as C
     import subprocess
     from sweepga_amd import _lib
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "sweepga_gpu.h"\nint main(void){printf("%zu %zu %zu\\n",'
-                   'sizeof(swg_config),sizeof(swg_records),sizeof(swg_stats));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "sweepga_gpu.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
+                   'sizeof(swg_config),sizeof(swg_records),sizeof(swg_stats),sizeof(swg_ani_input));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(_lib.SwgConfig), C.sizeof(_lib.SwgRecords), C.sizeof(_lib.SwgStats)]
+    assert sizes == [C.sizeof(_lib.SwgConfig), C.sizeof(_lib.SwgRecords), C.sizeof(_lib.SwgStats), C.sizeof(_lib.SwgAniInput)]
 
 
 def test_no_gpu_is_a_loud_error(lib):
