@@ -435,33 +435,31 @@ int parse_text(swg_paf* p, int threads) {
     if (dbg) std::fprintf(stderr, "[swg paf] %s %.1f ms\n", what, ms_since(tp));
     tp = clk::now();
   };
-  // pass 1: lines and records per slice
+  // pass 1: lines per slice (a vectorisable byte count).  A record is a line with >= 11 fields -- nearly every line
+  // of a PAF -- so the columns are sized by the line count and every slice parses into the slots starting at its first
+  // line; the rare input with skipped lines is closed up afterwards.
   parallel_for(threads, [&](int t) {
     Slice& s = sl[t];
-    uint64_t lines = 0, recs = 0;
-    for (size_t pos = s.begin; pos < s.end;) {
-      const void* nl = std::memchr(text + pos, '\n', s.end - pos);
-      const size_t end = nl ? (size_t)(static_cast<const char*>(nl) - text) : s.end;
-      int tabs = 0;
-      for (const char *q = text + pos, *qe = text + end; q < qe && tabs < 10; ++q) tabs += *q == '\t';
-      recs += tabs >= 10;
-      ++lines;
-      pos = end + 1;
+    uint64_t nl = 0;
+    size_t i = s.begin;
+    for (; i + 8 <= s.end; i += 8) {  // eight bytes at a time: exact zero-byte mask of (word ^ "\n\n...")
+      uint64_t w;
+      std::memcpy(&w, text + i, 8);
+      w ^= 0x0a0a0a0a0a0a0a0aull;
+      const uint64_t t = (w & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full;
+      nl += (uint64_t)__builtin_popcountll(~(t | w | 0x7f7f7f7f7f7f7f7full));
     }
-    s.lines = lines;
-    s.recs = recs;
+    for (; i < s.end; ++i) nl += text[i] == '\n';
+    s.lines = nl + ((s.end > s.begin && text[s.end - 1] != '\n') ? 1 : 0);  // a last line without its newline
   });
-  lap("pass 1 (count)");
-  uint64_t n_lines = 0, n = 0;
+  lap("pass 1 (count lines)");
+  uint64_t n_lines = 0;
   for (auto& s : sl) {
     s.line_base = n_lines;
-    s.rec_base = n;
     n_lines += s.lines;
-    n += s.recs;
   }
   p->n_lines = n_lines;
-  if (n >= (uint64_t(1) << 31)) return paf_error(SWG_ERR_RANGE, "more than 2^31-1 records");
-  const size_t cap = n ? n : 1;
+  const size_t cap = n_lines ? n_lines : 1;
   for (auto* v : {&p->q_id, &p->t_id, &p->qs, &p->qe, &p->ts, &p->te, &p->matches, &p->block, &p->rec_len}) v->alloc(cap);
   p->identity.alloc(cap);
   p->strand.alloc(cap);
@@ -471,7 +469,7 @@ int parse_text(swg_paf* p, int threads) {
   // pass 2: parse into the columns
   parallel_for(threads, [&](int t) {
     Slice& s = sl[t];
-    uint64_t line = s.line_base, k = s.rec_base;
+    uint64_t line = s.line_base, k = s.line_base;
     const char* f[12];
     auto fail = [&](const char* what) {
       if (s.err == SWG_OK) {
@@ -534,12 +532,40 @@ int parse_text(swg_paf* p, int threads) {
       if (ll > 0xffffffffull) fail("line length");
       ++k;
     }
+    s.recs = k - s.line_base;
   });
   lap("alloc + pass 2 (parse)");
   for (auto& s : sl)
     if (s.err != SWG_OK)
       return paf_error(s.err, "%s >= 2^32 on line %llu is not supported by the GPU layout", s.err_what,
                        (unsigned long long)(s.err_line + 1));
+  // close the gaps left by skipped lines (slices in file order: a slice only ever moves towards the front)
+  uint64_t n = 0;
+  for (auto& s : sl) {
+    s.rec_base = n;
+    n += s.recs;
+  }
+  if (n >= (uint64_t(1) << 31)) return paf_error(SWG_ERR_RANGE, "more than 2^31-1 records");
+  if (n != n_lines) {
+    auto close_up = [&](auto& col) {
+      for (auto& s : sl)
+        if (s.recs && s.rec_base != s.line_base) std::memmove(col.data() + s.rec_base, col.data() + s.line_base, s.recs * sizeof(col[0]));
+    };
+    close_up(p->q_id);
+    close_up(p->t_id);
+    close_up(p->qs);
+    close_up(p->qe);
+    close_up(p->ts);
+    close_up(p->te);
+    close_up(p->matches);
+    close_up(p->block);
+    close_up(p->rec_len);
+    close_up(p->identity);
+    close_up(p->strand);
+    close_up(p->rank);
+    close_up(p->rec_off);
+    lap("close gaps");
+  }
 
   // global ids: slices in file order, each slice's names in its own first-appearance order
   {
