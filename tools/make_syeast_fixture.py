@@ -31,6 +31,9 @@ FLAG_SETS = {
     "c2_defaults": [],
     "c2_num_mappings_1to1": ["--num-mappings", "1:1"],
     "c2_full_1to1_rescue": ["--num-mappings", "1:1", "--scaffold-filter", "1:1", "--scaffold-dist", "20000"],
+    # identity thresholds from the ANI pre-pass (main.rs:3571-3595)
+    "c2_ani50_minus2": ["--min-aln-identity", "ani50-2"],
+    "c2_orthogonal_ani_scaffolds": ["--num-mappings", "1:1", "--min-scaffold-identity", "ani50-1", "--ani-method", "orthogonal"],
 }
 
 
