@@ -211,6 +211,10 @@ def end_to_end(n_lines, ref_lines, threads):
     import tempfile
     from sweepga_amd import build as _build
     ref_bin = os.path.join(ROOT, "oracle", "sweepga-ref")
+    if not os.path.exists(_build.CLI):
+        _build.build_cli()
+    if not os.path.exists(_build.SYNTH):
+        _build.build_synth()
     work = tempfile.mkdtemp(prefix="swg_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
         paf = os.path.join(work, "in.paf")

@@ -22,4 +22,15 @@ def _build_oracle():
     srcs = [os.path.join(odir, f) for f in os.listdir(odir) if f.endswith((".cpp", ".h"))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", odir, "-s"])
+    # the oracle's command line and the two host binaries are git-ignored build products: make sure they exist even if
+    # a snapshot of the tree came without them (the HIP library itself is never rebuilt here)
+    if not os.path.exists(os.path.join(odir, "sweepga-ref")):
+        subprocess.check_call(["make", "-C", odir, "-s"])
+    lib = os.path.join(ROOT, "sweepga_amd", "libsweepga_gpu.so")
+    if os.path.exists(lib):
+        from sweepga_amd import build
+        if not os.path.exists(build.CLI):
+            build.build_cli()
+        if not os.path.exists(build.SYNTH):
+            build.build_synth()
     yield
