@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- PAF mappings/s through the MI355X plane-sweep (+scaffold) filter.
+"""bench.py -- PAF mappings/s through the MI355X plane-sweep + scaffold filter.
 
-One "step" = one pass of the whole filter (PafFilter::apply_filters, src/paf_filter.rs:379-747)
-over one synthetic PAF shard that is already resident in HBM as the SoA of include/sweepga_gpu.h.
-Workload (BASELINE.json configs[3], "S-pan"): 100 single-chromosome genomes, 9,900 ordered
-non-self genome pairs ("10 k groups"), 10^8 mappings per GPU, lognormal group sizes; flags
-`--num-mappings 1:1 --scaffold-jump 0` by default (the sort+sweep path), `--pipeline full` for
-1:1 + scaffold chaining + scaffold 1:1 filter + rescue.  Genome pairs are independent, so with
-N GPUs every rank filters its own shard (weak scaling, no collective on the data path).
+One "step" = one pass of the whole filter (PafFilter::apply_filters, src/paf_filter.rs:379-747) over one synthetic
+record set that is already resident in HBM as the SoA of include/sweepga_gpu.h.
 
-Prints ONE JSON line on rank 0 (see the field list at the bottom).
+Workload of the headline (BASELINE.json configs[3], "S-pan" in SURVEY.md 8d): 100 single-chromosome genomes, 9,900
+ordered non-self genome pairs ("10 k groups"), 10^8 mappings per GPU, lognormal group sizes.  Three flag sets of the
+reference's command line are timed on it with the same K / W:
+    default  `sweepga <paf> --output-file ...` with every flag at its default (many:many, jump 50 k, mass 10 k)   <- `value`
+    sweep    `--num-mappings 1:1 --scaffold-jump 0`                      (the sort + plane-sweep path alone)
+    full     `--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000`   (BASELINE.json configs[4])
+and BASELINE.json configs[2] ("S-big1": ONE chromosome pair, 10^7 mappings, depth ~165) is timed beside them.
+
+N GPUs: one process per GPU (launched by torch.distributed.run, or by this script itself when it is started with
+--gpus N outside a launcher).  `--scaling weak` (default): every rank filters its own 10^8-mapping shard.
+`--scaling strong`: ONE 10^8 record set, genome pairs bin-packed over the ranks by sweepga_amd.shard (LPT), each
+rank filters its device-resident shard, kept-chain counts are exchanged (one all_gather of two small vectors) and
+every rank renumbers its own chains.  Genome pairs are independent units of the filter, so there is no other
+collective on the data path.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,26 +36,40 @@ if ROOT not in sys.path:
 ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
 ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-
+PROFILE_TAG = "r02"     # profiles/<tag>_hbm_traffic_<pipeline>_100m.json: rocprofv3 PMC bytes per launch
 
 # BASELINE.json's metric, verbatim
 BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
+PIPELINES = ("default", "sweep", "full")
+FLAGS = {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
+         "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
+         "default": "(defaults)"}
+REC_COLS = ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand")
+SBIG1_LEN = 248_956_422
 
 
-def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000):
-    """S-pan shard on the device: group-major order, as an aligner emits pairs."""
+def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pair=False):
+    """Synthetic records on the device, group-major order, as an aligner emits pairs.
+    S-pan: n_genomes single-chromosome genomes, every ordered non-self pair, lognormal(0.5) group sizes.
+    S-big1 (single_pair): every record maps sequence 0 onto sequence 1 (one query segment, one target segment)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    P = n_genomes * (n_genomes - 1)
-    w = torch.exp(0.5 * torch.randn(P, generator=g, device=device, dtype=torch.float64))
-    sizes = torch.floor(w / w.sum() * n).to(torch.int64)
-    sizes[0] += n - int(sizes.sum())
-    pair = torch.repeat_interleave(torch.arange(P, device=device, dtype=torch.int32), sizes)
-    q = torch.div(pair, n_genomes - 1, rounding_mode="floor")
-    t = pair - q * (n_genomes - 1)
-    t = t + (t >= q).to(torch.int32)
-    del pair
+    if single_pair:
+        sizes = torch.tensor([n], dtype=torch.int64, device=device)
+        q = torch.zeros(n, dtype=torch.int32, device=device)
+        t = torch.ones(n, dtype=torch.int32, device=device)
+    else:
+        P = n_genomes * (n_genomes - 1)
+        w = torch.exp(0.5 * torch.randn(P, generator=g, device=device, dtype=torch.float64))
+        sizes = torch.floor(w / w.sum() * n).to(torch.int64)
+        sizes[0] += n - int(sizes.sum())
+        pair = torch.repeat_interleave(torch.arange(P, device=device, dtype=torch.int32), sizes)
+        q = torch.div(pair, n_genomes - 1, rounding_mode="floor")
+        t = pair - q * (n_genomes - 1)
+        t = t + (t >= q).to(torch.int32)
+        del pair
     ln = torch.exp(7.6009 + 1.2 * torch.randn(n, generator=g, device=device)).clamp_(100, 500_000).to(torch.int32)
+    ln = torch.minimum(ln, torch.tensor(max(chr_len // 2, 100), dtype=torch.int32, device=device))
     room = (chr_len - ln).to(torch.float32)
     qs = (torch.rand(n, generator=g, device=device) * room).to(torch.int32)
     syn = torch.rand(n, generator=g, device=device) < 0.7
@@ -68,10 +93,17 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000):
     return cols, sizes
 
 
+def span_names(n_genomes):
+    return [f"g{i:03d}#1#chr1" for i in range(n_genomes)]
+
+
+SBIG1_NAMES = ["hgA#1#chr1", "hgB#1#chr1"]
+
+
 def make_records(lib_mod, cols, n, n_genomes):
     r = lib_mod.SwgRecords()
     r.n = n
-    for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
+    for k in REC_COLS:
         setattr(r, k, cols[k].data_ptr())
     r.n_seq = n_genomes
     r.seq_genome_last = cols["seq_genome_last"].data_ptr()
@@ -89,15 +121,19 @@ def make_config(sw, pipeline):
                                scaffold_gap=50_000, min_scaffold_length=10_000, scaffold_max_deviation=20_000)
     if pipeline == "default":  # all CLI defaults (many:many, jump 50k, mass 10k)
         return sw.FilterConfig()
-    raise SystemExit(f"unknown --pipeline {pipeline}")
+    raise SystemExit(f"unknown pipeline {pipeline}")
 
 
-def _oracle_records(cols, lo, hi, n_names):
+# ---- CPU side (the oracle = port of the reference; checker and cpu_baseline only) ---------------------------------
+def _host_cols(cols, lo, hi):
+    import numpy as np
+    return {k: np.ascontiguousarray(cols[k][lo:hi].cpu().numpy()) for k in REC_COLS}
+
+
+def _oracle_records(cols, lo, hi, names):
     import numpy as np
     from tests import orc
-    h = {k: cols[k][lo:hi].cpu().numpy() for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity",
-                                                   "matches", "block_len", "strand")}
-    names = [f"g{i:03d}#1#chr1" for i in range(n_names)]
+    h = _host_cols(cols, lo, hi)
     u = lambda a: np.ascontiguousarray(a.astype(np.uint64))
     return orc.Records([names[i] for i in h["q_id"]], [names[i] for i in h["t_id"]], u(h["q_start"]), u(h["q_end"]),
                        u(h["t_start"]), u(h["t_end"]), u(h["block_len"]), np.ascontiguousarray(h["identity"]),
@@ -117,7 +153,7 @@ def _oracle_config(cfg):
                       min_identity=cfg.min_identity, min_scaffold_identity=cfg.min_scaffold_identity)
 
 
-def cpu_baseline_all_cores(cols, sizes, cfg, n_names, first_group, per_thread=150_000, max_threads=32):
+def cpu_baseline_all_cores(cols, sizes, cfg, names, first_group, per_thread=150_000, max_threads=32):
     """'What a group-parallel CPU filter would give' (SURVEY.md 8d-ii): the same oracle on T host threads at once,
     every thread on its own whole genome-pair groups (the reference itself filters on one thread)."""
     import threading
@@ -132,7 +168,7 @@ def cpu_baseline_all_cores(cols, sizes, cfg, n_names, first_group, per_thread=15
         g2 = min(max(g2, g + 1), len(csum) - 1)
         if g2 <= g:
             break
-        jobs.append(_oracle_records(cols, int(csum[g]), int(csum[g2]), n_names))
+        jobs.append(_oracle_records(cols, int(csum[g]), int(csum[g2]), names))
         g = g2
     if not jobs:
         return None
@@ -150,7 +186,7 @@ def cpu_baseline_all_cores(cols, sizes, cfg, n_names, first_group, per_thread=15
                 sample=f"{len(jobs)} threads x ~{per_thread} mappings (whole groups), all started together, wall {wall:.2f} s")
 
 
-def full_parity(cols, sizes, cfg, n_names, status_dev, chain_dev, target, max_threads=64, groups_per_job=25):
+def full_parity(cols, sizes, cfg, names, status_dev, chain_dev, target, max_threads=64, groups_per_job=25):
     """Parity beyond the single-thread sample: the oracle over whole genome-pair groups on all host threads (groups
     are independent units of the filter), compared record by record with the device results of the timed workload."""
     import numpy as np
@@ -161,9 +197,7 @@ def full_parity(cols, sizes, cfg, n_names, status_dev, chain_dev, target, max_th
     g_hi = max(1, min(g_hi, len(csum) - 1))
     bounds = np.unique(np.concatenate([csum[0:g_hi:groups_per_job], [csum[g_hi]]]))
     m = int(bounds[-1])
-    h = {k: np.ascontiguousarray(cols[k][:m].cpu().numpy()) for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end",
-                                                                       "identity", "matches", "block_len", "strand")}
-    names = [f"g{i:03d}#1#chr1" for i in range(n_names)]
+    h = _host_cols(cols, 0, m)
     ost, och, wall = orc.apply_filters_by_groups(_oracle_config(cfg), h, names, bounds, T)
     gst = status_dev[:m].cpu().numpy()
     status_equal = bool(np.array_equal(gst, ost))
@@ -176,29 +210,24 @@ def full_parity(cols, sizes, cfg, n_names, status_dev, chain_dev, target, max_th
             "oracle_threads": T, "oracle_wall_s": wall, "oracle_value": m / wall, "unit": "mappings/s"}
 
 
-def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev, n_names):
+def cpu_baseline(cols, sizes, cfg, sample_target, status_dev, chain_dev, names):
     """The CPU oracle (port of the reference, 1 thread like the reference's filter) timed on a bounded
-    sample: the first whole genome-pair groups of this rank's shard.  Also the parity check."""
+    sample: the first whole genome-pair groups of this rank's shard.  Also a parity check."""
     import numpy as np
     from tests import orc
     csum = sizes.cumsum(0).cpu().numpy()
     g = int(np.searchsorted(csum, sample_target)) + 1
     m = int(csum[min(g, len(csum)) - 1])
-    rec = _oracle_records(cols, 0, m, n_names)
+    rec = _oracle_records(cols, 0, m, names)
     ocfg = _oracle_config(cfg)
     ost, och, secs = orc.apply_filters(ocfg, rec, want_seconds=True)
     gst = status_dev[:m].cpu().numpy()
     parity = bool(np.array_equal(gst, ost))
     if parity and cfg.scaffold_gap:
         # chain numbers are global to a call; compare the partition they induce on the sample
-        gch = chain_dev[:m].cpu().numpy()
-        a = {}
-        for x, y in zip(gch.tolist(), och.tolist()):
-            if (x == 0) != (y == 0) or a.setdefault(x, y) != y:
-                parity = False
-                break
+        parity = bool(orc.same_chain_partition(chain_dev[:m].cpu().numpy(), och))
     return dict(value=m / secs, unit="mappings/s", cores=1, kind="port",
-                sample=f"first {g} genome-pair groups of rank 0's shard = {m} mappings, oracle apply_filters {secs:.2f} s"), parity
+                sample=f"first {min(g, len(csum))} genome-pair groups of rank 0's shard = {m} mappings, oracle apply_filters {secs:.2f} s"), parity
 
 
 def end_to_end(n_lines, ref_lines, threads):
@@ -207,7 +236,6 @@ def end_to_end(n_lines, ref_lines, threads):
     import hashlib
     import re
     import shutil
-    import subprocess
     import tempfile
     from sweepga_amd import build as _build
     ref_bin = os.path.join(ROOT, "oracle", "sweepga-ref")
@@ -260,38 +288,270 @@ def end_to_end(n_lines, ref_lines, threads):
         shutil.rmtree(work, ignore_errors=True)
 
 
+# ---- timing ----------------------------------------------------------------------------------------------------
+class Runner:
+    """One context, one record set in HBM; times K calls of swg_filter_device per flag set."""
+
+    def __init__(self, torch, sw, lib_mod, ctx, device, dist, cols, n, n_seq):
+        self.torch, self.sw, self.lib_mod, self.ctx, self.device, self.dist = torch, sw, lib_mod, ctx, device, dist
+        self.cols, self.n = cols, n
+        self.rec = make_records(lib_mod, cols, n, n_seq)
+        self.status = torch.zeros(max(n, 1), dtype=torch.uint8, device=device)
+        self.chain = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        self.stats = lib_mod.SwgStats()
+
+    def step(self, ccfg, with_stats=False):
+        self.ctx.check(self.ctx.lib.swg_filter_device(self.ctx.handle, C.byref(self.rec), C.byref(ccfg), self.status.data_ptr(),
+                                                      self.chain.data_ptr(), C.byref(self.stats) if with_stats else None))
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        self.ctx.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def time(self, pipeline, steps, warmup, keep_results=False):
+        """W untimed steps, barrier + synchronize, exactly K timed steps, synchronize, MAX over ranks."""
+        torch, ctx = self.torch, self.ctx
+        cfg = make_config(self.sw, pipeline)
+        ccfg = cfg.to_c()
+        for _ in range(warmup):
+            self.step(ccfg)
+        self.barrier()
+        ctx.profile_reset()
+        ctx.profile(True)   # HIP events around every kernel launch on the library's own stream
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(ccfg)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        local_elapsed = elapsed
+        if self.dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        ctx.profile(False)
+        prof = ctx.profile_table()
+        self.step(ccfg, with_stats=True)  # untimed: counts for the report
+        ctx.synchronize()
+        s = self.stats
+        out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3, "prof": prof,
+               "counts": {"in": s.n_in, "retained": s.n_retained, "swept": s.n_swept, "chains": s.n_chains,
+                          "chains_kept": s.n_chains_kept, "out": s.n_out, "device_ms_last_step": s.device_ms}}
+        if keep_results:
+            out["status"], out["chain"] = self.status[:self.n].clone(), self.chain[:self.n].clone()
+        return out
+
+
+def roofline(pipeline, n, steps, t, n_ref_traffic):
+    """Dominant kernel of one flag set.  `achieved` follows the contract: ALGORITHMIC bytes of one call (SURVEY 8d:
+    33 or 47 B per mapping x the n mappings one launch works on) / that kernel's average launch duration, measured
+    with HIP events on the library's stream.  `kernel_own_*` is the kernel's own HBM traffic per launch (rocprofv3
+    PMC, committed under profiles/) / the same duration, and `pipeline_*` the end-to-end figure."""
+    algo = ALGO_BYTES_SWEEP if pipeline == "sweep" else ALGO_BYTES_FULL
+    prof = t["prof"]
+    total_kernel_ms = sum(ms for _, ms in prof.values())
+    dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
+    dom_avg_ms = dom_ms / max(dom_launches, 1)
+    achieved = algo * n / (dom_avg_ms * 1e-3) / 1e9
+    traffic, tfile = None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_100m.json"
+    try:
+        tj = json.load(open(os.path.join(ROOT, tfile)))
+        if tj.get("n_mappings") == n_ref_traffic and dom_name in tj["kernels"]:
+            traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    pipe_achieved = algo * n / (t["ms_per_step"] * 1e-3) / 1e9
+    own = traffic / (dom_avg_ms * 1e-3) / 1e9 if traffic else None
+    return {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_unit": f"HBM bytes per launch of that kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {tfile})",
+            "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / steps,
+            "algorithmic_bytes_per_mapping": algo, "units_per_launch": n,
+            "kernel_own_achieved": own, "kernel_own_frac": own / HBM_PEAK_GBPS if own else None,
+            "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
+            "kernel_ms_per_step": total_kernel_ms / steps}
+
+
+def kernels_table(t, steps):
+    return {k: round(v[1] / steps, 4) for k, v in sorted(t["prof"].items(), key=lambda kv: -kv[1][1])}
+
+
+# ---- configs[2]: S-big1 --------------------------------------------------------------------------------------------
+def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
+    """BASELINE.json configs[2]: 10^7 mappings in ONE (query, target) pair of 248,956,422-bp chromosomes (seed 1234).
+    Timed at full size for the three flag sets.  Parity inside the bench run is bounded: the oracle needs ~2 min for
+    the full 10^7 sweep and hours for the scaffold flags at this depth (its chaining scan is O(n x window)), so the bench
+    checks S-big1-shaped instances of the SAME depth (chromosome length scaled with n); the full-size record-for-record
+    check of the sweep flags lives in tests/test_gpu_sbig1.py."""
+    import threading
+    import numpy as np
+    from tests import orc
+    n = args.sbig1
+    cols, sizes = gen_shard(torch, n, 2, 1234, device, chr_len=SBIG1_LEN, single_pair=True)
+    run = Runner(torch, sw, lib_mod, ctx, device, None, cols, n, 2)
+    steps, warm = max(1, min(args.steps, 5)), 1
+    out = {"workload": f"BASELINE.json configs[2] (S-big1): {n} mappings in one pair {SBIG1_NAMES[0]} -> {SBIG1_NAMES[1]}, "
+                       f"{SBIG1_LEN} bp, seed 1234", "steps": steps, "warmup": warm, "pipelines": {}}
+    for p in ("sweep", "default", "full"):
+        t = run.time(p, steps, warm)
+        out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n / (t["ms_per_step"] * 1e-3),
+                               "unit": "mappings/s", "counts": t["counts"], "roofline": roofline(p, n, steps, t, -1),
+                               "kernels_ms_per_step": kernels_table(t, steps)}
+    del run, cols
+    if args.cpu_sample > 0:
+        jobs = [("sweep", args.sbig1_parity_sweep), ("default", args.sbig1_parity_scaffold), ("full", args.sbig1_parity_scaffold)]
+        res, threads = {}, []
+
+        def check(p, m):
+            c, _ = gen_shard(torch, m, 2, 1234, device, chr_len=max(int(SBIG1_LEN * (m / 1e7)), 1_000_000), single_pair=True)
+            r = Runner(torch, sw, lib_mod, sw.Context(device.index or 0), device, None, c, m, 2)
+            cfg = make_config(sw, p)
+            r.step(cfg.to_c())
+            r.ctx.synchronize()
+            st, ch = r.status[:m].cpu().numpy(), r.chain[:m].cpu().numpy()
+            rec = _oracle_records(c, 0, m, SBIG1_NAMES)
+            ost, och, secs = orc.apply_filters(_oracle_config(cfg), rec, want_seconds=True)
+            res[p] = {"mappings_checked": m, "same_depth_as_full_size": True, "status_equal": bool(np.array_equal(st, ost)),
+                      "chain_equal": bool(np.array_equal(ch, och)) if cfg.scaffold_gap else None,
+                      "oracle_s": secs, "cpu_baseline": {"value": m / secs, "unit": "mappings/s", "cores": 1, "kind": "port",
+                                                         "sample": f"{m} S-big1-shaped mappings (one pair, depth as at 10^7)"}}
+        for p, m in jobs:
+            if m > 0:
+                th = threading.Thread(target=check, args=(p, m))
+                th.start()
+                threads.append(th)
+        for th in threads:
+            th.join()
+        for p in res:
+            out["pipelines"][p]["parity"] = res[p]
+    return out
+
+
+# ---- strong scaling ------------------------------------------------------------------------------------------------
+def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world):
+    """ONE S-pan record set (the same on every rank, seed --seed), genome pairs bin-packed over the ranks by
+    sweepga_amd.shard (LPT by mapping count), every rank keeps only its shard in HBM and filters it; the kept-chain
+    ranges of all pairs are exchanged with one all_gather and every rank renumbers its own chains."""
+    import numpy as np
+    from sweepga_amd import shard
+    n, G = args.mappings, args.genomes
+    cols, _ = gen_shard(torch, n, G, args.seed, device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    q_h, t_h = cols["q_id"].cpu().numpy(), cols["t_id"].cpu().numpy()
+    table = np.arange(G, dtype=np.uint32)
+    shard_of_key, counts = shard.plan_dense(q_h, t_h, table, G, world)
+    plan_s = time.perf_counter() - t0
+    loads = np.bincount(shard_of_key[counts > 0], weights=counts[counts > 0], minlength=world)
+    t0 = time.perf_counter()
+    key_d = cols["q_id"].to(torch.int64) * G + cols["t_id"].to(torch.int64)
+    mine = torch.nonzero(torch.as_tensor(shard_of_key, device=device)[key_d] == rank).flatten()
+    scols = {k: cols[k][mine].contiguous() for k in REC_COLS}
+    scols["seq_genome_last"], scols["seq_genome_two"] = cols["seq_genome_last"], cols["seq_genome_two"]
+    pair_mine = key_d[mine]
+    m = int(mine.numel())
+    del cols, key_d
+    torch.cuda.synchronize()
+    partition_s = time.perf_counter() - t0
+    run = Runner(torch, sw, lib_mod, ctx, device, dist, scols, m, G)
+    res = {}
+    for p in PIPELINES:
+        t = run.time(p, args.steps, args.warmup, keep_results=True)
+        lt = torch.tensor([t["local_elapsed"] / args.steps * 1e3], dtype=torch.float64, device=device)
+        per_rank = [torch.zeros_like(lt) for _ in range(world)]
+        if dist is not None:
+            dist.all_gather(per_rank, lt)
+        else:
+            per_rank = [lt]
+        per_rank_ms = [float(x.item()) for x in per_rank]
+        # exchange + local renumbering (chain numbers are global in the reference, src/paf_filter.rs:517-521)
+        renumber_s = None
+        if t["cfg"].scaffold_gap:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ch = t["chain"].cpu().numpy().astype(np.int64)
+            pr = pair_mine.cpu().numpy()
+            idx = mine.cpu().numpy()
+            lo, hi, first = shard.pair_chain_ranges(ch, pr, idx, G * G, n)
+            if dist is not None:
+                buf = torch.as_tensor(np.stack([lo, -hi, first]), device=device)
+                dist.all_reduce(buf, op=dist.ReduceOp.MIN)   # every pair lives on exactly one rank
+                lo, hi, first = buf[0].cpu().numpy(), -buf[1].cpu().numpy(), buf[2].cpu().numpy()
+            shift = shard.chain_shifts(lo, hi, first)
+            has = ch != 0
+            ch[has] += shift[pr[has]]
+            renumber_s = time.perf_counter() - t1
+        res[p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n / (t["ms_per_step"] * 1e-3), "unit": "mappings/s",
+                  "per_rank_ms": per_rank_ms, "renumber_s": renumber_s, "counts_rank0": t["counts"]}
+    return {"mappings_total": n, "plan_s": plan_s, "partition_s": partition_s, "shard_mappings_rank0": m,
+            "load_max_over_mean": float(loads.max() / loads.mean()), "loads": [int(x) for x in loads], "pipelines": res}
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` outside a launcher: start N ranks as fresh child processes (torch.distributed.run) BEFORE this
+    process touches a GPU, and pass their exit code on."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mappings", type=int, default=100_000_000, help="mappings per GPU")
+    ap.add_argument("--mappings", type=int, default=100_000_000, help="mappings per GPU (weak) / in total (strong)")
     ap.add_argument("--genomes", type=int, default=100)
-    ap.add_argument("--pipeline", default="sweep", choices=["sweep", "full", "default"])
-    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="mappings in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pipeline", default="default", choices=list(PIPELINES), help="flag set reported as `value`")
+    ap.add_argument("--only", action="store_true", help="time only --pipeline (profiling runs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="mappings in the 1-thread CPU sample (0 = no CPU legs)")
     ap.add_argument("--seed", type=int, default=2025)
-    ap.add_argument("--others", type=int, default=2, help="timed steps for the other two flag sets (0 = skip them)")
-    ap.add_argument("--pcie", action="store_true", help="also time swg_filter (host buffers in/out, PCIe included)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the swg_filter leg (host buffers in/out, PCIe included)")
     ap.add_argument("--shuffle", action="store_true",
                     help="random record order instead of group-major (no locality for the gathers; implies no CPU legs)")
     ap.add_argument("--parity-mappings", type=int, default=-1,
                     help="mappings of the timed workload checked against the oracle on all host threads "
-                         "(-1 = auto: 2M (sweep) / 0.5M (scaffold pipelines) per host thread, up to the whole shard; 0 = skip)")
-    ap.add_argument("--e2e", type=int, default=0, help="lines of synthetic PAF for the file->file leg (0 = skip)")
+                         "(-1 = auto: 2M (sweep) / 0.5M (scaffold flag sets) per host thread, up to the whole shard; 0 = skip)")
+    ap.add_argument("--sbig1", type=int, default=10_000_000, help="mappings of the S-big1 leg (configs[2]); 0 = skip")
+    ap.add_argument("--sbig1-parity-sweep", type=int, default=1_000_000)
+    ap.add_argument("--sbig1-parity-scaffold", type=int, default=200_000)
+    ap.add_argument("--e2e", type=int, default=10_000_000, help="lines of synthetic PAF for the file->file leg (0 = skip)")
     ap.add_argument("--e2e-ref", type=int, default=1_000_000, help="prefix of that file the oracle CLI is timed on")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the e2e leg (0 = all cores)")
     args = ap.parse_args()
 
-    import torch
+    launched = "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; refusing to report a {world}-GPU number as "
+              f"{args.gpus}-GPU", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
+    if launched:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
@@ -300,175 +560,116 @@ def main():
     import sweepga_amd as sw
     from sweepga_amd import _lib
     ctx = sw.Context(local_rank)
-    n = args.mappings
-    cols, sizes = gen_shard(torch, n, args.genomes, args.seed + 7919 * rank, device)
-    if args.shuffle:  # the CPU legs index whole groups by position, so they are skipped for a shuffled shard
-        perm = torch.randperm(n, device=device)
-        for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
-            cols[k] = cols[k][perm].contiguous()
-        del perm
-        args.cpu_sample = 0
-        args.parity_mappings = 0
-    torch.cuda.synchronize()
-    rec = make_records(_lib, cols, n, args.genomes)
-    cfg = make_config(sw, args.pipeline)
-    ccfg = cfg.to_c()
-    status = torch.zeros(n, dtype=torch.uint8, device=device)
-    chain = torch.zeros(n, dtype=torch.int32, device=device)
-    stats = _lib.SwgStats()
+    n, G = args.mappings, args.genomes
+    names = span_names(G)
+    order = [args.pipeline] + ([] if args.only else [p for p in PIPELINES if p != args.pipeline])
+    out = None
 
-    def step(with_stats=False):
-        ctx.check(ctx.lib.swg_filter_device(ctx.handle, C.byref(rec), C.byref(ccfg), status.data_ptr(), chain.data_ptr(),
-                                            C.byref(stats) if with_stats else None))
-
-    def barrier():
+    if args.scaling == "strong":
+        ss = strong_scaling(torch, sw, _lib, ctx, device, dist, args, rank, world)
+        if rank == 0:
+            head = ss["pipelines"][args.pipeline]
+            out = {"metric": BASELINE_METRIC, "value": head["value"], "unit": "mappings/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "u32 coordinates, f64 scores", "data": "synthetic",
+                   "config": {"workload": f"BASELINE.json configs[3]/[4]: ONE S-pan record set of {n} mappings over {G * (G - 1)} "
+                                          f"genome-pair groups, sharded by genome pair over {world} GPU(s) (LPT by mapping count), "
+                                          f"pipeline={args.pipeline}", "flags": FLAGS[args.pipeline]},
+                   "strong_scaling": ss}
+    else:
+        cols, sizes = gen_shard(torch, n, G, args.seed + 7919 * rank, device)
+        if args.shuffle:  # the CPU legs index whole groups by position, so they are skipped for a shuffled shard
+            perm = torch.randperm(n, device=device)
+            for k in REC_COLS:
+                cols[k] = cols[k][perm].contiguous()
+            del perm
+            args.cpu_sample = 0
+            args.parity_mappings = 0
         torch.cuda.synchronize()
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+        run = Runner(torch, sw, _lib, ctx, device, dist, cols, n, G)
+        cpu_legs = world == 1 and args.cpu_sample > 0   # the CPU legs belong to the N=1 run
+        timed = {p: run.time(p, args.steps, args.warmup, keep_results=cpu_legs) for p in order}
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_reset()
-    ctx.profile(True)   # HIP events around every kernel launch on the library's own stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ctx.profile(False)
-    prof = ctx.profile_table()
-    step(with_stats=True)  # untimed: counts for the report
-    ctx.synchronize()
-    main_counts = {"in": stats.n_in, "retained": stats.n_retained, "swept": stats.n_swept, "chains": stats.n_chains,
-                   "chains_kept": stats.n_chains_kept, "out": stats.n_out, "device_ms_last_step": stats.device_ms}
-    status_main, chain_main = status.clone(), chain.clone()
+        pcie = None
+        if not args.no_pcie and rank == 0 and world == 1:
+            import numpy as np
+            host = {k: v.cpu().numpy() for k, v in cols.items()}
+            hrec = _lib.SwgRecords()
+            hrec.n = n
+            for k in REC_COLS + ("seq_genome_last", "seq_genome_two"):
+                setattr(hrec, k, host[k].ctypes.data)
+            hrec.n_seq = hrec.n_genome_last = hrec.n_genome_two = G
+            hst = np.zeros(n, dtype=np.uint8)
+            hch = np.zeros(n, dtype=np.uint32)
+            hs = _lib.SwgStats()
+            ccfg = make_config(sw, args.pipeline).to_c()
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(hrec), C.byref(ccfg), hst.ctypes.data, hch.ctypes.data, C.byref(hs)))
+                dt = time.perf_counter() - t1
+                if best is None or dt < best[0]:
+                    best = (dt, hs.h2d_ms, hs.d2h_ms, hs.device_ms)
+            pcie = {"value": n / best[0], "unit": "mappings/s", "ms": best[0] * 1e3, "h2d_ms": best[1], "d2h_ms": best[2],
+                    "device_ms": best[3], "flags": FLAGS[args.pipeline],
+                    "note": "swg_filter: pageable host buffers in and out (what a host binding calls), best of 3"}
+            del host, hst, hch
 
-    # the other flag sets of the same workload (shorter, same timing discipline), for the record
-    others = {}
-    if args.others > 0:
-        for name in ("sweep", "full", "default"):
-            if name == args.pipeline:
-                continue
-            ocfg = make_config(sw, name).to_c()
-
-            def ostep(with_stats=False):
-                ctx.check(ctx.lib.swg_filter_device(ctx.handle, C.byref(rec), C.byref(ocfg), status.data_ptr(),
-                                                    chain.data_ptr(), C.byref(stats) if with_stats else None))
-            ostep()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.others):
-                ostep()
-            ctx.synchronize()
-            dt = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([dt], dtype=torch.float64, device=device)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
-            ostep(with_stats=True)
-            ctx.synchronize()
-            others[name] = {"value": n * world / (dt / args.others), "unit": "mappings/s", "ms_per_step": dt / args.others * 1e3,
-                            "steps": args.others, "out": stats.n_out, "chains": stats.n_chains, "chains_kept": stats.n_chains_kept}
-
-    pcie = None
-    if args.pcie and rank == 0:
-        import numpy as np
-        host = {k: v.cpu().numpy() for k, v in cols.items()}
-        hrec = _lib.SwgRecords()
-        hrec.n = n
-        for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand",
-                  "seq_genome_last", "seq_genome_two"):
-            setattr(hrec, k, host[k].ctypes.data)
-        hrec.n_seq = hrec.n_genome_last = hrec.n_genome_two = args.genomes
-        hst = np.zeros(n, dtype=np.uint8)
-        hch = np.zeros(n, dtype=np.uint32)
-        hs = _lib.SwgStats()
-        for _ in range(2):
-            t1 = time.perf_counter()
-            ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(hrec), C.byref(ccfg), hst.ctypes.data, hch.ctypes.data, C.byref(hs)))
-            dt = time.perf_counter() - t1
-        pcie = {"value": n / dt, "unit": "mappings/s", "ms": dt * 1e3, "h2d_ms": hs.h2d_ms, "d2h_ms": hs.d2h_ms,
-                "device_ms": hs.device_ms, "note": "swg_filter: pageable host buffers in and out, second call"}
-
-    e2e = end_to_end(args.e2e, args.e2e_ref, args.threads) if (args.e2e > 0 and rank == 0 and world == 1) else None
+        if rank == 0:
+            pipes = {}
+            for p in order:
+                t = timed[p]
+                e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n * world / (t["ms_per_step"] * 1e-3),
+                     "unit": "mappings/s", "steps": args.steps, "warmup": args.warmup, "counts": t["counts"],
+                     "roofline": roofline(p, n, args.steps, t, 100_000_000), "kernels_ms_per_step": kernels_table(t, args.steps)}
+                if cpu_legs:
+                    cb, par = cpu_baseline(cols, sizes, t["cfg"], args.cpu_sample if p == "sweep" else args.cpu_sample // 4,
+                                           t["status"], t["chain"], names)
+                    e["cpu_baseline"], e["parity_vs_oracle_on_sample"] = cb, par
+                    e["cpu_baseline_all_cores"] = cpu_baseline_all_cores(cols, sizes, t["cfg"], names, 0)
+                    pm = args.parity_mappings
+                    if pm < 0:
+                        per_thread = 2_000_000 if p == "sweep" else 500_000  # ~10 s of oracle time either way
+                        pm = min(n, per_thread * min(os.cpu_count() or 1, 64))
+                    e["parity_all_threads"] = full_parity(cols, sizes, t["cfg"], names, t["status"], t["chain"], pm) if pm > 0 else None
+                    del t["status"], t["chain"]
+                pipes[p] = e
+            head = pipes[args.pipeline]
+            out = {
+                "metric": BASELINE_METRIC,
+                "value": head["value"],
+                "unit": "mappings/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": head["ms_per_step"],
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "u32 coordinates, f64 scores",
+                "data": "synthetic",
+                "config": {"workload": f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
+                                       f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {G * (G - 1)} "
+                                       f"genome-pair groups ({G} single-chromosome genomes), pipeline={args.pipeline}",
+                           "flags": FLAGS[args.pipeline], "mappings_per_gpu": n, "groups_per_gpu": G * (G - 1)},
+                "roofline": head["roofline"],
+                "cpu_baseline": head.get("cpu_baseline"),
+                "cpu_baseline_all_cores": head.get("cpu_baseline_all_cores"),
+                "parity_vs_oracle_on_sample": head.get("parity_vs_oracle_on_sample"),
+                "parity_all_threads": head.get("parity_all_threads"),
+                "counts": head["counts"],
+                "pipelines": pipes,
+                "pcie_inclusive": pcie,
+                "arena_bytes_per_mapping": {"capacity": ctx.memory_info()[0] / n, "peak_last_call": ctx.memory_info()[1] / n},
+                "kernels_ms_per_step": head["kernels_ms_per_step"],
+            }
+        del run, cols
+        if rank == 0 and world == 1:
+            torch.cuda.empty_cache()
+            out["sbig1"] = sbig1_leg(torch, sw, _lib, ctx, device, args) if args.sbig1 > 0 else None
+            out["end_to_end"] = end_to_end(args.e2e, args.e2e_ref, args.threads) if args.e2e > 0 else None
 
     if rank == 0:
-        algo = ALGO_BYTES_SWEEP if args.pipeline == "sweep" else ALGO_BYTES_FULL
-        ms_per_step = elapsed / args.steps * 1e3
-        total_kernel_ms = sum(ms for _, ms in prof.values())
-        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
-        dom_name, (dom_launches, dom_ms) = dom
-        dom_avg_ms = dom_ms / max(dom_launches, 1)
-        achieved = algo * n / (dom_avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC run (same command, same n)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_v30_hbm_traffic_sweep_100m.json")))
-            if tj.get("n_mappings") == n and args.pipeline == "sweep" and dom_name in tj["kernels"]:
-                traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        pipe_achieved = algo * n / (ms_per_step * 1e-3) / 1e9
-        cpu, parity, cpu_mt = (None, None, None)
-        if world > 1:  # the CPU legs belong to the N=1 run (rank 0 would keep the other ranks waiting at the last barrier)
-            args.cpu_sample = 0
-            if args.parity_mappings < 0:
-                args.parity_mappings = 0
-        if args.cpu_sample > 0:
-            cpu, parity = cpu_baseline(cols, sizes, cfg, args.cpu_sample, status_main, chain_main, args.genomes)
-            cpu_mt = cpu_baseline_all_cores(cols, sizes, cfg, args.genomes, 0)
-        parity_full = None
-        pm = args.parity_mappings
-        if pm < 0:
-            per_thread = 2_000_000 if args.pipeline == "sweep" else 500_000  # ~10 s of oracle time either way
-            pm = min(n, per_thread * min(os.cpu_count() or 1, 64)) if args.cpu_sample > 0 else 0
-        if pm > 0:
-            parity_full = full_parity(cols, sizes, cfg, args.genomes, status_main, chain_main, pm)
-        out = {
-            "metric": BASELINE_METRIC,
-            "value": n * world / (elapsed / args.steps),
-            "unit": "mappings/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32 coordinates, f64 scores",
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
-                                   f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {args.genomes * (args.genomes - 1)} "
-                                   f"genome-pair groups ({args.genomes} single-chromosome genomes), pipeline={args.pipeline}",
-                       "flags": {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
-                                 "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
-                                 "default": "(defaults)"}[args.pipeline],
-                       "mappings_per_gpu": n, "groups_per_gpu": args.genomes * (args.genomes - 1)},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_v30_hbm_traffic_sweep_100m.json)",
-                         "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / args.steps,
-                         "algorithmic_bytes_per_mapping": algo, "units_per_launch": n,
-                         "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
-                         "kernel_ms_per_step": total_kernel_ms / args.steps},
-            "cpu_baseline": cpu,
-            "cpu_baseline_all_cores": cpu_mt,
-            "parity_vs_oracle_on_sample": parity,
-            "parity_all_threads": parity_full,
-            "counts": main_counts,
-            "other_pipelines": others,
-            "pcie_inclusive": pcie,
-            "end_to_end": e2e,
-            "arena_bytes_per_mapping": {"capacity": ctx.memory_info()[0] / n, "peak_last_call": ctx.memory_info()[1] / n},
-            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
-        }
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

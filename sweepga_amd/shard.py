@@ -35,6 +35,20 @@ def names_allow_sharding(index: SequenceIndex) -> bool:
     return all(SequenceIndex.prefix_last(nm) == SequenceIndex.prefix_two(nm) for nm in index.names)
 
 
+def lpt(counts: np.ndarray, world: int) -> np.ndarray:
+    """Longest-processing-time bin packing (deterministic: largest first, ties by id): shard of every unit."""
+    shard_of = np.zeros(len(counts), dtype=np.int32)
+    load = np.zeros(world, dtype=np.int64)
+    order = np.lexsort((np.arange(len(counts)), -np.asarray(counts, dtype=np.int64)))
+    for p in order:
+        if counts[p] == 0:
+            continue
+        r = int(np.argmin(load))
+        shard_of[p] = r
+        load[r] += counts[p]
+    return shard_of
+
+
 def plan(packed: PackedRecords, world: int) -> ShardPlan:
     """Longest-processing-time bin packing of genome pairs by mapping count (deterministic)."""
     n = packed.n
@@ -42,16 +56,53 @@ def plan(packed: PackedRecords, world: int) -> ShardPlan:
     key = g2[packed.cols["q_id"]].astype(np.uint64) * np.uint64(packed.n_genome_two) + g2[packed.cols["t_id"]].astype(np.uint64)
     uniq, inv, counts = np.unique(key, return_inverse=True, return_counts=True)
     ok = world > 1 and packed.index is not None and names_allow_sharding(packed.index)
-    shard_of_pair = np.zeros(len(uniq), dtype=np.int32)
-    if ok:
-        load = np.zeros(world, dtype=np.int64)
-        order = np.lexsort((np.arange(len(uniq)), -counts))  # largest first, ties by pair id
-        for p in order:
-            r = int(np.argmin(load))
-            shard_of_pair[p] = r
-            load[r] += counts[p]
+    shard_of_pair = lpt(counts, world) if ok else np.zeros(len(uniq), dtype=np.int32)
     return ShardPlan(world, shard_of_pair[inv].astype(np.int32) if n else np.zeros(0, np.int32), inv.astype(np.int64),
                      len(uniq), bool(ok))
+
+
+def plan_dense(q_id: np.ndarray, t_id: np.ndarray, seq_genome_two: np.ndarray, n_genome_two: int, world: int):
+    """The same plan without sorting the records: genome-pair key = genome(q) * G + genome(t) counted into a dense G x G
+    table (for the 10^8-record sets of bench.py --scaling strong; G^2 must be small).  Returns (shard of every key,
+    mappings of every key)."""
+    G = int(n_genome_two)
+    if G * G > (1 << 26):
+        raise ValueError("plan_dense: genome-pair table too large, use plan()")
+    g2 = np.asarray(seq_genome_two, dtype=np.int64)
+    key = g2[q_id] * G + g2[t_id]
+    counts = np.bincount(key, minlength=G * G).astype(np.int64)
+    return lpt(counts, world), counts
+
+
+def pair_chain_ranges(chain: np.ndarray, pair: np.ndarray, record_index: np.ndarray, n_pairs: int, n_total: int, retained=None):
+    """Per genome pair, over the records of ONE shard: lowest / highest shard-local chain number and the first retained
+    record (global index).  Pairs without records keep (int64 max, 0, n_total), so the per-pair results of several shards
+    combine with min / max / min (every pair lives on exactly one shard)."""
+    big = np.iinfo(np.int64).max
+    lo = np.full(n_pairs, big, dtype=np.int64)
+    hi = np.zeros(n_pairs, dtype=np.int64)
+    first = np.full(n_pairs, n_total, dtype=np.int64)
+    has = chain != 0
+    np.minimum.at(lo, pair[has], chain[has].astype(np.int64))
+    np.maximum.at(hi, pair[has], chain[has].astype(np.int64))
+    if retained is None:
+        np.minimum.at(first, pair, record_index.astype(np.int64))
+    else:
+        np.minimum.at(first, pair[retained], record_index[retained].astype(np.int64))
+    return lo, hi, first
+
+
+def chain_shifts(lo: np.ndarray, hi: np.ndarray, first: np.ndarray) -> np.ndarray:
+    """What to add to a pair's shard-local chain numbers to make them global: kept chains are numbered genome pair by
+    genome pair in the order the pairs first appear (src/paf_filter.rs:517-521 over plane_sweep_scaffolds' output order),
+    and inside a shard a pair's kept chains are the contiguous numbers lo..hi."""
+    shift = np.zeros(len(lo), dtype=np.int64)
+    with_chains = np.nonzero(hi > 0)[0]
+    order = with_chains[np.argsort(first[with_chains], kind="stable")]
+    counts = hi[order] - lo[order] + 1
+    offsets = np.concatenate(([0], np.cumsum(counts)[:-1])) if len(order) else np.zeros(0, dtype=np.int64)
+    shift[order] = offsets - (lo[order] - 1)
+    return shift
 
 
 def subset(packed: PackedRecords, idx: np.ndarray) -> PackedRecords:
@@ -81,19 +132,8 @@ def merge(packed: PackedRecords, pl: ShardPlan, parts: List[tuple], retained: np
         return status, chain  # one shard: the numbers are already global
     pair = pl.pair_of_record
     has = chain != 0
-    lo = np.full(pl.n_pairs, np.iinfo(np.int64).max, dtype=np.int64)
-    hi = np.zeros(pl.n_pairs, dtype=np.int64)
-    np.minimum.at(lo, pair[has], chain[has].astype(np.int64))
-    np.maximum.at(hi, pair[has], chain[has].astype(np.int64))
-    first = np.full(pl.n_pairs, n, dtype=np.int64)
-    ridx = np.nonzero(retained)[0]
-    np.minimum.at(first, pair[ridx], ridx)
-    with_chains = np.nonzero(hi > 0)[0]
-    order = with_chains[np.argsort(first[with_chains], kind="stable")]
-    counts = hi[order] - lo[order] + 1
-    offsets = np.concatenate(([0], np.cumsum(counts)[:-1]))
-    shift = np.zeros(pl.n_pairs, dtype=np.int64)
-    shift[order] = offsets - (lo[order] - 1)
+    lo, hi, first = pair_chain_ranges(chain, pair, np.arange(n), pl.n_pairs, n, retained)
+    shift = chain_shifts(lo, hi, first)
     chain[has] = (chain[has].astype(np.int64) + shift[pair[has]]).astype(np.uint32)
     return status, chain
 

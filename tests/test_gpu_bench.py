@@ -1,5 +1,6 @@
-"""bench.py contract (one JSON line with `roofline` and `cpu_baseline`) and, through its all-threads parity leg, a
-multi-million-record parity check of all three flag sets on a scaled-down S-pan workload.  Also smoke()."""
+"""bench.py contract (one JSON line with `roofline` and `cpu_baseline`, the three flag sets under `pipelines`, the S-big1
+leg, the PCIe leg) and, through its all-threads parity leg, a multi-million-record parity check of all three flag sets on
+a scaled-down S-pan workload.  Also --gpus validation, the strong-scaling mode on one GPU, and smoke()."""
 import json
 import os
 import subprocess
@@ -11,40 +12,94 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
+def run_bench(*args, env=None, expect_rc=0):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, cwd=ROOT,
-                       timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+                       timeout=900, env=e)
+    assert r.returncode == expect_rc, r.stderr[-2000:]
+    if expect_rc != 0:
+        return r
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
-def test_bench_line_and_parity(pipeline):
+@pytest.fixture(scope="module")
+def line():
     n = 4_000_000
-    d = run_bench("--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1", "--others", "0", "--pipeline", pipeline,
-                  "--cpu-sample", "300000", "--parity-mappings", str(n))
+    return n, run_bench("--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1", "--cpu-sample", "300000",
+                        "--parity-mappings", str(n), "--sbig1", "300000", "--sbig1-parity-sweep", "300000",
+                        "--sbig1-parity-scaffold", "60000", "--e2e", "0")
+
+
+def test_bench_line_contract(line):
+    n, d = line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "pipelines", "sbig1", "pcie_inclusive"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["flags"] == "(defaults)" and "pipeline=default" in d["config"]["workload"]   # headline = the default flags
     assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["value"] == d["pipelines"]["default"]["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    assert rf["pipeline_achieved"] > 0 and rf["algorithmic_bytes_per_mapping"] == 47
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
-    assert d["parity_vs_oracle_on_sample"] is True
-    pa = d["parity_all_threads"]
+    assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["h2d_ms"] > 0
+
+
+@pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
+def test_bench_pipelines_and_parity(line, pipeline):
+    n, d = line
+    p = d["pipelines"][pipeline]
+    assert p["ms_per_step"] > 0 and abs(p["value"] - n / (p["ms_per_step"] * 1e-3)) / p["value"] < 1e-6
+    assert p["roofline"]["algorithmic_bytes_per_mapping"] == (33 if pipeline == "sweep" else 47)
+    assert p["cpu_baseline"]["cores"] == 1 and p["cpu_baseline_all_cores"]["cores"] >= 1
+    assert p["parity_vs_oracle_on_sample"] is True
+    pa = p["parity_all_threads"]
     assert pa["mappings_checked"] == n and pa["status_equal"] is True
     assert pa["chain_partition_equal"] is (None if pipeline == "sweep" else True)
-    assert d["counts"]["in"] == n and 0 < d["counts"]["out"] < n
+    assert p["counts"]["in"] == n and 0 < p["counts"]["out"] < n
+
+
+@pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
+def test_bench_sbig1_leg(line, pipeline):
+    _, d = line
+    p = d["sbig1"]["pipelines"][pipeline]
+    assert p["ms_per_step"] > 0 and p["counts"]["in"] == 300000
+    assert p["parity"]["status_equal"] is True
+    assert p["parity"]["chain_equal"] is (None if pipeline == "sweep" else True)
+
+
+def test_gpus_flag_is_validated():
+    # more GPUs than the box has: refuses instead of measuring one GPU and calling it N
+    import torch
+    r = run_bench("--gpus", str(torch.cuda.device_count() + 1), "--mappings", "100000", expect_rc=2)
+    assert "GPU" in r.stderr
+    # under a launcher with a different world size: refuses as well
+    r = run_bench("--gpus", "2", "--mappings", "100000", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, expect_rc=2)
+    assert "WORLD_SIZE" in r.stderr
+
+
+def test_strong_scaling_mode_one_gpu():
+    n = 2_000_000
+    d = run_bench("--scaling", "strong", "--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1")
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    ss = d["strong_scaling"]
+    assert ss["mappings_total"] == n and ss["shard_mappings_rank0"] == n and ss["load_max_over_mean"] == 1.0
+    for p in ("default", "sweep", "full"):
+        assert ss["pipelines"][p]["ms_per_step"] > 0 and len(ss["pipelines"][p]["per_rank_ms"]) == 1
+    assert ss["pipelines"]["default"]["renumber_s"] is not None and ss["pipelines"]["sweep"]["renumber_s"] is None
 
 
 def test_smoke_entry():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"], capture_output=True,
                        text=True, cwd=ROOT, timeout=600)
-    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-2000:]
+    assert r.returncode == 0 and "smoke ok" in r.stderr + r.stdout, r.stderr[-2000:]
