@@ -283,18 +283,283 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
   return __ddiv_rn(ol, ml) > thr;
 }
 
-template <bool K1>
-__global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
+// ---- k == 1 -----------------------------------------------------------------------------------------------------
+// With T(x) the best active interval at x and T-(x) the best one just before x (active set {s < x <= e}):
+//   * `ever top` only has to be recorded where T changes, and T(x) != T-(x) exactly there;
+//   * an active i != T(x) has been tested against this T already unless T changed at x or i begins at x
+//     (induction over the event coordinates), so the O(active) pass over everything runs only at points where the top
+//     changes (and at the tile's first coordinate); elsewhere only the begins AT x are tested;
+//   * inside a tile, let S* be the best carry-in that spans the tile's whole coordinate range: it is active at every point
+//     of the tile, so an interval that ranks below it is never T there.  Candidates for T are S* and the intervals that
+//     rank above it, and only THEIR ends can change T, so the other intervals' ends are not evaluation points at all.
+// On deep data (S-big1: ~165 active intervals everywhere) a tile keeps a handful of candidates instead of ~420
+// intervals x ~600 points x 2 passes; on sparse data there is no spanning interval, every interval is a candidate and
+// the kernel degenerates to the plain per-point evaluation with the cheaper second pass.
+// tools/model_sweep_k1.py is the executable model of this kernel (checked against the oracle).
+constexpr int CCAP = 256;  // candidate carry-ins kept in LDS
+
+__global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
+  __shared__ uint64_t sx[TB];    // composite start of begin q
+  __shared__ uint64_t se2[2 * TB];   // [0, TB): its composite end; [TB, 2 TB): the same for candidates, 0 for the others
+  __shared__ uint64_t spm2[2 * TB];  // prefix maxima of the two halves of se2
+  __shared__ uint64_t skey[TB];      // its score key
+  __shared__ uint32_t sid[TB];   // its interval index
+  __shared__ uint64_t wmax[TB / 64];
+  __shared__ uint64_t ls[CCAP], le[CCAP], lkey[CCAP];  // candidate carry-ins
+  __shared__ uint32_t lid[CCAP];
+  __shared__ uint32_t l_count;
+  __shared__ uint64_t r_k[TB / 64], r_s[TB / 64], r_e[TB / 64];
+  __shared__ uint32_t r_i[TB / 64], r_have[TB / 64];
+
+  const uint32_t tile_id = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t p = (uint64_t)tile_id * TB + tid;
+  const bool valid = p < a.n;
+  uint64_t X = ~0ull, EE = 0, KEY = 0;
+  uint32_t ID = 0;
+  if (valid) {
+    X = a.S[p];
+    EE = a.E[p];
+    KEY = a.KEY[p];
+    ID = a.I[p];
+  }
+  sx[tid] = X;
+  se2[tid] = EE;
+  skey[tid] = KEY;
+  sid[tid] = ID;
+  if (tid == 0) l_count = 0;
+  auto block_prefix_max = [&](uint64_t v, uint64_t* dst) {  // dst[tid] = max(v of threads 0..tid); two barriers
+    uint64_t m = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t t = __shfl_up(m, d, 64);
+      if (lane >= d && t > m) m = t;
+    }
+    if (lane == 63) wmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (w < wave && wmax[w] > m) m = wmax[w];
+    dst[tid] = m;
+    __syncthreads();
+  };
+  block_prefix_max(EE, spm2);
+  const uint64_t x_b = sx[0];
+  const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
+  const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
+
+  // ---- S*: the best carry-in that is active over the whole range of the tile
+  bool have_star = false;
+  uint64_t star_k = 0, star_s = 0, star_e = 0;
+  uint32_t star_i = 0;
+  if (c_begin != c_end) {  // block-uniform
+    bool hv = false;
+    uint64_t bk = 0, bs = 0, be = 0;
+    uint32_t bi = 0;
+    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+      const uint64_t e = a.c_e[c];
+      if (e >= x_next) {
+        const uint64_t k = a.c_key[c], s = a.c_s[c];
+        const uint32_t id = a.c_id[c];
+        if (!hv || prio_less(k, s, id, bk, bs, bi)) {
+          bk = k;
+          bs = s;
+          be = e;
+          bi = id;
+          hv = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ok = __shfl_down(bk, o, 64), os = __shfl_down(bs, o, 64), oe = __shfl_down(be, o, 64);
+      const uint32_t oi = __shfl_down(bi, o, 64);
+      const bool oh = __shfl_down((int)hv, o, 64) != 0;
+      if (oh && (!hv || prio_less(ok, os, oi, bk, bs, bi))) {
+        bk = ok;
+        bs = os;
+        be = oe;
+        bi = oi;
+        hv = true;
+      }
+    }
+    if (lane == 0) {
+      r_k[wave] = bk;
+      r_s[wave] = bs;
+      r_e[wave] = be;
+      r_i[wave] = bi;
+      r_have[wave] = hv ? 1u : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (r_have[w] && (!have_star || prio_less(r_k[w], r_s[w], r_i[w], star_k, star_s, star_i))) {
+        star_k = r_k[w];
+        star_s = r_s[w];
+        star_e = r_e[w];
+        star_i = r_i[w];
+        have_star = true;
+      }
+    // ---- candidate carry-ins: end inside the tile's range and (no S* or better than S*)
+    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+      const uint64_t e = a.c_e[c];
+      if (e < x_next) {
+        const uint64_t k = a.c_key[c], s = a.c_s[c];
+        const uint32_t id = a.c_id[c];
+        if (!have_star || prio_less(k, s, id, star_k, star_s, star_i)) {
+          const uint32_t slot = atomicAdd(&l_count, 1u);
+          if (slot < CCAP) {
+            ls[slot] = s;
+            le[slot] = e;
+            lkey[slot] = k;
+            lid[slot] = id;
+          }
+        }
+      }
+    }
+  }
+  // candidates among the tile's own begins
+  const uint64_t* se = se2;
+  const uint64_t* spm = spm2;
+  int o1 = 0;  // offset of the candidate view in se2 / spm2 (no S*: every begin is a candidate)
+  if (have_star) {  // block-uniform
+    const bool cand = valid && X != 0 && prio_less(KEY, X, ID, star_k, star_s, star_i);
+    se2[TB + tid] = cand ? EE : 0;
+    block_prefix_max(cand ? EE : 0, spm2 + TB);
+    o1 = TB;
+  } else {
+    __syncthreads();
+  }
+  const uint32_t n_cc = l_count;
+  const bool cc_in_lds = n_cc <= CCAP;            // else: every carry-in is scanned from global memory (a superset is harmless)
+  const bool cc_complete = cc_in_lds && !have_star;  // the LDS list holds every carry-in of the tile
+  const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TB - 1) / TB);
+  const bool pass2 = a.thr < 1.0;
+
+  for (uint32_t batch = 0; batch < n_batches; ++batch) {
+    // ---- this thread's evaluation point: coordinate PX, last own begin at or before it Q0
+    bool eval;
+    uint64_t PX;
+    int Q0;
+    if (batch == 0) {  // start coordinates: the last begin of each run, unless the run continues in the next tile
+      eval = valid && X != 0 && (tid == TB - 1 || sx[tid + 1] != X) && X != x_next;
+      PX = X;
+      Q0 = tid;
+    } else {
+      // end coordinates of candidates that fall inside this tile's range (X_b < PX < X_{b+1}); an end equal to the next
+      // tile's first key is evaluated there as a start coordinate
+      if (batch == 1) {
+        eval = valid && X != 0 && EE > X && EE < x_next && se2[o1 + tid] != 0;
+        PX = EE;
+      } else if (cc_in_lds) {
+        eval = (uint32_t)tid < n_cc;
+        PX = eval ? le[tid] : 0;
+      } else {
+        const uint32_t ci = c_begin + (batch - 2) * TB + tid;
+        eval = ci < c_end;
+        PX = eval ? a.c_e[ci] : 0;
+        eval = eval && PX < x_next;
+      }
+      int l = 0, r = TB;  // upper_bound(sx, PX) - 1; sx is ~0 past the end of a short last tile
+      while (l < r) {
+        const int mid = (l + r) >> 1;
+        if (sx[mid] <= PX)
+          l = mid + 1;
+        else
+          r = mid;
+      }
+      Q0 = l - 1;
+    }
+    if (!eval) continue;  // no barrier below this line
+
+    // ---- pass 1: T(x) = best of {s <= x < e}, T-(x) = best of {s < x <= e}, over S* and the candidates
+    uint64_t tk = star_k, ts = star_s, te = star_e, mk = star_k, ms = star_s;
+    uint32_t ti = star_i, mi = star_i;
+    bool have_t = have_star, have_m = have_star;
+    auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {  // caller: s <= PX, e >= PX
+      if (e > PX && (!have_t || prio_less(key, s, id, tk, ts, ti))) {
+        tk = key;
+        ts = s;
+        te = e;
+        ti = id;
+        have_t = true;
+      }
+      if (s < PX && (!have_m || prio_less(key, s, id, mk, ms, mi))) {
+        mk = key;
+        ms = s;
+        mi = id;
+        have_m = true;
+      }
+    };
+    for (int q = Q0; q >= 0; --q) {
+      if (spm2[o1 + q] < PX) break;  // no earlier candidate reaches PX
+      const uint64_t ee = se2[o1 + q];
+      if (ee >= PX) take(sx[q], ee, skey[q], sid[q]);
+    }
+    if (cc_in_lds) {
+      for (uint32_t c = 0; c < n_cc; ++c) {
+        const uint64_t e = le[c];
+        if (e >= PX) take(ls[c], e, lkey[c], lid[c]);
+      }
+    } else {
+      for (uint32_t c = c_begin; c < c_end; ++c) {
+        const uint64_t e = a.c_e[c];
+        if (e >= PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
+      }
+    }
+    if (!have_t) continue;
+    a.top[ti] = 1;
+    if (!pass2) continue;
+    // ---- pass 2: active intervals that overlap T(x) too much
+    const bool full = !have_m || mi != ti || PX == x_b;
+    if (full) {  // the top changed here: everything that is active
+      for (int q = Q0; q >= 0; --q) {
+        if (spm[q] <= PX) break;
+        const uint64_t ee = se[q];
+        if (ee > PX) {
+          const uint32_t id = sid[q];
+          if (id != ti && overlap_exceeds(sx[q], ee, ts, te, a.thr)) a.ovl[id] = 1;
+        }
+      }
+      if (cc_complete) {
+        for (uint32_t c = 0; c < n_cc; ++c) {
+          const uint64_t e = le[c];
+          if (e > PX) {
+            const uint32_t id = lid[c];
+            if (id != ti && overlap_exceeds(ls[c], e, ts, te, a.thr)) a.ovl[id] = 1;
+          }
+        }
+      } else {
+        for (uint32_t c = c_begin; c < c_end; ++c) {
+          const uint64_t e = a.c_e[c];
+          if (e > PX) {
+            const uint32_t id = a.c_id[c];
+            if (id != ti && overlap_exceeds(a.c_s[c], e, ts, te, a.thr)) a.ovl[id] = 1;
+          }
+        }
+      }
+    } else {  // same top as just before x: only the intervals that begin at x have not met it yet
+      for (int q = Q0; q >= 0 && sx[q] == PX; --q) {
+        const uint64_t ee = se[q];
+        if (ee > PX) {
+          const uint32_t id = sid[q];
+          if (id != ti && overlap_exceeds(PX, ee, ts, te, a.thr)) a.ovl[id] = 1;
+        }
+      }
+    }
+  }
+}
+
+// ---- 2 <= k < inf ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void sweep_tile_kn_kernel(TileArgs a) {
   __shared__ uint64_t sx[TB];    // composite start of begin q
   __shared__ uint64_t se[TB];    // its composite end
   __shared__ uint64_t skey[TB];  // its score key
   __shared__ uint64_t spm[TB];   // prefix maximum of se
   __shared__ uint32_t sid[TB];   // its interval index
   __shared__ uint64_t wmax[TB / 64];
-  __shared__ uint64_t cs[CC], ce[CC], ckey[CC];
-  __shared__ uint32_t cid[CC];
 
-  const uint32_t tile_id = blockIdx.x;  // (an XCD-aware order was measured: no gain on sparse data, 9 % slower on deep data)
+  const uint32_t tile_id = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t p0 = (uint64_t)tile_id * TB;
   const uint64_t p = p0 + tid;
@@ -372,58 +637,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kernel(TileArgs a) {
       }
     };
 
-    if (K1) {
-      // ---- pass 1: the best active interval ------------------------------------------------------
-      uint64_t bk = ~0ull, bs = ~0ull, be = 0;
-      uint32_t bi = ~0u;
-      bool have = false;
-      auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {
-        if (!have || prio_less(key, s, id, bk, bs, bi)) {
-          bk = key;
-          bs = s;
-          be = e;
-          bi = id;
-          have = true;
-        }
-      };
-      if (eval) own_tile(take);
-      for (uint32_t c0 = c_begin; c0 < c_end; c0 += CC) {
-        __syncthreads();
-        const uint32_t cnt = c_end - c0 < CC ? c_end - c0 : CC;
-        if ((uint32_t)tid < cnt) {
-          cs[tid] = a.c_s[c0 + tid];
-          ce[tid] = a.c_e[c0 + tid];
-          ckey[tid] = a.c_key[c0 + tid];
-          cid[tid] = a.c_id[c0 + tid];
-        }
-        __syncthreads();
-        if (eval)
-          for (uint32_t c = 0; c < cnt; ++c)
-            if (ce[c] > PX) take(cs[c], ce[c], ckey[c], cid[c]);
-      }
-      if (eval && have) a.top[bi] = 1;
-      // ---- pass 2: everything else that is active and overlaps the best too much --------------------
-      if (a.thr < 1.0) {
-        auto mark = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {
-          (void)key;
-          if (id != bi && overlap_exceeds(s, e, bs, be, a.thr)) a.ovl[id] = 1;
-        };
-        if (eval && have) own_tile(mark);
-        for (uint32_t c0 = c_begin; c0 < c_end; c0 += CC) {
-          __syncthreads();
-          const uint32_t cnt = c_end - c0 < CC ? c_end - c0 : CC;
-          if ((uint32_t)tid < cnt) {
-            cs[tid] = a.c_s[c0 + tid];
-            ce[tid] = a.c_e[c0 + tid];
-            cid[tid] = a.c_id[c0 + tid];
-          }
-          __syncthreads();
-          if (eval && have)
-            for (uint32_t c = 0; c < cnt; ++c)
-              if (ce[c] > PX) mark(cs[c], ce[c], 0, cid[c]);
-        }
-      }
-    } else if (eval) {
+    if (eval) {
       // ---- general k: walk the priority order by successive minima; no per-thread storage.
       // Carry-ins are read straight from global memory here (every lane reads the same entry, so
       // the loads coalesce to one request); this path is for 2 <= k < inf.
@@ -691,9 +905,9 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.top = top;
   ta.ovl = ovl;
   if (k == 1)
-    SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_kernel<true><<<ntiles, TB, 0, st>>>(ta));
+    SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<<<ntiles, TB, 0, st>>>(ta));
   else
-    SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kernel<false><<<ntiles, TB, 0, st>>>(ta));
+    SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kn_kernel<<<ntiles, TB, 0, st>>>(ta));
   SWG_KERNEL_CHECK(ctx);
   {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(in.alive) | reinterpret_cast<uintptr_t>(single) | reinterpret_cast<uintptr_t>(top) |
