@@ -243,6 +243,131 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
   c_ext[p] = ext;
 }
 
+// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): the 256 windows of a
+// work-group overlap almost entirely, so the union is staged through LDS in chunks and every (i, j) costs three LDS reads
+// and 32-bit arithmetic instead of three global loads and 64-bit arithmetic (coordinates are u32; a gap limit beyond 2^32
+// cannot bind, so it is clamped).  Results are identical to chain_candidates_kernel.
+constexpr int CT_CHUNK = 1024;
+__global__ __launch_bounds__(EW) void chain_candidates_tiled_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                                    const uint32_t* __restrict__ group_begin,
+                                                                    uint32_t n_groups, const uint64_t* __restrict__ s_grp,
+                                                                    const uint32_t* __restrict__ s_qs,
+                                                                    const uint32_t* __restrict__ s_qe,
+                                                                    const uint32_t* __restrict__ s_ts,
+                                                                    const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                                    unsigned long long* __restrict__ c_d,
+                                                                    uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
+                                                                    uint32_t* __restrict__ c_ext) {
+  __shared__ uint32_t l_qs[CT_CHUNK], l_ts[CT_CHUNK], l_te[CT_CHUNK];
+  const uint64_t p0 = (uint64_t)blockIdx.x * EW;
+  const uint64_t p = p0 + threadIdx.x;
+  const bool valid = p < m;
+  uint32_t e = 0, qe_i = 0, ts_i = 0, te_i = 0;
+  bool minus = false;
+  if (valid) {
+    const uint32_t g = s_gidx[p];
+    e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
+    minus = (s_grp[p] & 1ull) != 0;
+    qe_i = s_qe[p];
+    ts_i = s_ts[p];
+    te_i = s_te[p];
+  }
+  const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
+  const bool wrap = max_gap == ~0ull;
+  const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
+  const uint64_t bound64 = (uint64_t)qe_i + max_gap;
+  const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
+  uint64_t bd[KC];
+  uint32_t bj[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    bd[k] = ~0ull;
+    bj[k] = NONE;
+  }
+  uint32_t count = 0, ext = 0;
+  bool done = !valid || (uint32_t)p + 1 >= e;
+  for (uint64_t c0 = p0 + 1; c0 < m; c0 += CT_CHUNK) {
+    for (int t = threadIdx.x; t < CT_CHUNK; t += EW) {
+      const uint64_t j = c0 + t;
+      if (j < m) {
+        l_qs[t] = s_qs[j];
+        l_ts[t] = s_ts[j];
+        l_te[t] = s_te[j];
+      }
+    }
+    __syncthreads();
+    if (!done) {
+      const uint32_t j_lo = (uint32_t)p + 1 > (uint32_t)c0 ? (uint32_t)p + 1 : (uint32_t)c0;
+      const uint64_t c_hi = c0 + CT_CHUNK;
+      const uint32_t j_hi = (uint64_t)e < c_hi ? e : (uint32_t)c_hi;
+      for (uint32_t j = j_lo; j < j_hi; ++j) {
+        const uint32_t t = j - (uint32_t)c0;
+        const uint32_t qs_j = l_qs[t];
+        if (qs_j > bound) {  // sorted by q_start (paf_filter.rs:794-796)
+          done = true;
+          break;
+        }
+        ext = j - (uint32_t)p;
+        // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic
+        // (an overlap beyond gap / 5 becomes `max_gap + 1` = reject; with max_gap = u64::MAX that wraps to 0 in
+        // release Rust, which `wrap` reproduces)
+        uint32_t q_gap, r_gap;
+        bool ok = true;
+        if (qs_j >= qe_i) {
+          q_gap = qs_j - qe_i;
+        } else {
+          q_gap = qe_i - qs_j;
+          if (q_gap > fifth) {
+            ok = wrap;
+            q_gap = 0;
+          }
+        }
+        const uint32_t ts_j = l_ts[t], te_j = l_te[t];
+        const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
+        if (a >= b) {
+          r_gap = a - b;
+        } else {
+          r_gap = b - a;
+          if (r_gap > fifth) {
+            ok = ok && wrap;
+            r_gap = 0;
+          }
+        }
+        if (!ok || q_gap > gap || r_gap > gap) continue;
+        const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+        if (count < 0xffffffffu) ++count;
+        if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
+          uint64_t cd = d;
+          uint32_t cj = j;
+          bool placed = false;
+#pragma unroll
+          for (int k = 0; k < KC; ++k) {
+            if (placed || cd < bd[k]) {
+              placed = true;
+              const uint64_t td = bd[k];
+              const uint32_t tj = bj[k];
+              bd[k] = cd;
+              bj[k] = cj;
+              cd = td;
+              cj = tj;
+            }
+          }
+        }
+      }
+      if (!done && j_hi >= e) done = true;
+    }
+    if (__syncthreads_and(done ? 1 : 0)) break;
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    c_d[(uint64_t)k * m + p] = bd[k];
+    c_j[(uint64_t)k * m + p] = bj[k];
+  }
+  c_n[p] = count;
+  c_ext[p] = ext;
+}
+
 struct SelBlock {
   uint64_t d[KC];
   uint32_t j[KC];
@@ -509,6 +634,51 @@ __global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uin
     nblk_out[bi] = (e - b + S - 1) / S;
     atomicMax(s_max, S);
   }
+}
+// The same plan when a unit holds millions of elements (one work-group per unit would walk it alone): every element
+// of a long unit contributes its window extent to the unit's maximum (one atomic per wavefront whose lanes share the
+// unit), then one thread per long unit derives S and the block count.
+__global__ __launch_bounds__(EW) void unit_wmax_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
+                                                       const uint32_t* __restrict__ unit_excl,
+                                                       const uint8_t* __restrict__ is_big, const uint32_t* __restrict__ c_ext,
+                                                       uint32_t* __restrict__ wmax_u) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t base = (uint64_t)blockIdx.x * EW; base < m; base += (uint64_t)gridDim.x * EW) {  // block-uniform trip count
+    const uint64_t p = base + threadIdx.x;
+    const bool valid = p < m;
+    const uint32_t u = valid ? unit_excl[p] + unit_flag[p] - 1 : 0u;
+    const bool big = valid && is_big[u] != 0;
+    uint32_t w = big ? c_ext[p] : 0u;
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0) continue;  // wave-uniform
+    const uint32_t u0 = (uint32_t)__shfl((int)u, (int)__builtin_ctzll(vm), 64);
+    if (__ballot(valid && u != u0) == 0) {  // the wavefront's elements share one unit: one atomic
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(w, o, 64);
+        if (t > w) w = t;
+      }
+      if (lane == 0 && w) atomicMax(&wmax_u[u0], w);
+    } else if (big && w) {
+      atomicMax(&wmax_u[u], w);
+    }
+  }
+}
+__global__ __launch_bounds__(EW) void spec_plan_from_wmax_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
+                                                                 uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                                 uint32_t m, const uint32_t* __restrict__ wmax_u,
+                                                                 uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out,
+                                                                 uint32_t* __restrict__ s_max) {
+  const uint32_t bi = blockIdx.x * EW + threadIdx.x;
+  if (bi >= n_big) return;
+  const uint32_t u = big_list[bi];
+  const uint32_t b = unit_begin[u];
+  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+  uint32_t S = ((wmax_u[u] + 1 + 63) / 64) * 64;
+  if (S < 512) S = 512;
+  S_out[bi] = S;
+  nblk_out[bi] = (e - b + S - 1) / S;
+  atomicMax(s_max, S);
 }
 __global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
                                                        uint32_t n_units, const uint32_t* __restrict__ unit_begin,
@@ -1491,8 +1661,13 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
               (unsigned long long)n_groups, (unsigned long long)n_units);
-    SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    static const bool force_tiled = getenv("SWG_CHAIN_TILED") != nullptr;  // test knob: the deep-group kernel at any size
+    if (long_groups || force_tiled)
+      SWG_LAUNCH(ctx, "chain_candidates_tiled", chain_candidates_tiled_kernel<<<nblk(m), EW, 0, st>>>(
+                                                    m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    else
+      SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
+                                                                              s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "chain_select_lanes", chain_select_lanes_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
                                                                                     s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, bps,
@@ -1526,10 +1701,23 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         uint64_t* d_smax = swg_alloc<uint64_t>(ctx, 1);  // adjacent to d_nblk: read back together
         SWG_CHECK_ARENA(ctx);
         SWG_HIP(ctx, hipMemsetAsync(d_smax, 0, 8, st));
-        SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                        (uint32_t)m, c_ext, S_u, nblk_u,
-                                                                        reinterpret_cast<uint32_t*>(d_smax)));
-        SWG_KERNEL_CHECK(ctx);
+        if (m / n_big > 65536) {  // few, very long units
+          uint32_t* wmax_u = swg_alloc<uint32_t>(ctx, n_units);
+          SWG_CHECK_ARENA(ctx);
+          SWG_HIP(ctx, hipMemsetAsync(wmax_u, 0, n_units * sizeof(uint32_t), st));
+          const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
+          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                                (uint32_t)m, wmax_u, S_u, nblk_u,
+                                                                                reinterpret_cast<uint32_t*>(d_smax)));
+          SWG_KERNEL_CHECK(ctx);
+        } else {
+          SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                          (uint32_t)m, c_ext, S_u, nblk_u,
+                                                                          reinterpret_cast<uint32_t*>(d_smax)));
+          SWG_KERNEL_CHECK(ctx);
+        }
         SWG_TRY(swg_exclusive_scan_u32(ctx, nblk_u, blk_off, n_big, d_nblk));
         uint64_t n_spec = 0, s_max = 0;
         SWG_TRY(swg_read_scalars(ctx, d_nblk, &n_spec, 1));
@@ -1764,6 +1952,19 @@ __global__ __launch_bounds__(EW) void fwd_prefmax_kernel(uint32_t n_pairs, const
       carry = __shfl(v, 63, 64);
     }
   }
+}
+// the same as one segmented scan: key = (first slot of the chain's pair << 32) | q_end; slots of a pair are contiguous
+// and first slots grow with the slot index, so a u64 running maximum never crosses a pair boundary
+__global__ __launch_bounds__(EW) void fwd_compose_kernel(uint64_t nf, const uint32_t* __restrict__ f_dp,
+                                                         const uint32_t* __restrict__ pair_lo,
+                                                         const uint32_t* __restrict__ f_qe, uint64_t* __restrict__ comp) {
+  uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (k < nf) comp[k] = ((uint64_t)pair_lo[f_dp[k]] << 32) | f_qe[k];
+}
+__global__ __launch_bounds__(EW) void fwd_extract_kernel(uint64_t nf, const uint64_t* __restrict__ comp,
+                                                         uint32_t* __restrict__ f_pm) {
+  uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (k < nf) f_pm[k] = (uint32_t)comp[k];
 }
 // paf_filter.rs:535-597: a '-' record joins the first (lowest-numbered) kept '+' chain of its pair whose
 // diagonal it sits on.  Candidates: chains with q_start <= q_end(rec) + gap (binary search) and
@@ -2032,11 +2233,25 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_LAUNCH(ctx, "fwd_ranges", fwd_ranges_kernel<<<nblk(nf), EW, 0, st>>>(nf, f_dp, pair_lo, pair_hi));
       SWG_KERNEL_CHECK(ctx);
       {
-        uint64_t blocks = (np + 3) / 4;
-        const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
-        if (blocks > max_blocks) blocks = max_blocks;
-        SWG_LAUNCH(ctx, "fwd_prefmax", fwd_prefmax_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)np, pair_lo, pair_hi, f_qe, f_pm));
-        SWG_KERNEL_CHECK(ctx);
+        if (nf >= 4096 * np) {
+          // few pairs with very many chains (one deep chromosome pair): a wavefront per pair would walk millions of
+          // chains alone, so the running maximum becomes one u64 max-scan with the pair's first slot in the high word
+          swg_arena_mark mk = swg_arena_save(ctx);
+          uint64_t* comp = swg_alloc<uint64_t>(ctx, nf);
+          SWG_CHECK_ARENA(ctx);
+          SWG_LAUNCH(ctx, "fwd_compose", fwd_compose_kernel<<<nblk(nf), EW, 0, st>>>(nf, f_dp, pair_lo, f_qe, comp));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, nf));
+          SWG_LAUNCH(ctx, "fwd_extract", fwd_extract_kernel<<<nblk(nf), EW, 0, st>>>(nf, comp, f_pm));
+          SWG_KERNEL_CHECK(ctx);
+          swg_arena_restore(ctx, mk);
+        } else {
+          uint64_t blocks = (np + 3) / 4;
+          const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+          if (blocks > max_blocks) blocks = max_blocks;
+          SWG_LAUNCH(ctx, "fwd_prefmax", fwd_prefmax_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)np, pair_lo, pair_hi, f_qe, f_pm));
+          SWG_KERNEL_CHECK(ctx);
+        }
       }
       SWG_LAUNCH(ctx, "inversion", inversion_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits,
                                                                 pair_lo, pair_hi, f_qs, f_qe, f_pm, f_ts, f_num,

@@ -296,7 +296,8 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 // intervals x ~600 points x 2 passes; on sparse data there is no spanning interval, every interval is a candidate and
 // the kernel degenerates to the plain per-point evaluation with the cheaper second pass.
 // tools/model_sweep_k1.py is the executable model of this kernel (checked against the oracle).
-constexpr int CCAP = 256;  // candidate carry-ins kept in LDS
+constexpr int CCAP = 256;     // candidate carry-ins kept in LDS
+constexpr int STAR_MIN = 32;  // fewer carry-ins than this: no pruning (nothing to gain on sparse data)
 
 __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   __shared__ uint64_t sx[TB];    // composite start of begin q
@@ -348,28 +349,15 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
   const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
 
-  // ---- S*: the best carry-in that is active over the whole range of the tile
+  // ---- S*: the best carry-in that is active over the whole range of the tile, and the candidate carry-ins
   bool have_star = false;
   uint64_t star_k = 0, star_s = 0, star_e = 0;
   uint32_t star_i = 0;
-  if (c_begin != c_end) {  // block-uniform
-    bool hv = false;
-    uint64_t bk = 0, bs = 0, be = 0;
-    uint32_t bi = 0;
-    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
-      const uint64_t e = a.c_e[c];
-      if (e >= x_next) {
-        const uint64_t k = a.c_key[c], s = a.c_s[c];
-        const uint32_t id = a.c_id[c];
-        if (!hv || prio_less(k, s, id, bk, bs, bi)) {
-          bk = k;
-          bs = s;
-          be = e;
-          bi = id;
-          hv = true;
-        }
-      }
-    }
+  const uint32_t n_carry = c_end - c_begin;
+  uint32_t n_cc = 0;
+  bool cc_in_lds = true;
+  // wave-level then block-level arg-min of (key, start, index) over the lanes with hv set; every thread gets the result
+  auto reduce_star = [&](bool hv, uint64_t bk, uint64_t bs, uint64_t be, uint32_t bi) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const uint64_t ok = __shfl_down(bk, o, 64), os = __shfl_down(bs, o, 64), oe = __shfl_down(be, o, 64);
@@ -400,7 +388,49 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
         star_i = r_i[w];
         have_star = true;
       }
-    // ---- candidate carry-ins: end inside the tile's range and (no S* or better than S*)
+  };
+  if (n_carry != 0 && n_carry <= CCAP) {  // block-uniform.  The usual case: the whole list goes to LDS as it is
+    const bool mine = (uint32_t)tid < n_carry;
+    uint64_t cs_ = 0, ce_ = 0, ck_ = 0;
+    uint32_t ci_ = 0;
+    if (mine) {
+      cs_ = a.c_s[c_begin + tid];
+      ce_ = a.c_e[c_begin + tid];
+      ck_ = a.c_key[c_begin + tid];
+      ci_ = a.c_id[c_begin + tid];
+    }
+    if (n_carry >= STAR_MIN) {  // pruning only pays on deep data
+      reduce_star(mine && ce_ >= x_next, ck_, cs_, ce_, ci_);
+      // entries S* dominates leave the list (end 0 = never active); S* itself stays in registers
+      if (have_star && !(ce_ < x_next && prio_less(ck_, cs_, ci_, star_k, star_s, star_i))) ce_ = 0;
+    }
+    if (mine) {
+      ls[tid] = cs_;
+      le[tid] = ce_;
+      lkey[tid] = ck_;
+      lid[tid] = ci_;
+    }
+    n_cc = n_carry;
+  } else if (n_carry != 0) {  // long list: two passes over global memory
+    bool hv = false;
+    uint64_t bk = 0, bs = 0, be = 0;
+    uint32_t bi = 0;
+    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+      const uint64_t e = a.c_e[c];
+      if (e >= x_next) {
+        const uint64_t k = a.c_key[c], s = a.c_s[c];
+        const uint32_t id = a.c_id[c];
+        if (!hv || prio_less(k, s, id, bk, bs, bi)) {
+          bk = k;
+          bs = s;
+          be = e;
+          bi = id;
+          hv = true;
+        }
+      }
+    }
+    reduce_star(hv, bk, bs, be, bi);
+    // candidates: end inside the tile's range and (no S* or better than S*); without S* every carry-in ends inside
     for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
       const uint64_t e = a.c_e[c];
       if (e < x_next) {
@@ -427,11 +457,13 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     se2[TB + tid] = cand ? EE : 0;
     block_prefix_max(cand ? EE : 0, spm2 + TB);
     o1 = TB;
-  } else {
+  } else if (n_carry != 0) {
     __syncthreads();
   }
-  const uint32_t n_cc = l_count;
-  const bool cc_in_lds = n_cc <= CCAP;            // else: every carry-in is scanned from global memory (a superset is harmless)
+  if (n_carry > CCAP) {
+    n_cc = l_count;
+    cc_in_lds = n_cc <= CCAP;  // else: every carry-in is scanned from global memory (a superset is harmless)
+  }
   const bool cc_complete = cc_in_lds && !have_star;  // the LDS list holds every carry-in of the tile
   const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TB - 1) / TB);
   const bool pass2 = a.thr < 1.0;
@@ -452,8 +484,8 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
         eval = valid && X != 0 && EE > X && EE < x_next && se2[o1 + tid] != 0;
         PX = EE;
       } else if (cc_in_lds) {
-        eval = (uint32_t)tid < n_cc;
-        PX = eval ? le[tid] : 0;
+        PX = (uint32_t)tid < n_cc ? le[tid] : 0;
+        eval = PX != 0 && PX < x_next;
       } else {
         const uint32_t ci = c_begin + (batch - 2) * TB + tid;
         eval = ci < c_end;

@@ -23,7 +23,11 @@ def main(cases):
     for name, (pipeline, n, chr_len) in cases.items():
         cols, _ = bench.gen_shard(torch, n, 2, 1234, device, chr_len=chr_len, single_pair=True)
         run = bench.Runner(torch, sw, _lib, ctx, device, None, cols, n, 2)
-        cfg = bench.make_config(sw, pipeline)
+        if pipeline == "k32":
+            cfg = sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToMany, mapping_max_per_query=3, mapping_max_per_target=2,
+                                  scaffold_gap=0)
+        else:
+            cfg = bench.make_config(sw, pipeline)
         run.step(cfg.to_c(), with_stats=True)
         ctx.synchronize()
         st, ch = run.status[:n].cpu().numpy(), run.chain[:n].cpu().numpy()

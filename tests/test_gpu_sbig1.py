@@ -27,6 +27,8 @@ CASES = {  # name: (pipeline, n, chromosome length)
     "full_1e6_full_length": ("full", 1_000_000, 248_956_422),
     "full_2e5_same_depth": ("full", 200_000, 4_979_128),
     "sweep_1e6_same_depth": ("sweep", 1_000_000, 24_895_642),
+    # the 2 <= k < inf tile kernel on deep data: --num-mappings 3:2 --scaffold-jump 0
+    "k3_2_3e5_same_depth": ("k32", 300_000, 7_468_692),
 }
 
 

@@ -22,7 +22,7 @@ def overlap_exceeds(a_s, a_e, b_s, b_e, thr):
     return ol / ml > thr
 
 
-def sweep_axis_model(seg, start, end, key, thr, TB=8, CCAP=4, stats=None):
+def sweep_axis_model(seg, start, end, key, thr, TB=8, CCAP=6, STAR_MIN=3, stats=None):
     n = len(start)
     X = ((seg.astype(np.int64) + 1) << POS_BITS) | start.astype(np.int64)
     order = np.argsort(X, kind="stable")
@@ -63,13 +63,20 @@ def sweep_axis_model(seg, start, end, key, thr, TB=8, CCAP=4, stats=None):
         cin = carry[b]
         # step A: best carry-in spanning the whole range
         span = [p for p in cin if int(E[p]) >= x_next]
-        star = min(span, key=prio) if span else None
+        use_star = len(cin) >= STAR_MIN  # short lists are not pruned (lists longer than CCAP always are: CCAP >= STAR_MIN)
+        star = min(span, key=prio) if (span and use_star) else None
         # step B: candidates
         def is_cand(p):
             return star is None or prio(p) < prio(star)
         co = [p for p in own if is_cand(p)]
-        cc_all = [p for p in cin if int(E[p]) < x_next and is_cand(p)]
+        if star is None:
+            cc_all = list(cin)  # no pruning: every carry-in, the spanning ones included
+        else:
+            cc_all = [p for p in cin if int(E[p]) < x_next and is_cand(p)]
+        if len(cin) > CCAP and star is None:  # the long-list path of the kernel lists only the entries that end inside
+            cc_all = [p for p in cin if int(E[p]) < x_next]
         cc_in_lds = len(cc_all) <= CCAP
+        assert not (len(cin) > CCAP and star is None and span), "without S* no carry-in spans the tile"
         cc_complete = cc_in_lds and star is None   # then the list holds every carry-in
         pass1_carry = cc_all if cc_in_lds else cin  # overflow: scan every carry-in (a superset is harmless)
         if stats is not None:
