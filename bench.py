@@ -54,6 +54,8 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pai
     S-big1 (single_pair): every record maps sequence 0 onto sequence 1 (one query segment, one target segment)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    if device.type == "cuda":
+        torch.cuda.manual_seed(seed)   # _standard_gamma below draws from the device's default generator
     if single_pair:
         sizes = torch.tensor([n], dtype=torch.int64, device=device)
         q = torch.zeros(n, dtype=torch.int32, device=device)

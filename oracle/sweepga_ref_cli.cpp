@@ -19,9 +19,11 @@ static void die(const std::string& msg) {
   std::exit(2);
 }
 
-static // --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509): on the PAF path the value is only validated -- the
-// filter never reads FilterConfig.sparsity and no tree filter is applied to a PAF.  0 = fine (no effect),
-// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable.
+static // --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509).  `none`, `all`, a bare fraction and `random:<f>` have no
+// effect on the PAF path (the filter never reads FilterConfig.sparsity).  `tree:` / `knn:` make the reference run
+// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688); that pre-filter is not
+// built here, so they are refused rather than silently ignored.  0 = fine (no effect), 1 = a strategy that is "not valid
+// for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (valid in the reference, unsupported here).
 int check_sparsify(const std::string& v) {
   auto frac_ok = [](const std::string& t, bool open_top) {
     char* e = nullptr;
@@ -64,7 +66,7 @@ int check_sparsify(const std::string& v) {
       s0 = c + 1;
     }
     if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
-    return 0;
+    return 3;
   }
   return 2;
 }
@@ -78,7 +80,7 @@ int main(int argc, char** argv) {
   bool have_block_length = false;
   uint64_t block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false;
-  std::string bad_sparsify;
+  std::string bad_sparsify, tree_sparsify;
 
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]);
@@ -120,6 +122,7 @@ int main(int argc, char** argv) {
       const int rc = check_sparsify(v);
       if (rc == 2) die("invalid value for --sparsify");
       if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
+      if (rc == 3) tree_sparsify = v;
     }
     else if (a == "--no-adaptive-scaffolds" || a == "--quiet" || a == "--paf") { /* no effect here */ }
     else if (a == "--threads" || a == "-t") (void)value();
@@ -129,9 +132,9 @@ int main(int argc, char** argv) {
   if (input.empty()) die("usage: sweepga-ref <in.paf> [--output-file out.paf] [filter flags]");
 
   std::string out_path = output_file.empty() ? "/dev/stdout" : output_file;
-  if (no_filter) {  // main.rs:3461-3470
+  if (no_filter) {  // main.rs:3461-3473: always to stdout, --output-file is not consulted
     std::ifstream in(input, std::ios::binary);
-    std::ofstream out(out_path, std::ios::binary);
+    std::ofstream out("/dev/stdout", std::ios::binary);
     std::string line;
     while (std::getline(in, line)) {
       if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -142,6 +145,11 @@ int main(int argc, char** argv) {
 
   if (!bad_sparsify.empty()) {
     std::fprintf(stderr, "sweepga-ref: --sparsify '%s' is not valid for post-alignment PAF/1aln filtering\n", bad_sparsify.c_str());
+    return 1;
+  }
+  if (!tree_sparsify.empty()) {
+    std::fprintf(stderr, "sweepga-ref: --sparsify '%s': tree sparsification of the input PAF (src/main.rs:3640-3688) is not supported\n",
+                 tree_sparsify.c_str());
     return 1;
   }
   FilterConfig cfg;

@@ -129,6 +129,8 @@ struct Text {
   size_t len = 0;
   void* map = nullptr;  // munmap(map, map_len) when set
   size_t map_len = 0;
+  dev_t src_dev = 0;  // identity of the mapped input file (only meaningful while `map` is set)
+  ino_t src_ino = 0;
   std::vector<char> owned;
   ~Text() {
     if (map) munmap(map, map_len);
@@ -283,6 +285,8 @@ int load_text(const char* path, int threads, Text* t) {
   if (map) {
     t->map = map;
     t->map_len = raw_len;
+    t->src_dev = st.st_dev;
+    t->src_ino = st.st_ino;
     t->data = static_cast<const char*>(map);
     t->len = raw_len;
   } else {
@@ -757,8 +761,18 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   if (threads > 16) threads = 16;  // concurrent pwrite()s into one file stop scaling (and then degrade) beyond this
   if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
   const bool to_stdout = !std::strcmp(out_path, "-");
-  const int fd = to_stdout ? 1 : open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot create %s: %s", out_path, std::strerror(errno));
+  // Output path == the mapped input file: truncating it would pull the pages from under the mapping (SIGBUS).  The
+  // reference filters into a temporary file first (src/main.rs:3630-3636), so writing in place works there; here the
+  // result goes to a sibling temporary file that replaces the input when it is complete.
+  std::string tmp_path;
+  if (!to_stdout && p->text.map) {
+    struct stat so {};
+    if (stat(out_path, &so) == 0 && so.st_dev == p->text.src_dev && so.st_ino == p->text.src_ino)
+      tmp_path = std::string(out_path) + ".swg_tmp." + std::to_string((long)getpid());
+  }
+  const char* open_path = tmp_path.empty() ? out_path : tmp_path.c_str();
+  const int fd = to_stdout ? 1 : open(open_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot create %s: %s", open_path, std::strerror(errno));
   // sizes per thread range
   std::vector<uint64_t> bytes(threads + 1, 0), kept(threads, 0);
   auto lo = [&](int t) { return n / threads * t + (uint64_t)std::min<uint64_t>(t, n % threads); };
@@ -814,6 +828,10 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
     if (!bad && o != buf.data() && !write_all(fd, buf.data(), (size_t)(o - buf.data()))) bad = errno ? errno : EIO;
   }
   if (!to_stdout && close(fd) != 0 && !bad) bad = errno ? errno : EIO;
+  if (!tmp_path.empty()) {
+    if (!bad && rename(tmp_path.c_str(), out_path) != 0) bad = errno ? errno : EIO;
+    if (bad) unlink(tmp_path.c_str());
+  }
   if (bad) return paf_error(SWG_ERR_INVALID, "write to %s failed: %s", out_path, std::strerror(bad));
   return SWG_OK;
 }

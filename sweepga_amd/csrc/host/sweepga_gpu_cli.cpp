@@ -61,6 +61,11 @@ bool parse_f64(std::string_view sv, double* out) {  // str::parse::<f64>: no whi
   *out = v;
   return true;
 }
+bool parse_int(const std::string& t, int* out) {  // decimal digits only
+  if (t.empty() || t.size() > 9 || t.find_first_not_of("0123456789") != std::string::npos) return false;
+  *out = std::atoi(t.c_str());
+  return true;
+}
 bool parse_metric_number(const std::string& s, uint64_t* out) {  // cli.rs:26-61
   if (s.empty()) return false;
   std::string num = s;
@@ -129,9 +134,11 @@ bool parse_filter_mode(const std::string& mode, int32_t* fmode, uint64_t* pq, ui
   }
   return set(SWG_MODE_ONE_TO_ONE, 1, 1);
 }
-// --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509): on the PAF path the value is only validated -- the
-// filter never reads FilterConfig.sparsity and no tree filter is applied to a PAF.  0 = fine (no effect),
-// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable.
+// --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509).  `none`, `all`, a bare fraction and `random:<f>` have no
+// effect on the PAF path (the filter never reads FilterConfig.sparsity).  `tree:` / `knn:` make the reference run
+// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688); that pre-filter is not
+// built here, so they are refused rather than silently ignored.  0 = fine (no effect), 1 = a strategy that is "not valid
+// for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (valid in the reference, unsupported here).
 int check_sparsify(const std::string& v) {
   auto frac_ok = [](const std::string& t, bool open_top) {
     char* e = nullptr;
@@ -174,7 +181,7 @@ int check_sparsify(const std::string& v) {
       s0 = c + 1;
     }
     if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
-    return 0;
+    return 3;
   }
   return 2;
 }
@@ -191,7 +198,7 @@ int main(int argc, char** argv) {
   bool keep_self = false, no_filter = false, scaffolds_only = false, quiet = false;
   int device = 0, threads = 0;
   std::vector<int> devices;
-  std::string bad_sparsify;
+  std::string bad_sparsify, tree_sparsify;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], val;
     const size_t eq = a.find('=');
@@ -207,7 +214,7 @@ int main(int argc, char** argv) {
     };
     if (a == "--output-file" || a == "-o") output_file = value();
     else if (a == "--num-mappings") num_mappings = value();
-    else if (a == "--overlap") overlap = std::strtod(value().c_str(), nullptr);
+    else if (a == "--overlap") { if (!parse_f64(value(), &overlap)) die(2, "invalid value for --overlap"); }  // clap rejects it too
     else if (a == "--scoring") scoring = value();
     else if (a == "--min-aln-identity") min_identity = value();
     else if (a == "--min-aln-length") { if (!parse_metric_number(value(), &block_length)) die(2, "bad --min-aln-length"); }
@@ -216,7 +223,7 @@ int main(int argc, char** argv) {
     else if (a == "--scaffold-jump") { if (!parse_metric_number(value(), &scaffold_jump)) die(2, "bad --scaffold-jump"); }
     else if (a == "--scaffold-mass") { if (!parse_metric_number(value(), &scaffold_mass)) die(2, "bad --scaffold-mass"); }
     else if (a == "--scaffold-filter") scaffold_filter = value();
-    else if (a == "--scaffold-overlap") scaffold_overlap = std::strtod(value().c_str(), nullptr);
+    else if (a == "--scaffold-overlap") { if (!parse_f64(value(), &scaffold_overlap)) die(2, "invalid value for --scaffold-overlap"); }
     else if (a == "--scaffold-dist") { if (!parse_metric_number(value(), &scaffold_dist)) die(2, "bad --scaffold-dist"); }
     else if (a == "--min-scaffold-identity") min_scaffold_identity = value();
     else if (a == "--scaffolds-only") scaffolds_only = true;
@@ -226,8 +233,9 @@ int main(int argc, char** argv) {
       const int rc = check_sparsify(v);
       if (rc == 2) die(2, "invalid value for --sparsify");
       if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
+      if (rc == 3) tree_sparsify = v;
     }
-    else if (a == "--device") device = std::atoi(value().c_str());
+    else if (a == "--device") { if (!parse_int(value(), &device) || device < 0) die(2, "invalid value for --device"); }
     else if (a == "--devices") {  // comma-separated: shard the genome pairs over several GPUs of the node
       const std::string v = value();
       for (size_t s0 = 0; s0 <= v.size();) {
@@ -241,7 +249,7 @@ int main(int argc, char** argv) {
     }
     else if (a == "--quiet") quiet = true;
     else if (a == "--no-adaptive-scaffolds" || a == "--paf") { /* no effect for PAF input (main.rs:3515-3527) */ }
-    else if (a == "--threads" || a == "-t") threads = std::atoi(value().c_str());
+    else if (a == "--threads" || a == "-t") { if (!parse_int(value(), &threads) || threads < 0) die(2, "invalid value for --threads"); }
     else if (a == "--help" || a == "-h") {
       std::puts("usage: sweepga-gpu <in.paf> [--output-file out.paf] [--num-mappings M] [--overlap F] [--scoring S]\n"
                 "         [--min-aln-identity I] [--min-aln-length N] [--self] [--no-filter] [--scaffold-jump N]\n"
@@ -256,6 +264,8 @@ int main(int argc, char** argv) {
   if (input.empty()) die(2, "usage: sweepga-gpu <in.paf> [--output-file out.paf] [filter flags]   (--help)");
 
   if (!no_filter && !bad_sparsify.empty()) die(1, "--sparsify '" + bad_sparsify + "' is not valid for post-alignment PAF/1aln filtering");
+  if (!no_filter && !tree_sparsify.empty())
+    die(1, "--sparsify '" + tree_sparsify + "': tree sparsification of the input PAF (src/main.rs:3640-3688) is not supported");
   swg_config cfg{};
   if (!parse_filter_mode(num_mappings, &cfg.mapping_filter_mode, &cfg.mapping_max_per_query, &cfg.mapping_max_per_target)) return 1;
   if (!parse_filter_mode(scaffold_filter, &cfg.scaffold_filter_mode, &cfg.scaffold_max_per_query, &cfg.scaffold_max_per_target)) return 1;
@@ -314,12 +324,11 @@ int main(int argc, char** argv) {
   const std::string out_path = output_file.empty() ? "-" : output_file;
   const swg_records* r = swg_paf_records(paf);
   const uint64_t n = r->n;
-  if (no_filter) {  // main.rs:3461-3470: every line, newline-normalised
+  if (no_filter) {  // main.rs:3461-3473: every line, newline-normalised, ALWAYS to stdout (--output-file is not consulted)
     const char* text;
     uint64_t len;
     swg_paf_text(paf, &text, &len);
-    FILE* out = output_file.empty() ? stdout : std::fopen(output_file.c_str(), "wb");
-    if (!out) die(2, "cannot create " + output_file + ": " + std::strerror(errno));
+    FILE* out = stdout;
     for (uint64_t pos = 0; pos < len;) {
       const void* nl = std::memchr(text + pos, '\n', len - pos);
       const uint64_t end = nl ? (uint64_t)((const char*)nl - text) : len;
@@ -329,7 +338,6 @@ int main(int argc, char** argv) {
       std::fputc('\n', out);
       pos = end + 1;
     }
-    if (out != stdout) std::fclose(out);
     swg_paf_close(paf);
     gpu_init.join();
     return 0;

@@ -176,7 +176,17 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
   // Scratch high-water marks measured on the 10^8 workload: 58 B/record for the sweep-only pipeline, 252-370 B/record
   // with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a context's first call.
   {
-    const size_t want = (size_t)rec->n * (cfg->scaffold_gap == 0 ? 72 : 400) + (size_t(8) << 20);
+    size_t want = (size_t)rec->n * (cfg->scaffold_gap == 0 ? 72 : 400) + (size_t(8) << 20);
+    if (cfg->scaffold_gap != 0) {
+      // the scaffold stage keeps two dense genome-pair tables (first appearance of a pair under either prefix rule);
+      // with names without '#' every sequence is its own genome and the tables outgrow the per-record estimate
+      const uint64_t gl = rec->n_genome_last, g2 = rec->n_genome_two;
+      if (gl > (1u << 14) || g2 > (1u << 14))
+        return swg_set_error(ctx, SWG_ERR_UNSUPPORTED,
+                             "%llu / %llu genomes under the two prefix rules: more than 2^14 genomes is not supported "
+                             "(dense genome-pair tables)", (unsigned long long)gl, (unsigned long long)g2);
+      want += (size_t)(gl * gl + g2 * g2) * sizeof(uint32_t);
+    }
     if (ctx->arena_cap < want) {
       size_t free_b = 0, total_b = 0;
       const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;

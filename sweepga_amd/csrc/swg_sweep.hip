@@ -284,11 +284,12 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 }
 
 // ---- k == 1 -----------------------------------------------------------------------------------------------------
-// With T(x) the best active interval at x and T-(x) the best one just before x (active set {s < x <= e}):
-//   * `ever top` only has to be recorded where T changes, and T(x) != T-(x) exactly there;
+// With T(x) the best active interval at x:
+//   * T changes at an event coordinate x only if T(x) begins at x, or if the previous top ends at x;
 //   * an active i != T(x) has been tested against this T already unless T changed at x or i begins at x
 //     (induction over the event coordinates), so the O(active) pass over everything runs only at points where the top
-//     changes (and at the tile's first coordinate); elsewhere only the begins AT x are tested;
+//     changes (and at the tile's first coordinate); elsewhere only the begins AT x are tested; and an END coordinate
+//     needs no work at all unless the interval that ends there was the top just before it;
 //   * inside a tile, let S* be the best carry-in that spans the tile's whole coordinate range: it is active at every point
 //     of the tile, so an interval that ranks below it is never T there.  Candidates for T are S* and the intervals that
 //     rank above it, and only THEIR ends can change T, so the other intervals' ends are not evaluation points at all.
@@ -473,6 +474,8 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     bool eval;
     uint64_t PX;
     int Q0;
+    uint64_t PK = KEY, PS = X;  // priority of the interval whose end is the point (batches >= 1)
+    uint32_t PI = ID;
     if (batch == 0) {  // start coordinates: the last begin of each run, unless the run continues in the next tile
       eval = valid && X != 0 && (tid == TB - 1 || sx[tid + 1] != X) && X != x_next;
       PX = X;
@@ -486,11 +489,21 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
       } else if (cc_in_lds) {
         PX = (uint32_t)tid < n_cc ? le[tid] : 0;
         eval = PX != 0 && PX < x_next;
+        if (eval) {
+          PK = lkey[tid];
+          PS = ls[tid];
+          PI = lid[tid];
+        }
       } else {
         const uint32_t ci = c_begin + (batch - 2) * TB + tid;
         eval = ci < c_end;
         PX = eval ? a.c_e[ci] : 0;
         eval = eval && PX < x_next;
+        if (eval) {
+          PK = a.c_key[ci];
+          PS = a.c_s[ci];
+          PI = a.c_id[ci];
+        }
       }
       int l = 0, r = TB;  // upper_bound(sx, PX) - 1; sx is ~0 past the end of a short last tile
       while (l < r) {
@@ -504,46 +517,64 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     }
     if (!eval) continue;  // no barrier below this line
 
-    // ---- pass 1: T(x) = best of {s <= x < e}, T-(x) = best of {s < x <= e}, over S* and the candidates
-    uint64_t tk = star_k, ts = star_s, te = star_e, mk = star_k, ms = star_s;
-    uint32_t ti = star_i, mi = star_i;
-    bool have_t = have_star, have_m = have_star;
-    auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {  // caller: s <= PX, e >= PX
-      if (e > PX && (!have_t || prio_less(key, s, id, tk, ts, ti))) {
+    // ---- an end coordinate changes nothing unless the interval that ends here was the top just before x, i.e. unless no
+    // candidate j with s_j < x <= e_j ranks above it (S* ranks below every candidate; other intervals that end or begin
+    // at x have their own threads)
+    if (batch != 0) {
+      bool was_top = true;
+      for (int q = Q0; q >= 0 && was_top; --q) {
+        if (spm2[o1 + q] < PX) break;  // no earlier candidate reaches PX
+        if (se2[o1 + q] >= PX) {
+          const uint64_t sq = sx[q];
+          if (sq < PX && prio_less(skey[q], sq, sid[q], PK, PS, PI)) was_top = false;
+        }
+      }
+      if (cc_in_lds) {
+        for (uint32_t c = 0; c < n_cc && was_top; ++c)
+          if (le[c] >= PX && prio_less(lkey[c], ls[c], lid[c], PK, PS, PI)) was_top = false;
+      } else {
+        for (uint32_t c = c_begin; c < c_end && was_top; ++c)
+          if (a.c_e[c] >= PX && prio_less(a.c_key[c], a.c_s[c], a.c_id[c], PK, PS, PI)) was_top = false;
+      }
+      if (!was_top) continue;
+    }
+    // ---- pass 1: T(x) = best of {s <= x < e} over S* and the candidates
+    uint64_t tk = star_k, ts = star_s, te = star_e;
+    uint32_t ti = star_i;
+    bool have_t = have_star;
+    auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {  // caller: s <= PX < e
+      if (!have_t || prio_less(key, s, id, tk, ts, ti)) {
         tk = key;
         ts = s;
         te = e;
         ti = id;
         have_t = true;
       }
-      if (s < PX && (!have_m || prio_less(key, s, id, mk, ms, mi))) {
-        mk = key;
-        ms = s;
-        mi = id;
-        have_m = true;
-      }
     };
     for (int q = Q0; q >= 0; --q) {
-      if (spm2[o1 + q] < PX) break;  // no earlier candidate reaches PX
+      if (spm2[o1 + q] <= PX) break;  // no earlier candidate covers PX
       const uint64_t ee = se2[o1 + q];
-      if (ee >= PX) take(sx[q], ee, skey[q], sid[q]);
+      if (ee > PX) take(sx[q], ee, skey[q], sid[q]);
     }
     if (cc_in_lds) {
       for (uint32_t c = 0; c < n_cc; ++c) {
         const uint64_t e = le[c];
-        if (e >= PX) take(ls[c], e, lkey[c], lid[c]);
+        if (e > PX) take(ls[c], e, lkey[c], lid[c]);
       }
     } else {
       for (uint32_t c = c_begin; c < c_end; ++c) {
         const uint64_t e = a.c_e[c];
-        if (e >= PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
+        if (e > PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
       }
     }
     if (!have_t) continue;
     a.top[ti] = 1;
     if (!pass2) continue;
-    // ---- pass 2: active intervals that overlap T(x) too much
-    const bool full = !have_m || mi != ti || PX == x_b;
+    // ---- pass 2: active intervals that overlap T(x) too much.  The top is new at x when the old one ended here (an end
+    // point whose interval was the top) or when T(x) itself begins at x; otherwise every interval that was active before x
+    // has met this top already and only the begins AT x are tested.  The tile's first coordinate always takes the full
+    // pass (carry-ins that begin exactly there are not among the tile's own begins).
+    const bool full = batch != 0 || ts == PX || PX == x_b;
     if (full) {  // the top changed here: everything that is active
       for (int q = Q0; q >= 0; --q) {
         if (spm[q] <= PX) break;

@@ -32,13 +32,26 @@ def test_help_and_flag_errors(cli, tmp_path):
     assert r.returncode == 2 and "Invalid identity value" in r.stderr
 
 
-def test_no_filter_copies_input(cli, tmp_path):  # main.rs:3461-3470
+def test_no_filter_copies_input_to_stdout(cli, tmp_path):  # main.rs:3461-3473: stdout, --output-file is not consulted
+    import os
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "sweepga-ref")
     p = tmp_path / "a.paf"
     o = tmp_path / "o.paf"
     p.write_bytes(b"a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\r\nshort\n")
-    r = subprocess.run([cli, str(p), "--no-filter", "--output-file", str(o)], capture_output=True, text=True)
-    assert r.returncode == 0
-    assert o.read_bytes() == b"a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\nshort\n"
+    for exe in (cli, ref):
+        r = subprocess.run([exe, str(p), "--no-filter", "--output-file", str(o)], capture_output=True)
+        assert r.returncode == 0
+        assert r.stdout == b"a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\nshort\n"
+        assert not o.exists()
+
+
+def test_numeric_flags_are_checked(cli, tmp_path):
+    """clap rejects `--overlap abc`; so does this command line (also --scaffold-overlap, --device, --threads)."""
+    p = tmp_path / "a.paf"
+    p.write_text("a\t1\t0\t10\t+\tb\t1\t0\t10\t9\t10\t60\n")
+    for flag, v in (("--overlap", "abc"), ("--overlap", ""), ("--scaffold-overlap", "0.5x"), ("--device", "one"), ("--threads", "-3")):
+        r = subprocess.run([cli, str(p), "--no-filter", flag, v], capture_output=True, text=True)
+        assert r.returncode == 2 and "invalid value for " + flag in r.stderr, (flag, v, r.returncode, r.stderr)
 
 
 def test_without_gpu_exits_loudly(cli, tmp_path):
@@ -52,8 +65,10 @@ def test_without_gpu_exits_loudly(cli, tmp_path):
 
 
 def test_sparsify_flag_is_validated_only(cli, tmp_path):
-    """--sparsify on the PAF path (src/knn_graph.rs:59-160, src/main.rs:3494-3509): accepted values have no effect on
-    the filter, pre-alignment strategies are refused after the --no-filter shortcut, garbage is a usage error."""
+    """--sparsify on the PAF path (src/knn_graph.rs:59-160, src/main.rs:3494-3509): `none` / `all` / fractions / `random:`
+    have no effect on the filter, pre-alignment strategies are refused after the --no-filter shortcut, garbage is a usage
+    error, and `tree:` / `knn:` (which make the reference tree-filter the PAF first, src/main.rs:3640-3688) are refused as
+    unsupported instead of being silently ignored."""
     import os
     ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "sweepga-ref")
     p = tmp_path / "a.paf"
@@ -67,3 +82,7 @@ def test_sparsify_flag_is_validated_only(cli, tmp_path):
         for exe in (cli, ref):
             r = subprocess.run([exe, str(p), "--sparsify", v], capture_output=True, text=True)
             assert r.returncode == 1 and "not valid for post-alignment" in r.stderr, (exe, v, r.returncode, r.stderr)
+    for v in ("tree:2:1:0.1", "tree:3", "knn:3"):
+        for exe in (cli, ref):
+            r = subprocess.run([exe, str(p), "--sparsify", v], capture_output=True, text=True)
+            assert r.returncode == 1 and "not supported" in r.stderr and r.stdout == "", (exe, v, r.returncode, r.stderr)

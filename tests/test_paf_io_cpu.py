@@ -2,6 +2,7 @@
 write rules (paf_filter.rs:292-376, 1689-1726) and the Python mirror.  Host code only: runs without a GPU."""
 import ctypes as C
 import gzip
+import os
 import struct
 import zlib
 
@@ -186,3 +187,27 @@ def test_fuzz_slice_against_oracle(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_paf_io.py"), "--minutes", "0.1", "--seed", "500000"],
                        capture_output=True, text=True, cwd=root)
     assert r.returncode == 0 and "'failures': 0" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+
+
+def test_writing_onto_the_mapped_input(tmp_path):
+    """--output-file equal to the input path: the writer must not truncate the file it has mapped (the reference filters
+    into a temporary file first, src/main.rs:3630-3636).  The result replaces the input once it is complete."""
+    rng = np.random.default_rng(8)
+    rec = gen.random_records(rng, 5000)
+    text = gen.records_to_paf(rng, rec, junk_lines=False)
+    a, b = tmp_path / "a.paf", tmp_path / "b.paf"
+    a.write_text(text)
+    b.write_text(text)
+    with PafFile(b) as pf:
+        status = (rng.random(pf.n) < 0.5).astype(np.uint8) * 3
+        want_n = pf.write(tmp_path / "want.out", status)
+    for target in (a, tmp_path / "link.paf"):   # the same path, and another name of the same inode
+        if target.name == "link.paf":
+            os.link(a, target)
+        with PafFile(a) as pf:
+            assert pf.write(target, status) == want_n
+        assert target.read_bytes() == (tmp_path / "want.out").read_bytes()
+        assert not [p for p in os.listdir(tmp_path) if ".swg_tmp." in p]
+        a.write_text(text)
+        if target.name == "link.paf":
+            os.unlink(target)

@@ -83,33 +83,37 @@ def sweep_axis_model(seg, start, end, key, thr, TB=8, CCAP=6, STAR_MIN=3, stats=
             stats["tiles"] += 1
             stats["pruned"] += star is not None
             stats["overflow"] += not cc_in_lds
-        # step C: points
+        # step C: points = (coordinate, the interval whose END it is or None for a start coordinate)
         pts = []
         for j, p in enumerate(own):
             xs = int(S[p])
             if xs != 0 and (j == len(own) - 1 or int(S[own[j + 1]]) != xs) and xs != x_next:
-                pts.append(xs)
+                pts.append((xs, None))
         for p in co:
             if int(S[p]) != 0 and int(E[p]) > int(S[p]) and int(E[p]) < x_next:
-                pts.append(int(E[p]))
+                pts.append((int(E[p]), p))
         for p in (cc_all if cc_in_lds else cin):
             if int(E[p]) < x_next:
-                pts.append(int(E[p]))
-        for px in pts:
-            T = Tm = None
-            cands = ([star] if star is not None else []) + pass1_carry + co
+                pts.append((int(E[p]), p))
+        cands = pass1_carry + co   # S* is handled apart: it ranks below every candidate and never ends in the tile
+        for px, ender in pts:
+            if ender is not None:
+                # an end coordinate acts only if its interval was the top just before x
+                was_top = not any(int(S[p]) < px <= int(E[p]) and prio(p) < prio(ender) for p in cands)
+                if not was_top:
+                    continue
+            T = star
             for p in cands:
-                s, e = int(S[p]), int(E[p])
-                if s <= px < e and (T is None or prio(p) < prio(T)):
+                if int(S[p]) <= px < int(E[p]) and (T is None or prio(p) < prio(T)):
                     T = p
-                if s < px <= e and (Tm is None or prio(p) < prio(Tm)):
-                    Tm = p
             if T is None:
                 continue
             top[I[T]] = True
+            if stats is not None:
+                stats["points"] += 1
             if thr >= 1.0:
                 continue
-            need_full = (Tm is None) or (Tm != T) or px == x_b
+            need_full = ender is not None or int(S[T]) == px or px == x_b
             if need_full:
                 targets = [p for p in own + cin if int(S[p]) <= px < int(E[p])]
                 if stats is not None:
@@ -119,8 +123,6 @@ def sweep_axis_model(seg, start, end, key, thr, TB=8, CCAP=6, STAR_MIN=3, stats=
             for p in targets:
                 if p != T and overlap_exceeds(int(S[p]), int(E[p]), int(S[T]), int(E[T]), thr):
                     ovl[I[p]] = True
-            if stats is not None:
-                stats["points"] += 1
     return single | (top & ~ovl)
 
 
