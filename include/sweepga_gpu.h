@@ -245,6 +245,38 @@ int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, cons
                    swg_stats* stats, double timing_ms[4]);
 const char* swg_paf_last_error(void);
 
+/* ---- .1aln front end: record derivation (src/unified_filter.rs:21-154) ----------------------------------------
+ * The reference reads .1aln through fastga-rs (AlnReader::open / get_all_seq_names / read_alignment, call sites
+ * src/unified_filter.rs:27-36, 67), an un-vendored dependency (fastga-rs 0.1.2 @5216a15, onecode 0.1.0 @5fa1e93,
+ * Cargo.lock:617-619, 1192-1194): the DECODER stays in the Rust host.  What crosses the boundary is the decoded
+ * alignment as that reader returns it; the library derives the RecordMeta columns exactly as extract_1aln_metadata does:
+ *   names cut at the first white space after skipping leading white space, the whole header when it has no word
+ *     (split_whitespace().next().unwrap_or(full), :83-92; white space = Unicode White_Space)
+ *   block_length = (query_end - query_start) + (target_end - target_start)   (:107-112, wrapping u64)
+ *   identity = matches / query_span as f64, 0.0 when the span is 0           (:119-123)
+ *   rank = position of the alignment in the file                              (:63, :142)
+ * and interns the names like the PAF path.  swg_filter() over swg_aln_records() is filter_file's .1aln branch
+ * (src/unified_filter.rs:310-317); the host writes the passing alignments itself (write_1aln_filtered, :158-190: the
+ * ranks with status != 0).  Coordinates / block lengths >= 2^32: SWG_ERR_RANGE (same limit as the PAF path). */
+typedef struct swg_aln_input {
+  uint64_t n;
+  const char* const* query_name;   /* [n] NUL-terminated: id_to_name[aln.query_name], or the raw field (:71-82) */
+  const char* const* target_name;  /* [n] */
+  const uint64_t* query_start;     /* [n] aln.query_start as u64 ... */
+  const uint64_t* query_end;
+  const uint64_t* target_start;
+  const uint64_t* target_end;
+  const uint64_t* matches;         /* [n] aln.matches as u64 (:115) */
+  const char* strand;              /* [n] aln.strand: '+', anything else counts as '-' */
+} swg_aln_input;
+typedef struct swg_aln swg_aln;
+int swg_aln_open(const swg_aln_input* in, swg_aln** out);
+void swg_aln_close(swg_aln* a);
+/* records in file order (rank k = record k); pointers are owned by the handle */
+const swg_records* swg_aln_records(const swg_aln* a);
+uint32_t swg_aln_num_sequences(const swg_aln* a);
+const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id); /* the name after the first-word cut */
+
 /* ---- ANI pre-pass for "aniN" identity thresholds (src/main.rs:296-688, src/cli.rs:76-130) -------------------
  * calculate_ani_stats: median over genome pairs (last-'#' prefixes, unordered) of Σmatches / Σblock_len, over
  *   SWG_ANI_ALL         every inter-genome line                                   main.rs:339-342, 392-498

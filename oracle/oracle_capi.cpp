@@ -343,4 +343,36 @@ void orc_log_range(uint64_t first, uint64_t n, double* y) {
   for (uint64_t i = 0; i < n; ++i) y[i] = std::log((double)(first + i));
 }
 
+// extract_1aln_metadata's record derivation (src/unified_filter.rs:83-142) over decoded alignments.  Names come back
+// through name_out (n query names then n target names, name_cap bytes each, NUL-terminated).
+int64_t orc_records_from_1aln(uint64_t n, const char* const* qname, const char* const* tname, const uint64_t* qs,
+                              const uint64_t* qe, const uint64_t* ts, const uint64_t* te, const uint64_t* matches,
+                              const char* strand, uint64_t* block_length, double* identity, char* name_out,
+                              uint64_t name_cap) {
+  try {
+    std::vector<AlnRecord> alns(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      alns[i].query_name = qname[i];
+      alns[i].target_name = tname[i];
+      alns[i].query_start = qs[i];
+      alns[i].query_end = qe[i];
+      alns[i].target_start = ts[i];
+      alns[i].target_end = te[i];
+      alns[i].matches = matches[i];
+      alns[i].strand = strand[i];
+    }
+    const std::vector<RecordMeta> md = records_from_1aln(alns);
+    for (uint64_t i = 0; i < n; ++i) {
+      block_length[i] = md[i].block_length;
+      identity[i] = md[i].identity;
+      if (md[i].query_name.size() + 1 > name_cap || md[i].target_name.size() + 1 > name_cap) return -2;
+      std::memcpy(name_out + i * name_cap, md[i].query_name.c_str(), md[i].query_name.size() + 1);
+      std::memcpy(name_out + (n + i) * name_cap, md[i].target_name.c_str(), md[i].target_name.size() + 1);
+    }
+    return (int64_t)n;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -1290,4 +1290,64 @@ double calculate_ani_stats(const std::string& input_path, const AniMethod& metho
   return median_pair_ani(pairs);
 }
 
+// ---- .1aln record derivation (src/unified_filter.rs:83-142) ---------------------------------------------------------
+namespace {
+// char::is_whitespace = Unicode White_Space: U+0009-000D, U+0020, U+0085, U+00A0, U+1680, U+2000-200A, U+2028, U+2029,
+// U+202F, U+205F, U+3000.  Returns the byte length of the white-space character at s[i], or 0.
+size_t ws_len(const std::string& s, size_t i) {
+  const unsigned char c = (unsigned char)s[i];
+  if ((c >= 0x09 && c <= 0x0d) || c == 0x20) return 1;
+  if (c == 0xc2 && i + 1 < s.size()) {
+    const unsigned char d = (unsigned char)s[i + 1];
+    return (d == 0x85 || d == 0xa0) ? 2 : 0;
+  }
+  if (i + 2 < s.size()) {
+    const unsigned char d = (unsigned char)s[i + 1], e = (unsigned char)s[i + 2];
+    if (c == 0xe1 && d == 0x9a && e == 0x80) return 3;  // U+1680
+    if (c == 0xe2 && d == 0x80 && ((e >= 0x80 && e <= 0x8a) || e == 0xa8 || e == 0xa9 || e == 0xaf)) return 3;
+    if (c == 0xe2 && d == 0x81 && e == 0x9f) return 3;  // U+205F
+    if (c == 0xe3 && d == 0x80 && e == 0x80) return 3;  // U+3000
+  }
+  return 0;
+}
+}  // namespace
+
+std::string first_word_or_all(const std::string& s) {
+  size_t i = 0;
+  while (i < s.size()) {  // split_whitespace skips leading white space
+    const size_t w = ws_len(s, i);
+    if (!w) break;
+    i += w;
+  }
+  if (i >= s.size()) return s;  // no word at all: unwrap_or(&full)
+  size_t j = i;
+  while (j < s.size() && !ws_len(s, j)) ++j;
+  return s.substr(i, j - i);
+}
+
+std::vector<RecordMeta> records_from_1aln(const std::vector<AlnRecord>& alns) {
+  std::vector<RecordMeta> out;
+  out.reserve(alns.size());
+  size_t rank = 0;
+  for (const AlnRecord& a : alns) {
+    RecordMeta m;
+    m.rank = rank++;
+    m.query_name = first_word_or_all(a.query_name);    // :83-87
+    m.target_name = first_word_or_all(a.target_name);  // :88-92
+    const uint64_t query_span = a.query_end - a.query_start;     // :107 (wrapping in release Rust)
+    const uint64_t target_span = a.target_end - a.target_start;  // :108
+    m.block_length = query_span + target_span;                   // :112
+    m.matches = a.matches;                                       // :115
+    m.identity = query_span > 0 ? (double)m.matches / (double)query_span : 0.0;  // :119-123
+    m.query_start = a.query_start;
+    m.query_end = a.query_end;
+    m.target_start = a.target_start;
+    m.target_end = a.target_end;
+    m.alignment_length = m.block_length;
+    m.strand = a.strand;
+    out.push_back(m);
+  }
+  return out;
+}
+
 }  // namespace orc

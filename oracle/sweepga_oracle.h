@@ -119,6 +119,20 @@ struct RecordMeta {
   int chain_status = ST_UNASSIGNED;
 };
 
+// A decoded .1aln alignment as fastga-rs' AlnReader::read_alignment hands it to extract_1aln_metadata
+// (src/unified_filter.rs:67-82: names already looked up in id_to_name, or the raw field when the id is unknown).
+// The decoder itself (fastga-rs 0.1.2 / onecode 0.1.0) is an un-vendored dependency: parity of DECODING is unpinned.
+struct AlnRecord {
+  std::string query_name, target_name;  // full FASTA headers
+  uint64_t query_start = 0, query_end = 0, target_start = 0, target_end = 0;
+  uint64_t matches = 0;
+  char strand = '+';
+};
+// src/unified_filter.rs:83-142: the RecordMeta of every alignment (rank = position)
+std::vector<RecordMeta> records_from_1aln(const std::vector<AlnRecord>& alns);
+// str::split_whitespace().next().unwrap_or(full) (src/unified_filter.rs:83-92)
+std::string first_word_or_all(const std::string& s);
+
 // src/paf_filter.rs:142-155
 struct MergedChain {
   std::string query_name, target_name;

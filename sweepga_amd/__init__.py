@@ -8,6 +8,7 @@ from .filter import (ChainStatus, FilterConfig, FilterMode, PafFilter, PlaneSwee
                      ScoringFunction, SequenceIndex, pack_records, plane_sweep_both, plane_sweep_query,
                      plane_sweep_target, USIZE_MAX, UnionFind, merge_mappings_into_chains, plane_sweep_scaffolds)
 from .paf import PafFile  # noqa: F401
+from .aln import AlnRecords  # noqa: F401
 from .ani import (AniMethod, AniMethodKind, NSort, calculate_ani_stats, parse_ani_method,  # noqa: F401
                   parse_identity_value)
 

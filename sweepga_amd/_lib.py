@@ -20,7 +20,8 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
-           "swg_filter_multi", "swg_memory_info", "swg_reserve"]
+           "swg_filter_multi", "swg_memory_info", "swg_reserve",
+           "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name"]
 
 
 class SwgError(RuntimeError):
@@ -200,6 +201,16 @@ def load():
     lib.swg_reserve.argtypes = [C.c_void_p, C.c_uint64]
     lib.swg_paf_ani_stats.restype = C.c_int
     lib.swg_paf_ani_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.swg_aln_open.restype = C.c_int
+    lib.swg_aln_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.swg_aln_close.restype = None
+    lib.swg_aln_close.argtypes = [C.c_void_p]
+    lib.swg_aln_records.restype = C.POINTER(SwgRecords)
+    lib.swg_aln_records.argtypes = [C.c_void_p]
+    lib.swg_aln_num_sequences.restype = C.c_uint32
+    lib.swg_aln_num_sequences.argtypes = [C.c_void_p]
+    lib.swg_aln_sequence_name.restype = C.c_char_p
+    lib.swg_aln_sequence_name.argtypes = [C.c_void_p, C.c_uint32]
     _lib = lib
     return lib
 

@@ -1066,3 +1066,139 @@ int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, cons
 }
 
 }  // extern "C"
+
+// ---- .1aln front end: record derivation (src/unified_filter.rs:83-142) -------------------------------------------------
+struct swg_aln {
+  std::vector<uint32_t> q_id, t_id, qs, qe, ts, te, matches, block;
+  std::vector<double> identity;
+  std::vector<uint8_t> strand;
+  std::vector<std::string> names;
+  std::vector<uint32_t> g_last, g_two;
+  swg_records rec{};
+};
+
+namespace {
+// char::is_whitespace (Unicode White_Space): byte length of the white-space character at s[i], or 0
+size_t ws_len(std::string_view s, size_t i) {
+  const unsigned char c = (unsigned char)s[i];
+  if ((c >= 0x09 && c <= 0x0d) || c == 0x20) return 1;
+  if (c == 0xc2 && i + 1 < s.size()) {
+    const unsigned char d = (unsigned char)s[i + 1];
+    return (d == 0x85 || d == 0xa0) ? 2 : 0;
+  }
+  if (i + 2 < s.size()) {
+    const unsigned char d = (unsigned char)s[i + 1], e = (unsigned char)s[i + 2];
+    if (c == 0xe1 && d == 0x9a && e == 0x80) return 3;
+    if (c == 0xe2 && d == 0x80 && ((e >= 0x80 && e <= 0x8a) || e == 0xa8 || e == 0xa9 || e == 0xaf)) return 3;
+    if (c == 0xe2 && d == 0x81 && e == 0x9f) return 3;
+    if (c == 0xe3 && d == 0x80 && e == 0x80) return 3;
+  }
+  return 0;
+}
+// split_whitespace().next().unwrap_or(full), src/unified_filter.rs:83-92
+std::string_view first_word_or_all(std::string_view s) {
+  size_t i = 0;
+  while (i < s.size()) {
+    const size_t w = ws_len(s, i);
+    if (!w) break;
+    i += w;
+  }
+  if (i >= s.size()) return s;
+  size_t j = i;
+  while (j < s.size() && !ws_len(s, j)) ++j;
+  return s.substr(i, j - i);
+}
+}  // namespace
+
+extern "C" {
+
+int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
+  if (out) *out = nullptr;
+  if (!in || !out) return paf_error(SWG_ERR_INVALID, "swg_aln_open: NULL argument");
+  const uint64_t n = in->n;
+  if (n && (!in->query_name || !in->target_name || !in->query_start || !in->query_end || !in->target_start ||
+            !in->target_end || !in->matches || !in->strand))
+    return paf_error(SWG_ERR_INVALID, "swg_aln_open: a column is NULL");
+  if (n >= (uint64_t(1) << 31)) return paf_error(SWG_ERR_RANGE, "swg_aln_open: more than 2^31-1 alignments");
+  swg_aln* a = nullptr;
+  try {
+    a = new swg_aln;
+    const size_t cap = n ? n : 1;
+    a->q_id.resize(cap);
+    a->t_id.resize(cap);
+    a->qs.resize(cap);
+    a->qe.resize(cap);
+    a->ts.resize(cap);
+    a->te.resize(cap);
+    a->matches.resize(cap);
+    a->block.resize(cap);
+    a->identity.resize(cap);
+    a->strand.resize(cap);
+    std::unordered_map<std::string, uint32_t> ids;  // SequenceIndex: first appearance, query before target
+    auto intern = [&](std::string_view nm) {
+      auto it = ids.find(std::string(nm));
+      if (it != ids.end()) return it->second;
+      const uint32_t id = (uint32_t)a->names.size();
+      a->names.emplace_back(nm);
+      ids.emplace(std::string(nm), id);
+      return id;
+    };
+    for (uint64_t k = 0; k < n; ++k) {
+      if (!in->query_name[k] || !in->target_name[k]) {
+        delete a;
+        return paf_error(SWG_ERR_INVALID, "swg_aln_open: name %llu is NULL", (unsigned long long)k);
+      }
+      a->q_id[k] = intern(first_word_or_all(in->query_name[k]));
+      a->t_id[k] = intern(first_word_or_all(in->target_name[k]));
+      const uint64_t q0 = in->query_start[k], q1 = in->query_end[k], t0 = in->target_start[k], t1 = in->target_end[k];
+      const uint64_t query_span = q1 - q0, target_span = t1 - t0;  // :107-108 (wrapping, as release Rust)
+      const uint64_t block = query_span + target_span;             // :112
+      const uint64_t m = in->matches[k];                           // :115
+      if ((q0 | q1 | t0 | t1 | block | m) >> 32) {
+        delete a;
+        return paf_error(SWG_ERR_RANGE, "alignment %llu: a coordinate, the block length or the match count is >= 2^32",
+                         (unsigned long long)k);
+      }
+      a->qs[k] = (uint32_t)q0;
+      a->qe[k] = (uint32_t)q1;
+      a->ts[k] = (uint32_t)t0;
+      a->te[k] = (uint32_t)t1;
+      a->matches[k] = (uint32_t)m;
+      a->block[k] = (uint32_t)block;
+      a->identity[k] = query_span > 0 ? (double)m / (double)query_span : 0.0;  // :119-123
+      a->strand[k] = in->strand[k] == '+' ? 0 : 1;
+    }
+    const uint32_t n_last = genome_table(a->names, prefix_last, &a->g_last);
+    const uint32_t n_two = genome_table(a->names, prefix_two, &a->g_two);
+    swg_records& r = a->rec;
+    r.n = n;
+    r.q_id = a->q_id.data();
+    r.t_id = a->t_id.data();
+    r.q_start = a->qs.data();
+    r.q_end = a->qe.data();
+    r.t_start = a->ts.data();
+    r.t_end = a->te.data();
+    r.identity = a->identity.data();
+    r.matches = a->matches.data();
+    r.block_len = a->block.data();
+    r.strand = a->strand.data();
+    r.n_seq = (uint32_t)(a->names.empty() ? 1 : a->names.size());
+    r.seq_genome_last = a->g_last.data();
+    r.n_genome_last = n_last;
+    r.seq_genome_two = a->g_two.data();
+    r.n_genome_two = n_two;
+  } catch (const std::bad_alloc&) {
+    delete a;
+    return paf_error(SWG_ERR_OOM, "swg_aln_open: out of host memory");
+  }
+  *out = a;
+  return SWG_OK;
+}
+void swg_aln_close(swg_aln* a) { delete a; }
+const swg_records* swg_aln_records(const swg_aln* a) { return a ? &a->rec : nullptr; }
+uint32_t swg_aln_num_sequences(const swg_aln* a) { return a ? (uint32_t)a->names.size() : 0; }
+const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id) {
+  return (a && id < a->names.size()) ? a->names[id].c_str() : nullptr;
+}
+
+}  // extern "C"

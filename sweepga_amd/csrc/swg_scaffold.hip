@@ -243,74 +243,52 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
   c_ext[p] = ext;
 }
 
-// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): the 256 windows of a
-// work-group overlap almost entirely, so the union is staged through LDS in chunks and every (i, j) costs three LDS reads
-// and 32-bit arithmetic instead of three global loads and 64-bit arithmetic (coordinates are u32; a gap limit beyond 2^32
-// cannot bind, so it is clamped).  Results are identical to chain_candidates_kernel.
-constexpr int CT_CHUNK = 1024;
-__global__ __launch_bounds__(EW) void chain_candidates_tiled_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                                    const uint32_t* __restrict__ group_begin,
-                                                                    uint32_t n_groups, const uint64_t* __restrict__ s_grp,
-                                                                    const uint32_t* __restrict__ s_qs,
-                                                                    const uint32_t* __restrict__ s_qe,
-                                                                    const uint32_t* __restrict__ s_ts,
-                                                                    const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                                    unsigned long long* __restrict__ c_d,
-                                                                    uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
-                                                                    uint32_t* __restrict__ c_ext) {
-  __shared__ uint32_t l_qs[CT_CHUNK], l_ts[CT_CHUNK], l_te[CT_CHUNK];
-  const uint64_t p0 = (uint64_t)blockIdx.x * EW;
-  const uint64_t p = p0 + threadIdx.x;
-  const bool valid = p < m;
-  uint32_t e = 0, qe_i = 0, ts_i = 0, te_i = 0;
-  bool minus = false;
-  if (valid) {
-    const uint32_t g = s_gidx[p];
-    e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
-    minus = (s_grp[p] & 1ull) != 0;
-    qe_i = s_qe[p];
-    ts_i = s_ts[p];
-    te_i = s_te[p];
-  }
+// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): one WAVEFRONT per i.
+// A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
+// has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
+// neighbouring i's re-read the same lines from L1/L2), every lane keeps its own KC best in (d, j) order, and the KC best
+// of the wavefront are drawn by KC rounds of a wave-wide lexicographic minimum.  32-bit arithmetic (coordinates are u32; a
+// gap limit beyond 2^32 cannot bind, so it is clamped).  Results are identical to chain_candidates_kernel.
+constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
+__global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                                   const uint32_t* __restrict__ group_begin,
+                                                                   uint32_t n_groups, const uint64_t* __restrict__ s_grp,
+                                                                   const uint32_t* __restrict__ s_qs,
+                                                                   const uint32_t* __restrict__ s_qe,
+                                                                   const uint32_t* __restrict__ s_ts,
+                                                                   const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                                   unsigned long long* __restrict__ c_d,
+                                                                   uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
+                                                                   uint32_t* __restrict__ c_ext) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
   const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
-  const bool wrap = max_gap == ~0ull;
+  const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
-  const uint64_t bound64 = (uint64_t)qe_i + max_gap;
-  const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
-  uint64_t bd[KC];
-  uint32_t bj[KC];
+  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
+    const uint32_t g = s_gidx[p];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
+    const bool minus = (s_grp[p] & 1ull) != 0;
+    const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
+    const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
+    const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
+    uint64_t bd[KC];
+    uint32_t bj[KC];
 #pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    bd[k] = ~0ull;
-    bj[k] = NONE;
-  }
-  uint32_t count = 0, ext = 0;
-  bool done = !valid || (uint32_t)p + 1 >= e;
-  for (uint64_t c0 = p0 + 1; c0 < m; c0 += CT_CHUNK) {
-    for (int t = threadIdx.x; t < CT_CHUNK; t += EW) {
-      const uint64_t j = c0 + t;
-      if (j < m) {
-        l_qs[t] = s_qs[j];
-        l_ts[t] = s_ts[j];
-        l_te[t] = s_te[j];
-      }
+    for (int k = 0; k < KC; ++k) {
+      bd[k] = ~0ull;
+      bj[k] = NONE;
     }
-    __syncthreads();
-    if (!done) {
-      const uint32_t j_lo = (uint32_t)p + 1 > (uint32_t)c0 ? (uint32_t)p + 1 : (uint32_t)c0;
-      const uint64_t c_hi = c0 + CT_CHUNK;
-      const uint32_t j_hi = (uint64_t)e < c_hi ? e : (uint32_t)c_hi;
-      for (uint32_t j = j_lo; j < j_hi; ++j) {
-        const uint32_t t = j - (uint32_t)c0;
-        const uint32_t qs_j = l_qs[t];
-        if (qs_j > bound) {  // sorted by q_start (paf_filter.rs:794-796)
-          done = true;
-          break;
-        }
-        ext = j - (uint32_t)p;
-        // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic
-        // (an overlap beyond gap / 5 becomes `max_gap + 1` = reject; with max_gap = u64::MAX that wraps to 0 in
-        // release Rust, which `wrap` reproduces)
+    uint32_t count = 0, ext = 0;
+    for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool in = j < e;
+      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
+      const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
+      const uint64_t wmask = __ballot(inwin);
+      ext += (uint32_t)__popcll(wmask);
+      if (inwin) {
+        // d(i, j) of paf_filter.rs:798-836
         uint32_t q_gap, r_gap;
         bool ok = true;
         if (qs_j >= qe_i) {
@@ -322,7 +300,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_tiled_kernel(uint64_t m, 
             q_gap = 0;
           }
         }
-        const uint32_t ts_j = l_ts[t], te_j = l_te[t];
+        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
         const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
         if (a >= b) {
           r_gap = a - b;
@@ -333,39 +311,71 @@ __global__ __launch_bounds__(EW) void chain_candidates_tiled_kernel(uint64_t m, 
             r_gap = 0;
           }
         }
-        if (!ok || q_gap > gap || r_gap > gap) continue;
-        const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
-        if (count < 0xffffffffu) ++count;
-        if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
-          uint64_t cd = d;
-          uint32_t cj = j;
-          bool placed = false;
+        if (ok && q_gap <= gap && r_gap <= gap) {
+          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+          ++count;
+          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
+            uint64_t cd = d;
+            uint32_t cj = j;
+            bool placed = false;
 #pragma unroll
-          for (int k = 0; k < KC; ++k) {
-            if (placed || cd < bd[k]) {
-              placed = true;
-              const uint64_t td = bd[k];
-              const uint32_t tj = bj[k];
-              bd[k] = cd;
-              bj[k] = cj;
-              cd = td;
-              cj = tj;
+            for (int k = 0; k < KC; ++k) {
+              if (placed || cd < bd[k]) {
+                placed = true;
+                const uint64_t td = bd[k];
+                const uint32_t tj = bj[k];
+                bd[k] = cd;
+                bj[k] = cj;
+                cd = td;
+                cj = tj;
+              }
             }
           }
         }
       }
-      if (!done && j_hi >= e) done = true;
+      if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
     }
-    if (__syncthreads_and(done ? 1 : 0)) break;
-  }
-  if (!valid) return;
+    // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
 #pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    c_d[(uint64_t)k * m + p] = bd[k];
-    c_j[(uint64_t)k * m + p] = bj[k];
+    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    // the KC smallest (d, j) of the wavefront: KC rounds of a lexicographic wave minimum over the lanes' list heads
+    uint64_t out_d[KC];
+    uint32_t out_j[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      uint64_t md = bd[0];
+      uint32_t mj = bj[0];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t od = __shfl_xor(md, o, 64);
+        const uint32_t oj = __shfl_xor(mj, o, 64);
+        if (od < md || (od == md && oj < mj)) {
+          md = od;
+          mj = oj;
+        }
+      }
+      out_d[k] = md;
+      out_j[k] = mj;
+      if (mj != NONE && bj[0] == mj) {  // this lane's head was drawn: pop it
+#pragma unroll
+        for (int t = 0; t + 1 < KC; ++t) {
+          bd[t] = bd[t + 1];
+          bj[t] = bj[t + 1];
+        }
+        bd[KC - 1] = ~0ull;
+        bj[KC - 1] = NONE;
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        c_d[(uint64_t)k * m + p] = out_d[k];
+        c_j[(uint64_t)k * m + p] = out_j[k];
+      }
+      c_n[p] = count;
+      c_ext[p] = ext;
+    }
   }
-  c_n[p] = count;
-  c_ext[p] = ext;
 }
 
 struct SelBlock {
@@ -643,6 +653,7 @@ __global__ __launch_bounds__(EW) void unit_wmax_kernel(uint64_t m, const uint32_
                                                        const uint8_t* __restrict__ is_big, const uint32_t* __restrict__ c_ext,
                                                        uint32_t* __restrict__ wmax_u) {
   const int lane = threadIdx.x & 63;
+  uint32_t cur_u = NONE, cur_w = 0;  // wave-uniform: the unit this wavefront is accumulating and its maximum so far
   for (uint64_t base = (uint64_t)blockIdx.x * EW; base < m; base += (uint64_t)gridDim.x * EW) {  // block-uniform trip count
     const uint64_t p = base + threadIdx.x;
     const bool valid = p < m;
@@ -652,17 +663,23 @@ __global__ __launch_bounds__(EW) void unit_wmax_kernel(uint64_t m, const uint32_
     const uint64_t vm = __ballot(valid);
     if (vm == 0) continue;  // wave-uniform
     const uint32_t u0 = (uint32_t)__shfl((int)u, (int)__builtin_ctzll(vm), 64);
-    if (__ballot(valid && u != u0) == 0) {  // the wavefront's elements share one unit: one atomic
+    if (__ballot(valid && u != u0) == 0) {  // the wavefront's elements share one unit
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const uint32_t t = __shfl_xor(w, o, 64);
         if (t > w) w = t;
       }
-      if (lane == 0 && w) atomicMax(&wmax_u[u0], w);
+      if (u0 != cur_u) {  // flush the previous unit (one atomic per wavefront and unit, not per row)
+        if (lane == 0 && cur_w) atomicMax(&wmax_u[cur_u], cur_w);
+        cur_u = u0;
+        cur_w = 0;
+      }
+      if (w > cur_w) cur_w = w;
     } else if (big && w) {
       atomicMax(&wmax_u[u], w);
     }
   }
+  if (lane == 0 && cur_w) atomicMax(&wmax_u[cur_u], cur_w);
 }
 __global__ __launch_bounds__(EW) void spec_plan_from_wmax_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
                                                                  uint32_t n_units, const uint32_t* __restrict__ unit_begin,
@@ -1661,10 +1678,10 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
               (unsigned long long)n_groups, (unsigned long long)n_units);
-    static const bool force_tiled = getenv("SWG_CHAIN_TILED") != nullptr;  // test knob: the deep-group kernel at any size
-    if (long_groups || force_tiled)
-      SWG_LAUNCH(ctx, "chain_candidates_tiled", chain_candidates_tiled_kernel<<<nblk(m), EW, 0, st>>>(
-                                                    m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wave per i) kernel at any size
+    if (long_groups || force_deep)
+      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
+                                                   m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     else
       SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
                                                                               s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));

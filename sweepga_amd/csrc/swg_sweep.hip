@@ -297,7 +297,7 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 // intervals x ~600 points x 2 passes; on sparse data there is no spanning interval, every interval is a candidate and
 // the kernel degenerates to the plain per-point evaluation with the cheaper second pass.
 // tools/model_sweep_k1.py is the executable model of this kernel (checked against the oracle).
-constexpr int CCAP = 256;     // candidate carry-ins kept in LDS
+constexpr int CCAP = 128;     // candidate carry-ins kept in LDS (17 KB per work-group in all: 8 resident per CU)
 constexpr int STAR_MIN = 32;  // fewer carry-ins than this: no pruning (nothing to gain on sparse data)
 
 __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {

@@ -33,11 +33,13 @@ def test_struct_layouts_match_header(lib, tmp_path):
     from sweepga_amd import _lib
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "sweepga_gpu.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
-                   'sizeof(swg_config),sizeof(swg_records),sizeof(swg_stats),sizeof(swg_ani_input));return 0;}\n')
+                   'sizeof(swg_config),sizeof(swg_records),sizeof(swg_stats),sizeof(swg_ani_input));printf("%zu\\n",sizeof(swg_aln_input));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(_lib.SwgConfig), C.sizeof(_lib.SwgRecords), C.sizeof(_lib.SwgStats), C.sizeof(_lib.SwgAniInput)]
+    from sweepga_amd.aln import SwgAlnInput
+    assert sizes == [C.sizeof(_lib.SwgConfig), C.sizeof(_lib.SwgRecords), C.sizeof(_lib.SwgStats), C.sizeof(_lib.SwgAniInput),
+                     C.sizeof(SwgAlnInput)]
 
 
 def test_no_gpu_is_a_loud_error(lib):
