@@ -604,17 +604,20 @@ def main():
             hst = np.zeros(n, dtype=np.uint8)
             hch = np.zeros(n, dtype=np.uint32)
             hs = _lib.SwgStats()
-            ccfg = make_config(sw, args.pipeline).to_c()
-            best = None
-            for _ in range(3):
-                t1 = time.perf_counter()
-                ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(hrec), C.byref(ccfg), hst.ctypes.data, hch.ctypes.data, C.byref(hs)))
-                dt = time.perf_counter() - t1
-                if best is None or dt < best[0]:
-                    best = (dt, hs.h2d_ms, hs.d2h_ms, hs.device_ms)
-            pcie = {"value": n / best[0], "unit": "mappings/s", "ms": best[0] * 1e3, "h2d_ms": best[1], "d2h_ms": best[2],
-                    "device_ms": best[3], "flags": FLAGS[args.pipeline],
-                    "note": "swg_filter: pageable host buffers in and out (what a host binding calls), best of 3"}
+            pcie = {}
+            for pname in dict.fromkeys((args.pipeline, "sweep")):
+                ccfg = make_config(sw, pname).to_c()
+                best = None
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(hrec), C.byref(ccfg), hst.ctypes.data, hch.ctypes.data, C.byref(hs)))
+                    dt = time.perf_counter() - t1
+                    if best is None or dt < best[0]:
+                        best = (dt, hs.h2d_ms, hs.d2h_ms, hs.device_ms)
+                pcie[pname] = {"value": n / best[0], "unit": "mappings/s", "ms": best[0] * 1e3, "h2d_ms": best[1], "d2h_ms": best[2],
+                               "device_ms": best[3], "flags": FLAGS[pname],
+                               "note": "swg_filter: pageable host buffers in and out (what a host binding calls), best of 3; "
+                                       "columns the flag set does not read are not transferred"}
             del host, hst, hch
 
         if rank == 0:

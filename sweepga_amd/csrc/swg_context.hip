@@ -229,6 +229,7 @@ void swg_destroy(swg_ctx* ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->io_block) (void)hipFree(ctx->io_block);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -1,5 +1,6 @@
 // The filter pipeline: PafFilter::apply_filters (src/paf_filter.rs:379-747) on the device, and
 // the host-array entry points of the C ABI.
+#include <cstring>
 #include <vector>
 
 #include <algorithm>
@@ -209,7 +210,11 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
   return SWG_OK;
 }
 
-// Host buffers in / out: stage through device copies, then the device entry point.
+// Host buffers in / out: stage through device copies, then the device entry point.  The staging block lives in the
+// context (no allocation in steady state).  Only what the configuration reads crosses PCIe: `matches` and `strand` are
+// scaffold-stage inputs (src/paf_filter.rs:875-894, 761-770) and the chain ids are all zero without scaffolding
+// (:409-434), so with scaffold_gap == 0 they are neither uploaded nor downloaded (36 instead of 47 B up, 1 instead of
+// 5 B down per record).
 extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint8_t* status_out,
                           uint32_t* chain_out, swg_stats* stats) {
   SWG_TRY(validate(ctx, rec, cfg));
@@ -221,19 +226,30 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   if (!status_out || !chain_out) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // one device block for the inputs + outputs of this call (outside the scratch arena)
+  const bool scaffold = cfg->scaffold_gap != 0;
   const size_t col4 = ((n * 4 + 255) & ~size_t(255)), col8 = ((n * 8 + 255) & ~size_t(255)),
                col1 = ((n + 255) & ~size_t(255)), seqt = (((size_t)rec->n_seq * 4 + 255) & ~size_t(255));
   const size_t total = col4 * 8 + col8 + col1 * 2 + seqt * 2 + col4;
-  char* blk = nullptr;
-  {
+  if (ctx->io_cap < total) {
+    if (ctx->io_block) {
+      SWG_HIP(ctx, hipStreamSynchronize(st));
+      SWG_HIP(ctx, hipFree(ctx->io_block));
+      ctx->io_block = nullptr;
+      ctx->io_cap = 0;
+    }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, total);
+    size_t got = total + (total >> 3);  // a little headroom: the next file is rarely exactly this size
+    hipError_t e = hipMalloc(&p, got);
+    if (e != hipSuccess) {
+      got = total;
+      e = hipMalloc(&p, got);
+    }
     if (e != hipSuccess)
-      return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu bytes for record staging failed: %s", total,
-                           hipGetErrorString(e));
-    blk = static_cast<char*>(p);
+      return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu bytes for record staging failed: %s", total, hipGetErrorString(e));
+    ctx->io_block = static_cast<char*>(p);
+    ctx->io_cap = got;
   }
+  char* blk = ctx->io_block;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = blk + off;
@@ -244,25 +260,25 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
   int rc = SWG_OK;
   float h2d = 0.f, d2h = 0.f;
-  auto up = [&](const void* src, size_t bytes, size_t slot) -> void* {
+  auto up = [&](const void* src, size_t bytes, size_t slot, bool needed) -> void* {
     char* dst = take(slot);
-    if (rc == SWG_OK && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+    if (needed && rc == SWG_OK && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy failed");
     return dst;
   };
   (void)hipEventRecord(e0, st);
-  d.q_id = (const uint32_t*)up(rec->q_id, n * 4, col4);
-  d.t_id = (const uint32_t*)up(rec->t_id, n * 4, col4);
-  d.q_start = (const uint32_t*)up(rec->q_start, n * 4, col4);
-  d.q_end = (const uint32_t*)up(rec->q_end, n * 4, col4);
-  d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4);
-  d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4);
-  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4);
-  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4);
-  d.identity = (const double*)up(rec->identity, n * 8, col8);
-  d.strand = (const uint8_t*)up(rec->strand, n, col1);
-  d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt);
-  d.seq_genome_two = (const uint32_t*)up(rec->seq_genome_two, (size_t)rec->n_seq * 4, seqt);
+  d.q_id = (const uint32_t*)up(rec->q_id, n * 4, col4, true);
+  d.t_id = (const uint32_t*)up(rec->t_id, n * 4, col4, true);
+  d.q_start = (const uint32_t*)up(rec->q_start, n * 4, col4, true);
+  d.q_end = (const uint32_t*)up(rec->q_end, n * 4, col4, true);
+  d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4, true);
+  d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4, true);
+  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, scaffold);  // read by the scaffold stage only
+  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, true);
+  d.identity = (const double*)up(rec->identity, n * 8, col8, true);
+  d.strand = (const uint8_t*)up(rec->strand, n, col1, scaffold);         // read by the scaffold stage only
+  d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt, true);
+  d.seq_genome_two = (const uint32_t*)up(rec->seq_genome_two, (size_t)rec->n_seq * 4, seqt, true);
   uint8_t* d_status = (uint8_t*)take(col1);
   uint32_t* d_chain = (uint32_t*)take(col4);
   (void)hipEventRecord(e1, st);
@@ -272,16 +288,16 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   if (rc == SWG_OK) {
     (void)hipEventRecord(e0, st);
     if (hipMemcpyAsync(status_out, d_status, n, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(chain_out, d_chain, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        (scaffold && hipMemcpyAsync(chain_out, d_chain, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess))
       rc = swg_set_error(ctx, SWG_ERR_HIP, "D2H copy failed");
     (void)hipEventRecord(e1, st);
+    if (!scaffold) std::memset(chain_out, 0, n * sizeof(uint32_t));  // no ch:Z: tags without scaffolding; overlaps the status copy
     if (hipStreamSynchronize(st) != hipSuccess && rc == SWG_OK)
       rc = swg_set_error(ctx, SWG_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == SWG_OK) (void)hipEventElapsedTime(&d2h, e0, e1);
   } else {
     (void)hipStreamSynchronize(st);
   }
-  (void)hipFree(blk);
   if (stats && rc == SWG_OK) {
     *stats = local;
     stats->h2d_ms = h2d;

@@ -19,6 +19,10 @@ struct swg_ctx {
   size_t arena_off = 0;
   size_t arena_peak = 0;   // high-water mark of the current call (may exceed cap -> retry)
   bool arena_overflow = false;
+  // device block holding the records and results of swg_filter() (host buffers in / out): kept between calls, grown on
+  // demand, so a host that filters file after file pays no hipMalloc / hipFree in steady state
+  char* io_block = nullptr;
+  size_t io_cap = 0;
   // pinned host scratch for small read-backs
   uint64_t* h_scalars = nullptr;  // 64 x u64
   std::string err;

@@ -52,7 +52,8 @@ def test_bench_line_contract(line):
     assert rf["pipeline_achieved"] > 0 and rf["algorithmic_bytes_per_mapping"] == 47
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
-    assert d["pcie_inclusive"]["value"] > 0 and d["pcie_inclusive"]["h2d_ms"] > 0
+    for p in ("default", "sweep"):
+        assert d["pcie_inclusive"][p]["value"] > 0 and d["pcie_inclusive"][p]["h2d_ms"] > 0
 
 
 @pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
