@@ -213,8 +213,8 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
 // Host buffers in / out: stage through device copies, then the device entry point.  The staging block lives in the
 // context (no allocation in steady state).  Only what the configuration reads crosses PCIe: `matches` and `strand` are
 // scaffold-stage inputs (src/paf_filter.rs:875-894, 761-770) and the chain ids are all zero without scaffolding
-// (:409-434), so with scaffold_gap == 0 they are neither uploaded nor downloaded (36 instead of 47 B up, 1 instead of
-// 5 B down per record).
+// (:409-434), so with scaffold_gap == 0 they are neither uploaded nor downloaded; `block_len` is only needed by the
+// scaffold stage or a non-zero --min-aln-length (32 instead of 47 B up, 1 instead of 5 B down per record).
 extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint8_t* status_out,
                           uint32_t* chain_out, swg_stats* stats) {
   SWG_TRY(validate(ctx, rec, cfg));
@@ -274,7 +274,8 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4, true);
   d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4, true);
   d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, scaffold);  // read by the scaffold stage only
-  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, true);
+  // block_len: the retain test (vacuous for min_block_length 0; prepare_kernel then never reads it) and the scaffold stage
+  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, scaffold || cfg->min_block_length != 0);
   d.identity = (const double*)up(rec->identity, n * 8, col8, true);
   d.strand = (const uint8_t*)up(rec->strand, n, col1, scaffold);         // read by the scaffold stage only
   d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt, true);
