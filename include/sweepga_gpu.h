@@ -277,6 +277,17 @@ const swg_records* swg_aln_records(const swg_aln* a);
 uint32_t swg_aln_num_sequences(const swg_aln* a);
 const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id); /* the name after the first-word cut */
 
+/* ---- tree sparsification of the PAF before the filter (--sparsify tree:<near>[:<far>[:<random>]] / knn:...) ---------
+ * tree_filter::apply_tree_filter_to_paf (src/tree_filter.rs:205-285), which the reference runs on the input before
+ * PafFilter::filter_paf (src/main.rs:3640-3688): per unordered pair of genomes (first two '#' parts) identity =
+ * sum(matches) / sum(block length); every genome keeps its k_nearest best and k_farthest worst neighbours, plus every pair
+ * whose DefaultHasher (SipHash-1-3) value is <= random_fraction * 2^64; the lines of the kept pairs survive (input order,
+ * "\n" ends).  Identity ties fall to the neighbour's prefix in ascending order (the reference's order is arbitrary
+ * there).  Host code.  *out_text is allocated by the library: release it with swg_free(). */
+int swg_paf_tree_filter(const char* text, uint64_t len, uint64_t k_nearest, uint64_t k_farthest, double random_fraction,
+                        char** out_text, uint64_t* out_len);
+void swg_free(void* p);
+
 /* ---- ANI pre-pass for "aniN" identity thresholds (src/main.rs:296-688, src/cli.rs:76-130) -------------------
  * calculate_ani_stats: median over genome pairs (last-'#' prefixes, unordered) of Σmatches / Σblock_len, over
  *   SWG_ANI_ALL         every inter-genome line                                   main.rs:339-342, 392-498

@@ -375,4 +375,34 @@ int64_t orc_records_from_1aln(uint64_t n, const char* const* qname, const char* 
   }
 }
 
+// tree_filter::apply_tree_filter_to_paf (src/tree_filter.rs:205-285) over PAF text in memory (lines split like BufRead::lines:
+// "\n" or "\r\n").  Returns the length of the filtered text written to out (cap bytes), or -2 if it does not fit.
+int64_t orc_tree_filter_text(const char* text, uint64_t len, uint64_t k_nearest, uint64_t k_farthest, double random_fraction,
+                             char* out, uint64_t cap) {
+  try {
+    std::vector<std::string> lines;
+    uint64_t pos = 0;
+    while (pos < len) {
+      const void* nl = std::memchr(text + pos, '\n', len - pos);
+      uint64_t end = nl ? (uint64_t)((const char*)nl - text) : len;
+      uint64_t ll = end - pos;
+      if (ll && text[pos + ll - 1] == '\r' && nl) --ll;
+      lines.emplace_back(text + pos, ll);
+      pos = end + 1;
+    }
+    const std::vector<std::string> kept = tree_filter_paf_lines(lines, (size_t)k_nearest, (size_t)k_farthest, random_fraction);
+    uint64_t o = 0;
+    for (const std::string& l : kept) {
+      if (o + l.size() + 1 > cap) return -2;
+      std::memcpy(out + o, l.data(), l.size());
+      o += l.size();
+      out[o++] = '\n';
+    }
+    return (int64_t)o;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+uint64_t orc_default_hash_str_pair(const char* a, const char* b) { return default_hash_str_pair(a, b); }
+
 }  // extern "C"

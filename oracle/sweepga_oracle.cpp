@@ -1350,4 +1350,153 @@ std::vector<RecordMeta> records_from_1aln(const std::vector<AlnRecord>& alns) {
   return out;
 }
 
+// ---- tree sparsification (src/tree_filter.rs) -------------------------------------------------------------------------
+namespace {
+inline uint64_t rotl64(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+struct Sip13 {  // core::hash::sip::SipHasher13 with k0 = k1 = 0 (DefaultHasher::new())
+  uint64_t v0 = 0x736f6d6570736575ull, v1 = 0x646f72616e646f6dull, v2 = 0x6c7967656e657261ull, v3 = 0x7465646279746573ull;
+  uint64_t tail = 0;
+  int ntail = 0;
+  uint64_t length = 0;
+  void round() {
+    v0 += v1; v1 = rotl64(v1, 13); v1 ^= v0; v0 = rotl64(v0, 32);
+    v2 += v3; v3 = rotl64(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl64(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl64(v1, 17); v1 ^= v2; v2 = rotl64(v2, 32);
+  }
+  void write(const unsigned char* p, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      tail |= (uint64_t)p[i] << (8 * ntail);
+      ++length;
+      if (++ntail == 8) {
+        v3 ^= tail;
+        round();  // c_rounds = 1
+        v0 ^= tail;
+        tail = 0;
+        ntail = 0;
+      }
+    }
+  }
+  uint64_t finish() {
+    const uint64_t b = ((length & 0xff) << 56) | tail;
+    v3 ^= b;
+    round();
+    v0 ^= b;
+    v2 ^= 0xff;
+    round(); round(); round();  // d_rounds = 3
+    return v0 ^ v1 ^ v2 ^ v3;
+  }
+};
+std::string tree_genome_prefix(const std::string& name) {  // src/tree_filter.rs:15-24
+  const size_t p1 = name.find('#');
+  if (p1 == std::string::npos) return name;
+  const size_t p2 = name.find('#', p1 + 1);
+  return name.substr(0, p1) + "#" + (p2 == std::string::npos ? name.substr(p1 + 1) : name.substr(p1 + 1, p2 - p1 - 1)) + "#";
+}
+bool parse_u64_rust(const std::string& s, uint64_t* out) {  // str::parse::<u64>: optional '+', digits, no overflow
+  size_t i = 0;
+  if (i < s.size() && s[i] == '+') ++i;
+  if (i >= s.size()) return false;
+  uint64_t v = 0;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    const uint64_t d = (uint64_t)(s[i] - '0');
+    if (v > (UINT64_MAX - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  *out = v;
+  return true;
+}
+}  // namespace
+
+uint64_t default_hash_str_pair(const std::string& a, const std::string& b) {
+  Sip13 h;  // impl Hash for str: write(bytes) then write_u8(0xff)
+  const unsigned char ff = 0xff;
+  h.write(reinterpret_cast<const unsigned char*>(a.data()), a.size());
+  h.write(&ff, 1);
+  h.write(reinterpret_cast<const unsigned char*>(b.data()), b.size());
+  h.write(&ff, 1);
+  return h.finish();
+}
+
+std::vector<std::string> tree_filter_paf_lines(const std::vector<std::string>& lines, size_t k_nearest, size_t k_farthest,
+                                               double random_fraction) {
+  struct Aln {
+    std::string qg, tg;
+    uint64_t matches, block;
+    size_t line;
+  };
+  std::vector<Aln> alns;
+  for (size_t li = 0; li < lines.size(); ++li) {  // src/tree_filter.rs:222-252
+    const std::string& line = lines[li];
+    if (line.empty() || line[0] == '#') continue;
+    std::vector<std::string> f;
+    size_t s0 = 0;
+    while (true) {
+      const size_t t = line.find('\t', s0);
+      f.push_back(line.substr(s0, t == std::string::npos ? std::string::npos : t - s0));
+      if (t == std::string::npos) break;
+      s0 = t + 1;
+    }
+    if (f.size() < 11) continue;
+    Aln a;
+    a.qg = tree_genome_prefix(f[0]);
+    a.tg = tree_genome_prefix(f[5]);
+    if (!parse_u64_rust(f[9], &a.matches)) a.matches = 0;
+    if (!parse_u64_rust(f[10], &a.block)) a.block = 1;
+    a.line = li;
+    alns.push_back(a);
+  }
+  // build_identity_matrix (:39-75): canonical (sorted) genome pair -> (sum matches, sum block length) as f64
+  std::map<std::pair<std::string, std::string>, std::pair<double, double>> sums;
+  for (const Aln& a : alns) {
+    if (a.qg == a.tg) continue;
+    auto key = a.qg < a.tg ? std::make_pair(a.qg, a.tg) : std::make_pair(a.tg, a.qg);
+    auto& e = sums[key];
+    e.first += (double)a.matches;
+    e.second += (double)a.block;
+  }
+  std::map<std::pair<std::string, std::string>, double> identity;
+  for (const auto& kv : sums) identity[kv.first] = kv.second.second > 0.0 ? kv.second.first / kv.second.second : 0.0;
+  // select_tree_pairs (:79-160)
+  std::set<std::string> genomes;
+  for (const auto& kv : identity) {
+    genomes.insert(kv.first.first);
+    genomes.insert(kv.first.second);
+  }
+  std::set<std::pair<std::string, std::string>> selected;
+  for (const std::string& g : genomes) {
+    std::vector<std::pair<std::string, double>> nb;  // std::map order = neighbour prefix ascending (the tie order chosen here)
+    for (const auto& kv : identity) {
+      if (kv.first.first == g)
+        nb.emplace_back(kv.first.second, kv.second);
+      else if (kv.first.second == g)
+        nb.emplace_back(kv.first.first, kv.second);
+    }
+    std::stable_sort(nb.begin(), nb.end(), [](const auto& x, const auto& y) { return x.second > y.second; });  // :110
+    auto add = [&](const std::string& other) {
+      selected.insert(g < other ? std::make_pair(g, other) : std::make_pair(other, g));
+    };
+    for (size_t k = 0; k < nb.size() && k < k_nearest; ++k) add(nb[k].first);  // :113-120
+    if (k_farthest > 0) {                                                       // :123-133
+      std::reverse(nb.begin(), nb.end());
+      for (size_t k = 0; k < nb.size() && k < k_farthest; ++k) add(nb[k].first);
+    }
+  }
+  if (random_fraction > 0.0) {  // :137-156
+    const double scaled = random_fraction * 18446744073709551615.0;  // u64::MAX as f64 = 2^64
+    const uint64_t threshold = scaled >= 18446744073709551615.0 ? UINT64_MAX : (scaled <= 0.0 ? 0 : (uint64_t)scaled);  // `as u64` saturates
+    for (const auto& kv : identity)
+      if (default_hash_str_pair(kv.first.first, kv.first.second) <= threshold) selected.insert(kv.first);
+  }
+  // filter_tree_based (:172-200) + the writer (:277-282)
+  std::vector<std::string> out;
+  for (const Aln& a : alns) {
+    if (a.qg == a.tg) continue;
+    auto key = a.qg < a.tg ? std::make_pair(a.qg, a.tg) : std::make_pair(a.tg, a.qg);
+    if (selected.count(key)) out.push_back(lines[a.line]);
+  }
+  return out;
+}
+
 }  // namespace orc

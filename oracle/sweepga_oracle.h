@@ -133,6 +133,17 @@ std::vector<RecordMeta> records_from_1aln(const std::vector<AlnRecord>& alns);
 // str::split_whitespace().next().unwrap_or(full) (src/unified_filter.rs:83-92)
 std::string first_word_or_all(const std::string& s);
 
+// ---- tree sparsification of a PAF (src/tree_filter.rs:13-285), run by the reference BEFORE the filter when
+// --sparsify tree:<near>[:<far>[:<random>]] is given (src/main.rs:3640-3688).  Returns the kept lines (input order,
+// each without its line terminator).  The reference breaks identity ties among a genome's neighbours by HashMap
+// iteration order (arbitrary); here ties fall to the neighbour's genome prefix in ascending byte order -- one admissible
+// instance.  Parity unpinned: the reference holds no test vector for this pass beyond extract_genome_prefix.
+std::vector<std::string> tree_filter_paf_lines(const std::vector<std::string>& lines, size_t k_nearest, size_t k_farthest,
+                                               double random_fraction);
+// std::collections::hash_map::DefaultHasher (SipHash-1-3, keys 0/0) over `a.hash(); b.hash()` of two strs
+// (src/tree_filter.rs:142-147)
+uint64_t default_hash_str_pair(const std::string& a, const std::string& b);
+
 // src/paf_filter.rs:142-155
 struct MergedChain {
   std::string query_name, target_name;

@@ -3,6 +3,8 @@
 // PAFs of the reference's binary-invoking tests can be replayed.  Flag names and defaults
 // follow src/cli.rs:204-288; flag -> FilterConfig mapping follows src/main.rs:3477-3568,
 // 3590-3619, 3689-3691.
+#include <vector>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,10 +23,10 @@ static void die(const std::string& msg) {
 
 static // --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509).  `none`, `all`, a bare fraction and `random:<f>` have no
 // effect on the PAF path (the filter never reads FilterConfig.sparsity).  `tree:` / `knn:` make the reference run
-// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688); that pre-filter is not
-// built here, so they are refused rather than silently ignored.  0 = fine (no effect), 1 = a strategy that is "not valid
-// for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (valid in the reference, unsupported here).
-int check_sparsify(const std::string& v) {
+// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688).  0 = fine (no effect),
+// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (parameters
+// returned through the pointers).
+int check_sparsify(const std::string& v, unsigned long* tree_near = nullptr, unsigned long* tree_far = nullptr, double* tree_rand = nullptr) {
   auto frac_ok = [](const std::string& t, bool open_top) {
     char* e = nullptr;
     const double f = std::strtod(t.c_str(), &e);
@@ -66,6 +68,9 @@ int check_sparsify(const std::string& v) {
       s0 = c + 1;
     }
     if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
+    if (tree_near) *tree_near = kn;
+    if (tree_far) *tree_far = kf;
+    if (tree_rand) *tree_rand = rf;
     return 3;
   }
   return 2;
@@ -81,6 +86,8 @@ int main(int argc, char** argv) {
   uint64_t block_length = 0;
   bool keep_self = false, no_filter = false, scaffolds_only = false;
   std::string bad_sparsify, tree_sparsify;
+  unsigned long tree_near = 0, tree_far = 0;
+  double tree_rand = 0.0;
 
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]);
@@ -119,10 +126,10 @@ int main(int argc, char** argv) {
     else if (a == "--ani-method") ani_method_s = value();
     else if (a == "--sparsify") {
       const std::string v = value();
-      const int rc = check_sparsify(v);
+      const int rc = check_sparsify(v, &tree_near, &tree_far, &tree_rand);
       if (rc == 2) die("invalid value for --sparsify");
       if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
-      if (rc == 3) tree_sparsify = v;
+      tree_sparsify = rc == 3 ? v : std::string();
     }
     else if (a == "--no-adaptive-scaffolds" || a == "--quiet" || a == "--paf") { /* no effect here */ }
     else if (a == "--threads" || a == "-t") (void)value();
@@ -145,11 +152,6 @@ int main(int argc, char** argv) {
 
   if (!bad_sparsify.empty()) {
     std::fprintf(stderr, "sweepga-ref: --sparsify '%s' is not valid for post-alignment PAF/1aln filtering\n", bad_sparsify.c_str());
-    return 1;
-  }
-  if (!tree_sparsify.empty()) {
-    std::fprintf(stderr, "sweepga-ref: --sparsify '%s': tree sparsification of the input PAF (src/main.rs:3640-3688) is not supported\n",
-                 tree_sparsify.c_str());
     return 1;
   }
   FilterConfig cfg;
@@ -199,7 +201,28 @@ int main(int argc, char** argv) {
   cfg.scaffolds_only = scaffolds_only;
 
   try {
-    PafFilter(cfg).filter_paf(input, out_path);
+    std::string filter_input = input;
+    std::string tree_tmp;
+    if (!tree_sparsify.empty()) {  // main.rs:3640-3688: the filter runs on the tree-filtered temporary file
+      std::vector<std::string> lines;
+      {
+        std::ifstream in(input, std::ios::binary);
+        if (!in) die("cannot open " + input);
+        std::string line;
+        while (std::getline(in, line)) {
+          if (!line.empty() && line.back() == '\r') line.pop_back();
+          lines.push_back(line);
+        }
+      }
+      const std::vector<std::string> kept = tree_filter_paf_lines(lines, tree_near, tree_far, tree_rand);
+      tree_tmp = (output_file.empty() ? std::string("/tmp/sweepga_ref") : output_file) + ".tree." + std::to_string((long)getpid()) + ".paf";
+      std::ofstream out(tree_tmp, std::ios::binary);
+      for (const std::string& l : kept) out << l << "\n";
+      out.close();
+      filter_input = tree_tmp;
+    }
+    PafFilter(cfg).filter_paf(filter_input, out_path);
+    if (!tree_tmp.empty()) std::remove(tree_tmp.c_str());
   } catch (const std::exception& e) {
     die(e.what());
   }

@@ -21,7 +21,8 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
            "swg_filter_multi", "swg_memory_info", "swg_reserve",
-           "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name"]
+           "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name",
+           "swg_paf_tree_filter", "swg_free"]
 
 
 class SwgError(RuntimeError):
@@ -211,6 +212,11 @@ def load():
     lib.swg_aln_num_sequences.argtypes = [C.c_void_p]
     lib.swg_aln_sequence_name.restype = C.c_char_p
     lib.swg_aln_sequence_name.argtypes = [C.c_void_p, C.c_uint32]
+    lib.swg_paf_tree_filter.restype = C.c_int
+    lib.swg_paf_tree_filter.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_uint64)]
+    lib.swg_free.restype = None
+    lib.swg_free.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

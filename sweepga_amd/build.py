@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsweepga_gpu.so")
-SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_segsort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip", "swg_ani.hip", "swg_shard.hip",
-           os.path.join("host", "paf_io.cpp")]
+SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip", "swg_ani.hip", "swg_shard.hip",
+           os.path.join("host", "paf_io.cpp"), os.path.join("host", "tree_filter.cpp")]
 
 
 def _hipcc():

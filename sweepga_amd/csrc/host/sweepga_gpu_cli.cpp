@@ -136,10 +136,10 @@ bool parse_filter_mode(const std::string& mode, int32_t* fmode, uint64_t* pq, ui
 }
 // --sparsify (src/knn_graph.rs:59-160, src/main.rs:3494-3509).  `none`, `all`, a bare fraction and `random:<f>` have no
 // effect on the PAF path (the filter never reads FilterConfig.sparsity).  `tree:` / `knn:` make the reference run
-// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688); that pre-filter is not
-// built here, so they are refused rather than silently ignored.  0 = fine (no effect), 1 = a strategy that is "not valid
-// for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (valid in the reference, unsupported here).
-int check_sparsify(const std::string& v) {
+// tree_filter::apply_tree_filter_to_paf on the input BEFORE the filter (src/main.rs:3640-3688).  0 = fine (no effect),
+// 1 = a strategy that is "not valid for post-alignment PAF/1aln filtering", 2 = unparsable, 3 = tree sampling (parameters
+// returned through the pointers).
+int check_sparsify(const std::string& v, unsigned long* tree_near = nullptr, unsigned long* tree_far = nullptr, double* tree_rand = nullptr) {
   auto frac_ok = [](const std::string& t, bool open_top) {
     char* e = nullptr;
     const double f = std::strtod(t.c_str(), &e);
@@ -181,6 +181,9 @@ int check_sparsify(const std::string& v) {
       s0 = c + 1;
     }
     if (parts > 3 || (kn == 0 && kf == 0) || rf < 0.0 || rf > 1.0) return 2;
+    if (tree_near) *tree_near = kn;
+    if (tree_far) *tree_far = kf;
+    if (tree_rand) *tree_rand = rf;
     return 3;
   }
   return 2;
@@ -199,6 +202,8 @@ int main(int argc, char** argv) {
   int device = 0, threads = 0;
   std::vector<int> devices;
   std::string bad_sparsify, tree_sparsify;
+  unsigned long tree_near = 0, tree_far = 0;
+  double tree_rand = 0.0;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i], val;
     const size_t eq = a.find('=');
@@ -230,10 +235,10 @@ int main(int argc, char** argv) {
     else if (a == "--ani-method") ani_method_s = value();
     else if (a == "--sparsify") {
       const std::string v = value();
-      const int rc = check_sparsify(v);
+      const int rc = check_sparsify(v, &tree_near, &tree_far, &tree_rand);
       if (rc == 2) die(2, "invalid value for --sparsify");
       if (rc == 1) bad_sparsify = v;  // reported after the --no-filter shortcut, as in main.rs:3461-3509
-      if (rc == 3) tree_sparsify = v;
+      tree_sparsify = rc == 3 ? v : std::string();
     }
     else if (a == "--device") { if (!parse_int(value(), &device) || device < 0) die(2, "invalid value for --device"); }
     else if (a == "--devices") {  // comma-separated: shard the genome pairs over several GPUs of the node
@@ -264,8 +269,6 @@ int main(int argc, char** argv) {
   if (input.empty()) die(2, "usage: sweepga-gpu <in.paf> [--output-file out.paf] [filter flags]   (--help)");
 
   if (!no_filter && !bad_sparsify.empty()) die(1, "--sparsify '" + bad_sparsify + "' is not valid for post-alignment PAF/1aln filtering");
-  if (!no_filter && !tree_sparsify.empty())
-    die(1, "--sparsify '" + tree_sparsify + "': tree sparsification of the input PAF (src/main.rs:3640-3688) is not supported");
   swg_config cfg{};
   if (!parse_filter_mode(num_mappings, &cfg.mapping_filter_mode, &cfg.mapping_max_per_query, &cfg.mapping_max_per_target)) return 1;
   if (!parse_filter_mode(scaffold_filter, &cfg.scaffold_filter_mode, &cfg.scaffold_max_per_query, &cfg.scaffold_max_per_target)) return 1;
@@ -323,7 +326,7 @@ int main(int argc, char** argv) {
   }
   const std::string out_path = output_file.empty() ? "-" : output_file;
   const swg_records* r = swg_paf_records(paf);
-  const uint64_t n = r->n;
+  uint64_t n = r->n;
   if (no_filter) {  // main.rs:3461-3473: every line, newline-normalised, ALWAYS to stdout (--output-file is not consulted)
     const char* text;
     uint64_t len;
@@ -363,6 +366,23 @@ int main(int argc, char** argv) {
   }
   if (need_ani) set_identities(ani_percentile);
   if (need_ani && !quiet) std::fprintf(stderr, "[sweepga-gpu] ANI pre-pass (%s): median %.6f in %.1f ms\n", ani_method_s.c_str(), ani_percentile, ani_ms);
+
+  // ---- tree sparsification of the input (src/main.rs:3640-3688): the filter then runs on the surviving lines, whose ranks
+  // are their positions in the sparsified text (the reference filters the temporary tree-filtered file)
+  if (!tree_sparsify.empty()) {
+    const char* text;
+    uint64_t len;
+    swg_paf_text(paf, &text, &len);
+    char* kept_text = nullptr;
+    uint64_t kept_len = 0;
+    if (swg_paf_tree_filter(text, len, tree_near, tree_far, tree_rand, &kept_text, &kept_len) != SWG_OK) die(2, "tree sparsification failed");
+    swg_paf_close(paf);
+    paf = nullptr;
+    if (swg_paf_open_buffer(kept_text, kept_len, threads, &paf) != SWG_OK) die(2, swg_paf_last_error());
+    swg_free(kept_text);
+    r = swg_paf_records(paf);
+    n = r->n;
+  }
 
   // ---- apply_filters on the GPU
   std::vector<uint8_t> status(n ? n : 1, 0);

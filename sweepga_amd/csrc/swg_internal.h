@@ -195,9 +195,6 @@ struct swg_axis_input {
   int packed_end = 0;                    //   which end of `packed` is this axis' end
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
-// Segmented sort of the axis' begins (swg_segsort.hip): on *taken = 1, S / I hold exactly what begin_build + the LSD radix
-// sort would produce; on *taken = 0 (input not grouped by segment, too small, or switched off) nothing was written.
-int swg_segsort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint64_t* P_scratch, int* taken);
 
 // score keys: key[i] = order-preserving transform of -score so that smaller key = better
 // (src/plane_sweep_exact.rs:29-86, 183-193); length is always q_end - q_start.

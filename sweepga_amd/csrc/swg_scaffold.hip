@@ -249,9 +249,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
 // neighbouring i's re-read the same lines from L1/L2), every lane keeps its own KC best in (d, j) order, and the KC best
 // of the wavefront are drawn by KC rounds of a wave-wide lexicographic minimum.  32-bit arithmetic (coordinates are u32; a
 // gap limit beyond 2^32 cannot bind, so it is clamped).  Results are identical to chain_candidates_kernel.
-constexpr int CW_PER_WAVE = 16;            // consecutive i handled by one wavefront
-constexpr int CW_BLOCK_I = CW_PER_WAVE * 4;  // i handled by one work-group (4 wavefronts)
-constexpr int CW_STAGE = 6144;               // elements after the work-group's first i staged in LDS (72 KB: two groups per CU)
+constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
                                                                    uint32_t n_groups, const uint64_t* __restrict__ s_grp,
@@ -262,27 +260,12 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
                                                                    unsigned long long* __restrict__ c_d,
                                                                    uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
                                                                    uint32_t* __restrict__ c_ext) {
-  // the 64 windows of a work-group overlap almost entirely: their union (the CW_STAGE elements after the group's first i)
-  // is staged once; only the tail of an unusually long window is read from global memory
-  __shared__ uint32_t l_qs[CW_STAGE], l_ts[CW_STAGE], l_te[CW_STAGE];
-  const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
-  const uint64_t p0 = (uint64_t)blockIdx.x * CW_BLOCK_I;
-  const uint64_t st0 = p0 + 1;  // first staged element
-  for (int t = threadIdx.x; t < CW_STAGE; t += EW) {
-    const uint64_t j = st0 + t;
-    if (j < m) {
-      l_qs[t] = s_qs[j];
-      l_ts[t] = s_ts[j];
-      l_te[t] = s_te[j];
-    }
-  }
-  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
   const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
-  const bool small_gap = gap <= 0xffffu;  // squares of accepted gaps fit 32 bits: 24-bit multiplies (full rate)
-  const uint64_t pb = p0 + (uint64_t)wave_in_block * CW_PER_WAVE;
-  for (uint64_t p = pb; p < pb + CW_PER_WAVE && p < m; ++p) {  // wave-uniform
+  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
     const uint32_t g = s_gidx[p];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
     const bool minus = (s_grp[p] & 1ull) != 0;
@@ -300,9 +283,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
       const uint32_t j = j0 + lane;
       const bool in = j < e;
-      const uint32_t t = j - (uint32_t)st0;
-      const bool staged = t < (uint32_t)CW_STAGE;
-      const uint32_t qs_j = in ? (staged ? l_qs[t] : s_qs[j]) : 0xffffffffu;
+      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
       const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
       const uint64_t wmask = __ballot(inwin);
       ext += (uint32_t)__popcll(wmask);
@@ -319,7 +300,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
             q_gap = 0;
           }
         }
-        const uint32_t ts_j = staged ? l_ts[t] : s_ts[j], te_j = staged ? l_te[t] : s_te[j];
+        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
         const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
         if (a >= b) {
           r_gap = a - b;
@@ -331,11 +312,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
           }
         }
         if (ok && q_gap <= gap && r_gap <= gap) {
-          uint64_t d;
-          if (small_gap)
-            d = (uint64_t)__umul24(q_gap, q_gap) + (uint64_t)__umul24(r_gap, r_gap);
-          else
-            d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
           ++count;
           if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
             uint64_t cd = d;
@@ -1703,7 +1680,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
               (unsigned long long)n_groups, (unsigned long long)n_units);
     static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wave per i) kernel at any size
     if (long_groups || force_deep)
-      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<(unsigned)((m + CW_BLOCK_I - 1) / CW_BLOCK_I), EW, 0, st>>>(
+      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
                                                    m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     else
       SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,

@@ -892,14 +892,10 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     tile_x = swg_alloc<uint64_t>(ctx, (size_t)ntiles + 1);
     single = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
-    int seg_sorted = 0;  // grouped input: every segment sorted inside LDS instead of global radix passes
-    SWG_TRY(swg_segsort_begins(ctx, in, S, I, S2, &seg_sorted));
-    if (!seg_sorted) {
-      SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                         n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I));
-      SWG_KERNEL_CHECK(ctx);
-      SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits));
-    }
+    SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+                                       n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits));
     E = S2;  // the sort's scratch key buffer is free again
     SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
     SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(

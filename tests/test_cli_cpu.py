@@ -67,8 +67,7 @@ def test_without_gpu_exits_loudly(cli, tmp_path):
 def test_sparsify_flag_is_validated_only(cli, tmp_path):
     """--sparsify on the PAF path (src/knn_graph.rs:59-160, src/main.rs:3494-3509): `none` / `all` / fractions / `random:`
     have no effect on the filter, pre-alignment strategies are refused after the --no-filter shortcut, garbage is a usage
-    error, and `tree:` / `knn:` (which make the reference tree-filter the PAF first, src/main.rs:3640-3688) are refused as
-    unsupported instead of being silently ignored."""
+    error, and `tree:` / `knn:` tree-filter the PAF before the filter (src/main.rs:3640-3688)."""
     import os
     ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "sweepga-ref")
     p = tmp_path / "a.paf"
@@ -82,7 +81,16 @@ def test_sparsify_flag_is_validated_only(cli, tmp_path):
         for exe in (cli, ref):
             r = subprocess.run([exe, str(p), "--sparsify", v], capture_output=True, text=True)
             assert r.returncode == 1 and "not valid for post-alignment" in r.stderr, (exe, v, r.returncode, r.stderr)
-    for v in ("tree:2:1:0.1", "tree:3", "knn:3"):
-        for exe in (cli, ref):
-            r = subprocess.run([exe, str(p), "--sparsify", v], capture_output=True, text=True)
-            assert r.returncode == 1 and "not supported" in r.stderr and r.stdout == "", (exe, v, r.returncode, r.stderr)
+    # tree / knn: the input is tree-filtered first (src/main.rs:3640-3688).  The oracle's command line runs on the CPU: two
+    # genome pairs, tree:1 keeps the better neighbour of every genome; the GPU command line needs its device for the filter.
+    t = tmp_path / "t.paf"
+    mk = lambda q, tt, m: f"{q}\t9000\t0\t5000\t+\t{tt}\t9000\t0\t5000\t{m}\t5000\t60\n"
+    t.write_text(mk("A#1#c", "B#1#c", 4900) + mk("A#1#c", "C#1#c", 4000) + mk("B#1#c", "C#1#c", 4500))
+    r = subprocess.run([ref, str(t), "--sparsify", "tree:1", "--scaffold-jump", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # A's best neighbour is B (0.98), B's is A, C's is B (0.90 > 0.80): A-C is dropped
+    assert [ln.split("\t")[0] + ">" + ln.split("\t")[5] for ln in r.stdout.splitlines()] == ["A#1#c>B#1#c", "B#1#c>C#1#c"]
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([cli, str(t), "--sparsify", "tree:1", "--scaffold-jump", "0"], capture_output=True, text=True)
+        assert r.returncode == 3 and "no usable GPU" in r.stderr

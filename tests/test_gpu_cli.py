@@ -20,6 +20,9 @@ FLAG_SETS = [
      "--scaffold-filter", "2:1", "--scaffold-overlap", "0.3", "--min-aln-length", "200", "--min-aln-identity", "80"],
     ["--self", "--scaffolds-only", "--scaffold-jump", "30k", "--scaffold-mass", "5k", "--scoring", "matches"],
     ["--scoring", "ani", "--num-mappings", "1:many", "--scaffold-jump", "0", "--min-aln-identity", "0.9"],
+    # tree sparsification of the input before the filter (src/main.rs:3640-3688): ranks then count the surviving lines
+    ["--sparsify", "tree:1:1:0.3", "--num-mappings", "1:1", "--scaffold-jump", "10k", "--scaffold-mass", "2k", "--scaffold-dist", "5k"],
+    ["--sparsify", "knn:2", "--scaffold-jump", "0"],
 ]
 
 
@@ -77,12 +80,11 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_CHAIN_DEEP", "SWG_SEGSORT"])
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_CHAIN_DEEP"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
     onesweep pass (otherwise only used for n >= 2^30), SWG_CHAIN_DEEP=1 the wavefront-per-element candidate kernel of deep chaining
-    groups (otherwise only used when groups average more than 8192 mappings), SWG_SEGSORT=1 the segmented sort of the sweep's
-    begins (otherwise only used from 2^20 records up)."""
+    groups (otherwise only used when groups average more than 8192 mappings)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
