@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
 ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r02"     # profiles/<tag>_hbm_traffic_<pipeline>_100m.json: rocprofv3 PMC bytes per launch
+PROFILE_TAG = "r02"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
 
 # BASELINE.json's metric, verbatim
 BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
@@ -346,7 +346,7 @@ class Runner:
         return out
 
 
-def roofline(pipeline, n, steps, t, n_ref_traffic):
+def roofline(pipeline, n, steps, t, wl="100m"):
     """Dominant kernel of one flag set.  `achieved` follows the contract: ALGORITHMIC bytes of one call (SURVEY 8d:
     33 or 47 B per mapping x the n mappings one launch works on) / that kernel's average launch duration, measured
     with HIP events on the library's stream.  `kernel_own_*` is the kernel's own HBM traffic per launch (rocprofv3
@@ -357,10 +357,10 @@ def roofline(pipeline, n, steps, t, n_ref_traffic):
     dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     achieved = algo * n / (dom_avg_ms * 1e-3) / 1e9
-    traffic, tfile = None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_100m.json"
+    traffic, tfile = None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
     try:
         tj = json.load(open(os.path.join(ROOT, tfile)))
-        if tj.get("n_mappings") == n_ref_traffic and dom_name in tj["kernels"]:
+        if tj.get("n_mappings") == n and dom_name in tj["kernels"]:
             traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         traffic = None
@@ -399,7 +399,7 @@ def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
     for p in ("sweep", "default", "full"):
         t = run.time(p, steps, warm)
         out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n / (t["ms_per_step"] * 1e-3),
-                               "unit": "mappings/s", "counts": t["counts"], "roofline": roofline(p, n, steps, t, -1),
+                               "unit": "mappings/s", "counts": t["counts"], "roofline": roofline(p, n, steps, t, "sbig1_10m"),
                                "kernels_ms_per_step": kernels_table(t, steps)}
     del run, cols
     if args.cpu_sample > 0:
@@ -515,8 +515,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mappings", type=int, default=100_000_000, help="mappings per GPU (weak) / in total (strong)")
+    ap.add_argument("--mappings", type=int, default=0, help="mappings per GPU (weak) / in total (strong); 0 = the workload's size")
     ap.add_argument("--genomes", type=int, default=100)
+    ap.add_argument("--workload", default="span", choices=["span", "sbig1"],
+                    help="span: configs[3] (the headline).  sbig1: configs[2] as the MAIN record set (profiling runs of the dense "
+                         "case; --mappings defaults to 10^7, the S-big1 side leg is skipped)")
     ap.add_argument("--pipeline", default="default", choices=list(PIPELINES), help="flag set reported as `value`")
     ap.add_argument("--only", action="store_true", help="time only --pipeline (profiling runs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -562,8 +565,13 @@ def main():
     import sweepga_amd as sw
     from sweepga_amd import _lib
     ctx = sw.Context(local_rank)
-    n, G = args.mappings, args.genomes
-    names = span_names(G)
+    if args.workload == "sbig1":
+        args.genomes, args.sbig1 = 2, 0
+        if (args.mappings or 10_000_000) > 2_000_000:
+            args.cpu_sample = 0   # one group = one oracle thread: minutes at 10^7 (tests/test_gpu_sbig1.py does that check)
+    n, G = args.mappings or (10_000_000 if args.workload == "sbig1" else 100_000_000), args.genomes
+    args.mappings = n
+    names = SBIG1_NAMES if args.workload == "sbig1" else span_names(G)
     order = [args.pipeline] + ([] if args.only else [p for p in PIPELINES if p != args.pipeline])
     out = None
 
@@ -579,7 +587,10 @@ def main():
                                           f"pipeline={args.pipeline}", "flags": FLAGS[args.pipeline]},
                    "strong_scaling": ss}
     else:
-        cols, sizes = gen_shard(torch, n, G, args.seed + 7919 * rank, device)
+        if args.workload == "sbig1":
+            cols, sizes = gen_shard(torch, n, 2, 1234 + 7919 * rank, device, chr_len=SBIG1_LEN, single_pair=True)
+        else:
+            cols, sizes = gen_shard(torch, n, G, args.seed + 7919 * rank, device)
         if args.shuffle:  # the CPU legs index whole groups by position, so they are skipped for a shuffled shard
             perm = torch.randperm(n, device=device)
             for k in REC_COLS:
@@ -626,7 +637,8 @@ def main():
                 t = timed[p]
                 e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n * world / (t["ms_per_step"] * 1e-3),
                      "unit": "mappings/s", "steps": args.steps, "warmup": args.warmup, "counts": t["counts"],
-                     "roofline": roofline(p, n, args.steps, t, 100_000_000), "kernels_ms_per_step": kernels_table(t, args.steps)}
+                     "roofline": roofline(p, n, args.steps, t, "sbig1_10m" if args.workload == "sbig1" else "100m"),
+                     "kernels_ms_per_step": kernels_table(t, args.steps)}
                 if cpu_legs:
                     cb, par = cpu_baseline(cols, sizes, t["cfg"], args.cpu_sample if p == "sweep" else args.cpu_sample // 4,
                                            t["status"], t["chain"], names)
@@ -653,9 +665,11 @@ def main():
                 "vs_baseline": None,
                 "dtype": "u32 coordinates, f64 scores",
                 "data": "synthetic",
-                "config": {"workload": f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
-                                       f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {G * (G - 1)} "
-                                       f"genome-pair groups ({G} single-chromosome genomes), pipeline={args.pipeline}",
+                "config": {"workload": (f"BASELINE.json configs[2] (S-big1): {n} mappings per GPU in one chromosome pair of {SBIG1_LEN} bp, "
+                                        f"pipeline={args.pipeline}") if args.workload == "sbig1" else
+                                       (f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
+                                        f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {G * (G - 1)} "
+                                        f"genome-pair groups ({G} single-chromosome genomes), pipeline={args.pipeline}"),
                            "flags": FLAGS[args.pipeline], "mappings_per_gpu": n, "groups_per_gpu": G * (G - 1)},
                 "roofline": head["roofline"],
                 "cpu_baseline": head.get("cpu_baseline"),

@@ -1749,11 +1749,20 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
         SWG_KERNEL_CHECK(ctx);
         const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
         const bool small_ring = s_max + 64 <= 1024;  // every window fits a 1024-slot ring: 20 KB of LDS instead of 80
+        // The ring is a cache (positions outside it are read from global memory), so its size only trades LDS hits for
+        // resident wavefronts: with windows of at most a few hundred elements a 256-slot ring (5 KB) lets 32 one-wave
+        // work-groups share a CU instead of 8.
+        static const char* ring_knob = getenv("SWG_SPEC_RING");
+        const bool tiny_ring = ring_knob ? atoi(ring_knob) == 256 : s_max <= 512;
         int rounds = 0;
         for (uint64_t round = 0; round <= n_spec + 1; ++round) {
           SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
           SWG_KERNEL_CHECK(ctx);
-          if (small_ring)
+          if (tiny_ring)
+            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<256><<<(unsigned)(n_spec < (uint64_t)ctx->num_cu * 32 ? n_spec : (uint64_t)ctx->num_cu * 32), 64, 0, st>>>(
+                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
+                                              v_prev, p_own, p_prev));
+          else if (small_ring)
             SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<1024><<<(unsigned)rblocks, 64, 0, st>>>(
                                               (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
                                               v_prev, p_own, p_prev));
