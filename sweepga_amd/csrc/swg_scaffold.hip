@@ -2286,7 +2286,10 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     }
   }
   // ---- rescue
-  {
+  // anchors: status + chain in input order (coalesced); everything else starts as dropped
+  SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
+  SWG_KERNEL_CHECK(ctx);
+  if (cfg->scaffold_max_deviation != 0) {  // with a rescue distance of 0 only anchors are kept (paf_filter.rs:680, 740): no anchor sort
     uint8_t* aflag = swg_alloc<uint8_t>(ctx, M);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
@@ -2296,15 +2299,17 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     SWG_TRY(swg_flags_count(ctx, aflag, M, &anchor_scan, d_tot));
     uint64_t na = 0;
     SWG_TRY(swg_read_scalars(ctx, d_tot, &na, 1));
-    uint32_t* anchor_a = swg_alloc<uint32_t>(ctx, na + 1);
-    uint32_t* anchor_tmp = swg_alloc<uint32_t>(ctx, na + 1);
-    uint64_t* b_key = swg_alloc<uint64_t>(ctx, na + 1);
-    uint64_t* b_key_tmp = swg_alloc<uint64_t>(ctx, na + 1);
-    uint32_t* b_tc = swg_alloc<uint32_t>(ctx, na + 1);
-    uint32_t* b_idx = swg_alloc<uint32_t>(ctx, na + 1);
-    uint32_t* b_num = swg_alloc<uint32_t>(ctx, na + 1);
-    SWG_CHECK_ARENA(ctx);
     if (na) {
+      uint32_t* anchor_a = swg_alloc<uint32_t>(ctx, na + 1);
+      uint32_t* anchor_tmp = swg_alloc<uint32_t>(ctx, na + 1);
+      uint64_t* b_key = swg_alloc<uint64_t>(ctx, na + 1);
+      uint64_t* b_key_tmp = swg_alloc<uint64_t>(ctx, na + 1);
+      uint32_t* b_tc = swg_alloc<uint32_t>(ctx, na + 1);
+      uint32_t* b_idx = swg_alloc<uint32_t>(ctx, na + 1);
+      uint32_t* b_num = swg_alloc<uint32_t>(ctx, na + 1);
+      uint32_t* a_pair_lo = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
+      uint32_t* a_pair_hi = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
+      SWG_CHECK_ARENA(ctx);
       SWG_TRY(swg_flags_compact(ctx, anchor_scan, anchor_a));
       SWG_LAUNCH(ctx, "anchor_keys", anchor_keys_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.keyA, B.a_qe, B.a_dpair, pos_bits, b_key));
       SWG_KERNEL_CHECK(ctx);
@@ -2314,20 +2319,10 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_LAUNCH(ctx, "anchor_cols", anchor_cols_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.idxA, B.a_ts, B.a_te, anchor_num, b_tc, b_idx,
                                                                      b_num));
       SWG_KERNEL_CHECK(ctx);
-    }
-    uint32_t* a_pair_lo = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
-    uint32_t* a_pair_hi = swg_alloc<uint32_t>(ctx, B.n_pairs + 1);
-    SWG_CHECK_ARENA(ctx);
-    SWG_HIP(ctx, hipMemsetAsync(a_pair_lo, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
-    SWG_HIP(ctx, hipMemsetAsync(a_pair_hi, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
-    if (na) {
+      SWG_HIP(ctx, hipMemsetAsync(a_pair_lo, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
+      SWG_HIP(ctx, hipMemsetAsync(a_pair_hi, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
       SWG_LAUNCH(ctx, "anchor_ranges", anchor_ranges_kernel<<<nblk(na), EW, 0, st>>>(na, b_key, pos_bits, a_pair_lo, a_pair_hi));
       SWG_KERNEL_CHECK(ctx);
-    }
-    // anchors: status + chain in input order (coalesced); everything else starts as dropped
-    SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
-    SWG_KERNEL_CHECK(ctx);
-    if (cfg->scaffold_max_deviation != 0 && na != 0) {
       SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, aflag,
                                                           in_filtered, a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
                                                           cfg->scaffold_max_deviation, status_out, chain_out));
