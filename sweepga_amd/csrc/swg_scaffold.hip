@@ -153,6 +153,16 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
   return ((uint64_t)readlane_u32((uint32_t)(v >> 32), l) << 32) | readlane_u32((uint32_t)v, l);
 }
 
+// minimum of a u64 over the wavefront (all lanes get it)
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t t = __shfl_xor(v, o, 64);
+    if (t < v) v = t;
+  }
+  return v;
+}
+
 // d(i, j) of paf_filter.rs:798-836; returns false when a gap exceeds the limit
 __device__ __forceinline__ bool chain_dist(bool minus, uint64_t qe_i, uint64_t ts_i, uint64_t te_i, uint64_t qs_j,
                                            uint64_t ts_j, uint64_t te_j, uint64_t max_gap, uint64_t fifth, uint64_t* d) {
@@ -181,6 +191,12 @@ __device__ __forceinline__ bool chain_dist(bool minus, uint64_t qe_i, uint64_t t
   return true;
 }
 
+// The window scan stops early: j runs in q_start order, so once j lies past q_end[i] its query gap only grows, and as
+// soon as gap^2 reaches the KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances
+// keep the smaller j).  On deep data (S-big1: windows of ~2,000 elements) the KC nearest are found within the first
+// hundred or so.  After a cut the exact number of valid j is unknown: the count is reported as one more than what was
+// seen -- "the window may hold more" -- which at worst lets the selection re-evaluate a window that has nothing left to
+// offer (same result); the window extent comes from a binary search instead of the scan.
 __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                               const uint32_t* __restrict__ group_begin,
                                                               uint32_t n_groups, const uint64_t* __restrict__ s_grp,
@@ -207,9 +223,19 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
     bj[k] = NONE;
   }
   uint32_t count = 0, ext = 0;
-  for (uint32_t j = (uint32_t)p + 1; j < e; ++j) {
+  bool cut = false;
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap, d grows with the query gap
+  uint32_t j = (uint32_t)p + 1;
+  for (; j < e; ++j) {
     const uint64_t qs_j = s_qs[j];
     if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
+    if (can_cut && qs_j >= qe_i && bd[KC - 1] != ~0ull) {
+      const uint64_t qg = qs_j - qe_i;
+      if (qg * qg >= bd[KC - 1]) {  // no later j can displace a listed candidate
+        cut = true;
+        break;
+      }
+    }
     ext = j - (uint32_t)p;
     uint64_t d;
     if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
@@ -234,6 +260,19 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
       }
     }
   }
+  if (cut) {
+    // window extent: last element of the group with q_start <= bound (j itself is inside the window)
+    uint32_t lo = j, hi = e;  // s_qs[lo] <= bound; first index in (lo, hi] past the window
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if ((uint64_t)s_qs[mid] <= bound)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    ext = lo - (uint32_t)p;
+    if (count < 0xffffffffu) ++count;  // "there may be more": count > KC, which is all the selection asks
+  }
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     c_d[(uint64_t)k * m + p] = bd[k];
@@ -241,141 +280,6 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
   }
   c_n[p] = count;
   c_ext[p] = ext;
-}
-
-// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): one WAVEFRONT per i.
-// A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
-// has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
-// neighbouring i's re-read the same lines from L1/L2), every lane keeps its own KC best in (d, j) order, and the KC best
-// of the wavefront are drawn by KC rounds of a wave-wide lexicographic minimum.  32-bit arithmetic (coordinates are u32; a
-// gap limit beyond 2^32 cannot bind, so it is clamped).  Results are identical to chain_candidates_kernel.
-constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
-__global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                                   const uint32_t* __restrict__ group_begin,
-                                                                   uint32_t n_groups, const uint64_t* __restrict__ s_grp,
-                                                                   const uint32_t* __restrict__ s_qs,
-                                                                   const uint32_t* __restrict__ s_qe,
-                                                                   const uint32_t* __restrict__ s_ts,
-                                                                   const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                                   unsigned long long* __restrict__ c_d,
-                                                                   uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
-                                                                   uint32_t* __restrict__ c_ext) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
-  const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
-  const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
-  const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
-  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
-    const uint32_t g = s_gidx[p];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
-    const bool minus = (s_grp[p] & 1ull) != 0;
-    const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
-    const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
-    const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
-    uint64_t bd[KC];
-    uint32_t bj[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      bd[k] = ~0ull;
-      bj[k] = NONE;
-    }
-    uint32_t count = 0, ext = 0;
-    for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      const bool in = j < e;
-      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
-      const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
-      const uint64_t wmask = __ballot(inwin);
-      ext += (uint32_t)__popcll(wmask);
-      if (inwin) {
-        // d(i, j) of paf_filter.rs:798-836
-        uint32_t q_gap, r_gap;
-        bool ok = true;
-        if (qs_j >= qe_i) {
-          q_gap = qs_j - qe_i;
-        } else {
-          q_gap = qe_i - qs_j;
-          if (q_gap > fifth) {
-            ok = wrap;
-            q_gap = 0;
-          }
-        }
-        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
-        const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
-        if (a >= b) {
-          r_gap = a - b;
-        } else {
-          r_gap = b - a;
-          if (r_gap > fifth) {
-            ok = ok && wrap;
-            r_gap = 0;
-          }
-        }
-        if (ok && q_gap <= gap && r_gap <= gap) {
-          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
-          ++count;
-          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
-            uint64_t cd = d;
-            uint32_t cj = j;
-            bool placed = false;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-              if (placed || cd < bd[k]) {
-                placed = true;
-                const uint64_t td = bd[k];
-                const uint32_t tj = bj[k];
-                bd[k] = cd;
-                bj[k] = cj;
-                cd = td;
-                cj = tj;
-              }
-            }
-          }
-        }
-      }
-      if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
-    }
-    // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
-    // the KC smallest (d, j) of the wavefront: KC rounds of a lexicographic wave minimum over the lanes' list heads
-    uint64_t out_d[KC];
-    uint32_t out_j[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      uint64_t md = bd[0];
-      uint32_t mj = bj[0];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t od = __shfl_xor(md, o, 64);
-        const uint32_t oj = __shfl_xor(mj, o, 64);
-        if (od < md || (od == md && oj < mj)) {
-          md = od;
-          mj = oj;
-        }
-      }
-      out_d[k] = md;
-      out_j[k] = mj;
-      if (mj != NONE && bj[0] == mj) {  // this lane's head was drawn: pop it
-#pragma unroll
-        for (int t = 0; t + 1 < KC; ++t) {
-          bd[t] = bd[t + 1];
-          bj[t] = bj[t + 1];
-        }
-        bd[KC - 1] = ~0ull;
-        bj[KC - 1] = NONE;
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        c_d[(uint64_t)k * m + p] = out_d[k];
-        c_j[(uint64_t)k * m + p] = out_j[k];
-      }
-      c_n[p] = count;
-      c_ext[p] = ext;
-    }
-  }
 }
 
 struct SelBlock {
@@ -415,6 +319,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
   // one wavefront per listed unit (the middle-sized ones: longer than a lane should walk, shorter than BIG_UNIT)
   for (uint32_t k = wave_global; k < n_list; k += n_waves) {
     const uint32_t u = unit_list[k];
@@ -485,6 +390,11 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
         uint64_t ld = INF;
         uint32_t lj2 = NONE;
         for (uint32_t j0 = i + 1; j0 < ge; j0 += 64) {
+          if (can_cut) {  // the batch starts past q_end[i] and its smallest query gap already reaches the best distance held
+            const uint64_t wmin = wave_min_u64(ld);
+            const uint64_t q0 = s_qs[j0];
+            if (wmin != INF && q0 >= qe_i && (q0 - qe_i) * (q0 - qe_i) >= wmin) break;
+          }
           const uint32_t j = j0 + lane;
           bool in = j < ge;
           uint64_t qs_j = 0;
@@ -562,6 +472,7 @@ __global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units
   const uint32_t len = e - b;
   if (len > SMALL_UNIT) return;
   const uint64_t fifth = max_gap / 5;
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
   for (uint32_t i = b; i < e; ++i) {
     const uint32_t nvalid = c_n[i];
     if (nvalid == 0) continue;
@@ -583,8 +494,13 @@ __global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units
       const bool minus = (s_grp[i] & 1ull) != 0;
       const uint32_t last = i + c_ext[i];  // last element with q_start <= q_end[i] + max_gap (inside the unit)
       for (uint32_t j = i + 1; j <= last && j < e; ++j) {
+        const uint64_t qs_j = s_qs[j];
+        if (can_cut && qs_j >= qe_i && best_j != NONE) {  // past q_end[i] the query gap only grows:
+          const uint64_t qg = qs_j - qe_i;                                      // nothing closer can follow
+          if (qg * qg >= best_d) break;
+        }
         uint64_t d;
-        if (!chain_dist(minus, qe_i, ts_i, te_i, s_qs[j], s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
+        if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
         if (d < best_d && d < bps[j]) {
           best_d = d;
           best_j = j;
@@ -784,6 +700,7 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
   const int lane = threadIdx.x;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
     const uint32_t b = D.bb, be = D.be, e = D.ue;  // i runs over [b, be), j may reach into the next block (< e)
@@ -867,6 +784,11 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
         uint64_t ld = INF;
         uint32_t lj2 = NONE;
         for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+          if (can_cut) {  // see chain_select_kernel
+            const uint64_t wmin = wave_min_u64(ld);
+            const uint64_t q0 = (j0 - base) < (uint32_t)BIGW ? (uint64_t)rq[j0 % BIGW] : (uint64_t)s_qs[j0];
+            if (wmin != INF && q0 >= qe_i && (q0 - qe_i) * (q0 - qe_i) >= wmin) break;
+          }
           const uint32_t j = j0 + lane;
           bool in = j < e;
           const bool inring = in && (j - base) < (uint32_t)BIGW;
@@ -1678,13 +1600,8 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
               (unsigned long long)n_groups, (unsigned long long)n_units);
-    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wave per i) kernel at any size
-    if (long_groups || force_deep)
-      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
-                                                   m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
-    else
-      SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                              s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
+                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "chain_select_lanes", chain_select_lanes_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
                                                                                     s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, bps,
