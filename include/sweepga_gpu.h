@@ -196,6 +196,9 @@ int swg_profile_reset(swg_ctx* ctx);
 int swg_profile_count(swg_ctx* ctx);
 /* Entry i: name (owned by ctx, valid until the next reset), launches, summed milliseconds. */
 int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
+/* Elements worked on, summed over entry i's launches, for kernels that run on sub-problems of the call (the radix sort
+ * passes: pairs sorted); 0 for kernels that always run over the call's whole record set. */
+int swg_profile_units(swg_ctx* ctx, int i, uint64_t* units);
 
 /* Device scratch of this context: capacity of the arena (kept between calls, grown on demand) and the high-water
  * mark of the last call.  A call whose scratch does not fit grows the arena and runs once more, so a host that

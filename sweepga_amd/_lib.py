@@ -15,7 +15,7 @@ K_INF = 2**64 - 1
 SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
            "swg_filter", "swg_filter_device", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
            "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range", "swg_profile_enable",
-           "swg_profile_reset", "swg_profile_count", "swg_profile_get",
+           "swg_profile_reset", "swg_profile_count", "swg_profile_get", "swg_profile_units",
            "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",

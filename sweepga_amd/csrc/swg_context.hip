@@ -113,14 +113,15 @@ int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int c
   return SWG_OK;
 }
 
-swg_prof_scope::swg_prof_scope(swg_ctx* c, const char* kernel_name) : ctx(c) {
+swg_prof_scope::swg_prof_scope(swg_ctx* c, const char* kernel_name, uint64_t units) : ctx(c) {
   if (!ctx || !ctx->prof_on) return;
   for (size_t i = 0; i < ctx->prof_entries.size(); ++i)
     if (ctx->prof_entries[i].name == kernel_name) name = (int)i;
   if (name < 0) {
-    ctx->prof_entries.push_back({kernel_name, 0, 0.0});
+    ctx->prof_entries.push_back({kernel_name, 0, 0.0, 0});
     name = (int)ctx->prof_entries.size() - 1;
   }
+  ctx->prof_entries[name].units += units;
   auto get = [&]() -> hipEvent_t {
     if (!ctx->prof_free_events.empty()) {
       hipEvent_t e = ctx->prof_free_events.back();
@@ -184,6 +185,12 @@ int swg_profile_get(swg_ctx* ctx, int i, const char** name, uint64_t* launches, 
   if (name) *name = ctx->prof_entries[i].name.c_str();
   if (launches) *launches = ctx->prof_entries[i].launches;
   if (total_ms) *total_ms = ctx->prof_entries[i].ms;
+  return SWG_OK;
+}
+
+int swg_profile_units(swg_ctx* ctx, int i, uint64_t* units) {
+  if (!ctx || i < 0 || i >= (int)ctx->prof_entries.size() || !units) return SWG_ERR_INVALID;
+  *units = ctx->prof_entries[i].units;
   return SWG_OK;
 }
 

@@ -76,7 +76,7 @@ void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, ui
 
 // ---- mapping-level sweep ----------------------------------------------------------------------
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
-                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep) {
+                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order, int* q_order_valid) {
   const uint64_t n = r->n;
   uint64_t kq, kt;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
@@ -99,7 +99,11 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   ax.start = r->q_start;
   ax.end = r->q_end;
   ax.packed_end = 0;
+  ax.sorted_idx_out = q_order;
+  ax.sorted_idx_valid = q_order ? q_order_valid : nullptr;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
+  ax.sorted_idx_out = nullptr;
+  ax.sorted_idx_valid = nullptr;
   ax.seg_a = r->t_id;
   ax.seg_b = r->q_id;
   ax.start = r->t_start;
@@ -133,7 +137,12 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
   if (stats) stats->n_retained = h[1];
 
-  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1));
+  // with scaffolding on, the query axis' sorted order is kept: sort A of the chaining is the same order refined by
+  // (target sequence, strand)
+  uint32_t* q_order = cfg->scaffold_gap != 0 ? swg_alloc<uint32_t>(ctx, n) : nullptr;
+  SWG_CHECK_ARENA(ctx);
+  int q_order_valid = 0;
+  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(keep1) | reinterpret_cast<uintptr_t>(status_out) | reinterpret_cast<uintptr_t>(chain_out);
@@ -149,7 +158,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats);
+  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr);
 }
 
 static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {

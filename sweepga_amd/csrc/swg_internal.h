@@ -30,7 +30,7 @@ struct swg_ctx {
   // per-kernel profiler (swg_profile_*)
   bool prof_on = false;
   struct prof_pending { int name; hipEvent_t a, b; };
-  struct prof_entry { std::string name; uint64_t launches = 0; double ms = 0.0; };
+  struct prof_entry { std::string name; uint64_t launches = 0; double ms = 0.0; uint64_t units = 0; };
   std::vector<prof_pending> prof_pending_list;
   std::vector<hipEvent_t> prof_free_events;
   std::vector<prof_entry> prof_entries;
@@ -41,7 +41,8 @@ struct swg_prof_scope {
   swg_ctx* ctx;
   int name = -1;
   hipEvent_t a = nullptr, b = nullptr;
-  swg_prof_scope(swg_ctx* c, const char* kernel_name);
+  // units: elements this launch works on (0 = unknown: the whole record set of the call)
+  swg_prof_scope(swg_ctx* c, const char* kernel_name, uint64_t units = 0);
   ~swg_prof_scope();
 };
 // Resolves pending event pairs into the per-name table (synchronises the stream).
@@ -72,6 +73,12 @@ int swg_set_error(swg_ctx* ctx, int code, const char* fmt, ...);
   do {                                    \
     swg_prof_scope prof_scope_(ctx, name); \
     __VA_ARGS__;                          \
+  } while (0)
+// the same with the number of elements the launch works on (kernels launched on sub-problems, e.g. the sort passes)
+#define SWG_LAUNCH_N(ctx, name, units, ...)        \
+  do {                                             \
+    swg_prof_scope prof_scope_(ctx, name, units);  \
+    __VA_ARGS__;                                   \
   } while (0)
 
 // ---- arena --------------------------------------------------------------------------------
@@ -193,6 +200,8 @@ struct swg_axis_input {
   const uint8_t* and_with = nullptr;  // optional: keep[i] &= and_with[i] (intersection with another axis' result)
   const swg_key_ends* packed = nullptr;  // optional: replaces score_key / end in the post-sort gather
   int packed_end = 0;                    //   which end of `packed` is this axis' end
+  uint32_t* sorted_idx_out = nullptr;    // optional [n]: the record indices in (segment, start, index) order, dead first --
+  int* sorted_idx_valid = nullptr;       //   *valid = 1 when the begins were sorted (not for k = inf without zero lengths)
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
 

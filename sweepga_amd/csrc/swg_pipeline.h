@@ -4,11 +4,16 @@
 
 // Mapping-level plane sweep (src/paf_filter.rs:972-1123): query-axis sweep per (query sequence,
 // target genome), target-axis sweep per (target sequence, query genome), intersection.
+// q_order (optional, [n]): receives the records in the query axis' sorted order (segment = (query sequence, target genome),
+// then q_start, then index; dead records first); *q_order_valid says whether it was produced.
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
-                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep);
+                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order = nullptr,
+                      int* q_order_valid = nullptr);
 
 // Scaffold stage (src/paf_filter.rs:436-747): chaining, span/identity filter, scaffold sweep,
 // anchors, inversion capture, rescue.  alive = step-1 survivors, keep1 = mapping-sweep survivors.
+// q_order (optional): the alive records already ordered by q_start inside every (query, target, strand) group (the query
+// axis' order of the mapping sweep): sort A then only needs its passes over the group bits.
 int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                        const uint8_t* keep1, int pos_bits, uint8_t* status_out,
-                       uint32_t* chain_out, swg_stats* stats);
+                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order = nullptr);

@@ -1462,7 +1462,8 @@ struct ChainBuild {
 // merge_mappings_into_chains (paf_filter.rs:750-933) over the records with member[i] != 0, sorted
 // together with every alive[i] != 0 record (sort A is reused by the anchor / rescue steps).
 int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                 uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out) {
+                 uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out,
+                 const uint32_t* q_order = nullptr) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   ChainBuild& B = *out;
@@ -1493,11 +1494,23 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   uint32_t* pair_flag = swg_alloc<uint32_t>(ctx, M);
   uint32_t* pair_excl = swg_alloc<uint32_t>(ctx, M);
   SWG_CHECK_ARENA(ctx);
-  SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
-  SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
-                                                              r->n_seq, pos_bits, B.keyA));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
+  if (q_order) {
+    // The mapping sweep sorted the same alive records by (query sequence, target genome, q_start, index): dead records
+    // first, so the last M entries are the alive ones, and inside every (query, target, strand) group they already stand
+    // in q_start order with ties in index order -- the order sort A must end in (paf_filter.rs:777).  Stable passes over
+    // the group bits alone finish it: 2 radix passes instead of 6 for a 100-genome pangenome.
+    SWG_HIP(ctx, hipMemcpyAsync(B.idxA, q_order + (n - M), M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
+                                                                r->n_seq, pos_bits, B.keyA));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
+  } else {
+    SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
+    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
+                                                                r->n_seq, pos_bits, B.keyA));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
+  }
   SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
                                                         pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
   SWG_KERNEL_CHECK(ctx);
@@ -2095,14 +2108,14 @@ __global__ __launch_bounds__(EW) void count_status_kernel(uint64_t n, const uint
 
 int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                        const uint8_t* keep1, int pos_bits, uint8_t* status_out,
-                       uint32_t* chain_out, swg_stats* stats) {
+                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
   SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, n * sizeof(uint32_t), st));
   ChainBuild B;
   SWG_TRY(build_chains(ctx, r, alive, keep1, cfg->scaffold_gap, cfg->min_scaffold_length, cfg->min_scaffold_identity,
-                       pos_bits, true, &B));
+                       pos_bits, true, &B, q_order));
   if (stats) {
     stats->n_swept = B.m;
     stats->n_chains = B.T.nc;

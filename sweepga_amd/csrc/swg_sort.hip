@@ -660,11 +660,11 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     const uint32_t mask = (1u << bits) - 1u;
     SWG_HIP(ctx, hipMemsetAsync(status, 0, word * (size_t)ntiles * RS_RADIX, ctx->stream));
     if (wide)
-      SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<uint64_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint64_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
                                      *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
                                      static_cast<uint64_t*>(status), tickets + p));
     else
-      SWG_LAUNCH(ctx, "os_pass", os_pass_kernel<uint32_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint32_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
                                      *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
                                      static_cast<uint32_t*>(status), tickets + p));
     SWG_KERNEL_CHECK(ctx);

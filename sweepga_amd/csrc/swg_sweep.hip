@@ -868,6 +868,7 @@ int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8
 
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep) {
   const uint64_t n = in.n;
+  if (in.sorted_idx_valid) *in.sorted_idx_valid = 0;
   if (n == 0) return SWG_OK;
   if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "sweep: n >= 2^31 intervals");
   hipStream_t st = ctx->stream;
@@ -896,6 +897,10 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
                                        n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits));
+    if (in.sorted_idx_out) {
+      SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
+    }
     E = S2;  // the sort's scratch key buffer is free again
     SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
     SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
