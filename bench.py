@@ -335,10 +335,11 @@ class Runner:
             elapsed = float(tt.item())
         ctx.profile(False)
         prof = ctx.profile_table()
+        prof_units = ctx.profile_units()
         self.step(ccfg, with_stats=True)  # untimed: counts for the report
         ctx.synchronize()
         s = self.stats
-        out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3, "prof": prof,
+        out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3, "prof": prof, "prof_units": prof_units,
                "counts": {"in": s.n_in, "retained": s.n_retained, "swept": s.n_swept, "chains": s.n_chains,
                           "chains_kept": s.n_chains_kept, "out": s.n_out, "device_ms_last_step": s.device_ms}}
         if keep_results:
@@ -356,7 +357,10 @@ def roofline(pipeline, n, steps, t, wl="100m"):
     total_kernel_ms = sum(ms for _, ms in prof.values())
     dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
     dom_avg_ms = dom_ms / max(dom_launches, 1)
-    achieved = algo * n / (dom_avg_ms * 1e-3) / 1e9
+    # units one launch works on: n for the per-record kernels; the sort passes run on sub-problems of different sizes (the
+    # library counts the pairs of every pass), so their average launch is charged the average number of pairs
+    units = t.get("prof_units", {}).get(dom_name, 0) / max(dom_launches, 1) or n
+    achieved = algo * units / (dom_avg_ms * 1e-3) / 1e9
     traffic, tfile = None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
     try:
         tj = json.load(open(os.path.join(ROOT, tfile)))
@@ -370,7 +374,7 @@ def roofline(pipeline, n, steps, t, wl="100m"):
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_unit": f"HBM bytes per launch of that kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {tfile})",
             "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / steps,
-            "algorithmic_bytes_per_mapping": algo, "units_per_launch": n,
+            "algorithmic_bytes_per_mapping": algo, "units_per_launch": units,
             "kernel_own_achieved": own, "kernel_own_frac": own / HBM_PEAK_GBPS if own else None,
             "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
             "kernel_ms_per_step": total_kernel_ms / steps}

@@ -154,6 +154,8 @@ def load():
     lib.swg_profile_reset.argtypes = [C.c_void_p]
     lib.swg_profile_count.restype = C.c_int
     lib.swg_profile_count.argtypes = [C.c_void_p]
+    lib.swg_profile_units.restype = C.c_int
+    lib.swg_profile_units.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     lib.swg_profile_get.restype = C.c_int
     lib.swg_profile_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_double)]
@@ -262,6 +264,24 @@ class Context:
             ms = C.c_double()
             self.check(self.lib.swg_profile_get(self.handle, i, C.byref(name), C.byref(launches), C.byref(ms)))
             out[name.value.decode()] = (launches.value, ms.value)
+        return out
+
+    def profile_units(self):
+        """{kernel name: elements worked on, summed over its launches} for kernels that run on sub-problems of the call
+        (the radix sort passes); kernels that always run over the whole record set are absent."""
+        n = self.lib.swg_profile_count(self.handle)
+        if n < 0:
+            self.check(n)
+        out = {}
+        for i in range(n):
+            name = C.c_char_p()
+            launches = C.c_uint64()
+            ms = C.c_double()
+            units = C.c_uint64()
+            self.check(self.lib.swg_profile_get(self.handle, i, C.byref(name), C.byref(launches), C.byref(ms)))
+            self.check(self.lib.swg_profile_units(self.handle, i, C.byref(units)))
+            if units.value:
+                out[name.value.decode()] = units.value
         return out
 
     def memory_info(self):

@@ -191,12 +191,6 @@ __device__ __forceinline__ bool chain_dist(bool minus, uint64_t qe_i, uint64_t t
   return true;
 }
 
-// The window scan stops early: j runs in q_start order, so once j lies past q_end[i] its query gap only grows, and as
-// soon as gap^2 reaches the KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances
-// keep the smaller j).  On deep data (S-big1: windows of ~2,000 elements) the KC nearest are found within the first
-// hundred or so.  After a cut the exact number of valid j is unknown: the count is reported as one more than what was
-// seen -- "the window may hold more" -- which at worst lets the selection re-evaluate a window that has nothing left to
-// offer (same result); the window extent comes from a binary search instead of the scan.
 __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                               const uint32_t* __restrict__ group_begin,
                                                               uint32_t n_groups, const uint64_t* __restrict__ s_grp,
@@ -223,19 +217,9 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
     bj[k] = NONE;
   }
   uint32_t count = 0, ext = 0;
-  bool cut = false;
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap, d grows with the query gap
-  uint32_t j = (uint32_t)p + 1;
-  for (; j < e; ++j) {
+  for (uint32_t j = (uint32_t)p + 1; j < e; ++j) {
     const uint64_t qs_j = s_qs[j];
     if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
-    if (can_cut && qs_j >= qe_i && bd[KC - 1] != ~0ull) {
-      const uint64_t qg = qs_j - qe_i;
-      if (qg * qg >= bd[KC - 1]) {  // no later j can displace a listed candidate
-        cut = true;
-        break;
-      }
-    }
     ext = j - (uint32_t)p;
     uint64_t d;
     if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
@@ -260,19 +244,6 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
       }
     }
   }
-  if (cut) {
-    // window extent: last element of the group with q_start <= bound (j itself is inside the window)
-    uint32_t lo = j, hi = e;  // s_qs[lo] <= bound; first index in (lo, hi] past the window
-    while (hi - lo > 1) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if ((uint64_t)s_qs[mid] <= bound)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    ext = lo - (uint32_t)p;
-    if (count < 0xffffffffu) ++count;  // "there may be more": count > KC, which is all the selection asks
-  }
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
     c_d[(uint64_t)k * m + p] = bd[k];
@@ -280,6 +251,196 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
   }
   c_n[p] = count;
   c_ext[p] = ext;
+}
+
+// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): one WAVEFRONT per i.
+// A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
+// has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
+// neighbouring i's re-read the same lines from L1/L2), every lane keeps its own KC best in (d, j) order, and the KC best
+// of the wavefront are drawn by KC rounds of a wave-wide lexicographic minimum.  32-bit arithmetic (coordinates are u32; a
+// gap limit beyond 2^32 cannot bind, so it is clamped).
+// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once gap^2 reaches an
+// upper bound of the KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances keep the
+// smaller j).  The bound is the KC-th smallest of the lanes' own best distances (KC distinct candidates, so the true
+// KC-th best is not larger).  On S-big1 (windows of ~2,000 elements) a scan ends after ~500.  A thread per i cannot use
+// this: window lengths are heavy-tailed and a wavefront waits for its slowest lane.  After a cut the exact number of valid
+// j is unknown: the count is reported as one more than what was seen -- "the window may hold more" -- which at worst lets
+// the selection re-evaluate a window that has nothing left to offer (same result); the window extent then comes from a
+// binary search.  The lists are identical to chain_candidates_kernel's.
+constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
+__global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                                   const uint32_t* __restrict__ group_begin,
+                                                                   uint32_t n_groups, const uint64_t* __restrict__ s_grp,
+                                                                   const uint32_t* __restrict__ s_qs,
+                                                                   const uint32_t* __restrict__ s_qe,
+                                                                   const uint32_t* __restrict__ s_ts,
+                                                                   const uint32_t* __restrict__ s_te, uint64_t max_gap,
+                                                                   unsigned long long* __restrict__ c_d,
+                                                                   uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
+                                                                   uint32_t* __restrict__ c_ext) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
+  const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
+  const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap and grows with the query gap
+  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
+    const uint32_t g = s_gidx[p];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
+    const bool minus = (s_grp[p] & 1ull) != 0;
+    const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
+    const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
+    const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
+    uint64_t bd[KC];
+    uint32_t bj[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      bd[k] = ~0ull;
+      bj[k] = NONE;
+    }
+    uint32_t count = 0, ext = 0, cut_at = 0;
+    bool cut = false;
+    for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      const bool in = j < e;
+      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
+      const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
+      const uint64_t wmask = __ballot(inwin);
+      ext += (uint32_t)__popcll(wmask);
+      if (inwin) {
+        // d(i, j) of paf_filter.rs:798-836
+        uint32_t q_gap, r_gap;
+        bool ok = true;
+        if (qs_j >= qe_i) {
+          q_gap = qs_j - qe_i;
+        } else {
+          q_gap = qe_i - qs_j;
+          if (q_gap > fifth) {
+            ok = wrap;
+            q_gap = 0;
+          }
+        }
+        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
+        const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
+        if (a >= b) {
+          r_gap = a - b;
+        } else {
+          r_gap = b - a;
+          if (r_gap > fifth) {
+            ok = ok && wrap;
+            r_gap = 0;
+          }
+        }
+        if (ok && q_gap <= gap && r_gap <= gap) {
+          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+          ++count;
+          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
+            uint64_t cd = d;
+            uint32_t cj = j;
+            bool placed = false;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+              if (placed || cd < bd[k]) {
+                placed = true;
+                const uint64_t td = bd[k];
+                const uint32_t tj = bj[k];
+                bd[k] = cd;
+                bj[k] = cj;
+                cd = td;
+                cj = tj;
+              }
+            }
+          }
+        }
+      }
+      if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
+      if (can_cut && j0 + 64 < e) {
+        const uint32_t q_next = s_qs[j0 + 64];  // wave-uniform: first element of the next batch
+        if (q_next >= qe_i) {
+          // KC-th smallest of the lanes' best distances (KC rounds of wave minimum, the drawn lane steps to infinity)
+          uint64_t mine = bd[0], kth = ~0ull;
+#pragma unroll
+          for (int k = 0; k < KC; ++k) {
+            uint64_t md = mine;
+            uint32_t ml = (uint32_t)lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              const uint64_t od = __shfl_xor(md, o, 64);
+              const uint32_t ol = __shfl_xor(ml, o, 64);
+              if (od < md || (od == md && ol < ml)) {
+                md = od;
+                ml = ol;
+              }
+            }
+            kth = md;
+            if ((uint32_t)lane == ml) mine = ~0ull;
+          }
+          const uint64_t qg = (uint64_t)q_next - qe_i;
+          if (kth != ~0ull && qg * qg >= kth) {
+            cut = true;
+            cut_at = j0 + 64;
+            break;
+          }
+        }
+      }
+    }
+    if (cut) {  // window extent by binary search: s_qs[cut_at] <= bound (the batch before was entirely inside the window)
+      uint32_t lo = cut_at, hi = e;
+      if ((uint32_t)s_qs[lo] > bound) {
+        hi = lo;  // the window ended exactly at the batch boundary
+        lo = cut_at - 1;
+      }
+      while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (s_qs[mid] <= bound)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      ext = lo - (uint32_t)p;
+    }
+    // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    if (cut) ++count;  // "there may be more"
+    // the KC smallest (d, j) of the wavefront: KC rounds of a lexicographic wave minimum over the lanes' list heads
+    uint64_t out_d[KC];
+    uint32_t out_j[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      uint64_t md = bd[0];
+      uint32_t mj = bj[0];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t od = __shfl_xor(md, o, 64);
+        const uint32_t oj = __shfl_xor(mj, o, 64);
+        if (od < md || (od == md && oj < mj)) {
+          md = od;
+          mj = oj;
+        }
+      }
+      out_d[k] = md;
+      out_j[k] = mj;
+      if (mj != NONE && bj[0] == mj) {  // this lane's head was drawn: pop it
+#pragma unroll
+        for (int t = 0; t + 1 < KC; ++t) {
+          bd[t] = bd[t + 1];
+          bj[t] = bj[t + 1];
+        }
+        bd[KC - 1] = ~0ull;
+        bj[KC - 1] = NONE;
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        c_d[(uint64_t)k * m + p] = out_d[k];
+        c_j[(uint64_t)k * m + p] = out_j[k];
+      }
+      c_n[p] = count;
+      c_ext[p] = ext;
+    }
+  }
 }
 
 struct SelBlock {
@@ -1613,8 +1774,13 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
               (unsigned long long)n_groups, (unsigned long long)n_units);
-    SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                            s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wavefront per i) kernel at any size
+    if (long_groups || force_deep)
+      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
+                                                   m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+    else
+      SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
+                                                                              s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "chain_select_lanes", chain_select_lanes_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
                                                                                     s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, bps,

@@ -80,10 +80,11 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE"])
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_CHAIN_DEEP"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
-    onesweep pass (otherwise only used for n >= 2^30)."""
+    onesweep pass (otherwise only used for n >= 2^30), SWG_CHAIN_DEEP=1 the wavefront-per-element candidate kernel of deep
+    chaining groups (otherwise only used when groups average more than 8192 mappings)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
