@@ -50,7 +50,8 @@ __global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32
                                                         const uint8_t* __restrict__ strand,
                                                         const uint32_t* __restrict__ q_start, uint32_t n_seq,
                                                         int pos_bits, uint64_t* __restrict__ key) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  // a_idx is either ascending (coalesced reads) or the query axis' sorted order (gathers: neighbouring blocks on one XCD)
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (a >= M) return;
   const uint32_t i = a_idx[a];
   const uint64_t g = ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
@@ -355,8 +356,9 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       }
       if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
       if (can_cut && j0 + 64 < e) {
-        const uint32_t q_next = s_qs[j0 + 64];  // wave-uniform: first element of the next batch
-        if (q_next >= qe_i) {
+        // every later element starts at or after this batch's last one: its query gap is at least `qg`
+        const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
+        if (q_last >= qe_i) {
           // KC-th smallest of the lanes' best distances (KC rounds of wave minimum, the drawn lane steps to infinity)
           uint64_t mine = bd[0], kth = ~0ull;
 #pragma unroll
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
             kth = md;
             if ((uint32_t)lane == ml) mine = ~0ull;
           }
-          const uint64_t qg = (uint64_t)q_next - qe_i;
+          const uint64_t qg = (uint64_t)q_last - qe_i;
           if (kth != ~0ull && qg * qg >= kth) {
             cut = true;
             cut_at = j0 + 64;
@@ -384,18 +386,30 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         }
       }
     }
-    if (cut) {  // window extent by binary search: s_qs[cut_at] <= bound (the batch before was entirely inside the window)
-      uint32_t lo = cut_at, hi = e;
-      if ((uint32_t)s_qs[lo] > bound) {
-        hi = lo;  // the window ended exactly at the batch boundary
-        lo = cut_at - 1;
-      }
-      while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (s_qs[mid] <= bound)
-          lo = mid;
-        else
-          hi = mid;
+    if (cut) {
+      // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
+      // a time (one coalesced probe per lane), then resolve inside the 64-element block that holds the boundary.
+      uint32_t lo = cut_at - 1;  // last element known to be inside the window
+      bool found = false;
+      while (!found) {
+        const uint64_t pj = (uint64_t)lo + 1 + (uint64_t)lane * 64;  // first element of the lane's block
+        const bool inside = pj < e && s_qs[pj] <= bound;
+        const uint64_t m_in = __ballot(inside);
+        if (m_in == ~0ull) {  // all 64 block starts are inside: the boundary is further on
+          lo += 1 + 63 * 64;  // the last block start probed (inside)
+          if (lo + 1 >= e) found = true;
+          continue;
+        }
+        const int nb_in = __popcll(m_in);  // blocks whose first element is inside (a prefix: sorted)
+        if (nb_in == 0) {
+          found = true;  // the very next element is already outside
+          break;
+        }
+        const uint64_t blk = (uint64_t)lo + 1 + (uint64_t)(nb_in - 1) * 64;  // the boundary lies in [blk, blk + 64)
+        const uint64_t ej = blk + lane;
+        const bool in2 = ej < e && s_qs[ej] <= bound;
+        lo = (uint32_t)(blk + __popcll(__ballot(in2)) - 1);
+        found = true;
       }
       ext = lo - (uint32_t)p;
     }
