@@ -254,20 +254,60 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
   c_ext[p] = ext;
 }
 
+// The KC smallest (d, j) of a wavefront, every lane holding its own list sorted by (d asc, j asc) and every candidate
+// living in exactly one lane: butterfly all-reduce, six dependent shuffle rounds.  Merging two sorted KC-lists: the
+// element-wise minimum of A[k] and B[KC-1-k] is the KC smallest of the union as a bitonic sequence, which two
+// compare-exchange stages sort.  On return every lane holds the wavefront's list.
+static_assert(KC == 4, "wave_top_kc is written for four candidates");
+__device__ __forceinline__ bool cand_less(uint64_t ad, uint32_t aj, uint64_t bd_, uint32_t bj_) {
+  return ad < bd_ || (ad == bd_ && aj < bj_);
+}
+__device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint64_t pd[KC];
+    uint32_t pj[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      pd[k] = __shfl_xor(bd[k], o, 64);
+      pj[k] = __shfl_xor(bj[k], o, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (cand_less(pd[KC - 1 - k], pj[KC - 1 - k], bd[k], bj[k])) {
+        bd[k] = pd[KC - 1 - k];
+        bj[k] = pj[KC - 1 - k];
+      }
+    auto cx = [&](int x, int y) {
+      if (cand_less(bd[y], bj[y], bd[x], bj[x])) {
+        const uint64_t td = bd[x];
+        const uint32_t tj = bj[x];
+        bd[x] = bd[y];
+        bj[x] = bj[y];
+        bd[y] = td;
+        bj[y] = tj;
+      }
+    };
+    cx(0, 2);
+    cx(1, 3);
+    cx(0, 1);
+    cx(2, 3);
+  }
+}
+
 // The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): one WAVEFRONT per i.
 // A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
 // has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
-// neighbouring i's re-read the same lines from L1/L2), every lane keeps its own KC best in (d, j) order, and the KC best
-// of the wavefront are drawn by KC rounds of a wave-wide lexicographic minimum.  32-bit arithmetic (coordinates are u32; a
-// gap limit beyond 2^32 cannot bind, so it is clamped).
-// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once gap^2 reaches an
-// upper bound of the KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances keep the
-// smaller j).  The bound is the KC-th smallest of the lanes' own best distances (KC distinct candidates, so the true
-// KC-th best is not larger).  On S-big1 (windows of ~2,000 elements) a scan ends after ~500.  A thread per i cannot use
-// this: window lengths are heavy-tailed and a wavefront waits for its slowest lane.  After a cut the exact number of valid
-// j is unknown: the count is reported as one more than what was seen -- "the window may hold more" -- which at worst lets
-// the selection re-evaluate a window that has nothing left to offer (same result); the window extent then comes from a
-// binary search.  The lists are identical to chain_candidates_kernel's.
+// neighbouring i's re-read the same lines from L1/L2) and every lane keeps its own KC best in (d, j) order.
+// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once gap^2 reaches the
+// KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances keep the smaller j).  From
+// the first batch that ends past q_end[i] on, the lanes' lists are merged after every batch (wave_top_kc; lane 0 keeps the
+// merged list, the other lanes start again from empty: what they held cannot come back) and the test is made against the
+// exact KC-th best.  On S-big1 a scan ends after ~500 of ~2,000 elements.  After a cut the exact number of valid j is
+// unknown: the count is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the
+// selection re-evaluate a window that has nothing left to offer (same result); the window extent then comes from a
+// galloping search.  32-bit arithmetic (coordinates are u32; a gap limit beyond 2^32 cannot bind, so it is clamped).  The
+// lists are identical to chain_candidates_kernel's.
 constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
@@ -359,23 +399,14 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         // every later element starts at or after this batch's last one: its query gap is at least `qg`
         const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
         if (q_last >= qe_i) {
-          // KC-th smallest of the lanes' best distances (KC rounds of wave minimum, the drawn lane steps to infinity)
-          uint64_t mine = bd[0], kth = ~0ull;
+          wave_top_kc(bd, bj);  // every lane now holds the wavefront's KC best so far
+          const uint64_t kth = bd[KC - 1];
+          if (lane != 0) {  // lane 0 keeps them; what the other lanes held is either in that list or can never come back
 #pragma unroll
-          for (int k = 0; k < KC; ++k) {
-            uint64_t md = mine;
-            uint32_t ml = (uint32_t)lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-              const uint64_t od = __shfl_xor(md, o, 64);
-              const uint32_t ol = __shfl_xor(ml, o, 64);
-              if (od < md || (od == md && ol < ml)) {
-                md = od;
-                ml = ol;
-              }
+            for (int k = 0; k < KC; ++k) {
+              bd[k] = ~0ull;
+              bj[k] = NONE;
             }
-            kth = md;
-            if ((uint32_t)lane == ml) mine = ~0ull;
           }
           const uint64_t qg = (uint64_t)q_last - qe_i;
           if (kth != ~0ull && qg * qg >= kth) {
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     }
     if (cut) {
       // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
-      // a time (one coalesced probe per lane), then resolve inside the 64-element block that holds the boundary.
+      // a time (one probe per lane), then resolve inside the 64-element block that holds the boundary.
       uint32_t lo = cut_at - 1;  // last element known to be inside the window
       bool found = false;
       while (!found) {
@@ -401,10 +432,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
           continue;
         }
         const int nb_in = __popcll(m_in);  // blocks whose first element is inside (a prefix: sorted)
-        if (nb_in == 0) {
-          found = true;  // the very next element is already outside
-          break;
-        }
+        if (nb_in == 0) break;             // the very next element is already outside
         const uint64_t blk = (uint64_t)lo + 1 + (uint64_t)(nb_in - 1) * 64;  // the boundary lies in [blk, blk + 64)
         const uint64_t ej = blk + lane;
         const bool in2 = ej < e && s_qs[ej] <= bound;
@@ -417,39 +445,12 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
     if (cut) ++count;  // "there may be more"
-    // the KC smallest (d, j) of the wavefront: KC rounds of a lexicographic wave minimum over the lanes' list heads
-    uint64_t out_d[KC];
-    uint32_t out_j[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      uint64_t md = bd[0];
-      uint32_t mj = bj[0];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t od = __shfl_xor(md, o, 64);
-        const uint32_t oj = __shfl_xor(mj, o, 64);
-        if (od < md || (od == md && oj < mj)) {
-          md = od;
-          mj = oj;
-        }
-      }
-      out_d[k] = md;
-      out_j[k] = mj;
-      if (mj != NONE && bj[0] == mj) {  // this lane's head was drawn: pop it
-#pragma unroll
-        for (int t = 0; t + 1 < KC; ++t) {
-          bd[t] = bd[t + 1];
-          bj[t] = bj[t + 1];
-        }
-        bd[KC - 1] = ~0ull;
-        bj[KC - 1] = NONE;
-      }
-    }
+    wave_top_kc(bd, bj);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < KC; ++k) {
-        c_d[(uint64_t)k * m + p] = out_d[k];
-        c_j[(uint64_t)k * m + p] = out_j[k];
+        c_d[(uint64_t)k * m + p] = bd[k];
+        c_j[(uint64_t)k * m + p] = bj[k];
       }
       c_n[p] = count;
       c_ext[p] = ext;
