@@ -299,15 +299,12 @@ __device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
 // A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
 // has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
 // neighbouring i's re-read the same lines from L1/L2) and every lane keeps its own KC best in (d, j) order.
-// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once gap^2 reaches the
-// KC-th best distance found so far no later j can enter the list (d >= gap^2; equal distances keep the smaller j).  From
-// the first batch that ends past q_end[i] on, the lanes' lists are merged after every batch (wave_top_kc; lane 0 keeps the
-// merged list, the other lanes start again from empty: what they held cannot come back) and the test is made against the
-// exact KC-th best.  On S-big1 a scan ends after ~500 of ~2,000 elements.  After a cut the exact number of valid j is
-// unknown: the count is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the
-// selection re-evaluate a window that has nothing left to offer (same result); the window extent then comes from a
-// galloping search.  32-bit arithmetic (coordinates are u32; a gap limit beyond 2^32 cannot bind, so it is clamped).  The
-// lists are identical to chain_candidates_kernel's.
+// The KC best of the wavefront are drawn by one butterfly merge of the lanes' lists (wave_top_kc).  32-bit arithmetic
+// (coordinates are u32; a gap limit beyond 2^32 cannot bind, so it is clamped).  The lists are identical to
+// chain_candidates_kernel's.
+// (Stopping the scan once the query gap alone reaches the KC-th best distance -- exact, since j runs in q_start order -- was
+// measured and does not pay here: a 64-element batch costs ~300 cycles with its loads in flight, the merge that yields the
+// KC-th best ~2,000, and a thread per i gains nothing because window lengths are heavy-tailed; profiles/README.md.)
 constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
@@ -324,7 +321,6 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
   const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap and grows with the query gap
   for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
     const uint32_t g = s_gidx[p];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
@@ -339,8 +335,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       bd[k] = ~0ull;
       bj[k] = NONE;
     }
-    uint32_t count = 0, ext = 0, cut_at = 0;
-    bool cut = false;
+    uint32_t count = 0, ext = 0;
     for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
       const uint32_t j = j0 + lane;
       const bool in = j < e;
@@ -395,56 +390,10 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         }
       }
       if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
-      if (can_cut && j0 + 64 < e) {
-        // every later element starts at or after this batch's last one: its query gap is at least `qg`
-        const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
-        if (q_last >= qe_i) {
-          wave_top_kc(bd, bj);  // every lane now holds the wavefront's KC best so far
-          const uint64_t kth = bd[KC - 1];
-          if (lane != 0) {  // lane 0 keeps them; what the other lanes held is either in that list or can never come back
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-              bd[k] = ~0ull;
-              bj[k] = NONE;
-            }
-          }
-          const uint64_t qg = (uint64_t)q_last - qe_i;
-          if (kth != ~0ull && qg * qg >= kth) {
-            cut = true;
-            cut_at = j0 + 64;
-            break;
-          }
-        }
-      }
-    }
-    if (cut) {
-      // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
-      // a time (one probe per lane), then resolve inside the 64-element block that holds the boundary.
-      uint32_t lo = cut_at - 1;  // last element known to be inside the window
-      bool found = false;
-      while (!found) {
-        const uint64_t pj = (uint64_t)lo + 1 + (uint64_t)lane * 64;  // first element of the lane's block
-        const bool inside = pj < e && s_qs[pj] <= bound;
-        const uint64_t m_in = __ballot(inside);
-        if (m_in == ~0ull) {  // all 64 block starts are inside: the boundary is further on
-          lo += 1 + 63 * 64;  // the last block start probed (inside)
-          if (lo + 1 >= e) found = true;
-          continue;
-        }
-        const int nb_in = __popcll(m_in);  // blocks whose first element is inside (a prefix: sorted)
-        if (nb_in == 0) break;             // the very next element is already outside
-        const uint64_t blk = (uint64_t)lo + 1 + (uint64_t)(nb_in - 1) * 64;  // the boundary lies in [blk, blk + 64)
-        const uint64_t ej = blk + lane;
-        const bool in2 = ej < e && s_qs[ej] <= bound;
-        lo = (uint32_t)(blk + __popcll(__ballot(in2)) - 1);
-        found = true;
-      }
-      ext = lo - (uint32_t)p;
     }
     // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
-    if (cut) ++count;  // "there may be more"
     wave_top_kc(bd, bj);
     if (lane == 0) {
 #pragma unroll
