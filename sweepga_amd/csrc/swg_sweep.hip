@@ -541,14 +541,15 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if (pm < PX || (!is_end && pm == PX)) break;  // no earlier candidate reaches (end point) / covers (start point) PX
       const uint64_t ee = se2[o1 + q];
       if (ee >= PX) take(sx[q], ee, skey[q], sid[q]);
+      if (!was_top) break;  // nothing else matters for this point
     }
     if (cc_in_lds) {
-      for (uint32_t c = 0; c < n_cc; ++c) {
+      for (uint32_t c = 0; c < n_cc && was_top; ++c) {
         const uint64_t e = le[c];
         if (e >= PX) take(ls[c], e, lkey[c], lid[c]);
       }
     } else {
-      for (uint32_t c = c_begin; c < c_end; ++c) {
+      for (uint32_t c = c_begin; c < c_end && was_top; ++c) {
         const uint64_t e = a.c_e[c];
         if (e >= PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
       }
