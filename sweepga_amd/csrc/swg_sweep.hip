@@ -300,7 +300,7 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 constexpr int CCAP = 128;     // candidate carry-ins kept in LDS (17 KB per work-group in all: 8 resident per CU)
 constexpr int STAR_MIN = 32;  // fewer carry-ins than this: no pruning (nothing to gain on sparse data)
 
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(8, 8))) void sweep_tile_k1_kernel(TileArgs a) {
+__global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   __shared__ uint64_t sx[TB];    // composite start of begin q
   __shared__ uint64_t se2[2 * TB];   // [0, TB): its composite end; [TB, 2 TB): the same for candidates, 0 for the others
   __shared__ uint64_t spm2[2 * TB];  // prefix maxima of the two halves of se2
@@ -517,18 +517,33 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     if (!eval) continue;  // no barrier below this line
 
-    // ---- pass 1, one scan: T(x) = best of {s <= x < e} over S* and the candidates, and -- for an END coordinate -- whether
-    // the interval that ends here was the top just before x, i.e. no candidate j with s_j < x <= e_j ranks above it (S* ranks
-    // below every candidate).  An end coordinate whose interval was not the top changes nothing: other intervals that end
-    // or begin at x have their own threads.
-    const bool is_end = batch != 0;
-    bool was_top = true;
+    // ---- an end coordinate changes nothing unless the interval that ends here was the top just before x, i.e. unless no
+    // candidate j with s_j < x <= e_j ranks above it (S* ranks below every candidate; other intervals that end or begin
+    // at x have their own threads)
+    if (batch != 0) {
+      bool was_top = true;
+      for (int q = Q0; q >= 0 && was_top; --q) {
+        if (spm2[o1 + q] < PX) break;  // no earlier candidate reaches PX
+        if (se2[o1 + q] >= PX) {
+          const uint64_t sq = sx[q];
+          if (sq < PX && prio_less(skey[q], sq, sid[q], PK, PS, PI)) was_top = false;
+        }
+      }
+      if (cc_in_lds) {
+        for (uint32_t c = 0; c < n_cc && was_top; ++c)
+          if (le[c] >= PX && prio_less(lkey[c], ls[c], lid[c], PK, PS, PI)) was_top = false;
+      } else {
+        for (uint32_t c = c_begin; c < c_end && was_top; ++c)
+          if (a.c_e[c] >= PX && prio_less(a.c_key[c], a.c_s[c], a.c_id[c], PK, PS, PI)) was_top = false;
+      }
+      if (!was_top) continue;
+    }
+    // ---- pass 1: T(x) = best of {s <= x < e} over S* and the candidates
     uint64_t tk = star_k, ts = star_s, te = star_e;
     uint32_t ti = star_i;
     bool have_t = have_star;
-    auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {  // caller: s <= PX <= e
-      if (is_end && s < PX && prio_less(key, s, id, PK, PS, PI)) was_top = false;
-      if (e > PX && (!have_t || prio_less(key, s, id, tk, ts, ti))) {
+    auto take = [&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {  // caller: s <= PX < e
+      if (!have_t || prio_less(key, s, id, tk, ts, ti)) {
         tk = key;
         ts = s;
         te = e;
@@ -537,24 +552,21 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     };
     for (int q = Q0; q >= 0; --q) {
-      const uint64_t pm = spm2[o1 + q];
-      if (pm < PX || (!is_end && pm == PX)) break;  // no earlier candidate reaches (end point) / covers (start point) PX
+      if (spm2[o1 + q] <= PX) break;  // no earlier candidate covers PX
       const uint64_t ee = se2[o1 + q];
-      if (ee >= PX) take(sx[q], ee, skey[q], sid[q]);
-      if (!was_top) break;  // nothing else matters for this point
+      if (ee > PX) take(sx[q], ee, skey[q], sid[q]);
     }
     if (cc_in_lds) {
-      for (uint32_t c = 0; c < n_cc && was_top; ++c) {
+      for (uint32_t c = 0; c < n_cc; ++c) {
         const uint64_t e = le[c];
-        if (e >= PX) take(ls[c], e, lkey[c], lid[c]);
+        if (e > PX) take(ls[c], e, lkey[c], lid[c]);
       }
     } else {
-      for (uint32_t c = c_begin; c < c_end && was_top; ++c) {
+      for (uint32_t c = c_begin; c < c_end; ++c) {
         const uint64_t e = a.c_e[c];
-        if (e >= PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
+        if (e > PX) take(a.c_s[c], e, a.c_key[c], a.c_id[c]);
       }
     }
-    if (!was_top) continue;
     if (!have_t) continue;
     a.top[ti] = 1;
     if (!pass2) continue;
