@@ -92,6 +92,8 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pai
     cols = dict(q_id=q.contiguous(), t_id=t.contiguous(), q_start=qs, q_end=qs + ln, t_start=ts, t_end=ts + ln,
                 identity=identity.contiguous(), matches=matches, block_len=block.contiguous(), strand=strand,
                 seq_genome_last=table, seq_genome_two=table.clone())
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)   # the library works on its own stream: the columns must be complete before it reads them
     return cols, sizes
 
 
@@ -412,6 +414,7 @@ def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
 
         def check(p, m):
             c, _ = gen_shard(torch, m, 2, 1234, device, chr_len=max(int(SBIG1_LEN * (m / 1e7)), 1_000_000), single_pair=True)
+            torch.cuda.synchronize()   # the library runs on its own stream: the generator's kernels must have finished
             r = Runner(torch, sw, lib_mod, sw.Context(device.index or 0), device, None, c, m, 2)
             cfg = make_config(sw, p)
             r.step(cfg.to_c())

@@ -49,6 +49,8 @@ def random_flags(rng):
         fl += ["--min-scaffold-identity", str(rng.choice(["ani50-10", "0.85", "ani", "80"]))]
     if rng.random() < 0.6:
         fl += ["--ani-method", str(rng.choice(["all", "orthogonal", "1:1", "n50", "n100", "n90-length", "n20-score", "n5-identity", "zzz"]))]
+    if rng.random() < 0.2:   # tree sparsification of the input before the filter (src/main.rs:3640-3688)
+        fl += ["--sparsify", str(rng.choice(["tree:1", "tree:2:1", "tree:1:1:0.3", "knn:3", "tree:0:2", "tree:1:0:0.9", "none", "random:0.5"]))]
     if rng.random() < 0.25:
         fl += ["--self"]
     if rng.random() < 0.1:
