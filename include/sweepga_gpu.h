@@ -38,7 +38,7 @@ extern "C" {
 #define SWG_ERR_NO_DEVICE (-2)   /* no HIP device / device init failed */
 #define SWG_ERR_HIP (-3)         /* a HIP runtime call or kernel failed */
 #define SWG_ERR_OOM (-4)         /* device or host allocation failed */
-#define SWG_ERR_RANGE (-5)       /* coordinate >= 2^32, or composite sort key wider than 64 bits */
+#define SWG_ERR_RANGE (-5)       /* mapped stretch of a sequence >= 2^32 bases, or composite sort key wider than 64 bits */
 #define SWG_ERR_UNSUPPORTED (-6) /* valid in the reference, not implemented here (documented) */
 
 /* ScoringFunction, src/filter_types.rs:8-14 */
@@ -146,6 +146,36 @@ int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint
 int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg,
                       uint8_t* status_out, uint32_t* chain_out, swg_stats* stats);
 
+/* Vec<RecordMeta> with the reference's own field widths (query_start .. block_length are u64, src/paf_filter.rs:58-62).
+ * The device layout stays 32-bit: every coordinate is rebased to the smallest coordinate its sequence has anywhere in the
+ * record set (query and target appearances alike).  apply_filters only ever uses differences, orders and midpoints of
+ * positions on one sequence, so the results are those of the unrebased records; what has to fit 32 bits is the stretch of
+ * each sequence that mappings touch (and every matches / block_length value), otherwise SWG_ERR_RANGE.  start <= end is
+ * assumed, as in any PAF.  swg_filter64: host pointers, rebased by host threads, then swg_filter (no extra PCIe bytes);
+ * swg_filter_device64: device pointers, rebased by two kernels, then the same pipeline as swg_filter_device. */
+typedef struct swg_records64 {
+  uint64_t n;
+  const uint32_t* q_id;
+  const uint32_t* t_id;
+  const uint64_t* q_start;
+  const uint64_t* q_end;
+  const uint64_t* t_start;
+  const uint64_t* t_end;
+  const double* identity;
+  const uint64_t* matches;
+  const uint64_t* block_len;
+  const uint8_t* strand;
+  uint32_t n_seq;
+  const uint32_t* seq_genome_last;
+  uint32_t n_genome_last;
+  const uint32_t* seq_genome_two;
+  uint32_t n_genome_two;
+} swg_records64;
+int swg_filter64(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, uint8_t* status_out, uint32_t* chain_out,
+                 swg_stats* stats);
+int swg_filter_device64(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, uint8_t* status_out,
+                        uint32_t* chain_out, swg_stats* stats);
+
 /* ---- lower public seams of the reference, exercised by its tests ---------------------- */
 /* plane_sweep_query / plane_sweep_target / plane_sweep_both (src/plane_sweep_exact.rs:268,
  * 355, 436) on ONE segment of n mappings given as host arrays.  axis: 0 query, 1 target,
@@ -215,6 +245,8 @@ int swg_reserve(swg_ctx* ctx, uint64_t arena_bytes);
  * Results are identical to swg_filter(ctxs[0], ...).  Errors are reported on ctxs[0]. */
 int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_records* records, const swg_config* cfg, uint8_t* status_out,
                      uint32_t* chain_out, swg_stats* stats);
+int swg_filter_multi64(swg_ctx* const* ctxs, int n_ctx, const swg_records64* records, const swg_config* cfg, uint8_t* status_out,
+                       uint32_t* chain_out, swg_stats* stats); /* swg_filter64's rebasing, then the same */
 
 /* ---- PAF ingest / egress (host side; no GPU needed for open/write) ----------------------------------------
  * The reference reads the PAF twice (extract_metadata, then write_filtered_output re-reads it).  A swg_paf
@@ -229,8 +261,11 @@ int swg_paf_open(const char* path, int threads, swg_paf** out);
 /* same, over PAF text already in memory (copied) */
 int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** out);
 void swg_paf_close(swg_paf* p);
-/* records in input order; pointers are owned by the handle */
+/* records in input order; pointers are owned by the handle.  A file with a coordinate, matches or block length >= 2^32
+ * is parsed once more into 64-bit columns and rebased per sequence as swg_filter64 does: the coordinate columns are
+ * then relative to swg_paf_seq_offsets()[sequence id] (NULL for a file that needed no rebasing). */
 const swg_records* swg_paf_records(const swg_paf* p);
+const uint64_t* swg_paf_seq_offsets(const swg_paf* p);
 /* physical line count (incl. skipped lines) and each record's rank = 0-based line index (src/paf_filter.rs:298) */
 uint64_t swg_paf_num_lines(const swg_paf* p);
 const uint64_t* swg_paf_ranks(const swg_paf* p);
@@ -260,7 +295,9 @@ const char* swg_paf_last_error(void);
  *   rank = position of the alignment in the file                              (:63, :142)
  * and interns the names like the PAF path.  swg_filter() over swg_aln_records() is filter_file's .1aln branch
  * (src/unified_filter.rs:310-317); the host writes the passing alignments itself (write_1aln_filtered, :158-190: the
- * ranks with status != 0).  Coordinates / block lengths >= 2^32: SWG_ERR_RANGE (same limit as the PAF path). */
+ * ranks with status != 0).  Values >= 2^32: coordinates are rebased per sequence as in swg_filter64 (offsets from
+ * swg_aln_seq_offsets, NULL when nothing was rebased); SWG_ERR_RANGE if a sequence's mapped stretch, a block length or a
+ * match count still does not fit 32 bits (same limit as the PAF path). */
 typedef struct swg_aln_input {
   uint64_t n;
   const char* const* query_name;   /* [n] NUL-terminated: id_to_name[aln.query_name], or the raw field (:71-82) */
@@ -277,6 +314,7 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out);
 void swg_aln_close(swg_aln* a);
 /* records in file order (rank k = record k); pointers are owned by the handle */
 const swg_records* swg_aln_records(const swg_aln* a);
+const uint64_t* swg_aln_seq_offsets(const swg_aln* a);
 uint32_t swg_aln_num_sequences(const swg_aln* a);
 const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id); /* the name after the first-word cut */
 

@@ -13,15 +13,16 @@ K_INF = 2**64 - 1
 
 # every symbol include/sweepga_gpu.h declares
 SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
-           "swg_filter", "swg_filter_device", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
+           "swg_filter", "swg_filter_device", "swg_filter64", "swg_filter_device64", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
            "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range", "swg_profile_enable",
            "swg_profile_reset", "swg_profile_count", "swg_profile_get", "swg_profile_units",
            "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
-           "swg_filter_multi", "swg_memory_info", "swg_reserve",
+           "swg_filter_multi", "swg_filter_multi64", "swg_memory_info", "swg_reserve",
            "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name",
+           "swg_paf_seq_offsets", "swg_aln_seq_offsets",
            "swg_paf_tree_filter", "swg_free"]
 
 
@@ -124,7 +125,7 @@ def load():
     lib.swg_stream.argtypes = [C.c_void_p]
     lib.swg_synchronize.restype = C.c_int
     lib.swg_synchronize.argtypes = [C.c_void_p]
-    for name in ("swg_filter", "swg_filter_device"):
+    for name in ("swg_filter", "swg_filter_device", "swg_filter64", "swg_filter_device64"):  # swg_records64 = same layout
         f = getattr(lib, name)
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p, C.c_void_p,
@@ -198,6 +199,9 @@ def load():
     lib.swg_filter_multi.restype = C.c_int
     lib.swg_filter_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p,
                                      C.c_void_p, C.POINTER(SwgStats)]
+    lib.swg_filter_multi64.restype = C.c_int
+    lib.swg_filter_multi64.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SwgRecords), C.POINTER(SwgConfig), C.c_void_p,
+                                     C.c_void_p, C.POINTER(SwgStats)]
     lib.swg_memory_info.restype = C.c_int
     lib.swg_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.swg_reserve.restype = C.c_int
@@ -210,6 +214,10 @@ def load():
     lib.swg_aln_close.argtypes = [C.c_void_p]
     lib.swg_aln_records.restype = C.POINTER(SwgRecords)
     lib.swg_aln_records.argtypes = [C.c_void_p]
+    for name in ("swg_paf_seq_offsets", "swg_aln_seq_offsets"):
+        f = getattr(lib, name)
+        f.restype = C.POINTER(C.c_uint64)
+        f.argtypes = [C.c_void_p]
     lib.swg_aln_num_sequences.restype = C.c_uint32
     lib.swg_aln_num_sequences.argtypes = [C.c_void_p]
     lib.swg_aln_sequence_name.restype = C.c_char_p

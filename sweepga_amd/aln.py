@@ -65,6 +65,14 @@ class AlnRecords:
         k = self.lib.swg_aln_num_sequences(self.handle)
         return [self.lib.swg_aln_sequence_name(self.handle, i).decode("utf-8", errors="surrogateescape") for i in range(k)]
 
+    @property
+    def seq_offsets(self):
+        """[n_seq] what rebasing took off each sequence's coordinates, or None (no value reached 2^32)."""
+        ptr = self.lib.swg_aln_seq_offsets(self.handle)
+        if not ptr:
+            return None
+        return self._view(C.addressof(ptr.contents), np.uint64, int(self.records.n_seq))
+
     def packed(self):
         """The columns as a PackedRecords (what PafFilter.filter_columns takes); copies, so it outlives the handle."""
         from .filter import PackedRecords

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../../include/sweepga_gpu.h"
+#include "rebase.h"
 
 namespace {
 
@@ -372,6 +373,7 @@ struct Slice {
   int err = SWG_OK;
   uint64_t err_line = 0;
   const char* err_what = nullptr;
+  bool wide = false;             // met a coordinate / matches / block length >= 2^32
 };
 
 }  // namespace
@@ -384,6 +386,8 @@ struct swg_paf {
   Buf<uint8_t> strand;
   Buf<uint64_t> rank, rec_off;
   Buf<uint32_t> rec_len;
+  Buf<uint64_t> wide[6];             // q_start, q_end, t_start, t_end, matches, block length of a file with values >= 2^32
+  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing)
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
   swg_records rec{};
@@ -470,8 +474,10 @@ int parse_text(swg_paf* p, int threads) {
   p->rank.alloc(cap);
   p->rec_off.alloc(cap);
 
-  // pass 2: parse into the columns
-  parallel_for(threads, [&](int t) {
+  // pass 2: parse into the columns.  Values >= 2^32 (RecordMeta is u64, src/paf_filter.rs:58-62) are rare: the 32-bit
+  // columns are filled first, and only a file that has such a value is parsed once more into 64-bit columns, which are
+  // then rebased sequence by sequence (host/rebase.h).
+  auto pass2 = [&](const bool wide) { parallel_for(threads, [&](int t) {
     Slice& s = sl[t];
     uint64_t line = s.line_base, k = s.line_base;
     const char* f[12];
@@ -497,7 +503,10 @@ int parse_text(swg_paf* p, int threads) {
         uint64_t v;
         return parse_u64(f[i], (size_t)(f[i + 1] - 1 - f[i]), &v) ? v : d;
       };
-      auto narrow = [&](uint64_t v, const char* what) { return v > 0xffffffffull ? fail(what) : (uint32_t)v; };
+      auto narrow = [&](uint64_t v) {
+        if (v > 0xffffffffull) s.wide = true;
+        return (uint32_t)v;
+      };
       uint64_t matches = u64_or(9, 0);
       const uint64_t block = u64_or(10, 1);
       const double denom = (double)(block > 1 ? block : 1);
@@ -522,12 +531,21 @@ int parse_text(swg_paf* p, int threads) {
       }
       p->q_id[k] = s.names.get(fld(0), 0);
       p->t_id[k] = s.names.get(fld(5), 1);
-      p->qs[k] = narrow(u64_or(2, 0), "query_start");
-      p->qe[k] = narrow(u64_or(3, 0), "query_end");
-      p->ts[k] = narrow(u64_or(7, 0), "target_start");
-      p->te[k] = narrow(u64_or(8, 0), "target_end");
-      p->matches[k] = narrow(matches, "matches");
-      p->block[k] = narrow(block, "block_length");
+      if (wide) {
+        p->wide[0][k] = u64_or(2, 0);
+        p->wide[1][k] = u64_or(3, 0);
+        p->wide[2][k] = u64_or(7, 0);
+        p->wide[3][k] = u64_or(8, 0);
+        p->wide[4][k] = matches;
+        p->wide[5][k] = block;
+      } else {
+        p->qs[k] = narrow(u64_or(2, 0));
+        p->qe[k] = narrow(u64_or(3, 0));
+        p->ts[k] = narrow(u64_or(7, 0));
+        p->te[k] = narrow(u64_or(8, 0));
+        p->matches[k] = narrow(matches);
+        p->block[k] = narrow(block);
+      }
       p->identity[k] = identity;
       p->strand[k] = (f[5] - 1 - f[4] == 1 && *f[4] == '+') ? 0 : 1;
       p->rank[k] = line;
@@ -537,12 +555,19 @@ int parse_text(swg_paf* p, int threads) {
       ++k;
     }
     s.recs = k - s.line_base;
-  });
+  }); };
+  pass2(false);
   lap("alloc + pass 2 (parse)");
+  bool wide = false;
+  for (auto& s : sl) wide = wide || s.wide;
+  if (wide) {
+    for (auto& w : p->wide) w.alloc(cap);
+    pass2(true);
+    lap("pass 2 again (64-bit columns)");
+  }
   for (auto& s : sl)
     if (s.err != SWG_OK)
-      return paf_error(s.err, "%s >= 2^32 on line %llu is not supported by the GPU layout", s.err_what,
-                       (unsigned long long)(s.err_line + 1));
+      return paf_error(s.err, "%s >= 2^32 on line %llu is not supported", s.err_what, (unsigned long long)(s.err_line + 1));
   // close the gaps left by skipped lines (slices in file order: a slice only ever moves towards the front)
   uint64_t n = 0;
   for (auto& s : sl) {
@@ -568,6 +593,8 @@ int parse_text(swg_paf* p, int threads) {
     close_up(p->strand);
     close_up(p->rank);
     close_up(p->rec_off);
+    if (wide)
+      for (auto& w : p->wide) close_up(w);
     lap("close gaps");
   }
 
@@ -595,6 +622,26 @@ int parse_text(swg_paf* p, int threads) {
     }
   });
   lap("name merge + remap");
+  if (wide) {
+    const uint32_t n_seq = (uint32_t)(p->names.empty() ? 1 : p->names.size());
+    p->seq_offset.assign(n_seq, 0);
+    const uint64_t* const c64[6] = {p->wide[0].data(), p->wide[1].data(), p->wide[2].data(),
+                                    p->wide[3].data(), p->wide[4].data(), p->wide[5].data()};
+    uint32_t* const c32[6] = {p->qs.data(), p->qe.data(), p->ts.data(), p->te.data(), p->matches.data(), p->block.data()};
+    const swg_rebase::Result rr = swg_rebase::columns(n, p->q_id.data(), p->t_id.data(), c64, n_seq, threads, c32, p->seq_offset.data());
+    if (!rr.ok) {
+      const uint64_t k = rr.bad_record;
+      if (rr.bad_field >= 4)
+        return paf_error(SWG_ERR_RANGE, "%s >= 2^32 on line %llu is not supported", swg_rebase::field_name(rr.bad_field),
+                         (unsigned long long)(p->rank[k] + 1));
+      const uint32_t sid = rr.bad_field < 2 ? p->q_id[k] : p->t_id[k];
+      return paf_error(SWG_ERR_RANGE, "the mapped stretch of sequence %s spans 2^32 bases or more (%s on line %llu, first mapped base %llu): "
+                       "not supported by the 32-bit device layout", p->names[sid].c_str(), swg_rebase::field_name(rr.bad_field),
+                       (unsigned long long)(p->rank[k] + 1), (unsigned long long)p->seq_offset[sid]);
+    }
+    for (auto& w : p->wide) w.alloc(0);
+    lap("rebase");
+  }
   const uint32_t n_last = genome_table(p->names, prefix_last, &p->g_last);
   const uint32_t n_two = genome_table(p->names, prefix_two, &p->g_two);
   swg_records& r = p->rec;
@@ -735,6 +782,7 @@ int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** o
 
 void swg_paf_close(swg_paf* p) { delete p; }
 const swg_records* swg_paf_records(const swg_paf* p) { return p ? &p->rec : nullptr; }
+const uint64_t* swg_paf_seq_offsets(const swg_paf* p) { return (p && !p->seq_offset.empty()) ? p->seq_offset.data() : nullptr; }
 uint64_t swg_paf_num_lines(const swg_paf* p) { return p ? p->n_lines : 0; }
 const uint64_t* swg_paf_ranks(const swg_paf* p) { return p ? p->rank.data() : nullptr; }
 uint32_t swg_paf_num_sequences(const swg_paf* p) { return p ? (uint32_t)p->names.size() : 0; }
@@ -1074,6 +1122,7 @@ struct swg_aln {
   std::vector<uint8_t> strand;
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
+  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing)
   swg_records rec{};
 };
 
@@ -1143,6 +1192,7 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
       ids.emplace(std::string(nm), id);
       return id;
     };
+    bool wide = false;
     for (uint64_t k = 0; k < n; ++k) {
       if (!in->query_name[k] || !in->target_name[k]) {
         delete a;
@@ -1154,11 +1204,7 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
       const uint64_t query_span = q1 - q0, target_span = t1 - t0;  // :107-108 (wrapping, as release Rust)
       const uint64_t block = query_span + target_span;             // :112
       const uint64_t m = in->matches[k];                           // :115
-      if ((q0 | q1 | t0 | t1 | block | m) >> 32) {
-        delete a;
-        return paf_error(SWG_ERR_RANGE, "alignment %llu: a coordinate, the block length or the match count is >= 2^32",
-                         (unsigned long long)k);
-      }
+      if ((q0 | q1 | t0 | t1 | block | m) >> 32) wide = true;  // rebased below
       a->qs[k] = (uint32_t)q0;
       a->qe[k] = (uint32_t)q1;
       a->ts[k] = (uint32_t)t0;
@@ -1167,6 +1213,27 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
       a->block[k] = (uint32_t)block;
       a->identity[k] = query_span > 0 ? (double)m / (double)query_span : 0.0;  // :119-123
       a->strand[k] = in->strand[k] == '+' ? 0 : 1;
+    }
+    if (wide) {  // values >= 2^32: coordinates rebased sequence by sequence (host/rebase.h)
+      std::vector<uint64_t> block64(n);
+      for (uint64_t k = 0; k < n; ++k)
+        block64[k] = (in->query_end[k] - in->query_start[k]) + (in->target_end[k] - in->target_start[k]);
+      const uint32_t n_seq = (uint32_t)a->names.size();
+      a->seq_offset.assign(n_seq, 0);
+      const uint64_t* const c64[6] = {in->query_start, in->query_end, in->target_start, in->target_end, in->matches, block64.data()};
+      uint32_t* const c32[6] = {a->qs.data(), a->qe.data(), a->ts.data(), a->te.data(), a->matches.data(), a->block.data()};
+      const swg_rebase::Result rr = swg_rebase::columns(n, a->q_id.data(), a->t_id.data(), c64, n_seq, pick_threads(0), c32,
+                                                        a->seq_offset.data());
+      if (!rr.ok) {
+        const uint64_t k = rr.bad_record;
+        const int f = rr.bad_field;
+        std::string what = f >= 4 ? std::string(swg_rebase::field_name(f)) + " >= 2^32"
+                                  : "the mapped stretch of sequence " + a->names[f < 2 ? a->q_id[k] : a->t_id[k]] +
+                                        " spans 2^32 bases or more";
+        delete a;
+        return paf_error(SWG_ERR_RANGE, "alignment %llu: %s: not supported by the 32-bit device layout", (unsigned long long)k,
+                         what.c_str());
+      }
     }
     const uint32_t n_last = genome_table(a->names, prefix_last, &a->g_last);
     const uint32_t n_two = genome_table(a->names, prefix_two, &a->g_two);
@@ -1196,6 +1263,7 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
 }
 void swg_aln_close(swg_aln* a) { delete a; }
 const swg_records* swg_aln_records(const swg_aln* a) { return a ? &a->rec : nullptr; }
+const uint64_t* swg_aln_seq_offsets(const swg_aln* a) { return (a && !a->seq_offset.empty()) ? a->seq_offset.data() : nullptr; }
 uint32_t swg_aln_num_sequences(const swg_aln* a) { return a ? (uint32_t)a->names.size() : 0; }
 const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id) {
   return (a && id < a->names.size()) ? a->names[id].c_str() : nullptr;

@@ -1,0 +1,94 @@
+// RecordMeta holds u64 coordinates (src/paf_filter.rs:58-62); the device layout is 32-bit.  Every quantity
+// apply_filters derives from coordinates is a difference, an order or a midpoint of positions ON ONE SEQUENCE (spans,
+// overlaps, chaining gaps, bounding boxes, diagonals t - q of one sequence pair, rescue distances, the saturating
+// window starts, which only ever clamp below a sequence's smallest coordinate), so subtracting a per-sequence constant
+// from all of a sequence's coordinates -- query and target appearances alike -- changes no result.  The constant is the
+// smallest coordinate the sequence has anywhere in the record set; what must fit 32 bits is then only the stretch of
+// each sequence that mappings touch, not its absolute position.  Host version (threads); the device version of the same
+// two steps is in swg_filter.hip.
+#ifndef SWG_HOST_REBASE_H
+#define SWG_HOST_REBASE_H
+
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+namespace swg_rebase {
+
+struct Result {
+  bool ok = true;
+  uint64_t bad_record = 0;
+  int bad_field = -1;  // 0..3 = q_start, q_end, t_start, t_end (mapped stretch of the sequence >= 2^32); 4 matches; 5 block length
+};
+
+inline const char* field_name(int f) {
+  static const char* const N[6] = {"query_start", "query_end", "target_start", "target_end", "matches", "block_length"};
+  return (f >= 0 && f < 6) ? N[f] : "?";
+}
+
+template <class F>
+inline void run(int threads, F&& body) {
+  if (threads <= 1) {
+    body(0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(threads - 1);
+  for (int t = 1; t < threads; ++t) pool.emplace_back([&body, t] { body(t); });
+  body(0);
+  for (auto& th : pool) th.join();
+}
+
+// c64 = {q_start, q_end, t_start, t_end, matches, block_len}; matches / block_len may be NULL (then c32[4] / c32[5] are
+// left alone).  lo[n_seq] receives the offsets (UINT64_MAX for a sequence no record names).
+inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, const uint64_t* const c64[6], uint32_t n_seq,
+                      int threads, uint32_t* const c32[6], uint64_t* lo) {
+  if (threads < 1) threads = 1;
+  if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
+  std::vector<std::vector<uint64_t>> part(threads > 1 ? threads : 0);
+  for (uint32_t s = 0; s < n_seq; ++s) lo[s] = UINT64_MAX;
+  run(threads, [&](int t) {
+    uint64_t* m = lo;
+    if (threads > 1) {
+      part[t].assign(n_seq, UINT64_MAX);
+      m = part[t].data();
+    }
+    const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
+    for (uint64_t i = b; i < e; ++i) {
+      uint64_t& mq = m[q_id[i]];
+      const uint64_t q = c64[0][i] < c64[1][i] ? c64[0][i] : c64[1][i];
+      if (q < mq) mq = q;
+      uint64_t& mt = m[t_id[i]];
+      const uint64_t tt = c64[2][i] < c64[3][i] ? c64[2][i] : c64[3][i];
+      if (tt < mt) mt = tt;
+    }
+  });
+  for (int t = 0; t < threads && threads > 1; ++t)
+    for (uint32_t s = 0; s < n_seq; ++s)
+      if (part[t][s] < lo[s]) lo[s] = part[t][s];
+  std::vector<Result> res(threads);
+  run(threads, [&](int t) {
+    Result& r = res[t];
+    const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
+    for (uint64_t i = b; i < e; ++i) {
+      const uint64_t oq = lo[q_id[i]], ot = lo[t_id[i]];
+      const uint64_t v[6] = {c64[0][i] - oq, c64[1][i] - oq, c64[2][i] - ot, c64[3][i] - ot, c64[4] ? c64[4][i] : 0,
+                             c64[5] ? c64[5][i] : 0};
+      for (int f = 0; f < 6; ++f) {
+        if ((v[f] >> 32) && r.ok) {
+          r.ok = false;
+          r.bad_record = i;
+          r.bad_field = f;
+        }
+        if (f < 4 || c64[f]) c32[f][i] = (uint32_t)v[f];
+      }
+    }
+  });
+  for (auto& r : res)
+    if (!r.ok) return r;
+  return Result{};
+}
+
+}  // namespace swg_rebase
+
+#endif

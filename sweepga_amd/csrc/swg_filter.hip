@@ -8,6 +8,7 @@
 #include "swg_internal.h"
 #include "swg_log.h"
 #include "swg_pipeline.h"
+#include "host/rebase.h"
 
 namespace {
 
@@ -53,6 +54,67 @@ __global__ __launch_bounds__(EW) void log_range_kernel(uint64_t first, uint64_t 
                                                        double* __restrict__ y) {
   uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (i < n) y[i] = swg_log_glibc((double)(first + i * stride));
+}
+
+// ---- 64-bit records: per-sequence rebasing (host/rebase.h has the argument and the host version) ------------------
+// lo[s] = smallest coordinate sequence s has anywhere.  Grouped inputs name one query (and often one target) across a
+// whole wavefront: one atomic per wavefront then, one per lane otherwise.
+__device__ __forceinline__ void seq_min_atomic(unsigned long long* lo, uint32_t id, unsigned long long v, bool in) {
+  const uint32_t id0 = __shfl(id, __ffsll((long long)__ballot(in)) - 1, 64);
+  if (__all(!in || id == id0)) {
+    unsigned long long m = in ? v : ~0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long x = __shfl_xor(m, o, 64);
+      m = x < m ? x : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(lo + id0, m);
+  } else if (in) {
+    atomicMin(lo + id, v);
+  }
+}
+__global__ __launch_bounds__(EW) void seq_lo_kernel(uint64_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                    const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
+                                                    const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
+                                                    unsigned long long* __restrict__ lo) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  const bool in = i < n;
+  if (__ballot(in) == 0) return;
+  uint32_t q = 0, t = 0;
+  unsigned long long a = 0, b = 0;
+  if (in) {
+    q = q_id[i];
+    t = t_id[i];
+    a = qs[i] < qe[i] ? qs[i] : qe[i];
+    b = ts[i] < te[i] ? ts[i] : te[i];
+  }
+  seq_min_atomic(lo, q, a, in);
+  seq_min_atomic(lo, t, b, in);
+}
+// bad[0] = 1 + smallest record index whose rebased value does not fit 32 bits (0: none), bad[1] = its field
+__global__ __launch_bounds__(EW) void rebase_kernel(uint64_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                    const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
+                                                    const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
+                                                    const uint64_t* __restrict__ matches, const uint64_t* __restrict__ block,
+                                                    const unsigned long long* __restrict__ lo, uint32_t* __restrict__ o_qs,
+                                                    uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts, uint32_t* __restrict__ o_te,
+                                                    uint32_t* __restrict__ o_m, uint32_t* __restrict__ o_b,
+                                                    unsigned long long* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long oq = lo[q_id[i]], ot = lo[t_id[i]];
+  const unsigned long long v[6] = {qs[i] - oq, qe[i] - oq, ts[i] - ot, te[i] - ot, matches[i], block[i]};
+  o_qs[i] = (uint32_t)v[0];
+  o_qe[i] = (uint32_t)v[1];
+  o_ts[i] = (uint32_t)v[2];
+  o_te[i] = (uint32_t)v[3];
+  o_m[i] = (uint32_t)v[4];
+  o_b[i] = (uint32_t)v[5];
+  int f = -1;
+#pragma unroll
+  for (int k = 5; k >= 0; --k)
+    if (v[k] >> 32) f = k;
+  if (f >= 0) atomicMin(bad, ((unsigned long long)(i + 1) << 3) | (unsigned)f);
 }
 
 void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, uint64_t* kt) {
@@ -178,15 +240,57 @@ static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
   return SWG_OK;
 }
 
+// rec64 != NULL: rec's six 32-bit columns are produced from rec64's inside the arena before the pipeline runs
+static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_records64* rec64, const swg_config* cfg,
+                             uint8_t* status_out, uint32_t* chain_out, swg_stats* stats);
+
 extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg,
                                  uint8_t* status_out, uint32_t* chain_out, swg_stats* stats) {
   SWG_TRY(validate(ctx, rec, cfg));
+  return filter_device_any(ctx, rec, nullptr, cfg, status_out, chain_out, stats);
+}
+
+static swg_records narrow_view(const swg_records64* r) {  // everything but the six wide columns
+  swg_records v{};
+  v.n = r->n;
+  v.q_id = r->q_id;
+  v.t_id = r->t_id;
+  v.identity = r->identity;
+  v.strand = r->strand;
+  v.n_seq = r->n_seq;
+  v.seq_genome_last = r->seq_genome_last;
+  v.n_genome_last = r->n_genome_last;
+  v.seq_genome_two = r->seq_genome_two;
+  v.n_genome_two = r->n_genome_two;
+  return v;
+}
+static int validate64(swg_ctx* ctx, const swg_records64* r, const swg_config* cfg) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (!r || !cfg) return swg_set_error(ctx, SWG_ERR_INVALID, "records/config is NULL");
+  swg_records v = narrow_view(r);
+  static const uint32_t dummy = 0;  // the wide columns are checked here, the rest by validate()
+  v.q_start = v.q_end = v.t_start = v.t_end = v.matches = v.block_len = &dummy;
+  if (r->n && (!r->q_start || !r->q_end || !r->t_start || !r->t_end || !r->matches || !r->block_len))
+    return swg_set_error(ctx, SWG_ERR_INVALID, "a record column is NULL");
+  return validate(ctx, &v, cfg);
+}
+
+extern "C" int swg_filter_device64(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, uint8_t* status_out,
+                                   uint32_t* chain_out, swg_stats* stats) {
+  SWG_TRY(validate64(ctx, rec, cfg));
+  const swg_records v = narrow_view(rec);
+  return filter_device_any(ctx, &v, rec, cfg, status_out, chain_out, stats);
+}
+
+static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_records64* rec64, const swg_config* cfg,
+                             uint8_t* status_out, uint32_t* chain_out, swg_stats* stats) {
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   // Scratch high-water marks measured on the 10^8 workload: 58 B/record for the sweep-only pipeline, 252-370 B/record
   // with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a context's first call.
   {
-    size_t want = (size_t)rec->n * (cfg->scaffold_gap == 0 ? 72 : 400) + (size_t(8) << 20);
+    size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? 72 : 400) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
+                  (rec64 ? (size_t)rec->n_seq * 8 : 0);
     if (cfg->scaffold_gap != 0) {
       // the scaffold stage keeps two dense genome-pair tables (first appearance of a pair under either prefix rule);
       // with names without '#' every sequence is its own genome and the tables outgrow the per-record estimate
@@ -206,7 +310,42 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
     }
   }
   SWG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = swg_run_with_arena(ctx, [&]() { return filter_device_body(ctx, rec, cfg, status_out, chain_out, stats); });
+  int rc = swg_run_with_arena(ctx, [&]() -> int {
+    if (!rec64 || rec->n == 0) return filter_device_body(ctx, rec, cfg, status_out, chain_out, stats);
+    const uint64_t n = rec->n;
+    hipStream_t st = ctx->stream;
+    uint32_t* c[6];
+    for (auto& p : c) p = swg_alloc<uint32_t>(ctx, n);
+    unsigned long long* lo = swg_alloc<unsigned long long>(ctx, (size_t)rec->n_seq + 1);  // + the error word
+    SWG_CHECK_ARENA(ctx);
+    unsigned long long* bad = lo + rec->n_seq;
+    SWG_HIP(ctx, hipMemsetAsync(lo, 0xff, ((size_t)rec->n_seq + 1) * sizeof(unsigned long long), st));
+    SWG_LAUNCH(ctx, "seq_lo", seq_lo_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end,
+                                                                   rec64->t_start, rec64->t_end, lo));
+    SWG_LAUNCH(ctx, "rebase", rebase_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end,
+                                                                   rec64->t_start, rec64->t_end, rec64->matches, rec64->block_len,
+                                                                   lo, c[0], c[1], c[2], c[3], c[4], c[5], bad));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t hb;
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(bad), &hb, 1));
+    if (hb != ~0ull) {
+      static const char* const F[8] = {"query_start", "query_end", "target_start", "target_end", "matches", "block_length", "?", "?"};
+      const int f = (int)(hb & 7);
+      return swg_set_error(ctx, SWG_ERR_RANGE,
+                           f >= 4 ? "record %llu: %s >= 2^32 is not supported"
+                                  : "record %llu: the mapped stretch of its sequence spans 2^32 bases or more (%s): not supported by the "
+                                    "32-bit device layout",
+                           (unsigned long long)((hb >> 3) - 1), F[f]);
+    }
+    swg_records r32 = *rec;
+    r32.q_start = c[0];
+    r32.q_end = c[1];
+    r32.t_start = c[2];
+    r32.t_end = c[3];
+    r32.matches = c[4];
+    r32.block_len = c[5];
+    return filter_device_body(ctx, &r32, cfg, status_out, chain_out, stats);
+  });
   if (rc != SWG_OK) return rc;
   SWG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   if (stats) {
@@ -314,6 +453,51 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
     stats->d2h_ms = d2h;
   }
   return rc;
+}
+
+// RecordMeta's own widths from host memory: rebased by host threads into 32-bit columns kept in the context, then swg_filter
+// (the bytes crossing PCIe are those of the 32-bit layout).
+int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, swg_records* out) {
+  SWG_TRY(validate64(ctx, rec, cfg));
+  swg_records& v = *out;
+  v = narrow_view(rec);
+  const uint64_t n = rec->n;
+  if (n == 0) return SWG_OK;
+  std::vector<uint32_t>& h = ctx->narrow_host;
+  std::vector<uint64_t> lo;
+  try {
+    if (h.size() < 6 * n) h.resize(6 * n);
+    lo.resize(rec->n_seq);
+  } catch (const std::bad_alloc&) {
+    return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory for the 32-bit columns");
+  }
+  for (uint64_t i = 0; i < n; ++i)  // ids index the offset table below
+    if (rec->q_id[i] >= rec->n_seq || rec->t_id[i] >= rec->n_seq)
+      return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)i);
+  const uint64_t* const c64[6] = {rec->q_start, rec->q_end, rec->t_start, rec->t_end, rec->matches, rec->block_len};
+  uint32_t* const c32[6] = {h.data(), h.data() + n, h.data() + 2 * n, h.data() + 3 * n, h.data() + 4 * n, h.data() + 5 * n};
+  unsigned hc = std::thread::hardware_concurrency();
+  const swg_rebase::Result rr = swg_rebase::columns(n, rec->q_id, rec->t_id, c64, rec->n_seq, hc ? (int)(hc > 64 ? 64 : hc) : 1, c32,
+                                                    lo.data());
+  if (!rr.ok)
+    return swg_set_error(ctx, SWG_ERR_RANGE,
+                         rr.bad_field >= 4 ? "record %llu: %s >= 2^32 is not supported"
+                                           : "record %llu: the mapped stretch of its sequence spans 2^32 bases or more (%s): not "
+                                             "supported by the 32-bit device layout",
+                         (unsigned long long)rr.bad_record, swg_rebase::field_name(rr.bad_field));
+  v.q_start = c32[0];
+  v.q_end = c32[1];
+  v.t_start = c32[2];
+  v.t_end = c32[3];
+  v.matches = c32[4];
+  v.block_len = c32[5];
+  return SWG_OK;
+}
+extern "C" int swg_filter64(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, uint8_t* status_out, uint32_t* chain_out,
+                            swg_stats* stats) {
+  swg_records v;
+  SWG_TRY(swg_rebase_host(ctx, rec, cfg, &v));
+  return swg_filter(ctx, &v, cfg, status_out, chain_out, stats);
 }
 
 // ---- plane_sweep_query / target / both on one segment of host arrays --------------------------------

@@ -23,6 +23,7 @@ struct swg_ctx {
   // demand, so a host that filters file after file pays no hipMalloc / hipFree in steady state
   char* io_block = nullptr;
   size_t io_cap = 0;
+  std::vector<uint32_t> narrow_host;  // swg_filter64: the rebased 32-bit columns (host side), kept between calls
   // pinned host scratch for small read-backs
   uint64_t* h_scalars = nullptr;  // 64 x u64
   std::string err;
@@ -147,6 +148,8 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
 int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64_t* e0, uint32_t* out_s, uint32_t* out_e,
                       const char* axis);
+// swg_records64 (host pointers) -> 32-bit columns kept in ctx->narrow_host, coordinates rebased per sequence (host/rebase.h)
+int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, swg_records* out);
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
 
 static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represent max_value

@@ -201,3 +201,12 @@ extern "C" int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_recor
   }
   return SWG_OK;
 }
+
+// RecordMeta's own widths: rebased on the host first (ctxs[0] keeps the 32-bit columns), then the same sharding.
+extern "C" int swg_filter_multi64(swg_ctx* const* ctxs, int n_ctx, const swg_records64* r, const swg_config* cfg, uint8_t* status_out,
+                                  uint32_t* chain_out, swg_stats* stats) {
+  if (!ctxs || n_ctx < 1 || !ctxs[0]) return SWG_ERR_INVALID;
+  swg_records v;
+  SWG_TRY(swg_rebase_host(ctxs[0], r, cfg, &v));
+  return swg_filter_multi(ctxs, n_ctx, &v, cfg, status_out, chain_out, stats);
+}

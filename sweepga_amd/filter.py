@@ -289,6 +289,7 @@ class PackedRecords:
     seq_genome_two: np.ndarray
     n_genome_two: int
     index: SequenceIndex = field(default=None)
+    wide: bool = False   # q_start .. t_end, matches, block_len are uint64 (swg_records64; same struct layout, wider columns)
 
     def to_c(self) -> SwgRecords:
         r = SwgRecords()
@@ -304,17 +305,15 @@ class PackedRecords:
 
 
 def pack_records(metadata: List[RecordMeta]) -> PackedRecords:
-    """Interns names and narrows to the u32 device layout.  Values that do not fit raise."""
+    """Interns names; the u32 layout of swg_records when every value fits, else RecordMeta's own u64 widths
+    (swg_records64: the library rebases each sequence's coordinates)."""
     idx = SequenceIndex()
     n = len(metadata)
     q_id = np.fromiter((idx.get_or_insert(m.query_name) for m in metadata), dtype=np.uint32, count=n)
     t_id = np.fromiter((idx.get_or_insert(m.target_name) for m in metadata), dtype=np.uint32, count=n)
 
     def col32(get, what):
-        a = np.fromiter((get(m) for m in metadata), dtype=np.uint64, count=n)
-        if n and a.max() > 0xFFFFFFFF:
-            raise _lib.SwgError(-5, f"{what} >= 2^32 is not supported by the device layout")
-        return a.astype(np.uint32)
+        return np.fromiter((get(m) for m in metadata), dtype=np.uint64, count=n)
 
     cols = {
         "q_id": q_id, "t_id": t_id,
@@ -327,9 +326,14 @@ def pack_records(metadata: List[RecordMeta]) -> PackedRecords:
         "block_len": col32(lambda m: m.block_length, "block_length"),
         "strand": np.fromiter((0 if m.strand == "+" else 1 for m in metadata), dtype=np.uint8, count=n),
     }
+    six = ("q_start", "q_end", "t_start", "t_end", "matches", "block_len")
+    wide = bool(n) and max(int(cols[k].max()) for k in six) > 0xFFFFFFFF
+    if not wide:
+        for k in six:
+            cols[k] = cols[k].astype(np.uint32)
     cols = {k: np.ascontiguousarray(v) for k, v in cols.items()}
     last, n_last, two, n_two = idx.genome_tables()
-    return PackedRecords(n, cols, max(len(idx), 1), last, n_last, two, n_two, idx)
+    return PackedRecords(n, cols, max(len(idx), 1), last, n_last, two, n_two, idx, wide)
 
 
 class PafFilter:
@@ -374,8 +378,8 @@ class PafFilter:
         rec = packed.to_c()
         cfg = self.config.to_c(self.keep_self, self.scaffolds_only)
         ctx = self.ctx
-        ctx.check(ctx.lib.swg_filter(ctx.handle, C.byref(rec), C.byref(cfg), _ptr(status), _ptr(chain),
-                                     C.byref(stats)))
+        entry = ctx.lib.swg_filter64 if packed.wide else ctx.lib.swg_filter
+        ctx.check(entry(ctx.handle, C.byref(rec), C.byref(cfg), _ptr(status), _ptr(chain), C.byref(stats)))
         self.last_stats = stats
         return status[:n], chain[:n]
 
@@ -389,8 +393,8 @@ class PafFilter:
         rec = packed.to_c()
         cfg = self.config.to_c(self.keep_self, self.scaffolds_only)
         handles = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
-        contexts[0].check(contexts[0].lib.swg_filter_multi(handles, len(contexts), C.byref(rec), C.byref(cfg), _ptr(status),
-                                                           _ptr(chain), C.byref(stats)))
+        entry = contexts[0].lib.swg_filter_multi64 if packed.wide else contexts[0].lib.swg_filter_multi
+        contexts[0].check(entry(handles, len(contexts), C.byref(rec), C.byref(cfg), _ptr(status), _ptr(chain), C.byref(stats)))
         self.last_stats = stats
         return status[:n], chain[:n]
 

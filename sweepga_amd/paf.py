@@ -67,6 +67,14 @@ class PafFile:
         return self._view(self.records.seq_genome_two, np.uint32, max(int(self.records.n_seq), 1))
 
     @property
+    def seq_offsets(self):
+        """[n_seq] what rebasing took off each sequence's coordinates, or None (no value of the file reached 2^32)."""
+        ptr = self.lib.swg_paf_seq_offsets(self.handle)
+        if not ptr:
+            return None
+        return self._view(C.addressof(ptr.contents), np.uint64, int(self.records.n_seq))
+
+    @property
     def timing_ms(self):
         a, b = C.c_double(), C.c_double()
         self.lib.swg_paf_timing(self.handle, C.byref(a), C.byref(b))

@@ -76,9 +76,15 @@ def main():
         try:
             with PafFile(path, threads=int(rng.integers(1, 4))) as pf:
                 ok = pf.n == n and (pf.ranks == cols["rank"][:n]).all()
-                for name, key in (("q_start", "qs"), ("q_end", "qe"), ("t_start", "ts"), ("t_end", "te"), ("block_len", "block"),
-                                  ("matches", "matches")):
-                    ok = ok and (pf.column(name).astype(np.uint64) == cols[key][:n]).all()
+                off = pf.seq_offsets  # a file with values >= 2^32: coordinates relative to the sequence's smallest one
+                for name, key, ids in (("q_start", "qs", "q_id"), ("q_end", "qe", "q_id"), ("t_start", "ts", "t_id"),
+                                       ("t_end", "te", "t_id"), ("block_len", "block", None), ("matches", "matches", None)):
+                    col = pf.column(name).astype(np.uint64)
+                    if off is not None and ids is not None:
+                        col = col + off[pf.column(ids)]
+                    ok = ok and (col == cols[key][:n]).all()
+                if off is not None:
+                    ok = ok and any(int(v) > 0xffffffff for k in ("qs", "qe", "ts", "te", "block", "matches") for v in cols[k][:n])
                 ok = ok and (pf.column("identity").view(np.uint64) == ident[:n].view(np.uint64)).all()
                 ok = ok and (pf.column("strand") == (strand[:n] != ord("+"))).all()
                 rec = orc.parse_paf_text(text.replace("\r\n", "\n"))

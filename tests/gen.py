@@ -93,3 +93,16 @@ def records_to_paf(rng, rec, junk_lines=True):
         if junk_lines and rng.random() < 0.01:
             out.append(rng.choice(["", "# comment", "too\tfew\tfields", "q\t1\tx\ty\t+\tt\t1\t0\t0\tz\t\t0"]))
     return "\n".join(out) + "\n"
+
+
+WIDE_OFFSETS = [0, 2**32 - 1, 2**32 + 5, 5_000_000_000, 2**40 + 123, 2**62, 77]
+
+
+def shifted(rec, rng):
+    """The same records with every sequence moved by its own constant (as query and as target alike) -> (Records, {name: offset})."""
+    names = sorted(set(rec.qname) | set(rec.tname))
+    off = {nm: WIDE_OFFSETS[int(rng.integers(0, len(WIDE_OFFSETS)))] for nm in names}
+    oq = np.array([off[x] for x in rec.qname], dtype=np.uint64)
+    ot = np.array([off[x] for x in rec.tname], dtype=np.uint64)
+    return orc.Records(rec.qname, rec.tname, rec.qs + oq, rec.qe + oq, rec.ts + ot, rec.te + ot, rec.block_length, rec.identity,
+                       rec.matches, rec.strand, rec.rank), off

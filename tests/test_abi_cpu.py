@@ -3,6 +3,7 @@ header declares; the host mirror's pure-host logic (interning, PAF parsing, conf
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -95,12 +96,16 @@ def test_host_paf_parser_matches_oracle_parser(tmp_path):
     assert mine[3].identity == 0.5                                       # last tag wins
 
 
-def test_pack_records_rejects_wide_coordinates():
-    from sweepga_amd import RecordMeta, SwgError, pack_records
+def test_pack_records_keeps_wide_coordinates():
+    """RecordMeta is u64 (src/paf_filter.rs:58-62): values >= 2^32 go to the library in swg_records64 (rebased there)."""
+    from sweepga_amd import RecordMeta, pack_records
     m = RecordMeta(0, "a", "b", 0, 2**32, 0, 10, 10, 1.0, 10, 10, "+")
-    with pytest.raises(SwgError) as e:
-        pack_records([m])
-    assert e.value.code == -5
+    p = pack_records([m])
+    assert p.wide and p.cols["q_end"].dtype == np.uint64 and int(p.cols["q_end"][0]) == 2**32
+    assert p.cols["matches"].dtype == np.uint64
+    m = RecordMeta(0, "a", "b", 0, 2**32 - 1, 0, 10, 10, 1.0, 10, 10, "+")
+    p = pack_records([m])
+    assert not p.wide and p.cols["q_end"].dtype == np.uint32
 
 
 def test_device_log_restatement_on_host():

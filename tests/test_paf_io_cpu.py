@@ -169,13 +169,60 @@ def test_open_buffer_and_errors(tmp_path):
         assert (pf.n, pf.n_lines) == (9, 12)
     with pytest.raises(SwgError, match="cannot open"):
         PafFile(tmp_path / "missing.paf")
-    with pytest.raises(SwgError, match="2\\^32 on line 2"):
-        PafFile(text="q\t9\t1\t5\t+\tt\t9\t2\t6\t3\t4\t0\nq\t9\t1\t4294967296\t+\tt\t9\t2\t6\t3\t4\t0\n")
+    # a sequence whose mapped stretch itself spans 2^32 bases, and a match count >= 2^32, are beyond the 32-bit layout
+    with pytest.raises(SwgError, match="sequence q spans 2\\^32 bases or more \\(query_end on line 2"):
+        PafFile(text="q\t9\t0\t5\t+\tt\t9\t2\t6\t3\t4\t0\nq\t9\t1\t4294967296\t+\tt\t9\t2\t6\t3\t4\t0\n")
+    with pytest.raises(SwgError, match="matches >= 2\\^32 on line 1"):
+        PafFile(text="q\t9\t0\t5\t+\tt\t9\t2\t6\t4294967296\t4\t0\n")
     with PafFile(text=EDGE_TEXT) as pf:
         with pytest.raises(ValueError):
             pf.write(tmp_path / "o", np.zeros(3, dtype=np.uint8))
         with pytest.raises(SwgError, match="cannot create"):
             pf.write(tmp_path / "no_such_dir" / "o", np.ones(9, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_wide_coordinates_are_rebased_per_sequence(tmp_path, threads):
+    """RecordMeta is u64 (src/paf_filter.rs:58-62).  A file with values >= 2^32 is parsed into 64-bit columns and every
+    sequence's coordinates are taken relative to the smallest coordinate the sequence has anywhere (as query or target);
+    everything else equals the oracle's extract_metadata."""
+    rng = np.random.default_rng(5)
+    base = {"gA#1#c1": 5_000_000_000, "gA#1#c2": 0, "gB#1#c1": 2**33 + 17, "gB#1#c2": 123, "gC#1#x": 2**40}
+    names = list(base)
+    lines = []
+    for _ in range(3000):
+        q, t = names[rng.integers(0, 5)], names[rng.integers(0, 5)]
+        qs = base[q] + int(rng.integers(0, 3_000_000_000))
+        ts = base[t] + int(rng.integers(0, 3_000_000_000))
+        ql, tl = int(rng.integers(1, 50_000)), int(rng.integers(1, 50_000))
+        m = int(rng.integers(1, ql + 1))
+        lines.append(f"{q}\t99\t{qs}\t{qs + ql}\t{'+-'[int(rng.integers(0, 2))]}\t{t}\t99\t{ts}\t{ts + tl}\t{m}\t{max(ql, tl)}\t60")
+    text = "\n".join(lines) + "\n"
+    ref = orc.parse_paf_text(text)
+    lo = {}
+    for i in range(len(lines)):
+        for nm, v in ((ref.qname[i], int(ref.qs[i])), (ref.tname[i], int(ref.ts[i]))):
+            lo[nm] = min(lo.get(nm, v), v)
+    with PafFile(text=text, threads=threads) as pf:
+        assert pf.n == len(lines)
+        nm = pf.names
+        off = pf.seq_offsets
+        assert off is not None and {nm[i]: int(off[i]) for i in range(len(nm))} == lo
+        q = [nm[i] for i in pf.column("q_id")]
+        t = [nm[i] for i in pf.column("t_id")]
+        assert q == list(ref.qname) and t == list(ref.tname)
+        oq = np.array([lo[x] for x in q], dtype=np.uint64)
+        ot = np.array([lo[x] for x in t], dtype=np.uint64)
+        assert np.array_equal(pf.column("q_start").astype(np.uint64) + oq, ref.qs)
+        assert np.array_equal(pf.column("q_end").astype(np.uint64) + oq, ref.qe)
+        assert np.array_equal(pf.column("t_start").astype(np.uint64) + ot, ref.ts)
+        assert np.array_equal(pf.column("t_end").astype(np.uint64) + ot, ref.te)
+        assert np.array_equal(pf.column("matches"), ref.matches) and np.array_equal(pf.column("block_len"), ref.block_length)
+        assert np.array_equal(pf.column("identity"), ref.identity)
+    with PafFile(text=text.replace("5000", "4", 1) if False else "\n".join(lines[:5]) + "\n") as pf:
+        assert pf.seq_offsets is not None
+    with PafFile(text="q\t9\t1\t5\t+\tt\t9\t2\t6\t3\t4\t0\n") as pf:
+        assert pf.seq_offsets is None        # nothing reached 2^32: columns are the file's own values
 
 
 def test_fuzz_slice_against_oracle(tmp_path):
