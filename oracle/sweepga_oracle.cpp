@@ -624,7 +624,9 @@ static std::vector<std::string> split_tabs(const std::string& line) {
 // piece after the last '\n' is not a line.
 static bool next_line(std::istream& in, std::string* line) {
   if (!std::getline(in, *line)) return false;
-  if (!line->empty() && line->back() == '\r') line->pop_back();
+  // the '\r' goes only together with a '\n' (std's Lines::next: `if buf.ends_with('\n') { pop; if buf.ends_with('\r') { pop } }`):
+  // a last line that ends in '\r' without a newline keeps it
+  if (!in.eof() && !line->empty() && line->back() == '\r') line->pop_back();
   return true;
 }
 
@@ -1200,7 +1202,7 @@ std::vector<std::string> read_lines_lossless(const std::string& path) {
   std::vector<std::string> lines;
   std::string line;
   while (std::getline(in, line)) {
-    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (!in.eof() && !line.empty() && line.back() == '\r') line.pop_back();  // only with its '\n', see next_line
     lines.push_back(line);
   }
   return lines;

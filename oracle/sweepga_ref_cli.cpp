@@ -144,7 +144,7 @@ int main(int argc, char** argv) {
     std::ofstream out("/dev/stdout", std::ios::binary);
     std::string line;
     while (std::getline(in, line)) {
-      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (!in.eof() && !line.empty() && line.back() == '\r') line.pop_back();
       out << line << "\n";
     }
     return 0;
@@ -210,7 +210,7 @@ int main(int argc, char** argv) {
         if (!in) die("cannot open " + input);
         std::string line;
         while (std::getline(in, line)) {
-          if (!line.empty() && line.back() == '\r') line.pop_back();
+          if (!in.eof() && !line.empty() && line.back() == '\r') line.pop_back();
           lines.push_back(line);
         }
       }

@@ -493,7 +493,7 @@ int parse_text(swg_paf* p, int threads) {
       const void* nl = std::memchr(text + pos, '\n', s.end - pos);
       const size_t end = nl ? (size_t)(static_cast<const char*>(nl) - text) : s.end;
       size_t ll = end - pos;
-      if (ll && text[pos + ll - 1] == '\r') --ll;  // BufRead::lines strips "\r\n"
+      if (nl && ll && text[pos + ll - 1] == '\r') --ll;  // BufRead::lines strips "\n" and "\r\n" (a '\r' only with its '\n')
       const char* b = text + pos;
       const char* e = b + ll;
       pos = end + 1;

@@ -336,7 +336,7 @@ int main(int argc, char** argv) {
       const void* nl = std::memchr(text + pos, '\n', len - pos);
       const uint64_t end = nl ? (uint64_t)((const char*)nl - text) : len;
       uint64_t ll = end - pos;
-      if (ll && text[pos + ll - 1] == '\r') --ll;
+      if (nl && ll && text[pos + ll - 1] == '\r') --ll;
       std::fwrite(text + pos, 1, ll, out);
       std::fputc('\n', out);
       pos = end + 1;

@@ -269,13 +269,16 @@ def parse_paf_line(line: str, rank: int) -> Optional[RecordMeta]:
 
 
 def read_lines(path):
-    """BufRead::lines(): split on '\\n', strip one trailing '\\r'."""
+    """BufRead::lines(): split on '\\n'; a '\\r' goes only together with the '\\n' after it (a last line without a
+    newline keeps a trailing '\\r')."""
     with open(path, "rb") as fh:
         data = fh.read().decode("utf-8", errors="surrogateescape")
     lines = data.split("\n")
+    unterminated = bool(lines) and lines[-1] != ""
     if lines and lines[-1] == "":
         lines.pop()
-    return [ln[:-1] if ln.endswith("\r") else ln for ln in lines]
+    last = len(lines) - 1
+    return [ln[:-1] if ln.endswith("\r") and not (unterminated and i == last) else ln for i, ln in enumerate(lines)]
 
 
 @dataclass

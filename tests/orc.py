@@ -191,10 +191,11 @@ def parse_paf_text(text):
     """extract_metadata (paf_filter.rs:292-376) in Python for *small* fixtures: same rules."""
     qn, tn, cols, ranks = [], [], [], []
     lines = text.split("\n")
+    unterminated = bool(lines) and lines[-1] != ""
     if lines and lines[-1] == "":
         lines.pop()
     for rank, line in enumerate(lines):
-        if line.endswith("\r"):
+        if line.endswith("\r") and not (unterminated and rank == len(lines) - 1):   # a '\r' goes only with its '\n'
             line = line[:-1]
         f = line.split("\t")
         if len(f) < 11:

@@ -93,6 +93,16 @@ def test_many_hash_names(tmp_path):
     native_vs_oracle("\n".join(lines) + "\n", tmp_path, 4)
 
 
+def test_carriage_return_goes_only_with_its_newline(tmp_path):
+    """std's Lines::next pops a '\\r' only after popping a '\\n': the last line of a file without a final newline keeps its
+    '\\r', so an 11-field last line has block length "50\\r" (parse failure -> 1) and a tag there reads "dv:f:0.5\\r"."""
+    native_vs_oracle("q1\t100\t10\t60\t+\tt1\t100\t5\t55\t45\t50\r\nq1\t100\t10\t60\t+\tt1\t100\t5\t55\t45\t50\r", tmp_path, 2)
+    with PafFile(text="q1\t100\t10\t60\t+\tt1\t100\t5\t55\t45\t50\r\nq1\t100\t10\t60\t+\tt1\t100\t5\t55\t45\t50\r") as pf:
+        assert [int(x) for x in pf.column("block_len")] == [50, 1]
+        assert list(pf.column("identity")) == [45 / 50, 45.0]
+    native_vs_oracle("q1\t100\t10\t60\t+\tt1\t100\t5\t55\t45\t50\t60\tdv:f:0.5\r", tmp_path, 1)
+
+
 def test_empty_and_blank_inputs(tmp_path):
     for text, lines in (("", 0), ("\n", 1), ("\n\n\n", 3), ("a\tb", 1)):
         path = tmp_path / "e.paf"
