@@ -329,6 +329,34 @@ int swg_paf_tree_filter(const char* text, uint64_t len, uint64_t k_nearest, uint
                         char** out_text, uint64_t* out_len);
 void swg_free(void* p);
 
+/* ---- alnstats (src/bin/alnstats.rs): statistics of a PAF and the comparison of two ------------------------------------
+ * parse_paf (:103-164) over host threads: lines with fewer than 11 fields are skipped; a line whose columns 2, 3, 4, 7,
+ * 10 or 11 do not parse as u64 ends the run as in the reference (SWG_ERR_INVALID, "Invalid query length" ... in
+ * swg_alnstats_last_error()).  mapping length = query_end - query_start; genome = name up to the last '#' (:94-100);
+ * a genome's size = sum of the last-seen lengths of its sequences; coverage of (query genome, target genome) =
+ * 100 * bases / size(query genome) over the inter-genome lines (:42-73).  The reference lists the pairs in HashMap
+ * order; here they come in order of first appearance in the file (that fixes the summation order of avg_coverage and
+ * the order of equal coverages in the detailed table).  swg_alnstats_report / _compare produce the exact text of
+ * print_stats (:166-228) / compare_stats (:230-284); release it with swg_free().  Host code, no GPU. */
+typedef struct swg_alnstats swg_alnstats;
+typedef struct swg_alnstats_summary {
+  uint64_t total_mappings, total_bases, total_matches, self_mappings, inter_chromosomal, inter_genome, chr_pair_count;
+  uint64_t genome_pairs, above_95_pct;
+  double avg_identity; /* total_matches / total_bases, 0 when there are no bases (:75-81) */
+  double avg_coverage;
+} swg_alnstats_summary;
+int swg_alnstats_open(const char* path, int threads, swg_alnstats** out); /* plain / .gz / .bgz / "-" like swg_paf_open */
+int swg_alnstats_open_buffer(const char* text, uint64_t len, int threads, swg_alnstats** out);
+void swg_alnstats_close(swg_alnstats* s);
+const swg_alnstats_summary* swg_alnstats_get(const swg_alnstats* s);
+/* pair i < genome_pairs; the genome strings keep their trailing '#' and are owned by the handle */
+int swg_alnstats_pair(const swg_alnstats* s, uint64_t i, const char** q_genome, const char** t_genome, double* coverage,
+                      uint64_t* bases, uint64_t* matches);
+int swg_alnstats_report(const swg_alnstats* s, const char* label, int detailed, char** out_text, uint64_t* out_len);
+int swg_alnstats_compare(const swg_alnstats* a, const swg_alnstats* b, const char* file1, const char* file2,
+                         char** out_text, uint64_t* out_len);
+const char* swg_alnstats_last_error(void);
+
 /* ---- ANI pre-pass for "aniN" identity thresholds (src/main.rs:296-688, src/cli.rs:76-130) -------------------
  * calculate_ani_stats: median over genome pairs (last-'#' prefixes, unordered) of Σmatches / Σblock_len, over
  *   SWG_ANI_ALL         every inter-genome line                                   main.rs:339-342, 392-498

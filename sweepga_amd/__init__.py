@@ -9,6 +9,7 @@ from .filter import (ChainStatus, FilterConfig, FilterMode, PafFilter, PlaneSwee
                      plane_sweep_target, USIZE_MAX, UnionFind, merge_mappings_into_chains, plane_sweep_scaffolds)
 from .paf import PafFile  # noqa: F401
 from .aln import AlnRecords  # noqa: F401
+from .alnstats import AlnStats  # noqa: F401
 from .ani import (AniMethod, AniMethodKind, NSort, calculate_ani_stats, parse_ani_method,  # noqa: F401
                   parse_identity_value)
 

@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsweepga_gpu.so")
 SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip", "swg_ani.hip", "swg_shard.hip",
-           os.path.join("host", "paf_io.cpp"), os.path.join("host", "tree_filter.cpp")]
+           os.path.join("host", "paf_io.cpp"), os.path.join("host", "tree_filter.cpp"),
+           os.path.join("host", "alnstats.cpp")]
 
 
 def _hipcc():
@@ -44,6 +45,23 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+STATS_SRC = os.path.join(CSRC, "host", "alnstats_cli.cpp")
+STATS = os.path.join(HERE, "bin", "alnstats")
+
+
+def build_alnstats(force=False, verbose=False):
+    """The reference's second binary (src/bin/alnstats.rs) over the library's host code."""
+    if not force and os.path.exists(STATS) and os.path.getmtime(STATS) >= max(os.path.getmtime(STATS_SRC), os.path.getmtime(LIB)):
+        return STATS
+    os.makedirs(os.path.dirname(STATS), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", STATS, STATS_SRC, "-L", HERE, "-lsweepga_gpu",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return STATS
+
+
 SYNTH_SRC = os.path.join(CSRC, "host", "paf_synth.cpp")
 SYNTH = os.path.join(HERE, "bin", "paf-synth")
 
@@ -68,6 +86,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     build_cli(force=force, verbose=verbose)
+    build_alnstats(force=force, verbose=verbose)
     build_synth(force=force, verbose=verbose)
     return LIB
 

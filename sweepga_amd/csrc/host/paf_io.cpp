@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../../include/sweepga_gpu.h"
+#include "host_internal.h"
 #include "rebase.h"
 
 namespace {
@@ -723,6 +724,26 @@ bool pwrite_all(int fd, const char* b, size_t n, off_t at) {
 }
 
 }  // namespace
+
+int swg_host_text_load(const char* path, int threads, const char** data, size_t* len, void** handle) {
+  Text* t = nullptr;
+  try {
+    t = new Text;
+    const int rc = load_text(path, pick_threads(threads), t);
+    if (rc != SWG_OK) {
+      delete t;
+      return rc;
+    }
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return paf_error(SWG_ERR_OOM, "out of host memory reading %s", path);
+  }
+  *data = t->data ? t->data : "";
+  *len = t->len;
+  *handle = t;
+  return SWG_OK;
+}
+void swg_host_text_release(void* handle) { delete static_cast<Text*>(handle); }
 
 extern "C" {
 

@@ -24,7 +24,7 @@ def _build_oracle():
         subprocess.check_call(["make", "-C", odir, "-s"])
     # the oracle's command line and the two host binaries are git-ignored build products: make sure they exist even if
     # a snapshot of the tree came without them (the HIP library itself is never rebuilt here)
-    if not os.path.exists(os.path.join(odir, "sweepga-ref")):
+    if not os.path.exists(os.path.join(odir, "sweepga-ref")) or not os.path.exists(os.path.join(odir, "alnstats-ref")):
         subprocess.check_call(["make", "-C", odir, "-s"])
     lib = os.path.join(ROOT, "sweepga_amd", "libsweepga_gpu.so")
     if os.path.exists(lib):
@@ -33,4 +33,6 @@ def _build_oracle():
             build.build_cli()
         if not os.path.exists(build.SYNTH):
             build.build_synth()
+        if not os.path.exists(build.STATS):
+            build.build_alnstats()
     yield
