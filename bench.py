@@ -125,6 +125,9 @@ def make_config(sw, pipeline):
                                scaffold_gap=50_000, min_scaffold_length=10_000, scaffold_max_deviation=20_000)
     if pipeline == "default":  # all CLI defaults (many:many, jump 50k, mass 10k)
         return sw.FilterConfig()
+    if pipeline == "k32":      # --num-mappings 3:2 --scaffold-jump 0: the 2 <= k < inf tile kernel (--pipeline k32 --only)
+        return sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToMany, mapping_max_per_query=3, mapping_max_per_target=2,
+                               scaffold_gap=0)
     raise SystemExit(f"unknown pipeline {pipeline}")
 
 
@@ -354,7 +357,7 @@ def roofline(pipeline, n, steps, t, wl="100m"):
     33 or 47 B per mapping x the n mappings one launch works on) / that kernel's average launch duration, measured
     with HIP events on the library's stream.  `kernel_own_*` is the kernel's own HBM traffic per launch (rocprofv3
     PMC, committed under profiles/) / the same duration, and `pipeline_*` the end-to-end figure."""
-    algo = ALGO_BYTES_SWEEP if pipeline == "sweep" else ALGO_BYTES_FULL
+    algo = ALGO_BYTES_SWEEP if pipeline in ("sweep", "k32") else ALGO_BYTES_FULL
     prof = t["prof"]
     total_kernel_ms = sum(ms for _, ms in prof.values())
     dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
@@ -527,7 +530,7 @@ def main():
     ap.add_argument("--workload", default="span", choices=["span", "sbig1"],
                     help="span: configs[3] (the headline).  sbig1: configs[2] as the MAIN record set (profiling runs of the dense "
                          "case; --mappings defaults to 10^7, the S-big1 side leg is skipped)")
-    ap.add_argument("--pipeline", default="default", choices=list(PIPELINES), help="flag set reported as `value`")
+    ap.add_argument("--pipeline", default="default", choices=list(PIPELINES) + ["k32"], help="flag set reported as `value`")
     ap.add_argument("--only", action="store_true", help="time only --pipeline (profiling runs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="mappings in the 1-thread CPU sample (0 = no CPU legs)")

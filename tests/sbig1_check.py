@@ -24,11 +24,7 @@ def main(cases):
         cols, _ = bench.gen_shard(torch, n, 2, 1234, device, chr_len=chr_len, single_pair=True)
         torch.cuda.synchronize()   # the library runs on its own stream: the generator's kernels must have finished
         run = bench.Runner(torch, sw, _lib, ctx, device, None, cols, n, 2)
-        if pipeline == "k32":
-            cfg = sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToMany, mapping_max_per_query=3, mapping_max_per_target=2,
-                                  scaffold_gap=0)
-        else:
-            cfg = bench.make_config(sw, pipeline)
+        cfg = bench.make_config(sw, pipeline)
         run.step(cfg.to_c(), with_stats=True)
         ctx.synchronize()
         st, ch = run.status[:n].cpu().numpy(), run.chain[:n].cpu().numpy()
