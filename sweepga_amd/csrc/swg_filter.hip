@@ -292,14 +292,10 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
     size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? 72 : 400) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
                   (rec64 ? (size_t)rec->n_seq * 8 : 0);
     if (cfg->scaffold_gap != 0) {
-      // the scaffold stage keeps two dense genome-pair tables (first appearance of a pair under either prefix rule);
-      // with names without '#' every sequence is its own genome and the tables outgrow the per-record estimate
-      const uint64_t gl = rec->n_genome_last, g2 = rec->n_genome_two;
-      if (gl > (1u << 14) || g2 > (1u << 14))
-        return swg_set_error(ctx, SWG_ERR_UNSUPPORTED,
-                             "%llu / %llu genomes under the two prefix rules: more than 2^14 genomes is not supported "
-                             "(dense genome-pair tables)", (unsigned long long)gl, (unsigned long long)g2);
-      want += (size_t)(gl * gl + g2 * g2) * sizeof(uint32_t);
+      // the scaffold stage keeps two genome-pair tables (first appearance of a pair under either prefix rule): dense
+      // G x G up to 2^14 genomes, else hashed over the pairs that occur (names without '#': every sequence its own genome)
+      for (const uint64_t g : {(uint64_t)rec->n_genome_last, (uint64_t)rec->n_genome_two})
+        want += g * g <= (uint64_t(1) << 28) ? (size_t)(g * g) * sizeof(uint32_t) : (size_t)rec->n * 4 * 12;
     }
     if (ctx->arena_cap < want) {
       size_t free_b = 0, total_b = 0;

@@ -1199,6 +1199,39 @@ __global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, cons
     if (lane == 0) group_first[g] = v;
   }
 }
+// genome pair (gq, gt) -> u32, "first appearance" tables of the two prefix rules.  Up to 2^14 genomes: a dense G x G array
+// (one load per lookup).  Beyond (names without '#': every contig its own genome): open addressing over the pairs that
+// actually occur -- their number is bounded by the (query, target) groups the caller has already counted.
+struct PairTable {
+  uint32_t* dense;      // [G * G] or nullptr
+  unsigned long long* keys;  // sparse: [mask + 1], ~0 = empty
+  uint32_t* vals;       // sparse: [mask + 1]
+  uint32_t mask;
+  uint32_t n_genome;
+};
+__device__ __forceinline__ uint32_t* pair_slot(const PairTable& t, uint32_t gq, uint32_t gt) {  // inserts when absent
+  if (t.dense) return t.dense + ((size_t)gq * t.n_genome + gt);
+  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
+  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
+  for (;;) {
+    unsigned long long k = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == ~0ull) {
+      k = atomicCAS(&t.keys[h], ~0ull, key);
+      if (k == ~0ull) k = key;
+    }
+    if (k == key) return t.vals + h;
+    h = (h + 1) & t.mask;
+  }
+}
+__device__ __forceinline__ uint32_t pair_get(const PairTable& t, uint32_t gq, uint32_t gt) {  // the pair is present
+  if (t.dense) return t.dense[(size_t)gq * t.n_genome + gt];
+  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
+  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
+  while (t.keys[h] != key) h = (h + 1) & t.mask;
+  return t.vals[h];
+}
+constexpr uint64_t DENSE_PAIR_LIMIT = uint64_t(1) << 28;  // G * G entries
+
 // First (lowest) original index of every genome pair over the alive records, in ORIGINAL order (coalesced
 // reads).  Two filters keep the atomics rare: (1) a wavefront whose 256 records all belong to one pair (inputs
 // grouped by pair) reduces to one atomic; (2) otherwise (interleaved pairs) a plain cached read of the table --
@@ -1207,21 +1240,22 @@ __global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const
                                                                const uint32_t* __restrict__ q_id,
                                                                const uint32_t* __restrict__ t_id,
                                                                const uint32_t* __restrict__ seq_genome,
-                                                               uint32_t n_genome, uint32_t* table) {
+                                                               PairTable table) {
   constexpr int U = 4;
   const int lane = threadIdx.x & 63;
   const uint64_t stride = (uint64_t)gridDim.x * EW * U;
   // whole waves stay in the loop together (the bound is wave-uniform), so the cross-lane ops are safe
   for (uint64_t w0 = ((uint64_t)blockIdx.x * EW + (threadIdx.x & ~63)) * U; w0 < n; w0 += stride) {
     const uint64_t i0 = w0 + (uint64_t)lane * U;
-    uint32_t L[U];
+    unsigned long long L[U];  // (gq << 32) | gt
     bool live[U];
-    uint32_t first_i = 0xffffffffu, first_L = 0;
+    uint32_t first_i = 0xffffffffu;
+    unsigned long long first_L = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t i = i0 + u;
       live[u] = i < n && alive[i] != 0;
-      L[u] = live[u] ? seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]] : 0u;
+      L[u] = live[u] ? ((unsigned long long)seq_genome[q_id[i]] << 32) | seq_genome[t_id[i]] : 0ull;
       if (live[u] && first_i == 0xffffffffu) {
         first_i = (uint32_t)i;
         first_L = L[u];
@@ -1236,16 +1270,22 @@ __global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const
     }
     if (vmin == 0xffffffffu) continue;  // no live record in this wave's span
     const uint64_t holder = __ballot(first_i == vmin);
-    const uint32_t L0 = __shfl(first_L, __builtin_ctzll(holder), 64);
+    const unsigned long long L0 = __shfl(first_L, __builtin_ctzll(holder), 64);
     bool same = true;
 #pragma unroll
     for (int u = 0; u < U; ++u) same = same && (!live[u] || L[u] == L0);
     if (__all(same)) {
-      if (lane == 0 && table[L0] > vmin) atomicMin(&table[L0], vmin);
+      if (lane == 0) {
+        uint32_t* slot = pair_slot(table, (uint32_t)(L0 >> 32), (uint32_t)L0);
+        if (*slot > vmin) atomicMin(slot, vmin);
+      }
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (live[u] && table[L[u]] > (uint32_t)(i0 + u)) atomicMin(&table[L[u]], (uint32_t)(i0 + u));
+        if (live[u]) {
+          uint32_t* slot = pair_slot(table, (uint32_t)(L[u] >> 32), (uint32_t)L[u]);
+          if (*slot > (uint32_t)(i0 + u)) atomicMin(slot, (uint32_t)(i0 + u));
+        }
     }
   }
 }
@@ -1259,8 +1299,8 @@ __global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const
                                                         const uint32_t* __restrict__ group_first,
                                                         const uint32_t* __restrict__ q_id,
                                                         const uint32_t* __restrict__ t_id,
-                                                        const uint32_t* __restrict__ seq_genome, uint32_t n_genome,
-                                                        const uint32_t* __restrict__ gp_first, int idx_bits,
+                                                        const uint32_t* __restrict__ seq_genome, bool pair_major,
+                                                        PairTable gp_first, int idx_bits,
                                                         uint64_t* __restrict__ g_key, uint32_t* __restrict__ g_val,
                                                         uint32_t* __restrict__ g_first_chain,
                                                         uint32_t* __restrict__ g_nchains) {
@@ -1273,11 +1313,11 @@ __global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const
   g_first_chain[g] = first;
   g_nchains[g] = next - first;
   const uint32_t i = s_idx[b];
-  // gp_first == nullptr: groups in plain first-appearance order of the records as given
+  // !pair_major: groups in plain first-appearance order of the records as given
   // (merge_mappings_into_chains called on its own); otherwise genome-pair-major, which is the order
   // apply_plane_sweep_to_mappings leaves the metadata in (paf_filter.rs:1037-1046, 1117-1120).
   uint64_t hi = 0;
-  if (gp_first) hi = gp_first[seq_genome[q_id[i]] * n_genome + seq_genome[t_id[i]]];
+  if (pair_major) hi = pair_get(gp_first, seq_genome[q_id[i]], seq_genome[t_id[i]]);
   g_key[g] = (hi << idx_bits) | group_first[g];
   g_val[g] = g;
 }
@@ -1378,10 +1418,10 @@ __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const
                                                               const uint32_t* __restrict__ run_flag,
                                                               const uint32_t* __restrict__ C_qid,
                                                               const uint32_t* __restrict__ C_tid,
-                                                              const uint32_t* __restrict__ seq_genome2, uint32_t n_g2,
+                                                              const uint32_t* __restrict__ seq_genome2,
                                                               uint32_t* __restrict__ run_of_chain,
                                                               uint32_t* __restrict__ pair_first,
-                                                              uint32_t* __restrict__ gp2_first) {
+                                                              PairTable gp2_first) {
   uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (s >= nc) return;
   const uint32_t c = sorted_c[s];
@@ -1389,21 +1429,21 @@ __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const
   run_of_chain[c] = run;
   if (run_flag[s]) {
     pair_first[run] = c;
-    atomicMin(&gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]], c);
+    atomicMin(pair_slot(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]), c);
   }
 }
 __global__ __launch_bounds__(EW) void number_keys_kernel(uint64_t nk, const uint32_t* __restrict__ kept_list,
                                                          const uint32_t* __restrict__ run_of_chain,
                                                          const uint32_t* __restrict__ pair_first,
-                                                         const uint32_t* __restrict__ gp2_first,
+                                                         PairTable gp2_first,
                                                          const uint32_t* __restrict__ C_qid,
                                                          const uint32_t* __restrict__ C_tid,
-                                                         const uint32_t* __restrict__ seq_genome2, uint32_t n_g2,
+                                                         const uint32_t* __restrict__ seq_genome2,
                                                          int c_bits, uint64_t* __restrict__ key) {
   uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (j >= nk) return;
   const uint32_t c = kept_list[j];
-  const uint32_t g2 = gp2_first[seq_genome2[C_qid[c]] * n_g2 + seq_genome2[C_tid[c]]];
+  const uint32_t g2 = pair_get(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]);
   key[j] = ((uint64_t)g2 << c_bits) | pair_first[run_of_chain[c]];
 }
 __global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const uint32_t* __restrict__ sorted_kept,
@@ -1449,6 +1489,36 @@ struct ChainTable {
   uint8_t* ok = nullptr;  // passes span/identity filter (input of the scaffold sweep)
 };
 
+// Allocates (arena) and clears a PairTable for G genomes of which at most `bound` pairs occur.
+int pair_table_make(swg_ctx* ctx, uint32_t n_genome, uint64_t bound, PairTable* t) {
+  hipStream_t st = ctx->stream;
+  t->n_genome = n_genome;
+  t->dense = nullptr;
+  t->keys = nullptr;
+  t->vals = nullptr;
+  t->mask = 0;
+  const uint64_t g2 = (uint64_t)n_genome * n_genome;
+  if (g2 <= DENSE_PAIR_LIMIT) {
+    t->dense = swg_alloc<uint32_t>(ctx, g2);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(g2), EW, 0, st>>>(g2, t->dense, NONE));
+    SWG_KERNEL_CHECK(ctx);
+    return SWG_OK;
+  }
+  uint64_t cap = 1024;
+  while (cap < 2 * bound) cap <<= 1;
+  if (cap > (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "genome-pair table beyond 2^32 slots");
+  t->keys = swg_alloc<unsigned long long>(ctx, cap);
+  t->vals = swg_alloc<uint32_t>(ctx, cap);
+  SWG_CHECK_ARENA(ctx);
+  t->mask = (uint32_t)(cap - 1);
+  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(cap), EW, 0, st>>>(cap, reinterpret_cast<uint64_t*>(t->keys), ~0ull));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(cap), EW, 0, st>>>(cap, t->vals, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
 // plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
 // reference's all_chains order (their index is the plane sweep's tie-break `idx`).
 // Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).
@@ -1458,8 +1528,6 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   hipStream_t st = ctx->stream;
   *n_kept_out = 0;
   if (T.nc == 0) return SWG_OK;
-  if ((uint64_t)n_g2 * n_g2 > (uint64_t(1) << 28))
-    return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "more than 2^14 genomes (first-two-'#' prefix) is not supported");
   uint64_t kq, kt;
   if (mode == SWG_MODE_ONE_TO_ONE) {
     kq = 1;
@@ -1524,8 +1592,9 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   uint32_t* run_excl = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* gp2_first = swg_alloc<uint32_t>(ctx, (size_t)n_g2 * n_g2);
   SWG_CHECK_ARENA(ctx);
+  PairTable gp2_first;
+  SWG_TRY(pair_table_make(ctx, n_g2, nc, &gp2_first));  // pairs that occur <= chromosome-pair runs <= chains
   SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
   SWG_KERNEL_CHECK(ctx);
@@ -1533,10 +1602,8 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk((uint64_t)n_g2 * n_g2), EW, 0, st>>>((uint64_t)n_g2 * n_g2, gp2_first, NONE));
-  SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, run_excl, run_flag, qid, tid, seq_genome2,
-                                                                           n_g2, run_of_chain, pair_first, gp2_first));
+                                                                           run_of_chain, pair_first, gp2_first));
   SWG_KERNEL_CHECK(ctx);
   // kept chains, in index order
   swg_flag_scan kept_scan;
@@ -1554,7 +1621,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
     SWG_TRY(swg_flags_compact(ctx, kept_scan, kept_list));
     const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
     SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
-                                                                    seq_genome2, n_g2, c_bits, nkey));
+                                                                    seq_genome2, c_bits, nkey));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
     SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
@@ -1592,8 +1659,6 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   ChainBuild& B = *out;
-  if ((uint64_t)r->n_genome_last * r->n_genome_last > (uint64_t(1) << 28))
-    return swg_set_error(ctx, SWG_ERR_UNSUPPORTED, "more than 2^14 genomes (last-'#' prefix) is not supported");
   const int pair_bits = swg_bits_for((uint64_t)r->n_seq * r->n_seq * 2);
   if (pair_bits + pos_bits > 64)
     return swg_set_error(ctx, SWG_ERR_RANGE, "chain sort key (%d pair bits + %d coordinate bits) exceeds 64 bits",
@@ -1678,8 +1743,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
   uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
   uint32_t* group_first = swg_alloc<uint32_t>(ctx, m);
-  const uint64_t n_gp = (uint64_t)r->n_genome_last * r->n_genome_last;
-  uint32_t* gp_first = swg_alloc<uint32_t>(ctx, n_gp);
+  PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
@@ -1897,8 +1961,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   // ---- all_chains order
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, group_first, NONE));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_gp), EW, 0, st>>>(n_gp, gp_first, NONE));
-  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(pair_table_make(ctx, r->n_genome_last, B.n_pairs, &gp_first));
   if (m / n_groups > 8192) {
     swg_arena_mark mk = swg_arena_save(ctx);
     uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
@@ -1917,7 +1980,7 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   }
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
-                                                                                    r->seq_genome_last, r->n_genome_last, gp_first));
+                                                                                    r->seq_genome_last, gp_first));
   SWG_KERNEL_CHECK(ctx);
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
@@ -1947,8 +2010,8 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   const unsigned gblk = nblk(n_groups);
   SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, cpos, (uint32_t)nc,
                                                            B.s_idx, group_first, r->q_id, r->t_id, r->seq_genome_last,
-                                                           r->n_genome_last, genome_pair_major ? gp_first : nullptr,
-                                                           idx_bits, g_key, g_sorted, g_first_chain, g_nchains));
+                                                           genome_pair_major, gp_first, idx_bits, g_key, g_sorted, g_first_chain,
+                                                           g_nchains));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_radix_sort_pairs(ctx, &g_key, &g_sorted, &g_key_tmp, &g_sorted_tmp, n_groups, 0, 2 * idx_bits));
   SWG_LAUNCH(ctx, "group_sizes_sorted", group_sizes_sorted_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_nchains, g_sizes));
