@@ -43,7 +43,8 @@ BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8
 PIPELINES = ("default", "sweep", "full")
 FLAGS = {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
          "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
-         "default": "(defaults)"}
+         "default": "(defaults)",
+         "k32": "--num-mappings 3:2 --scaffold-jump 0"}
 REC_COLS = ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand")
 SBIG1_LEN = 248_956_422
 

@@ -302,9 +302,13 @@ __device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
 // The KC best of the wavefront are drawn by one butterfly merge of the lanes' lists (wave_top_kc).  32-bit arithmetic
 // (coordinates are u32; a gap limit beyond 2^32 cannot bind, so it is clamped).  The lists are identical to
 // chain_candidates_kernel's.
-// (Stopping the scan once the query gap alone reaches the KC-th best distance -- exact, since j runs in q_start order -- was
-// measured and does not pay here: a 64-element batch costs ~300 cycles with its loads in flight, the merge that yields the
-// KC-th best ~2,000, and a thread per i gains nothing because window lengths are heavy-tailed; profiles/README.md.)
+// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once KC candidates are held
+// whose distance is at most gap^2 of the next unseen element no later j can enter the list (d >= gap^2; equal distances keep
+// the smaller j).  The test needs no merge of the lanes' lists -- "how many held entries are <= T" is four compares per
+// lane and four ballots -- so it runs after every batch (an earlier attempt derived the KC-th best itself per batch, which
+// cost more than the batches it saved; profiles/README.md).  After a cut the exact number of valid j is unknown: the count
+// is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the selection re-evaluate
+// a window that has nothing left to offer (same result); the window extent then comes from a galloping search.
 constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
   const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap and grows with the query gap
   for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
     const uint32_t g = s_gidx[p];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       bd[k] = ~0ull;
       bj[k] = NONE;
     }
-    uint32_t count = 0, ext = 0;
+    uint32_t count = 0, ext = 0, cut_at = 0;
+    bool cut = false;
     for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
       const uint32_t j = j0 + lane;
       const bool in = j < e;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       const uint64_t wmask = __ballot(inwin);
       ext += (uint32_t)__popcll(wmask);
       if (inwin) {
-        // d(i, j) of paf_filter.rs:798-836
+        // d(i, j) of paf_filter.rs:798-836 (this block is the wave kernel's)
         uint32_t q_gap, r_gap;
         bool ok = true;
         if (qs_j >= qe_i) {
@@ -390,10 +396,51 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         }
       }
       if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
+      if (can_cut && j0 + 64 < e) {
+        // every later element starts at or after this batch's last one: its query gap is at least `qg`
+        const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
+        if (q_last >= qe_i) {
+          const uint64_t qg = (uint64_t)q_last - qe_i;
+          const uint64_t T = qg * qg;
+          const int c = (bd[0] <= T) + (bd[1] <= T) + (bd[2] <= T) + (bd[3] <= T);  // the lists are ascending
+          const int held = __popcll(__ballot(c >= 1)) + __popcll(__ballot(c >= 2)) + __popcll(__ballot(c >= 3)) +
+                           __popcll(__ballot(c >= 4));
+          if (held >= KC) {
+            cut = true;
+            cut_at = j0 + 64;
+            break;
+          }
+        }
+      }
+    }
+    if (cut) {
+      // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
+      // a time (one probe per lane), then resolve inside the 64-element block that holds the boundary.
+      uint32_t lo = cut_at - 1;  // last element known to be inside the window
+      bool found = false;
+      while (!found) {
+        const uint64_t pj = (uint64_t)lo + 1 + (uint64_t)lane * 64;  // first element of the lane's block
+        const bool inside = pj < e && s_qs[pj] <= bound;
+        const uint64_t m_in = __ballot(inside);
+        if (m_in == ~0ull) {  // all 64 block starts are inside: the boundary is further on
+          lo += 1 + 63 * 64;  // the last block start probed (inside)
+          if (lo + 1 >= e) found = true;
+          continue;
+        }
+        const int nb_in = __popcll(m_in);  // blocks whose first element is inside (a prefix: sorted)
+        if (nb_in == 0) break;             // the very next element is already outside
+        const uint64_t blk = (uint64_t)lo + 1 + (uint64_t)(nb_in - 1) * 64;  // the boundary lies in [blk, blk + 64)
+        const uint64_t ej = blk + lane;
+        const bool in2 = ej < e && s_qs[ej] <= bound;
+        lo = (uint32_t)(blk + __popcll(__ballot(in2)) - 1);
+        found = true;
+      }
+      ext = lo - (uint32_t)p;
     }
     // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
+    if (cut) ++count;  // "there may be more"
     wave_top_kc(bd, bj);
     if (lane == 0) {
 #pragma unroll

@@ -70,7 +70,9 @@ class Hip:
     """hipMalloc / hipMemcpy / hipFree of the runtime libsweepga_gpu.so itself is linked against."""
 
     def __init__(self):
-        self.lib = C.CDLL("libamdhip64.so")
+        from sweepga_amd import _lib
+        self.lib = _lib.load()   # dlsym on the library's handle reaches its dependencies: the very runtime it runs on
+        self.lib.hipMalloc.restype = self.lib.hipMemcpy.restype = self.lib.hipFree.restype = C.c_int
         self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.lib.hipFree.argtypes = [C.c_void_p]
