@@ -245,9 +245,6 @@ void swg_destroy(swg_ctx* ctx) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {ctx->ev_fork, ctx->ev_mid, ctx->ev_join})
-    if (e) (void)hipEventDestroy(e);
-  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -163,60 +163,16 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   ax.packed_end = 0;
   ax.sorted_idx_out = q_order;
   ax.sorted_idx_valid = q_order ? q_order_valid : nullptr;
-  swg_axis_input at = ax;
-  at.sorted_idx_out = nullptr;
-  at.sorted_idx_valid = nullptr;
-  at.seg_a = r->t_id;
-  at.seg_b = r->q_id;
-  at.start = r->t_start;
-  at.end = r->t_end;
-  at.packed_end = 1;
-  at.and_with = keep_q;  // intersection of the two axes, src/paf_filter.rs:1105-1111
-  // Both limits finite: the target axis' sort (bandwidth-bound) runs on a second stream beside the query axis' tile
-  // kernel (latency-bound).  The two meet again at the target axis' combine, which reads the query axis' result.
-  static const bool overlap = getenv("SWG_AXIS_OVERLAP") != nullptr;
-  if (!overlap || kq == SWG_K_INF || kt == SWG_K_INF) {
-    SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
-    SWG_TRY(swg_sweep_axis(ctx, at, kt, cfg->overlap_threshold, keep));
-  } else {
-    if (!ctx->stream2) {
-      SWG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-      SWG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      SWG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
-      SWG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    hipStream_t sa = ctx->stream, sb = ctx->stream2;
-    swg_axis_run rq, rt;
-    int rc = SWG_OK;
-    ++ctx->arena_hold;  // scratch released by one axis' helpers may still be read by the other stream's kernels
-    auto body = [&]() -> int {
-      static const bool ungated = getenv("SWG_AXIS_OVERLAP") && getenv("SWG_AXIS_OVERLAP")[0] == '2';  // trial: both sorts at once
-      if (ungated) SWG_HIP(ctx, hipEventRecord(ctx->ev_fork, sa));
-      SWG_TRY(swg_sweep_axis_begin(ctx, ax, kq, keep_q, &rq));           // query: sort .. carry counts, on `sa`
-      if (!ungated) SWG_HIP(ctx, hipEventRecord(ctx->ev_fork, sa));
-      SWG_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_fork, 0));
-      ctx->stream = sb;
-      SWG_TRY(swg_sweep_axis_begin(ctx, at, kt, keep, &rt));             // target: the same on `sb`, once the query's are done
-      ctx->stream = sa;
-      SWG_TRY(swg_sweep_axis_end(ctx, ax, kq, cfg->overlap_threshold, keep_q, &rq));  // query tiles || target sort
-      SWG_HIP(ctx, hipEventRecord(ctx->ev_mid, sa));
-      SWG_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_mid, 0));              // keep_q is complete before the target's combine
-      ctx->stream = sb;
-      SWG_TRY(swg_sweep_axis_end(ctx, at, kt, cfg->overlap_threshold, keep, &rt));
-      SWG_HIP(ctx, hipEventRecord(ctx->ev_join, sb));
-      ctx->stream = sa;
-      SWG_HIP(ctx, hipStreamWaitEvent(sa, ctx->ev_join, 0));
-      return SWG_OK;
-    };
-    rc = body();
-    ctx->stream = sa;
-    --ctx->arena_hold;
-    if (rc != SWG_OK) {
-      (void)hipStreamSynchronize(sb);  // nothing of the second stream may outlive the scratch
-      (void)hipStreamSynchronize(sa);
-      return rc;
-    }
-  }
+  SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
+  ax.sorted_idx_out = nullptr;
+  ax.sorted_idx_valid = nullptr;
+  ax.seg_a = r->t_id;
+  ax.seg_b = r->q_id;
+  ax.start = r->t_start;
+  ax.end = r->t_end;
+  ax.packed_end = 1;
+  ax.and_with = keep_q;  // intersection of the two axes, src/paf_filter.rs:1105-1111
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, cfg->overlap_threshold, keep));
   swg_arena_restore(ctx, mark);
   return SWG_OK;
 }

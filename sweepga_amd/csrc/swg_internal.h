@@ -13,11 +13,6 @@ struct swg_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // second stream for the stretch where the two axes of the mapping sweep run side by side (swg_mapping_sweep), with the
-  // events that fork it from / join it to `stream`; created on first use
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
-  int arena_hold = 0;      // > 0: swg_arena_restore keeps the scratch (kernels of another stream may still use it)
   // bump arena for per-call scratch; grown (never shrunk) between calls
   char* arena = nullptr;
   size_t arena_cap = 0;
@@ -103,9 +98,7 @@ struct swg_arena_mark {
   size_t off;
 };
 static inline swg_arena_mark swg_arena_save(swg_ctx* ctx) { return {ctx->arena_off}; }
-static inline void swg_arena_restore(swg_ctx* ctx, swg_arena_mark m) {
-  if (ctx->arena_hold == 0) ctx->arena_off = m.off;
-}
+static inline void swg_arena_restore(swg_ctx* ctx, swg_arena_mark m) { ctx->arena_off = m.off; }
 
 // Runs body(ctx) with a fresh arena; on overflow grows the arena and runs it once more.
 template <class F>
@@ -214,18 +207,6 @@ struct swg_axis_input {
   int* sorted_idx_valid = nullptr;       //   *valid = 1 when the begins were sorted (not for k = inf without zero lengths)
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
-// The same in two halves, so that a caller can put other work between them: `begin` enqueues everything up to the count of
-// the carry-ins (no host synchronisation), `end` reads that count back and enqueues the rest.
-struct swg_axis_run {
-  swg_arena_mark mark;
-  uint32_t ntiles = 0;
-  uint64_t *S = nullptr, *E = nullptr, *KEY = nullptr, *tile_x = nullptr, *d_total = nullptr;
-  uint32_t *I = nullptr, *te = nullptr, *carry_cnt = nullptr, *carry_cur = nullptr;
-  uint8_t *single = nullptr, *top = nullptr, *ovl = nullptr;
-  bool finished = false;  // nothing left for `end` (n = 0, k = inf)
-};
-int swg_sweep_axis_begin(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, uint8_t* keep, swg_axis_run* run);
-int swg_sweep_axis_end(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep, swg_axis_run* run);
 
 // score keys: key[i] = order-preserving transform of -score so that smaller key = better
 // (src/plane_sweep_exact.rs:29-86, 183-193); length is always q_end - q_start.

@@ -867,20 +867,12 @@ int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8
 }
 
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep) {
-  swg_axis_run run;
-  SWG_TRY(swg_sweep_axis_begin(ctx, in, k, keep, &run));
-  return swg_sweep_axis_end(ctx, in, k, thr, keep, &run);
-}
-
-int swg_sweep_axis_begin(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, uint8_t* keep, swg_axis_run* run) {
   const uint64_t n = in.n;
-  run->finished = true;
   if (in.sorted_idx_valid) *in.sorted_idx_valid = 0;
   if (n == 0) return SWG_OK;
   if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "sweep: n >= 2^31 intervals");
   hipStream_t st = ctx->stream;
   swg_arena_mark mark = swg_arena_save(ctx);
-  run->mark = mark;
   const int key_bits = in.seg_bits + in.pos_bits;  // seg_bits must cover (max segment id + 1)
   if (key_bits > 64)
     return swg_set_error(ctx, SWG_ERR_RANGE, "sweep: segment id (%d bits) + coordinate (%d bits) exceed 64 bits",
@@ -951,32 +943,6 @@ int swg_sweep_axis_begin(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, uin
   SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, tile_x, ntiles, te, carry_cnt));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)ntiles + 1, d_total));
-  run->ntiles = ntiles;
-  run->S = S;
-  run->E = E;
-  run->KEY = KEY;
-  run->tile_x = tile_x;
-  run->d_total = d_total;
-  run->I = I;
-  run->te = te;
-  run->carry_cnt = carry_cnt;
-  run->carry_cur = carry_cur;
-  run->single = single;
-  run->top = top;
-  run->ovl = ovl;
-  run->finished = false;
-  return SWG_OK;
-}
-
-int swg_sweep_axis_end(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep, swg_axis_run* run) {
-  if (run->finished) return SWG_OK;
-  const uint64_t n = in.n;
-  hipStream_t st = ctx->stream;
-  const uint32_t ntiles = run->ntiles;
-  uint64_t *S = run->S, *E = run->E, *KEY = run->KEY, *tile_x = run->tile_x, *d_total = run->d_total;
-  uint32_t *I = run->I, *te = run->te, *carry_cnt = run->carry_cnt, *carry_cur = run->carry_cur;
-  uint8_t *single = run->single, *top = run->top, *ovl = run->ovl;
-  const swg_arena_mark mark = run->mark;
   uint64_t n_carry = 0;
   SWG_TRY(swg_read_scalars(ctx, d_total, &n_carry, 1));
   uint64_t* c_s = swg_alloc<uint64_t>(ctx, n_carry + 1);
