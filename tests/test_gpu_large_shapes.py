@@ -97,13 +97,13 @@ def _many_genome_records(rng, n_seq, n_pairs, per_pair):
 
 @pytest.mark.parametrize("cfg_name", ["default", "full", "loose"])
 def test_more_than_2_14_genomes(cfg_name):
-    """20,000 contigs without '#' = 20,000 genomes: the genome-pair tables switch from dense G x G to open addressing over
+    """~20,000 contigs without '#' = 20,000 genomes: the genome-pair tables switch from dense G x G to open addressing over
     the pairs that occur (swg_scaffold.hip PairTable).  Status and chain numbers against the oracle."""
     import sweepga_amd as sw
     from tests import gen, orc
     from tests.test_gpu_scaffold import _cfg_pair
     rng = np.random.default_rng(2014)
-    rec = _many_genome_records(rng, 20_000, 3_000, 12)
+    rec = _many_genome_records(rng, 60_000, 12_000, 4)
     kw = {"default": dict(),
           "full": dict(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=50_000,
                        min_scaffold_length=10_000, scaffold_max_deviation=20_000),
