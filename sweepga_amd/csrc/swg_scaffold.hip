@@ -473,6 +473,11 @@ struct SpecBlock {
   uint32_t pad;
 };
 
+// best_pred_score[j] of an element beyond the 128 the wavefront keeps in registers; out of line for the same reason as
+// spec_view_far (an inlined load would make every step of the walk wait for the stores of the step before)
+__device__ __noinline__ uint64_t bps_far(const unsigned long long* bps, uint32_t j) {
+  return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, const uint32_t* __restrict__ unit_list,
                                                            uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                            uint32_t m, const uint64_t* __restrict__ s_grp,
@@ -527,14 +532,28 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
       const uint32_t lj = j - base;
       if (lj < 64) return readlane_u64(A.bps, (int)lj);
       if (lj < 128) return readlane_u64(B.bps, (int)(lj - 64));
-      return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return bps_far(bps, j);
     };
-    for (uint32_t i = b; i + 1 < e; ++i) {
-      if (i - base == 64) {
+    // steps in groups of 64; the two register blocks are loaded and touched before the inner loop, so that no step waits
+    // for vector memory (see spec_round_kernel)
+    for (uint32_t i0 = b; i0 + 1 < e; i0 += 64) {
+      if (i0 != b) {
         A = B;
         base += 64;
         B = load_block(base + 64);
       }
+      {
+        uint64_t t64 = A.bps ^ B.bps;
+        uint32_t t32 = A.n ^ B.n;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          t64 ^= A.d[c] ^ B.d[c];
+          t32 ^= A.j[c] ^ B.j[c];
+        }
+        asm volatile("" ::"v"(t64), "v"(t32));
+      }
+      const uint32_t i_end = i0 + 64;
+      for (uint32_t i = i0; i < i_end && i + 1 < e; ++i) {
       const int li = (int)(i - base);
       const uint32_t nvalid = readlane_u32(A.n, li);
       if (nvalid == 0) continue;
@@ -615,6 +634,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
       }
       if (lane == 0) pred[best_j] = i;
+      }
     }
   }
 }
@@ -855,6 +875,19 @@ __global__ __launch_bounds__(EW) void spec_final_kernel(uint32_t n_blocks, const
   }
 }
 
+// A position outside the LDS ring, read from the block's view in global memory.  Kept out of line on purpose: inlined, its
+// load shares a destination register with the ring's LDS read, and the hazard bookkeeping then makes every step of the walk
+// wait for all outstanding vector-memory operations -- i.e. for the write-through stores of the step before.
+__device__ __noinline__ uint64_t spec_view_far(const unsigned long long* own, const unsigned long long* prev, uint32_t be,
+                                               uint32_t p) {
+  return __hip_atomic_load(p < be ? &own[p] : &prev[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifdef SWG_SPEC_STATS
+__device__ unsigned long long g_spec_stats[8];
+#define SPEC_STAT(k, v) do { if (lane == 0) atomicAdd(&g_spec_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define SPEC_STAT(k, v) do { } while (0)
+#endif
 template <int BIGW>
 __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
                                                         const uint64_t* __restrict__ s_grp,
@@ -916,10 +949,15 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
     load_cands(base);
     auto current = [&](uint32_t j) -> uint64_t {
       if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
-      return view_load(j);
+      return spec_view_far(own, prev, be, j);
     };
-    for (uint32_t i = b; i < be && i + 1 < e; ++i) {
-      if (i - base == 64) {
+    // The walk is one dependent chain per wavefront, so what a step waits for is what the block costs.  Steps run in groups
+    // of 64 (one candidate list per lane); the lists are loaded and TOUCHED before the inner loop, so that the wait for those
+    // loads sits in front of it: inside, the only outstanding vector-memory operations are the write-through stores of
+    // earlier steps, which no instruction of a step depends on (a wait for the lists placed inside the loop would also
+    // drain those stores -- a memory round trip per step, 3/4 of the kernel's time on one deep chromosome pair).
+    for (uint32_t i0 = b; i0 < be && i0 + 1 < e; i0 += 64) {
+      if (i0 != b) {
         const uint32_t pn = base + BIGW + lane;
         __syncthreads();
         {
@@ -933,9 +971,17 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
         load_cands(base);
         __syncthreads();
       }
+      {
+        uint64_t touch = cd[0] ^ cd[1] ^ cd[2] ^ cd[3];
+        uint32_t touch32 = cj[0] ^ cj[1] ^ cj[2] ^ cj[3] ^ cn;
+        asm volatile("" ::"v"(touch), "v"(touch32));
+      }
+      const uint32_t i_end = (i0 + 64 < be ? i0 + 64 : be);
+      for (uint32_t i = i0; i < i_end && i + 1 < e; ++i) {
       const int li = (int)(i - base);
       const uint32_t nvalid = readlane_u32(cn, li);
       if (nvalid == 0) continue;
+      SPEC_STAT(0, 1);
       uint64_t best_d = INF;
       uint32_t best_j = NONE;
 #pragma unroll
@@ -950,12 +996,14 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
         }
       }
       if (best_j == NONE && nvalid > (uint32_t)KC) {
+        SPEC_STAT(1, 1);
         // every listed candidate is blocked and the window held more: evaluate it in full
         const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
         const uint64_t bound = qe_i + max_gap;
         uint64_t ld = INF;
         uint32_t lj2 = NONE;
         for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
+          SPEC_STAT(2, 1);
           if (can_cut) {  // see chain_select_kernel
             const uint64_t wmin = wave_min_u64(ld);
             const uint64_t q0 = (j0 - base) < (uint32_t)BIGW ? (uint64_t)rq[j0 % BIGW] : (uint64_t)s_qs[j0];
@@ -1003,6 +1051,7 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
         (best_j < be ? pred_own : pred_prev)[best_j] = i;
       }
       if (!in_ring) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before a later global read of it
+      }
     }
   }
 }
@@ -1951,8 +2000,16 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
           if ((uint32_t)ch == 0) break;
         }
         if (getenv("SWG_DEBUG"))
-          fprintf(stderr, "[swg] long units: %llu, blocks %llu, rounds %d\n", (unsigned long long)n_big,
-                  (unsigned long long)n_spec, rounds);
+          fprintf(stderr, "[swg] long units: %llu, blocks %llu (longest %llu), rounds %d\n", (unsigned long long)n_big,
+                  (unsigned long long)n_spec, (unsigned long long)s_max, rounds);
+#ifdef SWG_SPEC_STATS
+        {
+          unsigned long long hs[8];
+          (void)hipStreamSynchronize(st);
+          (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_spec_stats), sizeof hs);
+          fprintf(stderr, "[swg] spec stats (cumulative): steps %llu, fallbacks %llu, fallback batches %llu\n", hs[0], hs[1], hs[2]);
+        }
+#endif
         SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
       }
