@@ -269,6 +269,7 @@ struct TileArgs {
   double thr;
   uint8_t* top;
   uint8_t* ovl;
+  uint8_t* tile_done;  // [ntiles] 2 <= k < inf: written by the pruned kernel (1 = tile finished there), read by the plain one
 };
 
 __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64_t bs, uint64_t be, double thr) {
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kn_kernel(TileArgs a) {
   __shared__ uint64_t wmax[TB / 64];
 
   const uint32_t tile_id = blockIdx.x;
+  if (a.tile_done && a.tile_done[tile_id]) return;  // block-uniform: sweep_tile_kp_kernel has done this tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t p0 = (uint64_t)tile_id * TB;
   const uint64_t p = p0 + tid;
@@ -772,6 +774,320 @@ __global__ __launch_bounds__(TB) void sweep_tile_kn_kernel(TileArgs a) {
             all_active([&](uint64_t s, uint64_t e, uint64_t key, uint32_t id) {
               if (prio_less(tk, ts, ti, key, s, id) && overlap_exceeds(s, e, ms, me, a.thr)) a.ovl[id] = 1;
             });
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- 2 <= k <= KSTAR_MAX on deep data: the k = 1 kernel's pruning carried over ---------------------------------------
+// T(x) is the set of the k best active intervals ("members").  With S*_1..S*_k the k best carry-ins that are active over the
+// whole range of the tile, nothing ranked below S*_k is ever a member inside the tile, so only "candidates" (ranked above
+// S*_k) take part in finding T(x), and only THEIR end points are evaluated -- and those only when the ending interval was a
+// member just before x (fewer than k stars / candidates active there rank above it).  Non-members are flagged when they
+// overlap a member too much; a (non-member, member) pair first meets either where the member enters T (it begins at x, or a
+// member ended at x: every active interval is tested against every member there, as at the tile's first coordinate) or
+// where the non-member begins (only the begins at x are tested).  With fewer than k spanning carry-ins (sparse data) there is
+// no threshold: every interval is a candidate, and what remains is the saving on the end points and on the overlap passes.
+// Tiles with more candidates than the LDS list holds, and k > KSTAR_MAX, are left to sweep_tile_kn_kernel.
+constexpr int KSTAR_MAX = 8;
+constexpr int KP_CAP = CCAP;  // candidate carry-ins kept in LDS (256 was measured: slower, and the tiles that overflow have no threshold at all)
+__global__ __launch_bounds__(TB) void sweep_tile_kp_kernel(TileArgs a) {
+  __shared__ uint64_t sx[TB];
+  __shared__ uint64_t se2[2 * TB];   // [0, TB): ends; [TB, 2 TB): ends of the candidates, 0 for the others
+  __shared__ uint64_t spm2[2 * TB];  // prefix maxima of the two halves
+  __shared__ uint64_t skey[TB];
+  __shared__ uint32_t sid[TB];
+  __shared__ uint64_t wmax[TB / 64];
+  __shared__ uint64_t ls[KP_CAP], le[KP_CAP], lkey[KP_CAP];  // candidate carry-ins
+  __shared__ uint32_t lid[KP_CAP];
+  __shared__ uint32_t l_count;
+  __shared__ uint64_t r_k[TB / 64], r_s[TB / 64], r_e[TB / 64];
+  __shared__ uint32_t r_i[TB / 64], r_have[TB / 64];
+  __shared__ uint64_t st_k[KSTAR_MAX], st_s[KSTAR_MAX], st_e[KSTAR_MAX];  // the stars, best first
+  __shared__ uint32_t st_i[KSTAR_MAX];
+
+  const uint32_t tile_id = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
+  const uint32_t n_carry = c_end - c_begin;
+  const int K = (int)a.k;
+  if (a.k > (uint64_t)KSTAR_MAX) {  // block-uniform
+    if (tid == 0) a.tile_done[tile_id] = 0;
+    return;
+  }
+  const uint64_t p = (uint64_t)tile_id * TB + tid;
+  const bool valid = p < a.n;
+  uint64_t X = ~0ull, EE = 0, KEY = 0;
+  uint32_t ID = 0;
+  if (valid) {
+    X = a.S[p];
+    EE = a.E[p];
+    KEY = a.KEY[p];
+    ID = a.I[p];
+  }
+  sx[tid] = X;
+  se2[tid] = EE;
+  skey[tid] = KEY;
+  sid[tid] = ID;
+  if (tid == 0) l_count = 0;
+  auto block_prefix_max = [&](uint64_t v, uint64_t* dst) {  // dst[tid] = max(v of threads 0..tid); two barriers
+    uint64_t m = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t t = __shfl_up(m, d, 64);
+      if (lane >= d && t > m) m = t;
+    }
+    if (lane == 63) wmax[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (w < wave && wmax[w] > m) m = wmax[w];
+    dst[tid] = m;
+    __syncthreads();
+  };
+  block_prefix_max(EE, spm2);
+  const uint64_t x_b = sx[0];
+  const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
+
+  // ---- the stars: K rounds of a block-wide arg-min over the spanning carry-ins ranked after the previous star
+  int n_star = 0;
+  uint64_t pk = 0, ps = 0;
+  uint32_t pi = 0;
+  for (int r = 0; r < K; ++r) {
+    bool hv = false;
+    uint64_t bk = 0, bs = 0, be = 0;
+    uint32_t bi = 0;
+    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+      const uint64_t e = a.c_e[c];
+      if (e >= x_next) {
+        const uint64_t k = a.c_key[c], s_ = a.c_s[c];
+        const uint32_t id = a.c_id[c];
+        if (r > 0 && !prio_less(pk, ps, pi, k, s_, id)) continue;  // not after the previous star
+        if (!hv || prio_less(k, s_, id, bk, bs, bi)) {
+          bk = k;
+          bs = s_;
+          be = e;
+          bi = id;
+          hv = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ok = __shfl_down(bk, o, 64), os = __shfl_down(bs, o, 64), oe = __shfl_down(be, o, 64);
+      const uint32_t oi = __shfl_down(bi, o, 64);
+      const bool oh = __shfl_down((int)hv, o, 64) != 0;
+      if (oh && (!hv || prio_less(ok, os, oi, bk, bs, bi))) {
+        bk = ok;
+        bs = os;
+        be = oe;
+        bi = oi;
+        hv = true;
+      }
+    }
+    if (lane == 0) {
+      r_k[wave] = bk;
+      r_s[wave] = bs;
+      r_e[wave] = be;
+      r_i[wave] = bi;
+      r_have[wave] = hv ? 1u : 0u;
+    }
+    __syncthreads();
+    bool got = false;
+    uint64_t gk = 0, gs = 0, ge = 0;
+    uint32_t gi = 0;
+#pragma unroll
+    for (int w = 0; w < TB / 64; ++w)
+      if (r_have[w] && (!got || prio_less(r_k[w], r_s[w], r_i[w], gk, gs, gi))) {
+        gk = r_k[w];
+        gs = r_s[w];
+        ge = r_e[w];
+        gi = r_i[w];
+        got = true;
+      }
+    __syncthreads();  // r_* are rewritten by the next round
+    if (!got) break;  // block-uniform
+    if (tid == 0) {
+      st_k[r] = gk;
+      st_s[r] = gs;
+      st_e[r] = ge;
+      st_i[r] = gi;
+    }
+    pk = gk;
+    ps = gs;
+    pi = gi;
+    ++n_star;
+  }
+  // fewer than k carry-ins span the tile (the usual case on sparse data): no threshold, every interval is a candidate and
+  // the stars are simply the spanning carry-ins; else (pk, ps, pi) is S*_k
+  const bool have_thr = n_star == K;
+  // ---- candidate carry-ins: end inside the tile's range and ranked above S*_k
+  for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+    const uint64_t e = a.c_e[c];
+    if (e < x_next) {
+      const uint64_t k = a.c_key[c], s_ = a.c_s[c];
+      const uint32_t id = a.c_id[c];
+      if (!have_thr || prio_less(k, s_, id, pk, ps, pi)) {
+        const uint32_t slot = atomicAdd(&l_count, 1u);
+        if (slot < (uint32_t)KP_CAP) {
+          ls[slot] = s_;
+          le[slot] = e;
+          lkey[slot] = k;
+          lid[slot] = id;
+        }
+      }
+    }
+  }
+  // candidates among the tile's own begins
+  const bool own_cand = valid && X != 0 && (!have_thr || prio_less(KEY, X, ID, pk, ps, pi));
+  se2[TB + tid] = own_cand ? EE : 0;
+  block_prefix_max(own_cand ? EE : 0, spm2 + TB);  // two barriers: l_count, the LDS list and the stars are visible after it
+  const uint32_t n_cc = l_count;
+  if (n_cc > (uint32_t)KP_CAP) {  // block-uniform
+    if (tid == 0) a.tile_done[tile_id] = 0;
+    return;
+  }
+  if (tid == 0) a.tile_done[tile_id] = 1;
+  const uint64_t* se = se2;
+  const uint64_t* spm = spm2;
+  const uint64_t* sec = se2 + TB;   // candidate view
+  const uint64_t* spmc = spm2 + TB;
+  const bool pass2 = a.thr < 1.0;
+  const uint32_t n_batches = 2 + (n_cc ? 1u : 0u);
+
+  for (uint32_t batch = 0; batch < n_batches; ++batch) {
+    bool eval;
+    uint64_t PX;
+    int Q0;
+    uint64_t PK = KEY, PS = X;  // priority of the interval whose end is the point (batches >= 1)
+    uint32_t PI = ID;
+    if (batch == 0) {  // start coordinates: the last begin of each run, unless the run continues in the next tile
+      eval = valid && X != 0 && (tid == TB - 1 || sx[tid + 1] != X) && X != x_next;
+      PX = X;
+      Q0 = tid;
+    } else {
+      if (batch == 1) {  // ends of the tile's own candidates inside its range
+        eval = valid && X != 0 && EE > X && EE < x_next && sec[tid] != 0;
+        PX = EE;
+      } else {
+        PX = (uint32_t)tid < n_cc ? le[tid] : 0;
+        eval = PX != 0 && PX < x_next;
+        if (eval) {
+          PK = lkey[tid];
+          PS = ls[tid];
+          PI = lid[tid];
+        }
+      }
+      int l = 0, r = TB;  // upper_bound(sx, PX) - 1
+      while (l < r) {
+        const int mid = (l + r) >> 1;
+        if (sx[mid] <= PX)
+          l = mid + 1;
+        else
+          r = mid;
+      }
+      Q0 = l - 1;
+    }
+    if (!eval) continue;  // no barrier below this line
+
+    if (batch != 0) {
+      // was the ending interval a member just before x?  Count what ranks above it among the stars (all active) and the
+      // candidates with s < x <= e.
+      int above = 0;
+      for (int r = 0; r < n_star; ++r) above += prio_less(st_k[r], st_s[r], st_i[r], PK, PS, PI) ? 1 : 0;
+      for (int q = Q0; q >= 0 && above < K; --q) {
+        if (spmc[q] < PX) break;  // no earlier candidate reaches PX
+        if (sec[q] >= PX) {
+          const uint64_t sq = sx[q];
+          if (sq < PX && prio_less(skey[q], sq, sid[q], PK, PS, PI)) ++above;
+        }
+      }
+      for (uint32_t c = 0; c < n_cc && above < K; ++c)
+        if (le[c] >= PX && prio_less(lkey[c], ls[c], lid[c], PK, PS, PI)) ++above;
+      if (above >= K) continue;
+    }
+    // the stars and the candidates active at x (s <= x < e)
+    auto active_cands = [&](auto&& f) {
+      for (int r = 0; r < n_star; ++r) f(st_s[r], st_e[r], st_k[r], st_i[r]);
+      for (int q = Q0; q >= 0; --q) {
+        if (spmc[q] <= PX) break;
+        const uint64_t ee = sec[q];
+        if (ee > PX) f(sx[q], ee, skey[q], sid[q]);
+      }
+      for (uint32_t c = 0; c < n_cc; ++c) {
+        const uint64_t e = le[c];
+        if (e > PX) f(ls[c], e, lkey[c], lid[c]);
+      }
+    };
+    // next member after (mk, ms, mi) in priority order; false when the active set is exhausted
+    auto next_member = [&](bool have_prev, uint64_t mk, uint64_t ms, uint32_t mi, uint64_t* nk, uint64_t* ns, uint64_t* ne,
+                           uint32_t* ni) -> bool {
+      bool found = false;
+      uint64_t fk = 0, fs = 0, fe = 0;
+      uint32_t fi = 0;
+      active_cands([&](uint64_t s_, uint64_t e, uint64_t key, uint32_t id) {
+        if (have_prev && !prio_less(mk, ms, mi, key, s_, id)) return;
+        if (!found || prio_less(key, s_, id, fk, fs, fi)) {
+          fk = key;
+          fs = s_;
+          fe = e;
+          fi = id;
+          found = true;
+        }
+      });
+      if (found) {
+        *nk = fk;
+        *ns = fs;
+        *ne = fe;
+        *ni = fi;
+      }
+      return found;
+    };
+    // ---- members: ever top; does one of them begin here?
+    uint64_t tk = 0, ts = 0, te = 0;
+    uint32_t ti = 0;
+    bool member_begins = false;
+    int n_mem = 0;
+    for (int r = 0; r < K; ++r) {
+      if (!next_member(r > 0, tk, ts, ti, &tk, &ts, &te, &ti)) break;
+      ++n_mem;
+      a.top[ti] = 1;
+      member_begins = member_begins || ts == PX;
+    }
+    // with K members (tk, ts, ti) is the K-th: everything ranked after it is a non-member; with fewer, everything active is a
+    // member and there is nobody to flag (plane_sweep_exact.rs: the overlap pass needs more than k actives)
+    if (!pass2 || n_mem < K) continue;
+    const bool full = batch != 0 || member_begins || PX == x_b;
+    uint64_t mk = 0, ms = 0, me = 0;
+    uint32_t mi = 0;
+    for (int r = 0; r < K; ++r) {
+      (void)next_member(r > 0, mk, ms, mi, &mk, &ms, &me, &mi);
+      if (full) {  // the member set changed here: every active non-member against this member
+        for (int q = Q0; q >= 0; --q) {
+          if (spm[q] <= PX) break;
+          const uint64_t ee = se[q];
+          if (ee > PX) {
+            const uint32_t id = sid[q];
+            const uint64_t sq = sx[q];
+            if (prio_less(tk, ts, ti, skey[q], sq, id) && overlap_exceeds(sq, ee, ms, me, a.thr)) a.ovl[id] = 1;
+          }
+        }
+        for (uint32_t c = c_begin; c < c_end; ++c) {
+          const uint64_t e = a.c_e[c];
+          if (e > PX) {
+            const uint64_t s_ = a.c_s[c], key = a.c_key[c];
+            const uint32_t id = a.c_id[c];
+            if (prio_less(tk, ts, ti, key, s_, id) && overlap_exceeds(s_, e, ms, me, a.thr)) a.ovl[id] = 1;
+          }
+        }
+      } else {  // same members as just before x: only the intervals that begin at x have not met them yet
+        for (int q = Q0; q >= 0 && sx[q] == PX; --q) {
+          const uint64_t ee = se[q];
+          if (ee > PX) {
+            const uint32_t id = sid[q];
+            if (prio_less(tk, ts, ti, skey[q], PX, id) && overlap_exceeds(PX, ee, ms, me, a.thr)) a.ovl[id] = 1;
           }
         }
       }
@@ -972,10 +1288,19 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.thr = thr;
   ta.top = top;
   ta.ovl = ovl;
-  if (k == 1)
+  ta.tile_done = nullptr;
+  if (k == 1) {
     SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<<<ntiles, TB, 0, st>>>(ta));
-  else
+  } else {
+    static const bool no_prune = getenv("SWG_KN_PLAIN") != nullptr;  // test knob: every tile through the plain kernel
+    if (k <= (uint64_t)KSTAR_MAX && !no_prune) {
+      ta.tile_done = swg_alloc<uint8_t>(ctx, ntiles);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "sweep_tile_kp", sweep_tile_kp_kernel<<<ntiles, TB, 0, st>>>(ta));
+      SWG_KERNEL_CHECK(ctx);
+    }
     SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kn_kernel<<<ntiles, TB, 0, st>>>(ta));
+  }
   SWG_KERNEL_CHECK(ctx);
   {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(in.alive) | reinterpret_cast<uintptr_t>(single) | reinterpret_cast<uintptr_t>(top) |

@@ -80,17 +80,18 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_CHAIN_DEEP"])
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_CHAIN_DEEP", "SWG_KN_PLAIN"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
     onesweep pass (otherwise only used for n >= 2^30), SWG_CHAIN_DEEP=1 the wavefront-per-element candidate kernel of deep
-    chaining groups (otherwise only used when groups average more than 8192 mappings)."""
+    chaining groups (otherwise only used when groups average more than 8192 mappings), SWG_KN_PLAIN=1 sends every tile of a
+    2 <= k < inf sweep through the plain tile kernel (otherwise only the tiles the pruned kernel leaves)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
     paf = tmp_path / "in.paf"
     paf.write_text(gen.records_to_paf(rng, rec))
-    for k, flags in enumerate(FLAG_SETS[:4]):
+    for k, flags in enumerate(FLAG_SETS[:5] + [["--num-mappings", "3:2", "--scaffold-jump", "0"]]):
         o1, o2 = tmp_path / f"gpu{k}.paf", tmp_path / f"ref{k}.paf"
         r = subprocess.run([cli, str(paf), "--output-file", str(o1), "--quiet", *flags], capture_output=True, text=True,
                            env={**os.environ, knob: "1"})

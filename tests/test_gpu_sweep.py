@@ -170,6 +170,33 @@ def test_large_single_segment(sw, seed, n):
             assert bad.size == 0, (k, axis, bad.size)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_deep_segment_general_k(sw, seed):
+    """Deep segments (hundreds of carry-ins per tile) for 2 <= k: the pruned tile kernel (k <= 8: stars, candidates, member
+    changes) and the plain one (k = 9, and everything under SWG_KN_PLAIN), with ties, zero lengths and every threshold kind."""
+    import ctypes as C
+    rng = np.random.default_rng(100 + seed)
+    ctx = sw.default_context(0)
+    n = [12_000, 25_000, 40_000][seed]
+    qs, qe, ts, te, ident = gen.random_segment(rng, n, span=[300_000, 1_000_000, 2_500_000][seed], max_len=[20_000, 30_000, 60_000][seed],
+                                               zero_frac=0.002, dup_frac=0.05, ident_levels=[None, [0.8, 0.9, 0.95, 0.99, 1.0], None][seed])
+    fails = []
+    for k, thr, scoring in ((2, 0.95, 3), (3, 0.5, 3), (3, 1.0, 0), (4, 0.0, 1), (5, 0.7, 2), (8, 0.95, 4), (9, 0.6, 3), (2, 0.1, 3)):
+        for axis in (0, 1):
+            want = np.zeros(n, dtype=np.uint8)
+            want[orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k, k_t=k, thr=thr, scoring=scoring)] = 1
+            got = np.zeros(n, dtype=np.uint8)
+            ctx.check(ctx.lib.swg_plane_sweep(ctx.handle, axis, n, *(a.ctypes.data_as(C.c_void_p) for a in (qs, qe, ts, te, ident)),
+                                              k, k, thr, scoring, got.ctypes.data_as(C.c_void_p)))
+            bad = np.nonzero(got != want)[0]
+            if bad.size:
+                fails.append(dict(k=k, thr=thr, scoring=scoring, axis=axis, nbad=int(bad.size), first=bad[:10].tolist(),
+                                  got=got[bad[:10]].tolist()))
+    if fails:
+        _dump(f"sweep_deep_k_seed{seed}.json", dict(fails=fails))
+    assert not fails, fails[:4]
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_mapping_filter_no_scaffold(sw, seed):
     """apply_filters with scaffold_gap = 0 (plane sweep only) on multi-genome records."""
