@@ -143,8 +143,40 @@ int swg_inclusive_sum_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, 
 // *keys / *vals hold the input; the *_alt buffers are scratch of the same size.  Passes ping-pong
 // between the two pairs of buffers and the POINTERS are swapped so that on return *keys / *vals
 // address the sorted data (no copy-back pass).
+// `prehist` (optional): the digit histograms of every pass, [SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS] device words over the
+// same bit range, already accumulated by the kernel that wrote the keys (swg_radix_hist_add below) -- the sort then skips
+// its own pass over the keys.
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
-                         uint64_t n, int begin_bit, int end_bit);
+                         uint64_t n, int begin_bit, int end_bit, uint32_t* prehist = nullptr);
+constexpr int SWG_RADIX_BINS = 256;
+constexpr int SWG_RADIX_MAX_PASSES = 8;
+#ifdef __HIPCC__
+// Accumulates one key of every lane of the wavefront into the work-group's LDS histograms h[pass][bin] (256-thread
+// groups; zero them first, flush them with swg_radix_hist_flush).  High digits are usually the same for a whole
+// wavefront (segment bits): one add then instead of 64 serialised LDS atomics on one bin.
+__device__ __forceinline__ void swg_radix_hist_add(uint32_t (*h)[SWG_RADIX_BINS], uint64_t k, bool valid, int begin_bit,
+                                                   int end_bit, int npasses) {
+  const uint64_t vmask = __ballot(valid);
+  for (int p = 0; p < npasses; ++p) {
+    const int shift = begin_bit + 8 * p;
+    const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+    const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    const bool uniform = __ballot(valid && d != d0) == 0 && (vmask & 1ull);
+    if (uniform) {
+      if ((threadIdx.x & 63) == 0) atomicAdd(&h[p][d0], (uint32_t)__popcll(vmask));
+    } else if (valid) {
+      atomicAdd(&h[p][d], 1u);
+    }
+  }
+}
+__device__ __forceinline__ void swg_radix_hist_flush(uint32_t (*h)[SWG_RADIX_BINS], int npasses, uint32_t* ghist) {
+  for (int p = 0; p < npasses; ++p) {
+    const uint32_t c = h[p][threadIdx.x];
+    if (c) atomicAdd(&ghist[p * SWG_RADIX_BINS + threadIdx.x], c);
+  }
+}
+#endif
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
 int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64_t* e0, uint32_t* out_s, uint32_t* out_e,
                       const char* axis);

@@ -625,8 +625,9 @@ int radix_sort_three_kernel(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint
 
 }  // namespace
 
+static_assert(SWG_RADIX_BINS == RS_RADIX && SWG_RADIX_MAX_PASSES == OS_MAX_PASSES, "prehist layout");
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
-                         uint64_t n, int begin_bit, int end_bit) {
+                         uint64_t n, int begin_bit, int end_bit, uint32_t* prehist) {
   if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
   if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
   const int npasses = (end_bit - begin_bit + 7) / 8;
@@ -641,16 +642,18 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   const size_t word = wide ? sizeof(uint64_t) : sizeof(uint32_t);
   const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
-  uint32_t* ghist = swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
+  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
   void* status = swg_arena_alloc(ctx, (size_t)ntiles * RS_RADIX * word);
   uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
   SWG_CHECK_ARENA(ctx);
-  SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
   SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
   {
-    uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
-    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, begin_bit, end_bit, npasses, ghist));
-    SWG_KERNEL_CHECK(ctx);
+    if (!prehist) {
+      SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
+      uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
+      SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, begin_bit, end_bit, npasses, ghist));
+      SWG_KERNEL_CHECK(ctx);
+    }
     SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, RS_RADIX, 0, ctx->stream>>>(ghist));
     SWG_KERNEL_CHECK(ctx);
   }

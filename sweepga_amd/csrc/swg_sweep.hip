@@ -134,23 +134,41 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
                                                                  const uint32_t* __restrict__ start,
                                                                  const uint8_t* __restrict__ alive, int pos_bits,
                                                                  uint64_t* __restrict__ key,
-                                                                 uint32_t* __restrict__ val) {
-  uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
-  if (i >= n) return;
-  const bool live = alive ? alive[i] != 0 : true;
-  uint64_t k = 0;
-  if (live) {
-    uint64_t sg;
-    if (seg) {
-      sg = seg[i];
-    } else {
-      const uint32_t b = seg_b[i];
-      sg = (uint64_t)seg_a[i] * seg_mul + (seg_table ? seg_table[b] : b);
-    }
-    k = ((sg + 1) << pos_bits) | start[i];
+                                                                 uint32_t* __restrict__ val, int key_bits,
+                                                                 uint32_t* __restrict__ ghist) {
+  // grid-stride over whole work-groups (the trip count is block-uniform); with `ghist` the digit histograms of the sort
+  // that follows are accumulated here, while the key is in a register (the sort then skips its own pass over the keys)
+  __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
+  const int npasses = (key_bits + 7) / 8;
+  if (ghist) {
+    for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
   }
-  key[i] = k;
-  val[i] = (uint32_t)i;
+  for (uint64_t base = (uint64_t)blockIdx.x * EW_THREADS; base < n; base += (uint64_t)gridDim.x * EW_THREADS) {
+    const uint64_t i = base + threadIdx.x;
+    const bool in = i < n;
+    uint64_t k = 0;
+    if (in) {
+      const bool live = alive ? alive[i] != 0 : true;
+      if (live) {
+        uint64_t sg;
+        if (seg) {
+          sg = seg[i];
+        } else {
+          const uint32_t b = seg_b[i];
+          sg = (uint64_t)seg_a[i] * seg_mul + (seg_table ? seg_table[b] : b);
+        }
+        k = ((sg + 1) << pos_bits) | start[i];
+      }
+      key[i] = k;
+      val[i] = (uint32_t)i;
+    }
+    if (ghist) swg_radix_hist_add(h, k, in, 0, key_bits, npasses);
+  }
+  if (ghist) {
+    __syncthreads();
+    swg_radix_hist_flush(h, npasses, ghist);
+  }
 }
 
 // After the sort: pull each begin's end coordinate and score key next to it (so the tile kernel reads
@@ -1209,10 +1227,22 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     tile_x = swg_alloc<uint64_t>(ctx, (size_t)ntiles + 1);
     single = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                       n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I));
+    // the sort's digit histograms come out of begin_build (when the onesweep path will run: up to 8 passes)
+    static const bool sort_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
+    uint32_t* prehist = nullptr;
+    if (key_bits <= 8 * SWG_RADIX_MAX_PASSES && !sort_fallback && n > 1) {
+      prehist = swg_alloc<uint32_t>(ctx, (size_t)SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS);
+      SWG_CHECK_ARENA(ctx);
+      SWG_HIP(ctx, hipMemsetAsync(prehist, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
+    }
+    {
+      const unsigned full = blocks_for(n, EW_THREADS), cap = (unsigned)ctx->num_cu * 16;
+      SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<(prehist && full > cap) ? cap : full, EW_THREADS, 0, st>>>(
+                                         n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I,
+                                         key_bits, prehist));
+    }
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits));
+    SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits, prehist));
     if (in.sorted_idx_out) {
       SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
       if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
