@@ -665,27 +665,13 @@ __global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units
   if (len > SMALL_UNIT) return;
   const uint64_t fifth = max_gap / 5;
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
-  // the first candidate of the next element is loaded a step ahead: the lists are immutable, and a step is otherwise three
-  // dependent loads long (count -> candidate -> its score)
-  uint32_t n_next = c_n[b], j_next = c_j[b];
-  uint64_t d_next = c_d[b];
   for (uint32_t i = b; i < e; ++i) {
-    const uint32_t nvalid = n_next, j_first = j_next;
-    const uint64_t d_first = d_next;
-    if (i + 1 < e) {
-      n_next = c_n[i + 1];
-      d_next = c_d[i + 1];
-      j_next = c_j[i + 1];
-    }
+    const uint32_t nvalid = c_n[i];
     if (nvalid == 0) continue;
     uint64_t best_d = ~0ull;
     uint32_t best_j = NONE;
-    if (d_first < bps[j_first]) {  // nvalid >= 1
-      best_d = d_first;
-      best_j = j_first;
-    }
 #pragma unroll
-    for (int c = 1; c < KC; ++c) {
+    for (int c = 0; c < KC; ++c) {
       if (best_j == NONE && (uint32_t)c < nvalid) {
         const uint64_t d = c_d[(uint64_t)c * m + i];
         const uint32_t j = c_j[(uint64_t)c * m + i];
