@@ -88,6 +88,26 @@ __global__ __launch_bounds__(EW) void dense_from_scan_kernel(uint64_t M, const u
 }
 
 // ---- survivors (mapping-sweep survivors in A order) -----------------------------------------------------
+// The same when every record of sort A is a member (no mapping-level filter ran, or it kept everything): positions
+// coincide, so the ends / targets / indices of sort A are used as they are and only what sort A does not hold is produced.
+__global__ __launch_bounds__(EW) void gatherS_all_kernel(uint64_t m, const uint64_t* __restrict__ keyA,
+                                                         const uint32_t* __restrict__ idxA,
+                                                         const uint32_t* __restrict__ matches,
+                                                         const uint32_t* __restrict__ block_len, int pos_bits,
+                                                         uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_m,
+                                                         uint32_t* __restrict__ s_b, uint64_t* __restrict__ s_grp,
+                                                         uint32_t* __restrict__ head_flag) {
+  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint64_t k = keyA[p];
+  const uint32_t i = idxA[p];
+  s_qs[p] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
+  s_m[p] = matches[i];
+  s_b[p] = block_len[i];
+  const uint64_t g = k >> pos_bits;
+  s_grp[p] = g;
+  head_flag[p] = (p == 0 || (keyA[p - 1] >> pos_bits) != g) ? 1u : 0u;
+}
 __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t* __restrict__ s_a,
                                                      const uint64_t* __restrict__ keyA,
                                                      const uint32_t* __restrict__ idxA,
@@ -1843,9 +1863,18 @@ int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
-  SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
-                                                        r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
-                                                        B.s_idx, s_grp, head_flag));
+  if (m == M) {  // every record of sort A is a member: s_a is the identity
+    s_qe = B.a_qe;
+    s_ts = B.a_ts;
+    s_te = B.a_te;
+    B.s_idx = B.idxA;
+    SWG_LAUNCH(ctx, "gatherS", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
+                                                              s_m, s_b, s_grp, head_flag));
+  } else {
+    SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
+                                                          r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                          B.s_idx, s_grp, head_flag));
+  }
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, head_flag, gidx_excl, m, d_tot + 3));
   SWG_LAUNCH(ctx, "group_bounds", group_bounds_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, gidx_excl, s_gidx, group_begin));
