@@ -189,7 +189,11 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   if (n == 0) return SWG_OK;
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
-  swg_key_ends* key_ends = swg_alloc<swg_key_ends>(ctx, n);
+  // score keys and ends are what the mapping-level sweep sorts and ranks by: with both limits infinite (the CLI defaults)
+  // nothing sweeps, and the 16 bytes per record are neither computed nor stored
+  uint64_t kq0, kt0;
+  limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq0, &kt0);
+  swg_key_ends* key_ends = (kq0 == SWG_K_INF && kt0 == SWG_K_INF) ? nullptr : swg_alloc<swg_key_ends>(ctx, n);
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));

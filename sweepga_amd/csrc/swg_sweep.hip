@@ -104,11 +104,13 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
     const bool ok = (min_block == 0 || (uint64_t)block_len[i] >= min_block) && (keep_self || q_id[i] != t_id[i]) && id >= min_identity;
     alive[i] = ok ? 1 : 0;
-    swg_key_ends ke;
-    ke.key = score_key_of(a, b, id, scoring);
-    ke.end[0] = b;
-    ke.end[1] = d;
-    key_ends[i] = ke;
+    if (key_ends) {  // nullptr: no mapping-level sweep will run (both limits infinite), nobody reads the scores
+      swg_key_ends ke;
+      ke.key = score_key_of(a, b, id, scoring);
+      ke.end[0] = b;
+      ke.end[1] = d;
+      key_ends[i] = ke;
+    }
     const uint32_t m1 = a > b ? a : b, m2 = c > d ? c : d;
     const uint32_t m = m1 > m2 ? m1 : m2;
     if (m > mx) mx = m;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
       k = ke.key;
     } else {
       e = (s & ~posmask) | end[id];
-      k = score_key[id];
+      k = score_key ? score_key[id] : 0;  // no scores: the k = inf path only wants the `single` flags
     }
     const uint64_t sg = s >> pos_bits;
     const bool prev_same = p > 0 && (S[p - 1] >> pos_bits) == sg;
