@@ -142,6 +142,12 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   const uint64_t n = r->n;
   uint64_t kq, kt;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
+  if (kq == SWG_K_INF && kt == SWG_K_INF) {  // no limit on either axis: one pass, unless zero-length intervals exist
+    int done = 0;
+    if (q_order_valid) *q_order_valid = 0;
+    SWG_TRY(swg_kinf_both(ctx, n, r->q_start, r->q_end, r->t_start, r->t_end, alive, keep, &done));
+    if (done) return SWG_OK;
+  }
   swg_arena_mark mark = swg_arena_save(ctx);
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, n);
   SWG_CHECK_ARENA(ctx);

@@ -239,6 +239,9 @@ struct swg_axis_input {
   int* sorted_idx_valid = nullptr;       //   *valid = 1 when the begins were sorted (not for k = inf without zero lengths)
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
+// Both axes with k = inf in one pass; *done = 0 when zero-length intervals exist (then the per-axis calls are needed).
+int swg_kinf_both(swg_ctx* ctx, uint64_t n, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts, const uint32_t* te,
+                  const uint8_t* alive, uint8_t* keep, int* done);
 
 // score keys: key[i] = order-preserving transform of -score so that smaller key = better
 // (src/plane_sweep_exact.rs:29-86, 183-193); length is always q_end - q_start.

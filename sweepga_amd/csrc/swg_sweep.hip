@@ -1137,6 +1137,27 @@ __global__ __launch_bounds__(EW_THREADS) void kinf_mark_kernel(uint64_t n, const
   }
   keep[i] = kf;
 }
+// Both axes of a sweep with no limit at all (the CLI's default --num-mappings): keep = alive and both spans non-empty; the
+// zero-length intervals are only counted -- if there are any, the caller takes the two per-axis passes instead (they need
+// the segment sizes).
+__global__ __launch_bounds__(EW_THREADS) void kinf_mark_both_kernel(uint64_t n, const uint32_t* __restrict__ qs,
+                                                                    const uint32_t* __restrict__ qe,
+                                                                    const uint32_t* __restrict__ ts,
+                                                                    const uint32_t* __restrict__ te,
+                                                                    const uint8_t* __restrict__ alive,
+                                                                    uint8_t* __restrict__ keep, uint32_t* __restrict__ n_zero) {
+  uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const bool live = alive ? alive[i] != 0 : true;
+  uint8_t kf = 0;
+  if (live) {
+    if (qs[i] < qe[i] && ts[i] < te[i])
+      kf = 1;
+    else
+      atomicAdd(n_zero, 1u);
+  }
+  keep[i] = kf;
+}
 __global__ __launch_bounds__(EW_THREADS) void kinf_single_kernel(uint64_t n, const uint8_t* __restrict__ single,
                                                                  const uint8_t* __restrict__ and_with,
                                                                  uint8_t* __restrict__ keep) {
@@ -1181,6 +1202,27 @@ __global__ __launch_bounds__(EW_THREADS) void combine_kernel(uint64_t n, const u
 inline unsigned blocks_for(uint64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
+
+int swg_kinf_both(swg_ctx* ctx, uint64_t n, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts, const uint32_t* te,
+                  const uint8_t* alive, uint8_t* keep, int* done) {
+  *done = 0;
+  if (n == 0) {
+    *done = 1;
+    return SWG_OK;
+  }
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* n_zero = swg_alloc<uint32_t>(ctx, 2);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(n_zero, 0, 8, ctx->stream));
+  SWG_LAUNCH(ctx, "kinf_mark", kinf_mark_both_kernel<<<(unsigned)((n + EW_THREADS - 1) / EW_THREADS), EW_THREADS, 0, ctx->stream>>>(
+                                   n, qs, qe, ts, te, alive, keep, n_zero));
+  SWG_KERNEL_CHECK(ctx);
+  uint64_t h = 0;
+  SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(n_zero), &h, 1));
+  swg_arena_restore(ctx, mark);
+  *done = (uint32_t)h == 0;
+  return SWG_OK;
+}
 
 int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint32_t* q_end,
                    const double* identity, int scoring, uint64_t* key_out) {
