@@ -336,22 +336,6 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
 
   const uint32_t tile_id = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // A wavefront here lives ~10 us for ~600 vector instructions: what it spends is dependent memory round trips.  So every
-  // load whose address is known is issued at the top -- the tile's bounds first, then (they depend on those) the carry-ins
-  // of the usual short list -- and the barriers and reductions of the prologue run while they are in flight.
-  const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
-  const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
-  const uint32_t n_carry = c_end - c_begin;
-  const bool short_list = n_carry != 0 && n_carry <= (uint32_t)CCAP;  // block-uniform
-  const bool mine = short_list && (uint32_t)tid < n_carry;
-  uint64_t cs_ = 0, ce_ = 0, ck_ = 0;
-  uint32_t ci_ = 0;
-  if (mine) {
-    cs_ = a.c_s[c_begin + tid];
-    ce_ = a.c_e[c_begin + tid];
-    ck_ = a.c_key[c_begin + tid];
-    ci_ = a.c_id[c_begin + tid];
-  }
   const uint64_t p = (uint64_t)tile_id * TB + tid;
   const bool valid = p < a.n;
   uint64_t X = ~0ull, EE = 0, KEY = 0;
@@ -384,11 +368,14 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   };
   block_prefix_max(EE, spm2);
   const uint64_t x_b = sx[0];
+  const uint64_t x_next = (tile_id + 1 < a.ntiles) ? a.tile_x[tile_id + 1] : ~0ull;
+  const uint32_t c_begin = a.carry_off[tile_id], c_end = a.carry_off[tile_id + 1];
 
   // ---- S*: the best carry-in that is active over the whole range of the tile, and the candidate carry-ins
   bool have_star = false;
   uint64_t star_k = 0, star_s = 0, star_e = 0;
   uint32_t star_i = 0;
+  const uint32_t n_carry = c_end - c_begin;
   uint32_t n_cc = 0;
   bool cc_in_lds = true;
   // wave-level then block-level arg-min of (key, start, index) over the lanes with hv set; every thread gets the result
@@ -424,7 +411,16 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
         have_star = true;
       }
   };
-  if (short_list) {  // block-uniform.  The usual case: the whole list goes to LDS as it is (loaded at the top)
+  if (n_carry != 0 && n_carry <= CCAP) {  // block-uniform.  The usual case: the whole list goes to LDS as it is
+    const bool mine = (uint32_t)tid < n_carry;
+    uint64_t cs_ = 0, ce_ = 0, ck_ = 0;
+    uint32_t ci_ = 0;
+    if (mine) {
+      cs_ = a.c_s[c_begin + tid];
+      ce_ = a.c_e[c_begin + tid];
+      ck_ = a.c_key[c_begin + tid];
+      ci_ = a.c_id[c_begin + tid];
+    }
     if (n_carry >= STAR_MIN) {  // pruning only pays on deep data
       reduce_star(mine && ce_ >= x_next, ck_, cs_, ce_, ci_);
       // entries S* dominates leave the list (end 0 = never active); S* itself stays in registers
