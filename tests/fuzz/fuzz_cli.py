@@ -58,12 +58,16 @@ def random_flags(rng):
     return fl
 
 
-def random_paf(rng):
+def random_paf(rng, rng_wide=None):
+    """rng_wide (a second generator, so that the cases of earlier campaigns keep their seeds): one file in ten has every
+    sequence's coordinates moved by a constant of its own, up to 2^62 -- the ingest's 64-bit pass and per-sequence rebasing."""
     n = int(rng.choice([1, 5, 300, 3000, 15000]))
     chr_len = int(rng.choice([20_000, 300_000, 2_000_000]))
     rec = gen.random_records(rng, n, n_genomes=int(rng.integers(1, 6)), chrs_per_genome=int(rng.integers(1, 4)), span=chr_len - 5000,
                              max_len=min(8000, chr_len // 3), pansn=bool(rng.random() < 0.8), minus_frac=float(rng.choice([0.0, 0.3])),
                              self_frac=float(rng.choice([0.0, 0.1])))
+    if rng_wide is not None and rng_wide.random() < 0.1:
+        rec, _ = gen.shifted(rec, rng_wide)
     out = []
     for ln in gen.records_to_paf(rng, rec).split("\n"):
         f = ln.split("\t")
@@ -87,7 +91,7 @@ def main():
     while time.time() - t0 < args.minutes * 60:
         rng = np.random.default_rng(seed)
         with open(paf, "w", newline="") as fh:
-            fh.write(random_paf(rng))
+            fh.write(random_paf(rng, np.random.default_rng(seed + 10**9)))
         flags = random_flags(rng)
         dev = ["--devices", "0,0"] if seed % 5 == 0 else []
         r1 = subprocess.run([build.CLI, paf, "--output-file", o1, "--quiet", *flags, *dev], capture_output=True, text=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the whole filter on the GPU against the CPU oracle, beyond the fixed seeds of tests/:
 random record sets (sizes 1 .. 60k, 1-6 genomes, sparse to very dense, ties and duplicates, zero-length and
-zero-identity records, PanSN and plain names) x random configurations (filter modes and k, overlap thresholds,
+zero-identity records, PanSN and plain names, coordinates against the 32-bit limit or moved beyond it per sequence) x random configurations (filter modes and k, overlap thresholds,
 scorings, gaps, masses, deviations, identity / length cut-offs, self, scaffolds-only).  Exact equality of status
 and chain numbers is required.  A failing case is written to gpurun_out/fuzz_fail_<seed>.json for replay.
 
@@ -63,7 +63,12 @@ def random_case(rng, extras=True):
         min_scaffold_identity=float(rng.choice([0.0, 0.85])),
         min_block_length=int(rng.choice([0, 100, 2_000])),
     )
-    return rec, kw, bool(rng.random() < 0.3), bool(rng.random() < 0.15)
+    keep_self, scaffolds_only = bool(rng.random() < 0.3), bool(rng.random() < 0.15)
+    # (drawn last, so that the cases of earlier campaigns keep their seeds) every sequence moved by a constant of its own, up to
+    # 2^62: RecordMeta's u64 coordinates through swg_filter64 / swg_filter_multi64 and the per-sequence rebasing
+    if extras and rng.random() < 0.12:
+        rec, _ = gen.shifted(rec, rng)
+    return rec, kw, keep_self, scaffolds_only
 
 
 _CTXS = []
