@@ -1,7 +1,8 @@
 // Host-side sanitizer harness for sweepga_amd/csrc/host/paf_io.cpp (ASan + UBSan run on the CPU build only: the
 // GPU pool has no sanitizer support).  Opens every file given on the command line with several thread counts,
 // touches every column, builds the ANI view, writes the records back with all status/chain variants and checks
-// a few invariants.  The device entry points paf_io.cpp refers to are stubbed: nothing here needs a GPU.
+// a few invariants; then the tree sparsification, alnstats and the .1aln derivation over the same inputs.  The device entry
+// points paf_io.cpp refers to are stubbed: nothing here needs a GPU.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -54,8 +55,57 @@ int main(int argc, char** argv) {
       if (swg_paf_write(p, out.c_str(), status.data(), chain.data(), threads, &kept) != SWG_OK) return 14;
       if (swg_paf_write(p, out.c_str(), status.data(), nullptr, threads, &kept) != SWG_OK) return 15;
       std::remove(out.c_str());
+      // the other host-side passes over the same text: tree sparsification and alnstats
+      const char* text = nullptr;
+      uint64_t len = 0;
+      if (swg_paf_text(p, &text, &len) != SWG_OK) return 16;
+      for (double frac : {0.0, 0.5}) {
+        char* kept_text = nullptr;
+        uint64_t kept_len = 0;
+        if (swg_paf_tree_filter(text, len, 1 + threads % 2, threads % 3, frac, &kept_text, &kept_len) == SWG_OK) {
+          for (uint64_t i = 0; i < kept_len; ++i) checksum += (unsigned char)kept_text[i];
+          swg_free(kept_text);
+        }
+      }
+      swg_alnstats* st = nullptr;
+      if (swg_alnstats_open_buffer(text, len, threads, &st) == SWG_OK) {  // files with unparsable columns are refused, as in the reference
+        char* rep = nullptr;
+        uint64_t rl = 0;
+        if (swg_alnstats_report(st, argv[a], 1, &rep, &rl) == SWG_OK) {
+          checksum += rl;
+          swg_free(rep);
+        }
+        if (swg_alnstats_compare(st, st, "a", "b", &rep, &rl) != SWG_OK) return 17;
+        checksum += rl;
+        swg_free(rep);
+        const swg_alnstats_summary* sm = swg_alnstats_get(st);
+        for (uint64_t i = 0; i < sm->genome_pairs; ++i) {
+          const char *q, *t;
+          double cov;
+          uint64_t b, m;
+          if (swg_alnstats_pair(st, i, &q, &t, &cov, &b, &m) != SWG_OK) return 18;
+          checksum += std::string(q).size() + std::string(t).size() + b + m;
+        }
+        swg_alnstats_close(st);
+      }
       swg_paf_close(p);
     }
+  }
+  {  // .1aln record derivation, with coordinates beyond 2^32 (per-sequence rebasing) and a stretch that does not fit
+    const char* qn[4] = {"a x", "a", "b\tz", " "};
+    const char* tn[4] = {"b", "c", "a", "c"};
+    const uint64_t big = 1ull << 40;
+    uint64_t qs[4] = {big + 100, big + 5, 3, 9}, qe[4] = {big + 1100, big + 15, 10, 9}, ts[4] = {50, 3, big + 77, 4294967290ull},
+             te[4] = {950, 23, big + 84, 4294967295ull}, m[4] = {950, 9, 7, 0};
+    swg_aln_input in{4, qn, tn, qs, qe, ts, te, m, "+-++"};
+    swg_aln* h = nullptr;
+    if (swg_aln_open(&in, &h) != SWG_OK) return 20;
+    const swg_records* r = swg_aln_records(h);
+    for (uint64_t i = 0; i < r->n; ++i) checksum += r->q_start[i] + r->t_end[i] + r->block_len[i];
+    if (!swg_aln_seq_offsets(h)) return 21;
+    swg_aln_close(h);
+    te[3] += 1ull << 33;  // sequence c now spans more than 2^32
+    if (swg_aln_open(&in, &h) != SWG_ERR_RANGE) return 22;
   }
   std::printf("ok %llu\n", checksum);
   return 0;

@@ -1,4 +1,5 @@
-"""ASan + UBSan over the host-side PAF ingest/egress (sanitizers run on the CPU build only)."""
+"""ASan + UBSan over the host-side code: PAF ingest/egress, tree sparsification, alnstats, .1aln derivation (sanitizers run
+on the CPU build only)."""
 import gzip
 import os
 import subprocess
@@ -17,7 +18,9 @@ def harness(tmp_path_factory):
     out = tmp_path_factory.mktemp("san") / "paf_io_sanitize"
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            os.path.join(ROOT, "tests", "native", "paf_io_sanitize.cpp"),
-           os.path.join(ROOT, "sweepga_amd", "csrc", "host", "paf_io.cpp"), "-o", str(out), "-lz", "-lpthread"]
+           os.path.join(ROOT, "sweepga_amd", "csrc", "host", "paf_io.cpp"),
+           os.path.join(ROOT, "sweepga_amd", "csrc", "host", "tree_filter.cpp"),
+           os.path.join(ROOT, "sweepga_amd", "csrc", "host", "alnstats.cpp"), "-o", str(out), "-lz", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
@@ -40,6 +43,9 @@ def test_paf_io_under_asan_ubsan(harness, tmp_path):
         "big2.paf.bgz": bgzf_bytes(big.encode(), block=30000),
         "trunc.paf.gz": gzip.compress(big.encode())[:5000],
         "garbage.paf.gz": b"\x1f\x8b" + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),
+        # coordinates beyond 2^32: the 64-bit pass and the per-sequence rebasing of the ingest
+        "wide.paf": gen.records_to_paf(rng, gen.shifted(gen.random_records(rng, 3000), rng)[0]).encode(),
+        "too_wide.paf": b"q\t9\t0\t5\t+\tt\t9\t2\t6\t3\t4\t0\nq\t9\t1\t4294967296\t+\tt\t9\t2\t6\t3\t4\t0\n",
     }
     paths = []
     for name, blob in files.items():
@@ -49,4 +55,5 @@ def test_paf_io_under_asan_ubsan(harness, tmp_path):
     r = subprocess.run([harness, *paths, str(tmp_path / "missing.paf")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "ok " in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
-    assert r.stdout.count("open failed") == 3 * 3  # truncated gzip, garbage gzip, missing file; three thread counts each
+    # truncated gzip, garbage gzip, a mapped stretch beyond 2^32, missing file; three thread counts each
+    assert r.stdout.count("open failed") == 4 * 3
