@@ -165,3 +165,11 @@ def test_errors_and_edge_values(bins, tmp_path):
     from sweepga_amd import AlnStats, SwgError
     with pytest.raises(SwgError, match="Invalid block length \\(line 4\\)"):
         AlnStats(text=cases["bad_block"], threads=1)
+
+
+def test_fuzz_slice_against_oracle(bins):
+    """A slice of tests/fuzz/fuzz_alnstats.py."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_alnstats.py"), "--minutes", "0.1", "--seed", "77000"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "'failures': 0" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
