@@ -18,7 +18,8 @@ namespace swg_rebase {
 struct Result {
   bool ok = true;
   uint64_t bad_record = 0;
-  int bad_field = -1;  // 0..3 = q_start, q_end, t_start, t_end (mapped stretch of the sequence >= 2^32); 4 matches; 5 block length
+  int bad_field = -1;  // 0..3 = q_start, q_end, t_start, t_end (mapped stretch of the sequence >= 2^32); 4 matches; 5 block length;
+                       // 6 = a sequence id >= n_seq (nothing was rebased)
 };
 
 inline const char* field_name(int f) {
@@ -47,6 +48,7 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
   if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
   std::vector<std::vector<uint64_t>> part(threads > 1 ? threads : 0);
   for (uint32_t s = 0; s < n_seq; ++s) lo[s] = UINT64_MAX;
+  std::vector<uint64_t> bad_id(threads, UINT64_MAX);
   run(threads, [&](int t) {
     uint64_t* m = lo;
     if (threads > 1) {
@@ -55,6 +57,10 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
     }
     const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
     for (uint64_t i = b; i < e; ++i) {
+      if (q_id[i] >= n_seq || t_id[i] >= n_seq) {  // the ids index the table: checked in the same pass
+        if (bad_id[t] == UINT64_MAX) bad_id[t] = i;
+        continue;
+      }
       uint64_t& mq = m[q_id[i]];
       const uint64_t q = c64[0][i] < c64[1][i] ? c64[0][i] : c64[1][i];
       if (q < mq) mq = q;
@@ -63,6 +69,14 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
       if (tt < mt) mt = tt;
     }
   });
+  for (int t = 0; t < threads; ++t)
+    if (bad_id[t] != UINT64_MAX) {
+      Result r;
+      r.ok = false;
+      r.bad_record = bad_id[t];
+      r.bad_field = 6;
+      return r;
+    }
   for (int t = 0; t < threads && threads > 1; ++t)
     for (uint32_t s = 0; s < n_seq; ++s)
       if (part[t][s] < lo[s]) lo[s] = part[t][s];

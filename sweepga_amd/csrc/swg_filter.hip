@@ -477,14 +477,13 @@ int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cf
   } catch (const std::bad_alloc&) {
     return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory for the 32-bit columns");
   }
-  for (uint64_t i = 0; i < n; ++i)  // ids index the offset table below
-    if (rec->q_id[i] >= rec->n_seq || rec->t_id[i] >= rec->n_seq)
-      return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)i);
   const uint64_t* const c64[6] = {rec->q_start, rec->q_end, rec->t_start, rec->t_end, rec->matches, rec->block_len};
   uint32_t* const c32[6] = {h.data(), h.data() + n, h.data() + 2 * n, h.data() + 3 * n, h.data() + 4 * n, h.data() + 5 * n};
   unsigned hc = std::thread::hardware_concurrency();
   const swg_rebase::Result rr = swg_rebase::columns(n, rec->q_id, rec->t_id, c64, rec->n_seq, hc ? (int)(hc > 64 ? 64 : hc) : 1, c32,
                                                     lo.data());
+  if (!rr.ok && rr.bad_field == 6)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)rr.bad_record);
   if (!rr.ok)
     return swg_set_error(ctx, SWG_ERR_RANGE,
                          rr.bad_field >= 4 ? "record %llu: %s >= 2^32 is not supported"
