@@ -811,7 +811,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kn_kernel(TileArgs a) {
 // where the non-member begins (only the begins at x are tested).  With fewer than k spanning carry-ins (sparse data) there is
 // no threshold: every interval is a candidate, and what remains is the saving on the end points and on the overlap passes.
 // Tiles with more candidates than the LDS list holds, and k > KSTAR_MAX, are left to sweep_tile_kn_kernel.
-constexpr int KSTAR_MAX = 8;
+constexpr int KSTAR_MAX = 16;
 constexpr int KP_CAP = CCAP;  // candidate carry-ins kept in LDS (256 was measured: slower, and the tiles that overflow have no threshold at all)
 __global__ __launch_bounds__(TB) void sweep_tile_kp_kernel(TileArgs a) {
   __shared__ uint64_t sx[TB];

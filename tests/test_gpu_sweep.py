@@ -172,8 +172,8 @@ def test_large_single_segment(sw, seed, n):
 
 @pytest.mark.parametrize("seed", range(3))
 def test_deep_segment_general_k(sw, seed):
-    """Deep segments (hundreds of carry-ins per tile) for 2 <= k: the pruned tile kernel (k <= 8: stars, candidates, member
-    changes) and the plain one (k = 9, and everything under SWG_KN_PLAIN), with ties, zero lengths and every threshold kind."""
+    """Deep segments (hundreds of carry-ins per tile) for 2 <= k: the pruned tile kernel (k <= 16: stars, candidates, member
+    changes) and the plain one (k = 17, and everything under SWG_KN_PLAIN), with ties, zero lengths and every threshold kind."""
     import ctypes as C
     rng = np.random.default_rng(100 + seed)
     ctx = sw.default_context(0)
@@ -181,7 +181,7 @@ def test_deep_segment_general_k(sw, seed):
     qs, qe, ts, te, ident = gen.random_segment(rng, n, span=[300_000, 1_000_000, 2_500_000][seed], max_len=[20_000, 30_000, 60_000][seed],
                                                zero_frac=0.002, dup_frac=0.05, ident_levels=[None, [0.8, 0.9, 0.95, 0.99, 1.0], None][seed])
     fails = []
-    for k, thr, scoring in ((2, 0.95, 3), (3, 0.5, 3), (3, 1.0, 0), (4, 0.0, 1), (5, 0.7, 2), (8, 0.95, 4), (9, 0.6, 3), (2, 0.1, 3)):
+    for k, thr, scoring in ((2, 0.95, 3), (3, 0.5, 3), (3, 1.0, 0), (4, 0.0, 1), (5, 0.7, 2), (8, 0.95, 4), (9, 0.6, 3), (2, 0.1, 3), (12, 0.8, 3), (16, 0.5, 1), (17, 0.9, 3)):
         for axis in (0, 1):
             want = np.zeros(n, dtype=np.uint8)
             want[orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k, k_t=k, thr=thr, scoring=scoring)] = 1
