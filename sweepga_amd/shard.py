@@ -108,7 +108,7 @@ def chain_shifts(lo: np.ndarray, hi: np.ndarray, first: np.ndarray) -> np.ndarra
 def subset(packed: PackedRecords, idx: np.ndarray) -> PackedRecords:
     cols = {k: np.ascontiguousarray(packed.cols[k][idx]) for k in COLS}
     return PackedRecords(len(idx), cols, packed.n_seq, packed.seq_genome_last, packed.n_genome_last,
-                         packed.seq_genome_two, packed.n_genome_two, packed.index)
+                         packed.seq_genome_two, packed.n_genome_two, packed.index, packed.wide)
 
 
 def retained_mask(packed: PackedRecords, min_block_length: int, min_identity: float, keep_self: bool) -> np.ndarray:

@@ -162,3 +162,19 @@ def test_local_renumbering_equals_global_merge(world):
         ch[has] += shift[key[idx][has]]
         got_st[idx], got_ch[idx] = st, ch
     assert np.array_equal(got_st, want_st) and np.array_equal(got_ch, want_ch)
+
+
+def test_subset_keeps_wide_columns():
+    """Records with coordinates beyond 2^32 keep their u64 columns (and the `wide` mark that selects swg_filter64) through
+    the sharding helpers; plan() only looks at the ids."""
+    import sweepga_amd as sw
+    from sweepga_amd import shard
+    rng = np.random.default_rng(5)
+    rec, _ = gen.shifted(gen.random_records(rng, 500, n_genomes=3, chrs_per_genome=2), rng)
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    assert packed.wide
+    pl = shard.plan(packed, 2)
+    for r in range(2):
+        idx = np.nonzero(pl.shard_of_record == r)[0]
+        sub = shard.subset(packed, idx)
+        assert sub.wide and sub.cols["q_end"].dtype == np.uint64 and np.array_equal(sub.cols["q_end"], rec.qe[idx])
