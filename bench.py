@@ -19,7 +19,7 @@ rank filters its device-resident shard, kept-chain counts are exchanged (one all
 every rank renumbers its own chains.  Genome pairs are independent units of the filter, so there is no other
 collective on the data path.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line (< 4 KB) on rank 0; the full report (per-kernel tables, counts, every leg) goes to --detail.
 """
 import argparse
 import ctypes as C
@@ -342,10 +342,23 @@ class Runner:
         ctx.profile(False)
         prof = ctx.profile_table()
         prof_units = ctx.profile_units()
+        # the same K steps once more with the library's per-launch HIP events switched off: what a caller gets
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(ccfg)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        plain = time.perf_counter() - t0
+        if self.dist is not None:
+            tt = torch.tensor([plain], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            plain = float(tt.item())
         self.step(ccfg, with_stats=True)  # untimed: counts for the report
         ctx.synchronize()
         s = self.stats
-        out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3, "prof": prof, "prof_units": prof_units,
+        out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3,
+               "ms_per_step_unprofiled": plain / steps * 1e3, "prof": prof, "prof_units": prof_units,
                "counts": {"in": s.n_in, "retained": s.n_retained, "swept": s.n_swept, "chains": s.n_chains,
                           "chains_kept": s.n_chains_kept, "out": s.n_out, "device_ms_last_step": s.device_ms}}
         if keep_results:
@@ -408,7 +421,8 @@ def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
                        f"{SBIG1_LEN} bp, seed 1234", "steps": steps, "warmup": warm, "pipelines": {}}
     for p in ("sweep", "default", "full"):
         t = run.time(p, steps, warm)
-        out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n / (t["ms_per_step"] * 1e-3),
+        out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
+                               "value": n / (t["ms_per_step"] * 1e-3),
                                "unit": "mappings/s", "counts": t["counts"], "roofline": roofline(p, n, steps, t, "sbig1_10m"),
                                "kernels_ms_per_step": kernels_table(t, steps)}
     del run, cols
@@ -502,6 +516,70 @@ def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world):
             "load_max_over_mean": float(loads.max() / loads.mean()), "loads": [int(x) for x in loads], "pipelines": res}
 
 
+MAX_LINE_BYTES = 4096   # the driver keeps an 8 KB tail of stdout: the ONE line it parses must stay far below that
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def summary_line(out, detail_path):
+    """The one stdout line (< 4 KB): contract keys, the headline's roofline and CPU baselines, and ONE scalar per other leg.
+    Per-kernel tables, counts, notes and samples are in the detail file (`--detail`, default gpurun_out/bench_detail.json)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_unprofiled", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(out.get(k)) for k in keep}
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in ("workload", "flags", "mappings_per_gpu", "groups_per_gpu") if k in cfg}
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: _r(rf.get(k), 5) for k in
+                            ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "kernel_launches_per_step",
+                             "units_per_launch", "algorithmic_bytes_per_mapping", "kernel_own_frac", "pipeline_frac", "kernel_ms_per_step")}
+    for k in ("cpu_baseline", "cpu_baseline_all_cores"):
+        cb = out.get(k)
+        if cb:
+            line[k] = {"value": _r(cb["value"], 1), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:160]}
+    pipes = out.get("pipelines") or {}
+    par = {}
+    for p, e in pipes.items():
+        if p != (cfg.get("pipeline") or "default"):
+            line[f"{p}_ms_per_step"] = _r(e["ms_per_step"])
+            line[f"{p}_pipeline_frac"] = _r(e["roofline"]["pipeline_frac"], 5)
+        pa = e.get("parity_all_threads")
+        if pa:
+            par[f"span_{p}"] = {"checked": pa["mappings_checked"], "ok": bool(pa["status_equal"] and pa["chain_partition_equal"] is not False)}
+        elif e.get("parity_vs_oracle_on_sample") is not None:
+            par[f"span_{p}"] = {"checked": "sample", "ok": bool(e["parity_vs_oracle_on_sample"])}
+    sb = out.get("sbig1")
+    if sb:
+        for p, e in sb["pipelines"].items():
+            line[f"sbig1_{p}_ms"] = _r(e["ms_per_step"])
+            pa = e.get("parity")
+            if pa:
+                par[f"sbig1_{p}"] = {"checked": pa["mappings_checked"], "ok": bool(pa["status_equal"] and pa["chain_equal"] is not False)}
+    pc = out.get("pcie_inclusive")
+    if pc:
+        for p, e in pc.items():
+            line[f"pcie_{p}_ms"] = _r(e["ms"], 2)
+    ee = out.get("end_to_end")
+    if ee and "wall_s" in ee:
+        line["e2e_lines"], line["e2e_wall_s"] = ee["lines"], _r(ee["wall_s"])
+        line["e2e_byte_identical_on_prefix"] = ee.get("byte_identical_on_prefix")
+        if ee.get("cpu_reference_cli"):
+            line["e2e_cpu_cli_mappings_per_s"] = _r(ee["cpu_reference_cli"]["value"], 1)
+    ss = out.get("strong_scaling")
+    if ss:
+        line["strong"] = {"mappings_total": ss["mappings_total"], "load_max_over_mean": _r(ss["load_max_over_mean"], 5),
+                          "plan_s": _r(ss["plan_s"]), "partition_s": _r(ss["partition_s"]),
+                          "ms_per_step": {p: _r(e["ms_per_step"]) for p, e in ss["pipelines"].items()}}
+    if par:
+        line["parity"] = par
+        line["parity_ok"] = all(v["ok"] for v in par.values())
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return line
+
+
 def spawn_ranks(args, argv):
     """`bench.py --gpus N` outside a launcher: start N ranks as fresh child processes (torch.distributed.run) BEFORE this
     process touches a GPU, and pass their exit code on."""
@@ -548,6 +626,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=10_000_000, help="lines of synthetic PAF for the file->file leg (0 = skip)")
     ap.add_argument("--e2e-ref", type=int, default=1_000_000, help="prefix of that file the oracle CLI is timed on")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the e2e leg (0 = all cores)")
+    ap.add_argument("--detail", default="", help="file for the full report (per-kernel tables, counts, every leg); "
+                                                 "default gpurun_out/bench_detail.json.  stdout carries ONE line < 4 KB")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ
@@ -646,8 +726,8 @@ def main():
             pipes = {}
             for p in order:
                 t = timed[p]
-                e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n * world / (t["ms_per_step"] * 1e-3),
-                     "unit": "mappings/s", "steps": args.steps, "warmup": args.warmup, "counts": t["counts"],
+                e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
+                     "value": n * world / (t["ms_per_step"] * 1e-3), "unit": "mappings/s", "steps": args.steps, "warmup": args.warmup, "counts": t["counts"],
                      "roofline": roofline(p, n, args.steps, t, "sbig1_10m" if args.workload == "sbig1" else "100m"),
                      "kernels_ms_per_step": kernels_table(t, args.steps)}
                 if cpu_legs:
@@ -671,6 +751,7 @@ def main():
                 "steps": args.steps,
                 "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"],
+                "ms_per_step_unprofiled": head["ms_per_step_unprofiled"],
                 "higher_is_better": True,
                 "scaling": "weak",
                 "vs_baseline": None,
@@ -681,7 +762,7 @@ def main():
                                        (f"BASELINE.json configs[3] (synthetic 100 M mappings across 10 k (q,t) groups, 100-genome pangenome "
                                         f"shape; S-pan in SURVEY.md 8d): {n} mappings per GPU over {G * (G - 1)} "
                                         f"genome-pair groups ({G} single-chromosome genomes), pipeline={args.pipeline}"),
-                           "flags": FLAGS[args.pipeline], "mappings_per_gpu": n, "groups_per_gpu": G * (G - 1)},
+                           "flags": FLAGS[args.pipeline], "pipeline": args.pipeline, "mappings_per_gpu": n, "groups_per_gpu": G * (G - 1)},
                 "roofline": head["roofline"],
                 "cpu_baseline": head.get("cpu_baseline"),
                 "cpu_baseline_all_cores": head.get("cpu_baseline_all_cores"),
@@ -700,7 +781,17 @@ def main():
             out["end_to_end"] = end_to_end(args.e2e, args.e2e_ref, args.threads) if args.e2e > 0 else None
 
     if rank == 0:
-        print(json.dumps(out))
+        detail = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+            with open(detail, "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            print(f"bench.py: could not write {detail}: {e}", file=sys.stderr)
+            detail = None
+        line = json.dumps(summary_line(out, detail))
+        assert len(line) < MAX_LINE_BYTES, len(line)
+        print(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

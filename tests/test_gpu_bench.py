@@ -1,5 +1,5 @@
-"""bench.py contract (one JSON line with `roofline` and `cpu_baseline`, the three flag sets under `pipelines`, the S-big1
-leg, the PCIe leg) and, through its all-threads parity leg, a multi-million-record parity check of all three flag sets on
+"""bench.py contract (ONE stdout line under 4 KB with `roofline` and `cpu_baseline`; the full report -- the three flag sets
+under `pipelines`, the S-big1 leg, the PCIe leg -- in the --detail file) and, through its all-threads parity leg, a multi-million-record parity check of all three flag sets on
 a scaled-down S-pan workload.  Also --gpus validation, the strong-scaling mode on one GPU, and smoke()."""
 import json
 import os
@@ -13,18 +13,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_bench(*args, env=None, expect_rc=0):
+    """-> the full report (the --detail file) with the parsed stdout line under "_line" and its length under "_line_bytes"."""
+    import tempfile
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         e.pop(k, None)
     e.update(env or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, cwd=ROOT,
-                       timeout=900, env=e)
-    assert r.returncode == expect_rc, r.stderr[-2000:]
-    if expect_rc != 0:
-        return r
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--detail", detail], capture_output=True,
+                           text=True, cwd=ROOT, timeout=900, env=e)
+        assert r.returncode == expect_rc, r.stderr[-2000:]
+        if expect_rc != 0:
+            return r
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # stdout is the ONE line and nothing else
+        d = json.load(open(detail))
+    d["_line"], d["_line_bytes"] = json.loads(lines[0]), len(lines[0])
+    return d
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +39,25 @@ def line():
     return n, run_bench("--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1", "--cpu-sample", "300000",
                         "--parity-mappings", str(n), "--sbig1", "300000", "--sbig1-parity-sweep", "300000",
                         "--sbig1-parity-scaffold", "60000", "--e2e", "0")
+
+
+def test_stdout_line_is_small_and_complete(line):
+    """The driver keeps an 8 KB tail of stdout (round 2's 20 KB line could not be parsed): the line stays under 4 KB and
+    still carries the contract keys, `roofline`, `cpu_baseline` and one scalar per other leg."""
+    n, d = line
+    ln = d["_line"]
+    assert d["_line_bytes"] < 4096, d["_line_bytes"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_unprofiled", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores",
+              "sweep_ms_per_step", "full_ms_per_step", "sbig1_sweep_ms", "sbig1_default_ms", "sbig1_full_ms", "pcie_default_ms",
+              "pcie_sweep_ms", "parity", "parity_ok", "detail"):
+        assert k in ln, k
+    assert ln["value"] == pytest.approx(d["value"], rel=1e-6) and ln["ms_per_step"] == pytest.approx(d["ms_per_step"], abs=1e-3)
+    assert ln["parity_ok"] is True and len(ln["parity"]) == 6
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "pipeline_frac"):
+        assert k in ln["roofline"], k
+    assert ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] == 1
+    assert ln["ms_per_step_unprofiled"] > 0
 
 
 def test_bench_line_contract(line):
@@ -92,7 +117,7 @@ def test_gpus_flag_is_validated():
 def test_strong_scaling_mode_one_gpu():
     n = 2_000_000
     d = run_bench("--scaling", "strong", "--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1")
-    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["_line_bytes"] < 4096 and d["_line"]["strong"]["mappings_total"] == n
     ss = d["strong_scaling"]
     assert ss["mappings_total"] == n and ss["shard_mappings_rank0"] == n and ss["load_max_over_mean"] == 1.0
     for p in ("default", "sweep", "full"):
