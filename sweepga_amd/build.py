@@ -6,7 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsweepga_gpu.so")
-SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_scaffold.hip", "swg_ani.hip", "swg_shard.hip",
+SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_chain.hip", "swg_chain_table.hip", "swg_scaffold_sweep.hip", "swg_scaffold.hip",
+           "swg_union_find.hip", "swg_ani.hip", "swg_shard.hip",
            os.path.join("host", "paf_io.cpp"), os.path.join("host", "tree_filter.cpp"),
            os.path.join("host", "alnstats.cpp")]
 
@@ -78,13 +79,47 @@ def build_synth(force=False, verbose=False):
     return SYNTH
 
 
-def build(force=False, verbose=False):
-    if force or stale():
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
-        cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread"]
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs += [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "sweepga_gpu.h"))
+    return hs
+
+
+def build_lib(force=False, verbose=False):
+    """One object per translation unit (cached under csrc/build/, recompiled when the source or any header changed),
+    compiled side by side, then linked into libsweepga_gpu.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs + ["-lz", "-lpthread"])
+    return LIB
+
+
+def build(force=False, verbose=False):
+    if force or stale():
+        build_lib(force=force, verbose=verbose)
     build_cli(force=force, verbose=verbose)
     build_alnstats(force=force, verbose=verbose)
     build_synth(force=force, verbose=verbose)

@@ -1,0 +1,492 @@
+// Scaffold stage, part 2 (src/union_find.rs, src/paf_filter.rs:854-933, 449-455): chains from the predecessor forest.
+//
+//   labelling   chains = paths of the predecessor forest; heads by pointer jumping -- the role of
+//               union_find.rs (every union joins a path's tail, so the union-find root is the path head)
+//   aggregates  bounding box, sum of matches / block lengths per chain (atomics keyed by the head)
+//   ordering    chains are put in the reference's `all_chains` order: groups by first appearance in the
+//               plane-swept metadata order (genome-pair-major, paf_filter.rs:1037-1046, 761-770), then
+//               by head position
+//   filter      span / identity (paf_filter.rs:449-455), weighted identity with glibc-exact ln
+#include "swg_scaffold_internal.h"
+
+namespace swg_scaf {
+namespace {
+
+__global__ __launch_bounds__(EW) void seg_compose_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
+                                                         const uint32_t* __restrict__ v, int complement,
+                                                         uint64_t* __restrict__ out) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) out[p] = ((uint64_t)s_gidx[p] << 32) | (complement ? 0xffffffffu - v[p] : v[p]);
+}
+__global__ __launch_bounds__(EW) void group_first_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
+                                                                   const uint64_t* __restrict__ run_max,
+                                                                   uint32_t* __restrict__ group_first) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  if (p + 1 == m || head_flag[p + 1]) {  // last member of its group
+    const uint64_t v = run_max[p];
+    group_first[(uint32_t)(v >> 32)] = 0xffffffffu - (uint32_t)v;
+  }
+}
+
+// ---- chain labelling ---------------------------------------------------------------------------------------
+// hd[p] = pred[p] (or p), then followed through LDS as far as the block's own 1024-element range goes: predecessors
+// precede their successors and are usually close, so most elements reach their head here and the global pointer
+// jumping below only has to connect chains across ranges.
+constexpr int HEAD_SPAN = 1024;
+__global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
+                                                       uint32_t* __restrict__ hd) {
+  __shared__ uint32_t l[HEAD_SPAN];
+  const uint64_t base = (uint64_t)blockIdx.x * HEAD_SPAN;
+  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p < m) l[k] = pred[p] == NONE ? (uint32_t)p : pred[p];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p >= m) break;
+    uint32_t h = l[k];
+    while (h >= base) {  // h <= p < base + HEAD_SPAN
+      const uint32_t hh = l[h - base];
+      if (hh == h) break;
+      h = hh;
+    }
+    hd[p] = h;
+  }
+}
+// hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
+__global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t h = hd[p];
+  const uint32_t hh = hd[h];
+  if (hh != h) {
+    hd[p] = hh;
+    *changed = 1;
+  }
+}
+
+// Chain aggregates live at the head's slot.  Pass 1 seeds every slot with the element's own values (plain
+// stores, this is also the initialisation); pass 2 folds the non-head members into their head with atomics.
+// Most chains are singletons, so most elements never issue an atomic.
+__global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                                  const uint32_t* __restrict__ s_qe,
+                                                                  const uint32_t* __restrict__ s_ts,
+                                                                  const uint32_t* __restrict__ s_te,
+                                                                  const uint32_t* __restrict__ s_m,
+                                                                  const uint32_t* __restrict__ s_b,
+                                                                  uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
+                                                                  uint32_t* __restrict__ h_te,
+                                                                  unsigned long long* __restrict__ h_sm,
+                                                                  unsigned long long* __restrict__ h_sb,
+                                                                  uint32_t* __restrict__ is_head) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  is_head[p] = hd[p] == p ? 1u : 0u;
+  h_qe[p] = s_qe[p];
+  h_ts[p] = s_ts[p];
+  h_te[p] = s_te[p];
+  h_sm[p] = s_m[p];
+  h_sb[p] = s_b[p];
+}
+// A member is usually a few positions after its head, so a block first folds the members whose head lies inside its
+// own 1024-element range into LDS (LDS atomics), then merges each touched partial aggregate into the head's seeded
+// global slot with one set of atomics per chain instead of one per member; members whose head lies before the range
+// go to global memory directly.
+constexpr int AGG_SPAN = 1024;
+__global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                             const uint32_t* __restrict__ s_qe,
+                                                             const uint32_t* __restrict__ s_ts,
+                                                             const uint32_t* __restrict__ s_te,
+                                                             const uint32_t* __restrict__ s_m,
+                                                             const uint32_t* __restrict__ s_b,
+                                                             uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
+                                                             uint32_t* __restrict__ h_te,
+                                                             unsigned long long* __restrict__ h_sm,
+                                                             unsigned long long* __restrict__ h_sb) {
+  __shared__ uint32_t l_qe[AGG_SPAN], l_ts[AGG_SPAN], l_te[AGG_SPAN], l_cnt[AGG_SPAN];
+  __shared__ unsigned long long l_sm[AGG_SPAN], l_sb[AGG_SPAN];
+  const uint64_t base = (uint64_t)blockIdx.x * AGG_SPAN;
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    l_qe[k] = 0;
+    l_ts[k] = 0xffffffffu;
+    l_te[k] = 0;
+    l_cnt[k] = 0;
+    l_sm[k] = 0;
+    l_sb[k] = 0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    const uint64_t p = base + k;
+    if (p >= m) break;
+    const uint32_t h = hd[p];
+    if (h == p) continue;
+    if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
+      const uint32_t l = (uint32_t)(h - base);
+      atomicMax(&l_qe[l], s_qe[p]);
+      atomicMin(&l_ts[l], s_ts[p]);
+      atomicMax(&l_te[l], s_te[p]);
+      atomicAdd(&l_sm[l], (unsigned long long)s_m[p]);
+      atomicAdd(&l_sb[l], (unsigned long long)s_b[p]);
+      l_cnt[l] = 1;
+    } else {
+      atomicMax(&h_qe[h], s_qe[p]);
+      atomicMin(&h_ts[h], s_ts[p]);
+      atomicMax(&h_te[h], s_te[p]);
+      atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
+      atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+    if (!l_cnt[k]) continue;
+    const uint64_t h = base + k;  // a head of this range with members in it; members of later ranges use atomics too
+    atomicMax(&h_qe[h], l_qe[k]);
+    atomicMin(&h_ts[h], l_ts[k]);
+    atomicMax(&h_te[h], l_te[k]);
+    atomicAdd(&h_sm[h], l_sm[k]);
+    atomicAdd(&h_sb[h], l_sb[k]);
+  }
+}
+
+// min original index per (q,t,strand) group, and per genome pair (prefix-last) over ALL alive records
+__global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                         uint32_t m, const uint32_t* __restrict__ s_idx,
+                                                         uint32_t* __restrict__ group_first) {
+  // one wavefront per (q,t,strand) group: members are contiguous in survivor order
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * EW) >> 6;
+  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
+    const uint32_t b = group_begin[g];
+    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+    uint32_t v = 0xffffffffu;
+    for (uint32_t p = b + lane; p < e; p += 64) {
+      const uint32_t x = s_idx[p];
+      if (x < v) v = x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(v, o, 64);
+      if (t < v) v = t;
+    }
+    if (lane == 0) group_first[g] = v;
+  }
+}
+
+// First (lowest) original index of every genome pair over the alive records, in ORIGINAL order (coalesced
+// reads).  Two filters keep the atomics rare: (1) a wavefront whose 256 records all belong to one pair (inputs
+// grouped by pair) reduces to one atomic; (2) otherwise (interleaved pairs) a plain cached read of the table --
+// it only ever decreases, so a stale value is merely conservative -- drops every record that cannot lower it.
+__global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const uint8_t* __restrict__ alive,
+                                                               const uint32_t* __restrict__ q_id,
+                                                               const uint32_t* __restrict__ t_id,
+                                                               const uint32_t* __restrict__ seq_genome,
+                                                               PairTable table) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const uint64_t stride = (uint64_t)gridDim.x * EW * U;
+  // whole waves stay in the loop together (the bound is wave-uniform), so the cross-lane ops are safe
+  for (uint64_t w0 = ((uint64_t)blockIdx.x * EW + (threadIdx.x & ~63)) * U; w0 < n; w0 += stride) {
+    const uint64_t i0 = w0 + (uint64_t)lane * U;
+    unsigned long long L[U];  // (gq << 32) | gt
+    bool live[U];
+    uint32_t first_i = 0xffffffffu;
+    unsigned long long first_L = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t i = i0 + u;
+      live[u] = i < n && alive[i] != 0;
+      L[u] = live[u] ? ((unsigned long long)seq_genome[q_id[i]] << 32) | seq_genome[t_id[i]] : 0ull;
+      if (live[u] && first_i == 0xffffffffu) {
+        first_i = (uint32_t)i;
+        first_L = L[u];
+      }
+    }
+    // wave minimum of first_i, and the pair of the lane holding it
+    uint32_t vmin = first_i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t x = __shfl_xor(vmin, o, 64);
+      if (x < vmin) vmin = x;
+    }
+    if (vmin == 0xffffffffu) continue;  // no live record in this wave's span
+    const uint64_t holder = __ballot(first_i == vmin);
+    const unsigned long long L0 = __shfl(first_L, __builtin_ctzll(holder), 64);
+    bool same = true;
+#pragma unroll
+    for (int u = 0; u < U; ++u) same = same && (!live[u] || L[u] == L0);
+    if (__all(same)) {
+      if (lane == 0) {
+        uint32_t* slot = pair_slot(table, (uint32_t)(L0 >> 32), (uint32_t)L0);
+        if (*slot > vmin) atomicMin(slot, vmin);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (live[u]) {
+          uint32_t* slot = pair_slot(table, (uint32_t)(L[u] >> 32), (uint32_t)L[u]);
+          if (*slot > (uint32_t)(i0 + u)) atomicMin(slot, (uint32_t)(i0 + u));
+        }
+    }
+  }
+}
+
+// all_chains order = (q,t,strand) groups by first appearance, chains of a group by head position.  Chains in
+// head-position order are already contiguous per group, so only the GROUPS are sorted; a chain's place is its
+// group's base plus its rank inside the group.
+__global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                        uint32_t m, const uint32_t* __restrict__ cpos_excl, uint32_t nc,
+                                                        const uint32_t* __restrict__ s_idx,
+                                                        const uint32_t* __restrict__ group_first,
+                                                        const uint32_t* __restrict__ q_id,
+                                                        const uint32_t* __restrict__ t_id,
+                                                        const uint32_t* __restrict__ seq_genome, bool pair_major,
+                                                        PairTable gp_first, int idx_bits,
+                                                        uint64_t* __restrict__ g_key, uint32_t* __restrict__ g_val,
+                                                        uint32_t* __restrict__ g_first_chain,
+                                                        uint32_t* __restrict__ g_nchains) {
+  uint32_t g = blockIdx.x * EW + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t b = group_begin[g];
+  const uint32_t first = cpos_excl[b];  // a group's first member is always a chain head
+  const uint32_t next = (g + 1 < n_groups) ? cpos_excl[group_begin[g + 1]] : nc;
+  (void)m;
+  g_first_chain[g] = first;
+  g_nchains[g] = next - first;
+  const uint32_t i = s_idx[b];
+  // !pair_major: groups in plain first-appearance order of the records as given
+  // (merge_mappings_into_chains called on its own); otherwise genome-pair-major, which is the order
+  // apply_plane_sweep_to_mappings leaves the metadata in (paf_filter.rs:1037-1046, 1117-1120).
+  uint64_t hi = 0;
+  if (pair_major) hi = pair_get(gp_first, seq_genome[q_id[i]], seq_genome[t_id[i]]);
+  g_key[g] = (hi << idx_bits) | group_first[g];
+  g_val[g] = g;
+}
+__global__ __launch_bounds__(EW) void group_sizes_sorted_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
+                                                                const uint32_t* __restrict__ g_nchains,
+                                                                uint32_t* __restrict__ sizes) {
+  uint32_t r = blockIdx.x * EW + threadIdx.x;
+  if (r < n_groups) sizes[r] = g_nchains[g_sorted[r]];
+}
+__global__ __launch_bounds__(EW) void group_base_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
+                                                        const uint32_t* __restrict__ base_sorted,
+                                                        uint32_t* __restrict__ g_base) {
+  uint32_t r = blockIdx.x * EW + threadIdx.x;
+  if (r < n_groups) g_base[g_sorted[r]] = base_sorted[r];
+}
+// per chain head: position-order ordinal c -> all_chains index c2 (and the inverse)
+__global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
+                                                         const uint32_t* __restrict__ cpos_excl,
+                                                         const uint32_t* __restrict__ s_gidx,
+                                                         const uint32_t* __restrict__ g_first_chain,
+                                                         const uint32_t* __restrict__ g_base,
+                                                         uint32_t* __restrict__ ch_head, uint32_t* __restrict__ order) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m || !is_head[p]) return;
+  const uint32_t c = cpos_excl[p];
+  const uint32_t g = s_gidx[p];
+  ch_head[c] = (uint32_t)p;
+  order[g_base[g] + (c - g_first_chain[g])] = c;
+}
+
+// chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
+__global__ __launch_bounds__(EW) void chain_columns_kernel(
+    uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
+    const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
+    const uint32_t* __restrict__ h_te, const unsigned long long* __restrict__ h_sm,
+    const unsigned long long* __restrict__ h_sb, const uint64_t* __restrict__ s_grp, const uint32_t* __restrict__ s_a,
+    const uint32_t* __restrict__ a_dpair, uint32_t n_seq, uint64_t min_len, double min_ident,
+    uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
+    uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
+    double* __restrict__ C_wid, uint8_t* __restrict__ C_strand, uint32_t* __restrict__ C_dpair,
+    uint8_t* __restrict__ C_ok, uint32_t* __restrict__ rank_of_poschain) {
+  uint64_t c2 = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c2 >= nc) return;
+  const uint32_t c = order[c2];
+  rank_of_poschain[c] = (uint32_t)c2;
+  const uint32_t p = ch_head[c];
+  const uint64_t g = s_grp[p];
+  const uint64_t pair = g >> 1;
+  const uint32_t qs = s_qs[p], qe = h_qe[p], ts = h_ts[p], te = h_te[p];
+  C_qid[c2] = (uint32_t)(pair / n_seq);
+  C_tid[c2] = (uint32_t)(pair % n_seq);
+  C_strand[c2] = (uint8_t)(g & 1);
+  C_qs[c2] = qs;
+  C_qe[c2] = qe;
+  C_ts[c2] = ts;
+  C_te[c2] = te;
+  C_dpair[c2] = a_dpair[s_a[p]];
+  const uint64_t total_length = (uint64_t)qe - (uint64_t)qs;  // q_max - q_min
+  const uint64_t sm = h_sm[p], sb = h_sb[p];
+  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
+  double lcg = 0.0;
+  if (gap_length > 0) {
+    lcg = swg_log_glibc((double)gap_length);
+    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
+  }
+  const double eff = __dadd_rn((double)sb, lcg);
+  const double wid = eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
+  C_wid[c2] = wid;
+  C_ok[c2] = (total_length >= min_len && wid >= min_ident) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                            const uint32_t* __restrict__ cpos_excl,
+                                                            const uint32_t* __restrict__ rank_of_poschain,
+                                                            uint32_t* __restrict__ s_chain) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) s_chain[p] = rank_of_poschain[cpos_excl[hd[p]]];
+}
+
+}  // namespace
+
+int pair_table_make(swg_ctx* ctx, uint32_t n_genome, uint64_t bound, PairTable* t) {
+  hipStream_t st = ctx->stream;
+  t->n_genome = n_genome;
+  t->dense = nullptr;
+  t->keys = nullptr;
+  t->vals = nullptr;
+  t->mask = 0;
+  const uint64_t g2 = (uint64_t)n_genome * n_genome;
+  if (g2 <= DENSE_PAIR_LIMIT) {
+    t->dense = swg_alloc<uint32_t>(ctx, g2);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(g2), EW, 0, st>>>(g2, t->dense, NONE));
+    SWG_KERNEL_CHECK(ctx);
+    return SWG_OK;
+  }
+  uint64_t cap = 1024;
+  while (cap < 2 * bound) cap <<= 1;
+  if (cap > (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "genome-pair table beyond 2^32 slots");
+  t->keys = swg_alloc<unsigned long long>(ctx, cap);
+  t->vals = swg_alloc<uint32_t>(ctx, cap);
+  SWG_CHECK_ARENA(ctx);
+  t->mask = (uint32_t)(cap - 1);
+  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(cap), EW, 0, st>>>(cap, reinterpret_cast<uint64_t*>(t->keys), ~0ull));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(cap), EW, 0, st>>>(cap, t->vals, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, uint64_t min_len, double min_ident,
+                      bool genome_pair_major, ChainBuild* out, const ChainWork& W) {
+  const uint64_t n = r->n;
+  hipStream_t st = ctx->stream;
+  ChainBuild& B = *out;
+  const uint64_t m = B.m, n_groups = W.n_groups;
+  uint32_t *s_qs = W.s_qs, *s_qe = W.s_qe, *s_ts = W.s_ts, *s_te = W.s_te, *s_m = W.s_m, *s_b = W.s_b;
+  uint64_t* s_grp = W.s_grp;
+  uint32_t *head_flag = W.head_flag, *s_gidx = W.s_gidx, *group_begin = W.group_begin, *pred = W.pred;
+  uint64_t* d_tot = W.d_tot;
+  uint32_t* hd = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_qe = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_ts = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* h_te = swg_alloc<uint32_t>(ctx, m);
+  unsigned long long* h_sm = swg_alloc<unsigned long long>(ctx, m);
+  unsigned long long* h_sb = swg_alloc<unsigned long long>(ctx, m);
+  uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* group_first = swg_alloc<uint32_t>(ctx, m);
+  PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
+  uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
+  SWG_CHECK_ARENA(ctx);
+  // ---- labelling by pointer jumping
+  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd));
+  SWG_KERNEL_CHECK(ctx);
+  for (int round = 0; round < 64; ++round) {
+    SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
+    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t ch = 0;
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
+    if ((uint32_t)ch == 0) break;
+  }
+  // ---- aggregates
+  SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
+                                                                                  h_te, h_sm, h_sb, is_head));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
+                                                                        h_sm, h_sb));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
+  uint64_t nc = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
+  // ---- all_chains order
+  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, group_first, NONE));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(pair_table_make(ctx, r->n_genome_last, B.n_pairs, &gp_first));
+  if (m / n_groups > 8192) {
+    swg_arena_mark mk = swg_arena_save(ctx);
+    uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, B.s_idx, 1, comp));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
+    SWG_LAUNCH(ctx, "group_first_from_scan", group_first_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, group_first));
+    swg_arena_restore(ctx, mk);
+  } else {
+    uint64_t blocks = (n_groups + 3) / 4;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+    if (blocks > max_blocks) blocks = max_blocks;
+    SWG_LAUNCH(ctx, "group_first", group_first_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m,
+                                                                               B.s_idx, group_first));
+  }
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
+                                                                                    r->seq_genome_last, gp_first));
+  SWG_KERNEL_CHECK(ctx);
+  uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
+  uint64_t* g_key = swg_alloc<uint64_t>(ctx, n_groups);
+  uint64_t* g_key_tmp = swg_alloc<uint64_t>(ctx, n_groups);
+  uint32_t* g_sorted = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_sorted_tmp = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_first_chain = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_nchains = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_sizes = swg_alloc<uint32_t>(ctx, n_groups);
+  uint32_t* g_base = swg_alloc<uint32_t>(ctx, n_groups);
+  ChainTable& T = B.T;
+  T.nc = nc;
+  T.qid = swg_alloc<uint32_t>(ctx, nc);
+  T.tid = swg_alloc<uint32_t>(ctx, nc);
+  T.qs = swg_alloc<uint32_t>(ctx, nc);
+  T.qe = swg_alloc<uint32_t>(ctx, nc);
+  T.ts = swg_alloc<uint32_t>(ctx, nc);
+  T.te = swg_alloc<uint32_t>(ctx, nc);
+  T.wid = swg_alloc<double>(ctx, nc);
+  T.ok = swg_alloc<uint8_t>(ctx, nc);
+  B.C_strand = swg_alloc<uint8_t>(ctx, nc);
+  B.C_dpair = swg_alloc<uint32_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
+  const unsigned gblk = nblk(n_groups);
+  SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, cpos, (uint32_t)nc,
+                                                           B.s_idx, group_first, r->q_id, r->t_id, r->seq_genome_last,
+                                                           genome_pair_major, gp_first, idx_bits, g_key, g_sorted, g_first_chain,
+                                                           g_nchains));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, &g_key, &g_sorted, &g_key_tmp, &g_sorted_tmp, n_groups, 0, 2 * idx_bits));
+  SWG_LAUNCH(ctx, "group_sizes_sorted", group_sizes_sorted_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_nchains, g_sizes));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, g_sizes, g_sizes, n_groups, nullptr));
+  SWG_LAUNCH(ctx, "group_base", group_base_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_sizes, g_base));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
+                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
+                                       r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
+                                       B.C_strand, B.C_dpair, T.ok, rank_of));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, cpos, rank_of, B.s_chain));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+}  // namespace swg_scaf

@@ -1,2168 +1,14 @@
-// Scaffold stage of the filter (src/paf_filter.rs:436-747) on the device:
+// Scaffold stage of the filter (src/paf_filter.rs:436-747) on the device: the driver and its last part.
 //
-//   sort A      all step-1 survivors by (query seq, target seq, strand, q_start), stable
-//               (groups of merge_mappings_into_chains, paf_filter.rs:761-777; ties fall to input order)
-//   chaining    best-buddy predecessor selection (paf_filter.rs:784-851), one wavefront per
-//               (q, t, strand) group: sequential over i as the greedy demands, the j-window spread over
-//               the 64 lanes, minimum by wave reduction
-//   labelling   chains = paths of the predecessor forest; heads by pointer jumping -- the role of
-//               union_find.rs (every union joins a path's tail, so the union-find root is the path head)
-//   aggregates  bounding box, sum of matches / block lengths per chain (atomics keyed by the head)
-//   ordering    chains are put in the reference's `all_chains` order: groups by first appearance in the
-//               plane-swept metadata order (genome-pair-major, paf_filter.rs:1037-1046, 761-770), then
-//               by head position
-//   filter      span / identity (paf_filter.rs:449-455), weighted identity with glibc-exact ln
-//   sweep       plane_sweep_both per chromosome pair (plane_sweep_scaffold.rs:108-251) on the sweep kernels
-//   numbering   chain_N in plane_sweep_scaffolds' output order (genome pair -> chromosome pair -> index)
+//   chains      swg_chain.hip (sort A, best-buddy predecessors) + swg_chain_table.hip (labels, aggregates, order, filter)
+//   sweep       swg_scaffold_sweep.hip: plane_sweep_both per chromosome pair + chain_N numbering
 //   anchors     members of kept chains; inversion capture (paf_filter.rs:535-597)
 //   rescue      per chromosome pair, anchors sorted by query centre, window search (paf_filter.rs:599-747)
-#include <cstdio>
-#include <cstdlib>
-#include <vector>
+#include "swg_scaffold_internal.h"
 
-#include "swg_log.h"
-#include "swg_pipeline.h"
+using namespace swg_scaf;
 
 namespace {
-
-constexpr int EW = 256;
-constexpr uint32_t NONE = 0xffffffffu;
-inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
-
-__global__ __launch_bounds__(EW) void fill_u32_kernel(uint64_t n, uint32_t* __restrict__ p, uint32_t v) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-__global__ __launch_bounds__(EW) void fill_u64_kernel(uint64_t n, uint64_t* __restrict__ p, uint64_t v) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-__global__ __launch_bounds__(EW) void iota_u32_kernel(uint64_t n, uint32_t* __restrict__ p) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
-}
-
-// ---- sort A -----------------------------------------------------------------------------------------
-// key = (((q * n_seq + t) * 2 + strand) << pos_bits) | q_start      value = original index
-__global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
-                                                        const uint32_t* __restrict__ q_id,
-                                                        const uint32_t* __restrict__ t_id,
-                                                        const uint8_t* __restrict__ strand,
-                                                        const uint32_t* __restrict__ q_start, uint32_t n_seq,
-                                                        int pos_bits, uint64_t* __restrict__ key) {
-  // a_idx is either ascending (coalesced reads) or the query axis' sorted order (gathers: neighbouring blocks on one XCD)
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a >= M) return;
-  const uint32_t i = a_idx[a];
-  const uint64_t g = ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
-  key[a] = (g << pos_bits) | q_start[i];
-}
-
-// After sort A: per A-position columns + pair boundaries.
-__global__ __launch_bounds__(EW) void gatherA_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
-                                                     const uint32_t* __restrict__ idxA,
-                                                     const uint32_t* __restrict__ q_end,
-                                                     const uint32_t* __restrict__ t_start,
-                                                     const uint32_t* __restrict__ t_end,
-                                                     const uint8_t* __restrict__ keep1, int pos_bits,
-                                                     uint32_t* __restrict__ a_qe, uint32_t* __restrict__ a_ts,
-                                                     uint32_t* __restrict__ a_te, uint8_t* __restrict__ a_keep,
-                                                     uint32_t* __restrict__ pair_flag) {
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a >= M) return;
-  const uint32_t i = idxA[a];
-  a_qe[a] = q_end[i];
-  a_ts[a] = t_start[i];
-  a_te[a] = t_end[i];
-  a_keep[a] = keep1[i] ? 1 : 0;
-  const uint64_t pair = keyA[a] >> (pos_bits + 1);
-  pair_flag[a] = (a == 0 || (keyA[a - 1] >> (pos_bits + 1)) != pair) ? 1u : 0u;
-}
-
-// dense pair id of every A position: inclusive count of pair heads - 1 (scan result is exclusive)
-__global__ __launch_bounds__(EW) void dense_from_scan_kernel(uint64_t M, const uint32_t* __restrict__ excl,
-                                                             const uint32_t* __restrict__ flag,
-                                                             uint32_t* __restrict__ dense) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (a < M) dense[a] = excl[a] + flag[a] - 1;
-}
-
-// ---- survivors (mapping-sweep survivors in A order) -----------------------------------------------------
-// The same when every record of sort A is a member (no mapping-level filter ran, or it kept everything): positions
-// coincide, so the ends / targets / indices of sort A are used as they are and only what sort A does not hold is produced.
-__global__ __launch_bounds__(EW) void gatherS_all_kernel(uint64_t m, const uint64_t* __restrict__ keyA,
-                                                         const uint32_t* __restrict__ idxA,
-                                                         const uint32_t* __restrict__ matches,
-                                                         const uint32_t* __restrict__ block_len, int pos_bits,
-                                                         uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_m,
-                                                         uint32_t* __restrict__ s_b, uint64_t* __restrict__ s_grp,
-                                                         uint32_t* __restrict__ head_flag) {
-  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint64_t k = keyA[p];
-  const uint32_t i = idxA[p];
-  s_qs[p] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
-  s_m[p] = matches[i];
-  s_b[p] = block_len[i];
-  const uint64_t g = k >> pos_bits;
-  s_grp[p] = g;
-  head_flag[p] = (p == 0 || (keyA[p - 1] >> pos_bits) != g) ? 1u : 0u;
-}
-__global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t* __restrict__ s_a,
-                                                     const uint64_t* __restrict__ keyA,
-                                                     const uint32_t* __restrict__ idxA,
-                                                     const uint32_t* __restrict__ a_qe,
-                                                     const uint32_t* __restrict__ a_ts,
-                                                     const uint32_t* __restrict__ a_te,
-                                                     const uint32_t* __restrict__ matches,
-                                                     const uint32_t* __restrict__ block_len, int pos_bits,
-                                                     uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
-                                                     uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
-                                                     uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
-                                                     uint32_t* __restrict__ s_idx, uint64_t* __restrict__ s_grp,
-                                                     uint32_t* __restrict__ head_flag) {
-  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t a = s_a[p];
-  const uint64_t k = keyA[a];
-  const uint32_t i = idxA[a];
-  s_qs[p] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
-  s_qe[p] = a_qe[a];
-  s_ts[p] = a_ts[a];
-  s_te[p] = a_te[a];
-  s_m[p] = matches[i];
-  s_b[p] = block_len[i];
-  s_idx[p] = i;
-  const uint64_t g = k >> pos_bits;
-  s_grp[p] = g;
-  bool head = p == 0;
-  if (!head) head = (keyA[s_a[p - 1]] >> pos_bits) != g;
-  head_flag[p] = head ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
-                                                          const uint32_t* __restrict__ gidx_excl,
-                                                          uint32_t* __restrict__ s_gidx,
-                                                          uint32_t* __restrict__ group_begin) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t g = gidx_excl[p] + head_flag[p] - 1;
-  s_gidx[p] = g;
-  if (head_flag[p]) group_begin[g] = (uint32_t)p;
-}
-
-// ---- best-buddy chaining (paf_filter.rs:784-851) -----------------------------------------------------------
-// The reference's greedy is sequential in i (later i read best_pred_score[] written by earlier i), but the
-// expensive part of a step -- the distance d(i, j) to every j of the window -- does not depend on that state.
-// So the work is split:
-//   chain_candidates : parallel, one thread per i: the KC smallest (d, j) over the valid j of i's window
-//                      (both gaps within the limit), sorted by (d, j); plus how many valid j there were.
-//   chain_select     : one wavefront per unit (a group cut where no window can straddle, chain_cuts), sequential
-//                      in i: i takes the first of its candidates with d < best_pred_score[j] -- which is the
-//                      reference's choice, because any valid j outside the list is worse than every listed one.
-//                      best_pred_score of the next 128 elements lives in registers (one element per lane and
-//                      block); a step is a handful of v_readlane + scalar compares.  Only when all KC listed
-//                      candidates are blocked AND the window held more than KC valid j is the window
-//                      re-evaluated in full (wave-parallel, global memory).
-constexpr int KC = 4;
-constexpr uint32_t BIG_UNIT = 2048;  // units at least this long take the block-speculative path (spec_round_kernel)
-
-__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
-  return ((uint64_t)readlane_u32((uint32_t)(v >> 32), l) << 32) | readlane_u32((uint32_t)v, l);
-}
-
-// minimum of a u64 over the wavefront (all lanes get it)
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint64_t t = __shfl_xor(v, o, 64);
-    if (t < v) v = t;
-  }
-  return v;
-}
-
-// d(i, j) of paf_filter.rs:798-836; returns false when a gap exceeds the limit
-__device__ __forceinline__ bool chain_dist(bool minus, uint64_t qe_i, uint64_t ts_i, uint64_t te_i, uint64_t qs_j,
-                                           uint64_t ts_j, uint64_t te_j, uint64_t max_gap, uint64_t fifth, uint64_t* d) {
-  uint64_t q_gap, r_gap;
-  if (qs_j >= qe_i) {
-    q_gap = qs_j - qe_i;
-  } else {
-    const uint64_t ov = qe_i - qs_j;
-    q_gap = ov <= fifth ? ov : max_gap + 1;
-  }
-  if (!minus) {
-    if (ts_j >= te_i) {
-      r_gap = ts_j - te_i;
-    } else {
-      const uint64_t ov = te_i - ts_j;
-      r_gap = ov <= fifth ? ov : max_gap + 1;
-    }
-  } else if (ts_i >= te_j) {
-    r_gap = ts_i - te_j;
-  } else {
-    const uint64_t ov = te_j - ts_i;
-    r_gap = ov <= fifth ? ov : max_gap + 1;
-  }
-  if (q_gap > max_gap || r_gap > max_gap) return false;
-  *d = q_gap * q_gap + r_gap * r_gap;  // wrapping, as release Rust
-  return true;
-}
-
-__global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                              const uint32_t* __restrict__ group_begin,
-                                                              uint32_t n_groups, const uint64_t* __restrict__ s_grp,
-                                                              const uint32_t* __restrict__ s_qs,
-                                                              const uint32_t* __restrict__ s_qe,
-                                                              const uint32_t* __restrict__ s_ts,
-                                                              const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                              unsigned long long* __restrict__ c_d,  // [KC][m]
-                                                              uint32_t* __restrict__ c_j,            // [KC][m]
-                                                              uint32_t* __restrict__ c_n,            // valid count (saturating)
-                                                              uint32_t* __restrict__ c_ext) {        // window extent in elements
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t g = s_gidx[p];
-  const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
-  const bool minus = (s_grp[p] & 1ull) != 0;
-  const uint64_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
-  const uint64_t bound = qe_i + max_gap, fifth = max_gap / 5;
-  uint64_t bd[KC];
-  uint32_t bj[KC];
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    bd[k] = ~0ull;
-    bj[k] = NONE;
-  }
-  uint32_t count = 0, ext = 0;
-  for (uint32_t j = (uint32_t)p + 1; j < e; ++j) {
-    const uint64_t qs_j = s_qs[j];
-    if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
-    ext = j - (uint32_t)p;
-    uint64_t d;
-    if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
-    if (count < 0xffffffffu) ++count;
-    // insert (d, j) keeping (d asc, j asc): j only grows, so the new entry goes after every entry with d' <= d
-    // (strict `<` finds that slot); from there on every entry moves down one slot, equal distances included
-    if (d < bd[KC - 1]) {
-      uint64_t cd = d;
-      uint32_t cj = j;
-      bool placed = false;
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        if (placed || cd < bd[k]) {
-          placed = true;
-          const uint64_t td = bd[k];
-          const uint32_t tj = bj[k];
-          bd[k] = cd;
-          bj[k] = cj;
-          cd = td;
-          cj = tj;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < KC; ++k) {
-    c_d[(uint64_t)k * m + p] = bd[k];
-    c_j[(uint64_t)k * m + p] = bj[k];
-  }
-  c_n[p] = count;
-  c_ext[p] = ext;
-}
-
-// The KC smallest (d, j) of a wavefront, every lane holding its own list sorted by (d asc, j asc) and every candidate
-// living in exactly one lane: butterfly all-reduce, six dependent shuffle rounds.  Merging two sorted KC-lists: the
-// element-wise minimum of A[k] and B[KC-1-k] is the KC smallest of the union as a bitonic sequence, which two
-// compare-exchange stages sort.  On return every lane holds the wavefront's list.
-static_assert(KC == 4, "wave_top_kc is written for four candidates");
-__device__ __forceinline__ bool cand_less(uint64_t ad, uint32_t aj, uint64_t bd_, uint32_t bj_) {
-  return ad < bd_ || (ad == bd_ && aj < bj_);
-}
-__device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    uint64_t pd[KC];
-    uint32_t pj[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      pd[k] = __shfl_xor(bd[k], o, 64);
-      pj[k] = __shfl_xor(bj[k], o, 64);
-    }
-#pragma unroll
-    for (int k = 0; k < KC; ++k)
-      if (cand_less(pd[KC - 1 - k], pj[KC - 1 - k], bd[k], bj[k])) {
-        bd[k] = pd[KC - 1 - k];
-        bj[k] = pj[KC - 1 - k];
-      }
-    auto cx = [&](int x, int y) {
-      if (cand_less(bd[y], bj[y], bd[x], bj[x])) {
-        const uint64_t td = bd[x];
-        const uint32_t tj = bj[x];
-        bd[x] = bd[y];
-        bj[x] = bj[y];
-        bd[y] = td;
-        bj[y] = tj;
-      }
-    };
-    cx(0, 2);
-    cx(1, 3);
-    cx(0, 1);
-    cx(2, 3);
-  }
-}
-
-// The same candidate lists for deep groups (windows of hundreds to thousands of elements, S-big1): one WAVEFRONT per i.
-// A thread per i walks its ~2,000-element window alone and a wavefront waits for its longest window (a 500-kb mapping
-// has a window ten times the average); here the 64 lanes take the window 64 elements at a time (coalesced loads, the
-// neighbouring i's re-read the same lines from L1/L2) and every lane keeps its own KC best in (d, j) order.
-// The KC best of the wavefront are drawn by one butterfly merge of the lanes' lists (wave_top_kc).  32-bit arithmetic
-// (coordinates are u32; a gap limit beyond 2^32 cannot bind, so it is clamped).  The lists are identical to
-// chain_candidates_kernel's.
-// The scan stops early: j runs in q_start order, so past q_end[i] the query gap only grows, and once KC candidates are held
-// whose distance is at most gap^2 of the next unseen element no later j can enter the list (d >= gap^2; equal distances keep
-// the smaller j).  The test needs no merge of the lanes' lists -- "how many held entries are <= T" is four compares per
-// lane and four ballots -- so it runs after every batch (an earlier attempt derived the KC-th best itself per batch, which
-// cost more than the batches it saved; profiles/README.md).  After a cut the exact number of valid j is unknown: the count
-// is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the selection re-evaluate
-// a window that has nothing left to offer (same result); the window extent then comes from a galloping search.
-constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
-__global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                                   const uint32_t* __restrict__ group_begin,
-                                                                   uint32_t n_groups, const uint64_t* __restrict__ s_grp,
-                                                                   const uint32_t* __restrict__ s_qs,
-                                                                   const uint32_t* __restrict__ s_qe,
-                                                                   const uint32_t* __restrict__ s_ts,
-                                                                   const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                                   unsigned long long* __restrict__ c_d,
-                                                                   uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
-                                                                   uint32_t* __restrict__ c_ext) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
-  const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
-  const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
-  const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap and grows with the query gap
-  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
-    const uint32_t g = s_gidx[p];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
-    const bool minus = (s_grp[p] & 1ull) != 0;
-    const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
-    const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
-    const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
-    uint64_t bd[KC];
-    uint32_t bj[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      bd[k] = ~0ull;
-      bj[k] = NONE;
-    }
-    uint32_t count = 0, ext = 0, cut_at = 0;
-    bool cut = false;
-    for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
-      const uint32_t j = j0 + lane;
-      const bool in = j < e;
-      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
-      const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
-      const uint64_t wmask = __ballot(inwin);
-      ext += (uint32_t)__popcll(wmask);
-      if (inwin) {
-        // d(i, j) of paf_filter.rs:798-836 (this block is the wave kernel's)
-        uint32_t q_gap, r_gap;
-        bool ok = true;
-        if (qs_j >= qe_i) {
-          q_gap = qs_j - qe_i;
-        } else {
-          q_gap = qe_i - qs_j;
-          if (q_gap > fifth) {
-            ok = wrap;
-            q_gap = 0;
-          }
-        }
-        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
-        const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
-        if (a >= b) {
-          r_gap = a - b;
-        } else {
-          r_gap = b - a;
-          if (r_gap > fifth) {
-            ok = ok && wrap;
-            r_gap = 0;
-          }
-        }
-        if (ok && q_gap <= gap && r_gap <= gap) {
-          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
-          ++count;
-          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
-            uint64_t cd = d;
-            uint32_t cj = j;
-            bool placed = false;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-              if (placed || cd < bd[k]) {
-                placed = true;
-                const uint64_t td = bd[k];
-                const uint32_t tj = bj[k];
-                bd[k] = cd;
-                bj[k] = cj;
-                cd = td;
-                cj = tj;
-              }
-            }
-          }
-        }
-      }
-      if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
-      if (can_cut && j0 + 64 < e) {
-        // every later element starts at or after this batch's last one: its query gap is at least `qg`
-        const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
-        if (q_last >= qe_i) {
-          const uint64_t qg = (uint64_t)q_last - qe_i;
-          const uint64_t T = qg * qg;
-          const int c = (bd[0] <= T) + (bd[1] <= T) + (bd[2] <= T) + (bd[3] <= T);  // the lists are ascending
-          const int held = __popcll(__ballot(c >= 1)) + __popcll(__ballot(c >= 2)) + __popcll(__ballot(c >= 3)) +
-                           __popcll(__ballot(c >= 4));
-          if (held >= KC) {
-            cut = true;
-            cut_at = j0 + 64;
-            break;
-          }
-        }
-      }
-    }
-    if (cut) {
-      // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
-      // a time (one probe per lane), then resolve inside the 64-element block that holds the boundary.
-      uint32_t lo = cut_at - 1;  // last element known to be inside the window
-      bool found = false;
-      while (!found) {
-        const uint64_t pj = (uint64_t)lo + 1 + (uint64_t)lane * 64;  // first element of the lane's block
-        const bool inside = pj < e && s_qs[pj] <= bound;
-        const uint64_t m_in = __ballot(inside);
-        if (m_in == ~0ull) {  // all 64 block starts are inside: the boundary is further on
-          lo += 1 + 63 * 64;  // the last block start probed (inside)
-          if (lo + 1 >= e) found = true;
-          continue;
-        }
-        const int nb_in = __popcll(m_in);  // blocks whose first element is inside (a prefix: sorted)
-        if (nb_in == 0) break;             // the very next element is already outside
-        const uint64_t blk = (uint64_t)lo + 1 + (uint64_t)(nb_in - 1) * 64;  // the boundary lies in [blk, blk + 64)
-        const uint64_t ej = blk + lane;
-        const bool in2 = ej < e && s_qs[ej] <= bound;
-        lo = (uint32_t)(blk + __popcll(__ballot(in2)) - 1);
-        found = true;
-      }
-      ext = lo - (uint32_t)p;
-    }
-    // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
-    if (cut) ++count;  // "there may be more"
-    wave_top_kc(bd, bj);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        c_d[(uint64_t)k * m + p] = bd[k];
-        c_j[(uint64_t)k * m + p] = bj[k];
-      }
-      c_n[p] = count;
-      c_ext[p] = ext;
-    }
-  }
-}
-
-struct SelBlock {
-  uint64_t d[KC];
-  uint32_t j[KC];
-  uint32_t n;
-  uint64_t bps;
-};
-
-// Units come in three sizes.  Short ones (<= SMALL_UNIT elements: nearly all of them in sparse data) are walked one per
-// LANE (chain_select_lanes_kernel); the longest (>= BIG_UNIT) are cut into blocks that run speculatively in parallel
-// (spec_round_kernel); the middle ones get one wavefront each (chain_select_kernel), which keeps the scores of the
-// next 128 elements in registers.
-
-struct SpecBlock {
-  uint32_t ue;  // end of the unit
-  uint32_t bb;  // block begin
-  uint32_t be;  // block end
-  uint32_t pad;
-};
-
-// best_pred_score[j] of an element beyond the 128 the wavefront keeps in registers; out of line for the same reason as
-// spec_view_far (an inlined load would make every step of the walk wait for the stores of the step before)
-__device__ __noinline__ uint64_t bps_far(const unsigned long long* bps, uint32_t j) {
-  return __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, const uint32_t* __restrict__ unit_list,
-                                                           uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                           uint32_t m, const uint64_t* __restrict__ s_grp,
-                                                           const uint32_t* __restrict__ s_qs,
-                                                           const uint32_t* __restrict__ s_qe,
-                                                           const uint32_t* __restrict__ s_ts,
-                                                           const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                           const unsigned long long* __restrict__ c_d,
-                                                           const uint32_t* __restrict__ c_j,
-                                                           const uint32_t* __restrict__ c_n,
-                                                           const uint32_t* __restrict__ s_gidx,
-                                                           const uint32_t* __restrict__ group_begin, uint32_t n_groups,
-                                                           unsigned long long* bps, uint32_t* __restrict__ pred) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const uint32_t n_waves = (gridDim.x * 256) >> 6;
-  const uint64_t INF = ~0ull;
-  const uint64_t fifth = max_gap / 5;
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
-  // one wavefront per listed unit (the middle-sized ones: longer than a lane should walk, shorter than BIG_UNIT)
-  for (uint32_t k = wave_global; k < n_list; k += n_waves) {
-    const uint32_t u = unit_list[k];
-    const uint32_t b = unit_begin[u];
-    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-    if (e - b < 2) continue;
-    auto load_block = [&](uint32_t pos) {
-      SelBlock k;
-      const uint32_t p = pos + lane;
-      if (p < e) {
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          k.d[c] = c_d[(uint64_t)c * m + p];
-          k.j[c] = c_j[(uint64_t)c * m + p];
-        }
-        k.n = c_n[p];
-        k.bps = __hip_atomic_load(&bps[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          k.d[c] = INF;
-          k.j[c] = NONE;
-        }
-        k.n = 0;
-        k.bps = 0;
-      }
-      return k;
-    };
-    uint32_t base = b;
-    SelBlock A = load_block(base), B = load_block(base + 64);
-    // best_pred_score[j] as the sequential loop sees it now (wave-uniform j)
-    auto current = [&](uint32_t j) -> uint64_t {
-      const uint32_t lj = j - base;
-      if (lj < 64) return readlane_u64(A.bps, (int)lj);
-      if (lj < 128) return readlane_u64(B.bps, (int)(lj - 64));
-      return bps_far(bps, j);
-    };
-    // steps in groups of 64; the two register blocks are loaded and touched before the inner loop, so that no step waits
-    // for vector memory (see spec_round_kernel)
-    for (uint32_t i0 = b; i0 + 1 < e; i0 += 64) {
-      if (i0 != b) {
-        A = B;
-        base += 64;
-        B = load_block(base + 64);
-      }
-      {
-        uint64_t t64 = A.bps ^ B.bps;
-        uint32_t t32 = A.n ^ B.n;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          t64 ^= A.d[c] ^ B.d[c];
-          t32 ^= A.j[c] ^ B.j[c];
-        }
-        asm volatile("" ::"v"(t64), "v"(t32));
-      }
-      const uint32_t i_end = i0 + 64;
-      for (uint32_t i = i0; i < i_end && i + 1 < e; ++i) {
-      const int li = (int)(i - base);
-      const uint32_t nvalid = readlane_u32(A.n, li);
-      if (nvalid == 0) continue;
-      uint64_t best_d = INF;
-      uint32_t best_j = NONE;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        if (best_j == NONE && (uint32_t)c < nvalid) {
-          const uint64_t d = readlane_u64(A.d[c], li);
-          const uint32_t j = readlane_u32(A.j[c], li);
-          if (d < current(j)) {
-            best_d = d;
-            best_j = j;
-          }
-        }
-      }
-      if (best_j == NONE && nvalid > (uint32_t)KC) {
-        // every listed candidate is blocked and the window held more: evaluate it in full (rare)
-        const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
-        const bool minus = (s_grp[i] & 1ull) != 0;
-        const uint64_t bound = qe_i + max_gap;
-        // the window ends with i's (q, t, strand) group at the latest (the chunk may hold several groups)
-        const uint32_t gi = s_gidx[i];
-        const uint32_t ge = (gi + 1 < n_groups) ? group_begin[gi + 1] : m;
-        uint64_t ld = INF;
-        uint32_t lj2 = NONE;
-        for (uint32_t j0 = i + 1; j0 < ge; j0 += 64) {
-          if (can_cut) {  // the batch starts past q_end[i] and its smallest query gap already reaches the best distance held
-            const uint64_t wmin = wave_min_u64(ld);
-            const uint64_t q0 = s_qs[j0];
-            if (wmin != INF && q0 >= qe_i && (q0 - qe_i) * (q0 - qe_i) >= wmin) break;
-          }
-          const uint32_t j = j0 + lane;
-          bool in = j < ge;
-          uint64_t qs_j = 0;
-          if (in) {
-            qs_j = s_qs[j];
-            in = qs_j <= bound;
-          }
-          // this lane's own view of best_pred_score[j] (j differs per lane here); the cross-lane reads are
-          // done by all lanes before any branch
-          const uint32_t rel = in ? j - base : 0u;
-          const uint64_t va = __shfl(A.bps, (int)(rel & 63), 64), vb = __shfl(B.bps, (int)(rel & 63), 64);
-          if (in) {
-            uint64_t d;
-            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) {
-              const uint64_t cur = rel < 64 ? va
-                                   : rel < 128 ? vb
-                                               : __hip_atomic_load(&bps[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (d < cur && d < ld) {
-                ld = d;
-                lj2 = j;
-              }
-            }
-          }
-          if (!__any(in)) break;
-        }
-        uint64_t cand = __ballot(lj2 != NONE);
-        while (cand) {
-          const int l = __builtin_ctzll(cand);
-          cand &= cand - 1;
-          const uint64_t d = readlane_u64(ld, l);
-          const uint32_t j = readlane_u32(lj2, l);
-          if (d < best_d || (d == best_d && j < best_j)) {
-            best_d = d;
-            best_j = j;
-          }
-        }
-      }
-      if (best_j == NONE) continue;
-      const uint32_t lj = best_j - base;
-      if (lj < 64) {
-        if ((uint32_t)lane == lj) A.bps = best_d;
-      } else if (lj < 128) {
-        if ((uint32_t)lane == lj - 64) B.bps = best_d;
-      } else {
-        if (lane == 0) __hip_atomic_store(&bps[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before any later read of it
-      }
-      if (lane == 0) pred[best_j] = i;
-      }
-    }
-  }
-}
-
-// Short units -- the bulk of sparse data, where a gap larger than max_gap cuts a group every few dozen elements --
-// are the opposite case: a wavefront per chunk spends 64 lanes on one sequential walk.  Here every LANE walks its own
-// unit: the reference's greedy unchanged (listed candidates in (d, j) order against best_pred_score, full window when
-// all of them are blocked and the window held more), state in global memory but private to the lane, since windows
-// never leave a unit.
-constexpr uint32_t SMALL_UNIT = 256;
-
-__global__ __launch_bounds__(EW) void chain_select_lanes_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin, uint32_t m,
-                                                                const uint64_t* __restrict__ s_grp,
-                                                                const uint32_t* __restrict__ s_qs,
-                                                                const uint32_t* __restrict__ s_qe,
-                                                                const uint32_t* __restrict__ s_ts,
-                                                                const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                                const unsigned long long* __restrict__ c_d,
-                                                                const uint32_t* __restrict__ c_j,
-                                                                const uint32_t* __restrict__ c_n,
-                                                                const uint32_t* __restrict__ c_ext, unsigned long long* bps,
-                                                                uint32_t* pred) {
-  const uint32_t u = blockIdx.x * EW + threadIdx.x;
-  if (u >= n_units) return;
-  const uint32_t b = unit_begin[u];
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  const uint32_t len = e - b;
-  if (len > SMALL_UNIT) return;
-  const uint64_t fifth = max_gap / 5;
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
-  for (uint32_t i = b; i < e; ++i) {
-    const uint32_t nvalid = c_n[i];
-    if (nvalid == 0) continue;
-    uint64_t best_d = ~0ull;
-    uint32_t best_j = NONE;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (best_j == NONE && (uint32_t)c < nvalid) {
-        const uint64_t d = c_d[(uint64_t)c * m + i];
-        const uint32_t j = c_j[(uint64_t)c * m + i];
-        if (d < bps[j]) {
-          best_d = d;
-          best_j = j;
-        }
-      }
-    }
-    if (best_j == NONE && nvalid > (uint32_t)KC) {  // paf_filter.rs:794-840 over the whole window
-      const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
-      const bool minus = (s_grp[i] & 1ull) != 0;
-      const uint32_t last = i + c_ext[i];  // last element with q_start <= q_end[i] + max_gap (inside the unit)
-      for (uint32_t j = i + 1; j <= last && j < e; ++j) {
-        const uint64_t qs_j = s_qs[j];
-        if (can_cut && qs_j >= qe_i && best_j != NONE) {  // past q_end[i] the query gap only grows:
-          const uint64_t qg = qs_j - qe_i;                                      // nothing closer can follow
-          if (qg * qg >= best_d) break;
-        }
-        uint64_t d;
-        if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, s_ts[j], s_te[j], max_gap, fifth, &d)) continue;
-        if (d < best_d && d < bps[j]) {
-          best_d = d;
-          best_j = j;
-        }
-      }
-    }
-    if (best_j == NONE) continue;
-    bps[best_j] = best_d;
-    pred[best_j] = i;
-  }
-}
-
-// Long units (>= BIG_UNIT elements; dense data, or a few per genome pair in sparse data) would pin one wavefront
-// for their whole length.  They are cut into blocks of S elements, S >= the longest window of the unit, and all
-// blocks run in parallel, round after round, until nothing changes:
-//   * a predecessor i of j lies in j's block or in the block before it (windows are shorter than a block), so the
-//     only state a block needs from outside is, for each of its own j, the best distance offered by the previous
-//     block (`ext[j]`); it starts from the previous round's value, the previous block publishes this round's;
-//   * inside a block the reference's sequential greedy runs unchanged (candidate lists, LDS ring of scores);
-//   * block 0 of a unit needs nothing from outside, so after round r the first r blocks are final: the loop ends
-//     when a round reproduces `ext` (by then every block has run on the inputs its predecessor's final choices
-//     imply).  In practice two or three rounds.
-// Two views keep the rounds apart: own[j] is what j's block sees (starts at ext[j]), prev[j] what the previous
-// block sees (starts at infinity); each has its own predecessor array.
-
-
-// per long unit: block size S (multiple of 64, >= longest window + 1, >= 512) and number of blocks
-__global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
-                                                       uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                       uint32_t m, const uint32_t* __restrict__ c_ext,
-                                                       uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out,
-                                                       uint32_t* __restrict__ s_max) {
-  __shared__ uint32_t wmaxs[EW / 64];
-  const uint32_t bi = blockIdx.x;
-  if (bi >= n_big) return;
-  const uint32_t u = big_list[bi];
-  const uint32_t b = unit_begin[u];
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  uint32_t w = 0;
-  for (uint32_t p = b + threadIdx.x; p < e; p += EW) {
-    const uint32_t x = c_ext[p];
-    if (x > w) w = x;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = __shfl_xor(w, o, 64);
-    if (t > w) w = t;
-  }
-  if ((threadIdx.x & 63) == 0) wmaxs[threadIdx.x >> 6] = w;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < EW / 64; ++k)
-      if (wmaxs[k] > w) w = wmaxs[k];
-    uint32_t S = ((w + 1 + 63) / 64) * 64;
-    if (S < 512) S = 512;
-    S_out[bi] = S;
-    nblk_out[bi] = (e - b + S - 1) / S;
-    atomicMax(s_max, S);
-  }
-}
-// The same plan when a unit holds millions of elements (one work-group per unit would walk it alone): every element
-// of a long unit contributes its window extent to the unit's maximum (one atomic per wavefront whose lanes share the
-// unit), then one thread per long unit derives S and the block count.
-__global__ __launch_bounds__(EW) void unit_wmax_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
-                                                       const uint32_t* __restrict__ unit_excl,
-                                                       const uint8_t* __restrict__ is_big, const uint32_t* __restrict__ c_ext,
-                                                       uint32_t* __restrict__ wmax_u) {
-  const int lane = threadIdx.x & 63;
-  uint32_t cur_u = NONE, cur_w = 0;  // wave-uniform: the unit this wavefront is accumulating and its maximum so far
-  for (uint64_t base = (uint64_t)blockIdx.x * EW; base < m; base += (uint64_t)gridDim.x * EW) {  // block-uniform trip count
-    const uint64_t p = base + threadIdx.x;
-    const bool valid = p < m;
-    const uint32_t u = valid ? unit_excl[p] + unit_flag[p] - 1 : 0u;
-    const bool big = valid && is_big[u] != 0;
-    uint32_t w = big ? c_ext[p] : 0u;
-    const uint64_t vm = __ballot(valid);
-    if (vm == 0) continue;  // wave-uniform
-    const uint32_t u0 = (uint32_t)__shfl((int)u, (int)__builtin_ctzll(vm), 64);
-    if (__ballot(valid && u != u0) == 0) {  // the wavefront's elements share one unit
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t t = __shfl_xor(w, o, 64);
-        if (t > w) w = t;
-      }
-      if (u0 != cur_u) {  // flush the previous unit (one atomic per wavefront and unit, not per row)
-        if (lane == 0 && cur_w) atomicMax(&wmax_u[cur_u], cur_w);
-        cur_u = u0;
-        cur_w = 0;
-      }
-      if (w > cur_w) cur_w = w;
-    } else if (big && w) {
-      atomicMax(&wmax_u[u], w);
-    }
-  }
-  if (lane == 0 && cur_w) atomicMax(&wmax_u[cur_u], cur_w);
-}
-__global__ __launch_bounds__(EW) void spec_plan_from_wmax_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
-                                                                 uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                                 uint32_t m, const uint32_t* __restrict__ wmax_u,
-                                                                 uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out,
-                                                                 uint32_t* __restrict__ s_max) {
-  const uint32_t bi = blockIdx.x * EW + threadIdx.x;
-  if (bi >= n_big) return;
-  const uint32_t u = big_list[bi];
-  const uint32_t b = unit_begin[u];
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  uint32_t S = ((wmax_u[u] + 1 + 63) / 64) * 64;
-  if (S < 512) S = 512;
-  S_out[bi] = S;
-  nblk_out[bi] = (e - b + S - 1) / S;
-  atomicMax(s_max, S);
-}
-__global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list,
-                                                       uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                       uint32_t m, const uint32_t* __restrict__ S_in,
-                                                       const uint32_t* __restrict__ nblk_in,
-                                                       const uint32_t* __restrict__ blk_off, SpecBlock* __restrict__ desc) {
-  // one thread per (unit, block) pair would need a search; units are few, blocks per unit can be many: one
-  // work-group per unit, threads stride over its blocks
-  const uint32_t bi = blockIdx.x;
-  if (bi >= n_big) return;
-  const uint32_t u = big_list[bi];
-  const uint32_t b = unit_begin[u];
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  const uint32_t S = S_in[bi], nb = nblk_in[bi], off = blk_off[bi];
-  for (uint32_t k = threadIdx.x; k < nb; k += EW) {
-    SpecBlock d;
-    d.ue = e;
-    d.bb = b + k * S;
-    d.be = d.bb + S < e ? d.bb + S : e;
-    d.pad = 0;
-    desc[off + k] = d;
-  }
-}
-// The three per-round passes touch only the elements of long units: one work-group per block descriptor.
-__global__ __launch_bounds__(EW) void spec_init_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
-                                                       const unsigned long long* __restrict__ ext,
-                                                       unsigned long long* __restrict__ own,
-                                                       unsigned long long* __restrict__ prev,
-                                                       uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
-  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
-    const SpecBlock D = desc[bk];
-    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
-      own[p] = ext[p];
-      prev[p] = ~0ull;
-      pred_own[p] = NONE;
-      pred_prev[p] = NONE;
-    }
-  }
-}
-__global__ __launch_bounds__(EW) void spec_check_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
-                                                        const unsigned long long* __restrict__ prev,
-                                                        unsigned long long* __restrict__ ext,
-                                                        uint32_t* __restrict__ changed) {
-  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
-    const SpecBlock D = desc[bk];
-    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
-      const unsigned long long v = prev[p];
-      if (v != ext[p]) {
-        ext[p] = v;
-        *changed = 1;
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(EW) void spec_final_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
-                                                        const uint32_t* __restrict__ pred_own,
-                                                        const uint32_t* __restrict__ pred_prev,
-                                                        uint32_t* __restrict__ pred) {
-  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
-    const SpecBlock D = desc[bk];
-    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
-      const uint32_t a = pred_own[p], b = pred_prev[p];
-      // own-block choosers come later in the sequence and had to beat the previous block's offer
-      if (a != NONE)
-        pred[p] = a;
-      else if (b != NONE)
-        pred[p] = b;
-    }
-  }
-}
-
-// A position outside the LDS ring, read from the block's view in global memory.  Kept out of line on purpose: inlined, its
-// load shares a destination register with the ring's LDS read, and the hazard bookkeeping then makes every step of the walk
-// wait for all outstanding vector-memory operations -- i.e. for the write-through stores of the step before.
-__device__ __noinline__ uint64_t spec_view_far(const unsigned long long* own, const unsigned long long* prev, uint32_t be,
-                                               uint32_t p) {
-  return __hip_atomic_load(p < be ? &own[p] : &prev[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#ifdef SWG_SPEC_STATS
-__device__ unsigned long long g_spec_stats[8];
-#define SPEC_STAT(k, v) do { if (lane == 0) atomicAdd(&g_spec_stats[k], (unsigned long long)(v)); } while (0)
-#else
-#define SPEC_STAT(k, v) do { } while (0)
-#endif
-template <int BIGW>
-__global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
-                                                        const uint64_t* __restrict__ s_grp,
-                                                        const uint32_t* __restrict__ s_qs,
-                                                        const uint32_t* __restrict__ s_qe,
-                                                        const uint32_t* __restrict__ s_ts,
-                                                        const uint32_t* __restrict__ s_te, uint64_t max_gap,
-                                                        const unsigned long long* __restrict__ c_d,
-                                                        const uint32_t* __restrict__ c_j,
-                                                        const uint32_t* __restrict__ c_n, unsigned long long* own,
-                                                        unsigned long long* prev, uint32_t* __restrict__ pred_own,
-                                                        uint32_t* __restrict__ pred_prev) {
-  __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this block sees them
-  __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end (for full-window passes)
-  const int lane = threadIdx.x;
-  const uint64_t INF = ~0ull;
-  const uint64_t fifth = max_gap / 5;
-  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
-  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
-    const SpecBlock D = desc[bk];
-    const uint32_t b = D.bb, be = D.be, e = D.ue;  // i runs over [b, be), j may reach into the next block (< e)
-    if (be - b < 1 || e - b < 2) continue;
-    const bool minus = (s_grp[b] & 1ull) != 0;
-    // this block's view of position p: its own elements start from ext (in `own`), later ones from infinity (`prev`)
-    auto view_load = [&](uint32_t p) -> uint64_t {
-      return __hip_atomic_load(p < be ? &own[p] : &prev[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    uint32_t base = b;
-    __syncthreads();
-    for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
-      const bool ok = p < e;
-      ring[p % BIGW] = ok ? view_load(p) : INF;
-      rq[p % BIGW] = ok ? s_qs[p] : 0xffffffffu;
-      rt[p % BIGW] = ok ? s_ts[p] : 0u;
-      re[p % BIGW] = ok ? s_te[p] : 0u;
-    }
-    __syncthreads();
-    uint64_t cd[KC];
-    uint32_t cj[KC];
-    uint32_t cn;
-    auto load_cands = [&](uint32_t pos) {
-      const uint32_t p = pos + lane;
-      if (p < be) {
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          cd[c] = c_d[(uint64_t)c * m + p];
-          cj[c] = c_j[(uint64_t)c * m + p];
-        }
-        cn = c_n[p];
-      } else {
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          cd[c] = INF;
-          cj[c] = NONE;
-        }
-        cn = 0;
-      }
-    };
-    load_cands(base);
-    auto current = [&](uint32_t j) -> uint64_t {
-      if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
-      return spec_view_far(own, prev, be, j);
-    };
-    // The walk is one dependent chain per wavefront, so what a step waits for is what the block costs.  Steps run in groups
-    // of 64 (one candidate list per lane); the lists are loaded and TOUCHED before the inner loop, so that the wait for those
-    // loads sits in front of it: inside, the only outstanding vector-memory operations are the write-through stores of
-    // earlier steps, which no instruction of a step depends on (a wait for the lists placed inside the loop would also
-    // drain those stores -- a memory round trip per step, 3/4 of the kernel's time on one deep chromosome pair).
-    for (uint32_t i0 = b; i0 < be && i0 + 1 < e; i0 += 64) {
-      if (i0 != b) {
-        const uint32_t pn = base + BIGW + lane;
-        __syncthreads();
-        {
-          const bool ok = pn < e;
-          ring[pn % BIGW] = ok ? view_load(pn) : INF;
-          rq[pn % BIGW] = ok ? s_qs[pn] : 0xffffffffu;
-          rt[pn % BIGW] = ok ? s_ts[pn] : 0u;
-          re[pn % BIGW] = ok ? s_te[pn] : 0u;
-        }
-        base += 64;
-        load_cands(base);
-        __syncthreads();
-      }
-      {
-        uint64_t touch = cd[0] ^ cd[1] ^ cd[2] ^ cd[3];
-        uint32_t touch32 = cj[0] ^ cj[1] ^ cj[2] ^ cj[3] ^ cn;
-        asm volatile("" ::"v"(touch), "v"(touch32));
-      }
-      const uint32_t i_end = (i0 + 64 < be ? i0 + 64 : be);
-      for (uint32_t i = i0; i < i_end && i + 1 < e; ++i) {
-      const int li = (int)(i - base);
-      const uint32_t nvalid = readlane_u32(cn, li);
-      if (nvalid == 0) continue;
-      SPEC_STAT(0, 1);
-      uint64_t best_d = INF;
-      uint32_t best_j = NONE;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        if (best_j == NONE && (uint32_t)c < nvalid) {
-          const uint64_t d = readlane_u64(cd[c], li);
-          const uint32_t j = readlane_u32(cj[c], li);
-          if (d < current(j)) {
-            best_d = d;
-            best_j = j;
-          }
-        }
-      }
-      if (best_j == NONE && nvalid > (uint32_t)KC) {
-        SPEC_STAT(1, 1);
-        // every listed candidate is blocked and the window held more: evaluate it in full
-        const uint64_t qe_i = s_qe[i], ts_i = s_ts[i], te_i = s_te[i];
-        const uint64_t bound = qe_i + max_gap;
-        uint64_t ld = INF;
-        uint32_t lj2 = NONE;
-        for (uint32_t j0 = i + 1; j0 < e; j0 += 64) {
-          SPEC_STAT(2, 1);
-          if (can_cut) {  // see chain_select_kernel
-            const uint64_t wmin = wave_min_u64(ld);
-            const uint64_t q0 = (j0 - base) < (uint32_t)BIGW ? (uint64_t)rq[j0 % BIGW] : (uint64_t)s_qs[j0];
-            if (wmin != INF && q0 >= qe_i && (q0 - qe_i) * (q0 - qe_i) >= wmin) break;
-          }
-          const uint32_t j = j0 + lane;
-          bool in = j < e;
-          const bool inring = in && (j - base) < (uint32_t)BIGW;
-          uint64_t qs_j = 0;
-          if (in) {
-            qs_j = inring ? rq[j % BIGW] : s_qs[j];
-            in = qs_j <= bound;
-          }
-          if (in) {
-            uint64_t d;
-            const uint64_t ts_j = inring ? rt[j % BIGW] : s_ts[j], te_j = inring ? re[j % BIGW] : s_te[j];
-            if (chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) {
-              const uint64_t cur = current(j);
-              if (d < cur && d < ld) {
-                ld = d;
-                lj2 = j;
-              }
-            }
-          }
-          if (!__any(in)) break;
-        }
-        uint64_t cand = __ballot(lj2 != NONE);
-        while (cand) {
-          const int l = __builtin_ctzll(cand);
-          cand &= cand - 1;
-          const uint64_t d = readlane_u64(ld, l);
-          const uint32_t j = readlane_u32(lj2, l);
-          if (d < best_d || (d == best_d && j < best_j)) {
-            best_d = d;
-            best_j = j;
-          }
-        }
-      }
-      if (best_j == NONE) continue;
-      const bool in_ring = best_j - base < (uint32_t)BIGW;
-      if (lane == 0) {
-        if (in_ring) ring[best_j % BIGW] = best_d;  // read back by this wavefront in program order
-        // write-through: the views are what the check / final kernels (and the ring refill) read
-        __hip_atomic_store(best_j < be ? &own[best_j] : &prev[best_j], best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (best_j < be ? pred_own : pred_prev)[best_j] = i;
-      }
-      if (!in_ring) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // drain before a later global read of it
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                           uint32_t m, uint8_t* __restrict__ is_big) {
-  uint32_t u = blockIdx.x * EW + threadIdx.x;
-  if (u >= n_units) return;
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  const uint8_t f = (e - unit_begin[u]) >= BIG_UNIT ? 1 : 0;
-  is_big[u] = f;
-}
-
-__global__ __launch_bounds__(EW) void unit_mid_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
-                                                           uint32_t m, uint8_t* __restrict__ is_mid) {
-  uint32_t u = blockIdx.x * EW + threadIdx.x;
-  if (u >= n_units) return;
-  const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  const uint32_t len = e - unit_begin[u];
-  is_mid[u] = (len > SMALL_UNIT && len < BIG_UNIT) ? 1 : 0;
-}
-
-// Independent sub-ranges of a group: position p opens a new unit when q_start[p] lies beyond every earlier
-// q_end of the group by more than the gap -- no (i, j) pair of the reference's window test
-// (`q_start[j] <= q_end[i] + gap`, paf_filter.rs:786-796) can then straddle p, so the greedy on either side is
-// independent.  One wavefront per group, 64 elements per step, running maximum carried along.
-__global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                        uint32_t m, const uint32_t* __restrict__ s_qs,
-                                                        const uint32_t* __restrict__ s_qe, uint64_t max_gap,
-                                                        uint32_t* __restrict__ unit_flag) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
-  const uint32_t n_waves = (gridDim.x * EW) >> 6;
-  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
-    const uint32_t b = group_begin[g];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
-    uint32_t carry = 0;  // max q_end over [b, p0)
-    for (uint32_t p0 = b; p0 < e; p0 += 64) {
-      const uint32_t p = p0 + lane;
-      const uint32_t qe = p < e ? s_qe[p] : 0u;
-      uint32_t inc = qe;  // inclusive running max inside the stripe
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d && t > inc) inc = t;
-      }
-      uint32_t before = __shfl_up(inc, 1, 64);  // max over earlier lanes of the stripe
-      if (lane == 0) before = 0;
-      if (carry > before) before = carry;
-      uint64_t lim = (uint64_t)before + max_gap;
-      if (lim < max_gap) lim = ~0ull;  // saturate
-      if (p < e) unit_flag[p] = (p == b || (uint64_t)s_qs[p] > lim) ? 1u : 0u;
-      const uint32_t last = __shfl(inc, 63, 64);
-      if (last > carry) carry = last;
-    }
-  }
-}
-// The same two per-group reductions for inputs with few, very long groups (one wavefront per group would crawl):
-// a running maximum over the composite (group index << 32 | value) is a segmented running maximum, because the
-// group index never decreases along the survivor order.
-__global__ __launch_bounds__(EW) void seg_compose_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
-                                                         const uint32_t* __restrict__ v, int complement,
-                                                         uint64_t* __restrict__ out) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) out[p] = ((uint64_t)s_gidx[p] << 32) | (complement ? 0xffffffffu - v[p] : v[p]);
-}
-__global__ __launch_bounds__(EW) void cuts_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
-                                                            const uint64_t* __restrict__ run_max,
-                                                            const uint32_t* __restrict__ s_qs, uint64_t max_gap,
-                                                            uint32_t* __restrict__ unit_flag) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  uint32_t f = 1;
-  if (!head_flag[p]) {  // p > 0 and p - 1 is in the same group
-    uint64_t lim = (run_max[p - 1] & 0xffffffffull) + max_gap;
-    if (lim < max_gap) lim = ~0ull;
-    f = (uint64_t)s_qs[p] > lim ? 1u : 0u;
-  }
-  unit_flag[p] = f;
-}
-__global__ __launch_bounds__(EW) void group_first_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
-                                                                   const uint64_t* __restrict__ run_max,
-                                                                   uint32_t* __restrict__ group_first) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  if (p + 1 == m || head_flag[p + 1]) {  // last member of its group
-    const uint64_t v = run_max[p];
-    group_first[(uint32_t)(v >> 32)] = 0xffffffffu - (uint32_t)v;
-  }
-}
-
-__global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
-                                                        const uint32_t* __restrict__ unit_excl,
-                                                        uint32_t* __restrict__ unit_begin) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m && unit_flag[p]) unit_begin[unit_excl[p]] = (uint32_t)p;
-}
-
-// ---- chain labelling ---------------------------------------------------------------------------------------
-// hd[p] = pred[p] (or p), then followed through LDS as far as the block's own 1024-element range goes: predecessors
-// precede their successors and are usually close, so most elements reach their head here and the global pointer
-// jumping below only has to connect chains across ranges.
-constexpr int HEAD_SPAN = 1024;
-__global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
-                                                       uint32_t* __restrict__ hd) {
-  __shared__ uint32_t l[HEAD_SPAN];
-  const uint64_t base = (uint64_t)blockIdx.x * HEAD_SPAN;
-  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p < m) l[k] = pred[p] == NONE ? (uint32_t)p : pred[p];
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p >= m) break;
-    uint32_t h = l[k];
-    while (h >= base) {  // h <= p < base + HEAD_SPAN
-      const uint32_t hh = l[h - base];
-      if (hh == h) break;
-      h = hh;
-    }
-    hd[p] = h;
-  }
-}
-// hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
-__global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t h = hd[p];
-  const uint32_t hh = hd[h];
-  if (hh != h) {
-    hd[p] = hh;
-    *changed = 1;
-  }
-}
-
-// Chain aggregates live at the head's slot.  Pass 1 seeds every slot with the element's own values (plain
-// stores, this is also the initialisation); pass 2 folds the non-head members into their head with atomics.
-// Most chains are singletons, so most elements never issue an atomic.
-__global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, const uint32_t* __restrict__ hd,
-                                                                  const uint32_t* __restrict__ s_qe,
-                                                                  const uint32_t* __restrict__ s_ts,
-                                                                  const uint32_t* __restrict__ s_te,
-                                                                  const uint32_t* __restrict__ s_m,
-                                                                  const uint32_t* __restrict__ s_b,
-                                                                  uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
-                                                                  uint32_t* __restrict__ h_te,
-                                                                  unsigned long long* __restrict__ h_sm,
-                                                                  unsigned long long* __restrict__ h_sb,
-                                                                  uint32_t* __restrict__ is_head) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  is_head[p] = hd[p] == p ? 1u : 0u;
-  h_qe[p] = s_qe[p];
-  h_ts[p] = s_ts[p];
-  h_te[p] = s_te[p];
-  h_sm[p] = s_m[p];
-  h_sb[p] = s_b[p];
-}
-// A member is usually a few positions after its head, so a block first folds the members whose head lies inside its
-// own 1024-element range into LDS (LDS atomics), then merges each touched partial aggregate into the head's seeded
-// global slot with one set of atomics per chain instead of one per member; members whose head lies before the range
-// go to global memory directly.
-constexpr int AGG_SPAN = 1024;
-__global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const uint32_t* __restrict__ hd,
-                                                             const uint32_t* __restrict__ s_qe,
-                                                             const uint32_t* __restrict__ s_ts,
-                                                             const uint32_t* __restrict__ s_te,
-                                                             const uint32_t* __restrict__ s_m,
-                                                             const uint32_t* __restrict__ s_b,
-                                                             uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
-                                                             uint32_t* __restrict__ h_te,
-                                                             unsigned long long* __restrict__ h_sm,
-                                                             unsigned long long* __restrict__ h_sb) {
-  __shared__ uint32_t l_qe[AGG_SPAN], l_ts[AGG_SPAN], l_te[AGG_SPAN], l_cnt[AGG_SPAN];
-  __shared__ unsigned long long l_sm[AGG_SPAN], l_sb[AGG_SPAN];
-  const uint64_t base = (uint64_t)blockIdx.x * AGG_SPAN;
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    l_qe[k] = 0;
-    l_ts[k] = 0xffffffffu;
-    l_te[k] = 0;
-    l_cnt[k] = 0;
-    l_sm[k] = 0;
-    l_sb[k] = 0;
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p >= m) break;
-    const uint32_t h = hd[p];
-    if (h == p) continue;
-    if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
-      const uint32_t l = (uint32_t)(h - base);
-      atomicMax(&l_qe[l], s_qe[p]);
-      atomicMin(&l_ts[l], s_ts[p]);
-      atomicMax(&l_te[l], s_te[p]);
-      atomicAdd(&l_sm[l], (unsigned long long)s_m[p]);
-      atomicAdd(&l_sb[l], (unsigned long long)s_b[p]);
-      l_cnt[l] = 1;
-    } else {
-      atomicMax(&h_qe[h], s_qe[p]);
-      atomicMin(&h_ts[h], s_ts[p]);
-      atomicMax(&h_te[h], s_te[p]);
-      atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
-      atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    if (!l_cnt[k]) continue;
-    const uint64_t h = base + k;  // a head of this range with members in it; members of later ranges use atomics too
-    atomicMax(&h_qe[h], l_qe[k]);
-    atomicMin(&h_ts[h], l_ts[k]);
-    atomicMax(&h_te[h], l_te[k]);
-    atomicAdd(&h_sm[h], l_sm[k]);
-    atomicAdd(&h_sb[h], l_sb[k]);
-  }
-}
-
-// min original index per (q,t,strand) group, and per genome pair (prefix-last) over ALL alive records
-__global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                         uint32_t m, const uint32_t* __restrict__ s_idx,
-                                                         uint32_t* __restrict__ group_first) {
-  // one wavefront per (q,t,strand) group: members are contiguous in survivor order
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
-  const uint32_t n_waves = (gridDim.x * EW) >> 6;
-  for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
-    const uint32_t b = group_begin[g];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
-    uint32_t v = 0xffffffffu;
-    for (uint32_t p = b + lane; p < e; p += 64) {
-      const uint32_t x = s_idx[p];
-      if (x < v) v = x;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t t = __shfl_xor(v, o, 64);
-      if (t < v) v = t;
-    }
-    if (lane == 0) group_first[g] = v;
-  }
-}
-// genome pair (gq, gt) -> u32, "first appearance" tables of the two prefix rules.  Up to 2^14 genomes: a dense G x G array
-// (one load per lookup).  Beyond (names without '#': every contig its own genome): open addressing over the pairs that
-// actually occur -- their number is bounded by the (query, target) groups the caller has already counted.
-struct PairTable {
-  uint32_t* dense;      // [G * G] or nullptr
-  unsigned long long* keys;  // sparse: [mask + 1], ~0 = empty
-  uint32_t* vals;       // sparse: [mask + 1]
-  uint32_t mask;
-  uint32_t n_genome;
-};
-__device__ __forceinline__ uint32_t* pair_slot(const PairTable& t, uint32_t gq, uint32_t gt) {  // inserts when absent
-  if (t.dense) return t.dense + ((size_t)gq * t.n_genome + gt);
-  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
-  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
-  for (;;) {
-    unsigned long long k = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == ~0ull) {
-      k = atomicCAS(&t.keys[h], ~0ull, key);
-      if (k == ~0ull) k = key;
-    }
-    if (k == key) return t.vals + h;
-    h = (h + 1) & t.mask;
-  }
-}
-__device__ __forceinline__ uint32_t pair_get(const PairTable& t, uint32_t gq, uint32_t gt) {  // the pair is present
-  if (t.dense) return t.dense[(size_t)gq * t.n_genome + gt];
-  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
-  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
-  while (t.keys[h] != key) h = (h + 1) & t.mask;
-  return t.vals[h];
-}
-constexpr uint64_t DENSE_PAIR_LIMIT = uint64_t(1) << 28;  // G * G entries
-
-// First (lowest) original index of every genome pair over the alive records, in ORIGINAL order (coalesced
-// reads).  Two filters keep the atomics rare: (1) a wavefront whose 256 records all belong to one pair (inputs
-// grouped by pair) reduces to one atomic; (2) otherwise (interleaved pairs) a plain cached read of the table --
-// it only ever decreases, so a stale value is merely conservative -- drops every record that cannot lower it.
-__global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const uint8_t* __restrict__ alive,
-                                                               const uint32_t* __restrict__ q_id,
-                                                               const uint32_t* __restrict__ t_id,
-                                                               const uint32_t* __restrict__ seq_genome,
-                                                               PairTable table) {
-  constexpr int U = 4;
-  const int lane = threadIdx.x & 63;
-  const uint64_t stride = (uint64_t)gridDim.x * EW * U;
-  // whole waves stay in the loop together (the bound is wave-uniform), so the cross-lane ops are safe
-  for (uint64_t w0 = ((uint64_t)blockIdx.x * EW + (threadIdx.x & ~63)) * U; w0 < n; w0 += stride) {
-    const uint64_t i0 = w0 + (uint64_t)lane * U;
-    unsigned long long L[U];  // (gq << 32) | gt
-    bool live[U];
-    uint32_t first_i = 0xffffffffu;
-    unsigned long long first_L = 0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t i = i0 + u;
-      live[u] = i < n && alive[i] != 0;
-      L[u] = live[u] ? ((unsigned long long)seq_genome[q_id[i]] << 32) | seq_genome[t_id[i]] : 0ull;
-      if (live[u] && first_i == 0xffffffffu) {
-        first_i = (uint32_t)i;
-        first_L = L[u];
-      }
-    }
-    // wave minimum of first_i, and the pair of the lane holding it
-    uint32_t vmin = first_i;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t x = __shfl_xor(vmin, o, 64);
-      if (x < vmin) vmin = x;
-    }
-    if (vmin == 0xffffffffu) continue;  // no live record in this wave's span
-    const uint64_t holder = __ballot(first_i == vmin);
-    const unsigned long long L0 = __shfl(first_L, __builtin_ctzll(holder), 64);
-    bool same = true;
-#pragma unroll
-    for (int u = 0; u < U; ++u) same = same && (!live[u] || L[u] == L0);
-    if (__all(same)) {
-      if (lane == 0) {
-        uint32_t* slot = pair_slot(table, (uint32_t)(L0 >> 32), (uint32_t)L0);
-        if (*slot > vmin) atomicMin(slot, vmin);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (live[u]) {
-          uint32_t* slot = pair_slot(table, (uint32_t)(L[u] >> 32), (uint32_t)L[u]);
-          if (*slot > (uint32_t)(i0 + u)) atomicMin(slot, (uint32_t)(i0 + u));
-        }
-    }
-  }
-}
-
-// all_chains order = (q,t,strand) groups by first appearance, chains of a group by head position.  Chains in
-// head-position order are already contiguous per group, so only the GROUPS are sorted; a chain's place is its
-// group's base plus its rank inside the group.
-__global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                        uint32_t m, const uint32_t* __restrict__ cpos_excl, uint32_t nc,
-                                                        const uint32_t* __restrict__ s_idx,
-                                                        const uint32_t* __restrict__ group_first,
-                                                        const uint32_t* __restrict__ q_id,
-                                                        const uint32_t* __restrict__ t_id,
-                                                        const uint32_t* __restrict__ seq_genome, bool pair_major,
-                                                        PairTable gp_first, int idx_bits,
-                                                        uint64_t* __restrict__ g_key, uint32_t* __restrict__ g_val,
-                                                        uint32_t* __restrict__ g_first_chain,
-                                                        uint32_t* __restrict__ g_nchains) {
-  uint32_t g = blockIdx.x * EW + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint32_t b = group_begin[g];
-  const uint32_t first = cpos_excl[b];  // a group's first member is always a chain head
-  const uint32_t next = (g + 1 < n_groups) ? cpos_excl[group_begin[g + 1]] : nc;
-  (void)m;
-  g_first_chain[g] = first;
-  g_nchains[g] = next - first;
-  const uint32_t i = s_idx[b];
-  // !pair_major: groups in plain first-appearance order of the records as given
-  // (merge_mappings_into_chains called on its own); otherwise genome-pair-major, which is the order
-  // apply_plane_sweep_to_mappings leaves the metadata in (paf_filter.rs:1037-1046, 1117-1120).
-  uint64_t hi = 0;
-  if (pair_major) hi = pair_get(gp_first, seq_genome[q_id[i]], seq_genome[t_id[i]]);
-  g_key[g] = (hi << idx_bits) | group_first[g];
-  g_val[g] = g;
-}
-__global__ __launch_bounds__(EW) void group_sizes_sorted_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
-                                                                const uint32_t* __restrict__ g_nchains,
-                                                                uint32_t* __restrict__ sizes) {
-  uint32_t r = blockIdx.x * EW + threadIdx.x;
-  if (r < n_groups) sizes[r] = g_nchains[g_sorted[r]];
-}
-__global__ __launch_bounds__(EW) void group_base_kernel(uint32_t n_groups, const uint32_t* __restrict__ g_sorted,
-                                                        const uint32_t* __restrict__ base_sorted,
-                                                        uint32_t* __restrict__ g_base) {
-  uint32_t r = blockIdx.x * EW + threadIdx.x;
-  if (r < n_groups) g_base[g_sorted[r]] = base_sorted[r];
-}
-// per chain head: position-order ordinal c -> all_chains index c2 (and the inverse)
-__global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
-                                                         const uint32_t* __restrict__ cpos_excl,
-                                                         const uint32_t* __restrict__ s_gidx,
-                                                         const uint32_t* __restrict__ g_first_chain,
-                                                         const uint32_t* __restrict__ g_base,
-                                                         uint32_t* __restrict__ ch_head, uint32_t* __restrict__ order) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m || !is_head[p]) return;
-  const uint32_t c = cpos_excl[p];
-  const uint32_t g = s_gidx[p];
-  ch_head[c] = (uint32_t)p;
-  order[g_base[g] + (c - g_first_chain[g])] = c;
-}
-
-// chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
-__global__ __launch_bounds__(EW) void chain_columns_kernel(
-    uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
-    const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
-    const uint32_t* __restrict__ h_te, const unsigned long long* __restrict__ h_sm,
-    const unsigned long long* __restrict__ h_sb, const uint64_t* __restrict__ s_grp, const uint32_t* __restrict__ s_a,
-    const uint32_t* __restrict__ a_dpair, uint32_t n_seq, uint64_t min_len, double min_ident,
-    uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
-    uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
-    double* __restrict__ C_wid, uint8_t* __restrict__ C_strand, uint32_t* __restrict__ C_dpair,
-    uint8_t* __restrict__ C_ok, uint32_t* __restrict__ rank_of_poschain) {
-  uint64_t c2 = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (c2 >= nc) return;
-  const uint32_t c = order[c2];
-  rank_of_poschain[c] = (uint32_t)c2;
-  const uint32_t p = ch_head[c];
-  const uint64_t g = s_grp[p];
-  const uint64_t pair = g >> 1;
-  const uint32_t qs = s_qs[p], qe = h_qe[p], ts = h_ts[p], te = h_te[p];
-  C_qid[c2] = (uint32_t)(pair / n_seq);
-  C_tid[c2] = (uint32_t)(pair % n_seq);
-  C_strand[c2] = (uint8_t)(g & 1);
-  C_qs[c2] = qs;
-  C_qe[c2] = qe;
-  C_ts[c2] = ts;
-  C_te[c2] = te;
-  C_dpair[c2] = a_dpair[s_a[p]];
-  const uint64_t total_length = (uint64_t)qe - (uint64_t)qs;  // q_max - q_min
-  const uint64_t sm = h_sm[p], sb = h_sb[p];
-  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
-  double lcg = 0.0;
-  if (gap_length > 0) {
-    lcg = swg_log_glibc((double)gap_length);
-    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
-  }
-  const double eff = __dadd_rn((double)sb, lcg);
-  const double wid = eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
-  C_wid[c2] = wid;
-  C_ok[c2] = (total_length >= min_len && wid >= min_ident) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
-                                                            const uint32_t* __restrict__ cpos_excl,
-                                                            const uint32_t* __restrict__ rank_of_poschain,
-                                                            uint32_t* __restrict__ s_chain) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) s_chain[p] = rank_of_poschain[cpos_excl[hd[p]]];
-}
-
-// ---- scaffold sweep + numbering ------------------------------------------------------------------------------
-__global__ __launch_bounds__(EW) void chain_seg_kernel(uint64_t nc, const uint32_t* __restrict__ C_qid,
-                                                       const uint32_t* __restrict__ C_tid, uint32_t n_seq,
-                                                       uint64_t* __restrict__ seg) {
-  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (c < nc) seg[c] = (uint64_t)C_qid[c] * n_seq + C_tid[c];
-}
-// after the stable sort of chains by chromosome pair: run heads
-__global__ __launch_bounds__(EW) void run_flag_kernel(uint64_t nc, const uint64_t* __restrict__ sorted_seg,
-                                                      uint32_t* __restrict__ flag) {
-  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (s < nc) flag[s] = (s == 0 || sorted_seg[s - 1] != sorted_seg[s]) ? 1u : 0u;
-}
-// Chains here are already the span/identity-filtered ones, in index order, and the sort by chromosome pair is
-// stable: the first chain of a run is the pair's first appearance (plane_sweep_scaffold.rs:116-130 insertion
-// order), and the genome pair's (first two '#' parts) first appearance is the minimum over its runs' heads.
-__global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
-                                                              const uint32_t* __restrict__ run_excl,
-                                                              const uint32_t* __restrict__ run_flag,
-                                                              const uint32_t* __restrict__ C_qid,
-                                                              const uint32_t* __restrict__ C_tid,
-                                                              const uint32_t* __restrict__ seq_genome2,
-                                                              uint32_t* __restrict__ run_of_chain,
-                                                              uint32_t* __restrict__ pair_first,
-                                                              PairTable gp2_first) {
-  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (s >= nc) return;
-  const uint32_t c = sorted_c[s];
-  const uint32_t run = run_excl[s] + run_flag[s] - 1;
-  run_of_chain[c] = run;
-  if (run_flag[s]) {
-    pair_first[run] = c;
-    atomicMin(pair_slot(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]), c);
-  }
-}
-__global__ __launch_bounds__(EW) void number_keys_kernel(uint64_t nk, const uint32_t* __restrict__ kept_list,
-                                                         const uint32_t* __restrict__ run_of_chain,
-                                                         const uint32_t* __restrict__ pair_first,
-                                                         PairTable gp2_first,
-                                                         const uint32_t* __restrict__ C_qid,
-                                                         const uint32_t* __restrict__ C_tid,
-                                                         const uint32_t* __restrict__ seq_genome2,
-                                                         int c_bits, uint64_t* __restrict__ key) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= nk) return;
-  const uint32_t c = kept_list[j];
-  const uint32_t g2 = pair_get(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]);
-  key[j] = ((uint64_t)g2 << c_bits) | pair_first[run_of_chain[c]];
-}
-__global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const uint32_t* __restrict__ sorted_kept,
-                                                            uint32_t* __restrict__ C_num) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
-}
-
-__global__ __launch_bounds__(EW) void chain_compact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
-                                                           const uint32_t* __restrict__ qid, const uint32_t* __restrict__ tid,
-                                                           const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
-                                                           const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
-                                                           const double* __restrict__ wid, uint32_t* __restrict__ o_qid,
-                                                           uint32_t* __restrict__ o_tid, uint32_t* __restrict__ o_qs,
-                                                           uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts,
-                                                           uint32_t* __restrict__ o_te, double* __restrict__ o_wid) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= no) return;
-  const uint32_t c = ok_idx[j];
-  o_qid[j] = qid[c];
-  o_tid[j] = tid[c];
-  o_qs[j] = qs[c];
-  o_qe[j] = qe[c];
-  o_ts[j] = ts[c];
-  o_te[j] = te[c];
-  o_wid[j] = wid[c];
-}
-__global__ __launch_bounds__(EW) void chain_uncompact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
-                                                             const uint8_t* __restrict__ kept_j,
-                                                             const uint32_t* __restrict__ num_j,
-                                                             uint8_t* __restrict__ C_kept, uint32_t* __restrict__ C_num) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= no) return;
-  const uint32_t c = ok_idx[j];
-  C_kept[c] = kept_j[j];
-  C_num[c] = num_j[j];
-}
-
-struct ChainTable {
-  uint64_t nc = 0;
-  uint32_t *qid = nullptr, *tid = nullptr, *qs = nullptr, *qe = nullptr, *ts = nullptr, *te = nullptr;
-  double* wid = nullptr;
-  uint8_t* ok = nullptr;  // passes span/identity filter (input of the scaffold sweep)
-};
-
-// Allocates (arena) and clears a PairTable for G genomes of which at most `bound` pairs occur.
-int pair_table_make(swg_ctx* ctx, uint32_t n_genome, uint64_t bound, PairTable* t) {
-  hipStream_t st = ctx->stream;
-  t->n_genome = n_genome;
-  t->dense = nullptr;
-  t->keys = nullptr;
-  t->vals = nullptr;
-  t->mask = 0;
-  const uint64_t g2 = (uint64_t)n_genome * n_genome;
-  if (g2 <= DENSE_PAIR_LIMIT) {
-    t->dense = swg_alloc<uint32_t>(ctx, g2);
-    SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(g2), EW, 0, st>>>(g2, t->dense, NONE));
-    SWG_KERNEL_CHECK(ctx);
-    return SWG_OK;
-  }
-  uint64_t cap = 1024;
-  while (cap < 2 * bound) cap <<= 1;
-  if (cap > (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "genome-pair table beyond 2^32 slots");
-  t->keys = swg_alloc<unsigned long long>(ctx, cap);
-  t->vals = swg_alloc<uint32_t>(ctx, cap);
-  SWG_CHECK_ARENA(ctx);
-  t->mask = (uint32_t)(cap - 1);
-  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(cap), EW, 0, st>>>(cap, reinterpret_cast<uint64_t*>(t->keys), ~0ull));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(cap), EW, 0, st>>>(cap, t->vals, NONE));
-  SWG_KERNEL_CHECK(ctx);
-  return SWG_OK;
-}
-
-// plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
-// reference's all_chains order (their index is the plane sweep's tie-break `idx`).
-// Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).
-int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
-                              uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
-                              int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out) {
-  hipStream_t st = ctx->stream;
-  *n_kept_out = 0;
-  if (T.nc == 0) return SWG_OK;
-  uint64_t kq, kt;
-  if (mode == SWG_MODE_ONE_TO_ONE) {
-    kq = 1;
-    kt = 1;
-  } else {
-    kq = max_q ? max_q : SWG_K_INF;
-    kt = max_t ? max_t : SWG_K_INF;
-  }
-  SWG_HIP(ctx, hipMemsetAsync(C_kept, 0, T.nc, st));
-  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, T.nc * sizeof(uint32_t), st));
-  // ---- only the span/identity-filtered chains take part (compaction keeps their relative order, which is
-  //      all the plane sweep's index tie-break needs)
-  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
-  SWG_CHECK_ARENA(ctx);
-  swg_flag_scan ok_scan;
-  SWG_TRY(swg_flags_count(ctx, T.ok, T.nc, &ok_scan, d_tot));
-  uint64_t nc = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
-  if (nc == 0) return SWG_OK;
-  uint32_t* ok_idx = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qid = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* tid = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qs = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qe = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* ts = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* te = swg_alloc<uint32_t>(ctx, nc);
-  double* wid = swg_alloc<double>(ctx, nc);
-  uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
-  uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
-  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
-  uint8_t* kept = swg_alloc<uint8_t>(ctx, nc);
-  uint32_t* num = swg_alloc<uint32_t>(ctx, nc);
-  SWG_CHECK_ARENA(ctx);
-  SWG_TRY(swg_flags_compact(ctx, ok_scan, ok_idx));
-  SWG_LAUNCH(ctx, "chain_compact", chain_compact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, qid,
-                                                                     tid, qs, qe, ts, te, wid));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, qid, tid, n_seq, seg));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
-  swg_axis_input ax;
-  ax.n = nc;
-  ax.seg = seg;
-  ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
-  ax.pos_bits = pos_bits;
-  ax.score_key = skey;
-  ax.alive = nullptr;
-  ax.start = qs;
-  ax.end = qe;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
-  ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
-  ax.start = ts;
-  ax.end = te;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
-
-  // ---- numbering -------------------------------------------------------------------------------------
-  uint64_t* seg_sorted = swg_alloc<uint64_t>(ctx, nc);
-  uint64_t* seg_tmp = swg_alloc<uint64_t>(ctx, nc);
-  uint32_t* c_sorted = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* c_tmp = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* run_flag = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* run_excl = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
-  SWG_CHECK_ARENA(ctx);
-  PairTable gp2_first;
-  SWG_TRY(pair_table_make(ctx, n_g2, nc, &gp2_first));  // pairs that occur <= chromosome-pair runs <= chains
-  SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
-  SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, ax.seg_bits));
-  SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
-  SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, run_excl, run_flag, qid, tid, seq_genome2,
-                                                                           run_of_chain, pair_first, gp2_first));
-  SWG_KERNEL_CHECK(ctx);
-  // kept chains, in index order
-  swg_flag_scan kept_scan;
-  SWG_TRY(swg_flags_count(ctx, kept, nc, &kept_scan, d_tot));
-  uint64_t nk = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
-  SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
-  *n_kept_out = nk;
-  if (nk) {
-    uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
-    uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
-    uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
-    uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
-    SWG_CHECK_ARENA(ctx);
-    SWG_TRY(swg_flags_compact(ctx, kept_scan, kept_list));
-    const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
-    SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
-                                                                    seq_genome2, c_bits, nkey));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
-    SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
-    SWG_KERNEL_CHECK(ctx);
-  }
-  SWG_LAUNCH(ctx, "chain_uncompact", chain_uncompact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, kept, num, C_kept, C_num));
-  SWG_KERNEL_CHECK(ctx);
-  return SWG_OK;
-}
-
-// ---- chains from records ------------------------------------------------------------------------------------------
-struct ChainBuild {
-  // sort A (all `alive` records)
-  uint64_t M = 0;
-  uint64_t* keyA = nullptr;
-  uint32_t* idxA = nullptr;  // original index at A position
-  uint32_t *a_qe = nullptr, *a_ts = nullptr, *a_te = nullptr, *a_dpair = nullptr;
-  uint64_t n_pairs = 0;
-  // survivors (members of chains)
-  uint64_t m = 0;
-  uint32_t* s_a = nullptr;      // A position
-  uint32_t* s_idx = nullptr;    // original index
-  uint32_t* s_chain = nullptr;  // chain (all_chains index)
-  // chains, in all_chains order
-  ChainTable T;
-  uint8_t* C_strand = nullptr;
-  uint32_t* C_dpair = nullptr;
-};
-
-// merge_mappings_into_chains (paf_filter.rs:750-933) over the records with member[i] != 0, sorted
-// together with every alive[i] != 0 record (sort A is reused by the anchor / rescue steps).
-int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                 uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out,
-                 const uint32_t* q_order = nullptr) {
-  const uint64_t n = r->n;
-  hipStream_t st = ctx->stream;
-  ChainBuild& B = *out;
-  const int pair_bits = swg_bits_for((uint64_t)r->n_seq * r->n_seq * 2);
-  if (pair_bits + pos_bits > 64)
-    return swg_set_error(ctx, SWG_ERR_RANGE, "chain sort key (%d pair bits + %d coordinate bits) exceeds 64 bits",
-                         pair_bits, pos_bits);
-  // ---- compaction of alive, sort A
-  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 4);
-  SWG_CHECK_ARENA(ctx);
-  swg_flag_scan alive_scan;
-  SWG_TRY(swg_flags_count(ctx, alive, n, &alive_scan, d_tot));
-  uint64_t M = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
-  B.M = M;
-  if (M == 0) return SWG_OK;
-  B.keyA = swg_alloc<uint64_t>(ctx, M);
-  B.idxA = swg_alloc<uint32_t>(ctx, M);
-  uint64_t* key_tmp = swg_alloc<uint64_t>(ctx, M);
-  uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
-  B.a_qe = swg_alloc<uint32_t>(ctx, M);
-  B.a_ts = swg_alloc<uint32_t>(ctx, M);
-  B.a_te = swg_alloc<uint32_t>(ctx, M);
-  B.a_dpair = swg_alloc<uint32_t>(ctx, M);
-  uint8_t* a_keep = swg_alloc<uint8_t>(ctx, M);
-  uint32_t* pair_flag = swg_alloc<uint32_t>(ctx, M);
-  uint32_t* pair_excl = swg_alloc<uint32_t>(ctx, M);
-  SWG_CHECK_ARENA(ctx);
-  if (q_order) {
-    // The mapping sweep sorted the same alive records by (query sequence, target genome, q_start, index): dead records
-    // first, so the last M entries are the alive ones, and inside every (query, target, strand) group they already stand
-    // in q_start order with ties in index order -- the order sort A must end in (paf_filter.rs:777).  Stable passes over
-    // the group bits alone finish it: 2 radix passes instead of 6 for a 100-genome pangenome.
-    SWG_HIP(ctx, hipMemcpyAsync(B.idxA, q_order + (n - M), M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
-                                                                r->n_seq, pos_bits, B.keyA));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
-  } else {
-    SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
-    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
-                                                                r->n_seq, pos_bits, B.keyA));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
-  }
-  SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
-                                                        pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, pair_excl, M, d_tot + 1));
-  SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
-  SWG_KERNEL_CHECK(ctx);
-  // ---- survivors in A order
-  swg_flag_scan keep_scan;
-  SWG_TRY(swg_flags_count(ctx, a_keep, M, &keep_scan, d_tot + 2));
-  uint64_t h3[3];
-  SWG_TRY(swg_read_scalars(ctx, d_tot, h3, 3));
-  B.n_pairs = h3[1];
-  const uint64_t m = h3[2];
-  B.m = m;
-  B.T.nc = 0;
-  if (m == 0) return SWG_OK;
-  if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
-  B.s_a = swg_alloc<uint32_t>(ctx, m);
-  B.s_idx = swg_alloc<uint32_t>(ctx, m);
-  B.s_chain = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_qs = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_qe = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_ts = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_te = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_m = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_b = swg_alloc<uint32_t>(ctx, m);
-  uint64_t* s_grp = swg_alloc<uint64_t>(ctx, m);
-  uint32_t* head_flag = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* gidx_excl = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_gidx = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* group_begin = swg_alloc<uint32_t>(ctx, m);
-  unsigned long long* bps = swg_alloc<unsigned long long>(ctx, m);
-  uint32_t* pred = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* hd = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* h_qe = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* h_ts = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* h_te = swg_alloc<uint32_t>(ctx, m);
-  unsigned long long* h_sm = swg_alloc<unsigned long long>(ctx, m);
-  unsigned long long* h_sb = swg_alloc<unsigned long long>(ctx, m);
-  uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* group_first = swg_alloc<uint32_t>(ctx, m);
-  PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
-  uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
-  SWG_CHECK_ARENA(ctx);
-  SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
-  if (m == M) {  // every record of sort A is a member: s_a is the identity
-    s_qe = B.a_qe;
-    s_ts = B.a_ts;
-    s_te = B.a_te;
-    B.s_idx = B.idxA;
-    SWG_LAUNCH(ctx, "gatherS", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
-                                                              s_m, s_b, s_grp, head_flag));
-  } else {
-    SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
-                                                          r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
-                                                          B.s_idx, s_grp, head_flag));
-  }
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, head_flag, gidx_excl, m, d_tot + 3));
-  SWG_LAUNCH(ctx, "group_bounds", group_bounds_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, gidx_excl, s_gidx, group_begin));
-  SWG_KERNEL_CHECK(ctx);
-  uint64_t n_groups = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot + 3, &n_groups, 1));
-  // ---- best-buddy chaining
-  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(bps), ~0ull));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
-  SWG_KERNEL_CHECK(ctx);
-  {
-    // units = groups cut where no window can straddle; short-window units go four per wavefront (16-lane
-    // slices), the rest one wavefront each
-    uint32_t* unit_flag = swg_alloc<uint32_t>(ctx, m);
-    uint32_t* unit_excl = swg_alloc<uint32_t>(ctx, m);
-    uint64_t* d_nu = swg_alloc<uint64_t>(ctx, 1);
-    SWG_CHECK_ARENA(ctx);
-    const bool long_groups = m / n_groups > 8192;  // few, long groups: scan-based reductions
-    if (long_groups) {
-      swg_arena_mark mk = swg_arena_save(ctx);
-      uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
-      SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, s_qe, 0, comp));
-      SWG_KERNEL_CHECK(ctx);
-      SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
-      SWG_LAUNCH(ctx, "cuts_from_scan", cuts_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, s_qs, max_gap, unit_flag));
-      SWG_KERNEL_CHECK(ctx);
-      swg_arena_restore(ctx, mk);
-    } else {
-      uint64_t blocks = (n_groups + 3) / 4;
-      const uint64_t mb = (uint64_t)ctx->num_cu * 16;
-      if (blocks > mb) blocks = mb;
-      SWG_LAUNCH(ctx, "chain_cuts", chain_cuts_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs, s_qe,
-                                                                           max_gap, unit_flag));
-      SWG_KERNEL_CHECK(ctx);
-    }
-    SWG_TRY(swg_exclusive_scan_u32(ctx, unit_flag, unit_excl, m, d_nu));
-    uint64_t n_units = 0;
-    SWG_TRY(swg_read_scalars(ctx, d_nu, &n_units, 1));
-    uint32_t* unit_begin = swg_alloc<uint32_t>(ctx, n_units);
-    SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
-    SWG_KERNEL_CHECK(ctx);
-    unsigned long long* c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
-    uint32_t* c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
-    uint32_t* c_n = swg_alloc<uint32_t>(ctx, m);
-    uint32_t* c_ext = swg_alloc<uint32_t>(ctx, m);
-    SWG_CHECK_ARENA(ctx);
-    if (getenv("SWG_DEBUG"))
-      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
-              (unsigned long long)n_groups, (unsigned long long)n_units);
-    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wavefront per i) kernel at any size
-    if (long_groups || force_deep)
-      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
-                                                   m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
-    else
-      SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                              s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "chain_select_lanes", chain_select_lanes_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, s_grp,
-                                                                                    s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, bps,
-                                                                                    pred));
-    SWG_KERNEL_CHECK(ctx);
-    {
-      uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
-      uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 1);
-      SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "unit_big_flag", unit_big_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_big));
-      SWG_KERNEL_CHECK(ctx);
-      swg_flag_scan big_scan;
-      SWG_TRY(swg_flags_count(ctx, is_big, n_units, &big_scan, d_nb));
-      uint64_t n_big = 0;
-      SWG_TRY(swg_read_scalars(ctx, d_nb, &n_big, 1));
-      if (n_big) {
-        uint32_t* big_list = swg_alloc<uint32_t>(ctx, n_big);
-        SWG_CHECK_ARENA(ctx);
-        SWG_TRY(swg_flags_compact(ctx, big_scan, big_list));
-        // ---- block-speculative selection of the long units
-        uint32_t* S_u = swg_alloc<uint32_t>(ctx, n_big);
-        uint32_t* nblk_u = swg_alloc<uint32_t>(ctx, n_big);
-        uint32_t* blk_off = swg_alloc<uint32_t>(ctx, n_big);
-        uint64_t* d_nblk = swg_alloc<uint64_t>(ctx, 1);
-        unsigned long long* ext = swg_alloc<unsigned long long>(ctx, m);
-        unsigned long long* v_own = swg_alloc<unsigned long long>(ctx, m);
-        unsigned long long* v_prev = swg_alloc<unsigned long long>(ctx, m);
-        uint32_t* p_own = swg_alloc<uint32_t>(ctx, m);
-        uint32_t* p_prev = swg_alloc<uint32_t>(ctx, m);
-        uint32_t* spec_changed = swg_alloc<uint32_t>(ctx, 2);
-        uint64_t* d_smax = swg_alloc<uint64_t>(ctx, 1);  // adjacent to d_nblk: read back together
-        SWG_CHECK_ARENA(ctx);
-        SWG_HIP(ctx, hipMemsetAsync(d_smax, 0, 8, st));
-        if (m / n_big > 65536) {  // few, very long units
-          uint32_t* wmax_u = swg_alloc<uint32_t>(ctx, n_units);
-          SWG_CHECK_ARENA(ctx);
-          SWG_HIP(ctx, hipMemsetAsync(wmax_u, 0, n_units * sizeof(uint32_t), st));
-          const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
-          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u));
-          SWG_KERNEL_CHECK(ctx);
-          SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                                (uint32_t)m, wmax_u, S_u, nblk_u,
-                                                                                reinterpret_cast<uint32_t*>(d_smax)));
-          SWG_KERNEL_CHECK(ctx);
-        } else {
-          SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                          (uint32_t)m, c_ext, S_u, nblk_u,
-                                                                          reinterpret_cast<uint32_t*>(d_smax)));
-          SWG_KERNEL_CHECK(ctx);
-        }
-        SWG_TRY(swg_exclusive_scan_u32(ctx, nblk_u, blk_off, n_big, d_nblk));
-        uint64_t n_spec = 0, s_max = 0;
-        SWG_TRY(swg_read_scalars(ctx, d_nblk, &n_spec, 1));
-        SWG_TRY(swg_read_scalars(ctx, d_smax, &s_max, 1));
-        s_max &= 0xffffffffull;
-        SpecBlock* desc = swg_alloc<SpecBlock>(ctx, n_spec);
-        SWG_CHECK_ARENA(ctx);
-        SWG_LAUNCH(ctx, "spec_desc", spec_desc_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                        (uint32_t)m, S_u, nblk_u, blk_off, desc));
-        SWG_KERNEL_CHECK(ctx);
-        SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(ext), ~0ull));
-        SWG_KERNEL_CHECK(ctx);
-        const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
-        const bool small_ring = s_max + 64 <= 1024;  // every window fits a 1024-slot ring: 20 KB of LDS instead of 80
-        // The ring is a cache (positions outside it are read from global memory), so its size only trades LDS hits for
-        // resident wavefronts: with windows of at most a few hundred elements a 256-slot ring (5 KB) lets 32 one-wave
-        // work-groups share a CU instead of 8.
-        static const char* ring_knob = getenv("SWG_SPEC_RING");
-        const bool tiny_ring = ring_knob ? atoi(ring_knob) == 256 : s_max <= 512;
-        int rounds = 0;
-        for (uint64_t round = 0; round <= n_spec + 1; ++round) {
-          SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
-          SWG_KERNEL_CHECK(ctx);
-          if (tiny_ring)
-            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<256><<<(unsigned)(n_spec < (uint64_t)ctx->num_cu * 32 ? n_spec : (uint64_t)ctx->num_cu * 32), 64, 0, st>>>(
-                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
-                                              v_prev, p_own, p_prev));
-          else if (small_ring)
-            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<1024><<<(unsigned)rblocks, 64, 0, st>>>(
-                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
-                                              v_prev, p_own, p_prev));
-          else
-            SWG_LAUNCH(ctx, "spec_round", spec_round_kernel<4096><<<(unsigned)rblocks, 64, 0, st>>>(
-                                              (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, v_own,
-                                              v_prev, p_own, p_prev));
-          SWG_KERNEL_CHECK(ctx);
-          SWG_HIP(ctx, hipMemsetAsync(spec_changed, 0, 8, st));
-          SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, v_prev, ext, spec_changed));
-          SWG_KERNEL_CHECK(ctx);
-          uint64_t ch = 0;
-          SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(spec_changed), &ch, 1));
-          ++rounds;
-          if ((uint32_t)ch == 0) break;
-        }
-        if (getenv("SWG_DEBUG"))
-          fprintf(stderr, "[swg] long units: %llu, blocks %llu (longest %llu), rounds %d\n", (unsigned long long)n_big,
-                  (unsigned long long)n_spec, (unsigned long long)s_max, rounds);
-#ifdef SWG_SPEC_STATS
-        {
-          unsigned long long hs[8];
-          (void)hipStreamSynchronize(st);
-          (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_spec_stats), sizeof hs);
-          fprintf(stderr, "[swg] spec stats (cumulative): steps %llu, fallbacks %llu, fallback batches %llu\n", hs[0], hs[1], hs[2]);
-        }
-#endif
-        SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
-        SWG_KERNEL_CHECK(ctx);
-      }
-    }
-    {
-      // what is left: units longer than a lane should walk and shorter than BIG_UNIT, one wavefront each
-      uint8_t* is_mid = swg_alloc<uint8_t>(ctx, n_units);
-      uint64_t* d_nm = swg_alloc<uint64_t>(ctx, 1);
-      SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "unit_mid_flag", unit_mid_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_mid));
-      SWG_KERNEL_CHECK(ctx);
-      swg_flag_scan mid_scan;
-      SWG_TRY(swg_flags_count(ctx, is_mid, n_units, &mid_scan, d_nm));
-      uint64_t n_mid = 0;
-      SWG_TRY(swg_read_scalars(ctx, d_nm, &n_mid, 1));
-      if (n_mid) {
-        uint32_t* mid_list = swg_alloc<uint32_t>(ctx, n_mid);
-        SWG_CHECK_ARENA(ctx);
-        SWG_TRY(swg_flags_compact(ctx, mid_scan, mid_list));
-        uint64_t blocks = (n_mid + 3) / 4;
-        const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-        if (blocks > max_blocks) blocks = max_blocks;
-        SWG_LAUNCH(ctx, "chain_select", chain_select_kernel<<<(unsigned)blocks, 256, 0, st>>>((uint32_t)n_mid, mid_list, (uint32_t)n_units, unit_begin,
-                                                                                  (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j,
-                                                                                  c_n, s_gidx, group_begin, (uint32_t)n_groups, bps, pred));
-        SWG_KERNEL_CHECK(ctx);
-      }
-    }
-  }
-  // ---- labelling by pointer jumping
-  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd));
-  SWG_KERNEL_CHECK(ctx);
-  for (int round = 0; round < 64; ++round) {
-    SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
-    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
-    SWG_KERNEL_CHECK(ctx);
-    uint64_t ch = 0;
-    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
-    if ((uint32_t)ch == 0) break;
-  }
-  // ---- aggregates
-  SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
-                                                                                  h_te, h_sm, h_sb, is_head));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
-                                                                        h_sm, h_sb));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
-  uint64_t nc = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
-  // ---- all_chains order
-  SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, group_first, NONE));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(pair_table_make(ctx, r->n_genome_last, B.n_pairs, &gp_first));
-  if (m / n_groups > 8192) {
-    swg_arena_mark mk = swg_arena_save(ctx);
-    uint64_t* comp = swg_alloc<uint64_t>(ctx, m);
-    SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, B.s_idx, 1, comp));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
-    SWG_LAUNCH(ctx, "group_first_from_scan", group_first_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, group_first));
-    swg_arena_restore(ctx, mk);
-  } else {
-    uint64_t blocks = (n_groups + 3) / 4;
-    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
-    if (blocks > max_blocks) blocks = max_blocks;
-    SWG_LAUNCH(ctx, "group_first", group_first_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m,
-                                                                               B.s_idx, group_first));
-  }
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
-                                                                                    r->seq_genome_last, gp_first));
-  SWG_KERNEL_CHECK(ctx);
-  uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
-  uint64_t* g_key = swg_alloc<uint64_t>(ctx, n_groups);
-  uint64_t* g_key_tmp = swg_alloc<uint64_t>(ctx, n_groups);
-  uint32_t* g_sorted = swg_alloc<uint32_t>(ctx, n_groups);
-  uint32_t* g_sorted_tmp = swg_alloc<uint32_t>(ctx, n_groups);
-  uint32_t* g_first_chain = swg_alloc<uint32_t>(ctx, n_groups);
-  uint32_t* g_nchains = swg_alloc<uint32_t>(ctx, n_groups);
-  uint32_t* g_sizes = swg_alloc<uint32_t>(ctx, n_groups);
-  uint32_t* g_base = swg_alloc<uint32_t>(ctx, n_groups);
-  ChainTable& T = B.T;
-  T.nc = nc;
-  T.qid = swg_alloc<uint32_t>(ctx, nc);
-  T.tid = swg_alloc<uint32_t>(ctx, nc);
-  T.qs = swg_alloc<uint32_t>(ctx, nc);
-  T.qe = swg_alloc<uint32_t>(ctx, nc);
-  T.ts = swg_alloc<uint32_t>(ctx, nc);
-  T.te = swg_alloc<uint32_t>(ctx, nc);
-  T.wid = swg_alloc<double>(ctx, nc);
-  T.ok = swg_alloc<uint8_t>(ctx, nc);
-  B.C_strand = swg_alloc<uint8_t>(ctx, nc);
-  B.C_dpair = swg_alloc<uint32_t>(ctx, nc);
-  SWG_CHECK_ARENA(ctx);
-  const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
-  const unsigned gblk = nblk(n_groups);
-  SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, cpos, (uint32_t)nc,
-                                                           B.s_idx, group_first, r->q_id, r->t_id, r->seq_genome_last,
-                                                           genome_pair_major, gp_first, idx_bits, g_key, g_sorted, g_first_chain,
-                                                           g_nchains));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &g_key, &g_sorted, &g_key_tmp, &g_sorted_tmp, n_groups, 0, 2 * idx_bits));
-  SWG_LAUNCH(ctx, "group_sizes_sorted", group_sizes_sorted_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_nchains, g_sizes));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, g_sizes, g_sizes, n_groups, nullptr));
-  SWG_LAUNCH(ctx, "group_base", group_base_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_sizes, g_base));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
-                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
-                                       r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
-                                       B.C_strand, B.C_dpair, T.ok, rank_of));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, cpos, rank_of, B.s_chain));
-  SWG_KERNEL_CHECK(ctx);
-  return SWG_OK;
-}
 
 // ---- anchors, inversions, rescue -------------------------------------------------------------------------------------
 // anchor_num[i] = chain number of the kept chain record i belongs to (0 = not an anchor);
@@ -2588,71 +434,6 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   return finish_counts();
 }
 
-// ---- public seams -----------------------------------------------------------------------------------------------------
-extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_t* q_id, const uint32_t* t_id,
-                                         uint32_t n_seq, const uint32_t* seq_genome_two, uint32_t n_genome_two,
-                                         const uint64_t* q_start, const uint64_t* q_end, const uint64_t* t_start,
-                                         const uint64_t* t_end, const double* identity, int mode,
-                                         uint64_t max_per_query, uint64_t max_per_target, double thr, int scoring,
-                                         uint64_t* order_out, uint64_t* n_kept) {
-  if (!ctx) return SWG_ERR_INVALID;
-  if (n_kept) *n_kept = 0;
-  if (n == 0) return SWG_OK;
-  if (!q_id || !t_id || !seq_genome_two || !q_start || !q_end || !t_start || !t_end || !identity || !order_out ||
-      !n_kept)
-    return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
-  if (mode < 0 || mode > 2 || scoring < 0 || scoring > 4 || n_seq == 0 || n_genome_two == 0)
-    return swg_set_error(ctx, SWG_ERR_INVALID, "bad mode / scoring / table size");
-  if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chains");
-  SWG_HIP(ctx, hipSetDevice(ctx->device));
-  std::vector<uint32_t> h(4 * n);
-  uint32_t mx = 0;
-  SWG_TRY(swg_narrow_coords(ctx, n, q_start, q_end, h.data(), h.data() + n, "query"));
-  SWG_TRY(swg_narrow_coords(ctx, n, t_start, t_end, h.data() + 2 * n, h.data() + 3 * n, "target"));
-  for (uint64_t i = 0; i < 4 * n; ++i)
-    if (h[i] > mx) mx = h[i];
-  for (uint64_t i = 0; i < n; ++i)
-    if (q_id[i] >= n_seq || t_id[i] >= n_seq) return swg_set_error(ctx, SWG_ERR_INVALID, "sequence id out of range");
-  const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
-  hipStream_t st = ctx->stream;
-  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 400 + (size_t(16) << 20)));
-  std::vector<uint32_t> num(n);
-  int rc = swg_run_with_arena(ctx, [&]() -> int {
-    ChainTable T;
-    T.nc = n;
-    uint32_t* d_c = swg_alloc<uint32_t>(ctx, 4 * n);
-    T.qid = swg_alloc<uint32_t>(ctx, n);
-    T.tid = swg_alloc<uint32_t>(ctx, n);
-    T.wid = swg_alloc<double>(ctx, n);
-    T.ok = swg_alloc<uint8_t>(ctx, n);
-    uint32_t* d_g2 = swg_alloc<uint32_t>(ctx, n_seq);
-    uint8_t* C_kept = swg_alloc<uint8_t>(ctx, n);
-    uint32_t* C_num = swg_alloc<uint32_t>(ctx, n);
-    SWG_CHECK_ARENA(ctx);
-    T.qs = d_c;
-    T.qe = d_c + n;
-    T.ts = d_c + 2 * n;
-    T.te = d_c + 3 * n;
-    SWG_HIP(ctx, hipMemcpyAsync(d_c, h.data(), 4 * n * 4, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemcpyAsync(T.qid, q_id, n * 4, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemcpyAsync(T.tid, t_id, n * 4, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemcpyAsync(T.wid, identity, n * 8, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemcpyAsync(d_g2, seq_genome_two, (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemsetAsync(T.ok, 1, n, st));
-    uint64_t nk = 0;
-    SWG_TRY(scaffold_sweep_and_number(ctx, T, n_seq, d_g2, n_genome_two, mode, max_per_query, max_per_target, thr,
-                                      scoring, pos_bits, C_kept, C_num, &nk));
-    SWG_HIP(ctx, hipMemcpyAsync(num.data(), C_num, n * 4, hipMemcpyDeviceToHost, st));
-    SWG_HIP(ctx, hipStreamSynchronize(st));
-    *n_kept = nk;
-    return SWG_OK;
-  });
-  if (rc != SWG_OK) return rc;
-  for (uint64_t i = 0; i < n; ++i)
-    if (num[i]) order_out[num[i] - 1] = i;
-  return SWG_OK;
-}
-
 extern "C" int swg_merge_chains(swg_ctx* ctx, const swg_records* rec, uint64_t max_gap, uint32_t* chain_of,
                                 uint32_t* c_q_start, uint32_t* c_q_end, uint32_t* c_t_start, uint32_t* c_t_end,
                                 double* c_weighted_identity, uint64_t* n_chains) {
@@ -2713,98 +494,6 @@ extern "C" int swg_merge_chains(swg_ctx* ctx, const swg_records* rec, uint64_t m
     SWG_HIP(ctx, hipStreamSynchronize(st));
     for (uint64_t p = 0; p < B.m; ++p) chain_of[s_idx[p]] = s_chain[p];
     *n_chains = nc;
-    return SWG_OK;
-  });
-}
-
-// Connected components standing in for UnionFind::get_sets (src/union_find.rs:52-63).  Sets are returned in
-// ascending order of their smallest member, members ascending -- identical to the reference's root order
-// whenever every union(x, y) joins a fresh singleton y > x to x's set (how the filter uses it,
-// paf_filter.rs:854-859); for arbitrary union orders the reference's order depends on union-by-rank history.
-namespace {
-__global__ __launch_bounds__(EW) void cc_hook_kernel(uint64_t m, const uint32_t* __restrict__ xs,
-                                                     const uint32_t* __restrict__ ys, uint32_t* label,
-                                                     uint32_t* __restrict__ changed) {
-  uint64_t e = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (e >= m) return;
-  const uint32_t lx = label[xs[e]], ly = label[ys[e]];
-  if (lx == ly) return;
-  const uint32_t lo = lx < ly ? lx : ly, hi = lx < ly ? ly : lx;
-  atomicMin(&label[hi], lo);
-  *changed = 1;
-}
-__global__ __launch_bounds__(EW) void cc_compress_kernel(uint64_t n, uint32_t* label, uint32_t* __restrict__ changed) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i >= n) return;
-  uint32_t l = label[i];
-  uint32_t ll = label[l];
-  if (ll != l) {
-    label[i] = ll;
-    *changed = 1;
-  }
-}
-__global__ __launch_bounds__(EW) void cc_root_flag_kernel(uint64_t n, const uint32_t* __restrict__ label,
-                                                          uint32_t* __restrict__ flag) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) flag[i] = label[i] == i ? 1u : 0u;
-}
-__global__ __launch_bounds__(EW) void cc_set_of_kernel(uint64_t n, const uint32_t* __restrict__ label,
-                                                       const uint32_t* __restrict__ root_excl,
-                                                       uint32_t* __restrict__ set_of) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i < n) set_of[i] = root_excl[label[i]];
-}
-}  // namespace
-
-extern "C" int swg_union_find_sets(swg_ctx* ctx, uint64_t n, uint64_t m, const uint32_t* xs, const uint32_t* ys,
-                                   uint32_t* set_of, uint64_t* n_sets) {
-  if (!ctx) return SWG_ERR_INVALID;
-  if (!n_sets) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL argument");
-  *n_sets = 0;
-  if (n == 0) return SWG_OK;
-  if (!set_of || (m && (!xs || !ys))) return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
-  if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many elements");
-  for (uint64_t e = 0; e < m; ++e)
-    if (xs[e] >= n || ys[e] >= n) return swg_set_error(ctx, SWG_ERR_INVALID, "element out of range");
-  SWG_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)(n + m) * 32 + (size_t(8) << 20)));
-  return swg_run_with_arena(ctx, [&]() -> int {
-    uint32_t* label = swg_alloc<uint32_t>(ctx, n);
-    uint32_t* flag = swg_alloc<uint32_t>(ctx, n);
-    uint32_t* excl = swg_alloc<uint32_t>(ctx, n);
-    uint32_t* d_set = swg_alloc<uint32_t>(ctx, n);
-    uint32_t* dx = swg_alloc<uint32_t>(ctx, m + 1);
-    uint32_t* dy = swg_alloc<uint32_t>(ctx, m + 1);
-    uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
-    uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
-    SWG_CHECK_ARENA(ctx);
-    if (m) {
-      SWG_HIP(ctx, hipMemcpyAsync(dx, xs, m * 4, hipMemcpyHostToDevice, st));
-      SWG_HIP(ctx, hipMemcpyAsync(dy, ys, m * 4, hipMemcpyHostToDevice, st));
-    }
-    SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(n), EW, 0, st>>>(n, label));
-    SWG_KERNEL_CHECK(ctx);
-    for (int round = 0; round < 100000 && m; ++round) {
-      SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
-      SWG_LAUNCH(ctx, "cc_hook", cc_hook_kernel<<<nblk(m), EW, 0, st>>>(m, dx, dy, label, changed));
-      SWG_KERNEL_CHECK(ctx);
-      SWG_LAUNCH(ctx, "cc_compress", cc_compress_kernel<<<nblk(n), EW, 0, st>>>(n, label, changed));
-      SWG_KERNEL_CHECK(ctx);
-      uint64_t ch = 0;
-      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
-      if ((uint32_t)ch == 0) break;
-    }
-    SWG_LAUNCH(ctx, "cc_root_flag", cc_root_flag_kernel<<<nblk(n), EW, 0, st>>>(n, label, flag));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_exclusive_scan_u32(ctx, flag, excl, n, d_tot));
-    SWG_LAUNCH(ctx, "cc_set_of", cc_set_of_kernel<<<nblk(n), EW, 0, st>>>(n, label, excl, d_set));
-    SWG_KERNEL_CHECK(ctx);
-    uint64_t ns = 0;
-    SWG_TRY(swg_read_scalars(ctx, d_tot, &ns, 1));
-    SWG_HIP(ctx, hipMemcpyAsync(set_of, d_set, n * 4, hipMemcpyDeviceToHost, st));
-    SWG_HIP(ctx, hipStreamSynchronize(st));
-    *n_sets = ns;
     return SWG_OK;
   });
 }

@@ -1,0 +1,132 @@
+// Shared declarations of the scaffold stage's translation units (internal):
+//   swg_chain.hip           sort A, survivors, best-buddy predecessor selection     (src/paf_filter.rs:761-851)
+//   swg_chain_table.hip     labelling, aggregates, all_chains order, span/identity   (src/union_find.rs, paf_filter.rs:854-933, 449-455)
+//   swg_scaffold_sweep.hip  plane_sweep_scaffolds + chain numbering                  (src/plane_sweep_scaffold.rs:47-251)
+//   swg_scaffold.hip        anchors, inversion capture, rescue, the stage driver     (src/paf_filter.rs:436-747)
+//   swg_union_find.hip      UnionFind::get_sets seam                                 (src/union_find.rs:52-63)
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "swg_log.h"
+#include "swg_pipeline.h"
+
+namespace swg_scaf {
+
+constexpr int EW = 256;
+constexpr uint32_t NONE = 0xffffffffu;
+inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
+
+// small fills; one copy per translation unit (internal linkage)
+static __global__ __launch_bounds__(EW) void fill_u32_kernel(uint64_t n, uint32_t* __restrict__ p, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static __global__ __launch_bounds__(EW) void fill_u64_kernel(uint64_t n, uint64_t* __restrict__ p, uint64_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static __global__ __launch_bounds__(EW) void iota_u32_kernel(uint64_t n, uint32_t* __restrict__ p) {
+  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+// genome pair (gq, gt) -> u32, "first appearance" tables of the two prefix rules.  Up to 2^14 genomes: a dense G x G array
+// (one load per lookup).  Beyond (names without '#': every contig its own genome): open addressing over the pairs that
+// actually occur -- their number is bounded by the (query, target) groups the caller has already counted.
+struct PairTable {
+  uint32_t* dense;      // [G * G] or nullptr
+  unsigned long long* keys;  // sparse: [mask + 1], ~0 = empty
+  uint32_t* vals;       // sparse: [mask + 1]
+  uint32_t mask;
+  uint32_t n_genome;
+};
+__device__ __forceinline__ uint32_t* pair_slot(const PairTable& t, uint32_t gq, uint32_t gt) {  // inserts when absent
+  if (t.dense) return t.dense + ((size_t)gq * t.n_genome + gt);
+  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
+  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
+  for (;;) {
+    unsigned long long k = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == ~0ull) {
+      k = atomicCAS(&t.keys[h], ~0ull, key);
+      if (k == ~0ull) k = key;
+    }
+    if (k == key) return t.vals + h;
+    h = (h + 1) & t.mask;
+  }
+}
+__device__ __forceinline__ uint32_t pair_get(const PairTable& t, uint32_t gq, uint32_t gt) {  // the pair is present
+  if (t.dense) return t.dense[(size_t)gq * t.n_genome + gt];
+  const unsigned long long key = (unsigned long long)gq * t.n_genome + gt;
+  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & t.mask;
+  while (t.keys[h] != key) h = (h + 1) & t.mask;
+  return t.vals[h];
+}
+constexpr uint64_t DENSE_PAIR_LIMIT = uint64_t(1) << 28;  // G * G entries
+
+// Allocates (arena) and clears a PairTable for G genomes of which at most `bound` pairs occur.  (swg_chain_table.hip)
+int pair_table_make(swg_ctx* ctx, uint32_t n_genome, uint64_t bound, PairTable* t);
+
+struct ChainTable {
+  uint64_t nc = 0;
+  uint32_t *qid = nullptr, *tid = nullptr, *qs = nullptr, *qe = nullptr, *ts = nullptr, *te = nullptr;
+  double* wid = nullptr;
+  uint8_t* ok = nullptr;  // passes span/identity filter (input of the scaffold sweep)
+};
+
+struct ChainBuild {
+  // sort A (all `alive` records)
+  uint64_t M = 0;
+  uint64_t* keyA = nullptr;
+  uint32_t* idxA = nullptr;  // original index at A position
+  uint32_t *a_qe = nullptr, *a_ts = nullptr, *a_te = nullptr, *a_dpair = nullptr;
+  uint64_t n_pairs = 0;
+  // survivors (members of chains)
+  uint64_t m = 0;
+  uint32_t* s_a = nullptr;      // A position
+  uint32_t* s_idx = nullptr;    // original index
+  uint32_t* s_chain = nullptr;  // chain (all_chains index)
+  // chains, in all_chains order
+  ChainTable T;
+  uint8_t* C_strand = nullptr;
+  uint32_t* C_dpair = nullptr;
+};
+
+// What the predecessor selection (swg_chain.hip) hands to the chain table (swg_chain_table.hip): the members of sort A in
+// A order (`s_*`, m entries), their (query, target, strand) groups, and pred[p] = best-buddy predecessor of p (NONE = head).
+struct ChainWork {
+  uint64_t n_groups = 0;
+  uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
+  uint64_t* s_grp = nullptr;        // (q * n_seq + t) * 2 + strand
+  uint32_t* head_flag = nullptr;    // 1 = first member of its group
+  uint32_t* s_gidx = nullptr;       // dense group index
+  uint32_t* group_begin = nullptr;  // [n_groups]
+  uint32_t* pred = nullptr;
+  uint64_t* d_tot = nullptr;        // 4 device scalars
+};
+
+// merge_mappings_into_chains (paf_filter.rs:750-933) in two halves:
+//   chain_predecessors  : sort A over the alive records, members compacted in A order, best-buddy selection -> pred
+//   chain_table_build   : chains = paths of pred; heads, aggregates, all_chains order, span / identity filter -> B.T, B.s_chain
+int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
+                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order);
+int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, uint64_t min_len, double min_ident,
+                      bool genome_pair_major, ChainBuild* out, const ChainWork& work);
+inline int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
+                        uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out,
+                        const uint32_t* q_order = nullptr) {
+  ChainWork W;
+  SWG_TRY(chain_predecessors(ctx, r, alive, member, max_gap, pos_bits, out, &W, q_order));
+  if (out->M == 0 || out->m == 0) return SWG_OK;
+  return chain_table_build(ctx, r, alive, min_len, min_ident, genome_pair_major, out, W);
+}
+
+// plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
+// reference's all_chains order (their index is the plane sweep's tie-break `idx`).
+// Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).  (swg_scaffold_sweep.hip)
+int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
+                              uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
+                              int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out);
+
+}  // namespace swg_scaf

@@ -1,0 +1,276 @@
+// Scaffold stage, part 3 (src/plane_sweep_scaffold.rs:47-251): plane_sweep_both per chromosome pair over the span /
+// identity-filtered chains on the sweep kernels, then chain_N numbering in plane_sweep_scaffolds' output order
+// (genome pair -> chromosome pair -> index).
+#include "swg_scaffold_internal.h"
+
+namespace swg_scaf {
+namespace {
+
+// ---- scaffold sweep + numbering ------------------------------------------------------------------------------
+__global__ __launch_bounds__(EW) void chain_seg_kernel(uint64_t nc, const uint32_t* __restrict__ C_qid,
+                                                       const uint32_t* __restrict__ C_tid, uint32_t n_seq,
+                                                       uint64_t* __restrict__ seg) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c < nc) seg[c] = (uint64_t)C_qid[c] * n_seq + C_tid[c];
+}
+// after the stable sort of chains by chromosome pair: run heads
+__global__ __launch_bounds__(EW) void run_flag_kernel(uint64_t nc, const uint64_t* __restrict__ sorted_seg,
+                                                      uint32_t* __restrict__ flag) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s < nc) flag[s] = (s == 0 || sorted_seg[s - 1] != sorted_seg[s]) ? 1u : 0u;
+}
+// Chains here are already the span/identity-filtered ones, in index order, and the sort by chromosome pair is
+// stable: the first chain of a run is the pair's first appearance (plane_sweep_scaffold.rs:116-130 insertion
+// order), and the genome pair's (first two '#' parts) first appearance is the minimum over its runs' heads.
+__global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
+                                                              const uint32_t* __restrict__ run_excl,
+                                                              const uint32_t* __restrict__ run_flag,
+                                                              const uint32_t* __restrict__ C_qid,
+                                                              const uint32_t* __restrict__ C_tid,
+                                                              const uint32_t* __restrict__ seq_genome2,
+                                                              uint32_t* __restrict__ run_of_chain,
+                                                              uint32_t* __restrict__ pair_first,
+                                                              PairTable gp2_first) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s >= nc) return;
+  const uint32_t c = sorted_c[s];
+  const uint32_t run = run_excl[s] + run_flag[s] - 1;
+  run_of_chain[c] = run;
+  if (run_flag[s]) {
+    pair_first[run] = c;
+    atomicMin(pair_slot(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]), c);
+  }
+}
+__global__ __launch_bounds__(EW) void number_keys_kernel(uint64_t nk, const uint32_t* __restrict__ kept_list,
+                                                         const uint32_t* __restrict__ run_of_chain,
+                                                         const uint32_t* __restrict__ pair_first,
+                                                         PairTable gp2_first,
+                                                         const uint32_t* __restrict__ C_qid,
+                                                         const uint32_t* __restrict__ C_tid,
+                                                         const uint32_t* __restrict__ seq_genome2,
+                                                         int c_bits, uint64_t* __restrict__ key) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= nk) return;
+  const uint32_t c = kept_list[j];
+  const uint32_t g2 = pair_get(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]);
+  key[j] = ((uint64_t)g2 << c_bits) | pair_first[run_of_chain[c]];
+}
+__global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const uint32_t* __restrict__ sorted_kept,
+                                                            uint32_t* __restrict__ C_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
+}
+
+__global__ __launch_bounds__(EW) void chain_compact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
+                                                           const uint32_t* __restrict__ qid, const uint32_t* __restrict__ tid,
+                                                           const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
+                                                           const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
+                                                           const double* __restrict__ wid, uint32_t* __restrict__ o_qid,
+                                                           uint32_t* __restrict__ o_tid, uint32_t* __restrict__ o_qs,
+                                                           uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts,
+                                                           uint32_t* __restrict__ o_te, double* __restrict__ o_wid) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= no) return;
+  const uint32_t c = ok_idx[j];
+  o_qid[j] = qid[c];
+  o_tid[j] = tid[c];
+  o_qs[j] = qs[c];
+  o_qe[j] = qe[c];
+  o_ts[j] = ts[c];
+  o_te[j] = te[c];
+  o_wid[j] = wid[c];
+}
+__global__ __launch_bounds__(EW) void chain_uncompact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
+                                                             const uint8_t* __restrict__ kept_j,
+                                                             const uint32_t* __restrict__ num_j,
+                                                             uint8_t* __restrict__ C_kept, uint32_t* __restrict__ C_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= no) return;
+  const uint32_t c = ok_idx[j];
+  C_kept[c] = kept_j[j];
+  C_num[c] = num_j[j];
+}
+
+}  // namespace
+
+// plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
+// reference's all_chains order (their index is the plane sweep's tie-break `idx`).
+// Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).
+int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
+                              uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
+                              int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out) {
+  hipStream_t st = ctx->stream;
+  *n_kept_out = 0;
+  if (T.nc == 0) return SWG_OK;
+  uint64_t kq, kt;
+  if (mode == SWG_MODE_ONE_TO_ONE) {
+    kq = 1;
+    kt = 1;
+  } else {
+    kq = max_q ? max_q : SWG_K_INF;
+    kt = max_t ? max_t : SWG_K_INF;
+  }
+  SWG_HIP(ctx, hipMemsetAsync(C_kept, 0, T.nc, st));
+  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, T.nc * sizeof(uint32_t), st));
+  // ---- only the span/identity-filtered chains take part (compaction keeps their relative order, which is
+  //      all the plane sweep's index tie-break needs)
+  uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
+  SWG_CHECK_ARENA(ctx);
+  swg_flag_scan ok_scan;
+  SWG_TRY(swg_flags_count(ctx, T.ok, T.nc, &ok_scan, d_tot));
+  uint64_t nc = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
+  if (nc == 0) return SWG_OK;
+  uint32_t* ok_idx = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qid = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* tid = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qs = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* qe = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* ts = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* te = swg_alloc<uint32_t>(ctx, nc);
+  double* wid = swg_alloc<double>(ctx, nc);
+  uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
+  uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
+  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
+  uint8_t* kept = swg_alloc<uint8_t>(ctx, nc);
+  uint32_t* num = swg_alloc<uint32_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  SWG_TRY(swg_flags_compact(ctx, ok_scan, ok_idx));
+  SWG_LAUNCH(ctx, "chain_compact", chain_compact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, qid,
+                                                                     tid, qs, qe, ts, te, wid));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, qid, tid, n_seq, seg));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
+  swg_axis_input ax;
+  ax.n = nc;
+  ax.seg = seg;
+  ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
+  ax.pos_bits = pos_bits;
+  ax.score_key = skey;
+  ax.alive = nullptr;
+  ax.start = qs;
+  ax.end = qe;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
+  ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
+  ax.start = ts;
+  ax.end = te;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
+
+  // ---- numbering -------------------------------------------------------------------------------------
+  uint64_t* seg_sorted = swg_alloc<uint64_t>(ctx, nc);
+  uint64_t* seg_tmp = swg_alloc<uint64_t>(ctx, nc);
+  uint32_t* c_sorted = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* c_tmp = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_flag = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_excl = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  PairTable gp2_first;
+  SWG_TRY(pair_table_make(ctx, n_g2, nc, &gp2_first));  // pairs that occur <= chromosome-pair runs <= chains
+  SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
+  SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, ax.seg_bits));
+  SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
+  SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, run_excl, run_flag, qid, tid, seq_genome2,
+                                                                           run_of_chain, pair_first, gp2_first));
+  SWG_KERNEL_CHECK(ctx);
+  // kept chains, in index order
+  swg_flag_scan kept_scan;
+  SWG_TRY(swg_flags_count(ctx, kept, nc, &kept_scan, d_tot));
+  uint64_t nk = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
+  SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
+  *n_kept_out = nk;
+  if (nk) {
+    uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
+    uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
+    uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
+    uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
+    SWG_CHECK_ARENA(ctx);
+    SWG_TRY(swg_flags_compact(ctx, kept_scan, kept_list));
+    const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
+    SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
+                                                                    seq_genome2, c_bits, nkey));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
+    SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  SWG_LAUNCH(ctx, "chain_uncompact", chain_uncompact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, kept, num, C_kept, C_num));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+}  // namespace swg_scaf
+
+using namespace swg_scaf;
+
+// ---- public seams -----------------------------------------------------------------------------------------------------
+extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_t* q_id, const uint32_t* t_id,
+                                         uint32_t n_seq, const uint32_t* seq_genome_two, uint32_t n_genome_two,
+                                         const uint64_t* q_start, const uint64_t* q_end, const uint64_t* t_start,
+                                         const uint64_t* t_end, const double* identity, int mode,
+                                         uint64_t max_per_query, uint64_t max_per_target, double thr, int scoring,
+                                         uint64_t* order_out, uint64_t* n_kept) {
+  if (!ctx) return SWG_ERR_INVALID;
+  if (n_kept) *n_kept = 0;
+  if (n == 0) return SWG_OK;
+  if (!q_id || !t_id || !seq_genome_two || !q_start || !q_end || !t_start || !t_end || !identity || !order_out ||
+      !n_kept)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "NULL array");
+  if (mode < 0 || mode > 2 || scoring < 0 || scoring > 4 || n_seq == 0 || n_genome_two == 0)
+    return swg_set_error(ctx, SWG_ERR_INVALID, "bad mode / scoring / table size");
+  if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chains");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> h(4 * n);
+  uint32_t mx = 0;
+  SWG_TRY(swg_narrow_coords(ctx, n, q_start, q_end, h.data(), h.data() + n, "query"));
+  SWG_TRY(swg_narrow_coords(ctx, n, t_start, t_end, h.data() + 2 * n, h.data() + 3 * n, "target"));
+  for (uint64_t i = 0; i < 4 * n; ++i)
+    if (h[i] > mx) mx = h[i];
+  for (uint64_t i = 0; i < n; ++i)
+    if (q_id[i] >= n_seq || t_id[i] >= n_seq) return swg_set_error(ctx, SWG_ERR_INVALID, "sequence id out of range");
+  const int pos_bits = swg_bits_for(mx) ? swg_bits_for(mx) : 1;
+  hipStream_t st = ctx->stream;
+  if (ctx->arena_cap == 0) SWG_TRY(swg_arena_reserve(ctx, (size_t)n * 400 + (size_t(16) << 20)));
+  std::vector<uint32_t> num(n);
+  int rc = swg_run_with_arena(ctx, [&]() -> int {
+    ChainTable T;
+    T.nc = n;
+    uint32_t* d_c = swg_alloc<uint32_t>(ctx, 4 * n);
+    T.qid = swg_alloc<uint32_t>(ctx, n);
+    T.tid = swg_alloc<uint32_t>(ctx, n);
+    T.wid = swg_alloc<double>(ctx, n);
+    T.ok = swg_alloc<uint8_t>(ctx, n);
+    uint32_t* d_g2 = swg_alloc<uint32_t>(ctx, n_seq);
+    uint8_t* C_kept = swg_alloc<uint8_t>(ctx, n);
+    uint32_t* C_num = swg_alloc<uint32_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    T.qs = d_c;
+    T.qe = d_c + n;
+    T.ts = d_c + 2 * n;
+    T.te = d_c + 3 * n;
+    SWG_HIP(ctx, hipMemcpyAsync(d_c, h.data(), 4 * n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.qid, q_id, n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.tid, t_id, n * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(T.wid, identity, n * 8, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemcpyAsync(d_g2, seq_genome_two, (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
+    SWG_HIP(ctx, hipMemsetAsync(T.ok, 1, n, st));
+    uint64_t nk = 0;
+    SWG_TRY(scaffold_sweep_and_number(ctx, T, n_seq, d_g2, n_genome_two, mode, max_per_query, max_per_target, thr,
+                                      scoring, pos_bits, C_kept, C_num, &nk));
+    SWG_HIP(ctx, hipMemcpyAsync(num.data(), C_num, n * 4, hipMemcpyDeviceToHost, st));
+    SWG_HIP(ctx, hipStreamSynchronize(st));
+    *n_kept = nk;
+    return SWG_OK;
+  });
+  if (rc != SWG_OK) return rc;
+  for (uint64_t i = 0; i < n; ++i)
+    if (num[i]) order_out[num[i] - 1] = i;
+  return SWG_OK;
+}
