@@ -36,6 +36,7 @@
 
 #include "../../../include/sweepga_gpu.h"
 #include "host_internal.h"
+#include "threads.h"
 #include "rebase.h"
 
 namespace {
@@ -59,16 +60,8 @@ int pick_threads(int threads) {
 }
 
 template <class F>
-void parallel_for(int threads, F&& body) {  // body(thread_index)
-  if (threads <= 1) {
-    body(0);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(threads - 1);
-  for (int t = 1; t < threads; ++t) pool.emplace_back([&body, t] { body(t); });
-  body(0);
-  for (auto& th : pool) th.join();
+void parallel_for(int threads, F&& body) {  // body(thread_index); nothing escapes a worker (host/threads.h)
+  swg_host::run(threads, body);
 }
 
 // ---- Rust-compatible scalar parsers (str::parse::<u64>, str::parse::<f64>) ---------------------------

@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+#include "threads.h"
+
 namespace swg_rebase {
 
 struct Result {
@@ -27,18 +29,7 @@ inline const char* field_name(int f) {
   return (f >= 0 && f < 6) ? N[f] : "?";
 }
 
-template <class F>
-inline void run(int threads, F&& body) {
-  if (threads <= 1) {
-    body(0);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(threads - 1);
-  for (int t = 1; t < threads; ++t) pool.emplace_back([&body, t] { body(t); });
-  body(0);
-  for (auto& th : pool) th.join();
-}
+using swg_host::run;
 
 // c64 = {q_start, q_end, t_start, t_end, matches, block_len}; matches / block_len may be NULL (then c32[4] / c32[5] are
 // left alone).  lo[n_seq] receives the offsets (UINT64_MAX for a sequence no record names).
@@ -49,12 +40,9 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
   std::vector<std::vector<uint64_t>> part(threads > 1 ? threads : 0);
   for (uint32_t s = 0; s < n_seq; ++s) lo[s] = UINT64_MAX;
   std::vector<uint64_t> bad_id(threads, UINT64_MAX);
+  for (auto& pt : part) pt.assign(n_seq, UINT64_MAX);  // before the threads start: a worker body allocates nothing
   run(threads, [&](int t) {
-    uint64_t* m = lo;
-    if (threads > 1) {
-      part[t].assign(n_seq, UINT64_MAX);
-      m = part[t].data();
-    }
+    uint64_t* m = threads > 1 ? part[t].data() : lo;
     const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
     for (uint64_t i = b; i < e; ++i) {
       if (q_id[i] >= n_seq || t_id[i] >= n_seq) {  // the ids index the table: checked in the same pass

@@ -190,9 +190,11 @@ __global__ __launch_bounds__(EW) void chain_candidates_kernel(uint64_t m, const 
                                                               unsigned long long* __restrict__ c_d,  // [KC][m]
                                                               uint32_t* __restrict__ c_j,            // [KC][m]
                                                               uint32_t* __restrict__ c_n,            // valid count (saturating)
-                                                              uint32_t* __restrict__ c_ext) {        // window extent in elements
+                                                              uint32_t* __restrict__ c_ext,          // window extent in elements
+                                                              const uint8_t* __restrict__ only = nullptr) {  // optional: lists for these elements only
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
+  if (only && !only[p]) return;
   const uint32_t g = s_gidx[p];
   const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
   const bool minus = (s_grp[p] & 1ull) != 0;
@@ -298,6 +300,12 @@ __device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
 // is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the selection re-evaluate
 // a window that has nothing left to offer (same result); the window extent then comes from a galloping search.
 constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
+// Round 3: the wavefront's KC best live in ONE wave-uniform list (scalar registers) instead of one list per lane.  A batch
+// of 64 elements is evaluated by the lanes; only the elements that beat the list's last entry (a ballot; rare once the list
+// has settled: ~4 ln(window / 4) insertions per element in all) are inserted, one at a time in ascending lane = ascending
+// j order, which is the sequential insertion order of chain_candidates_kernel.  No per-lane lists, no butterfly merge at the
+// end, and the early cut reads the list's last entry directly.  The results of the CW_PER_WAVE elements are parked in
+// lanes 0..15 and stored together (whole lines instead of one 8-byte store per array and element).
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
                                                                    uint32_t n_groups, const uint64_t* __restrict__ s_grp,
@@ -314,20 +322,25 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: q^2 + r^2 cannot wrap and grows with the query gap
-  for (uint64_t p = wave * CW_PER_WAVE; p < (wave + 1) * CW_PER_WAVE && p < m; ++p) {  // wave-uniform
+  uint64_t out_d[KC];
+  uint32_t out_j[KC];
+  uint32_t out_n = 0, out_ext = 0;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    out_d[k] = ~0ull;
+    out_j[k] = NONE;
+  }
+  const uint64_t p0 = wave * CW_PER_WAVE;
+  for (uint64_t p = p0; p < p0 + CW_PER_WAVE && p < m; ++p) {  // wave-uniform
     const uint32_t g = s_gidx[p];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
     const bool minus = (s_grp[p] & 1ull) != 0;
     const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
     const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
     const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
-    uint64_t bd[KC];
-    uint32_t bj[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      bd[k] = ~0ull;
-      bj[k] = NONE;
-    }
+    // the wavefront's list, (d asc, j asc); wave-uniform values
+    uint64_t sd0 = ~0ull, sd1 = ~0ull, sd2 = ~0ull, sd3 = ~0ull;
+    uint32_t sj0 = NONE, sj1 = NONE, sj2 = NONE, sj3 = NONE;
     uint32_t count = 0, ext = 0, cut_at = 0;
     bool cut = false;
     for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
@@ -337,10 +350,12 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
       const uint64_t wmask = __ballot(inwin);
       ext += (uint32_t)__popcll(wmask);
+      uint64_t d = ~0ull;
+      bool ok = false;
       if (inwin) {
-        // d(i, j) of paf_filter.rs:798-836 (this block is the wave kernel's)
+        // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic
         uint32_t q_gap, r_gap;
-        bool ok = true;
+        ok = true;
         if (qs_j >= qe_i) {
           q_gap = qs_j - qe_i;
         } else {
@@ -361,39 +376,36 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
             r_gap = 0;
           }
         }
-        if (ok && q_gap <= gap && r_gap <= gap) {
-          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
-          ++count;
-          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel (a lane's j only grows)
-            uint64_t cd = d;
-            uint32_t cj = j;
-            bool placed = false;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-              if (placed || cd < bd[k]) {
-                placed = true;
-                const uint64_t td = bd[k];
-                const uint32_t tj = bj[k];
-                bd[k] = cd;
-                bj[k] = cj;
-                cd = td;
-                cj = tj;
-              }
-            }
-          }
+        ok = ok && q_gap <= gap && r_gap <= gap;
+        if (ok) d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+      }
+      const uint64_t vmask = __ballot(ok);
+      count += (uint32_t)__popcll(vmask);  // cannot exceed 2^32 - 1 here
+      uint64_t cmask = __ballot(ok && d < sd3);
+      while (cmask) {  // ascending lane = ascending j: an entry goes after every entry with d' <= d (strict `<` finds the slot)
+        const int l = __builtin_ctzll(cmask);
+        cmask &= cmask - 1;
+        const uint64_t dl = readlane_u64(d, l);
+        if (dl >= sd3) continue;  // the list moved on since the ballot
+        const uint32_t jl = j0 + (uint32_t)l;
+        if (dl < sd0) {
+          sd3 = sd2; sj3 = sj2; sd2 = sd1; sj2 = sj1; sd1 = sd0; sj1 = sj0; sd0 = dl; sj0 = jl;
+        } else if (dl < sd1) {
+          sd3 = sd2; sj3 = sj2; sd2 = sd1; sj2 = sj1; sd1 = dl; sj1 = jl;
+        } else if (dl < sd2) {
+          sd3 = sd2; sj3 = sj2; sd2 = dl; sj2 = jl;
+        } else {
+          sd3 = dl; sj3 = jl;
         }
       }
       if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
-      if (can_cut && j0 + 64 < e) {
-        // every later element starts at or after this batch's last one: its query gap is at least `qg`
-        const uint32_t q_last = (uint32_t)__shfl((int)qs_j, 63, 64);
+      if (can_cut && j0 + 64 < e && sd3 != ~0ull) {
+        // every later element starts at or after this batch's last one: its query gap is at least `qg`; with KC entries held
+        // at distance <= qg^2 no later j can enter the list (d >= qg^2; equal distances keep the smaller j)
+        const uint32_t q_last = readlane_u32(qs_j, 63);
         if (q_last >= qe_i) {
           const uint64_t qg = (uint64_t)q_last - qe_i;
-          const uint64_t T = qg * qg;
-          const int c = (bd[0] <= T) + (bd[1] <= T) + (bd[2] <= T) + (bd[3] <= T);  // the lists are ascending
-          const int held = __popcll(__ballot(c >= 1)) + __popcll(__ballot(c >= 2)) + __popcll(__ballot(c >= 3)) +
-                           __popcll(__ballot(c >= 4));
-          if (held >= KC) {
+          if (sd3 <= qg * qg) {
             cut = true;
             cut_at = j0 + 64;
             break;
@@ -424,21 +436,24 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         found = true;
       }
       ext = lo - (uint32_t)p;
+      ++count;  // "there may be more": the exact number of valid j is unknown after a cut
     }
-    // valid count of the whole window (saturating like the per-thread kernel: it cannot exceed 2^32 - 1 here)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o, 64);
-    if (cut) ++count;  // "there may be more"
-    wave_top_kc(bd, bj);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        c_d[(uint64_t)k * m + p] = bd[k];
-        c_j[(uint64_t)k * m + p] = bj[k];
-      }
-      c_n[p] = count;
-      c_ext[p] = ext;
+    if (lane == (int)(p - p0)) {
+      out_d[0] = sd0; out_d[1] = sd1; out_d[2] = sd2; out_d[3] = sd3;
+      out_j[0] = sj0; out_j[1] = sj1; out_j[2] = sj2; out_j[3] = sj3;
+      out_n = count;
+      out_ext = ext;
     }
+  }
+  const uint64_t po = p0 + lane;
+  if (lane < CW_PER_WAVE && po < m) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      c_d[(uint64_t)k * m + po] = out_d[k];
+      c_j[(uint64_t)k * m + po] = out_j[k];
+    }
+    c_n[po] = out_n;
+    c_ext[po] = out_ext;
   }
 }
 
@@ -1044,6 +1059,311 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
   }
 }
 
+
+// ---- the walk: the reference's greedy, 64 elements per step -----------------------------------------------------------
+// One wavefront walks a range [bb, be) of consecutive elements in order (chain_walk_kernel), 64 at a time, lane l holding
+// element i0 + l.  The sequential rule (paf_filter.rs:790-831) -- i takes the first j of its (d, j)-ordered valid list
+// with d < best_pred_score[j], and best_pred_score[j] = d from then on -- is evaluated for the 64 elements at once:
+//
+//   * acc(i, c): d_c < score[j_c] as the scores stood BEFORE the batch (one LDS gather per listed candidate);
+//   * the lanes below i change what i sees only through proposals made inside the batch: i's candidate (d, j) is blocked
+//     iff a lower lane's FINAL choice is (d', j) with d' <= d (a blocked lower lane does not propose to j, but then an even
+//     lower lane with d'' <= d' <= d does, so testing against current choices of lower lanes that are final is exact);
+//   * every lane starts from its first acc candidate.  That choice stands unless a lower lane's final choice names the same
+//     j, so only lanes that share a j with a lower lane (LDS hash filter, a superset) are re-evaluated, in ascending lane
+//     order (scalar loop: v_readlane of the candidate, one ballot over the lower lanes' choices); a lane that moves to a new
+//     j puts the higher lanes holding that j on the work list.  Lower lanes are final when a lane is evaluated, so the loop
+//     reproduces the sequential order exactly;
+//   * a lane whose listed candidates are all refused although its window held more (rare) needs the whole window: the lanes
+//     below it are committed to the score ring, the wavefront scans the window together (as the old per-step kernels did)
+//     and the walk goes on;
+//   * commit: scores by atomic minimum (accepted distances to one j strictly decrease in lane order, so the minimum is the
+//     last acceptance and its lane is j's predecessor).
+//
+// Ranges come in two kinds.  Ranges that begin and end at unit boundaries (units shorter than BIG_UNIT, glued into chunks of
+// ~CHUNK elements) need nothing from outside: the candidate lists are built by the lanes themselves from the LDS ring
+// (FUSED: no candidate arrays in HBM at all).  Blocks of long units run speculatively (see above spec_plan_kernel), lists
+// from the candidate kernels.
+constexpr uint32_t WALK_CHUNK = 1024;
+constexpr int WALK_HASH = 256;
+
+template <int BIGW, bool FUSED>
+__global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
+                                                        const uint64_t* __restrict__ s_grp,
+                                                        const uint32_t* __restrict__ s_qs,
+                                                        const uint32_t* __restrict__ s_qe,
+                                                        const uint32_t* __restrict__ s_ts,
+                                                        const uint32_t* __restrict__ s_te,
+                                                        const uint32_t* __restrict__ s_gidx,
+                                                        const uint32_t* __restrict__ group_begin, uint32_t n_groups,
+                                                        uint64_t max_gap, const unsigned long long* __restrict__ c_d,
+                                                        const uint32_t* __restrict__ c_j, const uint32_t* __restrict__ c_n,
+                                                        int spec, unsigned long long* own, unsigned long long* prev,
+                                                        uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
+  __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this range sees them
+  __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end
+  __shared__ uint32_t hcnt[WALK_HASH];
+  const int lane = threadIdx.x;
+  const uint64_t INF = ~0ull;
+  const uint64_t fifth = max_gap / 5;
+  const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
+  for (int k = lane; k < WALK_HASH; k += 64) hcnt[k] = 0;
+  __syncthreads();
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    const uint32_t b = D.bb, be = D.be, ue = D.ue;  // i runs over [b, be), j may reach into the next block (< ue)
+    if (be <= b || ue - b < 2) continue;
+    auto view_ptr = [&](uint32_t p) -> unsigned long long* { return (spec && p >= be) ? &prev[p] : &own[p]; };
+    auto view_load = [&](uint32_t p) -> uint64_t {
+      return __hip_atomic_load(view_ptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint32_t base = b;
+    __syncthreads();
+    for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
+      const bool ok = p < ue;
+      ring[p % BIGW] = ok ? view_load(p) : INF;
+      rq[p % BIGW] = ok ? s_qs[p] : 0xffffffffu;
+      rt[p % BIGW] = ok ? s_ts[p] : 0u;
+      re[p % BIGW] = ok ? s_te[p] : 0u;
+    }
+    __syncthreads();
+    auto current = [&](uint32_t j) -> uint64_t {  // the committed score of j
+      if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
+      return view_load(j);
+    };
+    for (uint32_t i0 = b; i0 < be && i0 + 1 < ue; i0 += 64) {
+      if (i0 != b) {
+        const uint32_t pn = base + BIGW + lane;
+        __syncthreads();
+        {
+          const bool ok = pn < ue;
+          ring[pn % BIGW] = ok ? view_load(pn) : INF;
+          rq[pn % BIGW] = ok ? s_qs[pn] : 0xffffffffu;
+          rt[pn % BIGW] = ok ? s_ts[pn] : 0u;
+          re[pn % BIGW] = ok ? s_te[pn] : 0u;
+        }
+        base += 64;
+        __syncthreads();
+      }
+      const uint32_t i = i0 + lane;
+      const bool valid = i < be && i + 1 < ue;
+      // ---- the lane's candidate list
+      uint64_t bd[KC];
+      uint32_t bj[KC];
+      uint32_t nv = 0;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        bd[c] = INF;
+        bj[c] = NONE;
+      }
+      uint64_t qe_i = 0, ts_i = 0, te_i = 0;
+      bool minus = false;
+      uint32_t e_i = ue;  // end of the element's (query, target, strand) group inside the range
+      if (valid) {
+        if (!spec) {
+          const uint32_t g = s_gidx[i];
+          const uint32_t ge = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+          if (ge < e_i) e_i = ge;
+        }
+        if (FUSED) {
+          qe_i = s_qe[i];
+          ts_i = s_ts[i];
+          te_i = s_te[i];
+          minus = (s_grp[i] & 1ull) != 0;
+          const uint64_t bound = qe_i + max_gap;
+          for (uint32_t j = i + 1; j < e_i; ++j) {
+            const bool inr = j - base < (uint32_t)BIGW;
+            const uint64_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
+            if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
+            const uint64_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
+            uint64_t d;
+            if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) continue;
+            if (nv <= (uint32_t)KC) ++nv;
+            if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
+              uint64_t cd = d;
+              uint32_t cj = j;
+              bool placed = false;
+#pragma unroll
+              for (int c = 0; c < KC; ++c) {
+                if (placed || cd < bd[c]) {
+                  placed = true;
+                  const uint64_t td = bd[c];
+                  const uint32_t tj = bj[c];
+                  bd[c] = cd;
+                  bj[c] = cj;
+                  cd = td;
+                  cj = tj;
+                }
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {
+            bd[c] = c_d[(uint64_t)c * m + i];
+            bj[c] = c_j[(uint64_t)c * m + i];
+          }
+          nv = c_n[i];
+        }
+      }
+      // ---- acc bits and the first acceptable candidate
+      uint32_t acc = 0;
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if ((uint32_t)c < nv && bd[c] < current(bj[c])) acc |= 1u << c;
+      uint64_t fd = INF;
+      uint32_t fj = NONE;
+#pragma unroll
+      for (int c = KC - 1; c >= 0; --c)
+        if (acc & (1u << c)) {
+          fd = bd[c];
+          fj = bj[c];
+        }
+      // ---- lanes that share their j with another lane (hash filter; superset), and lanes that need their whole window
+      uint32_t* slot = &hcnt[fj & (WALK_HASH - 1)];
+      if (fj != NONE) atomicAdd(slot, 1u);
+      __syncthreads();
+      const bool shared_j = fj != NONE && *slot > 1u;
+      __syncthreads();
+      if (fj != NONE) *slot = 0;
+      uint64_t work = __ballot(shared_j || (fj == NONE && nv > (uint32_t)KC));
+      uint32_t committed = 0;  // lanes below this one are in the ring
+      auto commit = [&](uint32_t upto) {  // lanes [committed, upto)
+        const bool me = (uint32_t)lane >= committed && (uint32_t)lane < upto && fj != NONE;
+        const bool inr = me && (fj - base < (uint32_t)BIGW);
+        if (me) {
+          if (inr)
+            atomicMin(&ring[fj % BIGW], (unsigned long long)fd);
+          else
+            atomicMin(view_ptr(fj), (unsigned long long)fd);
+        }
+        __threadfence();
+        __syncthreads();
+        if (me) {
+          const uint64_t cur = inr ? (uint64_t)ring[fj % BIGW] : view_load(fj);
+          if (cur == fd) {  // the last acceptance: this lane is j's predecessor
+            ((spec && fj >= be) ? pred_prev : pred_own)[fj] = i;
+            if (inr && spec && fj >= be)  // the next block's input: must be in memory at the end of the round
+              __hip_atomic_store(&prev[fj], fd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        committed = upto;
+      };
+      while (work) {
+        const int l = __builtin_ctzll(work);
+        work &= work - 1;
+        const uint32_t nv_l = readlane_u32(nv, l), acc_l = readlane_u32(acc, l);
+        uint64_t nd = INF;
+        uint32_t nj = NONE;
+        const uint64_t lower = l ? (~0ull >> (64 - l)) : 0ull;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          if (nj == NONE && (acc_l & (1u << c))) {
+            const uint64_t d = readlane_u64(bd[c], l);
+            const uint32_t j = readlane_u32(bj[c], l);
+            if ((__ballot(fj == j && fd <= d) & lower) == 0) {
+              nd = d;
+              nj = j;
+            }
+          }
+        }
+        if (nj == NONE && nv_l > (uint32_t)KC) {
+          // every listed candidate is refused and the window held more: the whole window (paf_filter.rs:794-826), against
+          // the scores as they stand after every lower lane
+          commit((uint32_t)l);
+          const uint32_t ii = i0 + l;
+          const uint64_t qe_l = s_qe[ii], ts_l = s_ts[ii], te_l = s_te[ii];
+          const bool minus_l = (s_grp[ii] & 1ull) != 0;
+          const uint32_t e_l = readlane_u32(e_i, l);
+          const uint64_t bound = qe_l + max_gap;
+          uint64_t ld = INF;
+          uint32_t lj2 = NONE;
+          for (uint32_t j0 = ii + 1; j0 < e_l; j0 += 64) {
+            if (can_cut) {  // the batch starts past q_end[i] and its smallest query gap already reaches the best distance held
+              const uint64_t wmin = wave_min_u64(ld);
+              const uint64_t q0 = (j0 - base) < (uint32_t)BIGW ? (uint64_t)rq[j0 % BIGW] : (uint64_t)s_qs[j0];
+              if (wmin != INF && q0 >= qe_l && (q0 - qe_l) * (q0 - qe_l) >= wmin) break;
+            }
+            const uint32_t j = j0 + lane;
+            bool in = j < e_l;
+            const bool inring = in && (j - base) < (uint32_t)BIGW;
+            uint64_t qs_j = 0;
+            if (in) {
+              qs_j = inring ? rq[j % BIGW] : s_qs[j];
+              in = qs_j <= bound;
+            }
+            if (in) {
+              uint64_t d;
+              const uint64_t ts_j = inring ? rt[j % BIGW] : s_ts[j], te_j = inring ? re[j % BIGW] : s_te[j];
+              if (chain_dist(minus_l, qe_l, ts_l, te_l, qs_j, ts_j, te_j, max_gap, fifth, &d)) {
+                const uint64_t cur = current(j);
+                if (d < cur && d < ld) {
+                  ld = d;
+                  lj2 = j;
+                }
+              }
+            }
+            if (!__any(in)) break;
+          }
+          uint64_t cand = __ballot(lj2 != NONE);
+          while (cand) {
+            const int c2 = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const uint64_t d = readlane_u64(ld, c2);
+            const uint32_t j = readlane_u32(lj2, c2);
+            if (d < nd || (d == nd && j < nj)) {
+              nd = d;
+              nj = j;
+            }
+          }
+        }
+        const uint32_t old_j = readlane_u32(fj, l);
+        if (lane == l) {
+          fd = nd;
+          fj = nj;
+        }
+        if (nj != NONE && nj != old_j) work |= __ballot(fj == nj) & ~lower & ~(1ull << l);  // higher lanes holding the new j
+      }
+      commit(64u);
+    }
+  }
+}
+
+// Chunks of the walk over the units shorter than BIG_UNIT: unit u opens a chunk when it is the first unit to begin in its
+// WALK_CHUNK-element cell, or when it or its predecessor is a long unit (long units are chunks of their own, skipped here).
+__global__ __launch_bounds__(EW) void chunk_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                        const uint8_t* __restrict__ is_big, uint8_t* __restrict__ flag) {
+  uint32_t u = blockIdx.x * EW + threadIdx.x;
+  if (u >= n_units) return;
+  bool f = u == 0 || is_big[u] || is_big[u - 1];
+  if (!f) f = unit_begin[u] / WALK_CHUNK != unit_begin[u - 1] / WALK_CHUNK;
+  flag[u] = f ? 1 : 0;
+}
+__global__ __launch_bounds__(EW) void chunk_desc_kernel(uint32_t n_chunks, const uint32_t* __restrict__ chunk_unit,
+                                                        uint32_t n_units, const uint32_t* __restrict__ unit_begin,
+                                                        const uint8_t* __restrict__ is_big, uint32_t m,
+                                                        SpecBlock* __restrict__ desc) {
+  uint32_t c = blockIdx.x * EW + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uint32_t u = chunk_unit[c];
+  const uint32_t b = unit_begin[u];
+  const uint32_t un = c + 1 < n_chunks ? chunk_unit[c + 1] : n_units;
+  const uint32_t e = un < n_units ? unit_begin[un] : m;
+  SpecBlock d;
+  d.bb = b;
+  d.be = is_big[u] ? b : e;  // long units: empty range here (they take the block-speculative path)
+  d.ue = d.be;
+  d.pad = 0;
+  desc[c] = d;
+}
+// candidate lists only for the elements of long units (the walk builds the others' lists itself)
+__global__ __launch_bounds__(EW) void big_member_flag_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
+                                                             const uint32_t* __restrict__ unit_excl,
+                                                             const uint8_t* __restrict__ is_big, uint8_t* __restrict__ f) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p < m) f[p] = is_big[unit_excl[p] + unit_flag[p] - 1];
+}
+
 __global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                            uint32_t m, uint8_t* __restrict__ is_big) {
   uint32_t u = blockIdx.x * EW + threadIdx.x;
@@ -1267,15 +1587,157 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
     SWG_KERNEL_CHECK(ctx);
+    static const bool old_walk = getenv("SWG_CHAIN_OLD") != nullptr;  // A/B knob: the per-step kernels of round 2
+    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wavefront per i) kernel at any size
+    if (getenv("SWG_DEBUG"))
+      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
+              (unsigned long long)n_groups, (unsigned long long)n_units);
+    if (!old_walk) {
+      const bool lists_all = long_groups || force_deep;  // candidate lists for every element (wavefront per element)
+      uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
+      uint8_t* chunk_flag = swg_alloc<uint8_t>(ctx, n_units);
+      uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 2);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "unit_big_flag", unit_big_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, (uint32_t)m, is_big));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "chunk_flag", chunk_flag_kernel<<<nblk(n_units), EW, 0, st>>>((uint32_t)n_units, unit_begin, is_big, chunk_flag));
+      SWG_KERNEL_CHECK(ctx);
+      swg_flag_scan big_scan, chunk_scan;
+      SWG_TRY(swg_flags_count(ctx, is_big, n_units, &big_scan, d_nb));
+      SWG_TRY(swg_flags_count(ctx, chunk_flag, n_units, &chunk_scan, d_nb + 1));
+      uint64_t h2[2];
+      SWG_TRY(swg_read_scalars(ctx, d_nb, h2, 2));
+      const uint64_t n_big = h2[0], n_chunks = h2[1];
+      unsigned long long* c_d = nullptr;
+      uint32_t *c_j = nullptr, *c_n = nullptr, *c_ext = nullptr;
+      if (lists_all || n_big) {
+        c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
+        c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
+        c_n = swg_alloc<uint32_t>(ctx, m);
+        c_ext = swg_alloc<uint32_t>(ctx, m);
+        SWG_CHECK_ARENA(ctx);
+        if (lists_all) {
+          SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
+                                                       m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+        } else {
+          uint8_t* big_member = swg_alloc<uint8_t>(ctx, m);
+          SWG_CHECK_ARENA(ctx);
+          SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
+                                                                                  s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, big_member));
+        }
+        SWG_KERNEL_CHECK(ctx);
+      }
+      {
+        // ---- units shorter than BIG_UNIT, glued into chunks: one wavefront per chunk, 64 elements per step
+        uint32_t* chunk_unit = swg_alloc<uint32_t>(ctx, n_chunks);
+        SpecBlock* cdesc = swg_alloc<SpecBlock>(ctx, n_chunks);
+        SWG_CHECK_ARENA(ctx);
+        SWG_TRY(swg_flags_compact(ctx, chunk_scan, chunk_unit));
+        SWG_LAUNCH(ctx, "chunk_desc", chunk_desc_kernel<<<nblk(n_chunks), EW, 0, st>>>((uint32_t)n_chunks, chunk_unit, (uint32_t)n_units, unit_begin,
+                                                                          is_big, (uint32_t)m, cdesc));
+        SWG_KERNEL_CHECK(ctx);
+        const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * 64 ? n_chunks : (uint64_t)ctx->num_cu * 64;
+        if (lists_all)
+          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false><<<(unsigned)wb, 64, 0, st>>>(
+                                            (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
+                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 0, bps, bps, pred, pred));
+        else
+          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true><<<(unsigned)wb, 64, 0, st>>>(
+                                            (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
+                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, 0, bps, bps, pred, pred));
+        SWG_KERNEL_CHECK(ctx);
+      }
+      if (n_big) {
+        uint32_t* big_list = swg_alloc<uint32_t>(ctx, n_big);
+        SWG_CHECK_ARENA(ctx);
+        SWG_TRY(swg_flags_compact(ctx, big_scan, big_list));
+        // ---- block-speculative selection of the long units
+        uint32_t* S_u = swg_alloc<uint32_t>(ctx, n_big);
+        uint32_t* nblk_u = swg_alloc<uint32_t>(ctx, n_big);
+        uint32_t* blk_off = swg_alloc<uint32_t>(ctx, n_big);
+        uint64_t* d_nblk = swg_alloc<uint64_t>(ctx, 1);
+        unsigned long long* ext = swg_alloc<unsigned long long>(ctx, m);
+        unsigned long long* v_own = swg_alloc<unsigned long long>(ctx, m);
+        unsigned long long* v_prev = swg_alloc<unsigned long long>(ctx, m);
+        uint32_t* p_own = swg_alloc<uint32_t>(ctx, m);
+        uint32_t* p_prev = swg_alloc<uint32_t>(ctx, m);
+        uint32_t* spec_changed = swg_alloc<uint32_t>(ctx, 2);
+        uint64_t* d_smax = swg_alloc<uint64_t>(ctx, 1);  // adjacent to d_nblk: read back together
+        SWG_CHECK_ARENA(ctx);
+        SWG_HIP(ctx, hipMemsetAsync(d_smax, 0, 8, st));
+        if (m / n_big > 65536) {  // few, very long units
+          uint32_t* wmax_u = swg_alloc<uint32_t>(ctx, n_units);
+          SWG_CHECK_ARENA(ctx);
+          SWG_HIP(ctx, hipMemsetAsync(wmax_u, 0, n_units * sizeof(uint32_t), st));
+          const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
+          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u));
+          SWG_KERNEL_CHECK(ctx);
+          SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                                (uint32_t)m, wmax_u, S_u, nblk_u,
+                                                                                reinterpret_cast<uint32_t*>(d_smax)));
+          SWG_KERNEL_CHECK(ctx);
+        } else {
+          SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                          (uint32_t)m, c_ext, S_u, nblk_u,
+                                                                          reinterpret_cast<uint32_t*>(d_smax)));
+          SWG_KERNEL_CHECK(ctx);
+        }
+        SWG_TRY(swg_exclusive_scan_u32(ctx, nblk_u, blk_off, n_big, d_nblk));
+        uint64_t n_spec = 0, s_max = 0;
+        SWG_TRY(swg_read_scalars(ctx, d_nblk, &n_spec, 1));
+        SWG_TRY(swg_read_scalars(ctx, d_smax, &s_max, 1));
+        s_max &= 0xffffffffull;
+        SpecBlock* desc = swg_alloc<SpecBlock>(ctx, n_spec);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "spec_desc", spec_desc_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+                                                                        (uint32_t)m, S_u, nblk_u, blk_off, desc));
+        SWG_KERNEL_CHECK(ctx);
+        SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(ext), ~0ull));
+        SWG_KERNEL_CHECK(ctx);
+        const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
+        // The ring is a cache (positions outside it are read from global memory), so its size only trades LDS hits for
+        // resident wavefronts.
+        static const char* ring_knob = getenv("SWG_SPEC_RING");
+        const int ring = ring_knob ? atoi(ring_knob) : (s_max <= 512 ? 256 : s_max + 64 <= 1024 ? 1024 : 4096);
+        int rounds = 0;
+        for (uint64_t round = 0; round <= n_spec + 1; ++round) {
+          SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
+          SWG_KERNEL_CHECK(ctx);
+          const unsigned wblocks = (unsigned)(n_spec < (uint64_t)ctx->num_cu * 32 ? n_spec : (uint64_t)ctx->num_cu * 32);
+#define SWG_WALK_SPEC(W)                                                                                                          \
+  SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, false><<<wblocks, 64, 0, st>>>(                                           \
+                                         (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin, \
+                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 1, v_own, v_prev, p_own, p_prev))
+          if (ring <= 256)
+            SWG_WALK_SPEC(256);
+          else if (ring <= 1024)
+            SWG_WALK_SPEC(1024);
+          else
+            SWG_WALK_SPEC(4096);
+#undef SWG_WALK_SPEC
+          SWG_KERNEL_CHECK(ctx);
+          SWG_HIP(ctx, hipMemsetAsync(spec_changed, 0, 8, st));
+          SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, v_prev, ext, spec_changed));
+          SWG_KERNEL_CHECK(ctx);
+          uint64_t ch = 0;
+          SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(spec_changed), &ch, 1));
+          ++rounds;
+          if ((uint32_t)ch == 0) break;
+        }
+        if (getenv("SWG_DEBUG"))
+          fprintf(stderr, "[swg] long units: %llu, blocks %llu (longest %llu), rounds %d\n", (unsigned long long)n_big,
+                  (unsigned long long)n_spec, (unsigned long long)s_max, rounds);
+        SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
+        SWG_KERNEL_CHECK(ctx);
+      }
+    } else {
     unsigned long long* c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
     uint32_t* c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
     uint32_t* c_n = swg_alloc<uint32_t>(ctx, m);
     uint32_t* c_ext = swg_alloc<uint32_t>(ctx, m);
     SWG_CHECK_ARENA(ctx);
-    if (getenv("SWG_DEBUG"))
-      fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
-              (unsigned long long)n_groups, (unsigned long long)n_units);
-    static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wavefront per i) kernel at any size
     if (long_groups || force_deep)
       SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
                                                    m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
@@ -1414,6 +1876,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                                                                                   c_n, s_gidx, group_begin, (uint32_t)n_groups, bps, pred));
         SWG_KERNEL_CHECK(ctx);
       }
+    }
     }
   }
   ChainWork& W = *work;

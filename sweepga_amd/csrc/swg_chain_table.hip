@@ -250,7 +250,7 @@ __global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const
   uint32_t g = blockIdx.x * EW + threadIdx.x;
   if (g >= n_groups) return;
   const uint32_t b = group_begin[g];
-  const uint32_t first = cpos_excl[b];  // a group's first member is always a chain head
+  const uint32_t first = cpos_excl[b];  // exclusive count of passing heads before the group = its first chain
   const uint32_t next = (g + 1 < n_groups) ? cpos_excl[group_begin[g + 1]] : nc;
   (void)m;
   g_first_chain[g] = first;
@@ -291,17 +291,50 @@ __global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t m, const uint3
   order[g_base[g] + (c - g_first_chain[g])] = c;
 }
 
+// weighted identity of a chain (paf_filter.rs:896-913) from its aggregates
+__device__ __forceinline__ double chain_weighted_identity(uint64_t total_length, uint64_t sm, uint64_t sb) {
+  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
+  double lcg = 0.0;
+  if (gap_length > 0) {
+    lcg = swg_log_glibc((double)gap_length);
+    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
+  }
+  const double eff = __dadd_rn((double)sb, lcg);
+  return eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
+}
+// Span / identity filter (paf_filter.rs:449-455) decided at the head, in position order: ok_head[p] = 1 iff p heads a chain
+// that passes.  Most chains are short singletons that fail the span test; only the passing ones are placed, materialised and
+// swept.  The number of all chains (a statistic) is counted on the way.
+__global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
+                                                      const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe,
+                                                      const unsigned long long* __restrict__ h_sm,
+                                                      const unsigned long long* __restrict__ h_sb, uint64_t min_len,
+                                                      double min_ident, uint32_t* __restrict__ ok_head,
+                                                      unsigned long long* __restrict__ n_heads) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  const bool head = p < m && is_head[p] != 0;
+  bool ok = false;
+  if (head) {
+    const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
+    ok = total_length >= min_len;
+    if (ok) ok = chain_weighted_identity(total_length, h_sm[p], h_sb[p]) >= min_ident;
+  }
+  if (p < m) ok_head[p] = ok ? 1u : 0u;
+  const uint64_t hm = __ballot(head);
+  if ((threadIdx.x & 63) == 0 && hm) atomicAdd(n_heads, (unsigned long long)__popcll(hm));
+}
+
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
 __global__ __launch_bounds__(EW) void chain_columns_kernel(
     uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
     const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
     const uint32_t* __restrict__ h_te, const unsigned long long* __restrict__ h_sm,
     const unsigned long long* __restrict__ h_sb, const uint64_t* __restrict__ s_grp, const uint32_t* __restrict__ s_a,
-    const uint32_t* __restrict__ a_dpair, uint32_t n_seq, uint64_t min_len, double min_ident,
+    const uint32_t* __restrict__ a_dpair, uint32_t n_seq,
     uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
     uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
     double* __restrict__ C_wid, uint8_t* __restrict__ C_strand, uint32_t* __restrict__ C_dpair,
-    uint8_t* __restrict__ C_ok, uint32_t* __restrict__ rank_of_poschain) {
+    uint32_t* __restrict__ rank_of_poschain) {
   uint64_t c2 = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (c2 >= nc) return;
   const uint32_t c = order[c2];
@@ -319,25 +352,18 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
   C_te[c2] = te;
   C_dpair[c2] = a_dpair[s_a[p]];
   const uint64_t total_length = (uint64_t)qe - (uint64_t)qs;  // q_max - q_min
-  const uint64_t sm = h_sm[p], sb = h_sb[p];
-  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
-  double lcg = 0.0;
-  if (gap_length > 0) {
-    lcg = swg_log_glibc((double)gap_length);
-    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
-  }
-  const double eff = __dadd_rn((double)sb, lcg);
-  const double wid = eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
-  C_wid[c2] = wid;
-  C_ok[c2] = (total_length >= min_len && wid >= min_ident) ? 1 : 0;
+  C_wid[c2] = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
 }
 
 __global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
+                                                            const uint32_t* __restrict__ ok_head,
                                                             const uint32_t* __restrict__ cpos_excl,
                                                             const uint32_t* __restrict__ rank_of_poschain,
                                                             uint32_t* __restrict__ s_chain) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) s_chain[p] = rank_of_poschain[cpos_excl[hd[p]]];
+  if (p >= m) return;
+  const uint32_t h = hd[p];
+  s_chain[p] = ok_head[h] ? rank_of_poschain[cpos_excl[h]] : NONE;
 }
 
 }  // namespace
@@ -413,9 +439,20 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
                                                                         h_sm, h_sb));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, is_head, cpos, m, d_tot));
-  uint64_t nc = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
+  // span / identity filter at the heads; from here on "chain" means a chain that passes it
+  uint32_t* ok_head = swg_alloc<uint32_t>(ctx, m);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
+  SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head,
+                                                          reinterpret_cast<unsigned long long*>(d_tot + 1)));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, ok_head, cpos, m, d_tot));
+  uint64_t h2[2];
+  SWG_TRY(swg_read_scalars(ctx, d_tot, h2, 2));
+  const uint64_t nc = h2[0];
+  B.n_chains_all = h2[1];
+  B.T.nc = nc;
+  if (nc == 0) return SWG_OK;
   // ---- all_chains order
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(n_groups), EW, 0, st>>>(n_groups, group_first, NONE));
   SWG_KERNEL_CHECK(ctx);
@@ -460,7 +497,6 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   T.ts = swg_alloc<uint32_t>(ctx, nc);
   T.te = swg_alloc<uint32_t>(ctx, nc);
   T.wid = swg_alloc<double>(ctx, nc);
-  T.ok = swg_alloc<uint8_t>(ctx, nc);
   B.C_strand = swg_alloc<uint8_t>(ctx, nc);
   B.C_dpair = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
@@ -477,14 +513,13 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_TRY(swg_exclusive_scan_u32(ctx, g_sizes, g_sizes, n_groups, nullptr));
   SWG_LAUNCH(ctx, "group_base", group_base_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_sizes, g_base));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
+  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, ok_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
                                        nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
-                                       r->n_seq, min_len, min_ident, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid,
-                                       B.C_strand, B.C_dpair, T.ok, rank_of));
+                                       r->n_seq, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, B.C_strand, B.C_dpair, rank_of));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, cpos, rank_of, B.s_chain));
+  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, cpos, rank_of, B.s_chain));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }

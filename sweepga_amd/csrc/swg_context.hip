@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdlib>
+
 #include "swg_internal.h"
 
 thread_local std::string swg_create_error;
@@ -237,6 +239,7 @@ void swg_destroy(swg_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->io_block) (void)hipFree(ctx->io_block);
+  std::free(ctx->narrow_host);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

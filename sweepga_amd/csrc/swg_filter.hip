@@ -76,17 +76,24 @@ __device__ __forceinline__ void seq_min_atomic(unsigned long long* lo, uint32_t 
 __global__ __launch_bounds__(EW) void seq_lo_kernel(uint64_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
                                                     const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
                                                     const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
-                                                    unsigned long long* __restrict__ lo) {
+                                                    uint32_t n_seq, unsigned long long* __restrict__ lo,
+                                                    unsigned long long* __restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  const bool in = i < n;
+  bool in = i < n;
   if (__ballot(in) == 0) return;
   uint32_t q = 0, t = 0;
   unsigned long long a = 0, b = 0;
   if (in) {
     q = q_id[i];
     t = t_id[i];
-    a = qs[i] < qe[i] ? qs[i] : qe[i];
-    b = ts[i] < te[i] ? ts[i] : te[i];
+    if (q >= n_seq || t >= n_seq) {  // the ids index the table: reported like the host version does (field 6), never followed
+      atomicMin(bad, ((unsigned long long)(i + 1) << 3) | 6u);
+      in = false;
+      q = t = 0;
+    } else {
+      a = qs[i] < qe[i] ? qs[i] : qe[i];
+      b = ts[i] < te[i] ? ts[i] : te[i];
+    }
   }
   seq_min_atomic(lo, q, a, in);
   seq_min_atomic(lo, t, b, in);
@@ -96,12 +103,14 @@ __global__ __launch_bounds__(EW) void rebase_kernel(uint64_t n, const uint32_t* 
                                                     const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
                                                     const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
                                                     const uint64_t* __restrict__ matches, const uint64_t* __restrict__ block,
-                                                    const unsigned long long* __restrict__ lo, uint32_t* __restrict__ o_qs,
-                                                    uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts, uint32_t* __restrict__ o_te,
+                                                    uint32_t n_seq, const unsigned long long* __restrict__ lo,
+                                                    uint32_t* __restrict__ o_qs, uint32_t* __restrict__ o_qe,
+                                                    uint32_t* __restrict__ o_ts, uint32_t* __restrict__ o_te,
                                                     uint32_t* __restrict__ o_m, uint32_t* __restrict__ o_b,
                                                     unsigned long long* __restrict__ bad) {
   const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (i >= n) return;
+  if (q_id[i] >= n_seq || t_id[i] >= n_seq) return;  // reported by seq_lo_kernel
   const unsigned long long oq = lo[q_id[i]], ot = lo[t_id[i]];
   const unsigned long long v[6] = {qs[i] - oq, qe[i] - oq, ts[i] - ot, te[i] - ot, matches[i], block[i]};
   o_qs[i] = (uint32_t)v[0];
@@ -327,16 +336,18 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
     unsigned long long* bad = lo + rec->n_seq;
     SWG_HIP(ctx, hipMemsetAsync(lo, 0xff, ((size_t)rec->n_seq + 1) * sizeof(unsigned long long), st));
     SWG_LAUNCH(ctx, "seq_lo", seq_lo_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end,
-                                                                   rec64->t_start, rec64->t_end, lo));
+                                                                   rec64->t_start, rec64->t_end, rec->n_seq, lo, bad));
     SWG_LAUNCH(ctx, "rebase", rebase_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end,
                                                                    rec64->t_start, rec64->t_end, rec64->matches, rec64->block_len,
-                                                                   lo, c[0], c[1], c[2], c[3], c[4], c[5], bad));
+                                                                   rec->n_seq, lo, c[0], c[1], c[2], c[3], c[4], c[5], bad));
     SWG_KERNEL_CHECK(ctx);
     uint64_t hb;
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(bad), &hb, 1));
     if (hb != ~0ull) {
       static const char* const F[8] = {"query_start", "query_end", "target_start", "target_end", "matches", "block_length", "?", "?"};
       const int f = (int)(hb & 7);
+      if (f == 6)
+        return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)((hb >> 3) - 1));
       return swg_set_error(ctx, SWG_ERR_RANGE,
                            f >= 4 ? "record %llu: %s >= 2^32 is not supported"
                                   : "record %llu: the mapped stretch of its sequence spans 2^32 bases or more (%s): not supported by the "
@@ -469,19 +480,27 @@ int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cf
   v = narrow_view(rec);
   const uint64_t n = rec->n;
   if (n == 0) return SWG_OK;
-  std::vector<uint32_t>& h = ctx->narrow_host;
-  std::vector<uint64_t> lo;
-  try {
-    if (h.size() < 6 * n) h.resize(6 * n);
-    lo.resize(rec->n_seq);
-  } catch (const std::bad_alloc&) {
-    return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory for the 32-bit columns");
+  // six uninitialised 32-bit columns (every word is written by the threaded pass below); see swg_narrow_release
+  if (ctx->narrow_cap < 6 * n) {
+    std::free(ctx->narrow_host);
+    ctx->narrow_cap = 0;
+    ctx->narrow_host = static_cast<uint32_t*>(std::malloc(6 * n * sizeof(uint32_t)));
+    if (!ctx->narrow_host) return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory for the 32-bit columns");
+    ctx->narrow_cap = 6 * n;
   }
+  uint32_t* h = ctx->narrow_host;
   const uint64_t* const c64[6] = {rec->q_start, rec->q_end, rec->t_start, rec->t_end, rec->matches, rec->block_len};
-  uint32_t* const c32[6] = {h.data(), h.data() + n, h.data() + 2 * n, h.data() + 3 * n, h.data() + 4 * n, h.data() + 5 * n};
+  uint32_t* const c32[6] = {h, h + n, h + 2 * n, h + 3 * n, h + 4 * n, h + 5 * n};
   unsigned hc = std::thread::hardware_concurrency();
-  const swg_rebase::Result rr = swg_rebase::columns(n, rec->q_id, rec->t_id, c64, rec->n_seq, hc ? (int)(hc > 64 ? 64 : hc) : 1, c32,
-                                                    lo.data());
+  swg_rebase::Result rr;
+  try {
+    std::vector<uint64_t> lo(rec->n_seq);
+    rr = swg_rebase::columns(n, rec->q_id, rec->t_id, c64, rec->n_seq, hc ? (int)(hc > 64 ? 64 : hc) : 1, c32, lo.data());
+  } catch (const std::bad_alloc&) {  // also what a failed worker body turns into (host/threads.h)
+    return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory while rebasing %llu records", (unsigned long long)n);
+  } catch (const std::system_error& e) {
+    return swg_set_error(ctx, SWG_ERR_OOM, "cannot start host threads: %s", e.what());
+  }
   if (!rr.ok && rr.bad_field == 6)
     return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)rr.bad_record);
   if (!rr.ok)
@@ -502,7 +521,18 @@ extern "C" int swg_filter64(swg_ctx* ctx, const swg_records64* rec, const swg_co
                             swg_stats* stats) {
   swg_records v;
   SWG_TRY(swg_rebase_host(ctx, rec, cfg, &v));
-  return swg_filter(ctx, &v, cfg, status_out, chain_out, stats);
+  const int rc = swg_filter(ctx, &v, cfg, status_out, chain_out, stats);
+  swg_narrow_release(ctx);
+  return rc;
+}
+// The 32-bit host columns are only needed for the duration of one call: a small buffer stays with the context (a host that
+// filters file after file re-uses it), anything beyond 256 MB (10^7 records) goes back to the system.
+void swg_narrow_release(swg_ctx* ctx) {
+  if (ctx->narrow_cap * sizeof(uint32_t) > (size_t(256) << 20)) {
+    std::free(ctx->narrow_host);
+    ctx->narrow_host = nullptr;
+    ctx->narrow_cap = 0;
+  }
 }
 
 // ---- plane_sweep_query / target / both on one segment of host arrays --------------------------------

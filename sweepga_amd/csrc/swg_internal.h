@@ -23,7 +23,8 @@ struct swg_ctx {
   // demand, so a host that filters file after file pays no hipMalloc / hipFree in steady state
   char* io_block = nullptr;
   size_t io_cap = 0;
-  std::vector<uint32_t> narrow_host;  // swg_filter64: the rebased 32-bit columns (host side), kept between calls
+  uint32_t* narrow_host = nullptr;  // swg_filter64: the rebased 32-bit columns (host side, malloc), released by swg_narrow_release
+  size_t narrow_cap = 0;            //   in words
   // pinned host scratch for small read-backs
   uint64_t* h_scalars = nullptr;  // 64 x u64
   std::string err;
@@ -180,8 +181,9 @@ __device__ __forceinline__ void swg_radix_hist_flush(uint32_t (*h)[SWG_RADIX_BIN
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.
 int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64_t* e0, uint32_t* out_s, uint32_t* out_e,
                       const char* axis);
-// swg_records64 (host pointers) -> 32-bit columns kept in ctx->narrow_host, coordinates rebased per sequence (host/rebase.h)
+// swg_records64 (host pointers) -> 32-bit columns in ctx->narrow_host, coordinates rebased per sequence (host/rebase.h)
 int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, swg_records* out);
+void swg_narrow_release(swg_ctx* ctx);  // after the call that used them (keeps at most 256 MB with the context)
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
 
 static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represent max_value

@@ -15,15 +15,16 @@ namespace {
 // in_filtered[i] = 1 iff i is a member of a span/identity-filtered chain (pre_sweep_scaffold_members)
 __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint32_t* __restrict__ s_idx,
                                                           const uint32_t* __restrict__ s_chain,
-                                                          const uint8_t* __restrict__ C_ok,
                                                           const uint32_t* __restrict__ C_num,
                                                           uint32_t* __restrict__ anchor_num,
                                                           uint8_t* __restrict__ in_filtered) {
   uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
-  const uint32_t c = s_chain[p], i = s_idx[p];
+  const uint32_t c = s_chain[p];
+  if (c == NONE) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
+  const uint32_t i = s_idx[p];
   anchor_num[i] = C_num[c];
-  in_filtered[i] = C_ok[c];
+  in_filtered[i] = 1;
 }
 
 // Kept '+' chains compacted in all_chains order.  A chromosome pair's '+' group is contiguous in that order and
@@ -290,7 +291,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
                        pos_bits, true, &B, q_order));
   if (stats) {
     stats->n_swept = B.m;
-    stats->n_chains = B.T.nc;
+    stats->n_chains = B.n_chains_all;
   }
   if (B.M == 0 || B.m == 0 || B.T.nc == 0) return SWG_OK;  // nothing can be an anchor: everything is dropped
   const uint64_t nc = B.T.nc, M = B.M, m = B.m;
@@ -308,7 +309,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   if (stats) stats->n_chains_kept = n_kept;
   SWG_HIP(ctx, hipMemsetAsync(anchor_num, 0, n * sizeof(uint32_t), st));
   SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
-  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.s_chain, B.T.ok, C_num, anchor_num, in_filtered));
+  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.s_chain, C_num, anchor_num, in_filtered));
   SWG_KERNEL_CHECK(ctx);
 
   auto finish_counts = [&]() -> int {

@@ -72,7 +72,6 @@ struct ChainTable {
   uint64_t nc = 0;
   uint32_t *qid = nullptr, *tid = nullptr, *qs = nullptr, *qe = nullptr, *ts = nullptr, *te = nullptr;
   double* wid = nullptr;
-  uint8_t* ok = nullptr;  // passes span/identity filter (input of the scaffold sweep)
 };
 
 struct ChainBuild {
@@ -86,8 +85,10 @@ struct ChainBuild {
   uint64_t m = 0;
   uint32_t* s_a = nullptr;      // A position
   uint32_t* s_idx = nullptr;    // original index
-  uint32_t* s_chain = nullptr;  // chain (all_chains index)
-  // chains, in all_chains order
+  uint32_t* s_chain = nullptr;  // index into T of the member's chain, NONE when that chain fails the span / identity filter
+  // chains that pass the span / identity filter (paf_filter.rs:449-455), in all_chains order: only these reach the scaffold
+  // sweep, the numbering, the anchors; the others exist as a count
+  uint64_t n_chains_all = 0;
   ChainTable T;
   uint8_t* C_strand = nullptr;
   uint32_t* C_dpair = nullptr;

@@ -61,36 +61,6 @@ __global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const u
   if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
 }
 
-__global__ __launch_bounds__(EW) void chain_compact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
-                                                           const uint32_t* __restrict__ qid, const uint32_t* __restrict__ tid,
-                                                           const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
-                                                           const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
-                                                           const double* __restrict__ wid, uint32_t* __restrict__ o_qid,
-                                                           uint32_t* __restrict__ o_tid, uint32_t* __restrict__ o_qs,
-                                                           uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts,
-                                                           uint32_t* __restrict__ o_te, double* __restrict__ o_wid) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= no) return;
-  const uint32_t c = ok_idx[j];
-  o_qid[j] = qid[c];
-  o_tid[j] = tid[c];
-  o_qs[j] = qs[c];
-  o_qe[j] = qe[c];
-  o_ts[j] = ts[c];
-  o_te[j] = te[c];
-  o_wid[j] = wid[c];
-}
-__global__ __launch_bounds__(EW) void chain_uncompact_kernel(uint64_t no, const uint32_t* __restrict__ ok_idx,
-                                                             const uint8_t* __restrict__ kept_j,
-                                                             const uint32_t* __restrict__ num_j,
-                                                             uint8_t* __restrict__ C_kept, uint32_t* __restrict__ C_num) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= no) return;
-  const uint32_t c = ok_idx[j];
-  C_kept[c] = kept_j[j];
-  C_num[c] = num_j[j];
-}
-
 }  // namespace
 
 // plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
@@ -110,35 +80,18 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
     kq = max_q ? max_q : SWG_K_INF;
     kt = max_t ? max_t : SWG_K_INF;
   }
-  SWG_HIP(ctx, hipMemsetAsync(C_kept, 0, T.nc, st));
-  SWG_HIP(ctx, hipMemsetAsync(C_num, 0, T.nc * sizeof(uint32_t), st));
-  // ---- only the span/identity-filtered chains take part (compaction keeps their relative order, which is
-  //      all the plane sweep's index tie-break needs)
+  // every chain of T takes part (the span / identity filter was applied when T was built); index order = all_chains order
+  // restricted to them, which is all the plane sweep's index tie-break needs
+  const uint64_t nc = T.nc;
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
-  SWG_CHECK_ARENA(ctx);
-  swg_flag_scan ok_scan;
-  SWG_TRY(swg_flags_count(ctx, T.ok, T.nc, &ok_scan, d_tot));
-  uint64_t nc = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nc, 1));
-  if (nc == 0) return SWG_OK;
-  uint32_t* ok_idx = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qid = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* tid = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qs = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* qe = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* ts = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* te = swg_alloc<uint32_t>(ctx, nc);
-  double* wid = swg_alloc<double>(ctx, nc);
+  uint32_t *qid = T.qid, *tid = T.tid, *qs = T.qs, *qe = T.qe, *ts = T.ts, *te = T.te;
+  double* wid = T.wid;
   uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
   uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
-  uint8_t* kept = swg_alloc<uint8_t>(ctx, nc);
-  uint32_t* num = swg_alloc<uint32_t>(ctx, nc);
+  uint8_t* kept = C_kept;
+  uint32_t* num = C_num;
   SWG_CHECK_ARENA(ctx);
-  SWG_TRY(swg_flags_compact(ctx, ok_scan, ok_idx));
-  SWG_LAUNCH(ctx, "chain_compact", chain_compact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, qid,
-                                                                     tid, qs, qe, ts, te, wid));
-  SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, qid, tid, n_seq, seg));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
@@ -201,8 +154,6 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
     SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
     SWG_KERNEL_CHECK(ctx);
   }
-  SWG_LAUNCH(ctx, "chain_uncompact", chain_uncompact_kernel<<<nblk(nc), EW, 0, st>>>(nc, ok_idx, kept, num, C_kept, C_num));
-  SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
 
@@ -246,7 +197,6 @@ extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_
     T.qid = swg_alloc<uint32_t>(ctx, n);
     T.tid = swg_alloc<uint32_t>(ctx, n);
     T.wid = swg_alloc<double>(ctx, n);
-    T.ok = swg_alloc<uint8_t>(ctx, n);
     uint32_t* d_g2 = swg_alloc<uint32_t>(ctx, n_seq);
     uint8_t* C_kept = swg_alloc<uint8_t>(ctx, n);
     uint32_t* C_num = swg_alloc<uint32_t>(ctx, n);
@@ -260,7 +210,6 @@ extern "C" int swg_plane_sweep_scaffolds(swg_ctx* ctx, uint64_t n, const uint32_
     SWG_HIP(ctx, hipMemcpyAsync(T.tid, t_id, n * 4, hipMemcpyHostToDevice, st));
     SWG_HIP(ctx, hipMemcpyAsync(T.wid, identity, n * 8, hipMemcpyHostToDevice, st));
     SWG_HIP(ctx, hipMemcpyAsync(d_g2, seq_genome_two, (size_t)n_seq * 4, hipMemcpyHostToDevice, st));
-    SWG_HIP(ctx, hipMemsetAsync(T.ok, 1, n, st));
     uint64_t nk = 0;
     SWG_TRY(scaffold_sweep_and_number(ctx, T, n_seq, d_g2, n_genome_two, mode, max_per_query, max_per_target, thr,
                                       scoring, pos_bits, C_kept, C_num, &nk));
