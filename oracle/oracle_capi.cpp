@@ -143,6 +143,10 @@ static std::vector<RecordMeta> build_records(uint64_t n, const uint64_t* rank,
 // PafFilter::apply_filters.  status_out[i]: 0 dropped, 1 scaffold, 2 rescued, 3 unassigned.
 // chain_out[i]: N of "chain_N", 0 = no ch:Z: tag.  Returns number kept, or -1 on error.
 // seconds_out (optional) receives the wall time of apply_filters alone (records already built).
+// 1: apply_filters evaluates step 4b (paf_filter.rs:535-597) through a bucket index instead of the literal
+// chains x reverse-mappings loop (same result, tests/test_oracle_fast_cpu.py); for full-size checks of deep chromosome pairs.
+void orc_set_fast_inversion(int on) { g_fast_inversion = on != 0; }
+
 int64_t orc_apply_filters(const orc_config* cfg, uint64_t n, const uint64_t* rank,
                           const char* const* qnames, const char* const* tnames,
                           const uint64_t* qs, const uint64_t* qe, const uint64_t* ts,

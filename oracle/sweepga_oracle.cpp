@@ -876,6 +876,10 @@ std::vector<MergedChain> PafFilter::apply_scaffold_plane_sweep(std::vector<Merge
   return out;
 }
 
+// Test-infrastructure switch (oracle_capi: orc_set_fast_inversion): step 4b through a bucket index instead of the reference's
+// chains x reverse-mappings loop.  Off by default; every parity test of the suite runs the literal loop.
+bool g_fast_inversion = false;
+
 // paf_filter.rs:379-747
 std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<RecordMeta> metadata) const {
   std::unordered_map<size_t, RecordMeta> result;
@@ -941,32 +945,110 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
   for (size_t idx = 0; idx < all_original.size(); ++idx)
     if (all_original[idx].strand == '-')
       reverse_by_chr_pair[{all_original[idx].query_name, all_original[idx].target_name}].push_back(idx);
-  for (size_t ci = 0; ci < filtered_chains.size(); ++ci) {
-    const MergedChain& chain = filtered_chains[ci];
-    if (chain.strand != '+') continue;
-    std::string chain_id = "chain_" + std::to_string(ci + 1);
-    int64_t diagonal_offset = (int64_t)chain.target_start - (int64_t)chain.query_start;
-    auto it = reverse_by_chr_pair.find({chain.query_name, chain.target_name});
-    if (it == reverse_by_chr_pair.end()) continue;
-    for (size_t idx : it->second) {
-      const RecordMeta& mapping = all_original[idx];
-      if (anchor_ranks.count(mapping.rank)) continue;
-      uint64_t ext_start = chain.query_start > max_diagonal_distance
-                               ? chain.query_start - max_diagonal_distance
-                               : 0;  // saturating_sub
-      uint64_t ext_end = chain.query_end > UINT64_MAX - max_diagonal_distance
-                             ? UINT64_MAX
-                             : chain.query_end + max_diagonal_distance;  // saturating_add
-      if (mapping.query_end < ext_start || mapping.query_start > ext_end) continue;
-      uint64_t q_center = (mapping.query_start + mapping.query_end) / 2;
-      uint64_t t_center = (mapping.target_start + mapping.target_end) / 2;
-      int64_t dev = (int64_t)t_center - (int64_t)q_center - diagonal_offset;
-      uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;  // unsigned_abs
-      double pd = (double)deviation / 1.4142135623730951;  // std::f64::consts::SQRT_2
-      uint64_t perpendicular = pd >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)pd;
-      if (perpendicular <= max_diagonal_distance) {
-        anchor_ranks.insert(mapping.rank);
-        rank_to_chain_id[mapping.rank] = chain_id;
+  if (!g_fast_inversion) {
+    for (size_t ci = 0; ci < filtered_chains.size(); ++ci) {
+      const MergedChain& chain = filtered_chains[ci];
+      if (chain.strand != '+') continue;
+      std::string chain_id = "chain_" + std::to_string(ci + 1);
+      int64_t diagonal_offset = (int64_t)chain.target_start - (int64_t)chain.query_start;
+      auto it = reverse_by_chr_pair.find({chain.query_name, chain.target_name});
+      if (it == reverse_by_chr_pair.end()) continue;
+      for (size_t idx : it->second) {
+        const RecordMeta& mapping = all_original[idx];
+        if (anchor_ranks.count(mapping.rank)) continue;
+        uint64_t ext_start = chain.query_start > max_diagonal_distance
+                                 ? chain.query_start - max_diagonal_distance
+                                 : 0;  // saturating_sub
+        uint64_t ext_end = chain.query_end > UINT64_MAX - max_diagonal_distance
+                               ? UINT64_MAX
+                               : chain.query_end + max_diagonal_distance;  // saturating_add
+        if (mapping.query_end < ext_start || mapping.query_start > ext_end) continue;
+        uint64_t q_center = (mapping.query_start + mapping.query_end) / 2;
+        uint64_t t_center = (mapping.target_start + mapping.target_end) / 2;
+        int64_t dev = (int64_t)t_center - (int64_t)q_center - diagonal_offset;
+        uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;  // unsigned_abs
+        double pd = (double)deviation / 1.4142135623730951;  // std::f64::consts::SQRT_2
+        uint64_t perpendicular = pd >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)pd;
+        if (perpendicular <= max_diagonal_distance) {
+          anchor_ranks.insert(mapping.rank);
+          rank_to_chain_id[mapping.rank] = chain_id;
+        }
+      }
+    }
+  } else {
+    // NOT the reference's loop: the same result through an index, for record sets where chains x reverse mappings of a pair
+    // (1.4 * 10^6 x 10^6 on BASELINE.json configs[2]) makes the literal loop above take hours.  In that loop a reverse
+    // mapping joins the FIRST '+' chain in `filtered_chains` order whose window and diagonal tests it passes (later chains
+    // find it in anchor_ranks), and the tests depend on nothing but the chain and the mapping.  So: per chromosome pair the
+    // '+' chains are registered in every 65,536-bp bucket their extended query window touches; a mapping looks at the
+    // buckets its own query span touches, applies the reference's tests to those chains and keeps the lowest chain index.
+    // tests/test_oracle_fast_cpu.py holds this against the literal loop.
+    const uint64_t B = 65536;
+    struct PairIndex {
+      std::unordered_map<uint64_t, std::vector<size_t>> buckets;
+      std::vector<size_t> everywhere;  // chains whose window touches more than 2^16 buckets: tested against every mapping
+    };
+    std::map<std::pair<std::string, std::string>, PairIndex> index;
+    for (size_t ci = 0; ci < filtered_chains.size(); ++ci) {
+      const MergedChain& chain = filtered_chains[ci];
+      if (chain.strand != '+') continue;
+      auto it = reverse_by_chr_pair.find({chain.query_name, chain.target_name});
+      if (it == reverse_by_chr_pair.end()) continue;
+      const uint64_t ext_start = chain.query_start > max_diagonal_distance ? chain.query_start - max_diagonal_distance : 0;
+      const uint64_t ext_end = chain.query_end > UINT64_MAX - max_diagonal_distance ? UINT64_MAX
+                                                                                    : chain.query_end + max_diagonal_distance;
+      PairIndex& pi = index[{chain.query_name, chain.target_name}];
+      if (ext_end / B - ext_start / B > 65536) {
+        pi.everywhere.push_back(ci);
+        continue;
+      }
+      for (uint64_t b = ext_start / B;; ++b) {
+        pi.buckets[b].push_back(ci);
+        if (b == ext_end / B) break;
+      }
+    }
+    for (auto& kv : reverse_by_chr_pair) {
+      auto pit = index.find(kv.first);
+      if (pit == index.end()) continue;
+      for (size_t idx : kv.second) {
+        const RecordMeta& mapping = all_original[idx];
+        if (anchor_ranks.count(mapping.rank)) continue;  // members of kept chains (the only anchors before this step)
+        size_t best = SIZE_MAX;
+        auto test = [&](size_t ci) {
+          if (ci >= best) return;
+          const MergedChain& chain = filtered_chains[ci];
+          const int64_t diagonal_offset = (int64_t)chain.target_start - (int64_t)chain.query_start;
+          const uint64_t ext_start = chain.query_start > max_diagonal_distance ? chain.query_start - max_diagonal_distance : 0;
+          const uint64_t ext_end = chain.query_end > UINT64_MAX - max_diagonal_distance ? UINT64_MAX
+                                                                                        : chain.query_end + max_diagonal_distance;
+          if (mapping.query_end < ext_start || mapping.query_start > ext_end) return;
+          const uint64_t q_center = (mapping.query_start + mapping.query_end) / 2;
+          const uint64_t t_center = (mapping.target_start + mapping.target_end) / 2;
+          const int64_t dev = (int64_t)t_center - (int64_t)q_center - diagonal_offset;
+          const uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;
+          const double pd = (double)deviation / 1.4142135623730951;
+          const uint64_t perpendicular = pd >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)pd;
+          if (perpendicular <= max_diagonal_distance) best = ci;
+        };
+        for (size_t ci : pit->second.everywhere) test(ci);
+        // a window and a span that overlap share a bucket; a mapping with end < start (malformed) overlaps nothing the literal
+        // tests would accept beyond what its two coordinates' buckets hold... they are visited as a range all the same
+        const uint64_t lo_q = std::min(mapping.query_start, mapping.query_end), hi_q = std::max(mapping.query_start, mapping.query_end);
+        if (hi_q / B - lo_q / B > 65536) {
+          for (auto& bk : pit->second.buckets)
+            for (size_t ci : bk.second) test(ci);
+        } else {
+          for (uint64_t b = lo_q / B;; ++b) {
+            auto bit = pit->second.buckets.find(b);
+            if (bit != pit->second.buckets.end())
+              for (size_t ci : bit->second) test(ci);
+            if (b == hi_q / B) break;
+          }
+        }
+        if (best != SIZE_MAX) {
+          anchor_ranks.insert(mapping.rank);
+          rank_to_chain_id[mapping.rank] = "chain_" + std::to_string(best + 1);
+        }
       }
     }
   }

@@ -155,6 +155,8 @@ struct MergedChain {
   std::vector<size_t> member_indices;  // ranks
 };
 
+extern bool g_fast_inversion;  // see sweepga_oracle.cpp (step 4b through an index; full-size checks only)
+
 struct PafFilter {
   FilterConfig config;
   explicit PafFilter(const FilterConfig& c) : config(c) {}

@@ -388,3 +388,9 @@ def clamp_scaffold_params(jump, mass, avg, adaptive):
     lib().orc_clamp_scaffold_params(C.c_uint64(jump), C.c_uint64(mass), C.c_int(avg is not None),
                                     C.c_uint64(avg or 0), C.c_int(bool(adaptive)), C.byref(j), C.byref(m))
     return j.value, m.value
+
+
+def set_fast_inversion(on):
+    """apply_filters' step 4b (paf_filter.rs:535-597) through a bucket index instead of the literal chains x reverse-mappings
+    loop (oracle/sweepga_oracle.cpp; same result, tests/test_oracle_fast_cpu.py).  Process-wide; for full-size checks only."""
+    lib().orc_set_fast_inversion(C.c_int(1 if on else 0))

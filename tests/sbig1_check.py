@@ -15,7 +15,10 @@ def main(cases):
     import bench
     import sweepga_amd as sw
     from sweepga_amd import _lib
+    import os
     from tests import orc
+    if os.environ.get("SBIG1_FAST_INVERSION"):  # tools/sbig1_full_parity.py: step 4b through the oracle's bucket index
+        orc.set_fast_inversion(True)
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     ctx = sw.Context(0)

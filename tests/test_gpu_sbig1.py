@@ -2,9 +2,12 @@
 (seed 1234, depth ~165): a single query-axis segment and a single target-axis segment.
 
 Full size through swg_filter_device, record for record against the oracle (src/plane_sweep_exact.rs:268-433 via
-src/paf_filter.rs:972-1123), for `--num-mappings 1:1 --scaffold-jump 0`.  The reference's chaining scan is
-O(n x window) (src/paf_filter.rs:784-851) and at this depth a window holds ~2,000 mappings, so the oracle needs hours for
-the scaffold flag sets at 10^7; those are checked (status AND chain numbers) on
+src/paf_filter.rs:972-1123), for `--num-mappings 1:1 --scaffold-jump 0`.  For the scaffold flag sets the literal oracle
+needs hours at 10^7 -- not for the chaining scan (O(n x window), minutes) but for the inversion capture, which loops over
+kept '+' chains x '-' mappings of the pair (src/paf_filter.rs:535-597: 1.4 * 10^6 x 10^6 here).  The full-size check of
+those flag sets therefore lives outside the pytest budget (tools/sbig1_full_parity.py, ~15 min, the oracle's indexed form
+of that one step; results in profiles/r03_sbig1_full_size_parity_{default,full}.json); here they are checked (status AND
+chain numbers) with the literal oracle on
   * 10^6 mappings on the full-length chromosomes (depth ~16), and
   * 2 x 10^5 mappings with the chromosome length scaled by n / 10^7, i.e. at S-big1's own depth (long chaining units,
     the block-speculative path of swg_scaffold.hip),
