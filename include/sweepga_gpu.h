@@ -235,6 +235,10 @@ int swg_profile_units(swg_ctx* ctx, int i, uint64_t* units);
  * knows its sizes can avoid that by one warm-up call or by swg_reserve(). */
 int swg_memory_info(const swg_ctx* ctx, uint64_t* arena_capacity, uint64_t* arena_peak_last_call);
 int swg_reserve(swg_ctx* ctx, uint64_t arena_bytes);
+/* What a context's first swg_filter call would otherwise pay for inside the call (the reference has no counterpart: it has
+ * no device): scratch and staging memory for about n_records_hint records (0 = none) and the library's code objects on the
+ * device (one small built-in filter call).  Meant to run on its own host thread while the input is read and parsed. */
+int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_hint, int with_scaffold);
 
 /* ---- several devices of one node ---------------------------------------------------------------
  * swg_filter over n_ctx contexts (one per device, created by the caller): records are partitioned by genome pair

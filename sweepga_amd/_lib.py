@@ -20,7 +20,7 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
-           "swg_filter_multi", "swg_filter_multi64", "swg_memory_info", "swg_reserve",
+           "swg_filter_multi", "swg_filter_multi64", "swg_memory_info", "swg_reserve", "swg_warmup",
            "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name",
            "swg_paf_seq_offsets", "swg_aln_seq_offsets",
            "swg_paf_tree_filter", "swg_free",

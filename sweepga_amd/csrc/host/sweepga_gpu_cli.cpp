@@ -14,6 +14,8 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <sys/stat.h>
+
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -297,8 +299,15 @@ int main(int argc, char** argv) {
   };
   if (!need_ani) set_identities(-1.0);
 
-  // ---- HIP start-up (~0.1 s) runs on its own thread while the host threads read and parse the input
+  // ---- HIP start-up (~0.1 s), device memory for an input of this size and the library's code objects (swg_warmup) are
+  // prepared on a thread of their own while the host threads read and parse the input
   if (devices.empty()) devices.push_back(device);
+  uint64_t records_hint = 0;
+  {
+    struct stat sb;  // a PAF line is rarely shorter than ~90 bytes; compressed inputs are not guessed
+    const bool gz = input.size() > 3 && (input.rfind(".gz") == input.size() - 3 || input.rfind(".bgz") == input.size() - 4);
+    if (input != "-" && !gz && stat(input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) records_hint = (uint64_t)sb.st_size / 90;
+  }
   std::vector<swg_ctx*> ctxs;
   int init_rc = SWG_OK;
   std::string init_err;
@@ -312,6 +321,7 @@ int main(int argc, char** argv) {
         return;
       }
       ctxs.push_back(c);
+      (void)swg_warmup(c, records_hint / devices.size(), 4096, cfg.scaffold_gap != 0);  // best effort: a failure shows up in the call
     }
   });
 

@@ -331,11 +331,23 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     out_j[k] = NONE;
   }
   const uint64_t p0 = wave * CW_PER_WAVE;
+  // the parameters of the wavefront's CW_PER_WAVE elements, one element per lane (read once, up front: per element they would
+  // be two dependent memory round trips before its first batch)
+  uint32_t l_e = 0, l_qe = 0, l_ts = 0, l_te = 0, l_minus = 0;
+  if (lane < CW_PER_WAVE && p0 + lane < m) {
+    const uint64_t pl = p0 + lane;
+    const uint32_t g = s_gidx[pl];
+    l_e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
+    l_minus = (uint32_t)(s_grp[pl] & 1ull);
+    l_qe = s_qe[pl];
+    l_ts = s_ts[pl];
+    l_te = s_te[pl];
+  }
   for (uint64_t p = p0; p < p0 + CW_PER_WAVE && p < m; ++p) {  // wave-uniform
-    const uint32_t g = s_gidx[p];
-    const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : (uint32_t)m;
-    const bool minus = (s_grp[p] & 1ull) != 0;
-    const uint32_t qe_i = s_qe[p], ts_i = s_ts[p], te_i = s_te[p];
+    const int pt = (int)(p - p0);
+    const uint32_t e = readlane_u32(l_e, pt);
+    const bool minus = readlane_u32(l_minus, pt) != 0;
+    const uint32_t qe_i = readlane_u32(l_qe, pt), ts_i = readlane_u32(l_ts, pt), te_i = readlane_u32(l_te, pt);
     const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
     const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
     // the wavefront's list, (d asc, j asc); wave-uniform values
@@ -343,11 +355,30 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     uint32_t sj0 = NONE, sj1 = NONE, sj2 = NONE, sj3 = NONE;
     uint32_t count = 0, ext = 0, cut_at = 0;
     bool cut = false;
+    // software pipeline: the three coordinates of the NEXT batch are requested before the current one is evaluated (one
+    // memory round trip per batch, overlapped with the arithmetic, instead of two dependent ones)
+    uint32_t n_qs = 0xffffffffu, n_ts = 0, n_te = 0;
+    {
+      const uint32_t j = (uint32_t)p + 1 + lane;
+      if (j < e) {
+        n_qs = s_qs[j];
+        n_ts = s_ts[j];
+        n_te = s_te[j];
+      }
+    }
     for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
       const uint32_t j = j0 + lane;
-      const bool in = j < e;
-      const uint32_t qs_j = in ? s_qs[j] : 0xffffffffu;
-      const bool inwin = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
+      const uint32_t qs_j = n_qs, ts_j = n_ts, te_j = n_te;
+      {
+        const uint32_t jn = j + 64;
+        n_qs = 0xffffffffu;
+        if (jn < e) {
+          n_qs = s_qs[jn];
+          n_ts = s_ts[jn];
+          n_te = s_te[jn];
+        }
+      }
+      const bool inwin = j < e && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
       const uint64_t wmask = __ballot(inwin);
       ext += (uint32_t)__popcll(wmask);
       uint64_t d = ~0ull;
@@ -365,7 +396,6 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
             q_gap = 0;
           }
         }
-        const uint32_t ts_j = s_ts[j], te_j = s_te[j];
         const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
         if (a >= b) {
           r_gap = a - b;
@@ -379,14 +409,13 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         ok = ok && q_gap <= gap && r_gap <= gap;
         if (ok) d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
       }
-      const uint64_t vmask = __ballot(ok);
-      count += (uint32_t)__popcll(vmask);  // cannot exceed 2^32 - 1 here
+      count += (uint32_t)__popcll(__ballot(ok));  // cannot exceed 2^32 - 1 here
+      // ascending lane = ascending j: an entry goes after every entry with d' <= d (strict `<` finds the slot).  The ballot
+      // is taken again after every insertion: the list's last entry only falls, most lanes drop out at once.
       uint64_t cmask = __ballot(ok && d < sd3);
-      while (cmask) {  // ascending lane = ascending j: an entry goes after every entry with d' <= d (strict `<` finds the slot)
+      while (cmask) {
         const int l = __builtin_ctzll(cmask);
-        cmask &= cmask - 1;
         const uint64_t dl = readlane_u64(d, l);
-        if (dl >= sd3) continue;  // the list moved on since the ballot
         const uint32_t jl = j0 + (uint32_t)l;
         if (dl < sd0) {
           sd3 = sd2; sj3 = sj2; sd2 = sd1; sj2 = sj1; sd1 = sd0; sj1 = sj0; sd0 = dl; sj0 = jl;
@@ -397,6 +426,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         } else {
           sd3 = dl; sj3 = jl;
         }
+        cmask = __ballot(ok && d < sd3) & ~((2ull << l) - 1ull);  // lanes above l that still beat the list
       }
       if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
       if (can_cut && j0 + 64 < e && sd3 != ~0ull) {
@@ -1131,79 +1161,122 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
       return view_load(j);
     };
+    // What a batch needs from memory is requested one batch ahead (the walk of a range is one dependent chain per wavefront:
+    // what a batch waits for is what the range costs): the 64 positions that enter the ring, and the batch's own elements --
+    // their candidate lists (!FUSED) or their coordinates and group ends (FUSED).
+    struct Pre {
+      uint64_t view;
+      uint32_t q, t, e;  // ring refill
+      uint64_t bd[KC];
+      uint32_t bj[KC];
+      uint32_t nv;                    // lists
+      uint32_t qe, ts, te, minus, ei; // own element
+    };
+    auto prefetch = [&](uint32_t i0n, uint32_t base_n, bool refill) {
+      Pre P;
+      P.view = INF;
+      P.q = 0xffffffffu;
+      P.t = P.e = 0;
+      if (refill) {
+        const uint32_t pn = base_n + BIGW - 64 + lane;  // the positions that enter when the ring moves to base_n
+        if (pn < ue) {
+          P.view = view_load(pn);
+          P.q = s_qs[pn];
+          P.t = s_ts[pn];
+          P.e = s_te[pn];
+        }
+      }
+      const uint32_t i = i0n + lane;
+      const bool valid = i < be && i + 1 < ue;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        P.bd[c] = INF;
+        P.bj[c] = NONE;
+      }
+      P.nv = 0;
+      P.qe = P.ts = P.te = P.minus = 0;
+      P.ei = ue;
+      if (valid) {
+        if (!spec) {
+          const uint32_t g = s_gidx[i];
+          const uint32_t ge = (g + 1 < n_groups) ? group_begin[g + 1] : m;
+          if (ge < P.ei) P.ei = ge;
+        }
+        if (FUSED) {
+          P.qe = s_qe[i];
+          P.ts = s_ts[i];
+          P.te = s_te[i];
+          P.minus = (uint32_t)(s_grp[i] & 1ull);
+        } else {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {
+            P.bd[c] = c_d[(uint64_t)c * m + i];
+            P.bj[c] = c_j[(uint64_t)c * m + i];
+          }
+          P.nv = c_n[i];
+        }
+      }
+      return P;
+    };
+    Pre cur = prefetch(b, base, false);
+    bool far_dirty = false;  // a score beyond the ring was written during the batch: the prefetched refill may be stale
     for (uint32_t i0 = b; i0 < be && i0 + 1 < ue; i0 += 64) {
       if (i0 != b) {
         const uint32_t pn = base + BIGW + lane;
+        if (far_dirty && pn < ue) cur.view = view_load(pn);
+        far_dirty = false;
         __syncthreads();
-        {
-          const bool ok = pn < ue;
-          ring[pn % BIGW] = ok ? view_load(pn) : INF;
-          rq[pn % BIGW] = ok ? s_qs[pn] : 0xffffffffu;
-          rt[pn % BIGW] = ok ? s_ts[pn] : 0u;
-          re[pn % BIGW] = ok ? s_te[pn] : 0u;
-        }
+        ring[pn % BIGW] = cur.view;
+        rq[pn % BIGW] = cur.q;
+        rt[pn % BIGW] = cur.t;
+        re[pn % BIGW] = cur.e;
         base += 64;
         __syncthreads();
       }
+      const bool more = i0 + 64 < be && i0 + 65 < ue;
+      Pre nxt = cur;
+      if (more) nxt = prefetch(i0 + 64, base + 64, true);
       const uint32_t i = i0 + lane;
       const bool valid = i < be && i + 1 < ue;
       // ---- the lane's candidate list
       uint64_t bd[KC];
       uint32_t bj[KC];
-      uint32_t nv = 0;
+      uint32_t nv = cur.nv;
 #pragma unroll
       for (int c = 0; c < KC; ++c) {
-        bd[c] = INF;
-        bj[c] = NONE;
+        bd[c] = cur.bd[c];
+        bj[c] = cur.bj[c];
       }
-      uint64_t qe_i = 0, ts_i = 0, te_i = 0;
-      bool minus = false;
-      uint32_t e_i = ue;  // end of the element's (query, target, strand) group inside the range
-      if (valid) {
-        if (!spec) {
-          const uint32_t g = s_gidx[i];
-          const uint32_t ge = (g + 1 < n_groups) ? group_begin[g + 1] : m;
-          if (ge < e_i) e_i = ge;
-        }
-        if (FUSED) {
-          qe_i = s_qe[i];
-          ts_i = s_ts[i];
-          te_i = s_te[i];
-          minus = (s_grp[i] & 1ull) != 0;
-          const uint64_t bound = qe_i + max_gap;
-          for (uint32_t j = i + 1; j < e_i; ++j) {
-            const bool inr = j - base < (uint32_t)BIGW;
-            const uint64_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
-            if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
-            const uint64_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
-            uint64_t d;
-            if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) continue;
-            if (nv <= (uint32_t)KC) ++nv;
-            if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
-              uint64_t cd = d;
-              uint32_t cj = j;
-              bool placed = false;
+      const uint32_t e_i = cur.ei;  // end of the element's (query, target, strand) group inside the range
+      if (FUSED && valid) {
+        const uint64_t qe_i = cur.qe, ts_i = cur.ts, te_i = cur.te;
+        const bool minus = cur.minus != 0;
+        const uint64_t bound = qe_i + max_gap;
+        for (uint32_t j = i + 1; j < e_i; ++j) {
+          const bool inr = j - base < (uint32_t)BIGW;
+          const uint64_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
+          if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
+          const uint64_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
+          uint64_t d;
+          if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) continue;
+          if (nv <= (uint32_t)KC) ++nv;
+          if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
+            uint64_t cd = d;
+            uint32_t cj = j;
+            bool placed = false;
 #pragma unroll
-              for (int c = 0; c < KC; ++c) {
-                if (placed || cd < bd[c]) {
-                  placed = true;
-                  const uint64_t td = bd[c];
-                  const uint32_t tj = bj[c];
-                  bd[c] = cd;
-                  bj[c] = cj;
-                  cd = td;
-                  cj = tj;
-                }
+            for (int c = 0; c < KC; ++c) {
+              if (placed || cd < bd[c]) {
+                placed = true;
+                const uint64_t td = bd[c];
+                const uint32_t tj = bj[c];
+                bd[c] = cd;
+                bj[c] = cj;
+                cd = td;
+                cj = tj;
               }
             }
           }
-        } else {
-#pragma unroll
-          for (int c = 0; c < KC; ++c) {
-            bd[c] = c_d[(uint64_t)c * m + i];
-            bj[c] = c_j[(uint64_t)c * m + i];
-          }
-          nv = c_n[i];
         }
       }
       // ---- acc bits and the first acceptable candidate
@@ -1231,20 +1304,24 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       auto commit = [&](uint32_t upto) {  // lanes [committed, upto)
         const bool me = (uint32_t)lane >= committed && (uint32_t)lane < upto && fj != NONE;
         const bool inr = me && (fj - base < (uint32_t)BIGW);
-        if (me) {
-          if (inr)
-            atomicMin(&ring[fj % BIGW], (unsigned long long)fd);
-          else
-            atomicMin(view_ptr(fj), (unsigned long long)fd);
-        }
-        __threadfence();
+        // in the ring: LDS minimum, then the lane that finds its own distance there is the last acceptance
+        if (inr) atomicMin(&ring[fj % BIGW], (unsigned long long)fd);
         __syncthreads();
-        if (me) {
-          const uint64_t cur = inr ? (uint64_t)ring[fj % BIGW] : view_load(fj);
-          if (cur == fd) {  // the last acceptance: this lane is j's predecessor
-            ((spec && fj >= be) ? pred_prev : pred_own)[fj] = i;
-            if (inr && spec && fj >= be)  // the next block's input: must be in memory at the end of the round
-              __hip_atomic_store(&prev[fj], fd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (inr && (uint64_t)ring[fj % BIGW] == fd) {
+          ((spec && fj >= be) ? pred_prev : pred_own)[fj] = i;
+          if (spec && fj >= be)  // the next block's input: must be in memory at the end of the round
+            __hip_atomic_store(&prev[fj], fd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // beyond the ring (rare): one lane at a time in lane order, a returning atomic minimum at the memory side -- the lane
+        // that lowers the score is (so far) the last acceptance; no fence, no cache maintenance
+        uint64_t far = __ballot(me && !inr);
+        if (far) far_dirty = true;
+        while (far) {
+          const int l = __builtin_ctzll(far);
+          far &= far - 1;
+          if (lane == l) {
+            const unsigned long long old = atomicMin(view_ptr(fj), (unsigned long long)fd);
+            if (old > fd) ((spec && fj >= be) ? pred_prev : pred_own)[fj] = i;
           }
         }
         committed = upto;
@@ -1325,6 +1402,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         if (nj != NONE && nj != old_j) work |= __ballot(fj == nj) & ~lower & ~(1ull << l);  // higher lanes holding the new j
       }
       commit(64u);
+      cur = nxt;
     }
   }
 }

@@ -311,17 +311,21 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
                                                       const unsigned long long* __restrict__ h_sb, uint64_t min_len,
                                                       double min_ident, uint32_t* __restrict__ ok_head,
                                                       unsigned long long* __restrict__ n_heads) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  const bool head = p < m && is_head[p] != 0;
-  bool ok = false;
-  if (head) {
-    const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
-    ok = total_length >= min_len;
-    if (ok) ok = chain_weighted_identity(total_length, h_sm[p], h_sb[p]) >= min_ident;
+  uint32_t heads = 0;  // grid-stride: one atomic per wavefront of the whole launch, not per 64 elements
+  for (uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x; p < m; p += (uint64_t)gridDim.x * EW) {
+    const bool head = is_head[p] != 0;
+    bool ok = false;
+    if (head) {
+      const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
+      ok = total_length >= min_len;
+      if (ok) ok = chain_weighted_identity(total_length, h_sm[p], h_sb[p]) >= min_ident;
+      ++heads;
+    }
+    ok_head[p] = ok ? 1u : 0u;
   }
-  if (p < m) ok_head[p] = ok ? 1u : 0u;
-  const uint64_t hm = __ballot(head);
-  if ((threadIdx.x & 63) == 0 && hm) atomicAdd(n_heads, (unsigned long long)__popcll(hm));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
+  if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
 }
 
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
@@ -443,7 +447,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   uint32_t* ok_head = swg_alloc<uint32_t>(ctx, m);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
-  SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<nblk(m), EW, 0, st>>>(m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head,
+  SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16), EW, 0, st>>>(m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head,
                                                           reinterpret_cast<unsigned long long*>(d_tot + 1)));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, ok_head, cpos, m, d_tot));

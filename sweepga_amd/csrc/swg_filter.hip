@@ -375,6 +375,35 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
   return SWG_OK;
 }
 
+// bytes of the staging block swg_filter needs for n records over n_seq sequences (8 u32 columns + identity + strand +
+// status + chain + the two genome tables, every column rounded up to 256 bytes)
+static size_t io_block_bytes(uint64_t n, uint32_t n_seq) {
+  const size_t col4 = ((n * 4 + 255) & ~size_t(255)), col8 = ((n * 8 + 255) & ~size_t(255)),
+               col1 = ((n + 255) & ~size_t(255)), seqt = (((size_t)n_seq * 4 + 255) & ~size_t(255));
+  return col4 * 8 + col8 + col1 * 2 + seqt * 2 + col4;
+}
+static int io_block_reserve(swg_ctx* ctx, size_t total) {
+  if (ctx->io_cap >= total) return SWG_OK;
+  if (ctx->io_block) {
+    SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SWG_HIP(ctx, hipFree(ctx->io_block));
+    ctx->io_block = nullptr;
+    ctx->io_cap = 0;
+  }
+  void* p = nullptr;
+  size_t got = total + (total >> 3);  // a little headroom: the next file is rarely exactly this size
+  hipError_t e = hipMalloc(&p, got);
+  if (e != hipSuccess) {
+    got = total;
+    e = hipMalloc(&p, got);
+  }
+  if (e != hipSuccess)
+    return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu bytes for record staging failed: %s", total, hipGetErrorString(e));
+  ctx->io_block = static_cast<char*>(p);
+  ctx->io_cap = got;
+  return SWG_OK;
+}
+
 // Host buffers in / out: stage through device copies, then the device entry point.  The staging block lives in the
 // context (no allocation in steady state).  Only what the configuration reads crosses PCIe: `matches` and `strand` are
 // scaffold-stage inputs (src/paf_filter.rs:875-894, 761-770) and the chain ids are all zero without scaffolding
@@ -394,26 +423,7 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   const bool scaffold = cfg->scaffold_gap != 0;
   const size_t col4 = ((n * 4 + 255) & ~size_t(255)), col8 = ((n * 8 + 255) & ~size_t(255)),
                col1 = ((n + 255) & ~size_t(255)), seqt = (((size_t)rec->n_seq * 4 + 255) & ~size_t(255));
-  const size_t total = col4 * 8 + col8 + col1 * 2 + seqt * 2 + col4;
-  if (ctx->io_cap < total) {
-    if (ctx->io_block) {
-      SWG_HIP(ctx, hipStreamSynchronize(st));
-      SWG_HIP(ctx, hipFree(ctx->io_block));
-      ctx->io_block = nullptr;
-      ctx->io_cap = 0;
-    }
-    void* p = nullptr;
-    size_t got = total + (total >> 3);  // a little headroom: the next file is rarely exactly this size
-    hipError_t e = hipMalloc(&p, got);
-    if (e != hipSuccess) {
-      got = total;
-      e = hipMalloc(&p, got);
-    }
-    if (e != hipSuccess)
-      return swg_set_error(ctx, SWG_ERR_OOM, "hipMalloc of %zu bytes for record staging failed: %s", total, hipGetErrorString(e));
-    ctx->io_block = static_cast<char*>(p);
-    ctx->io_cap = got;
-  }
+  SWG_TRY(io_block_reserve(ctx, io_block_bytes(n, rec->n_seq)));
   char* blk = ctx->io_block;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -533,6 +543,66 @@ void swg_narrow_release(swg_ctx* ctx) {
     ctx->narrow_host = nullptr;
     ctx->narrow_cap = 0;
   }
+}
+
+// Everything a context's first swg_filter call would otherwise pay for inside the call: the scratch arena and the staging
+// block for `n_records_hint` records (hipMalloc), and the library's code objects on the device (the first launch from every
+// translation unit loads it) -- a 2,000-record filter call over a built-in record set, both flag families.  A host that
+// starts this on its own thread while it reads and parses its input (sweepga-gpu does) finds a warm context afterwards.
+extern "C" int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_hint, int with_scaffold) {
+  if (!ctx) return SWG_ERR_INVALID;
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_records_hint) {
+    size_t want = (size_t)n_records_hint * (with_scaffold ? 400 : 72) + (size_t(8) << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want + io_block_bytes(n_records_hint, n_seq_hint) > free_b / 2)
+      want = 0;  // not the kind of input to guess about: let the call size itself
+    if (want && ctx->arena_cap < want) SWG_TRY(swg_arena_reserve(ctx, want));
+    if (want) SWG_TRY(io_block_reserve(ctx, io_block_bytes(n_records_hint, n_seq_hint ? n_seq_hint : 1)));
+  }
+  const uint32_t n = 2000;
+  std::vector<uint32_t> q(n), t(n), qs(n), qe(n), ts(n), te(n), m(n), b(n), g(4);
+  std::vector<double> id(n);
+  std::vector<uint8_t> sd(n), status(n);
+  std::vector<uint32_t> chain(n);
+  uint64_t x = 0x9e3779b97f4a7c15ull;
+  for (uint32_t i = 0; i < n; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    q[i] = (uint32_t)(x & 1);
+    t[i] = 2 + (uint32_t)((x >> 1) & 1);
+    qs[i] = (uint32_t)((x >> 8) % 1000000);
+    const uint32_t len = 200 + (uint32_t)((x >> 32) % 5000);
+    qe[i] = qs[i] + len;
+    ts[i] = qs[i] + (uint32_t)((x >> 48) % 3000);
+    te[i] = ts[i] + len;
+    b[i] = len;
+    m[i] = len - len / 20;
+    id[i] = (double)m[i] / (double)b[i];
+    sd[i] = (uint8_t)((x >> 60) & 1);
+  }
+  for (uint32_t k = 0; k < 4; ++k) g[k] = k;
+  swg_records r{};
+  r.n = n;
+  r.q_id = q.data(); r.t_id = t.data(); r.q_start = qs.data(); r.q_end = qe.data(); r.t_start = ts.data(); r.t_end = te.data();
+  r.identity = id.data(); r.matches = m.data(); r.block_len = b.data(); r.strand = sd.data();
+  r.n_seq = 4; r.seq_genome_last = g.data(); r.n_genome_last = 4; r.seq_genome_two = g.data(); r.n_genome_two = 4;
+  swg_config c{};
+  c.mapping_filter_mode = SWG_MODE_ONE_TO_ONE;
+  c.scaffold_filter_mode = SWG_MODE_ONE_TO_ONE;
+  c.overlap_threshold = 0.95;
+  c.scaffold_overlap_threshold = 0.5;
+  c.scoring_function = 3;
+  c.scaffold_gap = with_scaffold ? 50000 : 0;
+  c.min_scaffold_length = 1000;
+  c.scaffold_max_deviation = with_scaffold ? 20000 : 0;
+  SWG_TRY(swg_filter(ctx, &r, &c, status.data(), chain.data(), nullptr));
+  if (with_scaffold) {  // the unlimited-sweep kernels of the default flags
+    c.mapping_filter_mode = SWG_MODE_MANY_TO_MANY;
+    c.scaffold_filter_mode = SWG_MODE_MANY_TO_MANY;
+    c.scaffold_max_deviation = 0;
+    SWG_TRY(swg_filter(ctx, &r, &c, status.data(), chain.data(), nullptr));
+  }
+  return SWG_OK;
 }
 
 // ---- plane_sweep_query / target / both on one segment of host arrays --------------------------------
