@@ -378,37 +378,25 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
           n_te = s_te[jn];
         }
       }
-      const bool inwin = j < e && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
+      const bool inwin = (j < e) & (qs_j <= bound);  // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
       const uint64_t wmask = __ballot(inwin);
       ext += (uint32_t)__popcll(wmask);
-      uint64_t d = ~0ull;
-      bool ok = false;
-      if (inwin) {
-        // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic
-        uint32_t q_gap, r_gap;
-        ok = true;
-        if (qs_j >= qe_i) {
-          q_gap = qs_j - qe_i;
-        } else {
-          q_gap = qe_i - qs_j;
-          if (q_gap > fifth) {
-            ok = wrap;
-            q_gap = 0;
-          }
-        }
-        const uint32_t a = minus ? ts_i : ts_j, b = minus ? te_j : te_i;  // gap = a - b, overlap = b - a
-        if (a >= b) {
-          r_gap = a - b;
-        } else {
-          r_gap = b - a;
-          if (r_gap > fifth) {
-            ok = ok && wrap;
-            r_gap = 0;
-          }
-        }
-        ok = ok && q_gap <= gap && r_gap <= gap;
-        if (ok) d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
-      }
+      // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic, branch-free (the kernel is bound by vector instructions: every
+      // lane evaluates every line, selects instead of divergent branches): a gap is the difference when it is one, the
+      // overlap when that is at most a fifth of the limit, and otherwise `limit + 1` = reject (which wraps to 0 in release
+      // Rust when the limit is u64::MAX)
+      const bool q_ge = qs_j >= qe_i;
+      const uint32_t q_ov = qe_i - qs_j;
+      const bool q_in = q_ge | (q_ov <= fifth);
+      const uint32_t q_gap = q_ge ? qs_j - qe_i : (q_in ? q_ov : 0u);
+      const uint32_t ra = minus ? ts_i : ts_j, rb = minus ? te_j : te_i;  // gap = ra - rb, overlap = rb - ra
+      const bool r_ge = ra >= rb;
+      const uint32_t r_ov = rb - ra;
+      const bool r_in = r_ge | (r_ov <= fifth);
+      const uint32_t r_gap = r_ge ? ra - rb : (r_in ? r_ov : 0u);
+      const bool ok = inwin & (q_in | wrap) & (r_in | wrap) & (q_gap <= gap) & (r_gap <= gap);
+      const uint64_t dd = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
+      const uint64_t d = ok ? dd : ~0ull;
       count += (uint32_t)__popcll(__ballot(ok));  // cannot exceed 2^32 - 1 here
       // ascending lane = ascending j: an entry goes after every entry with d' <= d (strict `<` finds the slot).  The ballot
       // is taken again after every insertion: the list's last entry only falls, most lanes drop out at once.
@@ -1129,7 +1117,8 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
                                                         uint64_t max_gap, const unsigned long long* __restrict__ c_d,
                                                         const uint32_t* __restrict__ c_j, const uint32_t* __restrict__ c_n,
                                                         int spec, unsigned long long* own, unsigned long long* prev,
-                                                        uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
+                                                        uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
+                                                        unsigned long long* __restrict__ wstats) {
   __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this range sees them
   __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end
   __shared__ uint32_t hcnt[WALK_HASH];
@@ -1300,6 +1289,10 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       __syncthreads();
       if (fj != NONE) *slot = 0;
       uint64_t work = __ballot(shared_j || (fj == NONE && nv > (uint32_t)KC));
+      if (wstats && lane == 0) {  // SWG_WALK_STATS: batches, lanes on the work list
+        atomicAdd(&wstats[0], 1ull);
+        atomicAdd(&wstats[1], (unsigned long long)__popcll(work));
+      }
       uint32_t committed = 0;  // lanes below this one are in the ring
       auto commit = [&](uint32_t upto) {  // lanes [committed, upto)
         const bool me = (uint32_t)lane >= committed && (uint32_t)lane < upto && fj != NONE;
@@ -1348,6 +1341,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           // every listed candidate is refused and the window held more: the whole window (paf_filter.rs:794-826), against
           // the scores as they stand after every lower lane
           commit((uint32_t)l);
+          if (wstats && lane == 0) atomicAdd(&wstats[2], 1ull);  // whole-window passes
           const uint32_t ii = i0 + l;
           const uint64_t qe_l = s_qe[ii], ts_l = s_ts[ii], te_l = s_te[ii];
           const bool minus_l = (s_grp[ii] & 1ull) != 0;
@@ -1356,6 +1350,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           uint64_t ld = INF;
           uint32_t lj2 = NONE;
           for (uint32_t j0 = ii + 1; j0 < e_l; j0 += 64) {
+            if (wstats && lane == 0) atomicAdd(&wstats[3], 1ull);  // their 64-element batches
             if (can_cut) {  // the batch starts past q_end[i] and its smallest query gap already reaches the best distance held
               const uint64_t wmin = wave_min_u64(ld);
               const uint64_t q0 = (j0 - base) < (uint32_t)BIGW ? (uint64_t)rq[j0 % BIGW] : (uint64_t)s_qs[j0];
@@ -1399,7 +1394,11 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           fd = nd;
           fj = nj;
         }
-        if (nj != NONE && nj != old_j) work |= __ballot(fj == nj) & ~lower & ~(1ull << l);  // higher lanes holding the new j
+        if (nj != NONE && nj != old_j) {
+          const uint64_t woken = __ballot(fj == nj) & ~lower & ~(1ull << l);  // higher lanes holding the new j
+          if (wstats && lane == 0) atomicAdd(&wstats[4], (unsigned long long)__popcll(woken & ~work));
+          work |= woken;
+        }
       }
       commit(64u);
       cur = nxt;
@@ -1672,6 +1671,13 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
               (unsigned long long)n_groups, (unsigned long long)n_units);
     if (!old_walk) {
       const bool lists_all = long_groups || force_deep;  // candidate lists for every element (wavefront per element)
+      static const bool want_wstats = getenv("SWG_WALK_STATS") != nullptr;  // diagnostic counters of the walk kernels
+      unsigned long long* wstats = nullptr;
+      if (want_wstats) {
+        wstats = swg_alloc<unsigned long long>(ctx, 16);
+        SWG_CHECK_ARENA(ctx);
+        SWG_HIP(ctx, hipMemsetAsync(wstats, 0, 16 * sizeof(unsigned long long), st));
+      }
       uint8_t* is_big = swg_alloc<uint8_t>(ctx, n_units);
       uint8_t* chunk_flag = swg_alloc<uint8_t>(ctx, n_units);
       uint64_t* d_nb = swg_alloc<uint64_t>(ctx, 2);
@@ -1720,11 +1726,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         if (lists_all)
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 0, bps, bps, pred, pred));
+                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 0, bps, bps, pred, pred, wstats));
         else
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, 0, bps, bps, pred, pred));
+                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, 0, bps, bps, pred, pred, wstats));
         SWG_KERNEL_CHECK(ctx);
       }
       if (n_big) {
@@ -1776,9 +1782,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_KERNEL_CHECK(ctx);
         const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
         // The ring is a cache (positions outside it are read from global memory), so its size only trades LDS hits for
-        // resident wavefronts.
+        // resident wavefronts -- and a block is one dependent chain, bound by latency, so residency wins: 256 slots when no
+        // window exceeds 511 elements, else 1024 (S-big1, windows up to 19,968: 12.4 ms with 4096 slots = one block per CU,
+        // 7.1 ms with 1024, 9.8 ms with 256).
         static const char* ring_knob = getenv("SWG_SPEC_RING");
-        const int ring = ring_knob ? atoi(ring_knob) : (s_max <= 512 ? 256 : s_max + 64 <= 1024 ? 1024 : 4096);
+        const int ring = ring_knob ? atoi(ring_knob) : (s_max <= 512 ? 256 : 1024);
         int rounds = 0;
         for (uint64_t round = 0; round <= n_spec + 1; ++round) {
           SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
@@ -1787,7 +1795,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
 #define SWG_WALK_SPEC(W)                                                                                                          \
   SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, false><<<wblocks, 64, 0, st>>>(                                           \
                                          (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin, \
-                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 1, v_own, v_prev, p_own, p_prev))
+                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 1, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr))
           if (ring <= 256)
             SWG_WALK_SPEC(256);
           else if (ring <= 1024)
@@ -1809,6 +1817,14 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                   (unsigned long long)n_spec, (unsigned long long)s_max, rounds);
         SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, p_own, p_prev, pred));
         SWG_KERNEL_CHECK(ctx);
+      }
+      if (wstats) {
+        uint64_t hs[16];
+        SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(wstats), hs, 16));
+        for (int k = 0; k < 2; ++k)
+          fprintf(stderr, "[swg] walk%s: batches %llu, work-list lanes %llu (+%llu woken), whole-window passes %llu (%llu batches)\n",
+                  k ? " (speculative blocks)" : " (chunks)", (unsigned long long)hs[8 * k], (unsigned long long)hs[8 * k + 1],
+                  (unsigned long long)hs[8 * k + 4], (unsigned long long)hs[8 * k + 2], (unsigned long long)hs[8 * k + 3]);
       }
     } else {
     unsigned long long* c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
