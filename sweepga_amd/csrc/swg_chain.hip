@@ -108,6 +108,50 @@ __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t*
   head_flag[p] = head ? 1u : 0u;
 }
 
+// Both gathers in one pass when every record of sort A is a member of the chaining (the mapping-level sweep removed
+// nothing: the CLI defaults): positions coincide, nothing is compacted, and the two boundary flags -- (query, target) pair
+// heads in the high word, (query, target, strand) group heads in the low word -- go through ONE u64 sum scan.
+__global__ __launch_bounds__(EW) void gather_all_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
+                                                        const uint32_t* __restrict__ idxA,
+                                                        const uint32_t* __restrict__ q_end,
+                                                        const uint32_t* __restrict__ t_start,
+                                                        const uint32_t* __restrict__ t_end,
+                                                        const uint32_t* __restrict__ matches,
+                                                        const uint32_t* __restrict__ block_len, int pos_bits,
+                                                        uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
+                                                        uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
+                                                        uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
+                                                        uint64_t* __restrict__ s_grp, uint64_t* __restrict__ flags) {
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint64_t k = keyA[a];
+  const uint32_t i = idxA[a];
+  s_qs[a] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
+  s_qe[a] = q_end[i];
+  s_ts[a] = t_start[i];
+  s_te[a] = t_end[i];
+  s_m[a] = matches[i];
+  s_b[a] = block_len[i];
+  const uint64_t g = k >> pos_bits;
+  s_grp[a] = g;
+  const uint64_t gp = a ? keyA[a - 1] >> pos_bits : ~0ull;
+  flags[a] = ((uint64_t)((gp >> 1) != (g >> 1)) << 32) | (uint64_t)(gp != g);
+}
+// after the inclusive sum scan of those flags: dense pair and group ids, group begins
+__global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64_t* __restrict__ incl,
+                                                        uint32_t* __restrict__ a_dpair, uint32_t* __restrict__ s_gidx,
+                                                        uint32_t* __restrict__ head_flag, uint32_t* __restrict__ group_begin) {
+  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint64_t v = incl[a];
+  const uint32_t g = (uint32_t)v - 1;
+  a_dpair[a] = (uint32_t)(v >> 32) - 1;
+  s_gidx[a] = g;
+  const bool head = a == 0 || (uint32_t)incl[a - 1] != (uint32_t)v;
+  head_flag[a] = head ? 1u : 0u;
+  if (head) group_begin[g] = (uint32_t)a;
+}
+
 __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
                                                           const uint32_t* __restrict__ gidx_excl,
                                                           uint32_t* __restrict__ s_gidx,
@@ -133,7 +177,6 @@ __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint
 //                      candidates are blocked AND the window held more than KC valid j is the window
 //                      re-evaluated in full (wave-parallel, global memory).
 constexpr int KC = 4;
-constexpr uint32_t BIG_UNIT = 2048;  // units at least this long take the block-speculative path (spec_round_kernel)
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
@@ -486,13 +529,6 @@ struct SelBlock {
 // LANE (chain_select_lanes_kernel); the longest (>= BIG_UNIT) are cut into blocks that run speculatively in parallel
 // (spec_round_kernel); the middle ones get one wavefront each (chain_select_kernel), which keeps the scores of the
 // next 128 elements in registers.
-
-struct SpecBlock {
-  uint32_t ue;  // end of the unit
-  uint32_t bb;  // block begin
-  uint32_t be;  // block end
-  uint32_t pad;
-};
 
 // best_pred_score[j] of an element beyond the 128 the wavefront keeps in registers; out of line for the same reason as
 // spec_view_far (an inlined load would make every step of the walk wait for the stores of the step before)
@@ -1102,7 +1138,6 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
 // ~CHUNK elements) need nothing from outside: the candidate lists are built by the lanes themselves from the LDS ring
 // (FUSED: no candidate arrays in HBM at all).  Blocks of long units run speculatively (see above spec_plan_kernel), lists
 // from the candidate kernels.
-constexpr uint32_t WALK_CHUNK = 1024;
 constexpr int WALK_HASH = 256;
 
 template <int BIGW, bool FUSED>
@@ -1125,6 +1160,9 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
   const int lane = threadIdx.x;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
+  const uint32_t gap32 = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;  // coordinates are u32: a larger limit cannot bind
+  const uint32_t fifth32 = fifth > 0xffffffffull ? 0xffffffffu : (uint32_t)fifth;
+  const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
   for (int k = lane; k < WALK_HASH; k += 64) hcnt[k] = 0;
   __syncthreads();
@@ -1238,16 +1276,27 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       }
       const uint32_t e_i = cur.ei;  // end of the element's (query, target, strand) group inside the range
       if (FUSED && valid) {
-        const uint64_t qe_i = cur.qe, ts_i = cur.ts, te_i = cur.te;
+        // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic, selects instead of branches (as in chain_candidates_wave_kernel)
+        const uint32_t qe_i = cur.qe, ts_i = cur.ts, te_i = cur.te;
         const bool minus = cur.minus != 0;
-        const uint64_t bound = qe_i + max_gap;
+        const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
+        const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
         for (uint32_t j = i + 1; j < e_i; ++j) {
           const bool inr = j - base < (uint32_t)BIGW;
-          const uint64_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
+          const uint32_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
           if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
-          const uint64_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
-          uint64_t d;
-          if (!chain_dist(minus, qe_i, ts_i, te_i, qs_j, ts_j, te_j, max_gap, fifth, &d)) continue;
+          const uint32_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
+          const bool q_ge = qs_j >= qe_i;
+          const uint32_t q_ov = qe_i - qs_j;
+          const bool q_in = q_ge | (q_ov <= fifth32);
+          const uint32_t q_gap = q_ge ? qs_j - qe_i : (q_in ? q_ov : 0u);
+          const uint32_t ra = minus ? ts_i : ts_j, rb = minus ? te_j : te_i;
+          const bool r_ge = ra >= rb;
+          const uint32_t r_ov = rb - ra;
+          const bool r_in = r_ge | (r_ov <= fifth32);
+          const uint32_t r_gap = r_ge ? ra - rb : (r_in ? r_ov : 0u);
+          if (!((q_in | wrap) & (r_in | wrap) & (q_gap <= gap32) & (r_gap <= gap32))) continue;
+          const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
           if (nv <= (uint32_t)KC) ++nv;
           if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
             uint64_t cd = d;
@@ -1567,65 +1616,113 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
   } else {
-    SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
+    if (M == n) {  // every record is alive: the compacted list is the identity
+      SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA));
+      SWG_KERNEL_CHECK(ctx);
+    } else {
+      SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
+    }
     SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
                                                                 r->n_seq, pos_bits, B.keyA));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
   }
-  SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
-                                                        pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, pair_excl, M, d_tot + 1));
-  SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
-  SWG_KERNEL_CHECK(ctx);
-  // ---- survivors in A order
-  swg_flag_scan keep_scan;
-  SWG_TRY(swg_flags_count(ctx, a_keep, M, &keep_scan, d_tot + 2));
-  uint64_t h3[3];
-  SWG_TRY(swg_read_scalars(ctx, d_tot, h3, 3));
-  B.n_pairs = h3[1];
-  const uint64_t m = h3[2];
-  B.m = m;
+  const bool all_members = member == alive;  // the mapping-level sweep removed nothing (the caller passes the same array)
+  uint64_t m = 0, n_groups = 0;
+  uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
+  uint64_t* s_grp = nullptr;
+  uint32_t *head_flag = nullptr, *s_gidx = nullptr, *group_begin = nullptr;
+  unsigned long long* bps = nullptr;
+  uint32_t* pred = nullptr;
   B.T.nc = 0;
-  if (m == 0) return SWG_OK;
-  if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
-  B.s_a = swg_alloc<uint32_t>(ctx, m);
-  B.s_idx = swg_alloc<uint32_t>(ctx, m);
-  B.s_chain = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_qs = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_qe = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_ts = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_te = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_m = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_b = swg_alloc<uint32_t>(ctx, m);
-  uint64_t* s_grp = swg_alloc<uint64_t>(ctx, m);
-  uint32_t* head_flag = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* gidx_excl = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* s_gidx = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* group_begin = swg_alloc<uint32_t>(ctx, m);
-  unsigned long long* bps = swg_alloc<unsigned long long>(ctx, m);
-  uint32_t* pred = swg_alloc<uint32_t>(ctx, m);
-  SWG_CHECK_ARENA(ctx);
-  SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
-  if (m == M) {  // every record of sort A is a member: s_a is the identity
+  if (all_members) {
+    m = M;
+    B.m = m;
+    if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
+    B.s_a = nullptr;  // positions coincide (nullptr = identity)
+    B.s_idx = B.idxA;
+    B.s_chain = swg_alloc<uint32_t>(ctx, m);
+    s_qs = swg_alloc<uint32_t>(ctx, m);
     s_qe = B.a_qe;
     s_ts = B.a_ts;
     s_te = B.a_te;
-    B.s_idx = B.idxA;
-    SWG_LAUNCH(ctx, "gatherS", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
-                                                              s_m, s_b, s_grp, head_flag));
+    s_m = swg_alloc<uint32_t>(ctx, m);
+    s_b = swg_alloc<uint32_t>(ctx, m);
+    s_grp = swg_alloc<uint64_t>(ctx, m);
+    head_flag = swg_alloc<uint32_t>(ctx, m);
+    s_gidx = swg_alloc<uint32_t>(ctx, m);
+    group_begin = swg_alloc<uint32_t>(ctx, m);
+    bps = swg_alloc<unsigned long long>(ctx, m);
+    pred = swg_alloc<uint32_t>(ctx, m);
+    uint64_t* flags64 = swg_alloc<uint64_t>(ctx, m);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
+                                                               r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
+                                                               flags64));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_inclusive_sum_scan_u64(ctx, flags64, flags64, M));
+    SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, flags64, B.a_dpair, s_gidx, head_flag, group_begin));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t tot = 0;
+    SWG_TRY(swg_read_scalars(ctx, flags64 + (M - 1), &tot, 1));
+    B.n_pairs = tot >> 32;
+    n_groups = tot & 0xffffffffull;
   } else {
-    SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
-                                                          r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
-                                                          B.s_idx, s_grp, head_flag));
+    SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
+                                                          pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, pair_excl, M, d_tot + 1));
+    SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
+    SWG_KERNEL_CHECK(ctx);
+    // ---- survivors in A order
+    swg_flag_scan keep_scan;
+    SWG_TRY(swg_flags_count(ctx, a_keep, M, &keep_scan, d_tot + 2));
+    uint64_t h3[3];
+    SWG_TRY(swg_read_scalars(ctx, d_tot, h3, 3));
+    B.n_pairs = h3[1];
+    m = h3[2];
+    B.m = m;
+    if (m == 0) return SWG_OK;
+    if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
+    B.s_a = swg_alloc<uint32_t>(ctx, m);
+    B.s_idx = swg_alloc<uint32_t>(ctx, m);
+    B.s_chain = swg_alloc<uint32_t>(ctx, m);
+    s_qs = swg_alloc<uint32_t>(ctx, m);
+    s_qe = swg_alloc<uint32_t>(ctx, m);
+    s_ts = swg_alloc<uint32_t>(ctx, m);
+    s_te = swg_alloc<uint32_t>(ctx, m);
+    s_m = swg_alloc<uint32_t>(ctx, m);
+    s_b = swg_alloc<uint32_t>(ctx, m);
+    s_grp = swg_alloc<uint64_t>(ctx, m);
+    head_flag = swg_alloc<uint32_t>(ctx, m);
+    uint32_t* gidx_excl = swg_alloc<uint32_t>(ctx, m);
+    s_gidx = swg_alloc<uint32_t>(ctx, m);
+    group_begin = swg_alloc<uint32_t>(ctx, m);
+    bps = swg_alloc<unsigned long long>(ctx, m);
+    pred = swg_alloc<uint32_t>(ctx, m);
+    SWG_CHECK_ARENA(ctx);
+    if (m == M)
+      B.s_a = nullptr;  // every record of sort A is a member: positions coincide (nullptr = identity)
+    else
+      SWG_TRY(swg_flags_compact(ctx, keep_scan, B.s_a));
+    if (m == M) {
+      s_qe = B.a_qe;
+      s_ts = B.a_ts;
+      s_te = B.a_te;
+      B.s_idx = B.idxA;
+      SWG_LAUNCH(ctx, "gatherS", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
+                                                                s_m, s_b, s_grp, head_flag));
+    } else {
+      SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
+                                                            r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                            B.s_idx, s_grp, head_flag));
+    }
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, head_flag, gidx_excl, m, d_tot + 3));
+    SWG_LAUNCH(ctx, "group_bounds", group_bounds_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, gidx_excl, s_gidx, group_begin));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_read_scalars(ctx, d_tot + 3, &n_groups, 1));
   }
-  SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, head_flag, gidx_excl, m, d_tot + 3));
-  SWG_LAUNCH(ctx, "group_bounds", group_bounds_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, gidx_excl, s_gidx, group_begin));
-  SWG_KERNEL_CHECK(ctx);
-  uint64_t n_groups = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot + 3, &n_groups, 1));
   // ---- best-buddy chaining
   SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(bps), ~0ull));
   SWG_KERNEL_CHECK(ctx);
@@ -1694,6 +1791,13 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       const uint64_t n_big = h2[0], n_chunks = h2[1];
       unsigned long long* c_d = nullptr;
       uint32_t *c_j = nullptr, *c_n = nullptr, *c_ext = nullptr;
+      uint8_t* big_member = nullptr;  // members of long units (also what the chain table's generic path is restricted to)
+      if (n_big) {
+        big_member = swg_alloc<uint8_t>(ctx, m);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member));
+        SWG_KERNEL_CHECK(ctx);
+      }
       if (lists_all || n_big) {
         c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
         c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
@@ -1704,10 +1808,6 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
                                                        m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
         } else {
-          uint8_t* big_member = swg_alloc<uint8_t>(ctx, m);
-          SWG_CHECK_ARENA(ctx);
-          SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member));
-          SWG_KERNEL_CHECK(ctx);
           SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
                                                                                   s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, big_member));
         }
@@ -1722,6 +1822,9 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_LAUNCH(ctx, "chunk_desc", chunk_desc_kernel<<<nblk(n_chunks), EW, 0, st>>>((uint32_t)n_chunks, chunk_unit, (uint32_t)n_units, unit_begin,
                                                                           is_big, (uint32_t)m, cdesc));
         SWG_KERNEL_CHECK(ctx);
+        work->chunks = cdesc;
+        work->n_chunks = n_chunks;
+        work->big_member = big_member;
         const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * 64 ? n_chunks : (uint64_t)ctx->num_cu * 64;
         if (lists_all)
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false><<<(unsigned)wb, 64, 0, st>>>(

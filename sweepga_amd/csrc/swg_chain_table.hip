@@ -35,7 +35,7 @@ __global__ __launch_bounds__(EW) void group_first_from_scan_kernel(uint64_t m, c
 // jumping below only has to connect chains across ranges.
 constexpr int HEAD_SPAN = 1024;
 __global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
-                                                       uint32_t* __restrict__ hd) {
+                                                       uint32_t* __restrict__ hd, const uint8_t* __restrict__ only) {
   __shared__ uint32_t l[HEAD_SPAN];
   const uint64_t base = (uint64_t)blockIdx.x * HEAD_SPAN;
   for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
@@ -52,13 +52,15 @@ __global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_
       if (hh == h) break;
       h = hh;
     }
-    hd[p] = h;
+    if (!only || only[p]) hd[p] = h;
   }
 }
 // hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
-__global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed) {
+__global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed,
+                                                       const uint8_t* __restrict__ only) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
+  if (only && !only[p]) return;
   const uint32_t h = hd[p];
   const uint32_t hh = hd[h];
   if (hh != h) {
@@ -80,9 +82,14 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
                                                                   uint32_t* __restrict__ h_te,
                                                                   unsigned long long* __restrict__ h_sm,
                                                                   unsigned long long* __restrict__ h_sb,
-                                                                  uint32_t* __restrict__ is_head) {
+                                                                  uint32_t* __restrict__ is_head,
+                                                                  const uint8_t* __restrict__ only) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
+  if (only && !only[p]) {
+    is_head[p] = 0;  // short units: labelled, aggregated and filtered by chain_label_kernel
+    return;
+  }
   is_head[p] = hd[p] == p ? 1u : 0u;
   h_qe[p] = s_qe[p];
   h_ts[p] = s_ts[p];
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
                                                              uint32_t* __restrict__ h_qe, uint32_t* __restrict__ h_ts,
                                                              uint32_t* __restrict__ h_te,
                                                              unsigned long long* __restrict__ h_sm,
-                                                             unsigned long long* __restrict__ h_sb) {
+                                                             unsigned long long* __restrict__ h_sb,
+                                                             const uint8_t* __restrict__ only) {
   __shared__ uint32_t l_qe[AGG_SPAN], l_ts[AGG_SPAN], l_te[AGG_SPAN], l_cnt[AGG_SPAN];
   __shared__ unsigned long long l_sm[AGG_SPAN], l_sb[AGG_SPAN];
   const uint64_t base = (uint64_t)blockIdx.x * AGG_SPAN;
@@ -120,6 +128,7 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
   for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
     const uint64_t p = base + k;
     if (p >= m) break;
+    if (only && !only[p]) continue;
     const uint32_t h = hd[p];
     if (h == p) continue;
     if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
@@ -233,6 +242,20 @@ __global__ __launch_bounds__(EW) void genome_pair_first_kernel(uint64_t n, const
   }
 }
 
+// The same from the groups' own first records (valid when every alive record is a member of some group's chains, i.e. the
+// mapping-level sweep removed nothing): one atomic per (query, target, strand) group instead of a pass over the records.
+__global__ __launch_bounds__(EW) void genome_pair_first_groups_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
+                                                                      const uint32_t* __restrict__ s_idx,
+                                                                      const uint32_t* __restrict__ group_first,
+                                                                      const uint32_t* __restrict__ q_id,
+                                                                      const uint32_t* __restrict__ t_id,
+                                                                      const uint32_t* __restrict__ seq_genome, PairTable table) {
+  uint32_t g = blockIdx.x * EW + threadIdx.x;
+  if (g >= n_groups) return;
+  const uint32_t i = s_idx[group_begin[g]];  // any record of the group names its sequences
+  atomicMin(pair_slot(table, seq_genome[q_id[i]], seq_genome[t_id[i]]), group_first[g]);
+}
+
 // all_chains order = (q,t,strand) groups by first appearance, chains of a group by head position.  Chains in
 // head-position order are already contiguous per group, so only the GROUPS are sorted; a chain's place is its
 // group's base plus its rank inside the group.
@@ -310,19 +333,94 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
                                                       const unsigned long long* __restrict__ h_sm,
                                                       const unsigned long long* __restrict__ h_sb, uint64_t min_len,
                                                       double min_ident, uint32_t* __restrict__ ok_head,
-                                                      unsigned long long* __restrict__ n_heads) {
-  uint32_t heads = 0;  // grid-stride: one atomic per wavefront of the whole launch, not per 64 elements
+                                                      double* __restrict__ h_wid, const uint8_t* __restrict__ only) {
   for (uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x; p < m; p += (uint64_t)gridDim.x * EW) {
-    const bool head = is_head[p] != 0;
+    if (only && !only[p]) continue;  // short units: chain_label_kernel wrote their flags
     bool ok = false;
-    if (head) {
+    if (is_head[p] != 0) {
       const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
       ok = total_length >= min_len;
-      if (ok) ok = chain_weighted_identity(total_length, h_sm[p], h_sb[p]) >= min_ident;
-      ++heads;
+      if (ok) {
+        const double wid = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
+        ok = wid >= min_ident;
+        if (ok) h_wid[p] = wid;
+      }
     }
     ok_head[p] = ok ? 1u : 0u;
   }
+}
+
+// Chains of the short units, chunk by chunk (one work-group per chunk of whole units, swg_chain.hip): a chain never leaves
+// its unit, so everything about it is inside the chunk.  Chains are simple paths -- every element proposes to at most one
+// successor and has at most one predecessor -- so with the successor links in LDS every HEAD walks its own chain and folds
+// its members' values in registers: no seeding pass over all elements, no atomics, no pointer-jumping rounds, and the span /
+// identity filter (paf_filter.rs:449-455) is decided right there; only passing heads write aggregates.
+constexpr int LABEL_CAP = (int)(WALK_CHUNK + BIG_UNIT);  // a chunk holds fewer elements than this
+__global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, const SpecBlock* __restrict__ chunks,
+                                                         const uint32_t* __restrict__ pred,
+                                                         const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
+                                                         const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te,
+                                                         const uint32_t* __restrict__ s_m, const uint32_t* __restrict__ s_b,
+                                                         uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
+                                                         uint32_t* __restrict__ ok_head, uint32_t* __restrict__ h_qe,
+                                                         uint32_t* __restrict__ h_ts, uint32_t* __restrict__ h_te,
+                                                         double* __restrict__ h_wid) {
+  __shared__ uint16_t succ[LABEL_CAP];
+  constexpr uint16_t NO = 0xffffu;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const uint32_t b = chunks[c].bb, e = chunks[c].be;
+    const uint32_t len = e > b ? e - b : 0;  // 0: a long unit's place holder
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < len; k += EW) succ[k] = NO;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < len; k += EW) {
+      const uint32_t pr = pred[b + k];
+      if (pr != NONE) succ[pr - b] = (uint16_t)k;  // one successor per element: no two writers
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < len; k += EW) {
+      const uint32_t p = b + k;
+      if (pred[p] != NONE) {  // a member: its head writes its label
+        ok_head[p] = 0;
+        continue;
+      }
+      // a head: walk the chain
+      hd[p] = p;
+      uint32_t qe = s_qe[p], ts = s_ts[p], te = s_te[p];
+      uint64_t sm = s_m[p], sb = s_b[p];
+      for (uint16_t nx = succ[k]; nx != NO;) {
+        const uint32_t q = b + nx;
+        const uint16_t nn = succ[nx];  // requested together with the member's values
+        const uint32_t a = s_qe[q], t0 = s_ts[q], t1 = s_te[q], mm = s_m[q], bb = s_b[q];
+        hd[q] = p;
+        qe = a > qe ? a : qe;
+        ts = t0 < ts ? t0 : ts;
+        te = t1 > te ? t1 : te;
+        sm += mm;
+        sb += bb;
+        nx = nn;
+      }
+      const uint64_t total_length = (uint64_t)qe - (uint64_t)s_qs[p];  // q_max - q_min (the head has the smallest q_start)
+      bool ok = total_length >= min_len;
+      if (ok) {
+        const double wid = chain_weighted_identity(total_length, sm, sb);
+        ok = wid >= min_ident;
+        if (ok) {
+          h_qe[p] = qe;
+          h_ts[p] = ts;
+          h_te[p] = te;
+          h_wid[p] = wid;
+        }
+      }
+      ok_head[p] = ok ? 1u : 0u;
+    }
+  }
+}
+// number of chains = members without a predecessor
+__global__ __launch_bounds__(EW) void count_heads_kernel(uint64_t m, const uint32_t* __restrict__ pred,
+                                                         unsigned long long* __restrict__ n_heads) {
+  uint32_t heads = 0;
+  for (uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x; p < m; p += (uint64_t)gridDim.x * EW) heads += pred[p] == NONE;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
   if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
@@ -332,8 +430,8 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
 __global__ __launch_bounds__(EW) void chain_columns_kernel(
     uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
     const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
-    const uint32_t* __restrict__ h_te, const unsigned long long* __restrict__ h_sm,
-    const unsigned long long* __restrict__ h_sb, const uint64_t* __restrict__ s_grp, const uint32_t* __restrict__ s_a,
+    const uint32_t* __restrict__ h_te, const double* __restrict__ h_wid, const uint64_t* __restrict__ s_grp,
+    const uint32_t* __restrict__ s_a,
     const uint32_t* __restrict__ a_dpair, uint32_t n_seq,
     uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
     uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
@@ -354,9 +452,8 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
   C_qe[c2] = qe;
   C_ts[c2] = ts;
   C_te[c2] = te;
-  C_dpair[c2] = a_dpair[s_a[p]];
-  const uint64_t total_length = (uint64_t)qe - (uint64_t)qs;  // q_max - q_min
-  C_wid[c2] = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
+  C_dpair[c2] = a_dpair[s_a ? s_a[p] : p];  // s_a == nullptr: every record of sort A is a member
+  C_wid[c2] = h_wid[p];
 }
 
 __global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
@@ -365,9 +462,7 @@ __global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const ui
                                                             const uint32_t* __restrict__ rank_of_poschain,
                                                             uint32_t* __restrict__ s_chain) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t h = hd[p];
-  s_chain[p] = ok_head[h] ? rank_of_poschain[cpos_excl[h]] : NONE;
+  if (p < m) s_chain[p] = chain_of_member(p, hd, ok_head, cpos_excl, rank_of_poschain);
 }
 
 }  // namespace
@@ -423,33 +518,50 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
-  // ---- labelling by pointer jumping
-  SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd));
-  SWG_KERNEL_CHECK(ctx);
-  for (int round = 0; round < 64; ++round) {
-    SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
-    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed));
-    SWG_KERNEL_CHECK(ctx);
-    uint64_t ch = 0;
-    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
-    if ((uint32_t)ch == 0) break;
-  }
-  // ---- aggregates
-  SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
-                                                                                  h_te, h_sm, h_sb, is_head));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te,
-                                                                        h_sm, h_sb));
-  SWG_KERNEL_CHECK(ctx);
-  // span / identity filter at the heads; from here on "chain" means a chain that passes it
+  double* h_wid = swg_alloc<double>(ctx, m);
   uint32_t* ok_head = swg_alloc<uint32_t>(ctx, m);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
-  SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16), EW, 0, st>>>(m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head,
-                                                          reinterpret_cast<unsigned long long*>(d_tot + 1)));
+  SWG_LAUNCH(ctx, "count_heads", count_heads_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 8 ? nblk(m) : (uint64_t)ctx->num_cu * 8), EW, 0, st>>>(
+                                     m, pred, reinterpret_cast<unsigned long long*>(d_tot + 1)));
   SWG_KERNEL_CHECK(ctx);
+  // ---- short units: labels, aggregates and the span / identity filter chunk by chunk
+  const uint8_t* only = nullptr;  // what the generic path below is restricted to (nullptr: everything)
+  bool generic = true;
+  if (W.n_chunks) {
+    const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
+    SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
+                                                                        s_m, s_b, min_len, min_ident, hd, ok_head, h_qe, h_ts,
+                                                                        h_te, h_wid));
+    SWG_KERNEL_CHECK(ctx);
+    only = W.big_member;
+    generic = only != nullptr;  // long units exist
+  }
+  if (generic) {
+    // ---- long units (or everything, without a chunk list): labelling by pointer jumping, aggregates by atomics at the head
+    SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd, only));
+    SWG_KERNEL_CHECK(ctx);
+    for (int round = 0; round < 64; ++round) {
+      SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
+      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed, only));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed, only));
+      SWG_KERNEL_CHECK(ctx);
+      uint64_t ch = 0;
+      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
+      if ((uint32_t)ch == 0) break;
+    }
+    SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
+                                                                                    h_te, h_sm, h_sb, is_head, only));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(
+                                           m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te, h_sm, h_sb, only));
+    SWG_KERNEL_CHECK(ctx);
+    // span / identity filter at the heads; from here on "chain" means a chain that passes it
+    SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16), EW, 0, st>>>(
+                                    m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head, h_wid, only));
+    SWG_KERNEL_CHECK(ctx);
+  }
   SWG_TRY(swg_exclusive_scan_u32(ctx, ok_head, cpos, m, d_tot));
   uint64_t h2[2];
   SWG_TRY(swg_read_scalars(ctx, d_tot, h2, 2));
@@ -478,8 +590,15 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
                                                                                B.s_idx, group_first));
   }
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
-                                                                                    r->seq_genome_last, gp_first));
+  if (B.m == B.M) {
+    // members == alive records: a genome pair's first record is the smallest of its (query, target, strand) groups' firsts
+    SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_groups_kernel<<<nblk(n_groups), EW, 0, st>>>(
+                                             (uint32_t)n_groups, group_begin, B.s_idx, group_first, r->q_id, r->t_id,
+                                             r->seq_genome_last, gp_first));
+  } else {
+    SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_kernel<<<ctx->num_cu * 8, EW, 0, st>>>(n, alive, r->q_id, r->t_id,
+                                                                                      r->seq_genome_last, gp_first));
+  }
   SWG_KERNEL_CHECK(ctx);
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
@@ -520,11 +639,17 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, ok_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
-                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, B.s_a, B.a_dpair,
+                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_wid, s_grp, B.s_a, B.a_dpair,
                                        r->n_seq, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, B.C_strand, B.C_dpair, rank_of));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, cpos, rank_of, B.s_chain));
-  SWG_KERNEL_CHECK(ctx);
+  B.m_hd = hd;
+  B.m_ok_head = ok_head;
+  B.m_cpos = cpos;
+  B.m_rank_of = rank_of;
+  if (B.want_s_chain) {
+    SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, cpos, rank_of, B.s_chain));
+    SWG_KERNEL_CHECK(ctx);
+  }
   return SWG_OK;
 }
 

@@ -213,17 +213,22 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
   SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, scalars));
-  uint64_t h[2];
-  SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 2));
+  uint64_t h[3];
+  SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 3));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
   if (stats) stats->n_retained = h[1];
+  // Both limits infinite and no retained record of zero length: the mapping-level sweep keeps exactly the retained
+  // records (every interval with start < end survives an unlimited sweep, plane_sweep_exact.rs:219-228), so it is not run
+  // and the scaffold stage is told that members == retained records (same array).
+  const bool sweep_is_identity = kq0 == SWG_K_INF && kt0 == SWG_K_INF && h[2] == 0;
+  if (sweep_is_identity) keep1 = alive;
 
   // with scaffolding on, the query axis' sorted order is kept: sort A of the chaining is the same order refined by
   // (target sequence, strand)
   uint32_t* q_order = cfg->scaffold_gap != 0 ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   int q_order_valid = 0;
-  SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid));
+  if (!sweep_is_identity) SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(keep1) | reinterpret_cast<uintptr_t>(status_out) | reinterpret_cast<uintptr_t>(chain_out);
@@ -231,10 +236,10 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
                                                                                             (ptrs & 15) == 0));
     SWG_KERNEL_CHECK(ctx);
     if (stats) {
-      SWG_LAUNCH(ctx, "count_nonzero", count_nonzero_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, keep1, scalars + 2));
+      SWG_LAUNCH(ctx, "count_nonzero", count_nonzero_kernel<<<ctx->num_cu * 4, EW, 0, st>>>(n, keep1, scalars + 3));
       SWG_KERNEL_CHECK(ctx);
       uint64_t c;
-      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars + 2), &c, 1));
+      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars + 3), &c, 1));
       stats->n_swept = stats->n_out = c;
     }
     return SWG_OK;

@@ -149,6 +149,13 @@ int swg_inclusive_sum_scan_u64(swg_ctx* ctx, const uint64_t* in, uint64_t* out, 
 // its own pass over the keys.
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                          uint64_t n, int begin_bit, int end_bit, uint32_t* prehist = nullptr);
+// The same sort over the key bits [0, key_bits) with 8-byte elements after the first pass: pass 1 reads the (key, value)
+// pairs and writes packed words ((key >> 8) << val_bits) | value; the later passes move 16 bytes per element instead of 24.
+// Needs key_bits - 8 + val_bits <= 64 and every value < 2^val_bits.  `keys` (n u64) is overwritten, `scratch` is n u64 of
+// scratch; *packed_out is whichever of the two holds the sorted packed words.  Returns SWG_ERR_UNSUPPORTED when the shape
+// does not qualify (the caller then uses swg_radix_sort_pairs).
+int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
+                          int val_bits, uint32_t* prehist, uint64_t** packed_out);
 constexpr int SWG_RADIX_BINS = 256;
 constexpr int SWG_RADIX_MAX_PASSES = 8;
 #ifdef __HIPCC__
@@ -213,11 +220,14 @@ __device__ __forceinline__ uint32_t swg_xcd_block(uint32_t bid, uint32_t nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// Score key and both end coordinates of a record in one 16-byte slot: the sweep's post-sort gather then costs one
-// random sector per begin instead of two.
-struct __attribute__((aligned(16))) swg_key_ends {
+// Score key and the four coordinates of a record in one 32-byte slot = one memory sector: the sweep's post-sort gather
+// costs one random sector per begin, and the begins can be sorted as packed 8-byte words (the low 8 bits of the start,
+// which the packed word drops after the first pass, come back from here).
+struct __attribute__((aligned(32))) swg_key_ends {
   uint64_t key;
-  uint32_t end[2];  // [0] query end, [1] target end
+  uint32_t start[2];  // [0] query start, [1] target start
+  uint32_t end[2];    // [0] query end, [1] target end
+  uint32_t pad[2];
 };
 
 struct swg_axis_input {

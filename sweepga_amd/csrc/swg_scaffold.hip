@@ -14,13 +14,16 @@ namespace {
 // anchor_num[i] = chain number of the kept chain record i belongs to (0 = not an anchor);
 // in_filtered[i] = 1 iff i is a member of a span/identity-filtered chain (pre_sweep_scaffold_members)
 __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint32_t* __restrict__ s_idx,
-                                                          const uint32_t* __restrict__ s_chain,
+                                                          const uint32_t* __restrict__ hd,
+                                                          const uint32_t* __restrict__ ok_head,
+                                                          const uint32_t* __restrict__ cpos,
+                                                          const uint32_t* __restrict__ rank_of,
                                                           const uint32_t* __restrict__ C_num,
                                                           uint32_t* __restrict__ anchor_num,
                                                           uint8_t* __restrict__ in_filtered) {
   uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
-  const uint32_t c = s_chain[p];
+  const uint32_t c = chain_of_member(p, hd, ok_head, cpos, rank_of);
   if (c == NONE) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
   const uint32_t i = s_idx[p];
   anchor_num[i] = C_num[c];
@@ -287,6 +290,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
   SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, n * sizeof(uint32_t), st));
   ChainBuild B;
+  B.want_s_chain = false;  // member_marks derives a member's chain from the labelling arrays
   SWG_TRY(build_chains(ctx, r, alive, keep1, cfg->scaffold_gap, cfg->min_scaffold_length, cfg->min_scaffold_identity,
                        pos_bits, true, &B, q_order));
   if (stats) {
@@ -309,7 +313,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   if (stats) stats->n_chains_kept = n_kept;
   SWG_HIP(ctx, hipMemsetAsync(anchor_num, 0, n * sizeof(uint32_t), st));
   SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
-  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.s_chain, C_num, anchor_num, in_filtered));
+  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.m_hd, B.m_ok_head, B.m_cpos, B.m_rank_of, C_num, anchor_num, in_filtered));
   SWG_KERNEL_CHECK(ctx);
 
   auto finish_counts = [&]() -> int {

@@ -86,6 +86,9 @@ struct ChainBuild {
   uint32_t* s_a = nullptr;      // A position
   uint32_t* s_idx = nullptr;    // original index
   uint32_t* s_chain = nullptr;  // index into T of the member's chain, NONE when that chain fails the span / identity filter
+                                //   (only materialised when want_s_chain; otherwise chain_of_member() derives it)
+  bool want_s_chain = true;
+  const uint32_t *m_hd = nullptr, *m_ok_head = nullptr, *m_cpos = nullptr, *m_rank_of = nullptr;  // per member / per chain
   // chains that pass the span / identity filter (paf_filter.rs:449-455), in all_chains order: only these reach the scaffold
   // sweep, the numbering, the anchors; the others exist as a count
   uint64_t n_chains_all = 0;
@@ -93,6 +96,27 @@ struct ChainBuild {
   uint8_t* C_strand = nullptr;
   uint32_t* C_dpair = nullptr;
 };
+
+// A range of consecutive members walked by one wavefront (swg_chain.hip): a chunk of whole short units (ue == be) or one
+// block of a long unit (ue = end of the unit).
+struct SpecBlock {
+  uint32_t ue;  // end of the unit
+  uint32_t bb;  // block begin
+  uint32_t be;  // block end
+  uint32_t pad;
+};
+constexpr uint32_t WALK_CHUNK = 1024;  // a chunk = the units that begin in one WALK_CHUNK-element cell ...
+constexpr uint32_t BIG_UNIT = 8192;    // ... all shorter than this (longer units take the block-speculative path)
+
+#ifdef __HIPCC__
+// index into T of member p's chain (NONE: its chain fails the span / identity filter), from the labelling arrays
+__device__ __forceinline__ uint32_t chain_of_member(uint64_t p, const uint32_t* __restrict__ hd,
+                                                    const uint32_t* __restrict__ ok_head, const uint32_t* __restrict__ cpos,
+                                                    const uint32_t* __restrict__ rank_of) {
+  const uint32_t h = hd[p];
+  return ok_head[h] ? rank_of[cpos[h]] : 0xffffffffu;
+}
+#endif
 
 // What the predecessor selection (swg_chain.hip) hands to the chain table (swg_chain_table.hip): the members of sort A in
 // A order (`s_*`, m entries), their (query, target, strand) groups, and pred[p] = best-buddy predecessor of p (NONE = head).
@@ -105,6 +129,11 @@ struct ChainWork {
   uint32_t* group_begin = nullptr;  // [n_groups]
   uint32_t* pred = nullptr;
   uint64_t* d_tot = nullptr;        // 4 device scalars
+  // chunks of whole short units (chains never leave a unit, so a chunk's chains are complete inside it); the members of
+  // long units are flagged in big_member (nullptr: there are none).  n_chunks == 0: no chunk list (the round-2 selection).
+  const SpecBlock* chunks = nullptr;
+  uint64_t n_chunks = 0;
+  const uint8_t* big_member = nullptr;
 };
 
 // merge_mappings_into_chains (paf_filter.rs:750-933) in two halves:

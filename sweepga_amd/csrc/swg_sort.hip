@@ -596,6 +596,144 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
   }
 }
 
+// The same pass over 8-byte packed words.  FIRST: the input is still the (key, value) pair, the digit is the key's lowest
+// one, and what is written is ((key >> 8) << val_bits) | value; later passes read and write packed words, the digit of pass
+// p sits at bit val_bits + 8 (p - 1).  One LDS staging round instead of two, 16 (20 for the first) bytes per element.
+template <typename ST, bool FIRST>
+__global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64_t* __restrict__ in,
+                                                                     const uint32_t* __restrict__ vals_in,
+                                                                     uint64_t* __restrict__ out, uint64_t n, int shift,
+                                                                     uint32_t mask, int val_bits,
+                                                                     const uint32_t* __restrict__ gbase, ST* status,
+                                                                     uint32_t* ticket) {
+  __shared__ uint64_t lkeys[OS_TILE];
+  __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
+  __shared__ uint32_t tile_excl[RS_RADIX];
+  __shared__ uint32_t dst_base[RS_RADIX];
+  __shared__ uint32_t lds_wave[OS_THREADS / 64];
+  __shared__ uint32_t lds_prev[OS_THREADS];
+  __shared__ uint32_t s_tile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t tile_base = (uint64_t)tile * OS_TILE;
+  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint64_t key[OS_ITEMS];  // the word that is written
+  uint32_t dig[OS_ITEMS];
+  uint32_t rank[OS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    if (FIRST) {
+      const uint64_t k = i < n ? in[i] : ~0ull;
+      const uint32_t v = i < n ? vals_in[i] : 0u;
+      dig[r] = (uint32_t)k & mask;  // shift = 0
+      key[r] = ((k >> 8) << val_bits) | v;
+    } else {
+      key[r] = i < n ? in[i] : ~0ull;
+      dig[r] = (uint32_t)(key[r] >> shift) & mask;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t d = dig[r];
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t prev = 0;
+    int leader = 0;
+    if (valid) {
+      leader = __builtin_ctzll(peers);
+      if (lane == leader) {
+        prev = cnt[wave][d];
+        cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+      }
+    }
+    prev = __shfl(prev, leader, 64);
+    rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
+  }
+  __syncthreads();
+  {
+    uint32_t c[OS_WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < OS_WAVES; ++w) {
+      c[w] = cnt[w][tid];
+      cnt[w][tid] = tot;  // exclusive over waves
+      tot += c[w];
+    }
+    uint32_t block_total;
+    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
+    tile_excl[tid] = ex;
+    using W = os_word<ST>;
+    ST excl = 0;
+    ST* my = status + (size_t)tile * RS_RADIX + tid;
+    if (tile == 0) {
+      __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my, W::LOCAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t tt = tile - 1;
+      while (true) {
+        const ST sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const ST f = sv & ~W::MASK;
+        if (f == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += sv & W::MASK;
+        if (f == W::GLOBAL) break;
+        --tt;
+      }
+      __hip_atomic_store(my, W::GLOBAL | (excl + (ST)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    dst_base[tid] = gbase[tid] + (uint32_t)excl - ex;
+  }
+  __syncthreads();
+  // reorder in LDS; the digit travels with the word (for FIRST it is no longer part of it): kept in the staging word's place
+  // by staging (digit, word) as two arrays would cost LDS, so the position's digit is recovered from the tile's digit
+  // boundaries instead: position p belongs to digit d iff tile_excl[d] <= p < tile_excl[d + 1]
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    const uint32_t d = dig[r];
+    const uint32_t pos = tile_excl[d] + cnt[wave][d] + rank[r];
+    if (i < n) lkeys[pos] = key[r];
+  }
+  __syncthreads();
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; ++r) {
+    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    if (p < tile_n) {
+      const uint64_t k = lkeys[p];
+      uint32_t d;
+      if (FIRST) {  // binary search over the 256 digit boundaries of the tile (tile_excl is ascending)
+        uint32_t lo = 0, hi = RS_RADIX - 1;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (tile_excl[mid] <= p)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+        d = lo;
+      } else {
+        d = (uint32_t)(k >> shift) & mask;
+      }
+      out[dst_base[d] + p] = k;
+    }
+  }
+}
+
 // Fallback (n >= 2^30): histogram / scan / scatter per pass.
 int radix_sort_three_kernel(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                             uint64_t n, int begin_bit, int end_bit) {
@@ -678,6 +816,54 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     *vals = *vals_alt;
     *vals_alt = tv;
   }
+  swg_arena_restore(ctx, mark);
+  return SWG_OK;
+}
+
+int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
+                          int val_bits, uint32_t* prehist, uint64_t** packed_out) {
+  static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
+  static const bool force_wide = getenv("SWG_SORT_WIDE") != nullptr;
+  static const bool no_packed = getenv("SWG_SORT_PAIRS") != nullptr;  // test knob: the 12-byte passes everywhere
+  const int npasses = (key_bits + 7) / 8;
+  if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || npasses < 2 || npasses > OS_MAX_PASSES ||
+      key_bits - 8 + val_bits > 64 || val_bits < 1 || val_bits > 32)
+    return SWG_ERR_UNSUPPORTED;
+  const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
+  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * RS_RADIX);
+  uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
+  if (!prehist) {
+    SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
+    uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
+    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(keys, n, 0, key_bits, npasses, ghist));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, RS_RADIX, 0, ctx->stream>>>(ghist));
+  SWG_KERNEL_CHECK(ctx);
+  uint64_t* src = keys;
+  uint64_t* dst = scratch;
+  for (int p = 0; p < npasses; ++p) {
+    const int kshift = 8 * p;
+    const int bits = key_bits - kshift < 8 ? key_bits - kshift : 8;
+    const uint32_t mask = (1u << bits) - 1u;
+    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * RS_RADIX, ctx->stream));
+    if (p == 0)
+      SWG_LAUNCH_N(ctx, "os_pass_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+                                             src, vals, dst, n, 0, mask, val_bits, ghist, status, tickets));
+    else
+      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+                                              src, nullptr, dst, n, val_bits + 8 * (p - 1), mask, val_bits,
+                                              ghist + (size_t)p * RS_RADIX, status, tickets + p));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
+  }
+  *packed_out = src;
   swg_arena_restore(ctx, mark);
   return SWG_OK;
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              int scoring, uint8_t* __restrict__ alive,
                                                              swg_key_ends* __restrict__ key_ends,
                                                              unsigned long long* __restrict__ scalars) {
-  uint32_t mx = 0, cnt = 0;
+  uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
     const double id = identity[i];
     const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
@@ -107,24 +107,30 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     if (key_ends) {  // nullptr: no mapping-level sweep will run (both limits infinite), nobody reads the scores
       swg_key_ends ke;
       ke.key = score_key_of(a, b, id, scoring);
+      ke.start[0] = a;
+      ke.start[1] = c;
       ke.end[0] = b;
       ke.end[1] = d;
+      ke.pad[0] = ke.pad[1] = 0;
       key_ends[i] = ke;
     }
     const uint32_t m1 = a > b ? a : b, m2 = c > d ? c : d;
     const uint32_t m = m1 > m2 ? m1 : m2;
     if (m > mx) mx = m;
     cnt += ok ? 1u : 0u;
+    zero += (ok && (a == b || c == d)) ? 1u : 0u;  // retained records of zero length on an axis (an unlimited sweep drops them)
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t t = __shfl_down(mx, o, 64);
     if (t > mx) mx = t;
     cnt += __shfl_down(cnt, o, 64);
+    zero += __shfl_down(zero, o, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     atomicMax(&scalars[0], (unsigned long long)mx);
     atomicAdd(&scalars[1], (unsigned long long)cnt);
+    if (zero) atomicAdd(&scalars[2], (unsigned long long)zero);
   }
 }
 
@@ -205,6 +211,40 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
     const bool next_same = p + 1 < n && (S[p + 1] >> pos_bits) == sg;
     if (!prev_same && !next_same) single[id] = 1;
   }
+  E[p] = e;
+  KEY[p] = k;
+  if ((p % TB) == 0) tile_x[p / TB] = s;
+}
+
+// The same after the packed sort (swg_radix_sort_packed): P[p] = ((X >> 8) << idx_bits) | record index.  The begin's full
+// key X (its low 8 bits are the low 8 bits of the start: pos_bits >= 8 here) and the index are written out for the routing
+// and tile kernels; start, end and score key come from the record's 32-byte slot, one sector.
+__global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_t n, const uint64_t* __restrict__ P, int idx_bits,
+                                                                         const swg_key_ends* __restrict__ packed, int axis,
+                                                                         int pos_bits, uint64_t* __restrict__ S,
+                                                                         uint32_t* __restrict__ I, uint64_t* __restrict__ E,
+                                                                         uint64_t* __restrict__ KEY,
+                                                                         uint64_t* __restrict__ tile_x,
+                                                                         uint8_t* __restrict__ single) {
+  uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW_THREADS + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t w = P[p];
+  const uint64_t hi = w >> idx_bits;  // X >> 8; 0 = a dead record (live keys are >= 2^pos_bits >= 256)
+  const uint32_t id = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
+  uint64_t s = 0, e = 0, k = 0;
+  if (hi != 0) {
+    const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
+    const swg_key_ends ke = packed[id];
+    s = (hi << 8) | (ke.start[axis] & 0xffu);
+    e = (s & ~posmask) | ke.end[axis];
+    k = ke.key;
+    const uint64_t sg = hi >> (pos_bits - 8);
+    const bool prev_same = p > 0 && ((P[p - 1] >> idx_bits) >> (pos_bits - 8)) == sg;
+    const bool next_same = p + 1 < n && ((P[p + 1] >> idx_bits) >> (pos_bits - 8)) == sg;
+    if (!prev_same && !next_same) single[id] = 1;
+  }
+  S[p] = s;
+  I[p] = id;
   E[p] = e;
   KEY[p] = k;
   if ((p % TB) == 0) tile_x[p / TB] = s;
@@ -1286,16 +1326,34 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
                                          key_bits, prehist));
     }
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits, prehist));
+    const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
+    uint64_t* P = nullptr;
+    int prc = SWG_ERR_UNSUPPORTED;
+    if (in.packed && in.pos_bits >= 8) prc = swg_radix_sort_packed(ctx, S, I, S2, n, key_bits, idx_bits, prehist, &P);
+    SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
+    if (prc == SWG_OK) {
+      // 8-byte passes after the first; the sorted packed words sit in S or S2, the other one and a third buffer take S and E
+      uint64_t* other = P == S ? S2 : S;
+      uint64_t* third = swg_alloc<uint64_t>(ctx, n);
+      SWG_CHECK_ARENA(ctx);
+      S = other;
+      E = third;
+      SWG_LAUNCH(ctx, "begin_gather", begin_gather_packed_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+                                          n, P, idx_bits, in.packed, in.packed_end, in.pos_bits, S, I, E, KEY, tile_x, single));
+      SWG_KERNEL_CHECK(ctx);
+    } else if (prc != SWG_ERR_UNSUPPORTED) {
+      return prc;
+    } else {
+      SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits, prehist));
+      E = S2;  // the sort's scratch key buffer is free again
+      SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+                                          n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_x, single));
+      SWG_KERNEL_CHECK(ctx);
+    }
     if (in.sorted_idx_out) {
       SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
       if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
     }
-    E = S2;  // the sort's scratch key buffer is free again
-    SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
-    SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                        n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_x, single));
-    SWG_KERNEL_CHECK(ctx);
     return SWG_OK;
   };
 
