@@ -12,6 +12,10 @@
 // admissible instance of the reference's behaviour.
 #include "sweepga_oracle.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -883,6 +887,14 @@ bool g_fast_inversion = false;
 // paf_filter.rs:379-747
 std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<RecordMeta> metadata) const {
   std::unordered_map<size_t, RecordMeta> result;
+  static const bool timing = getenv("ORC_TIMING") != nullptr;  // phase times on stderr (full-size runs)
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[oracle] %-28s %8.2f s\n", what, std::chrono::duration<double>(now - tprev).count());
+    tprev = now;
+  };
   // 1. retain :384-388 (NaN identity fails `>=`)
   {
     std::vector<RecordMeta> kept;
@@ -895,11 +907,13 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
   }
   const std::vector<RecordMeta> all_original = metadata;  // :391
   metadata = apply_plane_sweep_to_mappings(metadata);     // :400
+  lap("mapping plane sweep");
   if (config.scaffold_gap == 0) {                         // :409-434
     for (auto& m : metadata) result.emplace(m.rank, m);
     return result;
   }
   std::vector<MergedChain> merged = merge_mappings_into_chains(metadata, config.scaffold_gap);  // :441
+  lap("merge into chains");
   std::vector<MergedChain> filtered_chains;  // :449-455
   for (auto& c : merged)
     if (c.total_length >= config.min_scaffold_length &&
@@ -909,6 +923,7 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
   for (const auto& c : filtered_chains)
     for (size_t r : c.member_indices) pre_sweep_scaffold_members.insert(r);
   filtered_chains = apply_scaffold_plane_sweep(filtered_chains);  // :478
+  lap("scaffold plane sweep");
 
   std::unordered_map<size_t, const RecordMeta*> rank_to_meta;
   for (const auto& m : all_original) rank_to_meta[m.rank] = &m;
@@ -1052,6 +1067,7 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
       }
     }
   }
+  lap("anchors + inversion capture");
   // :601-604
   std::unordered_set<size_t> filtered_scaffold_members;
   for (size_t r : pre_sweep_scaffold_members)
@@ -1131,6 +1147,7 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
       }
     }
   }
+  lap("rescue + result");
   return result;
 }
 

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
                                                                    uint32_t* __restrict__ c_j, uint32_t* __restrict__ c_n,
                                                                    uint32_t* __restrict__ c_ext) {
   const int lane = threadIdx.x & 63;
-  const uint64_t wave = ((uint64_t)blockIdx.x * EW + threadIdx.x) >> 6;
+  // readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in all lanes of a wavefront, and would carry the
+  // whole loop nest below in divergent form (exec-mask bookkeeping on the scalar unit, loop counters in vector registers)
+  const uint64_t wave = (uint64_t)blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t gap = max_gap > 0xffffffffull ? 0xffffffffu : (uint32_t)max_gap;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const uint32_t fifth = (uint32_t)((max_gap / 5) > 0xffffffffull ? 0xffffffffull : (max_gap / 5));
@@ -409,7 +411,9 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         n_te = s_te[j];
       }
     }
-    for (uint32_t j0 = (uint32_t)p + 1; j0 < e; j0 += 64) {
+    // (loop control on values the compiler can see are wave-uniform -- readfirstlane -- so that it stays on the scalar unit
+    // without exec-mask bookkeeping: the kernel is bound by scalar instructions)
+    for (uint32_t j0 = (uint32_t)p + 1; j0 < e;) {
       const uint32_t j = j0 + lane;
       const uint32_t qs_j = n_qs, ts_j = n_ts, te_j = n_te;
       {
@@ -459,8 +463,8 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
         }
         cmask = __ballot(ok && d < sd3) & ~((2ull << l) - 1ull);  // lanes above l that still beat the list
       }
-      if (wmask != ~0ull) break;  // the window ended inside these 64 (or the group did)
-      if (can_cut && j0 + 64 < e && sd3 != ~0ull) {
+      int stop = (wmask != ~0ull) | (j0 + 64 >= e);  // the window ended inside these 64, or the group did
+      if (!stop && can_cut && sd3 != ~0ull) {
         // every later element starts at or after this batch's last one: its query gap is at least `qg`; with KC entries held
         // at distance <= qg^2 no later j can enter the list (d >= qg^2; equal distances keep the smaller j)
         const uint32_t q_last = readlane_u32(qs_j, 63);
@@ -469,10 +473,12 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
           if (sd3 <= qg * qg) {
             cut = true;
             cut_at = j0 + 64;
-            break;
+            stop = 1;
           }
         }
       }
+      if (__builtin_amdgcn_readfirstlane(stop)) break;
+      j0 += 64;
     }
     if (cut) {
       // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256) void chain_select_kernel(uint32_t n_list, cons
                                                            const uint32_t* __restrict__ group_begin, uint32_t n_groups,
                                                            unsigned long long* bps, uint32_t* __restrict__ pred) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint32_t wave_global = blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n_waves = (gridDim.x * 256) >> 6;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
@@ -1517,7 +1523,7 @@ __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const
                                                         const uint32_t* __restrict__ s_qe, uint64_t max_gap,
                                                         uint32_t* __restrict__ unit_flag) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t wave_global = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and visibly so
   const uint32_t n_waves = (gridDim.x * EW) >> 6;
   for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
     const uint32_t b = group_begin[g];

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(EW) void group_first_kernel(uint32_t n_groups, cons
                                                          uint32_t* __restrict__ group_first) {
   // one wavefront per (q,t,strand) group: members are contiguous in survivor order
   const int lane = threadIdx.x & 63;
-  const uint32_t wave_global = (blockIdx.x * EW + threadIdx.x) >> 6;
+  const uint32_t wave_global = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and visibly so
   const uint32_t n_waves = (gridDim.x * EW) >> 6;
   for (uint32_t g = wave_global; g < n_groups; g += n_waves) {
     const uint32_t b = group_begin[g];
