@@ -26,6 +26,38 @@ __global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32
   key[a] = (g << pos_bits) | q_start[i];
 }
 
+// The same for an ascending (or identity: a_idx == nullptr, then idx_out receives it) index list, with the digit histograms
+// of the sort that follows accumulated on the way (the sort then skips its own pass over the keys, as in the sweep's
+// begin_build).  Grid-stride over whole work-groups.
+__global__ __launch_bounds__(EW) void sortA_keys_hist_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
+                                                             uint32_t* __restrict__ idx_out,
+                                                             const uint32_t* __restrict__ q_id,
+                                                             const uint32_t* __restrict__ t_id,
+                                                             const uint8_t* __restrict__ strand,
+                                                             const uint32_t* __restrict__ q_start, uint32_t n_seq,
+                                                             int pos_bits, uint64_t* __restrict__ key, int key_bits,
+                                                             uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
+  const int npasses = (key_bits + 7) / 8;
+  for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t base = (uint64_t)blockIdx.x * EW; base < M; base += (uint64_t)gridDim.x * EW) {
+    const uint64_t a = base + threadIdx.x;
+    const bool in = a < M;
+    uint64_t k = 0;
+    if (in) {
+      const uint32_t i = a_idx ? a_idx[a] : (uint32_t)a;
+      const uint64_t g = ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
+      k = (g << pos_bits) | q_start[i];
+      key[a] = k;
+      if (idx_out) idx_out[a] = i;
+    }
+    swg_radix_hist_add(h, k, in, 0, key_bits, npasses);
+  }
+  __syncthreads();
+  swg_radix_hist_flush(h, npasses, ghist);
+}
+
 // After sort A: per A-position columns + pair boundaries.
 __global__ __launch_bounds__(EW) void gatherA_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
                                                      const uint32_t* __restrict__ idxA,
@@ -1522,6 +1554,8 @@ __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const
                                                         uint32_t m, const uint32_t* __restrict__ s_qs,
                                                         const uint32_t* __restrict__ s_qe, uint64_t max_gap,
                                                         uint32_t* __restrict__ unit_flag) {
+  // 256 elements per step: four consecutive elements per lane (their running maximum in registers), one wave scan over the
+  // lanes' totals, the carry from earlier steps on top
   const int lane = threadIdx.x & 63;
   const uint32_t wave_global = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform, and visibly so
   const uint32_t n_waves = (gridDim.x * EW) >> 6;
@@ -1529,21 +1563,37 @@ __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const
     const uint32_t b = group_begin[g];
     const uint32_t e = (g + 1 < n_groups) ? group_begin[g + 1] : m;
     uint32_t carry = 0;  // max q_end over [b, p0)
-    for (uint32_t p0 = b; p0 < e; p0 += 64) {
-      const uint32_t p = p0 + lane;
-      const uint32_t qe = p < e ? s_qe[p] : 0u;
-      uint32_t inc = qe;  // inclusive running max inside the stripe
+    for (uint32_t p0 = b; p0 < e; p0 += 256) {
+      const uint32_t p = p0 + (uint32_t)lane * 4;
+      uint32_t qe[4], qs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        qe[k] = p + k < e ? s_qe[p + k] : 0u;
+        qs[k] = p + k < e ? s_qs[p + k] : 0u;
+      }
+      // before[k] = max q_end over the lane's own elements before k
+      uint32_t own[4];
+      own[0] = 0;
+      own[1] = qe[0];
+      own[2] = qe[1] > own[1] ? qe[1] : own[1];
+      own[3] = qe[2] > own[2] ? qe[2] : own[2];
+      const uint32_t tot = qe[3] > own[3] ? qe[3] : own[3];
+      uint32_t inc = tot;  // inclusive running max over the lanes' totals
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(inc, d, 64);
         if (lane >= d && t > inc) inc = t;
       }
-      uint32_t before = __shfl_up(inc, 1, 64);  // max over earlier lanes of the stripe
+      uint32_t before = __shfl_up(inc, 1, 64);  // max over earlier lanes of the step
       if (lane == 0) before = 0;
       if (carry > before) before = carry;
-      uint64_t lim = (uint64_t)before + max_gap;
-      if (lim < max_gap) lim = ~0ull;  // saturate
-      if (p < e) unit_flag[p] = (p == b || (uint64_t)s_qs[p] > lim) ? 1u : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t bf = own[k] > before ? own[k] : before;
+        uint64_t lim = (uint64_t)bf + max_gap;
+        if (lim < max_gap) lim = ~0ull;  // saturate
+        if (p + k < e) unit_flag[p + k] = (p + k == b || (uint64_t)qs[k] > lim) ? 1u : 0u;
+      }
       const uint32_t last = __shfl(inc, 63, 64);
       if (last > carry) carry = last;
     }
@@ -1622,16 +1672,30 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
   } else {
-    if (M == n) {  // every record is alive: the compacted list is the identity
-      SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA));
+    if (M != n) SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));  // M == n: the list is the identity, written below
+    const int key_bits = pair_bits + pos_bits;
+    static const bool sort_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
+    if (key_bits <= 8 * SWG_RADIX_MAX_PASSES && !sort_fallback && M > 1 && M < (uint64_t(1) << 32)) {
+      // keys, (identity) indices and the sort's digit histograms in one pass
+      uint32_t* prehist = swg_alloc<uint32_t>(ctx, (size_t)SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS);
+      SWG_CHECK_ARENA(ctx);
+      SWG_HIP(ctx, hipMemsetAsync(prehist, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
+      const unsigned full = nblk(M), cap = (unsigned)ctx->num_cu * 16;
+      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
+                                        M, M == n ? nullptr : B.idxA, M == n ? B.idxA : nullptr, r->q_id, r->t_id, r->strand, r->q_start,
+                                        r->n_seq, pos_bits, B.keyA, key_bits, prehist));
       SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits, prehist));
     } else {
-      SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));
+      if (M == n) {
+        SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA));
+        SWG_KERNEL_CHECK(ctx);
+      }
+      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
+                                                                  r->n_seq, pos_bits, B.keyA));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits));
     }
-    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
-                                                                r->n_seq, pos_bits, B.keyA));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, pair_bits + pos_bits));
   }
   const bool all_members = member == alive;  // the mapping-level sweep removed nothing (the caller passes the same array)
   uint64_t m = 0, n_groups = 0;

@@ -436,12 +436,13 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
     uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
     uint32_t* __restrict__ C_qe, uint32_t* __restrict__ C_ts, uint32_t* __restrict__ C_te,
     double* __restrict__ C_wid, uint8_t* __restrict__ C_strand, uint32_t* __restrict__ C_dpair,
-    uint32_t* __restrict__ rank_of_poschain) {
+    uint32_t* __restrict__ rank_of_poschain, uint32_t* __restrict__ head_of_chain) {
   uint64_t c2 = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (c2 >= nc) return;
   const uint32_t c = order[c2];
   rank_of_poschain[c] = (uint32_t)c2;
   const uint32_t p = ch_head[c];
+  head_of_chain[c2] = p;
   const uint64_t g = s_grp[p];
   const uint64_t pair = g >> 1;
   const uint32_t qs = s_qs[p], qe = h_qe[p], ts = h_ts[p], te = h_te[p];
@@ -603,6 +604,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* head_of_chain = swg_alloc<uint32_t>(ctx, nc);
   uint64_t* g_key = swg_alloc<uint64_t>(ctx, n_groups);
   uint64_t* g_key_tmp = swg_alloc<uint64_t>(ctx, n_groups);
   uint32_t* g_sorted = swg_alloc<uint32_t>(ctx, n_groups);
@@ -640,8 +642,9 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
                                        nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_wid, s_grp, B.s_a, B.a_dpair,
-                                       r->n_seq, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, B.C_strand, B.C_dpair, rank_of));
+                                       r->n_seq, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, B.C_strand, B.C_dpair, rank_of, head_of_chain));
   SWG_KERNEL_CHECK(ctx);
+  B.m_head_of_chain = head_of_chain;
   B.m_hd = hd;
   B.m_ok_head = ok_head;
   B.m_cpos = cpos;

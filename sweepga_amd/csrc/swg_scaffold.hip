@@ -13,20 +13,25 @@ namespace {
 // ---- anchors, inversions, rescue -------------------------------------------------------------------------------------
 // anchor_num[i] = chain number of the kept chain record i belongs to (0 = not an anchor);
 // in_filtered[i] = 1 iff i is a member of a span/identity-filtered chain (pre_sweep_scaffold_members)
+// First the chain numbers go to the heads (one entry per kept chain), then every member reads its head's: one dependent
+// look-up per member instead of three (head -> position ordinal -> all_chains index -> number).
+__global__ __launch_bounds__(EW) void head_numbers_kernel(uint64_t nc, const uint32_t* __restrict__ head_of_chain,
+                                                          const uint32_t* __restrict__ C_num, uint32_t* __restrict__ head_num) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c < nc) head_num[head_of_chain[c]] = C_num[c];
+}
 __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint32_t* __restrict__ s_idx,
                                                           const uint32_t* __restrict__ hd,
                                                           const uint32_t* __restrict__ ok_head,
-                                                          const uint32_t* __restrict__ cpos,
-                                                          const uint32_t* __restrict__ rank_of,
-                                                          const uint32_t* __restrict__ C_num,
+                                                          const uint32_t* __restrict__ head_num,
                                                           uint32_t* __restrict__ anchor_num,
                                                           uint8_t* __restrict__ in_filtered) {
   uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
-  const uint32_t c = chain_of_member(p, hd, ok_head, cpos, rank_of);
-  if (c == NONE) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
+  const uint32_t h = hd[p];
+  if (!ok_head[h]) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
   const uint32_t i = s_idx[p];
-  anchor_num[i] = C_num[c];
+  anchor_num[i] = head_num[h];
   in_filtered[i] = 1;
 }
 
@@ -328,7 +333,11 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   if (stats) stats->n_chains_kept = n_kept;
   SWG_HIP(ctx, hipMemsetAsync(anchor_num, 0, n * sizeof(uint32_t), st));
   SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
-  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.m_hd, B.m_ok_head, B.m_cpos, B.m_rank_of, C_num, anchor_num, in_filtered));
+  uint32_t* head_num = swg_alloc<uint32_t>(ctx, m);  // valid at the heads of passing chains
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "head_numbers", head_numbers_kernel<<<nblk(nc), EW, 0, st>>>(nc, B.m_head_of_chain, C_num, head_num));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.m_hd, B.m_ok_head, head_num, anchor_num, in_filtered));
   SWG_KERNEL_CHECK(ctx);
 
   auto finish_counts = [&]() -> int {

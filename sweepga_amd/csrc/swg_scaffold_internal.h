@@ -89,6 +89,7 @@ struct ChainBuild {
                                 //   (only materialised when want_s_chain; otherwise chain_of_member() derives it)
   bool want_s_chain = true;
   const uint32_t *m_hd = nullptr, *m_ok_head = nullptr, *m_cpos = nullptr, *m_rank_of = nullptr;  // per member / per chain
+  const uint32_t* m_head_of_chain = nullptr;  // [T.nc] member position of the chain's head, in T order
   // chains that pass the span / identity filter (paf_filter.rs:449-455), in all_chains order: only these reach the scaffold
   // sweep, the numbering, the anchors; the others exist as a count
   uint64_t n_chains_all = 0;
