@@ -268,9 +268,11 @@ def end_to_end(n_lines, ref_lines, threads):
                 return {"error": r.stderr.strip()[-300:]}
             best = wall if best is None else min(best, wall)
         m = re.search(r"read ([\d.]+) ms \(load ([\d.]+), parse ([\d.]+)\), filter ([\d.]+) ms \(device ([\d.]+), h2d ([\d.]+), "
-                      r"d2h ([\d.]+)\), write ([\d.]+) ms", r.stderr)
-        phases = dict(zip(("read_ms", "load_ms", "parse_ms", "filter_ms", "device_ms", "h2d_ms", "d2h_ms", "write_ms"),
-                          map(float, m.groups()))) if m else None
+                      r"d2h ([\d.]+)\), write ([\d.]+) ms(?: \| device start-up ([\d.]+) ms beside the read \(create ([\d.]+), "
+                      r"warm-up ([\d.]+)\), ([\d.]+) ms waited for)?", r.stderr)
+        phases = {k: float(v) for k, v in zip(("read_ms", "load_ms", "parse_ms", "filter_ms", "device_ms", "h2d_ms", "d2h_ms", "write_ms",
+                                                "device_startup_ms", "create_ms", "warmup_ms", "startup_wait_ms"), m.groups())
+                  if v is not None} if m else None
         out = {"lines": n_lines, "input_bytes": size, "flags": "(defaults)", "host_threads": threads or os.cpu_count(),
                "wall_s": best, "value": n_lines / best, "unit": "mappings/s (process start to exit, page cache warm)",
                "phases": phases}

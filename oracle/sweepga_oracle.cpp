@@ -1091,6 +1091,12 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
       anchors_by_chr_pair[Key(all_original[idx].query_name, all_original[idx].target_name)]
           .push_back(idx);
   const uint64_t max_deviation = config.scaffold_max_deviation;
+  struct AnchorBuckets {
+    bool built = false;
+    uint64_t width = 1;
+    std::unordered_map<uint64_t, std::vector<size_t>> map;
+  };
+  std::map<Key, AnchorBuckets> anchor_buckets;  // indexed evaluation only (g_fast_inversion)
   for (auto& kv : mappings_by_chr_pair.items) {
     auto ait = anchors_by_chr_pair.find(kv.first);
     if (ait == anchors_by_chr_pair.end() || ait->second.empty()) continue;  // :658-660
@@ -1114,12 +1120,12 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
         uint64_t min_distance = UINT64_MAX;
         bool have_closest = false;
         size_t closest_anchor_rank = 0;
-        for (size_t aidx : chr_anchors) {
+        auto look_at = [&](size_t aidx) -> bool {  // the body of the reference's loop; true = stop (`break`)
           const RecordMeta& anchor = all_original[aidx];
           uint64_t aq = (anchor.query_start + anchor.query_end) / 2;
           int64_t dq = (int64_t)mq - (int64_t)aq;
           uint64_t q_diff = dq < 0 ? (uint64_t)0 - (uint64_t)dq : (uint64_t)dq;
-          if (q_diff > max_deviation) continue;
+          if (q_diff > max_deviation) return false;
           uint64_t at = (anchor.target_start + anchor.target_end) / 2;
           int64_t dt = (int64_t)mt - (int64_t)at;
           uint64_t t_diff = dt < 0 ? (uint64_t)0 - (uint64_t)dt : (uint64_t)dt;
@@ -1130,7 +1136,38 @@ std::unordered_map<size_t, RecordMeta> PafFilter::apply_filters(std::vector<Reco
             closest_anchor_rank = anchor.rank;
             have_closest = true;
           }
-          if (min_distance <= max_deviation) break;
+          return min_distance <= max_deviation;
+        };
+        if (!g_fast_inversion) {
+          for (size_t aidx : chr_anchors)
+            if (look_at(aidx)) break;
+        } else {
+          // NOT the reference's loop (same switch and same reason as step 4b above: mappings x anchors of a pair is 10^7 x
+          // 10^5 on BASELINE.json configs[2]).  The loop stops at the first anchor, in ascending input index, within the
+          // distance; anchors further than max_deviation in the query centre are skipped by the loop itself.  So: the pair's
+          // anchors are bucketed by query centre (bucket = max_deviation), the buckets the mapping's centre +- max_deviation
+          // touches are collected, and the same loop body runs over those anchors in ascending input index.  When no anchor
+          // is within the distance the loop's only other effect (min_distance, closest) is not observable.
+          auto& bk = anchor_buckets[kv.first];
+          if (!bk.built) {
+            bk.built = true;
+            bk.width = max_deviation ? max_deviation : 1;
+            for (size_t aidx : chr_anchors) {
+              const RecordMeta& a = all_original[aidx];
+              bk.map[((a.query_start + a.query_end) / 2) / bk.width].push_back(aidx);  // ascending aidx inside a bucket
+            }
+          }
+          std::vector<size_t> cand;
+          const uint64_t b_lo = (mq > max_deviation ? mq - max_deviation : 0) / bk.width;
+          const uint64_t b_hi = (mq > UINT64_MAX - max_deviation ? UINT64_MAX : mq + max_deviation) / bk.width;
+          for (uint64_t b = b_lo;; ++b) {
+            auto it = bk.map.find(b);
+            if (it != bk.map.end()) cand.insert(cand.end(), it->second.begin(), it->second.end());
+            if (b == b_hi) break;
+          }
+          std::sort(cand.begin(), cand.end());
+          for (size_t aidx : cand)
+            if (look_at(aidx)) break;
         }
         if (min_distance <= max_deviation) {
           RecordMeta rm = mapping;

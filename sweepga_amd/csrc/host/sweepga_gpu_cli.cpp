@@ -311,17 +311,22 @@ int main(int argc, char** argv) {
   std::vector<swg_ctx*> ctxs;
   int init_rc = SWG_OK;
   std::string init_err;
+  double create_ms = 0.0, warm_ms = 0.0;
   std::thread gpu_init([&] {
     if (no_filter) return;
     for (int d : devices) {
       swg_ctx* c = nullptr;
+      const auto c0 = std::chrono::steady_clock::now();
       init_rc = swg_create(d, &c);
+      create_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
       if (init_rc != SWG_OK) {
         init_err = swg_last_error(nullptr);  // thread-local: read it on this thread
         return;
       }
       ctxs.push_back(c);
+      const auto w0 = std::chrono::steady_clock::now();
       (void)swg_warmup(c, records_hint / devices.size(), 4096, cfg.scaffold_gap != 0);  // best effort: a failure shows up in the call
+      warm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
   });
 
@@ -359,6 +364,7 @@ int main(int argc, char** argv) {
 
   // ---- ANI pre-pass over the input when a threshold asks for it
   gpu_init.join();
+  const auto t1b = clk::now();  // what the device start-up took beyond the read
   if ((n || need_ani) && init_rc != SWG_OK) die(3, "no usable GPU: " + init_err);
   swg_ctx* ctx = ctxs.empty() ? nullptr : ctxs[0];
   double ani_percentile = -1.0, ani_ms = 0.0;
@@ -415,9 +421,9 @@ int main(int argc, char** argv) {
     swg_paf_timing(paf, &load_ms, &parse_ms);
     std::fprintf(stderr,
                  "[sweepga-gpu] %llu records -> %llu kept | read %.1f ms (load %.1f, parse %.1f), filter %.1f ms (device %.1f, h2d %.1f, "
-                 "d2h %.1f), write %.1f ms\n",
-                 (unsigned long long)n, (unsigned long long)kept, ms(t0, t1), load_ms, parse_ms, ms(t1, t2), st.device_ms, st.h2d_ms,
-                 st.d2h_ms, ms(t2, t3));
+                 "d2h %.1f), write %.1f ms | device start-up %.1f ms beside the read (create %.1f, warm-up %.1f), %.1f ms waited for\n",
+                 (unsigned long long)n, (unsigned long long)kept, ms(t0, t1), load_ms, parse_ms, ms(t1b, t2), st.device_ms, st.h2d_ms,
+                 st.d2h_ms, ms(t2, t3), create_ms + warm_ms, create_ms, warm_ms, ms(t1, t1b));
   }
   if (!quiet) {
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -1,5 +1,7 @@
 // The filter pipeline: PafFilter::apply_filters (src/paf_filter.rs:379-747) on the device, and
 // the host-array entry points of the C ABI.
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -11,6 +13,8 @@
 #include "host/rebase.h"
 
 namespace {
+
+constexpr size_t SWG_ARENA_B_SWEEP = 96, SWG_ARENA_B_SCAFFOLD = 336;  // scratch bytes per record reserved up front
 
 constexpr int EW = 256;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
@@ -310,10 +314,11 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
                              uint8_t* status_out, uint32_t* chain_out, swg_stats* stats) {
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
-  // Scratch high-water marks measured on the 10^8 workload: 58 B/record for the sweep-only pipeline, 252-370 B/record
-  // with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a context's first call.
+  // Scratch high-water marks measured on the 10^8 workload (round 3): 82 B/record for the sweep-only pipeline (32-byte record
+  // slots, packed sort), 215-304 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
+  // context's first call.
   {
-    size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? 72 : 400) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
+    size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
                   (rec64 ? (size_t)rec->n_seq * 8 : 0);
     if (cfg->scaffold_gap != 0) {
       // the scaffold stage keeps two genome-pair tables (first appearance of a pair under either prefix rule): dense
@@ -557,13 +562,19 @@ void swg_narrow_release(swg_ctx* ctx) {
 extern "C" int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_hint, int with_scaffold) {
   if (!ctx) return SWG_ERR_INVALID;
   SWG_HIP(ctx, hipSetDevice(ctx->device));
+  const bool dbg = getenv("SWG_DEBUG") != nullptr;
+  const auto w0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (dbg) fprintf(stderr, "[swg] warm-up: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+  };
   if (n_records_hint) {
-    size_t want = (size_t)n_records_hint * (with_scaffold ? 400 : 72) + (size_t(8) << 20);
+    size_t want = (size_t)n_records_hint * (with_scaffold ? SWG_ARENA_B_SCAFFOLD : SWG_ARENA_B_SWEEP) + (size_t(8) << 20);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want + io_block_bytes(n_records_hint, n_seq_hint) > free_b / 2)
       want = 0;  // not the kind of input to guess about: let the call size itself
     if (want && ctx->arena_cap < want) SWG_TRY(swg_arena_reserve(ctx, want));
     if (want) SWG_TRY(io_block_reserve(ctx, io_block_bytes(n_records_hint, n_seq_hint ? n_seq_hint : 1)));
+    lap("device memory reserved");
   }
   const uint32_t n = 2000;
   std::vector<uint32_t> q(n), t(n), qs(n), qe(n), ts(n), te(n), m(n), b(n), g(4);
@@ -601,12 +612,14 @@ extern "C" int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_
   c.min_scaffold_length = 1000;
   c.scaffold_max_deviation = with_scaffold ? 20000 : 0;
   SWG_TRY(swg_filter(ctx, &r, &c, status.data(), chain.data(), nullptr));
+  lap("first small call");
   if (with_scaffold) {  // the unlimited-sweep kernels of the default flags
     c.mapping_filter_mode = SWG_MODE_MANY_TO_MANY;
     c.scaffold_filter_mode = SWG_MODE_MANY_TO_MANY;
     c.scaffold_max_deviation = 0;
     SWG_TRY(swg_filter(ctx, &r, &c, status.data(), chain.data(), nullptr));
   }
+  lap("done");
   return SWG_OK;
 }
 

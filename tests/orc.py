@@ -6,7 +6,7 @@ from dataclasses import dataclass
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("SWG_ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")  # the override is for oracle development
 K_INF = 2**64 - 1
 
 IDENTITY, LENGTH, LENGTH_IDENTITY, LOG_LENGTH_IDENTITY, MATCHES = range(5)

@@ -1,5 +1,5 @@
-"""The oracle's indexed evaluation of step 4b (inversion capture, src/paf_filter.rs:535-597) against its literal
-chains x reverse-mappings loop.  The indexed form exists only so that BASELINE.json configs[2] (10^7 mappings in one
+"""The oracle's indexed evaluation of step 4b (inversion capture, src/paf_filter.rs:535-597) and of the rescue loop
+(:686-718) against its literal chains x reverse-mappings / mappings x anchors loops.  The indexed form exists only so that BASELINE.json configs[2] (10^7 mappings in one
 chromosome pair: 1.4 * 10^6 kept '+' chains x 10^6 '-' mappings) can be checked at full size (tools/sbig1_full_parity.py);
 every other parity test runs the literal loop."""
 import numpy as np
@@ -35,7 +35,7 @@ def test_indexed_inversion_capture_equals_the_literal_loop(seed):
                                  syntenic_frac=float(rng.choice([0.7, 0.98])))
         cfg = orc.Config(scaffold_gap=int(rng.choice([500, 10_000, 50_000, 10_000_000])),
                          min_scaffold_length=int(rng.choice([0, 1000, 10_000])),
-                         scaffold_max_deviation=int(rng.choice([0, 2000])),
+                         scaffold_max_deviation=int(rng.choice([0, 1, 300, 2000, 20_000, 5_000_000])),
                          mapping_filter_mode=int(rng.choice([orc.ONE_TO_ONE, orc.MANY_TO_MANY])),
                          scaffold_filter_mode=int(rng.choice([orc.ONE_TO_ONE, orc.MANY_TO_MANY])))
         (st_a, ch_a), (st_b, ch_b) = _both(cfg, rec)
@@ -53,3 +53,8 @@ def test_indexed_inversion_capture_on_a_deep_pair():
     (st_a, ch_a), (st_b, ch_b) = _both(orc.Config(), rec)
     assert np.array_equal(st_a, st_b) and np.array_equal(ch_a, ch_b)
     assert int((st_a != 0).sum()) > 1000
+    # the full flag set of BASELINE.json configs[4]: 1:1 sweeps and rescue (the indexed rescue loop)
+    cfg = orc.Config(mapping_filter_mode=orc.ONE_TO_ONE, scaffold_filter_mode=orc.ONE_TO_ONE, scaffold_max_deviation=20_000)
+    (st_a, ch_a), (st_b, ch_b) = _both(cfg, rec)
+    assert np.array_equal(st_a, st_b) and np.array_equal(ch_a, ch_b)
+    assert int((st_a == orc.RESCUED).sum()) > 100
