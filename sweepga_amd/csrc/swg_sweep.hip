@@ -187,23 +187,24 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
                                                                   const uint32_t* __restrict__ end,
                                                                   const uint64_t* __restrict__ score_key,
                                                                   const swg_key_ends* __restrict__ packed, int packed_end,
-                                                                  int pos_bits, uint64_t* __restrict__ E,
+                                                                  int pos_bits, uint32_t* __restrict__ E,
                                                                   uint64_t* __restrict__ KEY,
                                                                   uint64_t* __restrict__ tile_x,
                                                                   uint8_t* __restrict__ single) {
+  // E holds the END COORDINATE only (4 bytes): the composite end is the begin's segment part | end (swg_comp_end)
   uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW_THREADS + threadIdx.x;
   if (p >= n) return;
   const uint64_t s = S[p];
-  uint64_t e = 0, k = 0;
+  uint32_t e = 0;
+  uint64_t k = 0;
   if (s != 0) {
     const uint32_t id = I[p];
-    const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
     if (packed) {
       const swg_key_ends ke = packed[id];
-      e = (s & ~posmask) | ke.end[packed_end];
+      e = ke.end[packed_end];
       k = ke.key;
     } else {
-      e = (s & ~posmask) | end[id];
+      e = end[id];
       k = score_key ? score_key[id] : 0;  // no scores: the k = inf path only wants the `single` flags
     }
     const uint64_t sg = s >> pos_bits;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
 __global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_t n, const uint64_t* __restrict__ P, int idx_bits,
                                                                          const swg_key_ends* __restrict__ packed, int axis,
                                                                          int pos_bits, uint64_t* __restrict__ S,
-                                                                         uint32_t* __restrict__ I, uint64_t* __restrict__ E,
+                                                                         uint32_t* __restrict__ I, uint32_t* __restrict__ E,
                                                                          uint64_t* __restrict__ KEY,
                                                                          uint64_t* __restrict__ tile_x,
                                                                          uint8_t* __restrict__ single) {
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_
   const uint64_t w = P[p];
   const uint64_t hi = w >> idx_bits;  // X >> 8; 0 = a dead record (live keys are >= 2^pos_bits >= 256)
   const uint32_t id = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
-  uint64_t s = 0, e = 0, k = 0;
+  uint64_t s = 0, k = 0;
+  uint32_t e = 0;
   if (hi != 0) {
-    const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
     const swg_key_ends ke = packed[id];
     s = (hi << 8) | (ke.start[axis] & 0xffu);
-    e = (s & ~posmask) | ke.end[axis];
+    e = ke.end[axis];
     k = ke.key;
     const uint64_t sg = hi >> (pos_bits - 8);
     const bool prev_same = p > 0 && ((P[p - 1] >> idx_bits) >> (pos_bits - 8)) == sg;
@@ -248,6 +249,11 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_
   E[p] = e;
   KEY[p] = k;
   if ((p % TB) == 0) tile_x[p / TB] = s;
+}
+
+// composite end of a begin with composite start s (0 = dead) and end coordinate e
+__device__ __forceinline__ uint64_t swg_comp_end(uint64_t s, uint32_t e, int pos_bits) {
+  return s ? ((s >> pos_bits) << pos_bits) | e : 0ull;
 }
 
 // ---- routing: carry-ins and end points ----------------------------------------------------------
@@ -274,13 +280,13 @@ __device__ __forceinline__ uint32_t last_tile_below(const uint64_t* __restrict__
 }
 
 __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, const uint64_t* __restrict__ S,
-                                                                 const uint64_t* __restrict__ E,
+                                                                 const uint32_t* __restrict__ E, int pos_bits,
                                                                  const uint64_t* __restrict__ tile_x, uint32_t ntiles,
                                                                  uint32_t* __restrict__ te_out,
                                                                  uint32_t* __restrict__ carry_cnt) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
-  const uint64_t s = S[p], e = E[p];
+  const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits);
   const uint32_t tb = (uint32_t)(p / TB);
   uint32_t te = tb;
   if (s != 0 && e > s) {  // live and not zero-length
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, con
 }
 
 __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
-    uint64_t n, const uint64_t* __restrict__ S, const uint64_t* __restrict__ E, const uint64_t* __restrict__ KEY,
+    uint64_t n, const uint64_t* __restrict__ S, const uint32_t* __restrict__ E, int pos_bits, const uint64_t* __restrict__ KEY,
     const uint32_t* __restrict__ I, const uint32_t* __restrict__ te_in, const uint32_t* __restrict__ carry_off,
     uint32_t* __restrict__ carry_cur, uint64_t* __restrict__ c_s, uint64_t* __restrict__ c_e,
     uint64_t* __restrict__ c_key, uint32_t* __restrict__ c_id) {
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
   const uint32_t te = te_in[p];
   const uint32_t tb = (uint32_t)(p / TB);
   if (te <= tb) return;
-  const uint64_t s = S[p], e = E[p], k = KEY[p];
+  const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits), k = KEY[p];
   const uint32_t id = I[p];
   for (uint32_t b = tb + 1; b <= te; ++b) {
     const uint32_t slot = carry_off[b] + atomicAdd(&carry_cur[b], 1u);
@@ -315,7 +321,8 @@ __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
 struct TileArgs {
   uint64_t n;
   const uint64_t* S;    // sorted begin keys
-  const uint64_t* E;    // composite ends
+  const uint32_t* E;    // end coordinates (composite end = swg_comp_end)
+  int pos_bits;
   const uint64_t* KEY;  // score keys
   const uint32_t* I;    // interval ids
   const uint64_t* tile_x;
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   uint32_t ID = 0;
   if (valid) {
     X = a.S[p];
-    EE = a.E[p];
+    EE = swg_comp_end(X, a.E[p], a.pos_bits);
     KEY = a.KEY[p];
     ID = a.I[p];
   }
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kn_kernel(TileArgs a) {
   uint32_t ID = 0;
   if (valid) {
     X = a.S[p];
-    EE = a.E[p];
+    EE = swg_comp_end(X, a.E[p], a.pos_bits);
     KEY = a.KEY[p];
     ID = a.I[p];
   }
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_kp_kernel(TileArgs a) {
   uint32_t ID = 0;
   if (valid) {
     X = a.S[p];
-    EE = a.E[p];
+    EE = swg_comp_end(X, a.E[p], a.pos_bits);
     KEY = a.KEY[p];
     ID = a.I[p];
   }
@@ -1300,7 +1307,8 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   // sorted begins + gathered columns + `single` flags (shared by the k = inf and the general path)
   uint64_t* S = nullptr;
   uint32_t* I = nullptr;
-  uint64_t *E = nullptr, *KEY = nullptr, *tile_x = nullptr;
+  uint32_t* E = nullptr;  // end coordinates, in one of the sort's u64 scratch buffers
+  uint64_t *KEY = nullptr, *tile_x = nullptr;
   uint8_t* single = nullptr;
   auto sort_begins = [&]() -> int {
     S = swg_alloc<uint64_t>(ctx, n);
@@ -1337,7 +1345,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       uint64_t* third = swg_alloc<uint64_t>(ctx, n);
       SWG_CHECK_ARENA(ctx);
       S = other;
-      E = third;
+      E = reinterpret_cast<uint32_t*>(third);
       SWG_LAUNCH(ctx, "begin_gather", begin_gather_packed_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
                                           n, P, idx_bits, in.packed, in.packed_end, in.pos_bits, S, I, E, KEY, tile_x, single));
       SWG_KERNEL_CHECK(ctx);
@@ -1345,7 +1353,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       return prc;
     } else {
       SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits, prehist));
-      E = S2;  // the sort's scratch key buffer is free again
+      E = reinterpret_cast<uint32_t*>(S2);  // the sort's scratch key buffer is free again
       SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
                                           n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_x, single));
       SWG_KERNEL_CHECK(ctx);
@@ -1388,7 +1396,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* carry_cur = cnts + ((size_t)ntiles + 1);
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 2 * n_pad, st));
   SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 2 * ((size_t)ntiles + 1), st));
-  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, tile_x, ntiles, te, carry_cnt));
+  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, in.pos_bits, tile_x, ntiles, te, carry_cnt));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)ntiles + 1, d_total));
   uint64_t n_carry = 0;
@@ -1400,13 +1408,14 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   SWG_CHECK_ARENA(ctx);
   if (n_carry) {
     SWG_LAUNCH(ctx, "route_fill", route_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                      n, S, E, KEY, I, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
+                                      n, S, E, in.pos_bits, KEY, I, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
     SWG_KERNEL_CHECK(ctx);
   }
   TileArgs ta;
   ta.n = n;
   ta.S = S;
   ta.E = E;
+  ta.pos_bits = in.pos_bits;
   ta.KEY = KEY;
   ta.I = I;
   ta.tile_x = tile_x;
