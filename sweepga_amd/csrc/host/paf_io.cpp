@@ -826,14 +826,31 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   // Output path == the mapped input file: truncating it would pull the pages from under the mapping (SIGBUS).  The
   // reference filters into a temporary file first (src/main.rs:3630-3636), so writing in place works there; here the
   // result goes to a sibling temporary file that replaces the input when it is complete.
-  std::string tmp_path;
+  // The temporary file sits beside the RESOLVED path (a symlink named on the command line keeps pointing at the file that
+  // is replaced), is created exclusively and takes over the replaced file's permission bits.
+  std::string tmp_path, final_path;
+  mode_t keep_mode = 0644;
   if (!to_stdout && p->text.map) {
     struct stat so {};
-    if (stat(out_path, &so) == 0 && so.st_dev == p->text.src_dev && so.st_ino == p->text.src_ino)
-      tmp_path = std::string(out_path) + ".swg_tmp." + std::to_string((long)getpid());
+    if (stat(out_path, &so) == 0 && so.st_dev == p->text.src_dev && so.st_ino == p->text.src_ino) {
+      char* rp = realpath(out_path, nullptr);
+      final_path = rp ? rp : out_path;
+      std::free(rp);
+      tmp_path = final_path + ".swg_tmp." + std::to_string((long)getpid());
+      keep_mode = so.st_mode & 07777;
+    }
   }
   const char* open_path = tmp_path.empty() ? out_path : tmp_path.c_str();
-  const int fd = to_stdout ? 1 : open(open_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  int fd = 1;
+  if (!to_stdout) {
+    if (tmp_path.empty()) {
+      fd = open(open_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    } else {
+      fd = open(open_path, O_WRONLY | O_CREAT | O_EXCL, 0600);
+      if (fd < 0 && errno == EEXIST && unlink(open_path) == 0) fd = open(open_path, O_WRONLY | O_CREAT | O_EXCL, 0600);  // a stale one of ours
+      if (fd >= 0) (void)fchmod(fd, keep_mode);
+    }
+  }
   if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot create %s: %s", open_path, std::strerror(errno));
   // sizes per thread range
   std::vector<uint64_t> bytes(threads + 1, 0), kept(threads, 0);
@@ -891,7 +908,7 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   }
   if (!to_stdout && close(fd) != 0 && !bad) bad = errno ? errno : EIO;
   if (!tmp_path.empty()) {
-    if (!bad && rename(tmp_path.c_str(), out_path) != 0) bad = errno ? errno : EIO;
+    if (!bad && rename(tmp_path.c_str(), final_path.c_str()) != 0) bad = errno ? errno : EIO;
     if (bad) unlink(tmp_path.c_str());
   }
   if (bad) return paf_error(SWG_ERR_INVALID, "write to %s failed: %s", out_path, std::strerror(bad));

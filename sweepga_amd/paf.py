@@ -44,9 +44,27 @@ class PafFile:
         return a
 
     def column(self, name):
-        """Read-only numpy view of one record column (valid while the PafFile is open)."""
+        """Read-only numpy view of one record column (valid while the PafFile is open).  When `is_rebased` (a value of the
+        file reached 2^32) the four coordinate columns are RELATIVE to `seq_offsets[sequence id]`; `absolute(name)` gives
+        RecordMeta's own u64 values."""
         dtype = {"identity": np.float64, "strand": np.uint8}.get(name, np.uint32)
         return self._view(getattr(self.records, name), dtype, self.n)
+
+    @property
+    def is_rebased(self):
+        """True when the coordinate columns are relative to `seq_offsets` (results of the filter are unaffected)."""
+        return self.seq_offsets is not None
+
+    def absolute(self, name):
+        """q_start / q_end / t_start / t_end as u64 in the file's own coordinates (a copy)."""
+        if name not in ("q_start", "q_end", "t_start", "t_end"):
+            raise ValueError("absolute() is for the four coordinate columns")
+        v = self.column(name).astype(np.uint64)
+        off = self.seq_offsets
+        if off is None:
+            return v
+        ids = self.column("q_id" if name[0] == "q" else "t_id")
+        return v + off[ids]
 
     @property
     def ranks(self):

@@ -227,12 +227,16 @@ def test_wide_coordinates_are_rebased_per_sequence(tmp_path, threads):
         assert np.array_equal(pf.column("q_end").astype(np.uint64) + oq, ref.qe)
         assert np.array_equal(pf.column("t_start").astype(np.uint64) + ot, ref.ts)
         assert np.array_equal(pf.column("t_end").astype(np.uint64) + ot, ref.te)
+        assert pf.is_rebased    # the handle says so, and gives RecordMeta's own values back
+        for name, want in (("q_start", ref.qs), ("q_end", ref.qe), ("t_start", ref.ts), ("t_end", ref.te)):
+            assert np.array_equal(pf.absolute(name), want)
         assert np.array_equal(pf.column("matches"), ref.matches) and np.array_equal(pf.column("block_len"), ref.block_length)
         assert np.array_equal(pf.column("identity"), ref.identity)
     with PafFile(text=text.replace("5000", "4", 1) if False else "\n".join(lines[:5]) + "\n") as pf:
         assert pf.seq_offsets is not None
     with PafFile(text="q\t9\t1\t5\t+\tt\t9\t2\t6\t3\t4\t0\n") as pf:
         assert pf.seq_offsets is None        # nothing reached 2^32: columns are the file's own values
+        assert not pf.is_rebased and int(pf.absolute("q_start")[0]) == 1
 
 
 def test_fuzz_slice_against_oracle(tmp_path):
