@@ -1520,6 +1520,33 @@ __global__ __launch_bounds__(EW) void chunk_desc_kernel(uint32_t n_chunks, const
   d.pad = 0;
   desc[c] = d;
 }
+// Window extent of the members of long units (how many later elements of the unit start within q_end + gap): what the block
+// plan needs (a block must be at least as long as the longest window).  The unit is sorted by q_start: a binary search.
+__global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uint8_t* __restrict__ big_member,
+                                                           const uint32_t* __restrict__ unit_flag,
+                                                           const uint32_t* __restrict__ unit_excl,
+                                                           const uint32_t* __restrict__ unit_begin, uint32_t n_units,
+                                                           const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
+                                                           uint64_t max_gap, uint32_t* __restrict__ ext) {
+  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (p >= m) return;
+  uint32_t x = 0;
+  if (big_member[p]) {
+    const uint32_t u = unit_excl[p] + unit_flag[p] - 1;
+    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : (uint32_t)m;
+    const uint64_t bound = (uint64_t)s_qe[p] + max_gap;  // wrapping, as release Rust
+    uint32_t lo = (uint32_t)p + 1, hi = e;  // first position in (p, e) with q_start > bound
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if ((uint64_t)s_qs[mid] <= bound)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    x = lo - 1 - (uint32_t)p;
+  }
+  ext[p] = x;
+}
 // candidate lists only for the elements of long units (the walk builds the others' lists itself)
 __global__ __launch_bounds__(EW) void big_member_flag_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
                                                              const uint32_t* __restrict__ unit_excl,
@@ -1649,17 +1676,23 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
   B.M = M;
   if (M == 0) return SWG_OK;
-  B.keyA = swg_alloc<uint64_t>(ctx, M);
-  B.idxA = swg_alloc<uint32_t>(ctx, M);
-  uint64_t* key_tmp = swg_alloc<uint64_t>(ctx, M);
-  uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
+  const bool all_members = member == alive;  // the mapping-level sweep removed nothing (the caller passes the same array)
   B.a_qe = swg_alloc<uint32_t>(ctx, M);
   B.a_ts = swg_alloc<uint32_t>(ctx, M);
   B.a_te = swg_alloc<uint32_t>(ctx, M);
   B.a_dpair = swg_alloc<uint32_t>(ctx, M);
-  uint8_t* a_keep = swg_alloc<uint8_t>(ctx, M);
-  uint32_t* pair_flag = swg_alloc<uint32_t>(ctx, M);
-  uint32_t* pair_excl = swg_alloc<uint32_t>(ctx, M);
+  uint8_t* a_keep = all_members ? nullptr : swg_alloc<uint8_t>(ctx, M);
+  uint32_t* pair_flag = all_members ? nullptr : swg_alloc<uint32_t>(ctx, M);
+  uint32_t* pair_excl = all_members ? nullptr : swg_alloc<uint32_t>(ctx, M);
+  B.keyA = swg_alloc<uint64_t>(ctx, M);
+  B.idxA = swg_alloc<uint32_t>(ctx, M);
+  // the sort's scratch pair comes last: when the sorted data ends up in the primary buffers (an even number of passes) the
+  // scratch goes back to the arena right after the sort (12 of ~300 bytes of scratch per record; every GB of scratch is
+  // 30-45 ms of hipMalloc on a cold context)
+  const swg_arena_mark sort_mark = swg_arena_save(ctx);
+  uint64_t* const keyA0 = B.keyA;
+  uint64_t* key_tmp = swg_alloc<uint64_t>(ctx, M);
+  uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
   SWG_CHECK_ARENA(ctx);
   if (q_order) {
     // The mapping sweep sorted the same alive records by (query sequence, target genome, q_start, index): dead records
@@ -1697,7 +1730,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits));
     }
   }
-  const bool all_members = member == alive;  // the mapping-level sweep removed nothing (the caller passes the same array)
+  if (B.keyA == keyA0) swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA)
   uint64_t m = 0, n_groups = 0;
   uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
   uint64_t* s_grp = nullptr;
@@ -1711,7 +1744,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     if (m >= 0xffffffffull) return swg_set_error(ctx, SWG_ERR_RANGE, "too many chain members");
     B.s_a = nullptr;  // positions coincide (nullptr = identity)
     B.s_idx = B.idxA;
-    B.s_chain = swg_alloc<uint32_t>(ctx, m);
+    B.s_chain = B.want_s_chain ? swg_alloc<uint32_t>(ctx, m) : nullptr;
     s_qs = swg_alloc<uint32_t>(ctx, m);
     s_qe = B.a_qe;
     s_ts = B.a_ts;
@@ -1868,19 +1901,23 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member));
         SWG_KERNEL_CHECK(ctx);
       }
-      if (lists_all || n_big) {
+      if (lists_all) {
         c_d = swg_alloc<unsigned long long>(ctx, (size_t)KC * m);
         c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
         c_n = swg_alloc<uint32_t>(ctx, m);
         c_ext = swg_alloc<uint32_t>(ctx, m);
         SWG_CHECK_ARENA(ctx);
-        if (lists_all) {
-          SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
-                                                       m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
-        } else {
-          SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
-                                                                                  s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext, big_member));
-        }
+        SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
+                                                     m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+        SWG_KERNEL_CHECK(ctx);
+      } else if (n_big) {
+        // sparse data with a few long units: their blocks build their candidate lists while they walk, like the chunks (no
+        // 56 bytes of candidate arrays per record for the sake of a tenth of the records); the block plan only needs the
+        // window extents
+        c_ext = swg_alloc<uint32_t>(ctx, m);
+        SWG_CHECK_ARENA(ctx);
+        SWG_LAUNCH(ctx, "window_extent", window_extent_kernel<<<nblk(m), EW, 0, st>>>(m, big_member, unit_flag, unit_excl, unit_begin,
+                                                                         (uint32_t)n_units, s_qs, s_qe, max_gap, c_ext));
         SWG_KERNEL_CHECK(ctx);
       }
       {
@@ -1965,16 +2002,22 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext, v_own, v_prev, p_own, p_prev));
           SWG_KERNEL_CHECK(ctx);
           const unsigned wblocks = (unsigned)(n_spec < (uint64_t)ctx->num_cu * 32 ? n_spec : (uint64_t)ctx->num_cu * 32);
-#define SWG_WALK_SPEC(W)                                                                                                          \
-  SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, false><<<wblocks, 64, 0, st>>>(                                           \
+#define SWG_WALK_SPEC(W, F)                                                                                                       \
+  SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, F><<<wblocks, 64, 0, st>>>(                                               \
                                          (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin, \
                                          (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 1, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr))
-          if (ring <= 256)
-            SWG_WALK_SPEC(256);
-          else if (ring <= 1024)
-            SWG_WALK_SPEC(1024);
-          else
-            SWG_WALK_SPEC(4096);
+          if (!lists_all) {
+            if (ring <= 256)
+              SWG_WALK_SPEC(256, true);
+            else
+              SWG_WALK_SPEC(1024, true);
+          } else if (ring <= 256) {
+            SWG_WALK_SPEC(256, false);
+          } else if (ring <= 1024) {
+            SWG_WALK_SPEC(1024, false);
+          } else {
+            SWG_WALK_SPEC(4096, false);
+          }
 #undef SWG_WALK_SPEC
           SWG_KERNEL_CHECK(ctx);
           SWG_HIP(ctx, hipMemsetAsync(spec_changed, 0, 8, st));

@@ -515,7 +515,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   unsigned long long* h_sb = swg_alloc<unsigned long long>(ctx, m);
   uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
   uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* group_first = swg_alloc<uint32_t>(ctx, m);
+  uint32_t* group_first = swg_alloc<uint32_t>(ctx, n_groups);
   PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr size_t SWG_ARENA_B_SWEEP = 96, SWG_ARENA_B_SCAFFOLD = 336;  // scratch bytes per record reserved up front
+constexpr size_t SWG_ARENA_B_SWEEP = 96, SWG_ARENA_B_SCAFFOLD = 256;  // scratch bytes per record reserved up front
 
 constexpr int EW = 256;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
@@ -315,7 +315,7 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   // Scratch high-water marks measured on the 10^8 workload (round 3): 82 B/record for the sweep-only pipeline (32-byte record
-  // slots, packed sort), 215-304 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
+  // slots, packed sort), 204-223 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
   // context's first call.
   {
     size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
