@@ -208,6 +208,8 @@ def load():
     lib.swg_memory_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.swg_reserve.restype = C.c_int
     lib.swg_reserve.argtypes = [C.c_void_p, C.c_uint64]
+    lib.swg_warmup.restype = C.c_int
+    lib.swg_warmup.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
     lib.swg_paf_ani_stats.restype = C.c_int
     lib.swg_paf_ani_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.swg_aln_open.restype = C.c_int
@@ -302,6 +304,12 @@ class Context:
 
     def reserve(self, arena_bytes):
         self.check(self.lib.swg_reserve(self.handle, int(arena_bytes)))
+
+    def warmup(self, n_records_hint=0, n_seq_hint=0, with_scaffold=True):
+        """swg_warmup: device memory for about n_records_hint records and the library's code objects, ahead of the first call
+        (meant to run on a thread of its own while the input is read)."""
+        self.check(self.lib.swg_warmup(self.handle, C.c_uint64(int(n_records_hint)), C.c_uint32(int(n_seq_hint)),
+                                       C.c_int(1 if with_scaffold else 0)))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -405,6 +405,7 @@ constexpr int OS_THREADS = 256;
 #endif
 constexpr int OS_ITEMS = SWG_OS_ITEMS;
 constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
+static_assert(OS_ITEMS % 2 == 0, "rows are ranked in pairs");
 constexpr int OS_WAVES = OS_THREADS / 64;
 // look-back word: flag in the top two bits, count below.  32-bit words hold prefixes < 2^30; inputs of 2^30 .. 2^32-1
 // pairs use 64-bit words (same protocol, one relaxed 8-byte access instead of a 4-byte one).
@@ -415,6 +416,46 @@ struct os_word {
   static constexpr ST MASK = LOCAL - 1;
 };
 constexpr int OS_MAX_PASSES = 8;
+
+// Stable rank of a row of 64 digits inside its wavefront: the number of lower lanes holding the same digit (below) and the
+// number of lanes holding it at all (peers).  Eight ballots narrow the peer mask one digit bit at a time; with the bit
+// sign-extended over a word (v_bfe_i32) each half of the mask takes one three-operand bit op per ballot
+// (v_bitop3: mask &= ~(ballot ^ bit); 4 vector instructions per digit bit), and the count of lower peers is the mbcnt pair
+// over the final mask.  Two rows go through together: a ballot's SGPR result cannot feed the next vector instruction
+// (2 wait states on gfx950), the second row's instructions fill those slots.
+struct os_match {
+  uint32_t lo, hi;
+  __device__ __forceinline__ uint32_t below() const { return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)); }
+  __device__ __forceinline__ uint32_t peers() const { return (uint32_t)__popc(lo) + (uint32_t)__popc(hi); }
+};
+__device__ __forceinline__ void os_match_step(os_match& a, uint32_t d, int b) {
+  uint32_t nb = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);  // 0 or ~0
+  asm volatile("" : "+v"(nb));  // keeps the ballot's compare on nb itself (otherwise a shift + sign test of d is added)
+  const uint64_t m = __ballot(nb != 0u);
+  a.lo = __builtin_amdgcn_bitop3_b32(a.lo, (uint32_t)m, nb, 0x90);  // lo & ~(m ^ nb)
+  a.hi = __builtin_amdgcn_bitop3_b32(a.hi, (uint32_t)(m >> 32), nb, 0x90);
+}
+
+// Two rows of the ranking phase.  Every lane reads its digit's running count of the wave, the lowest lane of each digit adds
+// the row's peer count with a no-return LDS add: LDS operations of one wavefront execute in issue order, so the next row's
+// reads see the add, and nothing waits on the read before the add is issued.
+// Lanes past the end of the input carry the all-ones key: they rank behind every real element of the (last) tile, inflate
+// only the count of the highest digit there, and land in staging slots >= tile_n that are never written out.
+__device__ __forceinline__ void os_rank_rows(uint32_t* wave_cnt, uint32_t d0, uint32_t d1, uint32_t* r0, uint32_t* r1) {
+  os_match a{~0u, ~0u}, b{~0u, ~0u};
+  const uint32_t prev0 = __hip_atomic_load(wave_cnt + d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    os_match_step(a, d0, bit);
+    os_match_step(b, d1, bit);
+  }
+  const uint32_t below0 = a.below(), below1 = b.below();
+  if (below0 == 0) __hip_atomic_fetch_add(wave_cnt + d0, a.peers(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t prev1 = __hip_atomic_load(wave_cnt + d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (below1 == 0) __hip_atomic_fetch_add(wave_cnt + d1, b.peers(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  *r0 = prev0 + below0;
+  *r1 = prev1 + below1;
+}
 
 __global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n,
                                                               int begin_bit, int end_bit, int npasses,
@@ -472,7 +513,6 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
                                                               ST* status, uint32_t* ticket) {
   __shared__ uint64_t lkeys[OS_TILE];  // staging for the keys, then reused (as u32) for the values
   __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
-  __shared__ uint32_t tile_excl[RS_RADIX];
   __shared__ uint32_t dst_base[RS_RADIX];
   __shared__ uint32_t lds_wave[OS_THREADS / 64];
   __shared__ uint32_t lds_prev[OS_THREADS];
@@ -485,42 +525,28 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
   const uint32_t tile = s_tile;
   const uint64_t tile_base = (uint64_t)tile * OS_TILE;
   const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
-  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
   uint64_t key[OS_ITEMS];
   uint32_t val[OS_ITEMS];
   uint32_t rank[OS_ITEMS];
+  if (tile_base + OS_TILE <= n) {  // every tile but the last: no bounds checks
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    key[r] = i < n ? keys_in[i] : ~0ull;
-    val[r] = i < n ? vals_in[i] : 0u;
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      key[r] = keys_in[wbase + (uint64_t)r * 64 + lane];
+      val[r] = vals_in[wbase + (uint64_t)r * 64 + lane];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+      key[r] = i < n ? keys_in[i] : ~0ull;
+      val[r] = i < n ? vals_in[i] : 0u;
+    }
   }
   // ---- rank inside the wave (stable): match + per-wave running digit counters in LDS
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    const bool valid = i < n;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    uint64_t peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    uint32_t prev = 0;
-    int leader = 0;
-    if (valid) {
-      leader = __builtin_ctzll(peers);
-      if (lane == leader) {
-        prev = cnt[wave][d];
-        cnt[wave][d] = prev + (uint32_t)__popcll(peers);
-      }
-    }
-    prev = __shfl(prev, leader, 64);
-    rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
-  }
+  for (int r = 0; r < OS_ITEMS; r += 2)
+    os_rank_rows(cnt[wave], (uint32_t)(key[r] >> shift) & mask, (uint32_t)(key[r + 1] >> shift) & mask, &rank[r], &rank[r + 1]);
   __syncthreads();
   // ---- per digit (thread = digit): tile count, wave offsets, tile-exclusive prefix, look-back
   {
@@ -533,7 +559,8 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
     }
     uint32_t block_total;
     const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
-    tile_excl[tid] = ex;
+#pragma unroll
+    for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
     using W = os_word<ST>;
     ST excl = 0;
     ST* my = status + (size_t)tile * RS_RADIX + tid;
@@ -562,37 +589,48 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
   uint32_t pos[OS_ITEMS];
 #pragma unroll
   for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    pos[r] = tile_excl[d] + cnt[wave][d] + rank[r];
-    if (i < n) lkeys[pos[r]] = key[r];
+    pos[r] = cnt[wave][d] + rank[r];
+    lkeys[pos[r]] = key[r];
   }
   __syncthreads();
   const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+  const bool full_tile = tile_n == (uint32_t)OS_TILE;
   uint32_t dst[OS_ITEMS];
+  if (full_tile) {
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
-    dst[r] = 0;
-    if (p < tile_n) {
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
       const uint64_t k = lkeys[p];
-      const uint32_t d = (uint32_t)(k >> shift) & mask;
-      dst[r] = dst_base[d] + p;
+      dst[r] = dst_base[(uint32_t)(k >> shift) & mask] + p;
       keys_out[dst[r]] = k;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+      dst[r] = 0;
+      if (p < tile_n) {
+        const uint64_t k = lkeys[p];
+        dst[r] = dst_base[(uint32_t)(k >> shift) & mask] + p;
+        keys_out[dst[r]] = k;
+      }
     }
   }
   __syncthreads();
   uint32_t* lvals = reinterpret_cast<uint32_t*>(lkeys);
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (i < n) lvals[pos[r]] = val[r];
-  }
+  for (int r = 0; r < OS_ITEMS; ++r) lvals[pos[r]] = val[r];
   __syncthreads();
+  if (full_tile) {
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
-    if (p < tile_n) vals_out[dst[r]] = lvals[p];
+    for (int r = 0; r < OS_ITEMS; ++r) vals_out[dst[r]] = lvals[(uint32_t)r * OS_THREADS + tid];
+  } else {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+      if (p < tile_n) vals_out[dst[r]] = lvals[p];
+    }
   }
 }
 
@@ -608,7 +646,6 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
                                                                      uint32_t* ticket) {
   __shared__ uint64_t lkeys[OS_TILE];
   __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
-  __shared__ uint32_t tile_excl[RS_RADIX];
   __shared__ uint32_t dst_base[RS_RADIX];
   __shared__ uint32_t lds_wave[OS_THREADS / 64];
   __shared__ uint32_t lds_prev[OS_THREADS];
@@ -621,47 +658,39 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
   const uint32_t tile = s_tile;
   const uint64_t tile_base = (uint64_t)tile * OS_TILE;
   const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
-  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   uint64_t key[OS_ITEMS];  // the word that is written
   uint32_t dig[OS_ITEMS];
   uint32_t rank[OS_ITEMS];
+  if (tile_base + OS_TILE <= n) {  // every tile but the last: no bounds checks
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (FIRST) {
-      const uint64_t k = i < n ? in[i] : ~0ull;
-      const uint32_t v = i < n ? vals_in[i] : 0u;
-      dig[r] = (uint32_t)k & mask;  // shift = 0
-      key[r] = ((k >> 8) << val_bits) | v;
-    } else {
-      key[r] = i < n ? in[i] : ~0ull;
-      dig[r] = (uint32_t)(key[r] >> shift) & mask;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    const bool valid = i < n;
-    const uint32_t d = dig[r];
-    uint64_t peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    uint32_t prev = 0;
-    int leader = 0;
-    if (valid) {
-      leader = __builtin_ctzll(peers);
-      if (lane == leader) {
-        prev = cnt[wave][d];
-        cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+      if (FIRST) {
+        const uint64_t k = in[i];
+        dig[r] = (uint32_t)k & mask;  // shift = 0
+        key[r] = ((k >> 8) << val_bits) | vals_in[i];
+      } else {
+        key[r] = in[i];
+        dig[r] = (uint32_t)(key[r] >> shift) & mask;
       }
     }
-    prev = __shfl(prev, leader, 64);
-    rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
+  } else {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+      if (FIRST) {
+        const uint64_t k = i < n ? in[i] : ~0ull;
+        const uint32_t v = i < n ? vals_in[i] : 0u;
+        dig[r] = (uint32_t)k & mask;
+        key[r] = ((k >> 8) << val_bits) | v;
+      } else {
+        key[r] = i < n ? in[i] : ~0ull;
+        dig[r] = (uint32_t)(key[r] >> shift) & mask;
+      }
+    }
   }
+#pragma unroll
+  for (int r = 0; r < OS_ITEMS; r += 2) os_rank_rows(cnt[wave], dig[r], dig[r + 1], &rank[r], &rank[r + 1]);
   __syncthreads();
   {
     uint32_t c[OS_WAVES], tot = 0;
@@ -673,7 +702,8 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
     }
     uint32_t block_total;
     const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
-    tile_excl[tid] = ex;
+#pragma unroll
+    for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
     using W = os_word<ST>;
     ST excl = 0;
     ST* my = status + (size_t)tile * RS_RADIX + tid;
@@ -698,38 +728,39 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
     dst_base[tid] = gbase[tid] + (uint32_t)excl - ex;
   }
   __syncthreads();
-  // reorder in LDS; the digit travels with the word (for FIRST it is no longer part of it): kept in the staging word's place
-  // by staging (digit, word) as two arrays would cost LDS, so the position's digit is recovered from the tile's digit
-  // boundaries instead: position p belongs to digit d iff tile_excl[d] <= p < tile_excl[d + 1]
+  // reorder in LDS.  Later passes find a slot's digit in the staged word itself; the first pass's digit is no longer part of
+  // the word it writes, so the digits are staged too, as bytes over the (then dead) per-wave counters.
 #pragma unroll
   for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    const uint32_t d = dig[r];
-    const uint32_t pos = tile_excl[d] + cnt[wave][d] + rank[r];
-    if (i < n) lkeys[pos] = key[r];
+    rank[r] += cnt[wave][dig[r]];  // the element's slot in the tile
+    lkeys[rank[r]] = key[r];
   }
   __syncthreads();
-  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+  uint8_t* ldig = reinterpret_cast<uint8_t*>(&cnt[0][0]);
+  static_assert(sizeof(cnt) >= OS_TILE, "digit bytes alias the wave counters");
+  if (FIRST) {
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
-    const uint32_t p = (uint32_t)r * OS_THREADS + tid;
-    if (p < tile_n) {
+    for (int r = 0; r < OS_ITEMS; ++r) ldig[rank[r]] = (uint8_t)dig[r];
+    __syncthreads();
+  }
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
+  if (tile_n == (uint32_t)OS_TILE) {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
       const uint64_t k = lkeys[p];
-      uint32_t d;
-      if (FIRST) {  // binary search over the 256 digit boundaries of the tile (tile_excl is ascending)
-        uint32_t lo = 0, hi = RS_RADIX - 1;
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi + 1) >> 1;
-          if (tile_excl[mid] <= p)
-            lo = mid;
-          else
-            hi = mid - 1;
-        }
-        d = lo;
-      } else {
-        d = (uint32_t)(k >> shift) & mask;
-      }
+      const uint32_t d = FIRST ? (uint32_t)ldig[p] : (uint32_t)(k >> shift) & mask;
       out[dst_base[d] + p] = k;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < OS_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+      if (p < tile_n) {
+        const uint64_t k = lkeys[p];
+        const uint32_t d = FIRST ? (uint32_t)ldig[p] : (uint32_t)(k >> shift) & mask;
+        out[dst_base[d] + p] = k;
+      }
     }
   }
 }

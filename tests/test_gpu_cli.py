@@ -102,6 +102,31 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
         assert o1.read_bytes() == o2.read_bytes(), flags
 
 
+def test_warmup_reserves_and_changes_no_result(tmp_path):
+    """swg_warmup (arena + staging block for a hinted size, code objects through one small built-in call): the first real
+    call then needs no grow-and-rerun, and its results are those of a cold context."""
+    import sweepga_amd as sw
+    rng = np.random.default_rng(5)
+    rec = gen.random_records(rng, 20_000, n_genomes=3, chrs_per_genome=2)
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    cfg = sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_max_deviation=5_000)
+    cold, warm = sw.Context(0), sw.Context(0)
+    try:
+        want = sw.PafFilter(cfg, ctx=cold).filter_columns(packed)
+        assert warm.memory_info() == (0, 0)
+        warm.warmup(20_000, 64, True)
+        cap, _ = warm.memory_info()
+        assert cap >= 20_000 * 200
+        got = sw.PafFilter(cfg, ctx=warm).filter_columns(packed)
+        cap2, peak = warm.memory_info()
+        assert cap2 == cap and 0 < peak <= cap            # the reserved arena was enough
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        warm.warmup(0, 0, False)                          # no hint: code objects only
+    finally:
+        cold.close()
+        warm.close()
+
+
 def test_memory_info_reserve_and_filter_paf_errors(tmp_path):
     """swg_memory_info / swg_reserve, and error propagation of swg_filter_paf (missing input, unwritable output)."""
     import sweepga_amd as sw
