@@ -407,6 +407,16 @@ constexpr int OS_ITEMS = SWG_OS_ITEMS;
 constexpr int OS_TILE = OS_THREADS * OS_ITEMS;
 static_assert(OS_ITEMS % 2 == 0, "rows are ranked in pairs");
 constexpr int OS_WAVES = OS_THREADS / 64;
+// (the constants above: the stand-alone histogram kernel)
+// The pass kernels run 512-thread work-groups over 8192-element tiles (two per CU): the look-back is the longest wait in a
+// tile's life (an agent-scope round trip per hop, ~1 us across the XCDs, over every tile that has not published its
+// inclusive prefix yet -- as many as start during one look-back), and half as many tiles per pass halve that walk.
+constexpr int PK_THREADS = 512;
+constexpr int PK_ITEMS = 16;
+constexpr int PK_TILE = PK_THREADS * PK_ITEMS;
+constexpr int PK_WAVES = PK_THREADS / 64;
+static_assert(PK_ITEMS % 2 == 0 && PK_THREADS >= RS_RADIX, "rows are ranked in pairs; one thread per digit");
+
 // look-back word: flag in the top two bits, count below.  32-bit words hold prefixes < 2^30; inputs of 2^30 .. 2^32-1
 // pairs use 64-bit words (same protocol, one relaxed 8-byte access instead of a 4-byte one).
 template <typename ST>
@@ -504,40 +514,86 @@ __global__ __launch_bounds__(RS_RADIX) void os_scan_hist_kernel(uint32_t* __rest
   row[threadIdx.x] = ex;
 }
 
+// Decoupled look-back of one digit (thread = digit) of tile `tile`: publishes the tile's count, sums the counts of the tiles
+// before it back to the nearest tile whose inclusive prefix is known, publishes its own inclusive prefix and returns the
+// exclusive one.  OS_LOOKBACK predecessors are read per round trip (the loads are independent; an agent-scope load is ~1 us).
+#ifndef SWG_OS_LOOKBACK
+#define SWG_OS_LOOKBACK 4
+#endif
+constexpr int OS_LOOKBACK = SWG_OS_LOOKBACK;  // predecessors read per round trip
 template <typename ST>
-__global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __restrict__ keys_in,
+__device__ __forceinline__ ST os_lookback(ST* status, uint32_t tile, int tid, uint32_t tot) {
+  using W = os_word<ST>;
+  ST* my = status + (size_t)tile * RS_RADIX + tid;
+  if (tile == 0) {
+    __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  __hip_atomic_store(my, W::LOCAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ST excl = 0;
+  uint32_t tt = tile - 1;  // the next tile to account for
+  while (true) {
+    ST sv[OS_LOOKBACK];
+#pragma unroll
+    for (int j = 0; j < OS_LOOKBACK; ++j) {
+      const uint32_t t = tt >= (uint32_t)j ? tt - j : 0u;  // (tile 0 ends every walk: it only ever publishes GLOBAL)
+      sv[j] = __hip_atomic_load(status + (size_t)t * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool done = false;
+    int used = 0;
+#pragma unroll
+    for (int j = 0; j < OS_LOOKBACK; ++j) {
+      if (!done && used == j) {
+        const ST f = sv[j] & ~W::MASK;
+        if (f != 0) {
+          excl += sv[j] & W::MASK;
+          ++used;
+          if (f == W::GLOBAL) done = true;
+        }
+      }
+    }
+    if (done) break;
+    if (used == 0) __builtin_amdgcn_s_sleep(1);
+    tt -= (uint32_t)used;
+  }
+  __hip_atomic_store(my, W::GLOBAL | (excl + (ST)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(PK_THREADS) void os_pass_kernel(const uint64_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint64_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, uint64_t n, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ gbase,
                                                               ST* status, uint32_t* ticket) {
-  __shared__ uint64_t lkeys[OS_TILE];  // staging for the keys, then reused (as u32) for the values
-  __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
+  __shared__ uint64_t lkeys[PK_TILE];  // staging for the keys, then reused (as u32) for the values
+  __shared__ uint32_t cnt[PK_WAVES][RS_RADIX];
   __shared__ uint32_t dst_base[RS_RADIX];
-  __shared__ uint32_t lds_wave[OS_THREADS / 64];
-  __shared__ uint32_t lds_prev[OS_THREADS];
+  __shared__ uint32_t lds_wave[PK_THREADS / 64];
+  __shared__ uint32_t lds_prev[PK_THREADS];
   __shared__ uint32_t s_tile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] = 0;
+  const uint32_t gb = tid < RS_RADIX ? gbase[tid] : 0u;  // (early: its latency hides behind the ticket's)
+  for (int i = tid; i < PK_WAVES * RS_RADIX; i += PK_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
-  const uint64_t tile_base = (uint64_t)tile * OS_TILE;
-  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
+  const uint64_t tile_base = (uint64_t)tile * PK_TILE;
+  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * PK_ITEMS);
 
-  uint64_t key[OS_ITEMS];
-  uint32_t val[OS_ITEMS];
-  uint32_t rank[OS_ITEMS];
-  if (tile_base + OS_TILE <= n) {  // every tile but the last: no bounds checks
+  uint64_t key[PK_ITEMS];
+  uint32_t val[PK_ITEMS];
+  uint32_t rank[PK_ITEMS];
+  if (tile_base + PK_TILE <= n) {  // every tile but the last: no bounds checks
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < PK_ITEMS; ++r) {
       key[r] = keys_in[wbase + (uint64_t)r * 64 + lane];
       val[r] = vals_in[wbase + (uint64_t)r * 64 + lane];
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < PK_ITEMS; ++r) {
       const uint64_t i = wbase + (uint64_t)r * 64 + lane;
       key[r] = i < n ? keys_in[i] : ~0ull;
       val[r] = i < n ? vals_in[i] : 0u;
@@ -545,70 +601,55 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
   }
   // ---- rank inside the wave (stable): match + per-wave running digit counters in LDS
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r += 2)
+  for (int r = 0; r < PK_ITEMS; r += 2)
     os_rank_rows(cnt[wave], (uint32_t)(key[r] >> shift) & mask, (uint32_t)(key[r + 1] >> shift) & mask, &rank[r], &rank[r + 1]);
   __syncthreads();
   // ---- per digit (thread = digit): tile count, wave offsets, tile-exclusive prefix, look-back
   {
-    uint32_t c[OS_WAVES], tot = 0;
+    const bool dthread = tid < RS_RADIX;
+    uint32_t c[PK_WAVES], tot = 0;
+    if (dthread) {
 #pragma unroll
-    for (int w = 0; w < OS_WAVES; ++w) {
-      c[w] = cnt[w][tid];
-      cnt[w][tid] = tot;  // exclusive over waves
-      tot += c[w];
+      for (int w = 0; w < PK_WAVES; ++w) {
+        c[w] = cnt[w][tid];
+        cnt[w][tid] = tot;  // exclusive over waves
+        tot += c[w];
+      }
     }
     uint32_t block_total;
-    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
+    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);  // (threads >= 256 only keep step)
+    if (dthread) {
 #pragma unroll
-    for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
-    using W = os_word<ST>;
-    ST excl = 0;
-    ST* my = status + (size_t)tile * RS_RADIX + tid;
-    if (tile == 0) {
-      __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(my, W::LOCAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t tt = tile - 1;
-      while (true) {
-        const ST sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const ST f = sv & ~W::MASK;
-        if (f == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        excl += sv & W::MASK;
-        if (f == W::GLOBAL) break;
-        --tt;  // LOCAL: keep looking back (tile 0 always publishes GLOBAL)
-      }
-      __hip_atomic_store(my, W::GLOBAL | (excl + (ST)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 0; w < PK_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
+      const ST excl = os_lookback<ST>(status, tile, tid, tot);
+      dst_base[tid] = gb + (uint32_t)excl - ex;
     }
-    dst_base[tid] = gbase[tid] + (uint32_t)excl - ex;
   }
   __syncthreads();
   // ---- reorder the tile in LDS: keys first, then the values through the same buffer
-  uint32_t pos[OS_ITEMS];
+  uint32_t pos[PK_ITEMS];
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
+  for (int r = 0; r < PK_ITEMS; ++r) {
     const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
     pos[r] = cnt[wave][d] + rank[r];
     lkeys[pos[r]] = key[r];
   }
   __syncthreads();
-  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
-  const bool full_tile = tile_n == (uint32_t)OS_TILE;
-  uint32_t dst[OS_ITEMS];
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)PK_TILE ? (n - tile_base) : (uint64_t)PK_TILE);
+  const bool full_tile = tile_n == (uint32_t)PK_TILE;
+  uint32_t dst[PK_ITEMS];
   if (full_tile) {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
       const uint64_t k = lkeys[p];
       dst[r] = dst_base[(uint32_t)(k >> shift) & mask] + p;
       keys_out[dst[r]] = k;
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
       dst[r] = 0;
       if (p < tile_n) {
         const uint64_t k = lkeys[p];
@@ -620,15 +661,15 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
   __syncthreads();
   uint32_t* lvals = reinterpret_cast<uint32_t*>(lkeys);
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) lvals[pos[r]] = val[r];
+  for (int r = 0; r < PK_ITEMS; ++r) lvals[pos[r]] = val[r];
   __syncthreads();
   if (full_tile) {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) vals_out[dst[r]] = lvals[(uint32_t)r * OS_THREADS + tid];
+    for (int r = 0; r < PK_ITEMS; ++r) vals_out[dst[r]] = lvals[(uint32_t)r * PK_THREADS + tid];
   } else {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
       if (p < tile_n) vals_out[dst[r]] = lvals[p];
     }
   }
@@ -638,32 +679,32 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_kernel(const uint64_t* __r
 // one, and what is written is ((key >> 8) << val_bits) | value; later passes read and write packed words, the digit of pass
 // p sits at bit val_bits + 8 (p - 1).  One LDS staging round instead of two, 16 (20 for the first) bytes per element.
 template <typename ST, bool FIRST>
-__global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64_t* __restrict__ in,
+__global__ __launch_bounds__(PK_THREADS) void os_pass_packed_kernel(const uint64_t* __restrict__ in,
                                                                      const uint32_t* __restrict__ vals_in,
                                                                      uint64_t* __restrict__ out, uint64_t n, int shift,
                                                                      uint32_t mask, int val_bits,
                                                                      const uint32_t* __restrict__ gbase, ST* status,
                                                                      uint32_t* ticket) {
-  __shared__ uint64_t lkeys[OS_TILE];
-  __shared__ uint32_t cnt[OS_WAVES][RS_RADIX];
+  __shared__ uint64_t lkeys[PK_TILE];
+  __shared__ uint32_t cnt[PK_WAVES][RS_RADIX];
   __shared__ uint32_t dst_base[RS_RADIX];
-  __shared__ uint32_t lds_wave[OS_THREADS / 64];
-  __shared__ uint32_t lds_prev[OS_THREADS];
+  __shared__ uint32_t lds_wave[PK_THREADS / 64];
+  __shared__ uint32_t lds_prev[PK_THREADS];
   __shared__ uint32_t s_tile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] = 0;
+  const uint32_t gb = tid < RS_RADIX ? gbase[tid] : 0u;  // (early: its latency hides behind the ticket's)
+  for (int i = tid; i < PK_WAVES * RS_RADIX; i += PK_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
-  const uint64_t tile_base = (uint64_t)tile * OS_TILE;
-  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * OS_ITEMS);
-  uint64_t key[OS_ITEMS];  // the word that is written
-  uint32_t dig[OS_ITEMS];
-  uint32_t rank[OS_ITEMS];
-  if (tile_base + OS_TILE <= n) {  // every tile but the last: no bounds checks
+  const uint64_t tile_base = (uint64_t)tile * PK_TILE;
+  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * PK_ITEMS);
+  uint64_t key[PK_ITEMS];  // the word that is written
+  uint32_t dig[PK_ITEMS];
+  uint32_t rank[PK_ITEMS];
+  if (tile_base + PK_TILE <= n) {  // every tile but the last: no bounds checks
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < PK_ITEMS; ++r) {
       const uint64_t i = wbase + (uint64_t)r * 64 + lane;
       if (FIRST) {
         const uint64_t k = in[i];
@@ -676,7 +717,7 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
+    for (int r = 0; r < PK_ITEMS; ++r) {
       const uint64_t i = wbase + (uint64_t)r * 64 + lane;
       if (FIRST) {
         const uint64_t k = i < n ? in[i] : ~0ull;
@@ -690,72 +731,58 @@ __global__ __launch_bounds__(OS_THREADS) void os_pass_packed_kernel(const uint64
     }
   }
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; r += 2) os_rank_rows(cnt[wave], dig[r], dig[r + 1], &rank[r], &rank[r + 1]);
+  for (int r = 0; r < PK_ITEMS; r += 2) os_rank_rows(cnt[wave], dig[r], dig[r + 1], &rank[r], &rank[r + 1]);
   __syncthreads();
   {
-    uint32_t c[OS_WAVES], tot = 0;
+    // per digit (threads 0..255): tile count, wave offsets, tile-exclusive prefix, look-back
+    const bool dthread = tid < RS_RADIX;
+    uint32_t c[PK_WAVES], tot = 0;
+    if (dthread) {
 #pragma unroll
-    for (int w = 0; w < OS_WAVES; ++w) {
-      c[w] = cnt[w][tid];
-      cnt[w][tid] = tot;  // exclusive over waves
-      tot += c[w];
+      for (int w = 0; w < PK_WAVES; ++w) {
+        c[w] = cnt[w][tid];
+        cnt[w][tid] = tot;  // exclusive over waves
+        tot += c[w];
+      }
     }
     uint32_t block_total;
-    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);
+    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);  // (threads >= 256 only keep step)
+    if (dthread) {
 #pragma unroll
-    for (int w = 0; w < OS_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
-    using W = os_word<ST>;
-    ST excl = 0;
-    ST* my = status + (size_t)tile * RS_RADIX + tid;
-    if (tile == 0) {
-      __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(my, W::LOCAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t tt = tile - 1;
-      while (true) {
-        const ST sv = __hip_atomic_load(status + (size_t)tt * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const ST f = sv & ~W::MASK;
-        if (f == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        excl += sv & W::MASK;
-        if (f == W::GLOBAL) break;
-        --tt;
-      }
-      __hip_atomic_store(my, W::GLOBAL | (excl + (ST)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 0; w < PK_WAVES; ++w) cnt[w][tid] += ex;  // slot of the wave's first element of this digit in the tile
+      const ST excl = os_lookback<ST>(status, tile, tid, tot);
+      dst_base[tid] = gb + (uint32_t)excl - ex;
     }
-    dst_base[tid] = gbase[tid] + (uint32_t)excl - ex;
   }
   __syncthreads();
   // reorder in LDS.  Later passes find a slot's digit in the staged word itself; the first pass's digit is no longer part of
   // the word it writes, so the digits are staged too, as bytes over the (then dead) per-wave counters.
 #pragma unroll
-  for (int r = 0; r < OS_ITEMS; ++r) {
+  for (int r = 0; r < PK_ITEMS; ++r) {
     rank[r] += cnt[wave][dig[r]];  // the element's slot in the tile
     lkeys[rank[r]] = key[r];
   }
   __syncthreads();
   uint8_t* ldig = reinterpret_cast<uint8_t*>(&cnt[0][0]);
-  static_assert(sizeof(cnt) >= OS_TILE, "digit bytes alias the wave counters");
+  static_assert(sizeof(cnt) >= PK_TILE, "digit bytes alias the wave counters");
   if (FIRST) {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) ldig[rank[r]] = (uint8_t)dig[r];
+    for (int r = 0; r < PK_ITEMS; ++r) ldig[rank[r]] = (uint8_t)dig[r];
     __syncthreads();
   }
-  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)OS_TILE ? (n - tile_base) : (uint64_t)OS_TILE);
-  if (tile_n == (uint32_t)OS_TILE) {
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)PK_TILE ? (n - tile_base) : (uint64_t)PK_TILE);
+  if (tile_n == (uint32_t)PK_TILE) {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
       const uint64_t k = lkeys[p];
       const uint32_t d = FIRST ? (uint32_t)ldig[p] : (uint32_t)(k >> shift) & mask;
       out[dst_base[d] + p] = k;
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < OS_ITEMS; ++r) {
-      const uint32_t p = (uint32_t)r * OS_THREADS + tid;
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
       if (p < tile_n) {
         const uint64_t k = lkeys[p];
         const uint32_t d = FIRST ? (uint32_t)ldig[p] : (uint32_t)(k >> shift) & mask;
@@ -809,7 +836,8 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     return radix_sort_three_kernel(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit);
   const bool wide = force_wide || n >= (uint64_t(1) << 30);
   const size_t word = wide ? sizeof(uint64_t) : sizeof(uint32_t);
-  const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+  const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
+  const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
   uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
   void* status = swg_arena_alloc(ctx, (size_t)ntiles * RS_RADIX * word);
@@ -819,7 +847,7 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   {
     if (!prehist) {
       SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
-      uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
+      uint32_t hb = htiles < (uint32_t)ctx->num_cu * 8 ? htiles : (uint32_t)ctx->num_cu * 8;
       SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, begin_bit, end_bit, npasses, ghist));
       SWG_KERNEL_CHECK(ctx);
     }
@@ -832,11 +860,11 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     const uint32_t mask = (1u << bits) - 1u;
     SWG_HIP(ctx, hipMemsetAsync(status, 0, word * (size_t)ntiles * RS_RADIX, ctx->stream));
     if (wide)
-      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint64_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint64_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                      *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
                                      static_cast<uint64_t*>(status), tickets + p));
     else
-      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint32_t><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                      *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
                                      static_cast<uint32_t*>(status), tickets + p));
     SWG_KERNEL_CHECK(ctx);
@@ -860,7 +888,8 @@ int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, ui
   if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || npasses < 2 || npasses > OS_MAX_PASSES ||
       key_bits - 8 + val_bits > 64 || val_bits < 1 || val_bits > 32)
     return SWG_ERR_UNSUPPORTED;
-  const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+  const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
+  const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
   uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
   uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * RS_RADIX);
@@ -869,7 +898,7 @@ int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, ui
   SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
   if (!prehist) {
     SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
-    uint32_t hb = ntiles < (uint32_t)ctx->num_cu * 8 ? ntiles : (uint32_t)ctx->num_cu * 8;
+    uint32_t hb = htiles < (uint32_t)ctx->num_cu * 8 ? htiles : (uint32_t)ctx->num_cu * 8;
     SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(keys, n, 0, key_bits, npasses, ghist));
     SWG_KERNEL_CHECK(ctx);
   }
@@ -883,10 +912,10 @@ int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, ui
     const uint32_t mask = (1u << bits) - 1u;
     SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * RS_RADIX, ctx->stream));
     if (p == 0)
-      SWG_LAUNCH_N(ctx, "os_pass_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                              src, vals, dst, n, 0, mask, val_bits, ghist, status, tickets));
     else
-      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, OS_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                               src, nullptr, dst, n, val_bits + 8 * (p - 1), mask, val_bits,
                                               ghist + (size_t)p * RS_RADIX, status, tickets + p));
     SWG_KERNEL_CHECK(ctx);
