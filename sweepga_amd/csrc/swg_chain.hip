@@ -169,6 +169,40 @@ __global__ __launch_bounds__(EW) void gather_all_kernel(uint64_t M, const uint64
   const uint64_t gp = a ? keyA[a - 1] >> pos_bits : ~0ull;
   flags[a] = ((uint64_t)((gp >> 1) != (g >> 1)) << 32) | (uint64_t)(gp != g);
 }
+// The same after the packed sort (swg_radix_sort_packed): P[a] = ((key >> 8) << idx_bits) | record index.  The key's low
+// 8 bits are the low 8 bits of the start coordinate (pos_bits >= 8 here), which comes from the record like the other
+// columns; the full key and the index are written out for the later stages (inversion capture, rescue).
+__global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const uint64_t* __restrict__ P, int idx_bits,
+                                                               const uint32_t* __restrict__ q_start,
+                                                               const uint32_t* __restrict__ q_end,
+                                                               const uint32_t* __restrict__ t_start,
+                                                               const uint32_t* __restrict__ t_end,
+                                                               const uint32_t* __restrict__ matches,
+                                                               const uint32_t* __restrict__ block_len, int pos_bits,
+                                                               uint64_t* __restrict__ keyA, uint32_t* __restrict__ idxA,
+                                                               uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
+                                                               uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
+                                                               uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
+                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ flags) {
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint64_t w = P[a];
+  const uint32_t i = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
+  const uint64_t hi = w >> idx_bits;  // key >> 8
+  const uint32_t qs = q_start[i], qe = q_end[i], ts = t_start[i], te = t_end[i], mt = matches[i], bl = block_len[i];
+  keyA[a] = (hi << 8) | (uint64_t)(qs & 0xffu);
+  idxA[a] = i;
+  s_qs[a] = qs;
+  s_qe[a] = qe;
+  s_ts[a] = ts;
+  s_te[a] = te;
+  s_m[a] = mt;
+  s_b[a] = bl;
+  const uint64_t g = hi >> (pos_bits - 8);
+  s_grp[a] = g;
+  const uint64_t gp = a ? (P[a - 1] >> idx_bits) >> (pos_bits - 8) : ~0ull;
+  flags[a] = ((uint64_t)((gp >> 1) != (g >> 1)) << 32) | (uint64_t)(gp != g);
+}
 // after the inclusive sum scan of those flags: dense pair and group ids, group begins
 __global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64_t* __restrict__ incl,
                                                         uint32_t* __restrict__ a_dpair, uint32_t* __restrict__ s_gidx,
@@ -1694,6 +1728,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   uint64_t* key_tmp = swg_alloc<uint64_t>(ctx, M);
   uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
   SWG_CHECK_ARENA(ctx);
+  uint64_t* packedA = nullptr;  // sort A's result as packed words (then B.keyA / B.idxA are written by the gather)
+  int packed_idx_bits = 0;
   if (q_order) {
     // The mapping sweep sorted the same alive records by (query sequence, target genome, q_start, index): dead records
     // first, so the last M entries are the alive ones, and inside every (query, target, strand) group they already stand
@@ -1718,7 +1754,18 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                                         M, M == n ? nullptr : B.idxA, M == n ? B.idxA : nullptr, r->q_id, r->t_id, r->strand, r->q_start,
                                         r->n_seq, pos_bits, B.keyA, key_bits, prehist));
       SWG_KERNEL_CHECK(ctx);
-      SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits, prehist));
+      // 8-byte passes when every record is a member (the fused gather below unpacks the words) and the word has the room
+      int prc = SWG_ERR_UNSUPPORTED;
+      const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
+      if (all_members && pos_bits >= 8) prc = swg_radix_sort_packed(ctx, B.keyA, B.idxA, key_tmp, M, key_bits, idx_bits, prehist, &packedA);
+      if (prc == SWG_OK) {
+        packed_idx_bits = idx_bits;
+      } else if (prc != SWG_ERR_UNSUPPORTED) {
+        return prc;
+      } else {
+        packedA = nullptr;
+        SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits, prehist));
+      }
     } else {
       if (M == n) {
         SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA));
@@ -1730,7 +1777,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits));
     }
   }
-  if (B.keyA == keyA0) swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA)
+  if (packedA) {
+    B.keyA = packedA == keyA0 ? key_tmp : keyA0;  // the buffer the words are not in takes the unpacked keys (no release then)
+  } else if (B.keyA == keyA0) {
+    swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA)
+  }
   uint64_t m = 0, n_groups = 0;
   uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
   uint64_t* s_grp = nullptr;
@@ -1759,9 +1810,14 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     pred = swg_alloc<uint32_t>(ctx, m);
     uint64_t* flags64 = swg_alloc<uint64_t>(ctx, m);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
-                                                               r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
-                                                               flags64));
+    if (packedA)
+      SWG_LAUNCH(ctx, "gather_all", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
+                                        M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
+                                        pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, flags64));
+    else
+      SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
+                                                                 r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
+                                                                 flags64));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_inclusive_sum_scan_u64(ctx, flags64, flags64, M));
     SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, flags64, B.a_dpair, s_gidx, head_flag, group_begin));
