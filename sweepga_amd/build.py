@@ -79,6 +79,24 @@ def build_synth(force=False, verbose=False):
     return SYNTH
 
 
+SORT_BENCH_SRC = os.path.join(HERE, "..", "tests", "native", "sort_bench.cpp")
+SORT_BENCH = os.path.join(HERE, "bin", "sort_bench")
+
+
+def build_sort_bench(force=False, verbose=False):
+    """tests/native/sort_bench.cpp: the library's radix sorts on their own, timed and verified element by element (a GPU box
+    tool; tests/test_gpu_sort_native.py runs it)."""
+    if not force and os.path.exists(SORT_BENCH) and os.path.getmtime(SORT_BENCH) >= max(os.path.getmtime(SORT_BENCH_SRC), os.path.getmtime(LIB)):
+        return SORT_BENCH
+    os.makedirs(os.path.dirname(SORT_BENCH), exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", SORT_BENCH_SRC, "-o", SORT_BENCH, "-L", HERE, "-lsweepga_gpu",
+           "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SORT_BENCH
+
+
 OBJ_DIR = os.path.join(CSRC, "build")
 
 
@@ -123,6 +141,7 @@ def build(force=False, verbose=False):
     build_cli(force=force, verbose=verbose)
     build_alnstats(force=force, verbose=verbose)
     build_synth(force=force, verbose=verbose)
+    build_sort_bench(force=force, verbose=verbose)
     return LIB
 
 

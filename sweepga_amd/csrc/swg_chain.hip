@@ -143,6 +143,29 @@ __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t*
 // Both gathers in one pass when every record of sort A is a member of the chaining (the mapping-level sweep removed
 // nothing: the CLI defaults): positions coincide, nothing is compacted, and the two boundary flags -- (query, target) pair
 // heads in the high word, (query, target, strand) group heads in the low word -- go through ONE u64 sum scan.
+// Boundaries of a 256-element block, counted: (pair boundaries << 32) | group boundaries.  The dense pair and group numbers
+// are prefix counts of these flags; per-block counts + a scan over the blocks + the flags recomputed from the sorted keys
+// (group_pair_kernel) replace an element-wise 8-byte flag column and its 10^8-element scan.
+__device__ __forceinline__ void block_boundary_count(bool pf, bool gf, uint64_t* out) {
+  __shared__ uint32_t wc[2][EW / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t np = (uint32_t)__popcll(__ballot(pf)), ng = (uint32_t)__popcll(__ballot(gf));
+  if (lane == 0) {
+    wc[0][wave] = np;
+    wc[1][wave] = ng;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t p = 0, g = 0;
+#pragma unroll
+    for (int w = 0; w < EW / 64; ++w) {
+      p += wc[0][w];
+      g += wc[1][w];
+    }
+    *out = ((uint64_t)p << 32) | g;
+  }
+}
+
 __global__ __launch_bounds__(EW) void gather_all_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
                                                         const uint32_t* __restrict__ idxA,
                                                         const uint32_t* __restrict__ q_end,
@@ -153,21 +176,26 @@ __global__ __launch_bounds__(EW) void gather_all_kernel(uint64_t M, const uint64
                                                         uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
                                                         uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                         uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
-                                                        uint64_t* __restrict__ s_grp, uint64_t* __restrict__ flags) {
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a >= M) return;
-  const uint64_t k = keyA[a];
-  const uint32_t i = idxA[a];
-  s_qs[a] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
-  s_qe[a] = q_end[i];
-  s_ts[a] = t_start[i];
-  s_te[a] = t_end[i];
-  s_m[a] = matches[i];
-  s_b[a] = block_len[i];
-  const uint64_t g = k >> pos_bits;
-  s_grp[a] = g;
-  const uint64_t gp = a ? keyA[a - 1] >> pos_bits : ~0ull;
-  flags[a] = ((uint64_t)((gp >> 1) != (g >> 1)) << 32) | (uint64_t)(gp != g);
+                                                        uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt) {
+  const uint32_t lb = swg_xcd_block(blockIdx.x, gridDim.x);
+  const uint64_t a = (uint64_t)lb * EW + threadIdx.x;
+  bool pf = false, gf = false;  // a (query, target) pair / a (query, target, strand) group begins here
+  if (a < M) {
+    const uint64_t k = keyA[a];
+    const uint32_t i = idxA[a];
+    s_qs[a] = (uint32_t)(k & ((uint64_t(1) << pos_bits) - 1));
+    s_qe[a] = q_end[i];
+    s_ts[a] = t_start[i];
+    s_te[a] = t_end[i];
+    s_m[a] = matches[i];
+    s_b[a] = block_len[i];
+    const uint64_t g = k >> pos_bits;
+    s_grp[a] = g;
+    const uint64_t gp = a ? keyA[a - 1] >> pos_bits : ~0ull;
+    pf = (gp >> 1) != (g >> 1);
+    gf = gp != g;
+  }
+  block_boundary_count(pf, gf, blk_cnt + lb);
 }
 // The same after the packed sort (swg_radix_sort_packed): P[a] = ((key >> 8) << idx_bits) | record index.  The key's low
 // 8 bits are the low 8 bits of the start coordinate (pos_bits >= 8 here), which comes from the record like the other
@@ -183,39 +211,65 @@ __global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const
                                                                uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
                                                                uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                                uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
-                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ flags) {
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a >= M) return;
-  const uint64_t w = P[a];
-  const uint32_t i = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
-  const uint64_t hi = w >> idx_bits;  // key >> 8
-  const uint32_t qs = q_start[i], qe = q_end[i], ts = t_start[i], te = t_end[i], mt = matches[i], bl = block_len[i];
-  keyA[a] = (hi << 8) | (uint64_t)(qs & 0xffu);
-  idxA[a] = i;
-  s_qs[a] = qs;
-  s_qe[a] = qe;
-  s_ts[a] = ts;
-  s_te[a] = te;
-  s_m[a] = mt;
-  s_b[a] = bl;
-  const uint64_t g = hi >> (pos_bits - 8);
-  s_grp[a] = g;
-  const uint64_t gp = a ? (P[a - 1] >> idx_bits) >> (pos_bits - 8) : ~0ull;
-  flags[a] = ((uint64_t)((gp >> 1) != (g >> 1)) << 32) | (uint64_t)(gp != g);
+                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt) {
+  const uint32_t lb = swg_xcd_block(blockIdx.x, gridDim.x);
+  const uint64_t a = (uint64_t)lb * EW + threadIdx.x;
+  bool pf = false, gf = false;
+  if (a < M) {
+    const uint64_t w = P[a];
+    const uint32_t i = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
+    const uint64_t hi = w >> idx_bits;  // key >> 8
+    const uint32_t qs = q_start[i], qe = q_end[i], ts = t_start[i], te = t_end[i], mt = matches[i], bl = block_len[i];
+    keyA[a] = (hi << 8) | (uint64_t)(qs & 0xffu);
+    idxA[a] = i;
+    s_qs[a] = qs;
+    s_qe[a] = qe;
+    s_ts[a] = ts;
+    s_te[a] = te;
+    s_m[a] = mt;
+    s_b[a] = bl;
+    const uint64_t g = hi >> (pos_bits - 8);
+    s_grp[a] = g;
+    const uint64_t gp = a ? (P[a - 1] >> idx_bits) >> (pos_bits - 8) : ~0ull;
+    pf = (gp >> 1) != (g >> 1);
+    gf = gp != g;
+  }
+  block_boundary_count(pf, gf, blk_cnt + lb);
 }
-// after the inclusive sum scan of those flags: dense pair and group ids, group begins
-__global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64_t* __restrict__ incl,
+// after the inclusive sum scan of the blocks' counts: dense pair and group ids, group begins.  The flags are recomputed from
+// the sorted keys; a block's 256 prefix counts come from two ballots per wavefront and the wavefronts' totals in LDS.
+__global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64_t* __restrict__ keyA, int pos_bits,
+                                                        const uint64_t* __restrict__ blk_incl,
                                                         uint32_t* __restrict__ a_dpair, uint32_t* __restrict__ s_gidx,
                                                         uint32_t* __restrict__ head_flag, uint32_t* __restrict__ group_begin) {
-  uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  __shared__ uint32_t wc[2][EW / 64];
+  const uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool pf = false, gf = false;
+  if (a < M) {
+    const uint64_t g = keyA[a] >> pos_bits;
+    const uint64_t gp = a ? keyA[a - 1] >> pos_bits : ~0ull;
+    pf = (gp >> 1) != (g >> 1);
+    gf = gp != g;
+  }
+  const uint64_t mp = __ballot(pf), mg = __ballot(gf);
+  if (lane == 0) {
+    wc[0][wave] = (uint32_t)__popcll(mp);
+    wc[1][wave] = (uint32_t)__popcll(mg);
+  }
+  __syncthreads();
   if (a >= M) return;
-  const uint64_t v = incl[a];
-  const uint32_t g = (uint32_t)v - 1;
-  a_dpair[a] = (uint32_t)(v >> 32) - 1;
-  s_gidx[a] = g;
-  const bool head = a == 0 || (uint32_t)incl[a - 1] != (uint32_t)v;
-  head_flag[a] = head ? 1u : 0u;
-  if (head) group_begin[g] = (uint32_t)a;
+  const uint64_t base = blockIdx.x ? blk_incl[blockIdx.x - 1] : 0ull;
+  const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);  // lanes 0..lane
+  uint32_t np = (uint32_t)(base >> 32) + (uint32_t)__popcll(mp & upto), ng = (uint32_t)base + (uint32_t)__popcll(mg & upto);
+  for (int w = 0; w < wave; ++w) {
+    np += wc[0][w];
+    ng += wc[1][w];
+  }
+  a_dpair[a] = np - 1;  // (the first element is a boundary of both kinds: counts are >= 1)
+  s_gidx[a] = ng - 1;
+  head_flag[a] = gf ? 1u : 0u;
+  if (gf) group_begin[ng - 1] = (uint32_t)a;
 }
 
 __global__ __launch_bounds__(EW) void group_bounds_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
@@ -1808,22 +1862,24 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     group_begin = swg_alloc<uint32_t>(ctx, m);
     bps = swg_alloc<unsigned long long>(ctx, m);
     pred = swg_alloc<uint32_t>(ctx, m);
-    uint64_t* flags64 = swg_alloc<uint64_t>(ctx, m);
+    const uint64_t n_blk = nblk(M);
+    uint64_t* blk_cnt = swg_alloc<uint64_t>(ctx, n_blk);  // per 256-element block: (pair boundaries << 32) | group boundaries
     SWG_CHECK_ARENA(ctx);
     if (packedA)
       SWG_LAUNCH(ctx, "gather_all", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
                                         M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
-                                        pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, flags64));
+                                        pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt));
     else
       SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
                                                                  r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
-                                                                 flags64));
+                                                                 blk_cnt));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_inclusive_sum_scan_u64(ctx, flags64, flags64, M));
-    SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, flags64, B.a_dpair, s_gidx, head_flag, group_begin));
+    SWG_TRY(swg_inclusive_sum_scan_u64(ctx, blk_cnt, blk_cnt, n_blk));
+    SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, pos_bits, blk_cnt, B.a_dpair, s_gidx, head_flag,
+                                                               group_begin));
     SWG_KERNEL_CHECK(ctx);
     uint64_t tot = 0;
-    SWG_TRY(swg_read_scalars(ctx, flags64 + (M - 1), &tot, 1));
+    SWG_TRY(swg_read_scalars(ctx, blk_cnt + (n_blk - 1), &tot, 1));
     B.n_pairs = tot >> 32;
     n_groups = tot & 0xffffffffull;
   } else {
