@@ -1804,14 +1804,19 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_CHECK_ARENA(ctx);
       SWG_HIP(ctx, hipMemsetAsync(prehist, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
       const unsigned full = nblk(M), cap = (unsigned)ctx->num_cu * 16;
-      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
-                                        M, M == n ? nullptr : B.idxA, M == n ? B.idxA : nullptr, r->q_id, r->t_id, r->strand, r->q_start,
-                                        r->n_seq, pos_bits, B.keyA, key_bits, prehist));
-      SWG_KERNEL_CHECK(ctx);
-      // 8-byte passes when every record is a member (the fused gather below unpacks the words) and the word has the room
-      int prc = SWG_ERR_UNSUPPORTED;
+      // 8-byte passes when every record is a member (the fused gather below unpacks the words) and the word has the room;
+      // with M == n the index list is the identity and is not even written (the packed sort takes it as read)
       const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
-      if (all_members && pos_bits >= 8) prc = swg_radix_sort_packed(ctx, B.keyA, B.idxA, key_tmp, M, key_bits, idx_bits, prehist, &packedA);
+      const bool packed_sort = all_members && pos_bits >= 8 && swg_radix_sort_packed_applies(M, key_bits, idx_bits);
+      const bool identity = M == n;
+      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
+                                        M, identity ? nullptr : B.idxA, identity && !packed_sort ? B.idxA : nullptr, r->q_id, r->t_id,
+                                        r->strand, r->q_start, r->n_seq, pos_bits, B.keyA, key_bits, prehist));
+      SWG_KERNEL_CHECK(ctx);
+      int prc = SWG_ERR_UNSUPPORTED;
+      if (packed_sort)
+        prc = swg_radix_sort_packed(ctx, B.keyA, identity ? nullptr : B.idxA, key_tmp, M, key_bits, idx_bits, prehist, &packedA);
+      if (packed_sort && prc == SWG_ERR_UNSUPPORTED) return swg_set_error(ctx, SWG_ERR_HIP, "packed sort declined a shape it accepted");
       if (prc == SWG_OK) {
         packed_idx_bits = idx_bits;
       } else if (prc != SWG_ERR_UNSUPPORTED) {

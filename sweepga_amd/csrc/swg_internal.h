@@ -154,8 +154,11 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
 // Needs key_bits - 8 + val_bits <= 64 and every value < 2^val_bits.  `keys` (n u64) is overwritten, `scratch` is n u64 of
 // scratch; *packed_out is whichever of the two holds the sorted packed words.  Returns SWG_ERR_UNSUPPORTED when the shape
 // does not qualify (the caller then uses swg_radix_sort_pairs).
+// vals == nullptr: the values are the identity (element i carries i), no array is read.
 int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
                           int val_bits, uint32_t* prehist, uint64_t** packed_out);
+// whether swg_radix_sort_packed will take this shape (so that the caller can leave an identity value array unwritten)
+bool swg_radix_sort_packed_applies(uint64_t n, int key_bits, int val_bits);
 constexpr int SWG_RADIX_BINS = 256;
 constexpr int SWG_RADIX_MAX_PASSES = 8;
 #ifdef __HIPCC__

@@ -703,15 +703,25 @@ __global__ __launch_bounds__(PK_THREADS) void os_pass_packed_kernel(const uint64
   uint32_t dig[PK_ITEMS];
   uint32_t rank[PK_ITEMS];
   if (tile_base + PK_TILE <= n) {  // every tile but the last: no bounds checks
+    if (FIRST) {
+      uint32_t v[PK_ITEMS];
+      if (vals_in) {  // (one uniform branch around all the loads: a select per element would split them up)
 #pragma unroll
-    for (int r = 0; r < PK_ITEMS; ++r) {
-      const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-      if (FIRST) {
-        const uint64_t k = in[i];
+        for (int r = 0; r < PK_ITEMS; ++r) v[r] = vals_in[wbase + (uint64_t)r * 64 + lane];
+      } else {  // no array: the values are the identity
+#pragma unroll
+        for (int r = 0; r < PK_ITEMS; ++r) v[r] = (uint32_t)(wbase + (uint64_t)r * 64 + lane);
+      }
+#pragma unroll
+      for (int r = 0; r < PK_ITEMS; ++r) {
+        const uint64_t k = in[wbase + (uint64_t)r * 64 + lane];
         dig[r] = (uint32_t)k & mask;  // shift = 0
-        key[r] = ((k >> 8) << val_bits) | vals_in[i];
-      } else {
-        key[r] = in[i];
+        key[r] = ((k >> 8) << val_bits) | v[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < PK_ITEMS; ++r) {
+        key[r] = in[wbase + (uint64_t)r * 64 + lane];
         dig[r] = (uint32_t)(key[r] >> shift) & mask;
       }
     }
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(PK_THREADS) void os_pass_packed_kernel(const uint64
       const uint64_t i = wbase + (uint64_t)r * 64 + lane;
       if (FIRST) {
         const uint64_t k = i < n ? in[i] : ~0ull;
-        const uint32_t v = i < n ? vals_in[i] : 0u;
+        const uint32_t v = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
         dig[r] = (uint32_t)k & mask;
         key[r] = ((k >> 8) << val_bits) | v;
       } else {
@@ -879,15 +889,19 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   return SWG_OK;
 }
 
-int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
-                          int val_bits, uint32_t* prehist, uint64_t** packed_out) {
+bool swg_radix_sort_packed_applies(uint64_t n, int key_bits, int val_bits) {
   static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
   static const bool force_wide = getenv("SWG_SORT_WIDE") != nullptr;
   static const bool no_packed = getenv("SWG_SORT_PAIRS") != nullptr;  // test knob: the 12-byte passes everywhere
   const int npasses = (key_bits + 7) / 8;
-  if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || npasses < 2 || npasses > OS_MAX_PASSES ||
-      key_bits - 8 + val_bits > 64 || val_bits < 1 || val_bits > 32)
-    return SWG_ERR_UNSUPPORTED;
+  return !(force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || npasses < 2 || npasses > OS_MAX_PASSES ||
+           key_bits - 8 + val_bits > 64 || val_bits < 1 || val_bits > 32);
+}
+
+int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
+                          int val_bits, uint32_t* prehist, uint64_t** packed_out) {
+  const int npasses = (key_bits + 7) / 8;
+  if (!swg_radix_sort_packed_applies(n, key_bits, val_bits)) return SWG_ERR_UNSUPPORTED;
   const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
   const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);

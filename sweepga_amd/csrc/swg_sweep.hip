@@ -169,7 +169,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
         k = ((sg + 1) << pos_bits) | start[i];
       }
       key[i] = k;
-      val[i] = (uint32_t)i;
+      if (val) val[i] = (uint32_t)i;  // (nullptr: the packed sort takes the identity as read)
     }
     if (ghist) swg_radix_hist_add(h, k, in, 0, key_bits, npasses);
   }
@@ -1327,17 +1327,19 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_CHECK_ARENA(ctx);
       SWG_HIP(ctx, hipMemsetAsync(prehist, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
     }
+    const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
+    const bool packed_sort = in.packed && in.pos_bits >= 8 && swg_radix_sort_packed_applies(n, key_bits, idx_bits);
     {
       const unsigned full = blocks_for(n, EW_THREADS), cap = (unsigned)ctx->num_cu * 16;
       SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<(prehist && full > cap) ? cap : full, EW_THREADS, 0, st>>>(
-                                         n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, I,
-                                         key_bits, prehist));
+                                         n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S,
+                                         packed_sort ? nullptr : I, key_bits, prehist));
     }
     SWG_KERNEL_CHECK(ctx);
-    const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
     uint64_t* P = nullptr;
     int prc = SWG_ERR_UNSUPPORTED;
-    if (in.packed && in.pos_bits >= 8) prc = swg_radix_sort_packed(ctx, S, I, S2, n, key_bits, idx_bits, prehist, &P);
+    if (packed_sort) prc = swg_radix_sort_packed(ctx, S, nullptr, S2, n, key_bits, idx_bits, prehist, &P);
+    if (packed_sort && prc == SWG_ERR_UNSUPPORTED) return swg_set_error(ctx, SWG_ERR_HIP, "packed sort declined a shape it accepted");
     SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
     if (prc == SWG_OK) {
       // 8-byte passes after the first; the sorted packed words sit in S or S2, the other one and a third buffer take S and E

@@ -1,7 +1,7 @@
 // Times and checks the library's radix sorts on their own (a GPU box tool, not part of the pytest suites):
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 tests/native/sort_bench.cpp -o gpurun_out/sort_bench
 //         -Lsweepga_amd -lsweepga_gpu -Wl,-rpath,$PWD/sweepga_amd
-//   gpurun_out/sort_bench [n=100000000] [key_bits=42] [reps=5] [packed=1]
+//   gpurun_out/sort_bench [n=100000000] [key_bits=42] [reps=5] [packed=1]     (packed=2: no value array, identity taken as read)
 // Keys are uniform random key_bits-bit words, values the identity.  Every repetition is verified on the host: the output
 // is ordered by (key, value) -- the stable order -- and the values are a permutation (checksum + strict order).
 // Prints the per-repetition time of the whole sort (HIP events on the context's stream).
@@ -40,7 +40,8 @@ int main(int argc, char** argv) {
   const uint64_t n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ull;
   const int key_bits = argc > 2 ? atoi(argv[2]) : 42;
   const int reps = argc > 3 ? atoi(argv[3]) : 5;
-  const bool packed = argc > 4 ? atoi(argv[4]) != 0 : true;
+  const int packed_arg = argc > 4 ? atoi(argv[4]) : 1;
+  const bool packed = packed_arg != 0;
   const bool verify = getenv("SORT_BENCH_NO_VERIFY") == nullptr;
   swg_ctx* ctx = nullptr;
   if (swg_create(0, &ctx) != SWG_OK) {
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(a, ctx->stream));
     int rc;
     if (packed)
-      rc = swg_radix_sort_packed(ctx, k, v, ka, n, key_bits, idx_bits, nullptr, &out);
+      rc = swg_radix_sort_packed(ctx, k, packed_arg == 2 ? nullptr : v, ka, n, key_bits, idx_bits, nullptr, &out);
     else
       rc = swg_radix_sort_pairs(ctx, &k, &v, &ka, &va, n, 0, key_bits);
     CK(hipEventRecord(b, ctx->stream));

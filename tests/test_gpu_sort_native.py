@@ -19,6 +19,7 @@ def sort_bench():
 
 CASES = [  # n, key bits, packed, extra environment
     (5_000, 20, 1, {}), (8_192, 24, 1, {}), (8_193, 33, 1, {}), (16_385, 17, 1, {}), (1_000_003, 48, 1, {}), (3_000_000, 42, 1, {}),
+    (8_193, 33, 2, {}), (3_000_000, 42, 2, {}),
     (5_000, 9, 0, {}), (8_192, 17, 0, {}), (8_193, 64, 0, {}), (1_000_003, 56, 0, {}), (3_000_000, 43, 0, {}),
     (3_000_000, 40, 0, {"SWG_SORT_WIDE": "1"}), (300_000, 40, 0, {"SWG_SORT_FALLBACK": "1"}), (300_000, 40, 1, {"SWG_SORT_PAIRS": "1"}),
 ]
