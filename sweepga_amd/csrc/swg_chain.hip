@@ -35,11 +35,11 @@ __global__ __launch_bounds__(EW) void sortA_keys_hist_kernel(uint64_t M, const u
                                                              const uint32_t* __restrict__ t_id,
                                                              const uint8_t* __restrict__ strand,
                                                              const uint32_t* __restrict__ q_start, uint32_t n_seq,
-                                                             int pos_bits, uint64_t* __restrict__ key, int key_bits,
+                                                             int pos_bits, uint64_t* __restrict__ key, swg_radix_plan plan,
                                                              uint32_t* __restrict__ ghist) {
   __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
-  const int npasses = (key_bits + 7) / 8;
-  for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+  const int npasses = plan.npasses;
+  swg_radix_hist_zero(h, npasses);
   __syncthreads();
   for (uint64_t base = (uint64_t)blockIdx.x * EW; base < M; base += (uint64_t)gridDim.x * EW) {
     const uint64_t a = base + threadIdx.x;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(EW) void sortA_keys_hist_kernel(uint64_t M, const u
       key[a] = k;
       if (idx_out) idx_out[a] = i;
     }
-    swg_radix_hist_add(h, k, in, 0, key_bits, npasses);
+    swg_radix_hist_add(h, k, in, plan);
   }
   __syncthreads();
   swg_radix_hist_flush(h, npasses, ghist);
@@ -1811,7 +1811,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       const bool identity = M == n;
       SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
                                         M, identity ? nullptr : B.idxA, identity && !packed_sort ? B.idxA : nullptr, r->q_id, r->t_id,
-                                        r->strand, r->q_start, r->n_seq, pos_bits, B.keyA, key_bits, prehist));
+                                        r->strand, r->q_start, r->n_seq, pos_bits, B.keyA,
+                                        packed_sort ? swg_radix_plan_packed(key_bits) : swg_radix_plan_pairs(0, key_bits), prehist));
       SWG_KERNEL_CHECK(ctx);
       int prc = SWG_ERR_UNSUPPORTED;
       if (packed_sort)

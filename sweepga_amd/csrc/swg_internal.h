@@ -159,19 +159,43 @@ int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, ui
                           int val_bits, uint32_t* prehist, uint64_t** packed_out);
 // whether swg_radix_sort_packed will take this shape (so that the caller can leave an identity value array unwritten)
 bool swg_radix_sort_packed_applies(uint64_t n, int key_bits, int val_bits);
-constexpr int SWG_RADIX_BINS = 256;
+constexpr int SWG_RADIX_BINS = 512;  // row stride of the digit histograms: digits are 8 bits wide, 9 in some packed passes
 constexpr int SWG_RADIX_MAX_PASSES = 8;
+// The digits of a sort: pass p takes `bits[p]` key bits from bit `shift[p]` on.
+struct swg_radix_plan {
+  int npasses;
+  uint8_t shift[SWG_RADIX_MAX_PASSES];
+  uint8_t bits[SWG_RADIX_MAX_PASSES];
+};
+// swg_radix_sort_pairs: 8-bit digits over [begin_bit, end_bit) (npasses > 8: the three-kernel fallback takes the sort).
+static inline swg_radix_plan swg_radix_plan_pairs(int begin_bit, int end_bit) {
+  swg_radix_plan pl{};
+  const int np = (end_bit - begin_bit + 7) / 8;
+  pl.npasses = np > SWG_RADIX_MAX_PASSES ? 0 : np;
+  for (int p = 0; p < pl.npasses; ++p) {
+    pl.shift[p] = (uint8_t)(begin_bit + 8 * p);
+    pl.bits[p] = (uint8_t)(end_bit - (begin_bit + 8 * p) < 8 ? end_bit - (begin_bit + 8 * p) : 8);
+  }
+  return pl;
+}
+// swg_radix_sort_packed: the first pass takes the key's low 8 bits (the packed word drops exactly those); the rest is cut
+// into 9-bit digits where that saves a pass (34 remaining bits: 9 + 9 + 8 + 8 instead of five passes), else into 8-bit ones.
+// SWG_SORT_BITS8=1 (test knob): 8-bit digits everywhere.
+swg_radix_plan swg_radix_plan_packed(int key_bits);
 #ifdef __HIPCC__
-// Accumulates one key of every lane of the wavefront into the work-group's LDS histograms h[pass][bin] (256-thread
-// groups; zero them first, flush them with swg_radix_hist_flush).  High digits are usually the same for a whole
-// wavefront (segment bits): one add then instead of 64 serialised LDS atomics on one bin.
-__device__ __forceinline__ void swg_radix_hist_add(uint32_t (*h)[SWG_RADIX_BINS], uint64_t k, bool valid, int begin_bit,
-                                                   int end_bit, int npasses) {
+// Accumulates one key of every lane of the wavefront into the work-group's LDS histograms h[pass][bin] (zero them first,
+// flush them with swg_radix_hist_flush).  High digits are usually the same for a whole wavefront (segment bits): one add
+// then instead of 64 serialised LDS atomics on one bin.
+__device__ __forceinline__ void swg_radix_hist_zero(uint32_t (*h)[SWG_RADIX_BINS], int npasses) {
+  for (int p = 0; p < npasses; ++p)
+    for (int b = threadIdx.x; b < SWG_RADIX_BINS; b += blockDim.x) h[p][b] = 0;
+}
+__device__ __forceinline__ void swg_radix_hist_add(uint32_t (*h)[SWG_RADIX_BINS], uint64_t k, bool valid, const swg_radix_plan& pl) {
   const uint64_t vmask = __ballot(valid);
-  for (int p = 0; p < npasses; ++p) {
-    const int shift = begin_bit + 8 * p;
-    const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
-    const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
+#pragma unroll  // (constant indices into the plan: it stays in scalar registers instead of going through scratch)
+  for (int p = 0; p < SWG_RADIX_MAX_PASSES; ++p) {
+    if (p >= pl.npasses) break;
+    const uint32_t d = (uint32_t)(k >> pl.shift[p]) & ((1u << pl.bits[p]) - 1u);
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
     const bool uniform = __ballot(valid && d != d0) == 0 && (vmask & 1ull);
     if (uniform) {
@@ -182,10 +206,11 @@ __device__ __forceinline__ void swg_radix_hist_add(uint32_t (*h)[SWG_RADIX_BINS]
   }
 }
 __device__ __forceinline__ void swg_radix_hist_flush(uint32_t (*h)[SWG_RADIX_BINS], int npasses, uint32_t* ghist) {
-  for (int p = 0; p < npasses; ++p) {
-    const uint32_t c = h[p][threadIdx.x];
-    if (c) atomicAdd(&ghist[p * SWG_RADIX_BINS + threadIdx.x], c);
-  }
+  for (int p = 0; p < npasses; ++p)
+    for (int b = threadIdx.x; b < SWG_RADIX_BINS; b += blockDim.x) {
+      const uint32_t c = h[p][b];
+      if (c) atomicAdd(&ghist[p * SWG_RADIX_BINS + b], c);
+    }
 }
 #endif
 // Copies `count` u64 scalars from device to host (pinned), synchronising the stream.

@@ -467,51 +467,35 @@ __device__ __forceinline__ void os_rank_rows(uint32_t* wave_cnt, uint32_t d0, ui
   *r1 = prev1 + below1;
 }
 
-__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                              int begin_bit, int end_bit, int npasses,
+__global__ __launch_bounds__(OS_THREADS) void os_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, swg_radix_plan plan,
                                                               uint32_t* __restrict__ ghist) {
-  __shared__ uint32_t h[OS_MAX_PASSES][RS_RADIX];
-  for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+  __shared__ uint32_t h[OS_MAX_PASSES][SWG_RADIX_BINS];
+  swg_radix_hist_zero(h, plan.npasses);
   __syncthreads();
   for (uint64_t base = (uint64_t)blockIdx.x * OS_TILE; base < n; base += (uint64_t)gridDim.x * OS_TILE) {
 #pragma unroll 4
     for (int r = 0; r < OS_ITEMS; ++r) {
       const uint64_t i = base + (uint64_t)r * OS_THREADS + threadIdx.x;
       const bool valid = i < n;
-      const uint64_t k = valid ? keys[i] : 0ull;
-      const uint64_t vmask = __ballot(valid);
-      for (int p = 0; p < npasses; ++p) {
-        const int shift = begin_bit + 8 * p;
-        const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
-        const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
-        // high digits are usually the same for a whole wavefront (sorted-ish / segment bits): one add then,
-        // instead of 64 serialised LDS atomics on one bin
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-        const bool uniform = __ballot(valid && d != d0) == 0 && (vmask & 1ull);
-        if (uniform) {
-          if ((threadIdx.x & 63) == 0) atomicAdd(&h[p][d0], (uint32_t)__popcll(vmask));
-        } else if (valid) {
-          atomicAdd(&h[p][d], 1u);
-        }
-      }
+      swg_radix_hist_add(h, valid ? keys[i] : 0ull, valid, plan);
     }
   }
   __syncthreads();
-  for (int p = 0; p < npasses; ++p) {
-    const uint32_t c = h[p][threadIdx.x];
-    if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
-  }
+  swg_radix_hist_flush(h, plan.npasses, ghist);
 }
 
-// one block per pass: exclusive scan of its 256 bins, in place
-__global__ __launch_bounds__(RS_RADIX) void os_scan_hist_kernel(uint32_t* __restrict__ ghist) {
-  __shared__ uint32_t lds_wave[RS_RADIX / 64];
-  __shared__ uint32_t lds_prev[RS_RADIX];
-  uint32_t* row = ghist + (size_t)blockIdx.x * RS_RADIX;
+// one block per pass: exclusive scan of its (up to 512) bins, in place
+__global__ __launch_bounds__(SWG_RADIX_BINS) void os_scan_hist_kernel(uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t wsum[SWG_RADIX_BINS / 64];
+  uint32_t* row = ghist + (size_t)blockIdx.x * SWG_RADIX_BINS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t v = row[threadIdx.x];
-  uint32_t tot;
-  const uint32_t ex = block_exclusive_scan<0>(v, &tot, lds_wave, lds_prev);
-  row[threadIdx.x] = ex;
+  const uint32_t inc = wave_inclusive_scan<0>(v, lane);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  row[threadIdx.x] = base + inc - v;
 }
 
 // Decoupled look-back of one digit (thread = digit) of tile `tile`: publishes the tile's count, sums the counts of the tiles
@@ -522,9 +506,9 @@ __global__ __launch_bounds__(RS_RADIX) void os_scan_hist_kernel(uint32_t* __rest
 #endif
 constexpr int OS_LOOKBACK = SWG_OS_LOOKBACK;  // predecessors read per round trip
 template <typename ST>
-__device__ __forceinline__ ST os_lookback(ST* status, uint32_t tile, int tid, uint32_t tot) {
+__device__ __forceinline__ ST os_lookback(ST* status, uint32_t tile, int tid, uint32_t tot, int bins = RS_RADIX) {
   using W = os_word<ST>;
-  ST* my = status + (size_t)tile * RS_RADIX + tid;
+  ST* my = status + (size_t)tile * bins + tid;
   if (tile == 0) {
     __hip_atomic_store(my, W::GLOBAL | (ST)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return 0;
@@ -537,7 +521,7 @@ __device__ __forceinline__ ST os_lookback(ST* status, uint32_t tile, int tid, ui
 #pragma unroll
     for (int j = 0; j < OS_LOOKBACK; ++j) {
       const uint32_t t = tt >= (uint32_t)j ? tt - j : 0u;  // (tile 0 ends every walk: it only ever publishes GLOBAL)
-      sv[j] = __hip_atomic_load(status + (size_t)t * RS_RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sv[j] = __hip_atomic_load(status + (size_t)t * bins + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool done = false;
     int used = 0;
@@ -802,6 +786,130 @@ __global__ __launch_bounds__(PK_THREADS) void os_pass_packed_kernel(const uint64
   }
 }
 
+// A packed pass over a 9-bit digit (512 bins): one pass fewer where the key bits left after the first pass divide into
+// fewer 9-bit than 8-bit digits (34 bits: 9 + 9 + 8 + 8).  Same structure as the 8-bit pass; what differs:
+//   * the per-wave running counters are 16-bit halves of 256 words (digit d: word d & 255, half d >> 8; a wave holds at most
+//     1024 elements of a digit, a tile 8192) so that the LDS footprint stays at two work-groups per CU; the add of a row's
+//     peers goes to the word, shifted into its half;
+//   * threads 0..255 turn the counters of BOTH digits of their word into offsets -- the two tile-exclusive prefixes come out of
+//     one 256-wide scan over (low count | high count << 16), the high digits' prefix starts at the total of the low ones -- and
+//     hand the high digit's count to thread 256 + t, so that all 512 digits look back at once.
+constexpr int P9_BINS = 512;
+__device__ __forceinline__ void os_rank_rows9(uint32_t* wave_cnt, uint32_t d0, uint32_t d1, uint32_t* r0, uint32_t* r1) {
+  os_match a{~0u, ~0u}, b{~0u, ~0u};
+  const uint32_t w0 = __hip_atomic_load(wave_cnt + (d0 & 255u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+  for (int bit = 0; bit < 9; ++bit) {
+    os_match_step(a, d0, bit);
+    os_match_step(b, d1, bit);
+  }
+  const uint32_t below0 = a.below(), below1 = b.below();
+  if (below0 == 0)
+    __hip_atomic_fetch_add(wave_cnt + (d0 & 255u), a.peers() << ((d0 >> 8) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t w1 = __hip_atomic_load(wave_cnt + (d1 & 255u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (below1 == 0)
+    __hip_atomic_fetch_add(wave_cnt + (d1 & 255u), b.peers() << ((d1 >> 8) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  *r0 = ((w0 >> ((d0 >> 8) * 16)) & 0xffffu) + below0;
+  *r1 = ((w1 >> ((d1 >> 8) * 16)) & 0xffffu) + below1;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(PK_THREADS) void os_pass_packed9_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                                      uint64_t n, int shift, const uint32_t* __restrict__ gbase,
+                                                                      ST* status, uint32_t* ticket) {
+  __shared__ uint64_t lkeys[PK_TILE];
+  __shared__ uint32_t cnt[PK_WAVES][256];  // two 16-bit counters per word
+  __shared__ uint32_t dst_base[P9_BINS];
+  __shared__ uint32_t hi_tot[256], hi_ex[256];
+  __shared__ uint32_t lds_wave[PK_THREADS / 64];
+  __shared__ uint32_t lds_prev[PK_THREADS];
+  __shared__ uint32_t s_tile;
+  static_assert(PK_THREADS == P9_BINS, "one thread per digit in the look-back");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  const uint32_t gb = gbase[tid];
+  for (int i = tid; i < PK_WAVES * 256; i += PK_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t tile_base = (uint64_t)tile * PK_TILE;
+  const uint64_t wbase = tile_base + (uint64_t)wave * (64 * PK_ITEMS);
+  uint64_t key[PK_ITEMS];
+  uint32_t dig[PK_ITEMS];
+  uint32_t rank[PK_ITEMS];
+  if (tile_base + PK_TILE <= n) {  // every tile but the last: no bounds checks
+#pragma unroll
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      key[r] = in[wbase + (uint64_t)r * 64 + lane];
+      dig[r] = (uint32_t)(key[r] >> shift) & (P9_BINS - 1);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+      key[r] = i < n ? in[i] : ~0ull;
+      dig[r] = (uint32_t)(key[r] >> shift) & (P9_BINS - 1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PK_ITEMS; r += 2) os_rank_rows9(cnt[wave], dig[r], dig[r + 1], &rank[r], &rank[r + 1]);
+  __syncthreads();
+  {
+    uint32_t tot = 0;  // low count | high count << 16 of this thread's word (threads 0..255)
+    if (tid < 256) {
+#pragma unroll
+      for (int w = 0; w < PK_WAVES; ++w) {
+        const uint32_t c = cnt[w][tid];
+        cnt[w][tid] = tot;  // exclusive over waves, both halves at once (a tile holds 8192 elements: no carry)
+        tot += c;
+      }
+    }
+    uint32_t block_total;
+    const uint32_t ex = block_exclusive_scan<0>(tot, &block_total, lds_wave, lds_prev);  // (threads >= 256 only keep step)
+    uint32_t my_tot, my_ex;
+    if (tid < 256) {
+      const uint32_t ex_lo = ex & 0xffffu, ex_hi = (block_total & 0xffffu) + (ex >> 16);
+#pragma unroll
+      for (int w = 0; w < PK_WAVES; ++w) cnt[w][tid] += ex_lo | (ex_hi << 16);  // slots of the waves' first elements
+      hi_tot[tid] = tot >> 16;
+      hi_ex[tid] = ex_hi;
+      my_tot = tot & 0xffffu;
+      my_ex = ex_lo;
+    }
+    __syncthreads();
+    if (tid >= 256) {
+      my_tot = hi_tot[tid - 256];
+      my_ex = hi_ex[tid - 256];
+    }
+    const ST excl = os_lookback<ST>(status, tile, tid, my_tot, P9_BINS);
+    dst_base[tid] = gb + (uint32_t)excl - my_ex;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PK_ITEMS; ++r) {
+    rank[r] += (cnt[wave][dig[r] & 255u] >> ((dig[r] >> 8) * 16)) & 0xffffu;  // the element's slot in the tile
+    lkeys[rank[r]] = key[r];
+  }
+  __syncthreads();
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)PK_TILE ? (n - tile_base) : (uint64_t)PK_TILE);
+  if (tile_n == (uint32_t)PK_TILE) {
+#pragma unroll
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
+      const uint64_t k = lkeys[p];
+      out[dst_base[(uint32_t)(k >> shift) & (P9_BINS - 1)] + p] = k;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < PK_ITEMS; ++r) {
+      const uint32_t p = (uint32_t)r * PK_THREADS + tid;
+      if (p < tile_n) {
+        const uint64_t k = lkeys[p];
+        out[dst_base[(uint32_t)(k >> shift) & (P9_BINS - 1)] + p] = k;
+      }
+    }
+  }
+}
+
 // Fallback (n >= 2^30): histogram / scan / scatter per pass.
 int radix_sort_three_kernel(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                             uint64_t n, int begin_bit, int end_bit) {
@@ -831,12 +939,42 @@ int radix_sort_three_kernel(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint
 
 }  // namespace
 
-static_assert(SWG_RADIX_BINS == RS_RADIX && SWG_RADIX_MAX_PASSES == OS_MAX_PASSES, "prehist layout");
+static_assert(SWG_RADIX_BINS == 2 * RS_RADIX && SWG_RADIX_MAX_PASSES == OS_MAX_PASSES, "prehist layout");
+
+swg_radix_plan swg_radix_plan_packed(int key_bits) {
+  static const bool bits8 = getenv("SWG_SORT_BITS8") != nullptr;
+  swg_radix_plan pl{};
+  pl.shift[0] = 0;
+  pl.bits[0] = (uint8_t)(key_bits < 8 ? key_bits : 8);
+  pl.npasses = 1;
+  const int rest = key_bits - 8;
+  if (rest <= 0) return pl;
+  const int q8 = (rest + 7) / 8, q9 = (rest + 8) / 9;
+  if (bits8 || q9 == q8) {
+    for (int p = 0; p < q8; ++p) {
+      pl.shift[1 + p] = (uint8_t)(8 + 8 * p);
+      pl.bits[1 + p] = (uint8_t)(rest - 8 * p < 8 ? rest - 8 * p : 8);
+    }
+    pl.npasses = 1 + q8;
+  } else {  // q9 passes, as even as possible: the first `extra` of them one bit wider (at most 9)
+    const int base = rest / q9, extra = rest % q9;
+    int at = 8;
+    for (int p = 0; p < q9; ++p) {
+      const int b = base + (p < extra ? 1 : 0);
+      pl.shift[1 + p] = (uint8_t)at;
+      pl.bits[1 + p] = (uint8_t)b;
+      at += b;
+    }
+    pl.npasses = 1 + q9;
+  }
+  return pl;
+}
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                          uint64_t n, int begin_bit, int end_bit, uint32_t* prehist) {
   if (n <= 1 || end_bit <= begin_bit) return SWG_OK;
   if (n >= (uint64_t(1) << 32)) return swg_set_error(ctx, SWG_ERR_RANGE, "radix sort: n >= 2^32");
   const int npasses = (end_bit - begin_bit + 7) / 8;
+  const swg_radix_plan plan = swg_radix_plan_pairs(begin_bit, end_bit);
   // SWG_SORT_FALLBACK=1 forces the histogram/scan/scatter path (otherwise only reached for n >= 2^30) so that the
   // tests can exercise it at small sizes
   // SWG_SORT_WIDE=1 forces the 64-bit look-back words (otherwise only used for n >= 2^30)
@@ -849,19 +987,19 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
   const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
   const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
-  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
+  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * SWG_RADIX_BINS);
   void* status = swg_arena_alloc(ctx, (size_t)ntiles * RS_RADIX * word);
   uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
   {
     if (!prehist) {
-      SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
+      SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * SWG_RADIX_BINS, ctx->stream));
       uint32_t hb = htiles < (uint32_t)ctx->num_cu * 8 ? htiles : (uint32_t)ctx->num_cu * 8;
-      SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, begin_bit, end_bit, npasses, ghist));
+      SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(*keys, n, plan, ghist));
       SWG_KERNEL_CHECK(ctx);
     }
-    SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, RS_RADIX, 0, ctx->stream>>>(ghist));
+    SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, SWG_RADIX_BINS, 0, ctx->stream>>>(ghist));
     SWG_KERNEL_CHECK(ctx);
   }
   for (int p = 0; p < npasses; ++p) {
@@ -871,11 +1009,11 @@ int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_
     SWG_HIP(ctx, hipMemsetAsync(status, 0, word * (size_t)ntiles * RS_RADIX, ctx->stream));
     if (wide)
       SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint64_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
-                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
+                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * SWG_RADIX_BINS,
                                      static_cast<uint64_t*>(status), tickets + p));
     else
       SWG_LAUNCH_N(ctx, "os_pass", n, os_pass_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
-                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * RS_RADIX,
+                                     *keys, *vals, *keys_alt, *vals_alt, n, shift, mask, ghist + (size_t)p * SWG_RADIX_BINS,
                                      static_cast<uint32_t*>(status), tickets + p));
     SWG_KERNEL_CHECK(ctx);
     uint64_t* tk = *keys;
@@ -900,38 +1038,42 @@ bool swg_radix_sort_packed_applies(uint64_t n, int key_bits, int val_bits) {
 
 int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, uint64_t* scratch, uint64_t n, int key_bits,
                           int val_bits, uint32_t* prehist, uint64_t** packed_out) {
-  const int npasses = (key_bits + 7) / 8;
   if (!swg_radix_sort_packed_applies(n, key_bits, val_bits)) return SWG_ERR_UNSUPPORTED;
+  const swg_radix_plan plan = swg_radix_plan_packed(key_bits);
+  const int npasses = plan.npasses;
   const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
   const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
   swg_arena_mark mark = swg_arena_save(ctx);
-  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * RS_RADIX);
-  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * RS_RADIX);
+  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * SWG_RADIX_BINS);
+  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * SWG_RADIX_BINS);
   uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
   if (!prehist) {
-    SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * RS_RADIX, ctx->stream));
+    SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * SWG_RADIX_BINS, ctx->stream));
     uint32_t hb = htiles < (uint32_t)ctx->num_cu * 8 ? htiles : (uint32_t)ctx->num_cu * 8;
-    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(keys, n, 0, key_bits, npasses, ghist));
+    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(keys, n, plan, ghist));
     SWG_KERNEL_CHECK(ctx);
   }
-  SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, RS_RADIX, 0, ctx->stream>>>(ghist));
+  SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, SWG_RADIX_BINS, 0, ctx->stream>>>(ghist));
   SWG_KERNEL_CHECK(ctx);
   uint64_t* src = keys;
   uint64_t* dst = scratch;
   for (int p = 0; p < npasses; ++p) {
-    const int kshift = 8 * p;
-    const int bits = key_bits - kshift < 8 ? key_bits - kshift : 8;
+    const int bits = plan.bits[p];
     const uint32_t mask = (1u << bits) - 1u;
-    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * RS_RADIX, ctx->stream));
+    const int wshift = val_bits + plan.shift[p] - 8;  // where the digit sits in the packed word (p >= 1)
+    const uint32_t* gb = ghist + (size_t)p * SWG_RADIX_BINS;
+    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * (bits == 9 ? P9_BINS : RS_RADIX), ctx->stream));
     if (p == 0)
       SWG_LAUNCH_N(ctx, "os_pass_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
-                                             src, vals, dst, n, 0, mask, val_bits, ghist, status, tickets));
+                                             src, vals, dst, n, 0, mask, val_bits, gb, status, tickets));
+    else if (bits == 9)
+      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed9_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
+                                              src, dst, n, wshift, gb, status, tickets + p));
     else
       SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
-                                              src, nullptr, dst, n, val_bits + 8 * (p - 1), mask, val_bits,
-                                              ghist + (size_t)p * RS_RADIX, status, tickets + p));
+                                              src, nullptr, dst, n, wshift, mask, val_bits, gb, status, tickets + p));
     SWG_KERNEL_CHECK(ctx);
     uint64_t* t = src;
     src = dst;

@@ -142,14 +142,14 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
                                                                  const uint32_t* __restrict__ start,
                                                                  const uint8_t* __restrict__ alive, int pos_bits,
                                                                  uint64_t* __restrict__ key,
-                                                                 uint32_t* __restrict__ val, int key_bits,
+                                                                 uint32_t* __restrict__ val, swg_radix_plan plan,
                                                                  uint32_t* __restrict__ ghist) {
   // grid-stride over whole work-groups (the trip count is block-uniform); with `ghist` the digit histograms of the sort
   // that follows are accumulated here, while the key is in a register (the sort then skips its own pass over the keys)
   __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
-  const int npasses = (key_bits + 7) / 8;
+  const int npasses = plan.npasses;
   if (ghist) {
-    for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
+    swg_radix_hist_zero(h, npasses);
     __syncthreads();
   }
   for (uint64_t base = (uint64_t)blockIdx.x * EW_THREADS; base < n; base += (uint64_t)gridDim.x * EW_THREADS) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
       key[i] = k;
       if (val) val[i] = (uint32_t)i;  // (nullptr: the packed sort takes the identity as read)
     }
-    if (ghist) swg_radix_hist_add(h, k, in, 0, key_bits, npasses);
+    if (ghist) swg_radix_hist_add(h, k, in, plan);
   }
   if (ghist) {
     __syncthreads();
@@ -1333,7 +1333,8 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       const unsigned full = blocks_for(n, EW_THREADS), cap = (unsigned)ctx->num_cu * 16;
       SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<(prehist && full > cap) ? cap : full, EW_THREADS, 0, st>>>(
                                          n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S,
-                                         packed_sort ? nullptr : I, key_bits, prehist));
+                                         packed_sort ? nullptr : I, packed_sort ? swg_radix_plan_packed(key_bits) : swg_radix_plan_pairs(0, key_bits),
+                                         prehist));
     }
     SWG_KERNEL_CHECK(ctx);
     uint64_t* P = nullptr;
