@@ -45,6 +45,7 @@ namespace {
 constexpr int TB = 256;  // begins per tile == threads per workgroup
 constexpr int CC = 256;  // carry-in entries staged per LDS chunk
 constexpr int EW_THREADS = 256;
+constexpr uint64_t DEEP_CARRY_PER_TILE = 64;  // average carry-ins per 256-begin tile from which k = 1 uses 512-begin tiles
 
 __device__ __forceinline__ bool prio_less(uint64_t ak, uint64_t as, uint32_t ai, uint64_t bk, uint64_t bs,
                                           uint32_t bi) {
@@ -256,6 +257,13 @@ __device__ __forceinline__ uint64_t swg_comp_end(uint64_t s, uint32_t e, int pos
   return s ? ((s >> pos_bits) << pos_bits) | e : 0ull;
 }
 
+// first keys of the 512-begin tiles = every second one of the 256-begin tiles
+__global__ __launch_bounds__(EW_THREADS) void tile_x_pairs_kernel(uint32_t ntiles2, const uint64_t* __restrict__ tile_x,
+                                                                  uint64_t* __restrict__ tile_x2) {
+  const uint32_t b = blockIdx.x * EW_THREADS + threadIdx.x;
+  if (b < ntiles2) tile_x2[b] = tile_x[2 * (size_t)b];
+}
+
 // ---- routing: carry-ins and end points ----------------------------------------------------------
 // te = last tile b with X_b < E (>= the interval's own tile).  Exponential then binary search.
 __device__ __forceinline__ uint32_t last_tile_below(const uint64_t* __restrict__ tile_x, uint32_t ntiles, uint32_t tb,
@@ -279,32 +287,59 @@ __device__ __forceinline__ uint32_t last_tile_below(const uint64_t* __restrict__
   return l - 1;
 }
 
+// mode 0: 256-begin tiles; 1: 512-begin tiles; 2: chosen here from the estimate (route_estimate_kernel) -- the host learns the
+// choice from the same read-back that tells it the carry-in total
 __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, const uint64_t* __restrict__ S,
                                                                  const uint32_t* __restrict__ E, int pos_bits,
                                                                  const uint64_t* __restrict__ tile_x, uint32_t ntiles,
+                                                                 const uint64_t* __restrict__ tile_x2, uint32_t ntiles2, int mode,
+                                                                 const unsigned long long* __restrict__ reach, uint32_t stride,
                                                                  uint32_t* __restrict__ te_out,
                                                                  uint32_t* __restrict__ carry_cnt) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
+  const bool wide = mode == 1 || (mode == 2 && *reach * stride / ntiles >= DEEP_CARRY_PER_TILE);
+  const uint64_t* tx = wide ? tile_x2 : tile_x;
+  const uint32_t nt = wide ? ntiles2 : ntiles;
   const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits);
-  const uint32_t tb = (uint32_t)(p / TB);
+  const uint32_t tb = (uint32_t)(p / (wide ? 2 * TB : TB));
   uint32_t te = tb;
   if (s != 0 && e > s) {  // live and not zero-length
-    te = last_tile_below(tile_x, ntiles, tb, e);
+    te = last_tile_below(tx, nt, tb, e);
     for (uint32_t b = tb + 1; b <= te; ++b) atomicAdd(&carry_cnt[b], 1u);
   }
   te_out[p] = te;
 }
 
+// Estimate of the carry-in volume (sum over intervals of the tiles they reach into beyond their own) from every
+// `stride`-th begin: searches only, no per-tile counting.  Chooses the tile size before the real routing pass.
+__global__ __launch_bounds__(EW_THREADS) void route_estimate_kernel(uint64_t n, uint32_t stride, const uint64_t* __restrict__ S,
+                                                                    const uint32_t* __restrict__ E, int pos_bits,
+                                                                    const uint64_t* __restrict__ tile_x, uint32_t ntiles,
+                                                                    unsigned long long* __restrict__ out) {
+  const uint64_t p = ((uint64_t)blockIdx.x * EW_THREADS + threadIdx.x) * stride;
+  uint32_t reach = 0;
+  if (p < n) {
+    const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits);
+    if (s != 0 && e > s) {
+      const uint32_t tb = (uint32_t)(p / TB);
+      reach = last_tile_below(tile_x, ntiles, tb, e) - tb;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) reach += __shfl_down(reach, o, 64);
+  if ((threadIdx.x & 63) == 0 && reach) atomicAdd(out, (unsigned long long)reach);
+}
+
 __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
     uint64_t n, const uint64_t* __restrict__ S, const uint32_t* __restrict__ E, int pos_bits, const uint64_t* __restrict__ KEY,
-    const uint32_t* __restrict__ I, const uint32_t* __restrict__ te_in, const uint32_t* __restrict__ carry_off,
+    const uint32_t* __restrict__ I, uint32_t tile_size, const uint32_t* __restrict__ te_in, const uint32_t* __restrict__ carry_off,
     uint32_t* __restrict__ carry_cur, uint64_t* __restrict__ c_s, uint64_t* __restrict__ c_e,
     uint64_t* __restrict__ c_key, uint32_t* __restrict__ c_id) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
   const uint32_t te = te_in[p];
-  const uint32_t tb = (uint32_t)(p / TB);
+  const uint32_t tb = (uint32_t)(p / tile_size);
   if (te <= tb) return;
   const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits), k = KEY[p];
   const uint32_t id = I[p];
@@ -368,22 +403,23 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 constexpr int CCAP = 128;     // candidate carry-ins kept in LDS (17 KB per work-group in all: 8 resident per CU)
 constexpr int STAR_MIN = 32;  // fewer carry-ins than this: no pruning (nothing to gain on sparse data)
 
-__global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
-  __shared__ uint64_t sx[TB];    // composite start of begin q
-  __shared__ uint64_t se2[2 * TB];   // [0, TB): its composite end; [TB, 2 TB): the same for candidates, 0 for the others
-  __shared__ uint64_t spm2[2 * TB];  // prefix maxima of the two halves of se2
-  __shared__ uint64_t skey[TB];      // its score key
-  __shared__ uint32_t sid[TB];   // its interval index
-  __shared__ uint64_t wmax[TB / 64];
+template <int TBT>
+__global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
+  __shared__ uint64_t sx[TBT];    // composite start of begin q
+  __shared__ uint64_t se2[2 * TBT];   // [0, TBT): its composite end; [TBT, 2 TBT): the same for candidates, 0 for the others
+  __shared__ uint64_t spm2[2 * TBT];  // prefix maxima of the two halves of se2
+  __shared__ uint64_t skey[TBT];      // its score key
+  __shared__ uint32_t sid[TBT];   // its interval index
+  __shared__ uint64_t wmax[TBT / 64];
   __shared__ uint64_t ls[CCAP], le[CCAP], lkey[CCAP];  // candidate carry-ins
   __shared__ uint32_t lid[CCAP];
   __shared__ uint32_t l_count;
-  __shared__ uint64_t r_k[TB / 64], r_s[TB / 64], r_e[TB / 64];
-  __shared__ uint32_t r_i[TB / 64], r_have[TB / 64];
+  __shared__ uint64_t r_k[TBT / 64], r_s[TBT / 64], r_e[TBT / 64];
+  __shared__ uint32_t r_i[TBT / 64], r_have[TBT / 64];
 
   const uint32_t tile_id = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t p = (uint64_t)tile_id * TB + tid;
+  const uint64_t p = (uint64_t)tile_id * TBT + tid;
   const bool valid = p < a.n;
   uint64_t X = ~0ull, EE = 0, KEY = 0;
   uint32_t ID = 0;
@@ -408,7 +444,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     if (lane == 63) wmax[wave] = m;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < TB / 64; ++w)
+    for (int w = 0; w < TBT / 64; ++w)
       if (w < wave && wmax[w] > m) m = wmax[w];
     dst[tid] = m;
     __syncthreads();
@@ -449,7 +485,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < TB / 64; ++w)
+    for (int w = 0; w < TBT / 64; ++w)
       if (r_have[w] && (!have_star || prio_less(r_k[w], r_s[w], r_i[w], star_k, star_s, star_i))) {
         star_k = r_k[w];
         star_s = r_s[w];
@@ -484,7 +520,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     bool hv = false;
     uint64_t bk = 0, bs = 0, be = 0;
     uint32_t bi = 0;
-    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+    for (uint32_t c = c_begin + tid; c < c_end; c += TBT) {
       const uint64_t e = a.c_e[c];
       if (e >= x_next) {
         const uint64_t k = a.c_key[c], s = a.c_s[c];
@@ -500,7 +536,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     }
     reduce_star(hv, bk, bs, be, bi);
     // candidates: end inside the tile's range and (no S* or better than S*); without S* every carry-in ends inside
-    for (uint32_t c = c_begin + tid; c < c_end; c += TB) {
+    for (uint32_t c = c_begin + tid; c < c_end; c += TBT) {
       const uint64_t e = a.c_e[c];
       if (e < x_next) {
         const uint64_t k = a.c_key[c], s = a.c_s[c];
@@ -523,9 +559,9 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
   int o1 = 0;  // offset of the candidate view in se2 / spm2 (no S*: every begin is a candidate)
   if (have_star) {  // block-uniform
     const bool cand = valid && X != 0 && prio_less(KEY, X, ID, star_k, star_s, star_i);
-    se2[TB + tid] = cand ? EE : 0;
-    block_prefix_max(cand ? EE : 0, spm2 + TB);
-    o1 = TB;
+    se2[TBT + tid] = cand ? EE : 0;
+    block_prefix_max(cand ? EE : 0, spm2 + TBT);
+    o1 = TBT;
   } else if (n_carry != 0) {
     __syncthreads();
   }
@@ -534,7 +570,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     cc_in_lds = n_cc <= CCAP;  // else: every carry-in is scanned from global memory (a superset is harmless)
   }
   const bool cc_complete = cc_in_lds && !have_star;  // the LDS list holds every carry-in of the tile
-  const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TB - 1) / TB);
+  const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TBT - 1) / TBT);
   const bool pass2 = a.thr < 1.0;
 
   for (uint32_t batch = 0; batch < n_batches; ++batch) {
@@ -545,7 +581,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
     uint64_t PK = KEY, PS = X;  // priority of the interval whose end is the point (batches >= 1)
     uint32_t PI = ID;
     if (batch == 0) {  // start coordinates: the last begin of each run, unless the run continues in the next tile
-      eval = valid && X != 0 && (tid == TB - 1 || sx[tid + 1] != X) && X != x_next;
+      eval = valid && X != 0 && (tid == TBT - 1 || sx[tid + 1] != X) && X != x_next;
       PX = X;
       Q0 = tid;
     } else {
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
           PI = lid[tid];
         }
       } else {
-        const uint32_t ci = c_begin + (batch - 2) * TB + tid;
+        const uint32_t ci = c_begin + (batch - 2) * TBT + tid;
         eval = ci < c_end;
         PX = eval ? a.c_e[ci] : 0;
         eval = eval && PX < x_next;
@@ -573,7 +609,7 @@ __global__ __launch_bounds__(TB) void sweep_tile_k1_kernel(TileArgs a) {
           PI = a.c_id[ci];
         }
       }
-      int l = 0, r = TB;  // upper_bound(sx, PX) - 1; sx is ~0 past the end of a short last tile
+      int l = 0, r = TBT;  // upper_bound(sx, PX) - 1; sx is ~0 past the end of a short last tile
       while (l < r) {
         const int mid = (l + r) >> 1;
         if (sx[mid] <= PX)
@@ -1302,7 +1338,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   if (key_bits > 64)
     return swg_set_error(ctx, SWG_ERR_RANGE, "sweep: segment id (%d bits) + coordinate (%d bits) exceed 64 bits",
                          in.seg_bits, in.pos_bits);
-  const uint32_t ntiles = (uint32_t)((n + TB - 1) / TB);
+  uint32_t ntiles = (uint32_t)((n + TB - 1) / TB);
 
   // sorted begins + gathered columns + `single` flags (shared by the k = inf and the general path)
   uint64_t* S = nullptr;
@@ -1399,11 +1435,48 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* carry_cur = cnts + ((size_t)ntiles + 1);
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 2 * n_pad, st));
   SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 2 * ((size_t)ntiles + 1), st));
-  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(n, S, E, in.pos_bits, tile_x, ntiles, te, carry_cnt));
+  // Deep data (a tile's carry-in list is long: one chromosome pair at depth 165 has ~150 per 256-begin tile): tiles of 512
+  // begins -- half as many carry-in entries to route and stage, half as many tiles -- are faster there for k = 1 (S-big1 sweep
+  // 9.6 -> 8.8 ms) and slower on sparse data (S-pan's tile kernel 3.0 -> 3.7 ms), so the tiling is chosen by an estimate of
+  // the average list length from every 1021st begin.  The choice is made on the device (the routing pass reads the estimate)
+  // and comes back with the carry-in total: no extra synchronisation.  SWG_TILE_512=1 / SWG_TILE_256=1 (test knobs) force
+  // either.
+  constexpr uint32_t EST_STRIDE = 1021;  // (prime: the samples fall on every position inside a tile)
+  uint32_t tile_size = TB;
+  int mode = 0;
+  uint64_t* tile_x2 = tile_x;
+  uint32_t ntiles2 = ntiles;
+  SWG_HIP(ctx, hipMemsetAsync(d_total, 0, 2 * sizeof(uint64_t), st));
+  if (k == 1 && ntiles > 1) {
+    static const bool force512 = getenv("SWG_TILE_512") != nullptr, force256 = getenv("SWG_TILE_256") != nullptr;
+    mode = force512 ? 1 : force256 ? 0 : 2;
+    if (mode) {
+      ntiles2 = (uint32_t)((n + 2 * TB - 1) / (2 * TB));
+      tile_x2 = swg_alloc<uint64_t>(ctx, (size_t)ntiles2 + 1);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles2, EW_THREADS), EW_THREADS, 0, st>>>(ntiles2, tile_x, tile_x2));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    if (mode == 2) {
+      SWG_LAUNCH(ctx, "route_estimate", route_estimate_kernel<<<blocks_for((n + EST_STRIDE - 1) / EST_STRIDE, EW_THREADS), EW_THREADS, 0, st>>>(
+                                            n, EST_STRIDE, S, E, in.pos_bits, tile_x, ntiles, reinterpret_cast<unsigned long long*>(d_total + 1)));
+      SWG_KERNEL_CHECK(ctx);
+    }
+  }
+  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+                                     n, S, E, in.pos_bits, tile_x, ntiles, tile_x2, ntiles2, mode, reinterpret_cast<unsigned long long*>(d_total + 1),
+                                     EST_STRIDE, te, carry_cnt));
   SWG_KERNEL_CHECK(ctx);
+  // (scanned over the 256-begin tiling's length either way: the entries past a 512-begin tiling's end are zero)
   SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)ntiles + 1, d_total));
-  uint64_t n_carry = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_total, &n_carry, 1));
+  uint64_t h2[2] = {0, 0};
+  SWG_TRY(swg_read_scalars(ctx, d_total, h2, 2));
+  const uint64_t n_carry = h2[0];
+  if (mode == 1 || (mode == 2 && h2[1] * EST_STRIDE / ntiles >= DEEP_CARRY_PER_TILE)) {  // the kernel's rule
+    tile_size = 2 * TB;
+    tile_x = tile_x2;
+    ntiles = ntiles2;
+  }
   uint64_t* c_s = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_e = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_key = swg_alloc<uint64_t>(ctx, n_carry + 1);
@@ -1411,7 +1484,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   SWG_CHECK_ARENA(ctx);
   if (n_carry) {
     SWG_LAUNCH(ctx, "route_fill", route_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                      n, S, E, in.pos_bits, KEY, I, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
+                                      n, S, E, in.pos_bits, KEY, I, tile_size, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
     SWG_KERNEL_CHECK(ctx);
   }
   TileArgs ta;
@@ -1434,7 +1507,10 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.ovl = ovl;
   ta.tile_done = nullptr;
   if (k == 1) {
-    SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<<<ntiles, TB, 0, st>>>(ta));
+    if (tile_size == (uint32_t)TB)
+      SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<TB><<<ntiles, TB, 0, st>>>(ta));
+    else
+      SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<2 * TB><<<ntiles, 2 * TB, 0, st>>>(ta));
   } else {
     static const bool no_prune = getenv("SWG_KN_PLAIN") != nullptr;  // test knob: every tile through the plain kernel
     if (k <= (uint64_t)KSTAR_MAX && !no_prune) {

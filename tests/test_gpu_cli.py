@@ -80,7 +80,7 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_SORT_PAIRS", "SWG_SORT_BITS8", "SWG_CHAIN_DEEP", "SWG_CHAIN_OLD", "SWG_KN_PLAIN"])
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_SORT_PAIRS", "SWG_SORT_BITS8", "SWG_CHAIN_DEEP", "SWG_CHAIN_OLD", "SWG_KN_PLAIN", "SWG_TILE_512"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
     onesweep pass (otherwise only used for n >= 2^30), SWG_SORT_PAIRS=1 keeps the sweep's begins in 12-byte (key, index) pairs
@@ -88,7 +88,8 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     (otherwise 9-bit ones where they save a pass), SWG_CHAIN_OLD=1 the per-step selection kernels of round 2
     instead of the batch walk, SWG_CHAIN_DEEP=1 the wavefront-per-element candidate kernel of deep
     chaining groups (otherwise only used when groups average more than 8192 mappings), SWG_KN_PLAIN=1 sends every tile of a
-    2 <= k < inf sweep through the plain tile kernel (otherwise only the tiles the pruned kernel leaves)."""
+    2 <= k < inf sweep through the plain tile kernel (otherwise only the tiles the pruned kernel leaves), SWG_TILE_512=1 gives
+    every k = 1 sweep 512-begin tiles (otherwise only deep data: 64 carry-ins per 256-begin tile on average)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
