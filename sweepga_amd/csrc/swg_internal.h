@@ -192,10 +192,17 @@ __device__ __forceinline__ void swg_radix_hist_zero(uint32_t (*h)[SWG_RADIX_BINS
 }
 __device__ __forceinline__ void swg_radix_hist_add(uint32_t (*h)[SWG_RADIX_BINS], uint64_t k, bool valid, const swg_radix_plan& pl) {
   const uint64_t vmask = __ballot(valid);
-#pragma unroll  // (constant indices into the plan: it stays in scalar registers instead of going through scratch)
-  for (int p = 0; p < SWG_RADIX_MAX_PASSES; ++p) {
-    if (p >= pl.npasses) break;
-    const uint32_t d = (uint32_t)(k >> pl.shift[p]) & ((1u << pl.bits[p]) - 1u);
+  // the plan's two byte arrays as two 64-bit scalars: pass p's shift and width come out by shifting, the loop stays rolled
+  // (indexing the arrays sends the plan through scratch; unrolling all eight passes doubles the scalar work of kernels that
+  // are bound by the scalar unit)
+  uint64_t sh64, b64;
+  __builtin_memcpy(&sh64, pl.shift, 8);
+  __builtin_memcpy(&b64, pl.bits, 8);
+  static_assert(SWG_RADIX_MAX_PASSES == 8, "one byte per pass in a 64-bit word");
+#pragma unroll 1
+  for (int p = 0; p < pl.npasses; ++p) {
+    const int shift = (int)((sh64 >> (8 * p)) & 0xffu), bits = (int)((b64 >> (8 * p)) & 0xffu);
+    const uint32_t d = (uint32_t)(k >> shift) & ((1u << bits) - 1u);
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
     const bool uniform = __ballot(valid && d != d0) == 0 && (vmask & 1ull);
     if (uniform) {

@@ -956,11 +956,14 @@ swg_radix_plan swg_radix_plan_packed(int key_bits) {
       pl.bits[1 + p] = (uint8_t)(rest - 8 * p < 8 ? rest - 8 * p : 8);
     }
     pl.npasses = 1 + q8;
-  } else {  // q9 passes, as even as possible: the first `extra` of them one bit wider (at most 9)
+  } else {  // q9 passes, as even as possible: the last `extra` of them one bit wider (at most 9).  The wide digits go on top:
+            // the high key bits are segment bits, the same for a whole wavefront of a pair-major input, and a digit made of
+            // them alone costs the histogram kernels one LDS add per wavefront; a digit that mixes two or three coordinate
+            // bits into them takes four or eight values per wavefront and serialises its adds
     const int base = rest / q9, extra = rest % q9;
     int at = 8;
     for (int p = 0; p < q9; ++p) {
-      const int b = base + (p < extra ? 1 : 0);
+      const int b = base + (p >= q9 - extra ? 1 : 0);
       pl.shift[1 + p] = (uint8_t)at;
       pl.bits[1 + p] = (uint8_t)b;
       at += b;
