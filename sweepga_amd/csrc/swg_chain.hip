@@ -1638,9 +1638,13 @@ __global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uin
 // candidate lists only for the elements of long units (the walk builds the others' lists itself)
 __global__ __launch_bounds__(EW) void big_member_flag_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
                                                              const uint32_t* __restrict__ unit_excl,
-                                                             const uint8_t* __restrict__ is_big, uint8_t* __restrict__ f) {
+                                                             const uint8_t* __restrict__ is_big, uint8_t* __restrict__ f,
+                                                             uint8_t* __restrict__ span_big) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) f[p] = is_big[unit_excl[p] + unit_flag[p] - 1];
+  if (p >= m) return;
+  const uint8_t b = is_big[unit_excl[p] + unit_flag[p] - 1];
+  f[p] = b;
+  if (b) span_big[p >> BIG_SPAN_SHIFT] = 1;  // (pre-zeroed; every writer stores the same value)
 }
 
 __global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
@@ -2013,10 +2017,14 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       unsigned long long* c_d = nullptr;
       uint32_t *c_j = nullptr, *c_n = nullptr, *c_ext = nullptr;
       uint8_t* big_member = nullptr;  // members of long units (also what the chain table's generic path is restricted to)
+      uint8_t* span_big = nullptr;    // the same per 1024-element span: lets that path skip whole work-groups
       if (n_big) {
         big_member = swg_alloc<uint8_t>(ctx, m);
+        const uint64_t n_span = (m >> BIG_SPAN_SHIFT) + 1;
+        span_big = swg_alloc<uint8_t>(ctx, n_span);
         SWG_CHECK_ARENA(ctx);
-        SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member));
+        SWG_HIP(ctx, hipMemsetAsync(span_big, 0, n_span, st));
+        SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member, span_big));
         SWG_KERNEL_CHECK(ctx);
       }
       if (lists_all) {
@@ -2050,6 +2058,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         work->chunks = cdesc;
         work->n_chunks = n_chunks;
         work->big_member = big_member;
+        work->span_big = span_big;
         const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * 64 ? n_chunks : (uint64_t)ctx->num_cu * 64;
         if (lists_all)
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false><<<(unsigned)wb, 64, 0, st>>>(

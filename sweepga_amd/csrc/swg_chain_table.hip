@@ -35,38 +35,53 @@ __global__ __launch_bounds__(EW) void group_first_from_scan_kernel(uint64_t m, c
 // jumping below only has to connect chains across ranges.
 constexpr int HEAD_SPAN = 1024;
 __global__ __launch_bounds__(EW) void head_init_kernel(uint64_t m, const uint32_t* __restrict__ pred,
-                                                       uint32_t* __restrict__ hd, const uint8_t* __restrict__ only) {
+                                                       uint32_t* __restrict__ hd, const uint8_t* __restrict__ only,
+                                                       const uint8_t* __restrict__ span) {
   __shared__ uint32_t l[HEAD_SPAN];
-  const uint64_t base = (uint64_t)blockIdx.x * HEAD_SPAN;
-  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p < m) l[k] = pred[p] == NONE ? (uint32_t)p : pred[p];
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p >= m) break;
-    uint32_t h = l[k];
-    while (h >= base) {  // h <= p < base + HEAD_SPAN
-      const uint32_t hh = l[h - base];
-      if (hh == h) break;
-      h = hh;
+  static_assert(HEAD_SPAN == (1 << BIG_SPAN_SHIFT), "span flags");
+  const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+  for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {  // (block-uniform)
+    if (span && !span[sp]) continue;  // no member of a long unit in this span: nothing to write
+    const uint64_t base = sp * HEAD_SPAN;
+    __syncthreads();
+    for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+      const uint64_t p = base + k;
+      if (p < m) l[k] = pred[p] == NONE ? (uint32_t)p : pred[p];
     }
-    if (!only || only[p]) hd[p] = h;
+    __syncthreads();
+    for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+      const uint64_t p = base + k;
+      if (p >= m) break;
+      uint32_t h = l[k];
+      while (h >= base) {  // h <= p < base + HEAD_SPAN
+        const uint32_t hh = l[h - base];
+        if (hh == h) break;
+        h = hh;
+      }
+      if (!only || only[p]) hd[p] = h;
+    }
   }
 }
 // hd[p] <- hd[hd[p]]; in-place races are benign (every value read is an ancestor of p)
 __global__ __launch_bounds__(EW) void head_jump_kernel(uint64_t m, uint32_t* hd, uint32_t* __restrict__ changed,
-                                                       const uint8_t* __restrict__ only) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  if (only && !only[p]) return;
-  const uint32_t h = hd[p];
-  const uint32_t hh = hd[h];
-  if (hh != h) {
-    hd[p] = hh;
-    *changed = 1;
+                                                       const uint8_t* __restrict__ only, const uint8_t* __restrict__ span) {
+  const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+  bool any = false;
+  for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {
+    if (span && !span[sp]) continue;
+    for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+      const uint64_t p = sp * HEAD_SPAN + k;
+      if (p >= m) break;
+      if (only && !only[p]) continue;
+      const uint32_t h = hd[p];
+      const uint32_t hh = hd[h];
+      if (hh != h) {
+        hd[p] = hh;
+        any = true;
+      }
+    }
   }
+  if (any) *changed = 1;
 }
 
 // Chain aggregates live at the head's slot.  Pass 1 seeds every slot with the element's own values (plain
@@ -83,19 +98,26 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
                                                                   unsigned long long* __restrict__ h_sm,
                                                                   unsigned long long* __restrict__ h_sb,
                                                                   uint32_t* __restrict__ is_head,
-                                                                  const uint8_t* __restrict__ only) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  if (only && !only[p]) {
-    is_head[p] = 0;  // short units: labelled, aggregated and filtered by chain_label_kernel
-    return;
+                                                                  const uint8_t* __restrict__ only,
+                                                                  const uint8_t* __restrict__ span) {
+  const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+  for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {
+    if (span && !span[sp]) continue;  // (is_head is only read where `only` is set)
+    for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+      const uint64_t p = sp * HEAD_SPAN + k;
+      if (p >= m) break;
+      if (only && !only[p]) {
+        is_head[p] = 0;  // short units: labelled, aggregated and filtered by chain_label_kernel
+        continue;
+      }
+      is_head[p] = hd[p] == p ? 1u : 0u;
+      h_qe[p] = s_qe[p];
+      h_ts[p] = s_ts[p];
+      h_te[p] = s_te[p];
+      h_sm[p] = s_m[p];
+      h_sb[p] = s_b[p];
+    }
   }
-  is_head[p] = hd[p] == p ? 1u : 0u;
-  h_qe[p] = s_qe[p];
-  h_ts[p] = s_ts[p];
-  h_te[p] = s_te[p];
-  h_sm[p] = s_m[p];
-  h_sb[p] = s_b[p];
 }
 // A member is usually a few positions after its head, so a block first folds the members whose head lies inside its
 // own 1024-element range into LDS (LDS atomics), then merges each touched partial aggregate into the head's seeded
@@ -112,50 +134,56 @@ __global__ __launch_bounds__(EW) void chain_aggregate_kernel(uint64_t m, const u
                                                              uint32_t* __restrict__ h_te,
                                                              unsigned long long* __restrict__ h_sm,
                                                              unsigned long long* __restrict__ h_sb,
-                                                             const uint8_t* __restrict__ only) {
+                                                             const uint8_t* __restrict__ only, const uint8_t* __restrict__ span) {
   __shared__ uint32_t l_qe[AGG_SPAN], l_ts[AGG_SPAN], l_te[AGG_SPAN], l_cnt[AGG_SPAN];
   __shared__ unsigned long long l_sm[AGG_SPAN], l_sb[AGG_SPAN];
-  const uint64_t base = (uint64_t)blockIdx.x * AGG_SPAN;
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    l_qe[k] = 0;
-    l_ts[k] = 0xffffffffu;
-    l_te[k] = 0;
-    l_cnt[k] = 0;
-    l_sm[k] = 0;
-    l_sb[k] = 0;
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    const uint64_t p = base + k;
-    if (p >= m) break;
-    if (only && !only[p]) continue;
-    const uint32_t h = hd[p];
-    if (h == p) continue;
-    if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
-      const uint32_t l = (uint32_t)(h - base);
-      atomicMax(&l_qe[l], s_qe[p]);
-      atomicMin(&l_ts[l], s_ts[p]);
-      atomicMax(&l_te[l], s_te[p]);
-      atomicAdd(&l_sm[l], (unsigned long long)s_m[p]);
-      atomicAdd(&l_sb[l], (unsigned long long)s_b[p]);
-      l_cnt[l] = 1;
-    } else {
-      atomicMax(&h_qe[h], s_qe[p]);
-      atomicMin(&h_ts[h], s_ts[p]);
-      atomicMax(&h_te[h], s_te[p]);
-      atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
-      atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+  static_assert(AGG_SPAN == (1 << BIG_SPAN_SHIFT), "span flags");
+  const uint64_t n_span = (m + AGG_SPAN - 1) / AGG_SPAN;
+  for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {  // (block-uniform)
+    if (span && !span[sp]) continue;
+    const uint64_t base = sp * AGG_SPAN;
+    __syncthreads();
+    for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+      l_qe[k] = 0;
+      l_ts[k] = 0xffffffffu;
+      l_te[k] = 0;
+      l_cnt[k] = 0;
+      l_sm[k] = 0;
+      l_sb[k] = 0;
     }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
-    if (!l_cnt[k]) continue;
-    const uint64_t h = base + k;  // a head of this range with members in it; members of later ranges use atomics too
-    atomicMax(&h_qe[h], l_qe[k]);
-    atomicMin(&h_ts[h], l_ts[k]);
-    atomicMax(&h_te[h], l_te[k]);
-    atomicAdd(&h_sm[h], l_sm[k]);
-    atomicAdd(&h_sb[h], l_sb[k]);
+    __syncthreads();
+    for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+      const uint64_t p = base + k;
+      if (p >= m) break;
+      if (only && !only[p]) continue;
+      const uint32_t h = hd[p];
+      if (h == p) continue;
+      if (h >= base) {  // heads precede their members, so h < p < base + AGG_SPAN
+        const uint32_t l = (uint32_t)(h - base);
+        atomicMax(&l_qe[l], s_qe[p]);
+        atomicMin(&l_ts[l], s_ts[p]);
+        atomicMax(&l_te[l], s_te[p]);
+        atomicAdd(&l_sm[l], (unsigned long long)s_m[p]);
+        atomicAdd(&l_sb[l], (unsigned long long)s_b[p]);
+        l_cnt[l] = 1;
+      } else {
+        atomicMax(&h_qe[h], s_qe[p]);
+        atomicMin(&h_ts[h], s_ts[p]);
+        atomicMax(&h_te[h], s_te[p]);
+        atomicAdd(&h_sm[h], (unsigned long long)s_m[p]);
+        atomicAdd(&h_sb[h], (unsigned long long)s_b[p]);
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < AGG_SPAN; k += EW) {
+      if (!l_cnt[k]) continue;
+      const uint64_t h = base + k;  // a head of this range with members in it; members of later ranges use atomics too
+      atomicMax(&h_qe[h], l_qe[k]);
+      atomicMin(&h_ts[h], l_ts[k]);
+      atomicMax(&h_te[h], l_te[k]);
+      atomicAdd(&h_sm[h], l_sm[k]);
+      atomicAdd(&h_sb[h], l_sb[k]);
+    }
   }
 }
 
@@ -333,20 +361,27 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
                                                       const unsigned long long* __restrict__ h_sm,
                                                       const unsigned long long* __restrict__ h_sb, uint64_t min_len,
                                                       double min_ident, uint32_t* __restrict__ ok_head,
-                                                      double* __restrict__ h_wid, const uint8_t* __restrict__ only) {
-  for (uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x; p < m; p += (uint64_t)gridDim.x * EW) {
-    if (only && !only[p]) continue;  // short units: chain_label_kernel wrote their flags
-    bool ok = false;
-    if (is_head[p] != 0) {
-      const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
-      ok = total_length >= min_len;
-      if (ok) {
-        const double wid = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
-        ok = wid >= min_ident;
-        if (ok) h_wid[p] = wid;
+                                                      double* __restrict__ h_wid, const uint8_t* __restrict__ only,
+                                                      const uint8_t* __restrict__ span) {
+  const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+  for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {
+    if (span && !span[sp]) continue;
+    for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
+      const uint64_t p = sp * HEAD_SPAN + k;
+      if (p >= m) break;
+      if (only && !only[p]) continue;  // short units: chain_label_kernel wrote their flags
+      bool ok = false;
+      if (is_head[p] != 0) {
+        const uint64_t total_length = (uint64_t)h_qe[p] - (uint64_t)s_qs[p];  // q_max - q_min
+        ok = total_length >= min_len;
+        if (ok) {
+          const double wid = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
+          ok = wid >= min_ident;
+          if (ok) h_wid[p] = wid;
+        }
       }
+      ok_head[p] = ok ? 1u : 0u;
     }
-    ok_head[p] = ok ? 1u : 0u;
   }
 }
 
@@ -528,6 +563,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_KERNEL_CHECK(ctx);
   // ---- short units: labels, aggregates and the span / identity filter chunk by chunk
   const uint8_t* only = nullptr;  // what the generic path below is restricted to (nullptr: everything)
+  const uint8_t* span = nullptr;  // ... and the 1024-element spans that hold any of it
   bool generic = true;
   if (W.n_chunks) {
     const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
@@ -536,31 +572,35 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
                                                                         h_te, h_wid));
     SWG_KERNEL_CHECK(ctx);
     only = W.big_member;
+    span = W.span_big;
     generic = only != nullptr;  // long units exist
   }
   if (generic) {
-    // ---- long units (or everything, without a chunk list): labelling by pointer jumping, aggregates by atomics at the head
-    SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<(unsigned)((m + HEAD_SPAN - 1) / HEAD_SPAN), EW, 0, st>>>(m, pred, hd, only));
+    // ---- long units (or everything, without a chunk list): labelling by pointer jumping, aggregates by atomics at the head.
+    // Work-groups stride over the 1024-element spans and skip those without a member of a long unit.
+    const uint64_t n_span_all = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+    const unsigned span_grid = (unsigned)(n_span_all < (uint64_t)ctx->num_cu * 16 ? n_span_all : (uint64_t)ctx->num_cu * 16);
+    SWG_LAUNCH(ctx, "head_init", head_init_kernel<<<span_grid, EW, 0, st>>>(m, pred, hd, only, span));
     SWG_KERNEL_CHECK(ctx);
     for (int round = 0; round < 64; ++round) {
       SWG_HIP(ctx, hipMemsetAsync(changed, 0, 8, st));
-      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed, only));
+      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<span_grid, EW, 0, st>>>(m, hd, changed, only, span));
       SWG_KERNEL_CHECK(ctx);
-      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<nblk(m), EW, 0, st>>>(m, hd, changed, only));
+      SWG_LAUNCH(ctx, "head_jump", head_jump_kernel<<<span_grid, EW, 0, st>>>(m, hd, changed, only, span));
       SWG_KERNEL_CHECK(ctx);
       uint64_t ch = 0;
       SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(changed), &ch, 1));
       if ((uint32_t)ch == 0) break;
     }
-    SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<nblk(m), EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
-                                                                                    h_te, h_sm, h_sb, is_head, only));
+    SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<span_grid, EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
+                                                                                    h_te, h_sm, h_sb, is_head, only, span));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<(unsigned)((m + AGG_SPAN - 1) / AGG_SPAN), EW, 0, st>>>(
-                                           m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te, h_sm, h_sb, only));
+    SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<span_grid, EW, 0, st>>>(
+                                           m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te, h_sm, h_sb, only, span));
     SWG_KERNEL_CHECK(ctx);
     // span / identity filter at the heads; from here on "chain" means a chain that passes it
-    SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16), EW, 0, st>>>(
-                                    m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head, h_wid, only));
+    SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<span_grid, EW, 0, st>>>(
+                                    m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head, h_wid, only, span));
     SWG_KERNEL_CHECK(ctx);
   }
   SWG_TRY(swg_exclusive_scan_u32(ctx, ok_head, cpos, m, d_tot));

@@ -106,6 +106,7 @@ struct SpecBlock {
   uint32_t be;  // block end
   uint32_t pad;
 };
+constexpr int BIG_SPAN_SHIFT = 10;  // span_big's granularity = HEAD_SPAN = AGG_SPAN (swg_chain_table.hip)
 constexpr uint32_t WALK_CHUNK = 1024;  // a chunk = the units that begin in one WALK_CHUNK-element cell ...
 constexpr uint32_t BIG_UNIT = 8192;    // ... all shorter than this (longer units take the block-speculative path)
 
@@ -135,6 +136,7 @@ struct ChainWork {
   const SpecBlock* chunks = nullptr;
   uint64_t n_chunks = 0;
   const uint8_t* big_member = nullptr;
+  const uint8_t* span_big = nullptr;  // [m / 1024 + 1] whether a 1024-element span holds a member of a long unit (with big_member)
 };
 
 // merge_mappings_into_chains (paf_filter.rs:750-933) in two halves:
