@@ -942,10 +942,11 @@ __global__ __launch_bounds__(EW) void spec_plan_kernel(uint32_t n_big, const uin
 __global__ __launch_bounds__(EW) void unit_wmax_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
                                                        const uint32_t* __restrict__ unit_excl,
                                                        const uint8_t* __restrict__ is_big, const uint32_t* __restrict__ c_ext,
-                                                       uint32_t* __restrict__ wmax_u) {
+                                                       uint32_t* __restrict__ wmax_u, const uint8_t* __restrict__ span_big = nullptr) {
   const int lane = threadIdx.x & 63;
   uint32_t cur_u = NONE, cur_w = 0;  // wave-uniform: the unit this wavefront is accumulating and its maximum so far
   for (uint64_t base = (uint64_t)blockIdx.x * EW; base < m; base += (uint64_t)gridDim.x * EW) {  // block-uniform trip count
+    if (span_big && !span_big[base >> BIG_SPAN_SHIFT]) continue;  // no member of a long unit in these 256 elements' span
     const uint64_t p = base + threadIdx.x;
     const bool valid = p < m;
     const uint32_t u = valid ? unit_excl[p] + unit_flag[p] - 1 : 0u;
@@ -1615,9 +1616,11 @@ __global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uin
                                                            const uint32_t* __restrict__ unit_excl,
                                                            const uint32_t* __restrict__ unit_begin, uint32_t n_units,
                                                            const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
-                                                           uint64_t max_gap, uint32_t* __restrict__ ext) {
+                                                           uint64_t max_gap, uint32_t* __restrict__ ext,
+                                                           const uint8_t* __restrict__ span_big) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
+  if (span_big && !span_big[p >> BIG_SPAN_SHIFT]) return;  // (extents are only read for members of long units)
   uint32_t x = 0;
   if (big_member[p]) {
     const uint32_t u = unit_excl[p] + unit_flag[p] - 1;
@@ -2043,7 +2046,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         c_ext = swg_alloc<uint32_t>(ctx, m);
         SWG_CHECK_ARENA(ctx);
         SWG_LAUNCH(ctx, "window_extent", window_extent_kernel<<<nblk(m), EW, 0, st>>>(m, big_member, unit_flag, unit_excl, unit_begin,
-                                                                         (uint32_t)n_units, s_qs, s_qe, max_gap, c_ext));
+                                                                         (uint32_t)n_units, s_qs, s_qe, max_gap, c_ext, span_big));
         SWG_KERNEL_CHECK(ctx);
       }
       {
@@ -2093,7 +2096,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           SWG_CHECK_ARENA(ctx);
           SWG_HIP(ctx, hipMemsetAsync(wmax_u, 0, n_units * sizeof(uint32_t), st));
           const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
-          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u));
+          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u, span_big));
           SWG_KERNEL_CHECK(ctx);
           SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
                                                                                 (uint32_t)m, wmax_u, S_u, nblk_u,
