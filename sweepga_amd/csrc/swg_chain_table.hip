@@ -99,8 +99,10 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
                                                                   unsigned long long* __restrict__ h_sb,
                                                                   uint32_t* __restrict__ is_head,
                                                                   const uint8_t* __restrict__ only,
-                                                                  const uint8_t* __restrict__ span) {
+                                                                  const uint8_t* __restrict__ span,
+                                                                  unsigned long long* __restrict__ n_heads) {
   const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
+  uint32_t heads = 0;
   for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {
     if (span && !span[sp]) continue;  // (is_head is only read where `only` is set)
     for (int k = threadIdx.x; k < HEAD_SPAN; k += EW) {
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
         is_head[p] = 0;  // short units: labelled, aggregated and filtered by chain_label_kernel
         continue;
       }
-      is_head[p] = hd[p] == p ? 1u : 0u;
+      const bool head = hd[p] == p;
+      heads += head ? 1u : 0u;
+      is_head[p] = head ? 1u : 0u;
       h_qe[p] = s_qe[p];
       h_ts[p] = s_ts[p];
       h_te[p] = s_te[p];
@@ -118,6 +122,9 @@ __global__ __launch_bounds__(EW) void chain_aggregate_init_kernel(uint64_t m, co
       h_sb[p] = s_b[p];
     }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
+  if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
 }
 // A member is usually a few positions after its head, so a block first folds the members whose head lies inside its
 // own 1024-element range into LDS (LDS atomics), then merges each touched partial aggregate into the head's seeded
@@ -399,9 +406,10 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
                                                          uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
                                                          uint32_t* __restrict__ ok_head, uint32_t* __restrict__ h_qe,
                                                          uint32_t* __restrict__ h_ts, uint32_t* __restrict__ h_te,
-                                                         double* __restrict__ h_wid) {
+                                                         double* __restrict__ h_wid, unsigned long long* __restrict__ n_heads) {
   __shared__ uint16_t succ[LABEL_CAP];
   constexpr uint16_t NO = 0xffffu;
+  uint32_t heads = 0;  // chains headed in this thread's elements (a statistic: all chains, passing the filter or not)
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const uint32_t b = chunks[c].bb, e = chunks[c].be;
     const uint32_t len = e > b ? e - b : 0;  // 0: a long unit's place holder
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
         continue;
       }
       // a head: walk the chain
+      ++heads;
       hd[p] = p;
       uint32_t qe = s_qe[p], ts = s_ts[p], te = s_te[p];
       uint64_t sm = s_m[p], sb = s_b[p];
@@ -450,17 +459,10 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
       ok_head[p] = ok ? 1u : 0u;
     }
   }
-}
-// number of chains = members without a predecessor
-__global__ __launch_bounds__(EW) void count_heads_kernel(uint64_t m, const uint32_t* __restrict__ pred,
-                                                         unsigned long long* __restrict__ n_heads) {
-  uint32_t heads = 0;
-  for (uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x; p < m; p += (uint64_t)gridDim.x * EW) heads += pred[p] == NONE;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
   if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
 }
-
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
 __global__ __launch_bounds__(EW) void chain_columns_kernel(
     uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
@@ -558,9 +560,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   uint32_t* ok_head = swg_alloc<uint32_t>(ctx, m);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
-  SWG_LAUNCH(ctx, "count_heads", count_heads_kernel<<<(unsigned)(nblk(m) < (uint64_t)ctx->num_cu * 8 ? nblk(m) : (uint64_t)ctx->num_cu * 8), EW, 0, st>>>(
-                                     m, pred, reinterpret_cast<unsigned long long*>(d_tot + 1)));
-  SWG_KERNEL_CHECK(ctx);
+  unsigned long long* n_heads = reinterpret_cast<unsigned long long*>(d_tot + 1);  // all chains: counted where heads are found
   // ---- short units: labels, aggregates and the span / identity filter chunk by chunk
   const uint8_t* only = nullptr;  // what the generic path below is restricted to (nullptr: everything)
   const uint8_t* span = nullptr;  // ... and the 1024-element spans that hold any of it
@@ -569,7 +569,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
     const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
     SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
                                                                         s_m, s_b, min_len, min_ident, hd, ok_head, h_qe, h_ts,
-                                                                        h_te, h_wid));
+                                                                        h_te, h_wid, n_heads));
     SWG_KERNEL_CHECK(ctx);
     only = W.big_member;
     span = W.span_big;
@@ -593,7 +593,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
       if ((uint32_t)ch == 0) break;
     }
     SWG_LAUNCH(ctx, "chain_aggregate_init", chain_aggregate_init_kernel<<<span_grid, EW, 0, st>>>(m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts,
-                                                                                    h_te, h_sm, h_sb, is_head, only, span));
+                                                                                    h_te, h_sm, h_sb, is_head, only, span, n_heads));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "chain_aggregate", chain_aggregate_kernel<<<span_grid, EW, 0, st>>>(
                                            m, hd, s_qe, s_ts, s_te, s_m, s_b, h_qe, h_ts, h_te, h_sm, h_sb, only, span));
