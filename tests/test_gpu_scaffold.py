@@ -248,3 +248,29 @@ def test_fuzz_slice(sw, first_seed, extras):
     for seed in range(first_seed, first_seed + 60):
         ok, n, kw, keep_self, scaffolds_only, bs, bc = run_case(seed, extras)
         assert ok, (seed, n, bs, bc, kw, keep_self, scaffolds_only)
+
+
+@pytest.mark.parametrize("seed,n,span,gap,max_len", [(1, 3_000, 300_000, 10_000, 8_000), (2, 40_000, 2_000_000, 10_000, 8_000),
+                                                      (3, 60_000, 60_000, 300, 300)])
+def test_statistics_count_every_chain(sw, seed, n, span, gap, max_len):
+    """swg_stats of a call without a mapping-level sweep (the CLI defaults): n_swept = the retained records, n_chains = ALL
+    chains of merge_mappings_into_chains before the span / identity filter (src/paf_filter.rs:437-447), counted where the
+    heads are found -- by the chunk labelling for short units and by the generic path for long ones (the third case is one
+    dense pair: units of more than 8192 mappings) --, n_chains_kept = the chains that pass.  Expected numbers from the
+    independent Python model."""
+    from tests import model_apply_filters as model
+    from tests.test_model_cpu import _records
+    rng = np.random.default_rng(900 + seed)
+    rec = gen.random_records(rng, n, n_genomes=2 if seed == 3 else 3, chrs_per_genome=1 if seed == 3 else 2, span=span, max_len=max_len,
+                             zero_frac=0.0)  # (no zero-length records: an unlimited mapping sweep would drop those)
+    min_len = 5_000 if seed != 3 else 400
+    dcfg = sw.FilterConfig(scaffold_gap=gap, min_scaffold_length=min_len, scaffold_max_deviation=0)
+    f = sw.PafFilter(dcfg)
+    f.filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+    md = [m for m in _records(rec) if m["q"] != m["t"] and m["block"] >= dcfg.min_block_length and m["identity"] >= dcfg.min_identity]
+    chains = model._merge_mappings_into_chains(md, gap)
+    kept = [c for c in chains if c["total"] >= min_len and c["wid"] >= dcfg.min_scaffold_identity]
+    st = f.last_stats
+    assert (st.n_in, st.n_retained, st.n_swept) == (n, len(md), len(md))
+    assert st.n_chains == len(chains) and len(chains) > 0
+    assert st.n_chains_kept == len(kept) and 0 < len(kept) < len(chains)
