@@ -1,13 +1,14 @@
 // Scan and radix-sort primitives for gfx950 (wave64).
 //
 //  * swg_exclusive_scan_u32 : reduce / recurse / down-sweep scan, 4096 elements per workgroup.
-//  * swg_radix_sort_pairs   : stable LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.
-//      per pass: (1) per-tile digit histogram, (2) exclusive scan of the digit-major histogram,
-//      (3) stable scatter: each tile re-reads its keys in 256-element rows, ranks every row with
-//      a wavefront match (8 x 64-bit ballots) + cross-wave prefix in LDS, and writes the pair to
-//      its final slot.  Stability is what makes the multi-word sorts of the pipeline compose and
-//      is what carries the reference's "ties fall to input order" rule (sort_by_key is stable,
+//  * swg_radix_sort_pairs   : stable LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits, one "onesweep" kernel per
+//      digit (below); swg_radix_sort_packed: the same over 8-byte words ((key >> 8) << index bits | index) after the first
+//      pass, with 9-bit digits where they save a pass.  Stability is what makes the multi-word sorts of the pipeline compose
+//      and is what carries the reference's "ties fall to input order" rule (sort_by_key is stable,
 //      src/plane_sweep_exact.rs:300, src/paf_filter.rs:777).
+//      Fallback (more than 8 passes, or SWG_SORT_FALLBACK=1): per pass (1) per-tile digit histogram, (2) exclusive scan of
+//      the digit-major histogram, (3) stable scatter: each tile re-reads its keys in 256-element rows, ranks every row with a
+//      wavefront match (8 x 64-bit ballots) + cross-wave prefix in LDS, and writes the pair to its final slot.
 #include <cstdlib>
 
 #include "swg_internal.h"
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // "onesweep" pass: one kernel per digit, read once / write once.
-//   * digit histograms of every pass come from one upfront sweep over the keys;
-//   * a tile (4096 pairs) ranks its keys with wavefront match + per-wave LDS counters, learns the
+//   * digit histograms of every pass come from one upfront sweep over the keys (or from the kernel that wrote them);
+//   * a tile (8192 elements, 512 threads) ranks its keys with wavefront match + per-wave LDS counters, learns the
 //     number of equal-digit keys in all earlier tiles by decoupled look-back over per-tile status
 //     words (count | flag in one 32-bit word, agent-scope relaxed atomics: single-word hand-off),
 //     reorders the tile in LDS and writes digit runs with consecutive lanes on consecutive addresses.
