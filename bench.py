@@ -9,7 +9,9 @@ ordered non-self genome pairs ("10 k groups"), 10^8 mappings per GPU, lognormal 
 reference's command line are timed on it with the same K / W:
     default  `sweepga <paf> --output-file ...` with every flag at its default (many:many, jump 50 k, mass 10 k)   <- `value`
     sweep    `--num-mappings 1:1 --scaffold-jump 0`                      (the sort + plane-sweep path alone)
-    full     `--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000`   (BASELINE.json configs[4])
+    full     `--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000`   (the whole scaffold path behind a 1:1 sweep)
+    c5       `--scaffold-filter 1:1 --scaffold-dist 20000`   (BASELINE.json configs[4] as SURVEY.md 8d C5 states it: many:many
+             mappings, so all 10^8 records are chained and every one of them is a rescue candidate)
 and BASELINE.json configs[2] ("S-big1": ONE chromosome pair, 10^7 mappings, depth ~165) is timed beside them.
 
 N GPUs: one process per GPU (launched by torch.distributed.run, or by this script itself when it is started with
@@ -36,13 +38,14 @@ if ROOT not in sys.path:
 ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
 ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r03_v6"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
+PROFILE_TAG = "r04_v1"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
 
 # BASELINE.json's metric, verbatim
 BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
-PIPELINES = ("default", "sweep", "full")
+PIPELINES = ("default", "sweep", "full", "c5")
 FLAGS = {"sweep": "--num-mappings 1:1 --scaffold-jump 0",
          "full": "--num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000",
+         "c5": "--scaffold-filter 1:1 --scaffold-dist 20000",
          "default": "(defaults)",
          "k32": "--num-mappings 3:2 --scaffold-jump 0"}
 REC_COLS = ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand")
@@ -124,6 +127,9 @@ def make_config(sw, pipeline):
     if pipeline == "full":    # --num-mappings 1:1 --scaffold-filter 1:1 --scaffold-dist 20000 (jump 50k, mass 10k)
         return sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_filter_mode=sw.FilterMode.OneToOne,
                                scaffold_gap=50_000, min_scaffold_length=10_000, scaffold_max_deviation=20_000)
+    if pipeline == "c5":      # --scaffold-filter 1:1 --scaffold-dist 20000, mappings many:many (SURVEY.md 8d C5 = configs[4])
+        return sw.FilterConfig(scaffold_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=50_000, min_scaffold_length=10_000,
+                               scaffold_max_deviation=20_000)
     if pipeline == "default":  # all CLI defaults (many:many, jump 50k, mass 10k)
         return sw.FilterConfig()
     if pipeline == "k32":      # --num-mappings 3:2 --scaffold-jump 0: the 2 <= k < inf tile kernel (--pipeline k32 --only)
@@ -161,37 +167,38 @@ def _oracle_config(cfg):
                       min_identity=cfg.min_identity, min_scaffold_identity=cfg.min_scaffold_identity)
 
 
-def cpu_baseline_all_cores(cols, sizes, cfg, names, first_group, per_thread=150_000, max_threads=32):
-    """'What a group-parallel CPU filter would give' (SURVEY.md 8d-ii): the same oracle on T host threads at once,
-    every thread on its own whole genome-pair groups (the reference itself filters on one thread)."""
-    import threading
+def cpu_baseline_all_cores(cols, sizes, cfg, names, first_group, per_thread=150_000, total_cap=16_000_000):
+    """'What a group-parallel CPU filter would give' (SURVEY.md 8d-ii): the same oracle on ALL host threads at once
+    (os.cpu_count(), stated in `cores`), every thread on its own run of whole genome-pair groups (the reference itself
+    filters on one thread).  Wall time of the whole threaded run, best of 2; the oracle is a String-keyed port like the
+    reference (names are cloned and hashed per record), so this includes the allocator contention such a port has."""
     import numpy as np
     from tests import orc
-    csum = np.concatenate([[0], sizes.cumsum(0).cpu().numpy()])
-    T = max(1, min(os.cpu_count() or 1, max_threads))
-    ocfg = _oracle_config(cfg)
-    jobs, g = [], first_group
+    csum = np.concatenate([[0], sizes.cumsum(0).cpu().numpy()]).astype(np.int64)
+    T = max(1, os.cpu_count() or 1)
+    per_thread = max(20_000, min(per_thread, total_cap // T))
+    bounds, g = [int(csum[first_group])], first_group
     for _ in range(T):
         g2 = int(np.searchsorted(csum, csum[g] + per_thread)) if g < len(csum) - 1 else g
         g2 = min(max(g2, g + 1), len(csum) - 1)
         if g2 <= g:
             break
-        jobs.append(_oracle_records(cols, int(csum[g]), int(csum[g2]), names))
+        bounds.append(int(csum[g2]))
         g = g2
-    if not jobs:
+    if len(bounds) < 2:
         return None
-    bar = threading.Barrier(len(jobs) + 1)
-    th = [threading.Thread(target=orc.apply_filters, args=(ocfg, r), kwargs={"barrier": bar}) for r in jobs]
-    for t in th:
-        t.start()
-    bar.wait()
-    t0 = time.perf_counter()
-    for t in th:
-        t.join()
-    wall = time.perf_counter() - t0
-    m = sum(len(r) for r in jobs)
-    return dict(value=m / wall, unit="mappings/s", cores=len(jobs), kind="port",
-                sample=f"{len(jobs)} threads x ~{per_thread} mappings (whole groups), all started together, wall {wall:.2f} s")
+    lo, hi = bounds[0], bounds[-1]
+    h = _host_cols(cols, lo, hi)
+    rel = np.asarray(bounds, dtype=np.int64) - lo
+    ocfg = _oracle_config(cfg)
+    walls = []
+    for _ in range(2):
+        _, _, wall = orc.apply_filters_by_groups(ocfg, h, names, rel, len(rel) - 1)
+        walls.append(wall)
+    m = hi - lo
+    return dict(value=m / min(walls), unit="mappings/s", cores=len(rel) - 1, kind="port",
+                sample=f"{len(rel) - 1} threads (= all {T} host threads) x ~{per_thread} mappings of whole groups, String-keyed port, "
+                       f"wall {min(walls):.2f} s (best of 2: {walls[0]:.2f}, {walls[1]:.2f})")
 
 
 def full_parity(cols, sizes, cfg, names, status_dev, chain_dev, target, max_threads=64, groups_per_job=25):
@@ -302,8 +309,9 @@ def end_to_end(n_lines, ref_lines, threads):
 class Runner:
     """One context, one record set in HBM; times K calls of swg_filter_device per flag set."""
 
-    def __init__(self, torch, sw, lib_mod, ctx, device, dist, cols, n, n_seq):
+    def __init__(self, torch, sw, lib_mod, ctx, device, dist, cols, n, n_seq, coll_device=None):
         self.torch, self.sw, self.lib_mod, self.ctx, self.device, self.dist = torch, sw, lib_mod, ctx, device, dist
+        self.coll_device = coll_device or device   # where collective buffers live (the CPU under --rehearse: gloo)
         self.cols, self.n = cols, n
         self.rec = make_records(lib_mod, cols, n, n_seq)
         self.status = torch.zeros(max(n, 1), dtype=torch.uint8, device=device)
@@ -338,7 +346,7 @@ class Runner:
         elapsed = time.perf_counter() - t0
         local_elapsed = elapsed
         if self.dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.coll_device)
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         ctx.profile(False)
@@ -353,7 +361,7 @@ class Runner:
         torch.cuda.synchronize()
         plain = time.perf_counter() - t0
         if self.dist is not None:
-            tt = torch.tensor([plain], dtype=torch.float64, device=self.device)
+            tt = torch.tensor([plain], dtype=torch.float64, device=self.coll_device)
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             plain = float(tt.item())
         self.step(ccfg, with_stats=True)  # untimed: counts for the report
@@ -369,35 +377,49 @@ class Runner:
 
 
 def roofline(pipeline, n, steps, t, wl="100m"):
-    """Dominant kernel of one flag set.  `achieved` follows the contract: ALGORITHMIC bytes of one call (SURVEY 8d:
-    33 or 47 B per mapping x the n mappings one launch works on) / that kernel's average launch duration, measured
-    with HIP events on the library's stream.  `kernel_own_*` is the kernel's own HBM traffic per launch (rocprofv3
-    PMC, committed under profiles/) / the same duration, and `pipeline_*` the end-to-end figure."""
+    """Dominant kernel of one flag set = the launch label with the most time per step.  One label is one kernel function
+    (one rocprof name; tools/pmc_traffic.py maps names to the same labels), so every figure below averages over the SAME
+    launches: `kernel_avg_ms` = HIP-event time of that label / its launches, `traffic` = that kernel's rocprofv3 PMC bytes
+    per launch (profiles/<tag>_hbm_traffic_*.json, same label, same launches per call -- checked, else null).
+    `achieved` follows the contract: ALGORITHMIC bytes of one call (33 or 47 B per mapping x the mappings one
+    launch works on) / kernel_avg_ms.  `kernel_own_*` = traffic / kernel_avg_ms; `pipeline_*` the end-to-end figure."""
     algo = ALGO_BYTES_SWEEP if pipeline in ("sweep", "k32") else ALGO_BYTES_FULL
     prof = t["prof"]
     total_kernel_ms = sum(ms for _, ms in prof.values())
     dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
     dom_avg_ms = dom_ms / max(dom_launches, 1)
+    per_step = dom_launches / steps
     # units one launch works on: n for the per-record kernels; the sort passes run on sub-problems of different sizes (the
     # library counts the pairs of every pass), so their average launch is charged the average number of pairs
     units = t.get("prof_units", {}).get(dom_name, 0) / max(dom_launches, 1) or n
     achieved = algo * units / (dom_avg_ms * 1e-3) / 1e9
-    traffic, tfile = None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
+    traffic, tnote, total_traffic, tfile = None, None, None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
     try:
         tj = json.load(open(os.path.join(ROOT, tfile)))
-        if tj.get("n_mappings") == n and dom_name in tj["kernels"]:
-            traffic = tj["kernels"][dom_name]["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
+        if tj.get("n_mappings") != n:
+            tnote = f"{tfile} is for {tj.get('n_mappings')} mappings"
+        elif dom_name not in tj["kernels"]:
+            tnote = f"{dom_name} not in {tfile}"
+        else:
+            k = tj["kernels"][dom_name]
+            lpc = k.get("launches_per_call", k["launches_profiled"] / tj.get("calls_profiled", 3))
+            if abs(lpc - per_step) > 1e-6:
+                tnote = f"{tfile} has {lpc:g} launches of {dom_name} per call, this run {per_step:g}"
+            else:
+                traffic = k["hbm_bytes_per_launch"]
+        total_traffic = tj.get("hbm_bytes_per_call_all_kernels")
+    except (OSError, ValueError, KeyError) as e:
+        tnote = f"{tfile}: {type(e).__name__}"
     pipe_achieved = algo * n / (t["ms_per_step"] * 1e-3) / 1e9
     own = traffic / (dom_avg_ms * 1e-3) / 1e9 if traffic else None
     return {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": tnote,
             "traffic_unit": f"HBM bytes per launch of that kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {tfile})",
-            "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": dom_launches / steps,
+            "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": per_step,
             "algorithmic_bytes_per_mapping": algo, "units_per_launch": units,
             "kernel_own_achieved": own, "kernel_own_frac": own / HBM_PEAK_GBPS if own else None,
             "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
+            "pipeline_traffic": total_traffic, "pipeline_traffic_over_algorithmic": total_traffic / (algo * n) if total_traffic else None,
             "kernel_ms_per_step": total_kernel_ms / steps}
 
 
@@ -459,7 +481,18 @@ def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
 
 
 # ---- strong scaling ------------------------------------------------------------------------------------------------
-def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world):
+def _result_checksum(np, idx, status, chain):
+    """Order-independent 64-bit fingerprint of (global record index, status, chain number) triples: shards add up to the
+    fingerprint of the whole record set, so a sharded run can be compared with the unsharded one."""
+    with np.errstate(over="ignore"):
+        i = idx.astype(np.uint64) + np.uint64(1)
+        h = (i * np.uint64(0x9E3779B97F4A7C15)) ^ (chain.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F) + status.astype(np.uint64))
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        return int(np.add.reduce(h, dtype=np.uint64))
+
+
+def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world, coll_device=None):
     """ONE S-pan record set (the same on every rank, seed --seed), genome pairs bin-packed over the ranks by
     sweepga_amd.shard (LPT by mapping count), every rank keeps only its shard in HBM and filters it; the kept-chain
     ranges of all pairs are exchanged with one all_gather and every rank renumbers its own chains."""
@@ -484,11 +517,13 @@ def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world):
     del cols, key_d
     torch.cuda.synchronize()
     partition_s = time.perf_counter() - t0
-    run = Runner(torch, sw, lib_mod, ctx, device, dist, scols, m, G)
+    coll_device = coll_device or device
+    run = Runner(torch, sw, lib_mod, ctx, device, dist, scols, m, G, coll_device)
     res = {}
+    idx_h = mine.cpu().numpy()
     for p in PIPELINES:
         t = run.time(p, args.steps, args.warmup, keep_results=True)
-        lt = torch.tensor([t["local_elapsed"] / args.steps * 1e3], dtype=torch.float64, device=device)
+        lt = torch.tensor([t["local_elapsed"] / args.steps * 1e3], dtype=torch.float64, device=coll_device)
         per_rank = [torch.zeros_like(lt) for _ in range(world)]
         if dist is not None:
             dist.all_gather(per_rank, lt)
@@ -497,23 +532,28 @@ def strong_scaling(torch, sw, lib_mod, ctx, device, dist, args, rank, world):
         per_rank_ms = [float(x.item()) for x in per_rank]
         # exchange + local renumbering (chain numbers are global in the reference, src/paf_filter.rs:517-521)
         renumber_s = None
+        ch = t["chain"].cpu().numpy().astype(np.int64)
         if t["cfg"].scaffold_gap:
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            ch = t["chain"].cpu().numpy().astype(np.int64)
             pr = pair_mine.cpu().numpy()
-            idx = mine.cpu().numpy()
-            lo, hi, first = shard.pair_chain_ranges(ch, pr, idx, G * G, n)
+            lo, hi, first = shard.pair_chain_ranges(ch, pr, idx_h, G * G, n)
             if dist is not None:
-                buf = torch.as_tensor(np.stack([lo, -hi, first]), device=device)
+                buf = torch.as_tensor(np.stack([lo, -hi, first]), device=coll_device)
                 dist.all_reduce(buf, op=dist.ReduceOp.MIN)   # every pair lives on exactly one rank
                 lo, hi, first = buf[0].cpu().numpy(), -buf[1].cpu().numpy(), buf[2].cpu().numpy()
             shift = shard.chain_shifts(lo, hi, first)
             has = ch != 0
             ch[has] += shift[pr[has]]
             renumber_s = time.perf_counter() - t1
+        # fingerprint of (record, status, global chain number) over all shards: equal to the unsharded run's (tests compare)
+        chk = _result_checksum(np, idx_h, t["status"].cpu().numpy(), ch)
+        if dist is not None:
+            cb = torch.tensor([np.int64(np.uint64(chk).astype(np.int64))], dtype=torch.int64, device=coll_device)
+            dist.all_reduce(cb, op=dist.ReduceOp.SUM)   # wraps modulo 2^64 like the per-shard sums
+            chk = int(cb.item()) & 0xFFFFFFFFFFFFFFFF
         res[p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "value": n / (t["ms_per_step"] * 1e-3), "unit": "mappings/s",
-                  "per_rank_ms": per_rank_ms, "renumber_s": renumber_s, "counts_rank0": t["counts"]}
+                  "per_rank_ms": per_rank_ms, "renumber_s": renumber_s, "counts_rank0": t["counts"], "result_checksum": f"{chk:016x}"}
     return {"mappings_total": n, "plan_s": plan_s, "partition_s": partition_s, "shard_mappings_rank0": m,
             "load_max_over_mean": float(loads.max() / loads.mean()), "loads": [int(x) for x in loads], "pipelines": res}
 
@@ -574,12 +614,48 @@ def summary_line(out, detail_path):
     if ss:
         line["strong"] = {"mappings_total": ss["mappings_total"], "load_max_over_mean": _r(ss["load_max_over_mean"], 5),
                           "plan_s": _r(ss["plan_s"]), "partition_s": _r(ss["partition_s"]),
-                          "ms_per_step": {p: _r(e["ms_per_step"]) for p, e in ss["pipelines"].items()}}
+                          "ms_per_step": {p: _r(e["ms_per_step"]) for p, e in ss["pipelines"].items()},
+                          "result_checksum": {p: e["result_checksum"] for p, e in ss["pipelines"].items()}}
+    if out.get("rehearsal"):
+        line["rehearsal"] = out["rehearsal"]
     if par:
         line["parity"] = par
         line["parity_ok"] = all(v["ok"] for v in par.values())
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
     return line
+
+
+def fit_line(line):
+    """The stdout line must stay under MAX_LINE_BYTES whatever was measured: optional keys are dropped (least important
+    first) until it fits, and the line says so (`truncated`) -- a run never ends without its JSON line."""
+    text = json.dumps(line)
+    droppable = ("strong", "cpu_baseline_all_cores", "parity", "e2e_cpu_cli_mappings_per_s", "e2e_byte_identical_on_prefix",
+                 "e2e_lines", "e2e_wall_s", "ms_per_step_unprofiled")
+    dropped = []
+    for k in droppable:
+        if len(text) < MAX_LINE_BYTES:
+            break
+        if k in line:
+            del line[k]
+            dropped.append(k)
+            line["truncated"] = dropped
+            text = json.dumps(line)
+    if len(text) >= MAX_LINE_BYTES:  # still too long: shorten the free-text fields
+        for path in (("config", "workload"), ("cpu_baseline", "sample")):
+            d = line
+            for k in path[:-1]:
+                d = d.get(k) or {}
+            if isinstance(d.get(path[-1]), str):
+                d[path[-1]] = d[path[-1]][:80]
+        line["truncated"] = dropped + ["text"]
+        text = json.dumps(line)
+    if len(text) >= MAX_LINE_BYTES:  # last resort: the contract keys alone
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity_ok", "detail")
+        line = {k: line[k] for k in keep if k in line}
+        line["truncated"] = "all optional keys"
+        text = json.dumps(line)
+    return text
 
 
 def spawn_ranks(args, argv):
@@ -588,7 +664,9 @@ def spawn_ranks(args, argv):
     import socket
     import torch
     have = torch.cuda.device_count()   # counting devices does not initialise the GPU
-    if have < args.gpus:
+    if args.rehearse and have >= 1:
+        pass   # rehearsal: ranks share the GPUs there are (rank r on device r mod `have`), gloo instead of RCCL
+    elif have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -628,6 +706,10 @@ def main():
     ap.add_argument("--e2e", type=int, default=10_000_000, help="lines of synthetic PAF for the file->file leg (0 = skip)")
     ap.add_argument("--e2e-ref", type=int, default=1_000_000, help="prefix of that file the oracle CLI is timed on")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the e2e leg (0 = all cores)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="run the N-rank launch path on fewer GPUs than ranks: rank r uses device r mod (visible GPUs) and the "
+                         "process group is gloo (CPU buffers) instead of RCCL.  Exercises spawn -> torch.distributed.run -> "
+                         "init_process_group -> barrier / MAX-over-ranks / the chain renumbering all_reduce; NOT a scaling number")
     ap.add_argument("--detail", default="", help="file for the full report (per-kernel tables, counts, every leg); "
                                                  "default gpurun_out/bench_detail.json.  stdout carries ONE line < 4 KB")
     args = ap.parse_args()
@@ -643,21 +725,33 @@ def main():
               f"{args.gpus}-GPU", file=sys.stderr)
         sys.exit(2)
 
+    # stdout carries the ONE JSON line and nothing else: native libraries write there too (gloo's "[Gloo] Rank 0 is connected
+    # to ..." lines, RCCL with NCCL_DEBUG=INFO), so file descriptor 1 is pointed at stderr for the whole run and the line goes
+    # to a private duplicate of the original stdout
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if args.rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = torch.device("cpu") if args.rehearse else device
     dist = None
     if launched:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import sweepga_amd as sw
     from sweepga_amd import _lib
-    ctx = sw.Context(local_rank)
+    ctx = sw.Context(dev_index)
     if args.workload == "sbig1":
         args.genomes, args.sbig1 = 2, 0
         if (args.mappings or 10_000_000) > 2_000_000:
@@ -669,7 +763,7 @@ def main():
     out = None
 
     if args.scaling == "strong":
-        ss = strong_scaling(torch, sw, _lib, ctx, device, dist, args, rank, world)
+        ss = strong_scaling(torch, sw, _lib, ctx, device, dist, args, rank, world, coll_device)
         if rank == 0:
             head = ss["pipelines"][args.pipeline]
             out = {"metric": BASELINE_METRIC, "value": head["value"], "unit": "mappings/s", "n_gpus": world, "steps": args.steps,
@@ -692,7 +786,7 @@ def main():
             args.cpu_sample = 0
             args.parity_mappings = 0
         torch.cuda.synchronize()
-        run = Runner(torch, sw, _lib, ctx, device, dist, cols, n, G)
+        run = Runner(torch, sw, _lib, ctx, device, dist, cols, n, G, coll_device)
         cpu_legs = world == 1 and args.cpu_sample > 0   # the CPU legs belong to the N=1 run
         timed = {p: run.time(p, args.steps, args.warmup, keep_results=cpu_legs) for p in order}
 
@@ -782,6 +876,9 @@ def main():
             out["sbig1"] = sbig1_leg(torch, sw, _lib, ctx, device, args) if args.sbig1 > 0 else None
             out["end_to_end"] = end_to_end(args.e2e, args.e2e_ref, args.threads) if args.e2e > 0 else None
 
+    if rank == 0 and args.rehearse:
+        out["rehearsal"] = (f"{world} rank(s) on {torch.cuda.device_count()} GPU(s), gloo process group: the launch path only, "
+                            f"not a scaling measurement")
     if rank == 0:
         detail = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
         try:
@@ -791,9 +888,7 @@ def main():
         except OSError as e:
             print(f"bench.py: could not write {detail}: {e}", file=sys.stderr)
             detail = None
-        line = json.dumps(summary_line(out, detail))
-        assert len(line) < MAX_LINE_BYTES, len(line)
-        print(line)
+        print(fit_line(summary_line(out, detail)), file=line_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

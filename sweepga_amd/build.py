@@ -26,6 +26,8 @@ def stale():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sweepga_gpu.h")]
     deps += [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
     deps = [d for d in deps if not os.path.isdir(d)]
+    if os.path.isdir(OBJ_DIR):   # objects of an interrupted build that were never linked
+        deps += [os.path.join(OBJ_DIR, f) for f in os.listdir(OBJ_DIR) if f.endswith(".o")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
@@ -107,20 +109,47 @@ def _headers():
     return hs
 
 
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+STAMP = os.path.join(OBJ_DIR, "compile.stamp")
+
+
+def _stamp_text(hipcc):
+    """What the cached objects were compiled with: compiler path, its version and the flags.  A different stamp invalidates
+    every object (the mtime test alone would keep objects of another compiler or other flags)."""
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        ver = "?"
+    return "\n".join([hipcc, ver, " ".join(COMPILE_FLAGS)]) + "\n"
+
+
 def build_lib(force=False, verbose=False):
-    """One object per translation unit (cached under csrc/build/, recompiled when the source or any header changed),
-    compiled side by side, then linked into libsweepga_gpu.so."""
+    """One object per translation unit (cached under csrc/build/, recompiled when the source or any header changed, or
+    when the compiler / flags differ from the stamp), compiled side by side, then linked into libsweepga_gpu.so.  The
+    link runs whenever the library is missing or OLDER than any object: an interrupted build (objects written, link not
+    reached) is finished by the next call instead of leaving a stale library behind fresh objects."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
+    stamp = _stamp_text(hipcc)
+    try:
+        same_stamp = open(STAMP).read() == stamp
+    except OSError:
+        same_stamp = False
+    if not same_stamp:
+        force_objs = True
+        if os.path.exists(STAMP):
+            os.remove(STAMP)   # rewritten only after every object has been compiled with the new settings
+    else:
+        force_objs = force
     newest_header = max(os.path.getmtime(h) for h in _headers())
     jobs, objs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+        if force_objs or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([hipcc] + COMPILE_FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -130,8 +159,12 @@ def build_lib(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs + ["-lz", "-lpthread"])
+    if not same_stamp:
+        with open(STAMP, "w") as f:
+            f.write(stamp)
+    if jobs or not os.path.exists(LIB) or max(os.path.getmtime(o) for o in objs) > os.path.getmtime(LIB):
+        run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB + ".tmp"] + objs + ["-lz", "-lpthread"])
+        os.replace(LIB + ".tmp", LIB)   # never a half-written library
     return LIB
 
 

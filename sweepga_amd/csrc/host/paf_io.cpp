@@ -852,6 +852,12 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
     }
   }
   if (fd < 0) return paf_error(SWG_ERR_INVALID, "cannot create %s: %s", open_path, std::strerror(errno));
+  std::atomic<int> bad{0};
+  bool oom = false;
+  // A failed allocation -- also what a worker body that fails turns into (host/threads.h) -- must not unwind through this
+  // extern "C" function: it is caught, the descriptor is closed and a temporary file removed below, and the call returns
+  // SWG_ERR_OOM.
+  try {
   // sizes per thread range
   std::vector<uint64_t> bytes(threads + 1, 0), kept(threads, 0);
   auto lo = [&](int t) { return n / threads * t + (uint64_t)std::min<uint64_t>(t, n % threads); };
@@ -870,7 +876,6 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
   for (auto c : kept) total_kept += c;
   if (n_written) *n_written = total_kept;
   const bool seekable = !to_stdout && lseek(fd, 0, SEEK_CUR) != (off_t)-1;
-  std::atomic<int> bad{0};
   constexpr size_t BUF = size_t(8) << 20;
   if (seekable) {
     parallel_for(threads, [&](int t) {
@@ -906,11 +911,17 @@ int swg_paf_write(const swg_paf* p, const char* out_path, const uint8_t* status,
     }
     if (!bad && o != buf.data() && !write_all(fd, buf.data(), (size_t)(o - buf.data()))) bad = errno ? errno : EIO;
   }
+  } catch (const std::bad_alloc&) {
+    oom = true;
+  } catch (const std::system_error&) {  // a thread could not be started
+    oom = true;
+  }
   if (!to_stdout && close(fd) != 0 && !bad) bad = errno ? errno : EIO;
   if (!tmp_path.empty()) {
-    if (!bad && rename(tmp_path.c_str(), final_path.c_str()) != 0) bad = errno ? errno : EIO;
-    if (bad) unlink(tmp_path.c_str());
+    if (!bad && !oom && rename(tmp_path.c_str(), final_path.c_str()) != 0) bad = errno ? errno : EIO;
+    if (bad || oom) unlink(tmp_path.c_str());
   }
+  if (oom) return paf_error(SWG_ERR_OOM, "out of host memory (or host threads) while writing %s", out_path);
   if (bad) return paf_error(SWG_ERR_INVALID, "write to %s failed: %s", out_path, std::strerror(bad));
   return SWG_OK;
 }
@@ -927,6 +938,7 @@ int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out) {
   if (G * G > 0xffffffffull) return paf_error(SWG_ERR_UNSUPPORTED, "more than 65535 genomes in the ANI pass");
   threads = pick_threads(threads);
   if ((uint64_t)threads > n / 4096 + 1) threads = (int)(n / 4096 + 1);
+  try {  // allocations and worker bodies (host/threads.h): nothing unwinds through the C ABI
   const size_t cap = n ? n : 1;
   p->ani_eligible.alloc(cap);
   p->ani_pair.alloc(cap);
@@ -1009,6 +1021,11 @@ int swg_paf_ani_input(swg_paf* p, int threads, swg_ani_input* out) {
   p->ani.total_genome_size = total;
   p->have_ani = true;
   *out = p->ani;
+  } catch (const std::bad_alloc&) {
+    return paf_error(SWG_ERR_OOM, "out of host memory in the ANI pass over %llu records", (unsigned long long)n);
+  } catch (const std::system_error& e) {
+    return paf_error(SWG_ERR_OOM, "cannot start host threads: %s", e.what());
+  }
   return SWG_OK;
 }
 
@@ -1122,8 +1139,15 @@ int swg_filter_paf(swg_ctx* ctx, const char* in_path, const char* out_path, cons
   int rc = swg_paf_open(in_path, threads, &p);
   if (rc != SWG_OK) return rc;
   const uint64_t n = p->rec.n;
-  std::vector<uint8_t> status(n ? n : 1, 0);
-  std::vector<uint32_t> chain(n ? n : 1, 0);
+  std::vector<uint8_t> status;
+  std::vector<uint32_t> chain;
+  try {
+    status.assign(n ? n : 1, 0);
+    chain.assign(n ? n : 1, 0);
+  } catch (const std::bad_alloc&) {
+    swg_paf_close(p);
+    return paf_error(SWG_ERR_OOM, "out of host memory for the results of %llu records", (unsigned long long)n);
+  }
   auto t0 = clk::now();
   if (n) rc = swg_filter(ctx, &p->rec, cfg, status.data(), chain.data(), stats);
   const double filter_ms = ms_since(t0);

@@ -304,9 +304,27 @@ int main(int argc, char** argv) {
   if (devices.empty()) devices.push_back(device);
   uint64_t records_hint = 0;
   {
-    struct stat sb;  // a PAF line is rarely shorter than ~90 bytes; compressed inputs are not guessed
+    // lines in the file ~ file size / the average line length of its first 256 KB (real PAFs with cg:Z: / tp:A: tags run
+    // 150-250 bytes a line, bare ones ~90: a fixed guess over-reserves device memory for the whole run); compressed inputs
+    // are not guessed
+    struct stat sb;
     const bool gz = input.size() > 3 && (input.rfind(".gz") == input.size() - 3 || input.rfind(".bgz") == input.size() - 4);
-    if (input != "-" && !gz && stat(input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) records_hint = (uint64_t)sb.st_size / 90;
+    if (input != "-" && !gz && stat(input.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+      double per_line = 200.0;
+      if (FILE* f = fopen(input.c_str(), "rb")) {
+        std::vector<char> head(size_t(256) << 10);
+        const size_t got = fread(head.data(), 1, head.size(), f);
+        fclose(f);
+        size_t nl = 0, last = 0;
+        for (size_t i = 0; i < got; ++i)
+          if (head[i] == '\n') {
+            ++nl;
+            last = i + 1;
+          }
+        if (nl) per_line = (double)last / (double)nl;
+      }
+      records_hint = (uint64_t)((double)sb.st_size / per_line * 1.02) + 1;
+    }
   }
   std::vector<swg_ctx*> ctxs;
   int init_rc = SWG_OK;
@@ -325,7 +343,10 @@ int main(int argc, char** argv) {
       }
       ctxs.push_back(c);
       const auto w0 = std::chrono::steady_clock::now();
-      (void)swg_warmup(c, records_hint / devices.size(), 4096, cfg.scaffold_gap != 0);  // best effort: a failure shows up in the call
+      // best effort: a failure here (e.g. no room for the speculative reservation) shows up again, with its own message, in
+      // the filter call, which sizes itself; SWG_DEBUG prints this one too
+      if (swg_warmup(c, records_hint / devices.size(), 4096, cfg.scaffold_gap != 0) != SWG_OK && getenv("SWG_DEBUG"))
+        fprintf(stderr, "[sweepga-gpu] warm-up on device %d failed (ignored): %s\n", d, swg_last_error(c));
       warm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     }
   });

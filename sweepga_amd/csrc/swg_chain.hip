@@ -1267,7 +1267,9 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
 // from the candidate kernels.
 constexpr int WALK_HASH = 256;
 
-template <int BIGW, bool FUSED>
+// SPEC: a block of a long unit, run speculatively (own / prev views); a template parameter so that the main walk and the
+// speculative rounds are different kernels to a profiler (rocprofv3 and the library's own table then name the same launches).
+template <int BIGW, bool FUSED, bool SPEC>
 __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc, uint32_t m,
                                                         const uint64_t* __restrict__ s_grp,
                                                         const uint32_t* __restrict__ s_qs,
@@ -1278,9 +1280,10 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
                                                         const uint32_t* __restrict__ group_begin, uint32_t n_groups,
                                                         uint64_t max_gap, const unsigned long long* __restrict__ c_d,
                                                         const uint32_t* __restrict__ c_j, const uint32_t* __restrict__ c_n,
-                                                        int spec, unsigned long long* own, unsigned long long* prev,
+                                                        unsigned long long* own, unsigned long long* prev,
                                                         uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
                                                         unsigned long long* __restrict__ wstats) {
+  constexpr bool spec = SPEC;
   __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this range sees them
   __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end
   __shared__ uint32_t hcnt[WALK_HASH];
@@ -1816,7 +1819,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
       const bool packed_sort = all_members && pos_bits >= 8 && swg_radix_sort_packed_applies(M, key_bits, idx_bits);
       const bool identity = M == n;
-      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
+      SWG_LAUNCH(ctx, "sortA_keys_hist", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
                                         M, identity ? nullptr : B.idxA, identity && !packed_sort ? B.idxA : nullptr, r->q_id, r->t_id,
                                         r->strand, r->q_start, r->n_seq, pos_bits, B.keyA,
                                         packed_sort ? swg_radix_plan_packed(key_bits) : swg_radix_plan_pairs(0, key_bits), prehist));
@@ -1879,7 +1882,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     uint64_t* blk_cnt = swg_alloc<uint64_t>(ctx, n_blk);  // per 256-element block: (pair boundaries << 32) | group boundaries
     SWG_CHECK_ARENA(ctx);
     if (packedA)
-      SWG_LAUNCH(ctx, "gather_all", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
+      SWG_LAUNCH(ctx, "gather_all_packed", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
                                         M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
                                         pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt));
     else
@@ -1938,7 +1941,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       s_ts = B.a_ts;
       s_te = B.a_te;
       B.s_idx = B.idxA;
-      SWG_LAUNCH(ctx, "gatherS", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
+      SWG_LAUNCH(ctx, "gatherS_all", gatherS_all_kernel<<<nblk(m), EW, 0, st>>>(m, B.keyA, B.idxA, r->matches, r->block_len, pos_bits, s_qs,
                                                                 s_m, s_b, s_grp, head_flag));
     } else {
       SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
@@ -2064,13 +2067,13 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         work->span_big = span_big;
         const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * 64 ? n_chunks : (uint64_t)ctx->num_cu * 64;
         if (lists_all)
-          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false><<<(unsigned)wb, 64, 0, st>>>(
+          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 0, bps, bps, pred, pred, wstats));
+                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, bps, bps, pred, pred, wstats));
         else
-          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true><<<(unsigned)wb, 64, 0, st>>>(
+          SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, 0, bps, bps, pred, pred, wstats));
+                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, bps, bps, pred, pred, wstats));
         SWG_KERNEL_CHECK(ctx);
       }
       if (n_big) {
@@ -2098,7 +2101,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
           SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u, span_big));
           SWG_KERNEL_CHECK(ctx);
-          SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+          SWG_LAUNCH(ctx, "spec_plan_from_wmax", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
                                                                                 (uint32_t)m, wmax_u, S_u, nblk_u,
                                                                                 reinterpret_cast<uint32_t*>(d_smax)));
           SWG_KERNEL_CHECK(ctx);
@@ -2133,9 +2136,9 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           SWG_KERNEL_CHECK(ctx);
           const unsigned wblocks = (unsigned)(n_spec < (uint64_t)ctx->num_cu * 32 ? n_spec : (uint64_t)ctx->num_cu * 32);
 #define SWG_WALK_SPEC(W, F)                                                                                                       \
-  SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, F><<<wblocks, 64, 0, st>>>(                                               \
+  SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, F, true><<<wblocks, 64, 0, st>>>(                                         \
                                          (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin, \
-                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, 1, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr))
+                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr))
           if (!lists_all) {
             if (ring <= 256)
               SWG_WALK_SPEC(256, true);
@@ -2224,7 +2227,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
           const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
           SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u));
           SWG_KERNEL_CHECK(ctx);
-          SWG_LAUNCH(ctx, "spec_plan", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
+          SWG_LAUNCH(ctx, "spec_plan_from_wmax", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
                                                                                 (uint32_t)m, wmax_u, S_u, nblk_u,
                                                                                 reinterpret_cast<uint32_t*>(d_smax)));
           SWG_KERNEL_CHECK(ctx);

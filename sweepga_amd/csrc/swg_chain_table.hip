@@ -633,7 +633,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_KERNEL_CHECK(ctx);
   if (B.m == B.M) {
     // members == alive records: a genome pair's first record is the smallest of its (query, target, strand) groups' firsts
-    SWG_LAUNCH(ctx, "genome_pair_first", genome_pair_first_groups_kernel<<<nblk(n_groups), EW, 0, st>>>(
+    SWG_LAUNCH(ctx, "genome_pair_first_groups", genome_pair_first_groups_kernel<<<nblk(n_groups), EW, 0, st>>>(
                                              (uint32_t)n_groups, group_begin, B.s_idx, group_first, r->q_id, r->t_id,
                                              r->seq_genome_last, gp_first));
   } else {

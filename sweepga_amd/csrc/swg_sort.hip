@@ -1070,10 +1070,10 @@ int swg_radix_sort_packed(swg_ctx* ctx, uint64_t* keys, const uint32_t* vals, ui
     const uint32_t* gb = ghist + (size_t)p * SWG_RADIX_BINS;
     SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * (bits == 9 ? P9_BINS : RS_RADIX), ctx->stream));
     if (p == 0)
-      SWG_LAUNCH_N(ctx, "os_pass_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass_packed_first", n, os_pass_packed_kernel<uint32_t, true><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                              src, vals, dst, n, 0, mask, val_bits, gb, status, tickets));
     else if (bits == 9)
-      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed9_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
+      SWG_LAUNCH_N(ctx, "os_pass_packed9", n, os_pass_packed9_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
                                               src, dst, n, wshift, gb, status, tickets + p));
     else
       SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, PK_THREADS, 0, ctx->stream>>>(

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     const uint32_t m = m1 > m2 ? m1 : m2;
     if (m > mx) mx = m;
     cnt += ok ? 1u : 0u;
-    zero += (ok && (a == b || c == d)) ? 1u : 0u;  // retained records of zero length on an axis (an unlimited sweep drops them)
+    // retained records that are degenerate on an axis: zero length (an unlimited sweep drops them), and reversed (malformed
+    // PAF, not modelled -- DESIGN.md section 4 -- but counted here with the SAME test kinf_mark uses, start >= end, so that
+    // whether the identity shortcut is taken never depends on which other records share the input with such a record)
+    zero += (ok && (a >= b || c >= d)) ? 1u : 0u;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1297,7 +1300,7 @@ int swg_kinf_both(swg_ctx* ctx, uint64_t n, const uint32_t* qs, const uint32_t* 
   uint32_t* n_zero = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(n_zero, 0, 8, ctx->stream));
-  SWG_LAUNCH(ctx, "kinf_mark", kinf_mark_both_kernel<<<(unsigned)((n + EW_THREADS - 1) / EW_THREADS), EW_THREADS, 0, ctx->stream>>>(
+  SWG_LAUNCH(ctx, "kinf_mark_both", kinf_mark_both_kernel<<<(unsigned)((n + EW_THREADS - 1) / EW_THREADS), EW_THREADS, 0, ctx->stream>>>(
                                    n, qs, qe, ts, te, alive, keep, n_zero));
   SWG_KERNEL_CHECK(ctx);
   uint64_t h = 0;
@@ -1385,7 +1388,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_CHECK_ARENA(ctx);
       S = other;
       E = reinterpret_cast<uint32_t*>(third);
-      SWG_LAUNCH(ctx, "begin_gather", begin_gather_packed_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+      SWG_LAUNCH(ctx, "begin_gather_packed", begin_gather_packed_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
                                           n, P, idx_bits, in.packed, in.packed_end, in.pos_bits, S, I, E, KEY, tile_x, single));
       SWG_KERNEL_CHECK(ctx);
     } else if (prc != SWG_ERR_UNSUPPORTED) {

@@ -30,3 +30,23 @@ def test_summary_line_of_a_full_report_is_small():
     assert set(line["config"]) <= {"workload", "flags", "mappings_per_gpu", "groups_per_gpu"} and "model" not in line["config"]
     assert line["sbig1_default_ms"] == round(full["sbig1"]["pipelines"]["default"]["ms_per_step"], 4)
     assert line["parity_ok"] is True and line["detail"] == "gpurun_out/bench_detail.json"
+
+
+def test_line_degrades_instead_of_failing():
+    """A report that outgrows the limit still yields ONE parsable line under it (optional keys go first, `truncated` says
+    which) -- never an exception after a multi-minute run."""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench_100m.json")))
+    full["ms_per_step_unprofiled"] = full["ms_per_step"]
+    line = b.summary_line(full, None)
+    line["cpu_baseline"]["sample"] = "x" * 3000
+    line["cpu_baseline_all_cores"]["sample"] = "y" * 3000
+    line["config"]["workload"] = "w" * 3000
+    text = b.fit_line(line)
+    out = json.loads(text)
+    assert len(text) < b.MAX_LINE_BYTES and out["truncated"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    small = b.summary_line(full, None)
+    assert "truncated" not in json.loads(b.fit_line(small))

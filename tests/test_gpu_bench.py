@@ -49,11 +49,12 @@ def test_stdout_line_is_small_and_complete(line):
     assert d["_line_bytes"] < 4096, d["_line_bytes"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_unprofiled", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores",
-              "sweep_ms_per_step", "full_ms_per_step", "sbig1_sweep_ms", "sbig1_default_ms", "sbig1_full_ms", "pcie_default_ms",
+              "sweep_ms_per_step", "full_ms_per_step", "c5_ms_per_step", "sbig1_sweep_ms", "sbig1_default_ms", "sbig1_full_ms", "pcie_default_ms",
               "pcie_sweep_ms", "parity", "parity_ok", "detail"):
         assert k in ln, k
     assert ln["value"] == pytest.approx(d["value"], rel=1e-6) and ln["ms_per_step"] == pytest.approx(d["ms_per_step"], abs=1e-3)
-    assert ln["parity_ok"] is True and len(ln["parity"]) == 6
+    assert ln["parity_ok"] is True and len(ln["parity"]) == 7 and ln["parity"]["span_c5"]["ok"] is True
+    assert ln["parity"]["span_c5"]["checked"] == n
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "pipeline_frac"):
         assert k in ln["roofline"], k
     assert ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] == 1
@@ -81,7 +82,7 @@ def test_bench_line_contract(line):
         assert d["pcie_inclusive"][p]["value"] > 0 and d["pcie_inclusive"][p]["h2d_ms"] > 0
 
 
-@pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
+@pytest.mark.parametrize("pipeline", ["sweep", "full", "default", "c5"])
 def test_bench_pipelines_and_parity(line, pipeline):
     n, d = line
     p = d["pipelines"][pipeline]
@@ -93,6 +94,9 @@ def test_bench_pipelines_and_parity(line, pipeline):
     assert pa["mappings_checked"] == n and pa["status_equal"] is True
     assert pa["chain_partition_equal"] is (None if pipeline == "sweep" else True)
     assert p["counts"]["in"] == n and 0 < p["counts"]["out"] < n
+    if pipeline == "c5":  # BASELINE.json configs[4] as written: many:many mappings, so every record is chained (members = input)
+        assert p["flags"] == "--scaffold-filter 1:1 --scaffold-dist 20000" and p["counts"]["swept"] == n
+        assert p["counts"]["out"] > d["pipelines"]["full"]["counts"]["out"]
 
 
 @pytest.mark.parametrize("pipeline", ["sweep", "full", "default"])
@@ -120,9 +124,34 @@ def test_strong_scaling_mode_one_gpu():
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["_line_bytes"] < 4096 and d["_line"]["strong"]["mappings_total"] == n
     ss = d["strong_scaling"]
     assert ss["mappings_total"] == n and ss["shard_mappings_rank0"] == n and ss["load_max_over_mean"] == 1.0
-    for p in ("default", "sweep", "full"):
+    for p in ("default", "sweep", "full", "c5"):
         assert ss["pipelines"][p]["ms_per_step"] > 0 and len(ss["pipelines"][p]["per_rank_ms"]) == 1
     assert ss["pipelines"]["default"]["renumber_s"] is not None and ss["pipelines"]["sweep"]["renumber_s"] is None
+
+
+def test_two_rank_launch_rehearsal():
+    """The path an N-GPU driver run takes -- bench.py --gpus N spawns torch.distributed.run before touching a GPU, every
+    rank joins a process group, barriers, MAX-over-ranks timing, (strong) LPT shards + the all_reduce(MIN) chain
+    renumbering -- executed end to end with 2 ranks on this box's one GPU (`--rehearse`: rank r on device r mod 1, gloo
+    instead of RCCL).  Strong mode: the fingerprint of (record, status, GLOBAL chain number) over both shards must equal
+    the unsharded run's, for every flag set.  Not a scaling measurement."""
+    n = 2_000_000
+    common = ("--mappings", str(n), "--genomes", "21", "--steps", "2", "--warmup", "1")
+    one = run_bench("--scaling", "strong", *common)
+    two = run_bench("--scaling", "strong", "--gpus", "2", "--rehearse", *common)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "gloo" in two["_line"]["rehearsal"]
+    ss = two["strong_scaling"]
+    assert ss["mappings_total"] == n and 0 < ss["shard_mappings_rank0"] < n and 1.0 <= ss["load_max_over_mean"] < 1.05
+    assert sum(ss["loads"]) == n
+    for p in ("default", "sweep", "full", "c5"):
+        e = ss["pipelines"][p]
+        assert len(e["per_rank_ms"]) == 2 and all(x > 0 for x in e["per_rank_ms"])
+        assert e["ms_per_step"] >= max(e["per_rank_ms"]) * 0.999   # the reported time is the MAX over ranks
+        assert e["result_checksum"] == one["strong_scaling"]["pipelines"][p]["result_checksum"], p
+    # weak mode: every rank filters its own shard of n mappings; value = all ranks' mappings / max-over-ranks time
+    w = run_bench("--gpus", "2", "--rehearse", "--only", *common)
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["_line"]["n_gpus"] == 2
+    assert abs(w["value"] - 2 * n / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
 
 
 def test_smoke_entry():

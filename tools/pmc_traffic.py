@@ -26,6 +26,17 @@ def short_name(name):
         base = base[:-7]
     if base == "sweep_tile":
         base += "_k1" if "true" in targs else "_kn"
+    # the names below are the labels of the library's own per-launch table (SWG_LAUNCH): one label = one kernel = one rocprof
+    # name, so that bench.py divides a label's PMC bytes by the duration of the SAME launches
+    t = [x.strip() for x in targs.strip("<>").split(",")] if targs else []
+    if base == "chain_walk" and len(t) >= 3 and t[2] == "true":
+        base = "chain_walk_spec"      # blocks of long units, speculative rounds (template <BIGW, FUSED, SPEC>)
+    if base == "os_pass_packed" and len(t) >= 2 and t[1] == "true":
+        base = "os_pass_packed_first"  # the pass that reads (key, value) pairs and writes packed words
+    if base in ("fill_u32", "fill_u64"):
+        base = "fill"
+    if base == "iota_u32":
+        base = "iota"
     return base
 
 
@@ -35,6 +46,9 @@ def collect(d, counter):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
+            raw = row["Kernel_Name"]
+            if any(t in raw for t in ("at::", "rocprim::", "thrust::", "hipcub::", "c10::")):
+                continue  # torch's kernels (the synthetic record generator), not the library's
             a = acc[short_name(row["Kernel_Name"])]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
@@ -43,14 +57,22 @@ def collect(d, counter):
 
 def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    # filter calls inside one profiled bench.py run (--steps 1 --warmup 0: timed + un-profiled + statistics = 3)
+    calls = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
+    total = 0.0
     for k in sorted(set(fe) | set(wr)):
         f = fe[k][1] / fe[k][0] if fe[k][0] else 0.0
         w = wr[k][1] / wr[k][0] if wr[k][0] else 0.0
-        kernels[k] = {"launches_profiled": max(fe[k][0], wr[k][0]), "fetch_size_kb_per_launch": f,
-                      "write_size_kb_per_launch": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
-    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "kernels": kernels}, indent=1))
+        launches = max(fe[k][0], wr[k][0])
+        per_launch = (2.0 * f + w) * 1024.0
+        kernels[k] = {"launches_profiled": launches, "launches_per_call": launches / calls, "fetch_size_kb_per_launch": f,
+                      "write_size_kb_per_launch": w, "hbm_bytes_per_launch": per_launch,
+                      "hbm_bytes_per_call": per_launch * launches / calls}
+        total += per_launch * launches / calls
+    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "calls_profiled": calls, "hbm_bytes_per_call_all_kernels": total,
+                      "kernels": kernels}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the rocprof evidence of one version under gpurun_out/<tag>/ (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>        e.g. r02_v3
-# For the three flag sets on the S-pan workload (10^8 mappings) and for the S-big1 workload (10^7, one pair):
+# For the four flag sets (default, sweep, full, c5) on the S-pan workload (10^8 mappings) and three on S-big1 (10^7, one pair):
 #   * rocprofv3 --kernel-trace --stats               -> <tag>_<flags>_<workload>_kernel_stats.csv
 #   * two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, as MI355X_MICROARCH.md prescribes; never combined with other
 #     trace domains) reduced by tools/pmc_traffic.py  -> <tag>_hbm_traffic_<flags>_<workload>.json
@@ -13,16 +13,16 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--only --cpu-sample 0 --no-pcie --e2e 0 --sbig1 0"
-run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings
-  WL=$1; SUF=$2; NM=$3
-  for p in default sweep full; do
+run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = flag sets
+  WL=$1; SUF=$2; NM=$3; PIPES=$4
+  for p in $PIPES; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 3 --warmup 1 $COMMON > $OUT/stats_${p}_$SUF.log 2>&1
     f=$(find $OUT/stats_${p}_$SUF -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && cp $f $OUT/${TAG}_${p}_${SUF}_kernel_stats.csv
     find $OUT/stats_${p}_$SUF -name "*kernel_trace.csv" -delete
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_fetch_${p}_$SUF.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_write_${p}_$SUF.log 2>&1
-    python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
+    python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM 3 > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
     find $OUT -name "*kernel_trace.csv" -delete
   done
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1_$SUF -- python3 $R/bench.py --workload $WL --pipeline sweep --steps 1 --warmup 0 $COMMON > $OUT/sq1_$SUF.log 2>&1
@@ -30,7 +30,7 @@ run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings
   { echo "# rocprofv3 --pmc SQ counters, per-launch averages (tools/pmc_table.py), sweep flags, workload $SUF"; python3 $R/tools/pmc_table.py $OUT/sq1_$SUF; python3 $R/tools/pmc_table.py $OUT/sq2_$SUF; } > $OUT/${TAG}_sq_$SUF.txt
   find $OUT -name "*kernel_trace.csv" -delete
 }
-run_set span 100m 100000000
-run_set sbig1 sbig1_10m 10000000
+run_set span 100m 100000000 "default sweep full c5"   # c5 = BASELINE.json configs[4] as written (many:many + scaffold 1:1 + rescue)
+run_set sbig1 sbig1_10m 10000000 "default sweep full"
 cd $R
 ls -la $OUT | head -60
