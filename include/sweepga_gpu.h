@@ -100,7 +100,9 @@ typedef struct swg_records {
   const uint32_t* q_end;     /* [n] */
   const uint32_t* t_start;   /* [n] */
   const uint32_t* t_end;     /* [n] */
-  const double* identity;    /* [n] RecordMeta.identity */
+  const double* identity;    /* [n] RecordMeta.identity; may be NULL = matches / max(block_len, 1) for every record, which
+                                is what extract_metadata computes when no dv:f: tag overrides it (src/paf_filter.rs:322):
+                                evaluated on the device (one IEEE division, same bits), 8 of 47 bytes per record less over PCIe */
   const uint32_t* matches;   /* [n] RecordMeta.matches */
   const uint32_t* block_len; /* [n] RecordMeta.block_length */
   const uint8_t* strand;     /* [n] 0 = '+', 1 = '-' */
@@ -138,9 +140,17 @@ int swg_synchronize(swg_ctx* ctx);
 
 /* ---- the filter: PafFilter::apply_filters (src/paf_filter.rs:379-747) ----------------- */
 /* status_out[n]: SWG_ST_*; chain_out[n]: N of "ch:Z:chain_N", 0 = no ch:Z: tag.
- * Host buffers in, host buffers out (copies included). */
+ * Host buffers in, host buffers out (copies included).  When the records are grouped by query genome (an aligner writes its
+ * PAF query by query) and there are millions of them, the call is streamed: ranges of whole query genomes -- closed under
+ * genome pairs, the filter's independent units -- are uploaded while their predecessors are filtered, and each range's
+ * results are copied back as soon as it is done (SWG_STREAM=0 switches that off; results are identical either way). */
 int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg, uint8_t* status_out,
                uint32_t* chain_out, swg_stats* stats);
+/* The ranges such a call would use (host code, no GPU): bounds_out[0 .. *n_chunks] are record indices, ranges of at least
+ * target_records records cut where the query genome changes.  *n_chunks = 0: the records are not grouped by query genome
+ * (or the reference's two genome-prefix rules partition the sequences differently) -- the call runs in one piece. */
+int swg_stream_plan(const swg_records* rec, uint64_t target_records, uint64_t* bounds_out, uint64_t bounds_capacity,
+                    uint64_t* n_chunks);
 /* Same with every pointer of `rec`, status_out and chain_out in device memory of ctx's GPU.
  * Asynchronous on swg_stream(ctx) except for the small read-backs the pipeline needs. */
 int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cfg,
@@ -241,10 +251,13 @@ int swg_reserve(swg_ctx* ctx, uint64_t arena_bytes);
 int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_hint, int with_scaffold);
 
 /* ---- several devices of one node ---------------------------------------------------------------
- * swg_filter over n_ctx contexts (one per device, created by the caller): records are partitioned by genome pair
- * (first-two-'#'-parts prefix), pairs are bin-packed onto the contexts by mapping count, every context filters its
- * part on its own host thread, and chain numbers are made global again on the host (the reference numbers kept
- * chains genome pair by genome pair in first-appearance order, src/paf_filter.rs:517-521).  No collective.  Falls
+ * swg_filter over n_ctx contexts (one per device, created by the caller).  Records grouped by query genome: ranges of whole
+ * query genomes are dealt to the contexts by size (longest first), every context streams its ranges as swg_filter does --
+ * slices of the caller's columns in, slices of the caller's result arrays out, no host-side copy of the record set.
+ * Otherwise: records are partitioned by genome pair (first-two-'#'-parts prefix) on host threads, pairs are bin-packed
+ * onto the contexts by mapping count, every context filters its part on its own host thread.  Either way chain numbers are
+ * made global again on the host (the reference numbers kept chains genome pair by genome pair in first-appearance
+ * order, src/paf_filter.rs:517-521).  No collective.  Falls
  * back to ctxs[0] alone when the two genome-prefix rules of the reference partition the sequences differently.
  * Results are identical to swg_filter(ctxs[0], ...).  Errors are reported on ctxs[0]. */
 int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_records* records, const swg_config* cfg, uint8_t* status_out,
@@ -269,6 +282,9 @@ void swg_paf_close(swg_paf* p);
  * is parsed once more into 64-bit columns and rebased per sequence as swg_filter64 does: the coordinate columns are
  * then relative to swg_paf_seq_offsets()[sequence id] (NULL for a file that needed no rebasing). */
 const swg_records* swg_paf_records(const swg_paf* p);
+/* 1 when every record's identity is matches / max(block_len, 1) -- no dv:f: tag had the last word on any line: a caller may
+ * then pass identity = NULL in the records it hands to the filter and save the column's trip over PCIe. */
+int swg_paf_identity_is_derived(const swg_paf* p);
 const uint64_t* swg_paf_seq_offsets(const swg_paf* p);
 /* physical line count (incl. skipped lines) and each record's rank = 0-based line index (src/paf_filter.rs:298) */
 uint64_t swg_paf_num_lines(const swg_paf* p);

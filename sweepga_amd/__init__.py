@@ -5,7 +5,7 @@ this package is the thin host-side mirror of the reference's filter interface ov
 """
 from ._lib import Context, SwgError, K_INF, default_context, load  # noqa: F401
 from .filter import (ChainStatus, FilterConfig, FilterMode, PafFilter, PlaneSweepMapping, RecordMeta,  # noqa: F401
-                     ScoringFunction, SequenceIndex, pack_records, plane_sweep_both, plane_sweep_query,
+                     ScoringFunction, SequenceIndex, pack_records, stream_plan, plane_sweep_both, plane_sweep_query,
                      plane_sweep_target, USIZE_MAX, UnionFind, merge_mappings_into_chains, plane_sweep_scaffolds)
 from .paf import PafFile  # noqa: F401
 from .aln import AlnRecords  # noqa: F401

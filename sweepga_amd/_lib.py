@@ -23,7 +23,7 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_filter_multi", "swg_filter_multi64", "swg_memory_info", "swg_reserve", "swg_warmup",
            "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name",
            "swg_paf_seq_offsets", "swg_aln_seq_offsets",
-           "swg_paf_tree_filter", "swg_free",
+           "swg_paf_tree_filter", "swg_free", "swg_stream_plan", "swg_paf_identity_is_derived",
            "swg_alnstats_open", "swg_alnstats_open_buffer", "swg_alnstats_close", "swg_alnstats_get", "swg_alnstats_pair",
            "swg_alnstats_report", "swg_alnstats_compare", "swg_alnstats_last_error"]
 

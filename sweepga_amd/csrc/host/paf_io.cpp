@@ -368,6 +368,7 @@ struct Slice {
   uint64_t err_line = 0;
   const char* err_what = nullptr;
   bool wide = false;             // met a coordinate / matches / block length >= 2^32
+  bool custom_identity = false;  // a record whose identity is not matches / max(block length, 1) (a dv:f: tag had the last word)
 };
 
 }  // namespace
@@ -385,6 +386,7 @@ struct swg_paf {
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
   swg_records rec{};
+  bool identity_derived = false;     // every record's identity is matches / max(block length, 1)
   double load_ms = 0, parse_ms = 0;
   // ANI view (filled by swg_paf_ani_input)
   bool have_ani = false;
@@ -541,6 +543,9 @@ int parse_text(swg_paf* p, int threads) {
         p->block[k] = narrow(block);
       }
       p->identity[k] = identity;
+      // (what the device would compute from the 32-bit columns it is given; a value >= 2^32 sends the file to the wide path
+      // anyway, whose rebased matches / block lengths are the same numbers)
+      if (!(identity == (double)matches / denom)) s.custom_identity = true;
       p->strand[k] = (f[5] - 1 - f[4] == 1 && *f[4] == '+') ? 0 : 1;
       p->rank[k] = line;
       p->rec_off[k] = (uint64_t)(b - text);
@@ -553,7 +558,11 @@ int parse_text(swg_paf* p, int threads) {
   pass2(false);
   lap("alloc + pass 2 (parse)");
   bool wide = false;
-  for (auto& s : sl) wide = wide || s.wide;
+  p->identity_derived = true;
+  for (auto& s : sl) {
+    wide = wide || s.wide;
+    if (s.custom_identity) p->identity_derived = false;
+  }
   if (wide) {
     for (auto& w : p->wide) w.alloc(cap);
     pass2(true);
@@ -796,6 +805,7 @@ int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** o
 
 void swg_paf_close(swg_paf* p) { delete p; }
 const swg_records* swg_paf_records(const swg_paf* p) { return p ? &p->rec : nullptr; }
+int swg_paf_identity_is_derived(const swg_paf* p) { return p && p->identity_derived ? 1 : 0; }
 const uint64_t* swg_paf_seq_offsets(const swg_paf* p) { return (p && !p->seq_offset.empty()) ? p->seq_offset.data() : nullptr; }
 uint64_t swg_paf_num_lines(const swg_paf* p) { return p ? p->n_lines : 0; }
 const uint64_t* swg_paf_ranks(const swg_paf* p) { return p ? p->rank.data() : nullptr; }

@@ -86,7 +86,7 @@ struct Shard {
     sub.q_end = qe.data();
     sub.t_start = ts.data();
     sub.t_end = te.data();
-    sub.identity = identity.data();
+    sub.identity = whole.identity ? identity.data() : nullptr;  // NULL = derived from matches / block length on the device
     sub.matches = matches.data();
     sub.block_len = block.data();
     sub.strand = strand.data();
@@ -183,7 +183,7 @@ inline bool make_plan(const swg_records& r, const swg_config& cfg, int n_shards,
       pair[i] = p;
       ++c[p];
       if (f[p] == n && (uint64_t)r.block_len[i] >= cfg.min_block_length && (cfg.keep_self || r.q_id[i] != r.t_id[i]) &&
-          r.identity[i] >= cfg.min_identity)
+          (r.identity ? r.identity[i] : (double)r.matches[i] / (double)(r.block_len[i] > 1 ? r.block_len[i] : 1)) >= cfg.min_identity)
         f[p] = i;
     }
   });
@@ -231,7 +231,7 @@ inline void scatter(const swg_records& r, const Plan& P, std::vector<Shard>* sha
       Shard& S = sh[s];
       S.m = P.load[s];
       S.idx.alloc(S.m); S.q_id.alloc(S.m); S.t_id.alloc(S.m); S.qs.alloc(S.m); S.qe.alloc(S.m); S.ts.alloc(S.m);
-      S.te.alloc(S.m); S.matches.alloc(S.m); S.block.alloc(S.m); S.chain.alloc(S.m); S.identity.alloc(S.m);
+      S.te.alloc(S.m); S.matches.alloc(S.m); S.block.alloc(S.m); S.chain.alloc(S.m); if (r.identity) S.identity.alloc(S.m);
       S.strand.alloc(S.m); S.status.alloc(S.m);
     }
   });
@@ -256,7 +256,7 @@ inline void scatter(const swg_records& r, const Plan& P, std::vector<Shard>* sha
       S.te.data()[k] = r.t_end[i];
       S.matches.data()[k] = r.matches[i];
       S.block.data()[k] = r.block_len[i];
-      S.identity.data()[k] = r.identity[i];
+      if (r.identity) S.identity.data()[k] = r.identity[i];
       S.strand.data()[k] = r.strand[i];
     }
   });

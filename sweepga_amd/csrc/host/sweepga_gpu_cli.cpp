@@ -433,8 +433,12 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> chain(n ? n : 1, 0);
   swg_stats st{};
   if (n) {
-    const int rc = ctxs.size() > 1 ? swg_filter_multi(ctxs.data(), (int)ctxs.size(), r, &cfg, status.data(), chain.data(), &st)
-                                   : swg_filter(ctx, r, &cfg, status.data(), chain.data(), &st);
+    // no dv:f: override anywhere: identity = matches / max(block length, 1) for every record, which the device evaluates
+    // itself -- the column (8 of 47 bytes per record) stays on the host
+    swg_records rr = *r;
+    if (swg_paf_identity_is_derived(paf)) rr.identity = nullptr;
+    const int rc = ctxs.size() > 1 ? swg_filter_multi(ctxs.data(), (int)ctxs.size(), &rr, &cfg, status.data(), chain.data(), &st)
+                                   : swg_filter(ctx, &rr, &cfg, status.data(), chain.data(), &st);
     if (rc != SWG_OK) die(3, std::string("filter failed: ") + swg_last_error(ctx));
   }
   const auto t2 = clk::now();

@@ -1305,10 +1305,15 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       return __hip_atomic_load(view_ptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     uint32_t base = b;
+    // A chunk of whole units (!SPEC) starts from "no score anywhere" and nothing outside the chunk ever reads its scores, so
+    // they live in the LDS ring alone: the score array in memory (`own`) is neither initialised beforehand nor read -- until
+    // the first commit beyond the ring (rare), which first writes "no score" to the part of the chunk that has not entered
+    // the ring yet and from then on (far_any) the chunk reads that array like a speculative block does.
+    bool far_any = SPEC;
     __syncthreads();
     for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
       const bool ok = p < ue;
-      ring[p % BIGW] = ok ? view_load(p) : INF;
+      ring[p % BIGW] = (ok && SPEC) ? view_load(p) : INF;
       rq[p % BIGW] = ok ? s_qs[p] : 0xffffffffu;
       rt[p % BIGW] = ok ? s_ts[p] : 0u;
       re[p % BIGW] = ok ? s_te[p] : 0u;
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
     __syncthreads();
     auto current = [&](uint32_t j) -> uint64_t {  // the committed score of j
       if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
-      return view_load(j);
+      return far_any ? view_load(j) : INF;
     };
     // What a batch needs from memory is requested one batch ahead (the walk of a range is one dependent chain per wavefront:
     // what a batch waits for is what the range costs): the 64 positions that enter the ring, and the batch's own elements --
@@ -1337,7 +1342,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       if (refill) {
         const uint32_t pn = base_n + BIGW - 64 + lane;  // the positions that enter when the ring moves to base_n
         if (pn < ue) {
-          P.view = view_load(pn);
+          if (far_any) P.view = view_load(pn);
           P.q = s_qs[pn];
           P.t = s_ts[pn];
           P.e = s_te[pn];
@@ -1487,7 +1492,14 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         // beyond the ring (rare): one lane at a time in lane order, a returning atomic minimum at the memory side -- the lane
         // that lowers the score is (so far) the last acceptance; no fence, no cache maintenance
         uint64_t far = __ballot(me && !inr);
-        if (far) far_dirty = true;
+        if (far) {
+          far_dirty = true;
+          if (!far_any) {  // (wave-uniform) the first commit beyond the ring in this chunk: see far_any above
+            for (uint32_t p = base + BIGW + lane; p < ue; p += 64) own[p] = INF;
+            __threadfence();  // the stores are performed before the atomics below (once per chunk at most)
+            far_any = true;
+          }
+        }
         while (far) {
           const int l = __builtin_ctzll(far);
           far &= far - 1;
@@ -1955,8 +1967,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     SWG_TRY(swg_read_scalars(ctx, d_tot + 3, &n_groups, 1));
   }
   // ---- best-buddy chaining
-  SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(bps), ~0ull));
-  SWG_KERNEL_CHECK(ctx);
+  static const bool old_walk_fill = getenv("SWG_CHAIN_OLD") != nullptr;
+  if (old_walk_fill) {  // the round-2 selection kernels read the score array from the start; the walk initialises what it uses
+    SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(bps), ~0ull));
+    SWG_KERNEL_CHECK(ctx);
+  }
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
   SWG_KERNEL_CHECK(ctx);
   {

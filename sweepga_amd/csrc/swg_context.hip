@@ -248,6 +248,10 @@ void swg_destroy(swg_ctx* ctx) {
     (void)hipEventDestroy(p.b);
   }
   for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

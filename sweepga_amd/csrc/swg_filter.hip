@@ -255,7 +255,8 @@ static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
   if (!ctx) return SWG_ERR_INVALID;
   if (!r || !cfg) return swg_set_error(ctx, SWG_ERR_INVALID, "records/config is NULL");
   if (r->n >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "more than 2^31-1 records");
-  if (r->n && (!r->q_id || !r->t_id || !r->q_start || !r->q_end || !r->t_start || !r->t_end || !r->identity ||
+  // (identity may be NULL: then it is matches / max(block_len, 1), computed where it is read -- see swg_records)
+  if (r->n && (!r->q_id || !r->t_id || !r->q_start || !r->q_end || !r->t_start || !r->t_end ||
                !r->matches || !r->block_len || !r->strand || !r->seq_genome_last || !r->seq_genome_two))
     return swg_set_error(ctx, SWG_ERR_INVALID, "a record column is NULL");
   if (r->n && (r->n_seq == 0 || r->n_genome_last == 0 || r->n_genome_two == 0))
@@ -265,6 +266,28 @@ static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
   if (cfg->mapping_filter_mode < 0 || cfg->mapping_filter_mode > 2 || cfg->scaffold_filter_mode < 0 ||
       cfg->scaffold_filter_mode > 2)
     return swg_set_error(ctx, SWG_ERR_INVALID, "bad filter mode");
+  return SWG_OK;
+}
+
+// Scratch high-water marks measured on the 10^8 workload (round 3): 82 B/record for the sweep-only pipeline (32-byte record
+// slots, packed sort), 204-223 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
+// context's first call (and, for the streamed host path, any re-allocation between its ranges).
+int swg_filter_reserve_arena(swg_ctx* ctx, uint64_t n, const swg_records* rec, const swg_config* cfg, bool wide) {
+  size_t want = (size_t)n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + (wide ? 24 : 0)) + (size_t(8) << 20) +
+                (wide ? (size_t)rec->n_seq * 8 : 0);
+  if (cfg->scaffold_gap != 0) {
+    // the scaffold stage keeps two genome-pair tables (first appearance of a pair under either prefix rule): dense
+    // G x G up to 2^14 genomes, else hashed over the pairs that occur (names without '#': every sequence its own genome)
+    for (const uint64_t g : {(uint64_t)rec->n_genome_last, (uint64_t)rec->n_genome_two})
+      want += g * g <= (uint64_t(1) << 28) ? (size_t)(g * g) * sizeof(uint32_t) : (size_t)n * 4 * 12;
+  }
+  if (ctx->arena_cap < want) {
+    size_t free_b = 0, total_b = 0;
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    // never ask for more than what is free (plus what the old arena gives back); the retry path still covers the rest
+    const size_t room = known ? free_b + ctx->arena_cap : want;
+    SWG_TRY(swg_arena_reserve(ctx, want < room ? want : (room > (size_t(64) << 20) ? room - (size_t(64) << 20) : want)));
+  }
   return SWG_OK;
 }
 
@@ -314,26 +337,7 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
                              uint8_t* status_out, uint32_t* chain_out, swg_stats* stats) {
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
-  // Scratch high-water marks measured on the 10^8 workload (round 3): 82 B/record for the sweep-only pipeline (32-byte record
-  // slots, packed sort), 204-223 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
-  // context's first call.
-  {
-    size_t want = (size_t)rec->n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + (rec64 ? 24 : 0)) + (size_t(8) << 20) +
-                  (rec64 ? (size_t)rec->n_seq * 8 : 0);
-    if (cfg->scaffold_gap != 0) {
-      // the scaffold stage keeps two genome-pair tables (first appearance of a pair under either prefix rule): dense
-      // G x G up to 2^14 genomes, else hashed over the pairs that occur (names without '#': every sequence its own genome)
-      for (const uint64_t g : {(uint64_t)rec->n_genome_last, (uint64_t)rec->n_genome_two})
-        want += g * g <= (uint64_t(1) << 28) ? (size_t)(g * g) * sizeof(uint32_t) : (size_t)rec->n * 4 * 12;
-    }
-    if (ctx->arena_cap < want) {
-      size_t free_b = 0, total_b = 0;
-      const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-      // never ask for more than what is free (plus what the old arena gives back); the retry path still covers the rest
-      const size_t room = known ? free_b + ctx->arena_cap : want;
-      SWG_TRY(swg_arena_reserve(ctx, want < room ? want : (room > (size_t(64) << 20) ? room - (size_t(64) << 20) : want)));
-    }
-  }
+  SWG_TRY(swg_filter_reserve_arena(ctx, rec->n, rec, cfg, rec64 != nullptr));
   SWG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc = swg_run_with_arena(ctx, [&]() -> int {
     if (!rec64 || rec->n == 0) return filter_device_body(ctx, rec, cfg, status_out, chain_out, stats);
@@ -414,6 +418,8 @@ static int io_block_reserve(swg_ctx* ctx, size_t total) {
   return SWG_OK;
 }
 
+int swg_io_block_reserve(swg_ctx* ctx, uint64_t n, uint32_t n_seq) { return io_block_reserve(ctx, io_block_bytes(n, n_seq)); }
+
 // Host buffers in / out: stage through device copies, then the device entry point.  The staging block lives in the
 // context (no allocation in steady state).  Only what the configuration reads crosses PCIe: `matches` and `strand` are
 // scaffold-stage inputs (src/paf_filter.rs:875-894, 761-770) and the chain ids are all zero without scaffolding
@@ -428,9 +434,16 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
     return SWG_OK;
   }
   if (!status_out || !chain_out) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
+  {  // records grouped by query genome and enough of them: ranges uploaded while their predecessors are filtered
+    int taken = 0;
+    swg_ctx* one[1] = {ctx};
+    const int src = swg_stream_try(one, 1, rec, cfg, status_out, chain_out, stats, &taken);
+    if (src != SWG_OK || taken) return src;
+  }
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const bool scaffold = cfg->scaffold_gap != 0;
+  const bool derived_identity = rec->identity == nullptr;  // matches / max(block_len, 1), evaluated on the device
   const size_t col4 = ((n * 4 + 255) & ~size_t(255)), col8 = ((n * 8 + 255) & ~size_t(255)),
                col1 = ((n + 255) & ~size_t(255)), seqt = (((size_t)rec->n_seq * 4 + 255) & ~size_t(255));
   SWG_TRY(io_block_reserve(ctx, io_block_bytes(n, rec->n_seq)));
@@ -458,10 +471,12 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   d.q_end = (const uint32_t*)up(rec->q_end, n * 4, col4, true);
   d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4, true);
   d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4, true);
-  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, scaffold);  // read by the scaffold stage only
-  // block_len: the retain test (vacuous for min_block_length 0; prepare_kernel then never reads it) and the scaffold stage
-  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, scaffold || cfg->min_block_length != 0);
-  d.identity = (const double*)up(rec->identity, n * 8, col8, true);
+  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, scaffold || derived_identity);  // the scaffold stage; a derived identity
+  // block_len: the retain test (vacuous for min_block_length 0; prepare_kernel then never reads it), the scaffold stage, a
+  // derived identity
+  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, scaffold || cfg->min_block_length != 0 || derived_identity);
+  d.identity = (const double*)up(rec->identity, n * 8, col8, !derived_identity);
+  if (derived_identity) d.identity = nullptr;
   d.strand = (const uint8_t*)up(rec->strand, n, col1, scaffold);         // read by the scaffold stage only
   d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt, true);
   d.seq_genome_two = (const uint32_t*)up(rec->seq_genome_two, (size_t)rec->n_seq * 4, seqt, true);

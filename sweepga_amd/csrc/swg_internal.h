@@ -12,6 +12,7 @@
 struct swg_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D copies of the streamed host path (created on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // bump arena for per-call scratch; grown (never shrunk) between calls
   char* arena = nullptr;

@@ -10,6 +10,15 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
                       const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order = nullptr,
                       int* q_order_valid = nullptr);
 
+// Streamed host path (csrc/swg_stream.hip): ranges of whole query genomes, uploads overlapped with the filter.  *taken = 0:
+// not applicable (input not grouped by query genome, too small, SWG_STREAM=0), nothing was done; the caller runs its own path.
+int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const swg_config* cfg, uint8_t* status_out,
+                   uint32_t* chain_out, swg_stats* stats, int* taken);
+// Device memory a host-path call needs, reserved ahead (csrc/swg_filter.hip): the staging block for n records, the scratch
+// arena for a filter call over n records.
+int swg_io_block_reserve(swg_ctx* ctx, uint64_t n, uint32_t n_seq);
+int swg_filter_reserve_arena(swg_ctx* ctx, uint64_t n, const swg_records* rec, const swg_config* cfg, bool wide);
+
 // Scaffold stage (src/paf_filter.rs:436-747): chaining, span/identity filter, scaffold sweep,
 // anchors, inversion capture, rescue.  alive = step-1 survivors, keep1 = mapping-sweep survivors.
 // q_order (optional): the alive records already ordered by q_start inside every (query, target, strand) group (the query

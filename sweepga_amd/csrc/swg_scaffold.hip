@@ -32,7 +32,7 @@ __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint
   if (!ok_head[h]) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
   const uint32_t i = s_idx[p];
   anchor_num[i] = head_num[h];
-  in_filtered[i] = 1;
+  if (in_filtered) in_filtered[i] = 1;  // (nullptr: no rescue will run, nobody reads it)
 }
 
 // Kept '+' chains compacted in all_chains order.  A chromosome pair's '+' group is contiguous in that order and
@@ -282,13 +282,25 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
   }
 }
 
-__global__ __launch_bounds__(EW) void scaffolds_only_kernel(uint64_t n, const uint32_t* __restrict__ anchor_num,
-                                                            uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
-  uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t an = anchor_num[i];
-  status[i] = an ? SWG_ST_SCAFFOLD : SWG_ST_DROPPED;
-  chain[i] = an;
+// The anchors' chain numbers are collected in the caller's chain column itself (pre-zeroed; member_marks and the inversion
+// capture write it); this pass derives the status column from it, 16 records per thread: anchors are SCAFFOLD, the rest
+// DROPPED until the rescue says otherwise.
+__global__ __launch_bounds__(EW) void anchor_status_kernel(uint64_t n, const uint32_t* __restrict__ chain,
+                                                           uint8_t* __restrict__ status, int aligned) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * EW + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  if (aligned && i0 + 16 <= n) {
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 c = *reinterpret_cast<const uint4*>(chain + i0 + 4 * j);
+      w[j] = (c.x ? (uint32_t)SWG_ST_SCAFFOLD : 0u) | (c.y ? (uint32_t)SWG_ST_SCAFFOLD << 8 : 0u) |
+             (c.z ? (uint32_t)SWG_ST_SCAFFOLD << 16 : 0u) | (c.w ? (uint32_t)SWG_ST_SCAFFOLD << 24 : 0u);
+    }
+    *reinterpret_cast<uint4*>(status + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    return;
+  }
+  for (uint64_t i = i0; i < i0 + 16 && i < n; ++i) status[i] = chain[i] ? SWG_ST_SCAFFOLD : SWG_ST_DROPPED;
 }
 
 __global__ __launch_bounds__(EW) void count_status_kernel(uint64_t n, const uint8_t* __restrict__ status,
@@ -307,7 +319,8 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
                        uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
-  SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+  // chain_out doubles as the anchors' chain-number column (zero = not an anchor); status_out is written in full by
+  // anchor_status below and only needs clearing on the early exits
   SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, n * sizeof(uint32_t), st));
   ChainBuild B;
   B.want_s_chain = false;  // member_marks derives a member's chain from the labelling arrays
@@ -317,12 +330,16 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     stats->n_swept = B.m;
     stats->n_chains = B.n_chains_all;
   }
-  if (B.M == 0 || B.m == 0 || B.T.nc == 0) return SWG_OK;  // nothing can be an anchor: everything is dropped
+  if (B.M == 0 || B.m == 0 || B.T.nc == 0) {  // nothing can be an anchor: everything is dropped
+    SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+    return SWG_OK;
+  }
   const uint64_t nc = B.T.nc, M = B.M, m = B.m;
+  const bool rescue_on = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
   uint8_t* C_kept = swg_alloc<uint8_t>(ctx, nc);
   uint32_t* C_num = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* anchor_num = swg_alloc<uint32_t>(ctx, n);
-  uint8_t* in_filtered = swg_alloc<uint8_t>(ctx, n);
+  uint32_t* anchor_num = chain_out;
+  uint8_t* in_filtered = rescue_on ? swg_alloc<uint8_t>(ctx, n) : nullptr;  // read by the rescue only
   unsigned long long* d_cnt = swg_alloc<unsigned long long>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   uint64_t n_kept = 0;
@@ -331,8 +348,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
                                     cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, C_kept, C_num,
                                     &n_kept));
   if (stats) stats->n_chains_kept = n_kept;
-  SWG_HIP(ctx, hipMemsetAsync(anchor_num, 0, n * sizeof(uint32_t), st));
-  SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
+  if (in_filtered) SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
   uint32_t* head_num = swg_alloc<uint32_t>(ctx, m);  // valid at the heads of passing chains
   SWG_CHECK_ARENA(ctx);
   SWG_LAUNCH(ctx, "head_numbers", head_numbers_kernel<<<nblk(nc), EW, 0, st>>>(nc, B.m_head_of_chain, C_num, head_num));
@@ -351,12 +367,20 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     return SWG_OK;
   };
 
-  if (cfg->scaffolds_only) {  // paf_filter.rs:486-513
-    SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
+  const int out_aligned = ((reinterpret_cast<uintptr_t>(status_out) | reinterpret_cast<uintptr_t>(chain_out)) & 15) == 0;
+  auto anchor_status = [&]() -> int {
+    SWG_LAUNCH(ctx, "anchor_status", anchor_status_kernel<<<nblk((n + 15) / 16), EW, 0, st>>>(n, chain_out, status_out, out_aligned));
     SWG_KERNEL_CHECK(ctx);
+    return SWG_OK;
+  };
+  if (cfg->scaffolds_only) {  // paf_filter.rs:486-513
+    SWG_TRY(anchor_status());
     return finish_counts();
   }
-  if (n_kept == 0) return finish_counts();  // no anchors anywhere: every pair is skipped (paf_filter.rs:658-660)
+  if (n_kept == 0) {  // no anchors anywhere: every pair is skipped (paf_filter.rs:658-660)
+    SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+    return finish_counts();
+  }
 
   // ---- inversion capture
   {
@@ -418,8 +442,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   }
   // ---- rescue
   // anchors: status + chain in input order (coalesced); everything else starts as dropped
-  SWG_LAUNCH(ctx, "scaffolds_only", scaffolds_only_kernel<<<nblk(n), EW, 0, st>>>(n, anchor_num, status_out, chain_out));
-  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(anchor_status());
   if (cfg->scaffold_max_deviation != 0) {  // with a rescue distance of 0 only anchors are kept (paf_filter.rs:680, 740): no anchor sort
     uint8_t* aflag = swg_alloc<uint8_t>(ctx, M);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);

@@ -14,23 +14,11 @@
 #include <vector>
 
 #include "host/shard_host.h"
+#include "host/stream_plan.h"
 #include "swg_internal.h"
+#include "swg_pipeline.h"
 
-namespace {
-
-bool same_partition(const swg_records* r) {
-  std::vector<int64_t> l2t(r->n_genome_last, -1), t2l(r->n_genome_two, -1);
-  for (uint32_t s = 0; s < r->n_seq; ++s) {
-    const uint32_t a = r->seq_genome_last[s], b = r->seq_genome_two[s];
-    if (a >= r->n_genome_last || b >= r->n_genome_two) return false;
-    if (l2t[a] < 0) l2t[a] = b;
-    if (t2l[b] < 0) t2l[b] = a;
-    if (l2t[a] != (int64_t)b || t2l[b] != (int64_t)a) return false;
-  }
-  return true;
-}
-
-}  // namespace
+using swg_streamed::same_partition;
 
 extern "C" int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const swg_config* cfg, uint8_t* status_out,
                                 uint32_t* chain_out, swg_stats* stats) {
@@ -43,9 +31,20 @@ extern "C" int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_recor
   if (n_ctx == 1 || n == 0 || !r->seq_genome_last || !r->seq_genome_two || !same_partition(r))
     return swg_filter(ctx0, r, cfg, status_out, chain_out, stats);
   if (n >= (uint64_t(1) << 31)) return swg_set_error(ctx0, SWG_ERR_RANGE, "more than 2^31-1 records");
-  if (!r->q_id || !r->t_id || !r->q_start || !r->q_end || !r->t_start || !r->t_end || !r->identity || !r->matches || !r->block_len ||
-      !r->strand || !status_out || !chain_out)
+  if (!r->q_id || !r->t_id || !r->q_start || !r->q_end || !r->t_start || !r->t_end || !r->matches || !r->block_len ||
+      !r->strand || !status_out || !chain_out)   // (identity may be NULL: derived on the device, see swg_records)
     return swg_set_error(ctx0, SWG_ERR_INVALID, "a record column or an output buffer is NULL");
+  // Records grouped by query genome (what an aligner writes): ranges of whole query genomes go to the devices as slices of
+  // the caller's own columns, uploads overlapped with the filter, results straight into the caller's arrays -- no host-side
+  // scatter or merge (csrc/swg_stream.hip).  Otherwise: the scatter path below.
+  {
+    if (cfg->scoring_function < 0 || cfg->scoring_function > 4 || cfg->mapping_filter_mode < 0 || cfg->mapping_filter_mode > 2 ||
+        cfg->scaffold_filter_mode < 0 || cfg->scaffold_filter_mode > 2)
+      return swg_set_error(ctx0, SWG_ERR_INVALID, "bad scoring_function / filter mode");
+    int taken = 0;
+    const int rc = swg_stream_try(ctxs, n_ctx, r, cfg, status_out, chain_out, stats, &taken);
+    if (rc != SWG_OK || taken) return rc;
+  }
   // ---- plan + scatter on host threads (csrc/host/shard_host.h)
   swg_shard::Plan P;
   std::vector<swg_shard::Shard> sh;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(EW_THREADS) void score_key_kernel(uint64_t n, const
 __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
                                                              const uint32_t* __restrict__ t_id,
                                                              const uint32_t* __restrict__ block_len,
+                                                             const uint32_t* __restrict__ matches,
                                                              const double* __restrict__ identity,
                                                              const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
                                                              const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
@@ -101,7 +102,15 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              unsigned long long* __restrict__ scalars) {
   uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
-    const double id = identity[i];
+    // identity == nullptr: RecordMeta.identity as extract_metadata derives it without a dv:f: override -- matches over
+    // max(block length, 1), one IEEE division (src/paf_filter.rs:322; the host then sends 8 bytes less per record)
+    double id;
+    if (identity) {
+      id = identity[i];
+    } else {
+      const uint32_t bl = block_len[i];
+      id = __ddiv_rn((double)matches[i], (double)(bl > 1u ? bl : 1u));
+    }
     const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
     const bool ok = (min_block == 0 || (uint64_t)block_len[i] >= min_block) && (keep_self || q_id[i] != t_id[i]) && id >= min_identity;
     alive[i] = ok ? 1 : 0;
@@ -1323,7 +1332,7 @@ int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8
                 unsigned long long* scalars) {
   if (r->n == 0) return SWG_OK;
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
-                                 r->n, r->q_id, r->t_id, r->block_len, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
+                                 r->n, r->q_id, r->t_id, r->block_len, r->matches, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
                                  cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
                                  scalars));
   SWG_KERNEL_CHECK(ctx);

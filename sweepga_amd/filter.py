@@ -298,13 +298,30 @@ class PackedRecords:
         r = SwgRecords()
         r.n = self.n
         for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
-            setattr(r, k, self.cols[k].ctypes.data)
+            v = self.cols[k]   # identity may be None: matches / max(block_len, 1), evaluated on the device (swg_records)
+            setattr(r, k, v.ctypes.data if v is not None else None)
         r.n_seq = self.n_seq
         r.seq_genome_last = self.seq_genome_last.ctypes.data
         r.n_genome_last = self.n_genome_last
         r.seq_genome_two = self.seq_genome_two.ctypes.data
         r.n_genome_two = self.n_genome_two
         return r
+
+
+def stream_plan(packed: PackedRecords, target_records: int):
+    """The record ranges a streamed swg_filter call would use (swg_stream_plan; host code, no GPU): a list of bounds, or []
+    when the records are not grouped by query genome."""
+    from . import _lib
+    lib = _lib.load()
+    cap = packed.n + 2
+    bounds = np.zeros(cap, dtype=np.uint64)
+    k = C.c_uint64(0)
+    rec = packed.to_c()
+    lib.swg_stream_plan.restype = C.c_int
+    rc = lib.swg_stream_plan(C.byref(rec), C.c_uint64(target_records), bounds.ctypes.data_as(C.c_void_p), C.c_uint64(cap), C.byref(k))
+    if rc != 0:
+        raise RuntimeError(f"swg_stream_plan failed: {rc}")
+    return [int(x) for x in bounds[:k.value + 1]] if k.value else []
 
 
 def pack_records(metadata: List[RecordMeta]) -> PackedRecords:

@@ -51,6 +51,14 @@ class PafFile:
         return self._view(getattr(self.records, name), dtype, self.n)
 
     @property
+    def identity_is_derived(self):
+        """True when every record's identity is matches / max(block_len, 1) (no dv:f: tag had the last word): a caller may
+        pass identity = NULL to swg_filter and the device evaluates it (swg_paf_identity_is_derived)."""
+        self.lib.swg_paf_identity_is_derived.restype = C.c_int
+        self.lib.swg_paf_identity_is_derived.argtypes = [C.c_void_p]
+        return bool(self.lib.swg_paf_identity_is_derived(self.handle))
+
+    @property
     def is_rebased(self):
         """True when the coordinate columns are relative to `seq_offsets` (results of the filter are unaffected)."""
         return self.seq_offsets is not None

@@ -75,7 +75,7 @@ def records_to_meta(rec):
     return out
 
 
-def records_to_paf(rng, rec, junk_lines=True):
+def records_to_paf(rng, rec, junk_lines=True, dv_tags=True):
     """orc.Records -> PAF text.  Identity is carried the way real PAFs do it: a third of the lines by the
     matches/block columns only, a third with an extended CIGAR (cg:Z:<m>=<x>X, which overrides column 10),
     a third with a dv:f: tag; plus a few malformed / short lines that must be skipped but still counted."""
@@ -87,7 +87,7 @@ def records_to_paf(rng, rec, junk_lines=True):
         k = int(rng.integers(0, 3))
         if k == 1 and m > 0:
             line += ["NM:i:%d" % (b - m), "cg:Z:%d=%dX" % (m, b - m)]
-        elif k == 2:
+        elif k == 2 and dv_tags:   # (dv_tags=False: no line's identity is overridden -> the ingest reports it as derived)
             line += ["dv:f:%.4f" % (1.0 - m / max(b, 1)), "tp:A:P"]
         out.append("\t".join(line))
         if junk_lines and rng.random() < 0.01:
