@@ -1,7 +1,9 @@
 // paf-synth: deterministic S-pan-shaped PAF text for end-to-end timing (100 single-chromosome
 // genomes g000#1#chr1 ... , ordered non-self pairs, 70 % syntenic / 30 % repeat mappings, lognormal lengths,
 // 10 % '-' strand).  Generator only; it has no reference counterpart.
-//   paf-synth <n_lines> [n_genomes=100] [seed=2025] [chr_len=150000000] > out.paf
+//   paf-synth <n_lines> [n_genomes=100] [seed=2025] [chr_len=150000000] [order=random|query] > out.paf
+// order=query: the lines of a query genome form one run (query genomes ascending), the way an aligner writes its output
+// query by query; order=random (default): every line draws its query genome at random.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -38,6 +40,7 @@ int main(int argc, char** argv) {
   const uint64_t g = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 100;
   s_state = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 2025;
   const uint64_t L = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 150000000ull;
+  const bool by_query = argc > 5 && std::string(argv[5]) == "query";
   if (g < 2) return 2;
   std::vector<std::string> names(g);
   for (uint64_t i = 0; i < g; ++i) {
@@ -49,7 +52,8 @@ int main(int argc, char** argv) {
   char* o = buf.data();
   const std::string len_s = std::to_string(L);
   for (uint64_t i = 0; i < n; ++i) {
-    const uint64_t a = splitmix() % g;
+    uint64_t a = splitmix() % g;
+    if (by_query) a = (uint64_t)((__uint128_t)i * g / n);  // (the draw above is kept: the other columns do not depend on the order)
     uint64_t b = splitmix() % (g - 1);
     if (b >= a) ++b;
     double len = std::exp(std::log(2000.0) + 1.2 * gauss());

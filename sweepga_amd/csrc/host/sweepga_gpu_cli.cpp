@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -357,10 +358,12 @@ int main(int argc, char** argv) {
   swg_paf* paf = nullptr;
   // the parse leaves a few hardware threads to the device start-up that runs beside it (the HIP runtime's own threads and
   // the warm-up: with every hardware thread parsing, context creation took 0.4-1.0 s instead of 0.1 s at 10^8 lines)
+  // and no more than 64: the parse of 10^8 lines takes 0.62 s on 64 threads of the GPU box's 256-thread host, 0.91 s on 128
+  // and 1.29 s on 248 (first-touch page faults of ~7 GB of columns in one address space: more threads get in each other's way)
   int parse_threads = threads;
   if (parse_threads <= 0 && !no_filter) {
     const unsigned hc = std::thread::hardware_concurrency();
-    if (hc > 16) parse_threads = (int)hc - 8;
+    if (hc > 16) parse_threads = (int)std::min(hc - 8, 64u);
   }
   if (swg_paf_open(input.c_str(), parse_threads, &paf) != SWG_OK) {
     const std::string msg = swg_paf_last_error();
@@ -429,8 +432,20 @@ int main(int argc, char** argv) {
   }
 
   // ---- apply_filters on the GPU
-  std::vector<uint8_t> status(n ? n : 1, 0);
-  std::vector<uint32_t> chain(n ? n : 1, 0);
+  // result columns: uninitialised storage (the filter writes every entry; zero-filling 0.5 GB on this thread first cost
+  // ~85 ms per 10^8 records), 2 MB-aligned and marked for huge pages like the ingest's columns
+  auto alloc_col = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    const size_t two_mb = size_t(2) << 20;
+    if (bytes >= (size_t(8) << 20) && posix_memalign(&p, two_mb, (bytes + two_mb - 1) & ~(two_mb - 1)) == 0)
+      madvise(p, bytes, MADV_HUGEPAGE);
+    else
+      p = std::calloc(bytes ? bytes : 1, 1);
+    if (!p) die(3, "out of host memory for the result columns");
+    return p;
+  };
+  struct View8 { uint8_t* p; uint8_t* data() const { return p; } } status{static_cast<uint8_t*>(alloc_col(n ? n : 1))};
+  struct View32 { uint32_t* p; uint32_t* data() const { return p; } } chain{static_cast<uint32_t*>(alloc_col((n ? n : 1) * sizeof(uint32_t)))};
   swg_stats st{};
   if (n) {
     // no dv:f: override anywhere: identity = matches / max(block length, 1) for every record, which the device evaluates

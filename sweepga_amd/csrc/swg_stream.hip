@@ -72,8 +72,13 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
   }
   D.local_off[nc] = m;
   // device memory: the columns of all of this device's ranges (staging block of the context) + scratch for the longest one
+  const bool dbg = getenv("SWG_DEBUG") != nullptr;
+  const auto r0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count(); };
   if (int rc = swg_io_block_reserve(ctx, m, r->n_seq); rc != SWG_OK) return fail(rc);
   if (int rc = swg_filter_reserve_arena(ctx, longest, r, cfg, false); rc != SWG_OK) return fail(rc);
+  if (dbg) fprintf(stderr, "[swg] device %d: memory for %llu records in %zu ranges (longest %llu) reserved at %.1f ms\n", ctx->device,
+                   (unsigned long long)m, nc, (unsigned long long)longest, since());
   if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
     return fail(swg_set_error(ctx, SWG_ERR_HIP, "hipStreamCreate (copy stream) failed"));
   const size_t col4 = ((m * 4 + 255) & ~size_t(255)), col8 = ((m * 8 + 255) & ~size_t(255)), col1 = ((m + 255) & ~size_t(255)),
@@ -190,8 +195,11 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
     d.identity = r->identity ? d_identity + lo_d : nullptr;
     d.strand = d_strand + lo_d;
     swg_stats& st = D.cstats[j];
+    const double waited = since();
     rc = swg_filter_device(ctx, &d, cfg, d_status + lo_d, d_chain + lo_d, &st);  // (with stats: returns when the range is done)
     if (rc != SWG_OK) break;
+    if (dbg) fprintf(stderr, "[swg] device %d range %zu (%llu records): uploaded by %.1f ms, filtered by %.1f ms (device %.2f ms)\n", ctx->device, j,
+                     (unsigned long long)len, waited, since(), st.device_ms);
     D.device_ms += st.device_ms;
     if (scaffold && renumber_here && base)
       SWG_LAUNCH(ctx, "chain_shift", chain_shift_kernel<<<(unsigned)((len + EW - 1) / EW), EW, 0, ctx->stream>>>(len, d_chain + lo_d, base));
@@ -248,6 +256,12 @@ int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const 
     return swg_set_error(ctxs[0], SWG_ERR_OOM, "out of host memory while planning the streamed upload");
   }
   *taken = 1;
+  const bool dbg = getenv("SWG_DEBUG") != nullptr;
+  const auto w0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (dbg) fprintf(stderr, "[swg] streamed call: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count());
+  };
+  if (dbg) fprintf(stderr, "[swg] streamed call: %zu ranges over %d device(s), target %llu records\n", chunks.size(), n_ctx, (unsigned long long)target);
   std::vector<DeviceRun> runs((size_t)n_ctx);
   for (int d = 0; d < n_ctx; ++d) {
     runs[(size_t)d].ctx = ctxs[d];
@@ -259,6 +273,7 @@ int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const 
   } catch (const std::bad_alloc&) {
     return swg_set_error(ctxs[0], SWG_ERR_OOM, "out of host memory in the streamed filter");
   }
+  lap("devices done");
   for (int d = 0; d < n_ctx; ++d)
     if (runs[(size_t)d].rc != SWG_OK) {
       if (d == 0) return runs[0].rc;
