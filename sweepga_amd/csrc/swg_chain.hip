@@ -1267,6 +1267,19 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
 // from the candidate kernels.
 constexpr int WALK_HASH = 256;
 
+// The walk's work-group IS one wavefront (64 threads): what its barriers have to order are LDS accesses of different lanes,
+// and the LDS executes one wavefront's instructions in issue order.  __syncthreads() would do, but it lowers to a
+// workgroup-scope fence -- s_waitcnt vmcnt(0) lgkmcnt(0) -- in front of the (elided) s_barrier, i.e. every one of the six
+// barriers of a batch also waited for ALL outstanding vector-memory operations: the loads prefetched for the next batch and
+// the predecessor stores of this one.  This waits for the LDS queue only and keeps the compiler from moving memory
+// operations across it.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt and expcnt not waited for (gfx9 encoding)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // SPEC: a block of a long unit, run speculatively (own / prev views); a template parameter so that the main walk and the
 // speculative rounds are different kernels to a profiler (rocprofv3 and the library's own table then name the same launches).
 template <int BIGW, bool FUSED, bool SPEC>
@@ -1295,7 +1308,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
   for (int k = lane; k < WALK_HASH; k += 64) hcnt[k] = 0;
-  __syncthreads();
+  wave_lds_sync();
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
     const uint32_t b = D.bb, be = D.be, ue = D.ue;  // i runs over [b, be), j may reach into the next block (< ue)
@@ -1310,7 +1323,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
     // the first commit beyond the ring (rare), which first writes "no score" to the part of the chunk that has not entered
     // the ring yet and from then on (far_any) the chunk reads that array like a speculative block does.
     bool far_any = SPEC;
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t p = b + lane; p < b + BIGW; p += 64) {
       const bool ok = p < ue;
       ring[p % BIGW] = (ok && SPEC) ? view_load(p) : INF;
@@ -1318,7 +1331,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       rt[p % BIGW] = ok ? s_ts[p] : 0u;
       re[p % BIGW] = ok ? s_te[p] : 0u;
     }
-    __syncthreads();
+    wave_lds_sync();
     auto current = [&](uint32_t j) -> uint64_t {  // the committed score of j
       if (j - base < (uint32_t)BIGW) return ring[j % BIGW];
       return far_any ? view_load(j) : INF;
@@ -1387,13 +1400,13 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         const uint32_t pn = base + BIGW + lane;
         if (far_dirty && pn < ue) cur.view = view_load(pn);
         far_dirty = false;
-        __syncthreads();
+        wave_lds_sync();
         ring[pn % BIGW] = cur.view;
         rq[pn % BIGW] = cur.q;
         rt[pn % BIGW] = cur.t;
         re[pn % BIGW] = cur.e;
         base += 64;
-        __syncthreads();
+        wave_lds_sync();
       }
       const bool more = i0 + 64 < be && i0 + 65 < ue;
       Pre nxt = cur;
@@ -1468,9 +1481,9 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       // ---- lanes that share their j with another lane (hash filter; superset), and lanes that need their whole window
       uint32_t* slot = &hcnt[fj & (WALK_HASH - 1)];
       if (fj != NONE) atomicAdd(slot, 1u);
-      __syncthreads();
+      wave_lds_sync();
       const bool shared_j = fj != NONE && *slot > 1u;
-      __syncthreads();
+      wave_lds_sync();
       if (fj != NONE) *slot = 0;
       uint64_t work = __ballot(shared_j || (fj == NONE && nv > (uint32_t)KC));
       if (wstats && lane == 0) {  // SWG_WALK_STATS: batches, lanes on the work list
@@ -1483,7 +1496,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         const bool inr = me && (fj - base < (uint32_t)BIGW);
         // in the ring: LDS minimum, then the lane that finds its own distance there is the last acceptance
         if (inr) atomicMin(&ring[fj % BIGW], (unsigned long long)fd);
-        __syncthreads();
+        wave_lds_sync();
         if (inr && (uint64_t)ring[fj % BIGW] == fd) {
           ((spec && fj >= be) ? pred_prev : pred_own)[fj] = i;
           if (spec && fj >= be)  // the next block's input: must be in memory at the end of the round

@@ -12,7 +12,8 @@ namespace {
 
 // ---- anchors, inversions, rescue -------------------------------------------------------------------------------------
 // anchor_num[i] = chain number of the kept chain record i belongs to (0 = not an anchor);
-// in_filtered[i] = 1 iff i is a member of a span/identity-filtered chain (pre_sweep_scaffold_members)
+// a_state[a] (by A position, only with a rescue): 1 = anchor, 2 = member of a chain that passed the span / identity filter
+// but not the scaffold sweep (pre_sweep_scaffold_members minus anchors: never rescued, paf_filter.rs:601-604, 675-678)
 // First the chain numbers go to the heads (one entry per kept chain), then every member reads its head's: one dependent
 // look-up per member instead of three (head -> position ordinal -> all_chains index -> number).
 __global__ __launch_bounds__(EW) void head_numbers_kernel(uint64_t nc, const uint32_t* __restrict__ head_of_chain,
@@ -25,14 +26,15 @@ __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint
                                                           const uint32_t* __restrict__ ok_head,
                                                           const uint32_t* __restrict__ head_num,
                                                           uint32_t* __restrict__ anchor_num,
-                                                          uint8_t* __restrict__ in_filtered) {
+                                                          const uint32_t* __restrict__ s_a, uint8_t* __restrict__ a_state) {
   uint64_t p = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   if (p >= m) return;
   const uint32_t h = hd[p];
   if (!ok_head[h]) return;  // its chain failed the span / identity filter: neither anchor nor pre-sweep member (arrays pre-zeroed)
   const uint32_t i = s_idx[p];
-  anchor_num[i] = head_num[h];
-  if (in_filtered) in_filtered[i] = 1;  // (nullptr: no rescue will run, nobody reads it)
+  const uint32_t num = head_num[h];
+  anchor_num[i] = num;
+  if (a_state) a_state[s_a ? s_a[p] : p] = num ? 1 : 2;  // (nullptr: no rescue will run; pre-zeroed otherwise)
 }
 
 // Kept '+' chains compacted in all_chains order.  A chromosome pair's '+' group is contiguous in that order and
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
                                                        const uint32_t* __restrict__ f_pm,
                                                        const uint32_t* __restrict__ f_ts,
                                                        const uint32_t* __restrict__ f_num, uint64_t gap,
-                                                       uint32_t* anchor_num) {
+                                                       uint32_t* anchor_num, uint8_t* __restrict__ a_state) {
   uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (a >= M) return;
   const uint64_t k = keyA[a];
@@ -173,15 +175,23 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
       break;
     }
   }
-  if (best) anchor_num[i] = best;
+  if (best) {
+    anchor_num[i] = best;
+    if (a_state) a_state[a] = 1;  // an anchor from here on, whatever it was (a member of a swept-away chain included)
+  }
 }
 
-// anchors in A order -> keys (dense pair, query centre) for sort B
-__global__ __launch_bounds__(EW) void anchor_flag_kernel(uint64_t M, const uint32_t* __restrict__ idxA,
-                                                         const uint32_t* __restrict__ anchor_num,
-                                                         uint8_t* __restrict__ flag) {
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a < M) flag[a] = anchor_num[idxA[a]] ? 1 : 0;
+// anchors in A order -> keys (dense pair, query centre) for sort B.  (The states by A position are written where the anchors
+// are made, member_marks and the inversion capture -- round 3 derived the anchor flags with one more gather pass over all
+// records and kept the never-rescued members in a second, record-indexed array that the rescue had to gather from.)
+__global__ __launch_bounds__(EW) void anchor_flag_kernel(uint64_t M, const uint8_t* __restrict__ a_state, uint8_t* __restrict__ flag) {
+  const uint64_t a0 = ((uint64_t)blockIdx.x * EW + threadIdx.x) * 4;
+  if (a0 + 4 <= M) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(a_state + a0);
+    *reinterpret_cast<uint32_t*>(flag + a0) = w & 0x01010101u;  // state 1 = anchor, 2 = never-rescued member
+  } else {
+    for (uint64_t a = a0; a < M; ++a) flag[a] = a_state[a] & 1u;
+  }
 }
 __global__ __launch_bounds__(EW) void anchor_keys_kernel(uint64_t na, const uint32_t* __restrict__ anchor_a,
                                                          const uint64_t* __restrict__ keyA,
@@ -211,6 +221,30 @@ __global__ __launch_bounds__(EW) void anchor_cols_kernel(uint64_t na, const uint
   b_num[j] = anchor_num[i];
 }
 
+// The same after the packed sort (swg_radix_sort_packed): P[j] = ((key >> 8) << val_bits) | A position.  The key's low 8
+// bits -- the low 8 bits of the query centre, which the packed word drops -- come back from the record (pos_bits >= 8 here).
+__global__ __launch_bounds__(EW) void anchor_cols_packed_kernel(uint64_t na, const uint64_t* __restrict__ P, int val_bits,
+                                                                const uint64_t* __restrict__ keyA,
+                                                                const uint32_t* __restrict__ idxA,
+                                                                const uint32_t* __restrict__ a_qe,
+                                                                const uint32_t* __restrict__ a_ts,
+                                                                const uint32_t* __restrict__ a_te,
+                                                                const uint32_t* __restrict__ anchor_num, int pos_bits,
+                                                                uint64_t* __restrict__ b_key, uint32_t* __restrict__ b_tc,
+                                                                uint32_t* __restrict__ b_idx, uint32_t* __restrict__ b_num) {
+  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (j >= na) return;
+  const uint64_t w = P[j];
+  const uint32_t a = (uint32_t)(w & ((uint64_t(1) << val_bits) - 1));
+  const uint64_t qs = keyA[a] & ((uint64_t(1) << pos_bits) - 1);
+  const uint64_t qc = (qs + (uint64_t)a_qe[a]) / 2;
+  const uint32_t i = idxA[a];
+  b_key[j] = ((w >> val_bits) << 8) | (qc & 0xffu);
+  b_tc[j] = (uint32_t)(((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2);
+  b_idx[j] = i;
+  b_num[j] = anchor_num[i];
+}
+
 // [lo, hi) of every dense pair in the sorted anchor table (pairs without anchors keep the zero-initialised empty range)
 __global__ __launch_bounds__(EW) void anchor_ranges_kernel(uint64_t na, const uint64_t* __restrict__ b_key, int pos_bits,
                                                            uint32_t* __restrict__ pair_lo, uint32_t* __restrict__ pair_hi) {
@@ -221,16 +255,45 @@ __global__ __launch_bounds__(EW) void anchor_ranges_kernel(uint64_t na, const ui
   if (j + 1 == na || (b_key[j + 1] >> pos_bits) != dp) pair_hi[dp] = (uint32_t)(j + 1);
 }
 
+// lower_bound of `key` in b_key[lo, hi), found by the whole wavefront: 64 probes per round trip instead of one (a thread's own
+// binary search over a pair's ~3,000 anchors is 12 dependent loads).  All arguments and the result are wave-uniform.
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict__ b_key, uint32_t lo, uint32_t hi, uint64_t key) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (;;) {
+    const uint32_t n = hi - lo;
+    if (n == 0) return lo;
+    if (n <= 64) {
+      const bool ge = lane < n && b_key[lo + lane] >= key;
+      const uint64_t m = __ballot(ge);
+      return m ? lo + (uint32_t)__builtin_ctzll(m) : hi;
+    }
+    const uint32_t step = (n + 63) / 64;  // probe i looks at the LAST element of the i-th stretch of `step` elements
+    uint32_t pos = lo + (lane + 1) * step;
+    if (pos > hi) pos = hi;
+    const bool ge = b_key[pos - 1] >= key;
+    const uint64_t m = __ballot(ge);
+    if (!m) return hi;  // (the last probe is element hi - 1)
+    const uint32_t f = (uint32_t)__builtin_ctzll(m);
+    uint32_t nlo = lo + f * step, nhi = lo + (f + 1) * step;
+    if (nhi > hi) nhi = hi;
+    lo = nlo;       // stretch f: its last element is >= key, every earlier stretch's last element is < key
+    hi = nhi - 1;   // so the bound lies in [nlo, nhi - 1]; nhi - 1 itself qualifies (returned when nothing before it does)
+    // (n shrinks by a factor of 64 per round)
+  }
+}
+
 // paf_filter.rs:656-732 per record.  Rescued records take the chain of the lowest-index anchor in range
 // (the reference iterates a HashSet here; ascending input order is the instance the oracle fixes).
+// The records of a wavefront are consecutive in A order -- (pair, strand, q_start) -- so nearly always one pair's, with window
+// starts close together: the wavefront finds the bounds of its smallest and largest window start together
+// (wave_lower_bound), and each lane then searches only between them.
 __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
                                                     const uint32_t* __restrict__ idxA,
                                                     const uint32_t* __restrict__ a_qe,
                                                     const uint32_t* __restrict__ a_ts,
                                                     const uint32_t* __restrict__ a_te,
                                                     const uint32_t* __restrict__ a_dpair, int pos_bits,
-                                                    const uint8_t* __restrict__ a_is_anchor,
-                                                    const uint8_t* __restrict__ in_filtered,
+                                                    const uint8_t* __restrict__ a_state,
                                                     const uint32_t* __restrict__ pair_lo,
                                                     const uint32_t* __restrict__ pair_hi,
                                                     const uint64_t* __restrict__ b_key,
@@ -238,22 +301,48 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     const uint32_t* __restrict__ b_idx,
                                                     const uint32_t* __restrict__ b_num, uint64_t D,
                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
-  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
-  if (a >= M) return;
-  if (a_is_anchor[a]) return;  // anchors got their status from the coalesced pass in input order
-  const uint32_t i = idxA[a];
-  if (in_filtered[i]) return;  // status stays DROPPED
+  const uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  // anchors got their status from the coalesced pass in input order; members of span-filtered chains stay DROPPED
+  const bool act = a < M && a_state[a] == 0;
+  if (__ballot(act) == 0) return;  // (wave-uniform)
   const uint64_t posmask = (uint64_t(1) << pos_bits) - 1;
-  const uint64_t qs = keyA[a] & posmask;
-  const uint64_t qc = (qs + (uint64_t)a_qe[a]) / 2, tc = ((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2;
-  const uint64_t hi_part = (uint64_t)a_dpair[a] << pos_bits;
-  const uint64_t lo = hi_part | (qc > D ? qc - D : 0);
-  const uint64_t hi_q = qc + D < qc ? ~0ull : qc + D;
-  const uint64_t hi = hi_part | (hi_q > posmask ? posmask : hi_q);
-  // lower_bound(b_key, lo) inside the pair's own slice of the anchor table
-  const uint64_t slice_end = pair_hi[a_dpair[a]];
-  uint64_t l = pair_lo[a_dpair[a]], r = slice_end;
-  while (l < r) {
+  uint64_t qc = 0, tc = 0, lo = 0, hi = 0;
+  uint32_t dp = NONE;
+  if (act) {
+    const uint64_t qs = keyA[a] & posmask;
+    qc = (qs + (uint64_t)a_qe[a]) / 2;
+    tc = ((uint64_t)a_ts[a] + (uint64_t)a_te[a]) / 2;
+    dp = a_dpair[a];
+    const uint64_t hi_part = (uint64_t)dp << pos_bits;
+    lo = hi_part | (qc > D ? qc - D : 0);
+    const uint64_t hi_q = qc + D < qc ? ~0ull : qc + D;
+    hi = hi_part | (hi_q > posmask ? posmask : hi_q);
+  }
+  // the pair most of the wavefront works on: that of its first active lane
+  const uint32_t dp0 = (uint32_t)__shfl((int)dp, (int)__builtin_ctzll(__ballot(act)), 64);
+  const bool same = act && dp == dp0;
+  uint64_t kmin = same ? lo : ~0ull, kmax = same ? lo : 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t x = __shfl_xor(kmin, o, 64), y = __shfl_xor(kmax, o, 64);
+    kmin = x < kmin ? x : kmin;
+    kmax = y > kmax ? y : kmax;
+  }
+  const uint32_t s_lo = pair_lo[dp0], s_hi = pair_hi[dp0];
+  const uint32_t L = wave_lower_bound(b_key, s_lo, s_hi, kmin);
+  const uint32_t U = wave_lower_bound(b_key, L, s_hi, kmax);  // every lane's own bound lies in [L, U]
+  if (!act) return;
+  uint64_t slice_end, l, r;
+  if (same) {
+    slice_end = s_hi;
+    l = L;
+    r = U;
+  } else {  // another pair begins inside this wavefront (rare): the lane's own search over its pair's slice
+    slice_end = pair_hi[dp];
+    l = pair_lo[dp];
+    r = slice_end;
+  }
+  while (l < r) {  // lower_bound(b_key, lo) in [l, r]
     const uint64_t mid = (l + r) >> 1;
     if (b_key[mid] < lo)
       l = mid + 1;
@@ -277,6 +366,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
     }
   }
   if (best_idx != NONE) {
+    const uint32_t i = idxA[a];
     status[i] = SWG_ST_RESCUED;
     chain[i] = best_num;
   }
@@ -339,7 +429,8 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   uint8_t* C_kept = swg_alloc<uint8_t>(ctx, nc);
   uint32_t* C_num = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* anchor_num = chain_out;
-  uint8_t* in_filtered = rescue_on ? swg_alloc<uint8_t>(ctx, n) : nullptr;  // read by the rescue only
+  uint8_t* a_state = rescue_on ? swg_alloc<uint8_t>(ctx, M) : nullptr;  // by A position: anchors, never-rescued members (the rescue's inputs)
+  uint8_t* aflag = rescue_on ? swg_alloc<uint8_t>(ctx, M) : nullptr;    // a_state == 1, for the compaction of the anchors
   unsigned long long* d_cnt = swg_alloc<unsigned long long>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   uint64_t n_kept = 0;
@@ -348,12 +439,12 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
                                     cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, C_kept, C_num,
                                     &n_kept));
   if (stats) stats->n_chains_kept = n_kept;
-  if (in_filtered) SWG_HIP(ctx, hipMemsetAsync(in_filtered, 0, n, st));
+  if (a_state) SWG_HIP(ctx, hipMemsetAsync(a_state, 0, M, st));
   uint32_t* head_num = swg_alloc<uint32_t>(ctx, m);  // valid at the heads of passing chains
   SWG_CHECK_ARENA(ctx);
   SWG_LAUNCH(ctx, "head_numbers", head_numbers_kernel<<<nblk(nc), EW, 0, st>>>(nc, B.m_head_of_chain, C_num, head_num));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.m_hd, B.m_ok_head, head_num, anchor_num, in_filtered));
+  SWG_LAUNCH(ctx, "member_marks", member_marks_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_idx, B.m_hd, B.m_ok_head, head_num, anchor_num, B.s_a, a_state));
   SWG_KERNEL_CHECK(ctx);
 
   auto finish_counts = [&]() -> int {
@@ -436,7 +527,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       }
       SWG_LAUNCH(ctx, "inversion", inversion_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits,
                                                                 pair_lo, pair_hi, f_qs, f_qe, f_pm, f_ts, f_num,
-                                                                cfg->scaffold_gap, anchor_num));
+                                                                cfg->scaffold_gap, anchor_num, a_state));
       SWG_KERNEL_CHECK(ctx);
     }
   }
@@ -444,10 +535,9 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   // anchors: status + chain in input order (coalesced); everything else starts as dropped
   SWG_TRY(anchor_status());
   if (cfg->scaffold_max_deviation != 0) {  // with a rescue distance of 0 only anchors are kept (paf_filter.rs:680, 740): no anchor sort
-    uint8_t* aflag = swg_alloc<uint8_t>(ctx, M);
     uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "anchor_flag", anchor_flag_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, anchor_num, aflag));
+    SWG_LAUNCH(ctx, "anchor_flag", anchor_flag_kernel<<<nblk((M + 3) / 4), EW, 0, st>>>(M, a_state, aflag));
     SWG_KERNEL_CHECK(ctx);
     swg_flag_scan anchor_scan;
     SWG_TRY(swg_flags_count(ctx, aflag, M, &anchor_scan, d_tot));
@@ -469,16 +559,31 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_KERNEL_CHECK(ctx);
       const int dp_bits = swg_bits_for(B.n_pairs) ? swg_bits_for(B.n_pairs) : 1;
       if (dp_bits + pos_bits > 64) return swg_set_error(ctx, SWG_ERR_RANGE, "anchor sort key exceeds 64 bits");
-      SWG_TRY(swg_radix_sort_pairs(ctx, &b_key, &anchor_a, &b_key_tmp, &anchor_tmp, na, 0, dp_bits + pos_bits));
-      SWG_LAUNCH(ctx, "anchor_cols", anchor_cols_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.idxA, B.a_ts, B.a_te, anchor_num, b_tc, b_idx,
-                                                                     b_num));
-      SWG_KERNEL_CHECK(ctx);
+      // sort B: 8-byte packed passes (one pass fewer, two thirds of the bytes per pass) when the word has the room
+      const int val_bits = swg_bits_for(M - 1) ? swg_bits_for(M - 1) : 1;
+      uint64_t* packedB = nullptr;
+      int prc = SWG_ERR_UNSUPPORTED;
+      if (pos_bits >= 8) prc = swg_radix_sort_packed(ctx, b_key, anchor_a, b_key_tmp, na, dp_bits + pos_bits, val_bits, nullptr, &packedB);
+      if (prc == SWG_OK) {
+        uint64_t* b_key_out = packedB == b_key ? b_key_tmp : b_key;  // the buffer the words are not in
+        SWG_LAUNCH(ctx, "anchor_cols_packed", anchor_cols_packed_kernel<<<nblk(na), EW, 0, st>>>(na, packedB, val_bits, B.keyA, B.idxA, B.a_qe, B.a_ts,
+                                                                                   B.a_te, anchor_num, pos_bits, b_key_out, b_tc, b_idx, b_num));
+        SWG_KERNEL_CHECK(ctx);
+        b_key = b_key_out;
+      } else if (prc != SWG_ERR_UNSUPPORTED) {
+        return prc;
+      } else {
+        SWG_TRY(swg_radix_sort_pairs(ctx, &b_key, &anchor_a, &b_key_tmp, &anchor_tmp, na, 0, dp_bits + pos_bits));
+        SWG_LAUNCH(ctx, "anchor_cols", anchor_cols_kernel<<<nblk(na), EW, 0, st>>>(na, anchor_a, B.idxA, B.a_ts, B.a_te, anchor_num, b_tc, b_idx,
+                                                                       b_num));
+        SWG_KERNEL_CHECK(ctx);
+      }
       SWG_HIP(ctx, hipMemsetAsync(a_pair_lo, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
       SWG_HIP(ctx, hipMemsetAsync(a_pair_hi, 0, (B.n_pairs + 1) * sizeof(uint32_t), st));
       SWG_LAUNCH(ctx, "anchor_ranges", anchor_ranges_kernel<<<nblk(na), EW, 0, st>>>(na, b_key, pos_bits, a_pair_lo, a_pair_hi));
       SWG_KERNEL_CHECK(ctx);
-      SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, aflag,
-                                                          in_filtered, a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
+      SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, a_state,
+                                                          a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
                                                           cfg->scaffold_max_deviation, status_out, chain_out));
       SWG_KERNEL_CHECK(ctx);
     }
