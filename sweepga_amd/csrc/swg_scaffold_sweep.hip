@@ -13,6 +13,23 @@ __global__ __launch_bounds__(EW) void chain_seg_kernel(uint64_t nc, const uint32
   uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (c < nc) seg[c] = (uint64_t)C_qid[c] * n_seq + C_tid[c];
 }
+// score key + the four coordinates of a chain in one 32-byte slot, as prepare_kernel writes them for the mappings: the sweep
+// then sorts the chains' begins as packed 8-byte words and gathers one sector per begin (swg_key_ends, swg_internal.h)
+__global__ __launch_bounds__(EW) void chain_slots_kernel(uint64_t nc, const uint64_t* __restrict__ skey,
+                                                         const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qe,
+                                                         const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
+                                                         swg_key_ends* __restrict__ slots) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c >= nc) return;
+  swg_key_ends ke;
+  ke.key = skey[c];
+  ke.start[0] = qs[c];
+  ke.start[1] = ts[c];
+  ke.end[0] = qe[c];
+  ke.end[1] = te[c];
+  ke.pad[0] = ke.pad[1] = 0;
+  slots[c] = ke;
+}
 // after the stable sort of chains by chromosome pair: run heads
 __global__ __launch_bounds__(EW) void run_flag_kernel(uint64_t nc, const uint64_t* __restrict__ sorted_seg,
                                                       uint32_t* __restrict__ flag) {
@@ -28,39 +45,76 @@ __global__ __launch_bounds__(EW) void first_appearance_kernel(uint64_t nc, const
                                                               const uint32_t* __restrict__ C_qid,
                                                               const uint32_t* __restrict__ C_tid,
                                                               const uint32_t* __restrict__ seq_genome2,
-                                                              uint32_t* __restrict__ run_of_chain,
                                                               uint32_t* __restrict__ pair_first,
                                                               PairTable gp2_first) {
   uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (s >= nc) return;
-  const uint32_t c = sorted_c[s];
-  const uint32_t run = run_excl[s] + run_flag[s] - 1;
-  run_of_chain[c] = run;
   if (run_flag[s]) {
+    const uint32_t c = sorted_c[s];
+    const uint32_t run = run_excl[s];
     pair_first[run] = c;
     atomicMin(pair_slot(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]), c);
   }
 }
-__global__ __launch_bounds__(EW) void number_keys_kernel(uint64_t nk, const uint32_t* __restrict__ kept_list,
-                                                         const uint32_t* __restrict__ run_of_chain,
-                                                         const uint32_t* __restrict__ pair_first,
-                                                         PairTable gp2_first,
-                                                         const uint32_t* __restrict__ C_qid,
-                                                         const uint32_t* __restrict__ C_tid,
-                                                         const uint32_t* __restrict__ seq_genome2,
-                                                         int c_bits, uint64_t* __restrict__ key) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j >= nk) return;
-  const uint32_t c = kept_list[j];
+// Numbering without sorting the kept chains.  plane_sweep_scaffolds returns them genome pair by genome pair (first
+// appearance), chromosome pair by chromosome pair (first appearance) inside, index order inside that
+// (plane_sweep_scaffold.rs:116-130, 204-251).  The chains of a chromosome pair are one run of the seg-sorted order, in index
+// order (stable sort), so: the RUNS are sorted by (genome pair's first chain, run's first chain) -- a few thousand keys instead
+// of every kept chain (round 3 sorted all of them: seven 12-byte passes over 1.8*10^7 on S-pan) -- a run's base is the kept
+// chains of the runs before it, and a chain adds its rank among the kept chains of its run.
+__global__ __launch_bounds__(EW) void kept_sorted_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
+                                                         const uint8_t* __restrict__ kept, const uint32_t* __restrict__ run_flag,
+                                                         const uint32_t* __restrict__ run_excl, uint32_t* __restrict__ ks,
+                                                         uint32_t* __restrict__ run_start) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s >= nc) return;
+  ks[s] = kept[sorted_c[s]] ? 1u : 0u;
+  if (run_flag[s]) run_start[run_excl[s]] = (uint32_t)s;
+}
+__global__ __launch_bounds__(EW) void run_keys_kernel(uint32_t n_runs, const uint32_t* __restrict__ pair_first,
+                                                      const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ kex,
+                                                      uint32_t nc, uint32_t nk, PairTable gp2_first,
+                                                      const uint32_t* __restrict__ C_qid, const uint32_t* __restrict__ C_tid,
+                                                      const uint32_t* __restrict__ seq_genome2, int c_bits,
+                                                      uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                      uint32_t* __restrict__ run_kept) {
+  uint32_t r = blockIdx.x * EW + threadIdx.x;
+  if (r >= n_runs) return;
+  const uint32_t c = pair_first[r];
   const uint32_t g2 = pair_get(gp2_first, seq_genome2[C_qid[c]], seq_genome2[C_tid[c]]);
-  key[j] = ((uint64_t)g2 << c_bits) | pair_first[run_of_chain[c]];
+  key[r] = ((uint64_t)g2 << c_bits) | c;
+  val[r] = r;
+  const uint32_t b = kex[run_start[r]];
+  const uint32_t e = r + 1 < n_runs ? kex[run_start[r + 1]] : nk;
+  (void)nc;
+  run_kept[r] = e - b;
 }
-__global__ __launch_bounds__(EW) void assign_numbers_kernel(uint64_t nk, const uint32_t* __restrict__ sorted_kept,
-                                                            uint32_t* __restrict__ C_num) {
-  uint64_t j = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (j < nk) C_num[sorted_kept[j]] = (uint32_t)j + 1;
+__global__ __launch_bounds__(EW) void run_sizes_sorted_kernel(uint32_t n_runs, const uint32_t* __restrict__ r_sorted,
+                                                              const uint32_t* __restrict__ run_kept, uint32_t* __restrict__ sizes) {
+  uint32_t k = blockIdx.x * EW + threadIdx.x;
+  if (k < n_runs) sizes[k] = run_kept[r_sorted[k]];
 }
-
+__global__ __launch_bounds__(EW) void run_base_kernel(uint32_t n_runs, const uint32_t* __restrict__ r_sorted,
+                                                      const uint32_t* __restrict__ base_sorted, uint32_t* __restrict__ run_base) {
+  uint32_t k = blockIdx.x * EW + threadIdx.x;
+  if (k < n_runs) run_base[r_sorted[k]] = base_sorted[k];
+}
+__global__ __launch_bounds__(EW) void assign_numbers_runs_kernel(uint64_t nc, const uint32_t* __restrict__ sorted_c,
+                                                                 const uint32_t* __restrict__ ks, const uint32_t* __restrict__ kex,
+                                                                 const uint32_t* __restrict__ run_flag,
+                                                                 const uint32_t* __restrict__ run_excl,
+                                                                 const uint32_t* __restrict__ run_start,
+                                                                 const uint32_t* __restrict__ run_base, uint32_t* __restrict__ C_num) {
+  uint64_t s = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (s >= nc) return;
+  const uint32_t c = sorted_c[s];
+  uint32_t num = 0;
+  if (ks[s]) {
+    const uint32_t r = run_excl[s] + run_flag[s] - 1;
+    num = run_base[r] + (kex[s] - kex[run_start[r]]) + 1;
+  }
+  C_num[c] = num;  // (every chain is written: no memset of the column)
+}
 }  // namespace
 
 // plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
@@ -101,13 +155,22 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
   ax.pos_bits = pos_bits;
   ax.score_key = skey;
+  if (kq != SWG_K_INF || kt != SWG_K_INF) {  // a sorting sweep will run: the packed form of its inputs
+    swg_key_ends* slots = swg_alloc<swg_key_ends>(ctx, nc);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "chain_slots", chain_slots_kernel<<<nblk(nc), EW, 0, st>>>(nc, skey, qs, qe, ts, te, slots));
+    SWG_KERNEL_CHECK(ctx);
+    ax.packed = slots;
+  }
   ax.alive = nullptr;
   ax.start = qs;
   ax.end = qe;
+  ax.packed_end = 0;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
   ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
   ax.start = ts;
   ax.end = te;
+  ax.packed_end = 1;
   SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
 
   // ---- numbering -------------------------------------------------------------------------------------
@@ -117,7 +180,6 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   uint32_t* c_tmp = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* run_flag = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* run_excl = swg_alloc<uint32_t>(ctx, nc);
-  uint32_t* run_of_chain = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* pair_first = swg_alloc<uint32_t>(ctx, nc);
   SWG_CHECK_ARENA(ctx);
   PairTable gp2_first;
@@ -128,30 +190,49 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, ax.seg_bits));
   SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, nullptr));
+  SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, d_tot));  // total = number of chromosome-pair runs
   SWG_LAUNCH(ctx, "first_appearance", first_appearance_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, run_excl, run_flag, qid, tid, seq_genome2,
-                                                                           run_of_chain, pair_first, gp2_first));
+                                                                           pair_first, gp2_first));
   SWG_KERNEL_CHECK(ctx);
-  // kept chains, in index order
-  swg_flag_scan kept_scan;
-  SWG_TRY(swg_flags_count(ctx, kept, nc, &kept_scan, d_tot));
-  uint64_t nk = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &nk, 1));
-  SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
+  // kept flags in seg-sorted order and their prefix counts; run starts
+  uint32_t* ks = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* kex = swg_alloc<uint32_t>(ctx, nc);
+  uint32_t* run_start = swg_alloc<uint32_t>(ctx, nc);
+  uint64_t* d_nk = swg_alloc<uint64_t>(ctx, 1);  // (d_tot, d_nk adjacent allocations are not assumed: two read-backs in one call below)
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "kept_sorted", kept_sorted_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, kept, run_flag, run_excl, ks, run_start));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_exclusive_scan_u32(ctx, ks, kex, nc, d_nk));
+  uint64_t n_runs = 0, nk = 0;
+  SWG_TRY(swg_read_scalars(ctx, d_tot, &n_runs, 1));
+  SWG_TRY(swg_read_scalars(ctx, d_nk, &nk, 1));
   *n_kept_out = nk;
-  if (nk) {
-    uint32_t* kept_list = swg_alloc<uint32_t>(ctx, nk);
-    uint32_t* kept_tmp = swg_alloc<uint32_t>(ctx, nk);
-    uint64_t* nkey = swg_alloc<uint64_t>(ctx, nk);
-    uint64_t* nkey_tmp = swg_alloc<uint64_t>(ctx, nk);
+  if (nk == 0) {
+    SWG_HIP(ctx, hipMemsetAsync(num, 0, nc * sizeof(uint32_t), st));
+    return SWG_OK;
+  }
+  {
+    uint64_t* rkey = swg_alloc<uint64_t>(ctx, n_runs);
+    uint64_t* rkey_tmp = swg_alloc<uint64_t>(ctx, n_runs);
+    uint32_t* r_sorted = swg_alloc<uint32_t>(ctx, n_runs);
+    uint32_t* r_tmp = swg_alloc<uint32_t>(ctx, n_runs);
+    uint32_t* run_kept = swg_alloc<uint32_t>(ctx, n_runs);
+    uint32_t* r_sizes = swg_alloc<uint32_t>(ctx, n_runs);
+    uint32_t* run_base = swg_alloc<uint32_t>(ctx, n_runs);
     SWG_CHECK_ARENA(ctx);
-    SWG_TRY(swg_flags_compact(ctx, kept_scan, kept_list));
     const int c_bits = swg_bits_for(nc) ? swg_bits_for(nc) : 1;
-    SWG_LAUNCH(ctx, "number_keys", number_keys_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, run_of_chain, pair_first, gp2_first, qid, tid,
-                                                                    seq_genome2, c_bits, nkey));
+    const unsigned rb = nblk(n_runs);
+    SWG_LAUNCH(ctx, "run_keys", run_keys_kernel<<<rb, EW, 0, st>>>((uint32_t)n_runs, pair_first, run_start, kex, (uint32_t)nc, (uint32_t)nk, gp2_first,
+                                                        qid, tid, seq_genome2, c_bits, rkey, r_sorted, run_kept));
     SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &nkey, &kept_list, &nkey_tmp, &kept_tmp, nk, 0, 2 * c_bits));
-    SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_kernel<<<nblk(nk), EW, 0, st>>>(nk, kept_list, num));
+    SWG_TRY(swg_radix_sort_pairs(ctx, &rkey, &r_sorted, &rkey_tmp, &r_tmp, n_runs, 0, 2 * c_bits));
+    SWG_LAUNCH(ctx, "run_sizes_sorted", run_sizes_sorted_kernel<<<rb, EW, 0, st>>>((uint32_t)n_runs, r_sorted, run_kept, r_sizes));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_TRY(swg_exclusive_scan_u32(ctx, r_sizes, r_sizes, n_runs, nullptr));
+    SWG_LAUNCH(ctx, "run_base", run_base_kernel<<<rb, EW, 0, st>>>((uint32_t)n_runs, r_sorted, r_sizes, run_base));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "assign_numbers", assign_numbers_runs_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted, ks, kex, run_flag, run_excl, run_start,
+                                                                              run_base, num));
     SWG_KERNEL_CHECK(ctx);
   }
   return SWG_OK;
