@@ -977,13 +977,13 @@ __global__ __launch_bounds__(EW) void spec_plan_from_wmax_kernel(uint32_t n_big,
                                                                  uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                                  uint32_t m, const uint32_t* __restrict__ wmax_u,
                                                                  uint32_t* __restrict__ S_out, uint32_t* __restrict__ nblk_out,
-                                                                 uint32_t* __restrict__ s_max) {
+                                                                 uint32_t* __restrict__ s_max, int wmax_by_big_index = 0) {
   const uint32_t bi = blockIdx.x * EW + threadIdx.x;
   if (bi >= n_big) return;
   const uint32_t u = big_list[bi];
   const uint32_t b = unit_begin[u];
   const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : m;
-  uint32_t S = ((wmax_u[u] + 1 + 63) / 64) * 64;
+  uint32_t S = ((wmax_u[wmax_by_big_index ? bi : u] + 1 + 63) / 64) * 64;
   if (S < 512) S = 512;
   S_out[bi] = S;
   nblk_out[bi] = (e - b + S - 1) / S;
@@ -1009,6 +1009,13 @@ __global__ __launch_bounds__(EW) void spec_desc_kernel(uint32_t n_big, const uin
     d.be = d.bb + S < e ? d.bb + S : e;
     d.pad = 0;
     desc[off + k] = d;
+  }
+}
+__global__ __launch_bounds__(EW) void spec_ext_init_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
+                                                           unsigned long long* __restrict__ ext) {
+  for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
+    const SpecBlock D = desc[bk];
+    for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) ext[p] = ~0ull;
   }
 }
 // The three per-round passes touch only the elements of long units: one work-group per block descriptor.
@@ -1637,12 +1644,102 @@ __global__ __launch_bounds__(EW) void chunk_desc_kernel(uint32_t n_chunks, const
   d.pad = 0;
   desc[c] = d;
 }
+// The long units as ranges: big_rng[2k] = begin, big_rng[2k + 1] = end of the k-th long unit (ascending).
+__global__ __launch_bounds__(EW) void big_ranges_kernel(uint32_t n_big, const uint32_t* __restrict__ big_list, uint32_t n_units,
+                                                        const uint32_t* __restrict__ unit_begin, uint32_t m,
+                                                        uint32_t* __restrict__ big_rng) {
+  uint32_t k = blockIdx.x * EW + threadIdx.x;
+  if (k >= n_big) return;
+  const uint32_t u = big_list[k];
+  big_rng[2 * k] = unit_begin[u];
+  big_rng[2 * k + 1] = (u + 1 < n_units) ? unit_begin[u + 1] : m;
+}
+// index of the long unit that holds p, or NONE (the ranges are disjoint and ascending)
+__device__ __forceinline__ uint32_t big_unit_of(const uint32_t* __restrict__ big_rng, uint32_t n_big, uint32_t p) {
+  uint32_t l = 0, r = n_big;  // first k with begin > p
+  while (l < r) {
+    const uint32_t mid = l + ((r - l) >> 1);
+    if (big_rng[2 * mid] <= p)
+      l = mid + 1;
+    else
+      r = mid;
+  }
+  if (l == 0) return NONE;
+  return p < big_rng[2 * (l - 1) + 1] ? l - 1 : NONE;
+}
+// Membership of the long units, element by element and per 1024-element span.  One work-group per span: the long units are
+// few, so a span first asks whether any of them touches it at all (two searches) and then writes its 1024 flags -- nothing of
+// size m is read (round 3 looked every element's unit up in a u32 scan of the unit flags).
+__global__ __launch_bounds__(EW) void big_member_fill_kernel(uint64_t m, uint32_t n_big, const uint32_t* __restrict__ big_rng,
+                                                             uint8_t* __restrict__ f, uint8_t* __restrict__ span_big) {
+  const uint64_t sp = blockIdx.x;
+  const uint64_t base = sp << BIG_SPAN_SHIFT;
+  uint64_t top = base + (uint64_t(1) << BIG_SPAN_SHIFT);
+  if (top > m) top = m;
+  // the long units that can touch [base, top): from the one holding `base` (or the first beginning after it) on
+  uint32_t l = 0, r = n_big;  // first k with end > base
+  while (l < r) {
+    const uint32_t mid = l + ((r - l) >> 1);
+    if (big_rng[2 * mid + 1] <= base)
+      l = mid + 1;
+    else
+      r = mid;
+  }
+  const bool any = l < n_big && big_rng[2 * l] < top;
+  if (threadIdx.x == 0) span_big[sp] = any ? 1 : 0;
+  for (uint64_t p = base + threadIdx.x; p < top; p += EW) {
+    uint8_t b = 0;
+    if (any) {
+      for (uint32_t k = l; k < n_big && big_rng[2 * k] <= p; ++k)
+        if (p < big_rng[2 * k + 1]) {
+          b = 1;
+          break;
+        }
+    }
+    f[p] = b;
+  }
+}
+
+// Longest window per long unit (indexed like big_rng) when a unit holds millions of elements: every member contributes its
+// window extent to its unit's maximum -- one atomic per wavefront whose members share the unit, which they nearly always do.
+__global__ __launch_bounds__(EW) void big_wmax_kernel(uint64_t m, const uint8_t* __restrict__ big_member,
+                                                      const uint32_t* __restrict__ big_rng, uint32_t n_big,
+                                                      const uint32_t* __restrict__ c_ext, uint32_t* __restrict__ wmax_k,
+                                                      const uint8_t* __restrict__ span_big) {
+  const int lane = threadIdx.x & 63;
+  uint32_t cur_k = NONE, cur_w = 0;  // wave-uniform: the unit this wavefront is accumulating and its maximum so far
+  for (uint64_t base = (uint64_t)blockIdx.x * EW; base < m; base += (uint64_t)gridDim.x * EW) {  // block-uniform trip count
+    if (!span_big[base >> BIG_SPAN_SHIFT]) continue;
+    const uint64_t p = base + threadIdx.x;
+    const bool big = p < m && big_member[p] != 0;
+    const uint64_t bm = __ballot(big);
+    if (bm == 0) continue;  // wave-uniform
+    const uint32_t k = big ? big_unit_of(big_rng, n_big, (uint32_t)p) : NONE;
+    uint32_t w = big ? c_ext[p] : 0u;
+    const uint32_t k0 = (uint32_t)__shfl((int)k, (int)__builtin_ctzll(bm), 64);
+    if (__ballot(big && k != k0) == 0) {  // the wavefront's members share one unit
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = __shfl_xor(w, o, 64);
+        if (t > w) w = t;
+      }
+      if (k0 != cur_k) {  // flush the previous unit (one atomic per wavefront and unit, not per row)
+        if (lane == 0 && cur_w) atomicMax(&wmax_k[cur_k], cur_w);
+        cur_k = k0;
+        cur_w = 0;
+      }
+      if (w > cur_w) cur_w = w;
+    } else if (big && w) {
+      atomicMax(&wmax_k[k], w);
+    }
+  }
+  if (lane == 0 && cur_w) atomicMax(&wmax_k[cur_k], cur_w);
+}
+
 // Window extent of the members of long units (how many later elements of the unit start within q_end + gap): what the block
 // plan needs (a block must be at least as long as the longest window).  The unit is sorted by q_start: a binary search.
 __global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uint8_t* __restrict__ big_member,
-                                                           const uint32_t* __restrict__ unit_flag,
-                                                           const uint32_t* __restrict__ unit_excl,
-                                                           const uint32_t* __restrict__ unit_begin, uint32_t n_units,
+                                                           const uint32_t* __restrict__ big_rng, uint32_t n_big,
                                                            const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
                                                            uint64_t max_gap, uint32_t* __restrict__ ext,
                                                            const uint8_t* __restrict__ span_big) {
@@ -1651,8 +1748,7 @@ __global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uin
   if (span_big && !span_big[p >> BIG_SPAN_SHIFT]) return;  // (extents are only read for members of long units)
   uint32_t x = 0;
   if (big_member[p]) {
-    const uint32_t u = unit_excl[p] + unit_flag[p] - 1;
-    const uint32_t e = (u + 1 < n_units) ? unit_begin[u + 1] : (uint32_t)m;
+    const uint32_t e = big_rng[2 * big_unit_of(big_rng, n_big, (uint32_t)p) + 1];  // end of p's unit
     const uint64_t bound = (uint64_t)s_qe[p] + max_gap;  // wrapping, as release Rust
     uint32_t lo = (uint32_t)p + 1, hi = e;  // first position in (p, e) with q_start > bound
     while (lo < hi) {
@@ -1666,18 +1762,6 @@ __global__ __launch_bounds__(EW) void window_extent_kernel(uint64_t m, const uin
   }
   ext[p] = x;
 }
-// candidate lists only for the elements of long units (the walk builds the others' lists itself)
-__global__ __launch_bounds__(EW) void big_member_flag_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
-                                                             const uint32_t* __restrict__ unit_excl,
-                                                             const uint8_t* __restrict__ is_big, uint8_t* __restrict__ f,
-                                                             uint8_t* __restrict__ span_big) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m) return;
-  const uint8_t b = is_big[unit_excl[p] + unit_flag[p] - 1];
-  f[p] = b;
-  if (b) span_big[p >> BIG_SPAN_SHIFT] = 1;  // (pre-zeroed; every writer stores the same value)
-}
-
 __global__ __launch_bounds__(EW) void unit_big_flag_kernel(uint32_t n_units, const uint32_t* __restrict__ unit_begin,
                                                            uint32_t m, uint8_t* __restrict__ is_big) {
   uint32_t u = blockIdx.x * EW + threadIdx.x;
@@ -1700,10 +1784,12 @@ __global__ __launch_bounds__(EW) void unit_mid_flag_kernel(uint32_t n_units, con
 // q_end of the group by more than the gap -- no (i, j) pair of the reference's window test
 // (`q_start[j] <= q_end[i] + gap`, paf_filter.rs:786-796) can then straddle p, so the greedy on either side is
 // independent.  One wavefront per group, 64 elements per step, running maximum carried along.
+// (F: uint8_t -- the walk's path: the unit list comes out of a compaction of byte flags -- or uint32_t, the round-2 kernels')
+template <class F>
 __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
                                                         uint32_t m, const uint32_t* __restrict__ s_qs,
                                                         const uint32_t* __restrict__ s_qe, uint64_t max_gap,
-                                                        uint32_t* __restrict__ unit_flag) {
+                                                        F* __restrict__ unit_flag) {
   // 256 elements per step: four consecutive elements per lane (their running maximum in registers), one wave scan over the
   // lanes' totals, the carry from earlier steps on top
   const int lane = threadIdx.x & 63;
@@ -1742,7 +1828,7 @@ __global__ __launch_bounds__(EW) void chain_cuts_kernel(uint32_t n_groups, const
         const uint32_t bf = own[k] > before ? own[k] : before;
         uint64_t lim = (uint64_t)bf + max_gap;
         if (lim < max_gap) lim = ~0ull;  // saturate
-        if (p + k < e) unit_flag[p + k] = (p + k == b || (uint64_t)qs[k] > lim) ? 1u : 0u;
+        if (p + k < e) unit_flag[p + k] = (F)((p + k == b || (uint64_t)qs[k] > lim) ? 1 : 0);
       }
       const uint32_t last = __shfl(inc, 63, 64);
       if (last > carry) carry = last;
@@ -1758,10 +1844,11 @@ __global__ __launch_bounds__(EW) void seg_compose_kernel(uint64_t m, const uint3
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p < m) out[p] = ((uint64_t)s_gidx[p] << 32) | (complement ? 0xffffffffu - v[p] : v[p]);
 }
+template <class F>
 __global__ __launch_bounds__(EW) void cuts_from_scan_kernel(uint64_t m, const uint32_t* __restrict__ head_flag,
                                                             const uint64_t* __restrict__ run_max,
                                                             const uint32_t* __restrict__ s_qs, uint64_t max_gap,
-                                                            uint32_t* __restrict__ unit_flag) {
+                                                            F* __restrict__ unit_flag) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (p >= m) return;
   uint32_t f = 1;
@@ -1770,7 +1857,7 @@ __global__ __launch_bounds__(EW) void cuts_from_scan_kernel(uint64_t m, const ui
     if (lim < max_gap) lim = ~0ull;
     f = (uint64_t)s_qs[p] > lim ? 1u : 0u;
   }
-  unit_flag[p] = f;
+  unit_flag[p] = (F)f;
 }
 __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32_t* __restrict__ unit_flag,
                                                         const uint32_t* __restrict__ unit_excl,
@@ -1988,10 +2075,14 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(m), EW, 0, st>>>(m, pred, NONE));
   SWG_KERNEL_CHECK(ctx);
   {
-    // units = groups cut where no window can straddle; short-window units go four per wavefront (16-lane
-    // slices), the rest one wavefront each
-    uint32_t* unit_flag = swg_alloc<uint32_t>(ctx, m);
-    uint32_t* unit_excl = swg_alloc<uint32_t>(ctx, m);
+    // units = groups cut where no window can straddle.  The walk's path keeps the cut flags as BYTES and gets the list of unit
+    // begins from their compaction (per-tile counts, no element-wise scan, no per-element unit index: the few kernels that
+    // need the unit of an element -- only members of long units ask -- search the long units' ranges); the round-2 kernels
+    // (SWG_CHAIN_OLD) keep their u32 flags and the exclusive scan.
+    static const bool old_walk = getenv("SWG_CHAIN_OLD") != nullptr;  // A/B knob: the per-step kernels of round 2
+    uint32_t* unit_flag = old_walk ? swg_alloc<uint32_t>(ctx, m) : nullptr;
+    uint32_t* unit_excl = old_walk ? swg_alloc<uint32_t>(ctx, m) : nullptr;
+    uint8_t* unit_flag8 = old_walk ? nullptr : swg_alloc<uint8_t>(ctx, m);
     uint64_t* d_nu = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
     const bool long_groups = m / n_groups > 8192;  // few, long groups: scan-based reductions
@@ -2002,25 +2093,41 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_LAUNCH(ctx, "seg_compose", seg_compose_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, s_qe, 0, comp));
       SWG_KERNEL_CHECK(ctx);
       SWG_TRY(swg_inclusive_max_scan_u64(ctx, comp, comp, m));
-      SWG_LAUNCH(ctx, "cuts_from_scan", cuts_from_scan_kernel<<<nblk(m), EW, 0, st>>>(m, head_flag, comp, s_qs, max_gap, unit_flag));
+      if (old_walk)
+        SWG_LAUNCH(ctx, "cuts_from_scan", cuts_from_scan_kernel<uint32_t><<<nblk(m), EW, 0, st>>>(m, head_flag, comp, s_qs, max_gap, unit_flag));
+      else
+        SWG_LAUNCH(ctx, "cuts_from_scan", cuts_from_scan_kernel<uint8_t><<<nblk(m), EW, 0, st>>>(m, head_flag, comp, s_qs, max_gap, unit_flag8));
       SWG_KERNEL_CHECK(ctx);
       swg_arena_restore(ctx, mk);
     } else {
       uint64_t blocks = (n_groups + 3) / 4;
       const uint64_t mb = (uint64_t)ctx->num_cu * 16;
       if (blocks > mb) blocks = mb;
-      SWG_LAUNCH(ctx, "chain_cuts", chain_cuts_kernel<<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs, s_qe,
-                                                                           max_gap, unit_flag));
+      if (old_walk)
+        SWG_LAUNCH(ctx, "chain_cuts", chain_cuts_kernel<uint32_t><<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs,
+                                                                                       s_qe, max_gap, unit_flag));
+      else
+        SWG_LAUNCH(ctx, "chain_cuts", chain_cuts_kernel<uint8_t><<<(unsigned)blocks, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, s_qs,
+                                                                                      s_qe, max_gap, unit_flag8));
       SWG_KERNEL_CHECK(ctx);
     }
-    SWG_TRY(swg_exclusive_scan_u32(ctx, unit_flag, unit_excl, m, d_nu));
     uint64_t n_units = 0;
-    SWG_TRY(swg_read_scalars(ctx, d_nu, &n_units, 1));
-    uint32_t* unit_begin = swg_alloc<uint32_t>(ctx, n_units);
-    SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
-    SWG_KERNEL_CHECK(ctx);
-    static const bool old_walk = getenv("SWG_CHAIN_OLD") != nullptr;  // A/B knob: the per-step kernels of round 2
+    uint32_t* unit_begin = nullptr;
+    if (old_walk) {
+      SWG_TRY(swg_exclusive_scan_u32(ctx, unit_flag, unit_excl, m, d_nu));
+      SWG_TRY(swg_read_scalars(ctx, d_nu, &n_units, 1));
+      unit_begin = swg_alloc<uint32_t>(ctx, n_units);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "unit_begin", unit_begin_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, unit_begin));
+      SWG_KERNEL_CHECK(ctx);
+    } else {
+      swg_flag_scan unit_scan;
+      SWG_TRY(swg_flags_count(ctx, unit_flag8, m, &unit_scan, d_nu));
+      SWG_TRY(swg_read_scalars(ctx, d_nu, &n_units, 1));
+      unit_begin = swg_alloc<uint32_t>(ctx, n_units);
+      SWG_CHECK_ARENA(ctx);
+      SWG_TRY(swg_flags_compact(ctx, unit_scan, unit_begin));
+    }
     static const bool force_deep = getenv("SWG_CHAIN_DEEP") != nullptr;  // test knob: the deep-group (wavefront per i) kernel at any size
     if (getenv("SWG_DEBUG"))
       fprintf(stderr, "[swg] chaining: m=%llu groups=%llu units=%llu\n", (unsigned long long)m,
@@ -2052,13 +2159,21 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       uint32_t *c_j = nullptr, *c_n = nullptr, *c_ext = nullptr;
       uint8_t* big_member = nullptr;  // members of long units (also what the chain table's generic path is restricted to)
       uint8_t* span_big = nullptr;    // the same per 1024-element span: lets that path skip whole work-groups
+      uint32_t* big_list = nullptr;  // the long units (indices into unit_begin) ...
+      uint32_t* big_rng = nullptr;   // ... and their [begin, end) ranges
       if (n_big) {
         big_member = swg_alloc<uint8_t>(ctx, m);
-        const uint64_t n_span = (m >> BIG_SPAN_SHIFT) + 1;
-        span_big = swg_alloc<uint8_t>(ctx, n_span);
+        const uint64_t n_span = (m + (uint64_t(1) << BIG_SPAN_SHIFT) - 1) >> BIG_SPAN_SHIFT;
+        span_big = swg_alloc<uint8_t>(ctx, n_span + 1);
+        big_list = swg_alloc<uint32_t>(ctx, n_big);
+        big_rng = swg_alloc<uint32_t>(ctx, 2 * n_big);
         SWG_CHECK_ARENA(ctx);
-        SWG_HIP(ctx, hipMemsetAsync(span_big, 0, n_span, st));
-        SWG_LAUNCH(ctx, "big_member_flag", big_member_flag_kernel<<<nblk(m), EW, 0, st>>>(m, unit_flag, unit_excl, is_big, big_member, span_big));
+        SWG_TRY(swg_flags_compact(ctx, big_scan, big_list));
+        SWG_LAUNCH(ctx, "big_ranges", big_ranges_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin, (uint32_t)m,
+                                                                       big_rng));
+        SWG_KERNEL_CHECK(ctx);
+        SWG_HIP(ctx, hipMemsetAsync(span_big + n_span, 0, 1, st));  // (readers index spans up to m >> shift inclusive)
+        SWG_LAUNCH(ctx, "big_member_fill", big_member_fill_kernel<<<(unsigned)n_span, EW, 0, st>>>(m, (uint32_t)n_big, big_rng, big_member, span_big));
         SWG_KERNEL_CHECK(ctx);
       }
       if (lists_all) {
@@ -2076,8 +2191,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         // window extents
         c_ext = swg_alloc<uint32_t>(ctx, m);
         SWG_CHECK_ARENA(ctx);
-        SWG_LAUNCH(ctx, "window_extent", window_extent_kernel<<<nblk(m), EW, 0, st>>>(m, big_member, unit_flag, unit_excl, unit_begin,
-                                                                         (uint32_t)n_units, s_qs, s_qe, max_gap, c_ext, span_big));
+        SWG_LAUNCH(ctx, "window_extent", window_extent_kernel<<<nblk(m), EW, 0, st>>>(m, big_member, big_rng, (uint32_t)n_big, s_qs, s_qe, max_gap,
+                                                                         c_ext, span_big));
         SWG_KERNEL_CHECK(ctx);
       }
       {
@@ -2105,9 +2220,6 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_KERNEL_CHECK(ctx);
       }
       if (n_big) {
-        uint32_t* big_list = swg_alloc<uint32_t>(ctx, n_big);
-        SWG_CHECK_ARENA(ctx);
-        SWG_TRY(swg_flags_compact(ctx, big_scan, big_list));
         // ---- block-speculative selection of the long units
         uint32_t* S_u = swg_alloc<uint32_t>(ctx, n_big);
         uint32_t* nblk_u = swg_alloc<uint32_t>(ctx, n_big);
@@ -2123,15 +2235,15 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_CHECK_ARENA(ctx);
         SWG_HIP(ctx, hipMemsetAsync(d_smax, 0, 8, st));
         if (m / n_big > 65536) {  // few, very long units
-          uint32_t* wmax_u = swg_alloc<uint32_t>(ctx, n_units);
+          uint32_t* wmax_k = swg_alloc<uint32_t>(ctx, n_big);
           SWG_CHECK_ARENA(ctx);
-          SWG_HIP(ctx, hipMemsetAsync(wmax_u, 0, n_units * sizeof(uint32_t), st));
+          SWG_HIP(ctx, hipMemsetAsync(wmax_k, 0, n_big * sizeof(uint32_t), st));
           const uint64_t wb = nblk(m) < (uint64_t)ctx->num_cu * 16 ? nblk(m) : (uint64_t)ctx->num_cu * 16;
-          SWG_LAUNCH(ctx, "unit_wmax", unit_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, unit_flag, unit_excl, is_big, c_ext, wmax_u, span_big));
+          SWG_LAUNCH(ctx, "big_wmax", big_wmax_kernel<<<(unsigned)wb, EW, 0, st>>>(m, big_member, big_rng, (uint32_t)n_big, c_ext, wmax_k, span_big));
           SWG_KERNEL_CHECK(ctx);
           SWG_LAUNCH(ctx, "spec_plan_from_wmax", spec_plan_from_wmax_kernel<<<nblk(n_big), EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
-                                                                                (uint32_t)m, wmax_u, S_u, nblk_u,
-                                                                                reinterpret_cast<uint32_t*>(d_smax)));
+                                                                                (uint32_t)m, wmax_k, S_u, nblk_u,
+                                                                                reinterpret_cast<uint32_t*>(d_smax), 1));
           SWG_KERNEL_CHECK(ctx);
         } else {
           SWG_LAUNCH(ctx, "spec_plan", spec_plan_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
@@ -2149,9 +2261,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_LAUNCH(ctx, "spec_desc", spec_desc_kernel<<<(unsigned)n_big, EW, 0, st>>>((uint32_t)n_big, big_list, (uint32_t)n_units, unit_begin,
                                                                         (uint32_t)m, S_u, nblk_u, blk_off, desc));
         SWG_KERNEL_CHECK(ctx);
-        SWG_LAUNCH(ctx, "fill", fill_u64_kernel<<<nblk(m), EW, 0, st>>>(m, reinterpret_cast<uint64_t*>(ext), ~0ull));
-        SWG_KERNEL_CHECK(ctx);
         const uint64_t rblocks = n_spec < (uint64_t)ctx->num_cu * 8 ? n_spec : (uint64_t)ctx->num_cu * 8;
+        // `ext` (what the previous block offers each element) is only ever read and written inside the blocks: it starts as
+        // "no offer" there and nowhere else (round 3 filled all m entries)
+        SWG_LAUNCH(ctx, "spec_ext_init", spec_ext_init_kernel<<<(unsigned)rblocks, EW, 0, st>>>((uint32_t)n_spec, desc, ext));
+        SWG_KERNEL_CHECK(ctx);
         // The ring is a cache (positions outside it are read from global memory), so its size only trades LDS hits for
         // resident wavefronts -- and a block is one dependent chain, bound by latency, so residency wins: 256 slots when no
         // window exceeds 511 elements, else 1024 (S-big1, windows up to 19,968: 12.4 ms with 4096 slots = one block per CU,

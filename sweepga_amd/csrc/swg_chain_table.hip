@@ -294,8 +294,20 @@ __global__ __launch_bounds__(EW) void genome_pair_first_groups_kernel(uint32_t n
 // all_chains order = (q,t,strand) groups by first appearance, chains of a group by head position.  Chains in
 // head-position order are already contiguous per group, so only the GROUPS are sorted; a chain's place is its
 // group's base plus its rank inside the group.
+// number of passing heads before member position p = lower bound of p in the ascending list of passing heads
+__device__ __forceinline__ uint32_t heads_before(const uint32_t* __restrict__ ch_head, uint32_t nc, uint32_t p) {
+  uint32_t l = 0, r = nc;
+  while (l < r) {
+    const uint32_t mid = l + ((r - l) >> 1);
+    if (ch_head[mid] < p)
+      l = mid + 1;
+    else
+      r = mid;
+  }
+  return l;
+}
 __global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const uint32_t* __restrict__ group_begin,
-                                                        uint32_t m, const uint32_t* __restrict__ cpos_excl, uint32_t nc,
+                                                        uint32_t m, const uint32_t* __restrict__ ch_head, uint32_t nc,
                                                         const uint32_t* __restrict__ s_idx,
                                                         const uint32_t* __restrict__ group_first,
                                                         const uint32_t* __restrict__ q_id,
@@ -308,8 +320,8 @@ __global__ __launch_bounds__(EW) void group_keys_kernel(uint32_t n_groups, const
   uint32_t g = blockIdx.x * EW + threadIdx.x;
   if (g >= n_groups) return;
   const uint32_t b = group_begin[g];
-  const uint32_t first = cpos_excl[b];  // exclusive count of passing heads before the group = its first chain
-  const uint32_t next = (g + 1 < n_groups) ? cpos_excl[group_begin[g + 1]] : nc;
+  const uint32_t first = heads_before(ch_head, nc, b);  // passing heads before the group = its first chain
+  const uint32_t next = (g + 1 < n_groups) ? heads_before(ch_head, nc, group_begin[g + 1]) : nc;
   (void)m;
   g_first_chain[g] = first;
   g_nchains[g] = next - first;
@@ -334,19 +346,16 @@ __global__ __launch_bounds__(EW) void group_base_kernel(uint32_t n_groups, const
   uint32_t r = blockIdx.x * EW + threadIdx.x;
   if (r < n_groups) g_base[g_sorted[r]] = base_sorted[r];
 }
-// per chain head: position-order ordinal c -> all_chains index c2 (and the inverse)
-__global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
-                                                         const uint32_t* __restrict__ cpos_excl,
+// per passing chain: position-order ordinal c -> all_chains index (one thread per chain: the list of passing heads comes
+// out of the compaction of the byte flags; round 3 ran over all members with a u32 flag column and its element-wise scan)
+__global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t nc, const uint32_t* __restrict__ ch_head,
                                                          const uint32_t* __restrict__ s_gidx,
                                                          const uint32_t* __restrict__ g_first_chain,
-                                                         const uint32_t* __restrict__ g_base,
-                                                         uint32_t* __restrict__ ch_head, uint32_t* __restrict__ order) {
-  uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p >= m || !is_head[p]) return;
-  const uint32_t c = cpos_excl[p];
-  const uint32_t g = s_gidx[p];
-  ch_head[c] = (uint32_t)p;
-  order[g_base[g] + (c - g_first_chain[g])] = c;
+                                                         const uint32_t* __restrict__ g_base, uint32_t* __restrict__ order) {
+  uint64_t c = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (c >= nc) return;
+  const uint32_t g = s_gidx[ch_head[c]];
+  order[g_base[g] + ((uint32_t)c - g_first_chain[g])] = (uint32_t)c;
 }
 
 // weighted identity of a chain (paf_filter.rs:896-913) from its aggregates
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
                                                       const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe,
                                                       const unsigned long long* __restrict__ h_sm,
                                                       const unsigned long long* __restrict__ h_sb, uint64_t min_len,
-                                                      double min_ident, uint32_t* __restrict__ ok_head,
+                                                      double min_ident, uint8_t* __restrict__ ok_head,
                                                       double* __restrict__ h_wid, const uint8_t* __restrict__ only,
                                                       const uint8_t* __restrict__ span) {
   const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
           if (ok) h_wid[p] = wid;
         }
       }
-      ok_head[p] = ok ? 1u : 0u;
+      ok_head[p] = ok ? 1 : 0;
     }
   }
 }
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
                                                          const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te,
                                                          const uint32_t* __restrict__ s_m, const uint32_t* __restrict__ s_b,
                                                          uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
-                                                         uint32_t* __restrict__ ok_head, uint32_t* __restrict__ h_qe,
+                                                         uint8_t* __restrict__ ok_head, uint32_t* __restrict__ h_qe,
                                                          uint32_t* __restrict__ h_ts, uint32_t* __restrict__ h_te,
                                                          double* __restrict__ h_wid, unsigned long long* __restrict__ n_heads) {
   __shared__ uint16_t succ[LABEL_CAP];
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
           h_wid[p] = wid;
         }
       }
-      ok_head[p] = ok ? 1u : 0u;
+      ok_head[p] = ok ? 1 : 0;
     }
   }
 #pragma unroll
@@ -494,13 +503,16 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
   C_wid[c2] = h_wid[p];
 }
 
+// index into T of every member's chain (NONE: its chain fails the span / identity filter); only the merge_chains seam asks
 __global__ __launch_bounds__(EW) void survivor_chain_kernel(uint64_t m, const uint32_t* __restrict__ hd,
-                                                            const uint32_t* __restrict__ ok_head,
-                                                            const uint32_t* __restrict__ cpos_excl,
+                                                            const uint8_t* __restrict__ ok_head,
+                                                            const uint32_t* __restrict__ ch_head, uint32_t nc,
                                                             const uint32_t* __restrict__ rank_of_poschain,
                                                             uint32_t* __restrict__ s_chain) {
   uint64_t p = (uint64_t)blockIdx.x * EW + threadIdx.x;
-  if (p < m) s_chain[p] = chain_of_member(p, hd, ok_head, cpos_excl, rank_of_poschain);
+  if (p >= m) return;
+  const uint32_t h = hd[p];
+  s_chain[p] = ok_head[h] ? rank_of_poschain[heads_before(ch_head, nc, h)] : NONE;
 }
 
 }  // namespace
@@ -551,13 +563,12 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   unsigned long long* h_sm = swg_alloc<unsigned long long>(ctx, m);
   unsigned long long* h_sb = swg_alloc<unsigned long long>(ctx, m);
   uint32_t* is_head = swg_alloc<uint32_t>(ctx, m);
-  uint32_t* cpos = swg_alloc<uint32_t>(ctx, m);
   uint32_t* group_first = swg_alloc<uint32_t>(ctx, n_groups);
   PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   double* h_wid = swg_alloc<double>(ctx, m);
-  uint32_t* ok_head = swg_alloc<uint32_t>(ctx, m);
+  uint8_t* ok_head = swg_alloc<uint8_t>(ctx, m);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
   unsigned long long* n_heads = reinterpret_cast<unsigned long long*>(d_tot + 1);  // all chains: counted where heads are found
@@ -603,7 +614,9 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
                                     m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head, h_wid, only, span));
     SWG_KERNEL_CHECK(ctx);
   }
-  SWG_TRY(swg_exclusive_scan_u32(ctx, ok_head, cpos, m, d_tot));
+  // the passing heads, in position order: byte flags -> per-tile counts (-> the list, below)
+  swg_flag_scan ok_scan;
+  SWG_TRY(swg_flags_count(ctx, ok_head, m, &ok_scan, d_tot));
   uint64_t h2[2];
   SWG_TRY(swg_read_scalars(ctx, d_tot, h2, 2));
   const uint64_t nc = h2[0];
@@ -642,6 +655,8 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   }
   SWG_KERNEL_CHECK(ctx);
   uint32_t* ch_head = swg_alloc<uint32_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  SWG_TRY(swg_flags_compact(ctx, ok_scan, ch_head));
   uint32_t* order = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* rank_of = swg_alloc<uint32_t>(ctx, nc);
   uint32_t* head_of_chain = swg_alloc<uint32_t>(ctx, nc);
@@ -667,7 +682,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_CHECK_ARENA(ctx);
   const int idx_bits = swg_bits_for(n) ? swg_bits_for(n) : 1;
   const unsigned gblk = nblk(n_groups);
-  SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, cpos, (uint32_t)nc,
+  SWG_LAUNCH(ctx, "group_keys", group_keys_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, group_begin, (uint32_t)m, ch_head, (uint32_t)nc,
                                                            B.s_idx, group_first, r->q_id, r->t_id, r->seq_genome_last,
                                                            genome_pair_major, gp_first, idx_bits, g_key, g_sorted, g_first_chain,
                                                            g_nchains));
@@ -678,7 +693,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_TRY(swg_exclusive_scan_u32(ctx, g_sizes, g_sizes, n_groups, nullptr));
   SWG_LAUNCH(ctx, "group_base", group_base_kernel<<<gblk, EW, 0, st>>>((uint32_t)n_groups, g_sorted, g_sizes, g_base));
   SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(m), EW, 0, st>>>(m, ok_head, cpos, s_gidx, g_first_chain, g_base, ch_head, order));
+  SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(nc), EW, 0, st>>>(nc, ch_head, s_gidx, g_first_chain, g_base, order));
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
                                        nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_wid, s_grp, B.s_a, B.a_dpair,
@@ -687,10 +702,9 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   B.m_head_of_chain = head_of_chain;
   B.m_hd = hd;
   B.m_ok_head = ok_head;
-  B.m_cpos = cpos;
   B.m_rank_of = rank_of;
   if (B.want_s_chain) {
-    SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, cpos, rank_of, B.s_chain));
+    SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, ch_head, (uint32_t)nc, rank_of, B.s_chain));
     SWG_KERNEL_CHECK(ctx);
   }
   return SWG_OK;

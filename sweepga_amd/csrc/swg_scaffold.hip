@@ -23,7 +23,7 @@ __global__ __launch_bounds__(EW) void head_numbers_kernel(uint64_t nc, const uin
 }
 __global__ __launch_bounds__(EW) void member_marks_kernel(uint64_t m, const uint32_t* __restrict__ s_idx,
                                                           const uint32_t* __restrict__ hd,
-                                                          const uint32_t* __restrict__ ok_head,
+                                                          const uint8_t* __restrict__ ok_head,
                                                           const uint32_t* __restrict__ head_num,
                                                           uint32_t* __restrict__ anchor_num,
                                                           const uint32_t* __restrict__ s_a, uint8_t* __restrict__ a_state) {

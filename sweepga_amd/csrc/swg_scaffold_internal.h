@@ -88,7 +88,8 @@ struct ChainBuild {
   uint32_t* s_chain = nullptr;  // index into T of the member's chain, NONE when that chain fails the span / identity filter
                                 //   (only materialised when want_s_chain; otherwise chain_of_member() derives it)
   bool want_s_chain = true;
-  const uint32_t *m_hd = nullptr, *m_ok_head = nullptr, *m_cpos = nullptr, *m_rank_of = nullptr;  // per member / per chain
+  const uint32_t *m_hd = nullptr, *m_rank_of = nullptr;  // per member: head position / per chain (position order): T index
+  const uint8_t* m_ok_head = nullptr;                    // per member position: 1 = heads a chain that passes the filter
   const uint32_t* m_head_of_chain = nullptr;  // [T.nc] member position of the chain's head, in T order
   // chains that pass the span / identity filter (paf_filter.rs:449-455), in all_chains order: only these reach the scaffold
   // sweep, the numbering, the anchors; the others exist as a count
@@ -110,15 +111,6 @@ constexpr int BIG_SPAN_SHIFT = 10;  // span_big's granularity = HEAD_SPAN = AGG_
 constexpr uint32_t WALK_CHUNK = 1024;  // a chunk = the units that begin in one WALK_CHUNK-element cell ...
 constexpr uint32_t BIG_UNIT = 8192;    // ... all shorter than this (longer units take the block-speculative path)
 
-#ifdef __HIPCC__
-// index into T of member p's chain (NONE: its chain fails the span / identity filter), from the labelling arrays
-__device__ __forceinline__ uint32_t chain_of_member(uint64_t p, const uint32_t* __restrict__ hd,
-                                                    const uint32_t* __restrict__ ok_head, const uint32_t* __restrict__ cpos,
-                                                    const uint32_t* __restrict__ rank_of) {
-  const uint32_t h = hd[p];
-  return ok_head[h] ? rank_of[cpos[h]] : 0xffffffffu;
-}
-#endif
 
 // What the predecessor selection (swg_chain.hip) hands to the chain table (swg_chain_table.hip): the members of sort A in
 // A order (`s_*`, m entries), their (query, target, strand) groups, and pred[p] = best-buddy predecessor of p (NONE = head).
