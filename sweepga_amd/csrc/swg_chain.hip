@@ -268,7 +268,7 @@ __global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64
   }
   a_dpair[a] = np - 1;  // (the first element is a boundary of both kinds: counts are >= 1)
   s_gidx[a] = ng - 1;
-  head_flag[a] = gf ? 1u : 0u;
+  if (head_flag) head_flag[a] = gf ? 1u : 0u;  // (nullptr: nobody reads it -- only the scan-based reductions of few, long groups do)
   if (gf) group_begin[ng - 1] = (uint32_t)a;
 }
 
@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32
 }  // namespace
 
 int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order) {
+                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order, uint64_t n_alive) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   ChainBuild& B = *out;
@@ -1880,10 +1880,10 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   // ---- compaction of alive, sort A
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 4);
   SWG_CHECK_ARENA(ctx);
-  swg_flag_scan alive_scan;
-  SWG_TRY(swg_flags_count(ctx, alive, n, &alive_scan, d_tot));
-  uint64_t M = 0;
-  SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
+  swg_flag_scan alive_scan{};
+  uint64_t M = n_alive;  // the caller's count (prepare has it), or ~0: counted here
+  if (M == ~0ull || (M != n && !q_order)) SWG_TRY(swg_flags_count(ctx, alive, n, &alive_scan, d_tot));  // (M == n: nothing to compact)
+  if (M == ~0ull) SWG_TRY(swg_read_scalars(ctx, d_tot, &M, 1));
   B.M = M;
   if (M == 0) return SWG_OK;
   const bool all_members = member == alive;  // the mapping-level sweep removed nothing (the caller passes the same array)
@@ -1985,7 +1985,6 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     s_m = swg_alloc<uint32_t>(ctx, m);
     s_b = swg_alloc<uint32_t>(ctx, m);
     s_grp = swg_alloc<uint64_t>(ctx, m);
-    head_flag = swg_alloc<uint32_t>(ctx, m);
     s_gidx = swg_alloc<uint32_t>(ctx, m);
     group_begin = swg_alloc<uint32_t>(ctx, m);
     bps = swg_alloc<unsigned long long>(ctx, m);
@@ -2003,13 +2002,19 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                                                                  blk_cnt));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_inclusive_sum_scan_u64(ctx, blk_cnt, blk_cnt, n_blk));
-    SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, pos_bits, blk_cnt, B.a_dpair, s_gidx, head_flag,
-                                                               group_begin));
-    SWG_KERNEL_CHECK(ctx);
     uint64_t tot = 0;
     SWG_TRY(swg_read_scalars(ctx, blk_cnt + (n_blk - 1), &tot, 1));
     B.n_pairs = tot >> 32;
     n_groups = tot & 0xffffffffull;
+    // the group-head flags as a column are only read by the scan-based reductions of few, long groups (below and in the chain
+    // table): 4 bytes per member not written otherwise
+    if (n_groups && m / n_groups > 8192) {
+      head_flag = swg_alloc<uint32_t>(ctx, m);
+      SWG_CHECK_ARENA(ctx);
+    }
+    SWG_LAUNCH(ctx, "group_pair", group_pair_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, pos_bits, blk_cnt, B.a_dpair, s_gidx, head_flag,
+                                                               group_begin));
+    SWG_KERNEL_CHECK(ctx);
   } else {
     SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
                                                           pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));

@@ -248,7 +248,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr);
+  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1]);
 }
 
 static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
