@@ -337,40 +337,50 @@ class Runner:
         ccfg = cfg.to_c()
         for _ in range(warmup):
             self.step(ccfg)
-        self.barrier()
+
+        def timed(k):
+            """barrier + synchronize, exactly k steps, synchronize, MAX over ranks -> (seconds, this rank's seconds)"""
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                self.step(ccfg)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            local = time.perf_counter() - t0
+            allr = local
+            if self.dist is not None:
+                tt = torch.tensor([local], dtype=torch.float64, device=self.coll_device)
+                self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+                allr = float(tt.item())
+            return allr, local
+
+        # pass A (not the headline): HIP events around EVERY launch on the library's stream -> the per-kernel table, and which
+        # kernel is the dominant one.  ~200 event records per call cost about 1 ms of a ~100-launch pipeline.
         ctx.profile_reset()
-        ctx.profile(True)   # HIP events around every kernel launch on the library's own stream
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(ccfg)
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        local_elapsed = elapsed
-        if self.dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.coll_device)
-            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        ctx.profile_select(None)
+        ctx.profile(True)
+        all_events, _ = timed(steps)
         ctx.profile(False)
         prof = ctx.profile_table()
         prof_units = ctx.profile_units()
-        # the same K steps once more with the library's per-launch HIP events switched off: what a caller gets
-        self.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(ccfg)
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        plain = time.perf_counter() - t0
-        if self.dist is not None:
-            tt = torch.tensor([plain], dtype=torch.float64, device=self.coll_device)
-            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
-            plain = float(tt.item())
+        dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+        # pass B = THE TIMED REGION: the same K steps with HIP events around the dominant kernel's launches only (on the stream
+        # it is launched on): its live average duration for `roofline`, and a step time that is not inflated by the other events
+        ctx.profile_reset()
+        ctx.profile_select(dom)
+        ctx.profile(True)
+        elapsed, local_elapsed = timed(steps)
+        ctx.profile(False)
+        dom_live = ctx.profile_table().get(dom) if dom else None
+        ctx.profile_select(None)
+        # pass C: no events at all -- what a caller gets
+        plain, _ = timed(steps)
         self.step(ccfg, with_stats=True)  # untimed: counts for the report
         ctx.synchronize()
         s = self.stats
         out = {"cfg": cfg, "elapsed": elapsed, "local_elapsed": local_elapsed, "ms_per_step": elapsed / steps * 1e3,
-               "ms_per_step_unprofiled": plain / steps * 1e3, "prof": prof, "prof_units": prof_units,
+               "ms_per_step_all_events": all_events / steps * 1e3, "ms_per_step_unprofiled": plain / steps * 1e3,
+               "prof": prof, "prof_units": prof_units, "dom": dom, "dom_live": dom_live,
                "counts": {"in": s.n_in, "retained": s.n_retained, "swept": s.n_swept, "chains": s.n_chains,
                           "chains_kept": s.n_chains_kept, "out": s.n_out, "device_ms_last_step": s.device_ms}}
         if keep_results:
@@ -389,11 +399,14 @@ def roofline(pipeline, n, steps, t, wl="100m"):
     prof = t["prof"]
     total_kernel_ms = sum(ms for _, ms in prof.values())
     dom_name, (dom_launches, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, float("nan")))
+    dom_avg_ms_all_events = dom_ms / max(dom_launches, 1)   # (pass A: events around every launch)
+    if t.get("dom_live") and t.get("dom") == dom_name:      # the timed region's own measurement (events around this kernel only)
+        dom_launches, dom_ms = t["dom_live"]
     dom_avg_ms = dom_ms / max(dom_launches, 1)
     per_step = dom_launches / steps
     # units one launch works on: n for the per-record kernels; the sort passes run on sub-problems of different sizes (the
     # library counts the pairs of every pass), so their average launch is charged the average number of pairs
-    units = t.get("prof_units", {}).get(dom_name, 0) / max(dom_launches, 1) or n
+    units = t.get("prof_units", {}).get(dom_name, 0) / max(prof[dom_name][0] if prof else 1, 1) or n
     achieved = algo * units / (dom_avg_ms * 1e-3) / 1e9
     traffic, tnote, total_traffic, tfile = None, None, None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
     try:
@@ -417,7 +430,7 @@ def roofline(pipeline, n, steps, t, wl="100m"):
     return {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": tnote,
             "traffic_unit": f"HBM bytes per launch of that kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {tfile})",
-            "kernel_avg_ms": dom_avg_ms, "kernel_launches_per_step": per_step,
+            "kernel_avg_ms": dom_avg_ms, "kernel_avg_ms_all_events": dom_avg_ms_all_events, "kernel_launches_per_step": per_step,
             "algorithmic_bytes_per_mapping": algo, "units_per_launch": units,
             "kernel_own_achieved": own, "kernel_own_frac": own / HBM_PEAK_GBPS if own else None,
             "pipeline_achieved": pipe_achieved, "pipeline_frac": pipe_achieved / HBM_PEAK_GBPS,
@@ -447,7 +460,8 @@ def sbig1_leg(torch, sw, lib_mod, ctx, device, args):
                        f"{SBIG1_LEN} bp, seed 1234", "steps": steps, "warmup": warm, "pipelines": {}}
     for p in ("sweep", "default", "full"):
         t = run.time(p, steps, warm)
-        out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
+        out["pipelines"][p] = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_all_events": t["ms_per_step_all_events"],
+                               "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
                                "value": n / (t["ms_per_step"] * 1e-3),
                                "unit": "mappings/s", "counts": t["counts"], "roofline": roofline(p, n, steps, t, "sbig1_10m"),
                                "kernels_ms_per_step": kernels_table(t, steps)}
@@ -570,7 +584,7 @@ def _r(x, nd=4):
 def summary_line(out, detail_path):
     """The one stdout line (< 4 KB): contract keys, the headline's roofline and CPU baselines, and ONE scalar per other leg.
     Per-kernel tables, counts, notes and samples are in the detail file (`--detail`, default gpurun_out/bench_detail.json)."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_unprofiled", "higher_is_better",
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_all_events", "ms_per_step_unprofiled", "higher_is_better",
             "scaling", "vs_baseline", "dtype", "data")
     line = {k: _r(out.get(k)) for k in keep}
     cfg = out.get("config") or {}
@@ -632,7 +646,7 @@ def fit_line(line):
     first) until it fits, and the line says so (`truncated`) -- a run never ends without its JSON line."""
     text = json.dumps(line)
     droppable = ("strong", "cpu_baseline_all_cores", "parity", "e2e_cpu_cli_mappings_per_s", "e2e_byte_identical_on_prefix",
-                 "e2e_lines", "e2e_wall_s", "ms_per_step_unprofiled")
+                 "e2e_lines", "e2e_wall_s", "ms_per_step_unprofiled", "ms_per_step_all_events")
     dropped = []
     for k in droppable:
         if len(text) < MAX_LINE_BYTES:
@@ -836,7 +850,8 @@ def main():
             pipes = {}
             for p in order:
                 t = timed[p]
-                e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
+                e = {"flags": FLAGS[p], "ms_per_step": t["ms_per_step"], "ms_per_step_all_events": t["ms_per_step_all_events"],
+                     "ms_per_step_unprofiled": t["ms_per_step_unprofiled"],
                      "value": n * world / (t["ms_per_step"] * 1e-3), "unit": "mappings/s", "steps": args.steps, "warmup": args.warmup, "counts": t["counts"],
                      "roofline": roofline(p, n, args.steps, t, "sbig1_10m" if args.workload == "sbig1" else "100m"),
                      "kernels_ms_per_step": kernels_table(t, args.steps)}
@@ -861,6 +876,7 @@ def main():
                 "steps": args.steps,
                 "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"],
+                "ms_per_step_all_events": head["ms_per_step_all_events"],
                 "ms_per_step_unprofiled": head["ms_per_step_unprofiled"],
                 "higher_is_better": True,
                 "scaling": "weak",

@@ -231,6 +231,11 @@ int swg_log_range(swg_ctx* ctx, uint64_t first, uint64_t stride, uint64_t n, dou
 /* When enabled, every kernel launch of later calls is bracketed by HIP events on the context's
  * stream and its elapsed time accumulated per kernel name.  Costs two event records per launch. */
 int swg_profile_enable(swg_ctx* ctx, int on);
+/* Restricts the bracketing to the launches of ONE kernel (its name as swg_profile_get reports it; NULL or "" = every
+ * launch again): a timed region can then carry HIP events around the kernel it wants the duration of -- two event records
+ * per launch of that kernel -- without the ~200 event records per call that bracketing every launch costs (about 1 ms per
+ * call on a pipeline of ~100 launches). */
+int swg_profile_select(swg_ctx* ctx, const char* kernel_name);
 int swg_profile_reset(swg_ctx* ctx);
 /* Number of distinct kernel names seen since the last reset. */
 int swg_profile_count(swg_ctx* ctx);

@@ -15,7 +15,7 @@ K_INF = 2**64 - 1
 SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "swg_stream", "swg_synchronize",
            "swg_filter", "swg_filter_device", "swg_filter64", "swg_filter_device64", "swg_plane_sweep", "swg_plane_sweep_scaffolds",
            "swg_merge_chains", "swg_union_find_sets", "swg_log", "swg_log_range", "swg_profile_enable",
-           "swg_profile_reset", "swg_profile_count", "swg_profile_get", "swg_profile_units",
+           "swg_profile_reset", "swg_profile_count", "swg_profile_get", "swg_profile_units", "swg_profile_select",
            "swg_paf_open", "swg_paf_open_buffer", "swg_paf_close", "swg_paf_records", "swg_paf_num_lines",
            "swg_paf_ranks", "swg_paf_num_sequences", "swg_paf_sequence_name", "swg_paf_timing", "swg_paf_text",
            "swg_paf_write", "swg_filter_paf", "swg_paf_last_error",
@@ -155,6 +155,8 @@ def load():
     lib.swg_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.swg_profile_reset.restype = C.c_int
     lib.swg_profile_reset.argtypes = [C.c_void_p]
+    lib.swg_profile_select.restype = C.c_int
+    lib.swg_profile_select.argtypes = [C.c_void_p, C.c_char_p]
     lib.swg_profile_count.restype = C.c_int
     lib.swg_profile_count.argtypes = [C.c_void_p]
     lib.swg_profile_units.restype = C.c_int
@@ -263,6 +265,10 @@ class Context:
 
     def profile_reset(self):
         self.check(self.lib.swg_profile_reset(self.handle))
+
+    def profile_select(self, kernel_name=None):
+        """HIP events only around launches of this kernel (None: around every launch again)."""
+        self.check(self.lib.swg_profile_select(self.handle, kernel_name.encode() if kernel_name else None))
 
     def profile_table(self):
         """{kernel name: (launches, total_ms)} accumulated since the last reset."""

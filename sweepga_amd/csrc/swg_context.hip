@@ -117,6 +117,7 @@ int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int c
 
 swg_prof_scope::swg_prof_scope(swg_ctx* c, const char* kernel_name, uint64_t units) : ctx(c) {
   if (!ctx || !ctx->prof_on) return;
+  if (!ctx->prof_only.empty() && ctx->prof_only != kernel_name) return;  // swg_profile_select: events around one kernel only
   for (size_t i = 0; i < ctx->prof_entries.size(); ++i)
     if (ctx->prof_entries[i].name == kernel_name) name = (int)i;
   if (name < 0) {
@@ -169,6 +170,12 @@ int swg_profile_enable(swg_ctx* ctx, int on) {
   if (!ctx) return SWG_ERR_INVALID;
   if (!on) SWG_TRY(swg_prof_collect(ctx));
   ctx->prof_on = on != 0;
+  return SWG_OK;
+}
+int swg_profile_select(swg_ctx* ctx, const char* kernel_name) {
+  if (!ctx) return SWG_ERR_INVALID;
+  SWG_TRY(swg_prof_collect(ctx));
+  ctx->prof_only = kernel_name ? kernel_name : "";
   return SWG_OK;
 }
 int swg_profile_reset(swg_ctx* ctx) {

@@ -32,6 +32,7 @@ struct swg_ctx {
   int num_cu = 256;
   // per-kernel profiler (swg_profile_*)
   bool prof_on = false;
+  std::string prof_only;  // non-empty: only launches with this label are bracketed (swg_profile_select)
   struct prof_pending { int name; hipEvent_t a, b; };
   struct prof_entry { std::string name; uint64_t launches = 0; double ms = 0.0; uint64_t units = 0; };
   std::vector<prof_pending> prof_pending_list;

@@ -58,7 +58,13 @@ def test_stdout_line_is_small_and_complete(line):
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "pipeline_frac"):
         assert k in ln["roofline"], k
     assert ln["cpu_baseline"]["kind"] == "port" and ln["cpu_baseline"]["cores"] == 1
-    assert ln["ms_per_step_unprofiled"] > 0
+    assert ln["ms_per_step_unprofiled"] > 0 and ln["ms_per_step_all_events"] > 0
+    # the timed region carries HIP events around the dominant kernel only: its live duration is in the roofline object, next
+    # to the one measured with events around every launch (pass A, which also produced the kernel table)
+    rf = d["roofline"]
+    assert rf["kernel_avg_ms"] > 0 and rf["kernel_avg_ms_all_events"] > 0
+    assert abs(rf["kernel_avg_ms"] - rf["kernel_avg_ms_all_events"]) / rf["kernel_avg_ms_all_events"] < 0.25
+    assert rf["kernel"] in d["kernels_ms_per_step"]
 
 
 def test_bench_line_contract(line):

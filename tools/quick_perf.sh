@@ -17,7 +17,7 @@ one () {
 import json
 d = json.load(open("$OUT/${wl}_$p.json"))
 ks = d["kernels_ms_per_step"]
-print("$wl $p", round(d["ms_per_step"], 2), round(d["ms_per_step_unprofiled"], 2), "kernels", round(sum(ks.values()), 2))
+print("$wl $p", round(d["ms_per_step"], 2), "all-events", round(d["ms_per_step_all_events"], 2), "no-events", round(d["ms_per_step_unprofiled"], 2), "kernels", round(sum(ks.values()), 2))
 print("   ", ", ".join(f"{k} {v:.2f}" for k, v in list(ks.items())[:24]))
 P
 }
