@@ -79,6 +79,30 @@ __global__ __launch_bounds__(EW) void gatherA_kernel(uint64_t M, const uint64_t*
   pair_flag[a] = (a == 0 || (keyA[a - 1] >> (pos_bits + 1)) != pair) ? 1u : 0u;
 }
 
+// The same from the 32-byte record slots prepare wrote for the mapping sweep (swg_key_ends: both ends, both starts, matches
+// and block length in one sector): one gather per record instead of three, and matches / block length come along for gatherS.
+__global__ __launch_bounds__(EW) void gatherA_slots_kernel(uint64_t M, const uint64_t* __restrict__ keyA,
+                                                           const uint32_t* __restrict__ idxA,
+                                                           const swg_key_ends* __restrict__ slots,
+                                                           const uint8_t* __restrict__ keep1, int pos_bits,
+                                                           uint32_t* __restrict__ a_qe, uint32_t* __restrict__ a_ts,
+                                                           uint32_t* __restrict__ a_te, uint32_t* __restrict__ a_m,
+                                                           uint32_t* __restrict__ a_b, uint8_t* __restrict__ a_keep,
+                                                           uint32_t* __restrict__ pair_flag) {
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint32_t i = idxA[a];
+  const swg_key_ends ke = slots[i];
+  a_qe[a] = ke.end[0];
+  a_ts[a] = ke.start[1];
+  a_te[a] = ke.end[1];
+  a_m[a] = ke.pad[0];
+  a_b[a] = ke.pad[1];
+  a_keep[a] = keep1[i] ? 1 : 0;
+  const uint64_t pair = keyA[a] >> (pos_bits + 1);
+  pair_flag[a] = (a == 0 || (keyA[a - 1] >> (pos_bits + 1)) != pair) ? 1u : 0u;
+}
+
 // dense pair id of every A position: inclusive count of pair heads - 1 (scan result is exclusive)
 __global__ __launch_bounds__(EW) void dense_from_scan_kernel(uint64_t M, const uint32_t* __restrict__ excl,
                                                              const uint32_t* __restrict__ flag,
@@ -115,7 +139,9 @@ __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t*
                                                      const uint32_t* __restrict__ a_ts,
                                                      const uint32_t* __restrict__ a_te,
                                                      const uint32_t* __restrict__ matches,
-                                                     const uint32_t* __restrict__ block_len, int pos_bits,
+                                                     const uint32_t* __restrict__ block_len,
+                                                     const uint32_t* __restrict__ a_m, const uint32_t* __restrict__ a_b,
+                                                     int pos_bits,
                                                      uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
                                                      uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                      uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
@@ -130,8 +156,8 @@ __global__ __launch_bounds__(EW) void gatherS_kernel(uint64_t m, const uint32_t*
   s_qe[p] = a_qe[a];
   s_ts[p] = a_ts[a];
   s_te[p] = a_te[a];
-  s_m[p] = matches[i];
-  s_b[p] = block_len[i];
+  s_m[p] = a_m ? a_m[a] : matches[i];  // a_m / a_b: by A position, from the record slots (gatherA_slots_kernel); else gathered here
+  s_b[p] = a_b ? a_b[a] : block_len[i];
   s_idx[p] = i;
   const uint64_t g = k >> pos_bits;
   s_grp[p] = g;
@@ -1869,7 +1895,8 @@ __global__ __launch_bounds__(EW) void unit_begin_kernel(uint64_t m, const uint32
 }  // namespace
 
 int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order, uint64_t n_alive) {
+                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order, uint64_t n_alive,
+                       const swg_key_ends* slots) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   ChainBuild& B = *out;
@@ -2016,8 +2043,17 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                                                                group_begin));
     SWG_KERNEL_CHECK(ctx);
   } else {
-    SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
-                                                          pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
+    uint32_t *a_m = nullptr, *a_b = nullptr;  // matches / block length by A position (only with the record slots)
+    if (slots) {
+      a_m = swg_alloc<uint32_t>(ctx, M);
+      a_b = swg_alloc<uint32_t>(ctx, M);
+      SWG_CHECK_ARENA(ctx);
+      SWG_LAUNCH(ctx, "gatherA_slots", gatherA_slots_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, slots, member, pos_bits, B.a_qe, B.a_ts, B.a_te,
+                                                                        a_m, a_b, a_keep, pair_flag));
+    } else {
+      SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
+                                                            pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));
+    }
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_exclusive_scan_u32(ctx, pair_flag, pair_excl, M, d_tot + 1));
     SWG_LAUNCH(ctx, "dense_from_scan", dense_from_scan_kernel<<<nblk(M), EW, 0, st>>>(M, pair_excl, pair_flag, B.a_dpair));
@@ -2062,7 +2098,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
                                                                 s_m, s_b, s_grp, head_flag));
     } else {
       SWG_LAUNCH(ctx, "gatherS", gatherS_kernel<<<nblk(m), EW, 0, st>>>(m, B.s_a, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, r->matches,
-                                                            r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                            r->block_len, a_m, a_b, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b,
                                                             B.s_idx, s_grp, head_flag));
     }
     SWG_KERNEL_CHECK(ctx);

@@ -358,6 +358,16 @@ __global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t nc, const uint
   order[g_base[g] + ((uint32_t)c - g_first_chain[g])] = (uint32_t)c;
 }
 
+// What the chain table needs of a chain that passes the filter, written ONCE by whoever decides the filter at the chain's head
+// (chain_label_kernel for the chunks, chain_ok_kernel for the long units) into the head's slot of a sparse array: one 32-byte
+// sector per passing chain.  chain_columns_kernel then reads one sector per chain (round 3: six scattered 4 / 8-byte columns
+// at the head position, 250 bytes of HBM traffic per chain).
+struct __attribute__((aligned(32))) HeadRec {
+  uint32_t qs, qe, ts, te;
+  double wid;
+  uint64_t grp;  // (query * n_seq + target) * 2 + strand
+};
+
 // weighted identity of a chain (paf_filter.rs:896-913) from its aggregates
 __device__ __forceinline__ double chain_weighted_identity(uint64_t total_length, uint64_t sm, uint64_t sb) {
   const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
@@ -374,10 +384,12 @@ __device__ __forceinline__ double chain_weighted_identity(uint64_t total_length,
 // swept.  The number of all chains (a statistic) is counted on the way.
 __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t* __restrict__ is_head,
                                                       const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe,
+                                                      const uint32_t* __restrict__ h_ts, const uint32_t* __restrict__ h_te,
                                                       const unsigned long long* __restrict__ h_sm,
-                                                      const unsigned long long* __restrict__ h_sb, uint64_t min_len,
+                                                      const unsigned long long* __restrict__ h_sb,
+                                                      const uint64_t* __restrict__ s_grp, uint64_t min_len,
                                                       double min_ident, uint8_t* __restrict__ ok_head,
-                                                      double* __restrict__ h_wid, const uint8_t* __restrict__ only,
+                                                      HeadRec* __restrict__ rec, const uint8_t* __restrict__ only,
                                                       const uint8_t* __restrict__ span) {
   const uint64_t n_span = (m + HEAD_SPAN - 1) / HEAD_SPAN;
   for (uint64_t sp = blockIdx.x; sp < n_span; sp += gridDim.x) {
@@ -393,7 +405,16 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
         if (ok) {
           const double wid = chain_weighted_identity(total_length, h_sm[p], h_sb[p]);
           ok = wid >= min_ident;
-          if (ok) h_wid[p] = wid;
+          if (ok) {
+            HeadRec hr;
+            hr.qs = s_qs[p];
+            hr.qe = h_qe[p];
+            hr.ts = h_ts[p];
+            hr.te = h_te[p];
+            hr.wid = wid;
+            hr.grp = s_grp[p];
+            rec[p] = hr;
+          }
         }
       }
       ok_head[p] = ok ? 1 : 0;
@@ -412,10 +433,10 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
                                                          const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
                                                          const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te,
                                                          const uint32_t* __restrict__ s_m, const uint32_t* __restrict__ s_b,
+                                                         const uint64_t* __restrict__ s_grp,
                                                          uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
-                                                         uint8_t* __restrict__ ok_head, uint32_t* __restrict__ h_qe,
-                                                         uint32_t* __restrict__ h_ts, uint32_t* __restrict__ h_te,
-                                                         double* __restrict__ h_wid, unsigned long long* __restrict__ n_heads) {
+                                                         uint8_t* __restrict__ ok_head, HeadRec* __restrict__ rec,
+                                                         unsigned long long* __restrict__ n_heads) {
   __shared__ uint16_t succ[LABEL_CAP];
   constexpr uint16_t NO = 0xffffu;
   uint32_t heads = 0;  // chains headed in this thread's elements (a statistic: all chains, passing the filter or not)
@@ -453,16 +474,21 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
         sb += bb;
         nx = nn;
       }
-      const uint64_t total_length = (uint64_t)qe - (uint64_t)s_qs[p];  // q_max - q_min (the head has the smallest q_start)
+      const uint32_t qs0 = s_qs[p];
+      const uint64_t total_length = (uint64_t)qe - (uint64_t)qs0;  // q_max - q_min (the head has the smallest q_start)
       bool ok = total_length >= min_len;
       if (ok) {
         const double wid = chain_weighted_identity(total_length, sm, sb);
         ok = wid >= min_ident;
         if (ok) {
-          h_qe[p] = qe;
-          h_ts[p] = ts;
-          h_te[p] = te;
-          h_wid[p] = wid;
+          HeadRec hr;
+          hr.qs = qs0;
+          hr.qe = qe;
+          hr.ts = ts;
+          hr.te = te;
+          hr.wid = wid;
+          hr.grp = s_grp[p];
+          rec[p] = hr;
         }
       }
       ok_head[p] = ok ? 1 : 0;
@@ -474,9 +500,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
 }
 // chain columns in all_chains order.  weighted identity: paf_filter.rs:896-913
 __global__ __launch_bounds__(EW) void chain_columns_kernel(
-    uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head,
-    const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ h_qe, const uint32_t* __restrict__ h_ts,
-    const uint32_t* __restrict__ h_te, const double* __restrict__ h_wid, const uint64_t* __restrict__ s_grp,
+    uint64_t nc, const uint32_t* __restrict__ order, const uint32_t* __restrict__ ch_head, const HeadRec* __restrict__ rec,
     const uint32_t* __restrict__ s_a,
     const uint32_t* __restrict__ a_dpair, uint32_t n_seq,
     uint32_t* __restrict__ C_qid, uint32_t* __restrict__ C_tid, uint32_t* __restrict__ C_qs,
@@ -489,9 +513,10 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
   rank_of_poschain[c] = (uint32_t)c2;
   const uint32_t p = ch_head[c];
   head_of_chain[c2] = p;
-  const uint64_t g = s_grp[p];
+  const HeadRec hr = rec[p];
+  const uint64_t g = hr.grp;
   const uint64_t pair = g >> 1;
-  const uint32_t qs = s_qs[p], qe = h_qe[p], ts = h_ts[p], te = h_te[p];
+  const uint32_t qs = hr.qs, qe = hr.qe, ts = hr.ts, te = hr.te;
   C_qid[c2] = (uint32_t)(pair / n_seq);
   C_tid[c2] = (uint32_t)(pair % n_seq);
   C_strand[c2] = (uint8_t)(g & 1);
@@ -500,7 +525,7 @@ __global__ __launch_bounds__(EW) void chain_columns_kernel(
   C_ts[c2] = ts;
   C_te[c2] = te;
   C_dpair[c2] = a_dpair[s_a ? s_a[p] : p];  // s_a == nullptr: every record of sort A is a member
-  C_wid[c2] = h_wid[p];
+  C_wid[c2] = hr.wid;
 }
 
 // index into T of every member's chain (NONE: its chain fails the span / identity filter); only the merge_chains seam asks
@@ -567,7 +592,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   PairTable gp_first;  // made where it is filled (below); its pairs are among the B.n_pairs (query, target, strand) groups
   uint32_t* changed = swg_alloc<uint32_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
-  double* h_wid = swg_alloc<double>(ctx, m);
+  HeadRec* head_rec = swg_alloc<HeadRec>(ctx, m);  // sparse: touched at the heads of passing chains only
   uint8_t* ok_head = swg_alloc<uint8_t>(ctx, m);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, st));
@@ -579,8 +604,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   if (W.n_chunks) {
     const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
     SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
-                                                                        s_m, s_b, min_len, min_ident, hd, ok_head, h_qe, h_ts,
-                                                                        h_te, h_wid, n_heads));
+                                                                        s_m, s_b, s_grp, min_len, min_ident, hd, ok_head, head_rec, n_heads));
     SWG_KERNEL_CHECK(ctx);
     only = W.big_member;
     span = W.span_big;
@@ -611,7 +635,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
     SWG_KERNEL_CHECK(ctx);
     // span / identity filter at the heads; from here on "chain" means a chain that passes it
     SWG_LAUNCH(ctx, "chain_ok", chain_ok_kernel<<<span_grid, EW, 0, st>>>(
-                                    m, is_head, s_qs, h_qe, h_sm, h_sb, min_len, min_ident, ok_head, h_wid, only, span));
+                                    m, is_head, s_qs, h_qe, h_ts, h_te, h_sm, h_sb, s_grp, min_len, min_ident, ok_head, head_rec, only, span));
     SWG_KERNEL_CHECK(ctx);
   }
   // the passing heads, in position order: byte flags -> per-tile counts (-> the list, below)
@@ -696,7 +720,7 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   SWG_LAUNCH(ctx, "chain_place", chain_place_kernel<<<nblk(nc), EW, 0, st>>>(nc, ch_head, s_gidx, g_first_chain, g_base, order));
   SWG_KERNEL_CHECK(ctx);
   SWG_LAUNCH(ctx, "chain_columns", chain_columns_kernel<<<nblk(nc), EW, 0, st>>>(
-                                       nc, order, ch_head, s_qs, h_qe, h_ts, h_te, h_wid, s_grp, B.s_a, B.a_dpair,
+                                       nc, order, ch_head, head_rec, B.s_a, B.a_dpair,
                                        r->n_seq, T.qid, T.tid, T.qs, T.qe, T.ts, T.te, T.wid, B.C_strand, B.C_dpair, rank_of, head_of_chain));
   SWG_KERNEL_CHECK(ctx);
   B.m_head_of_chain = head_of_chain;

@@ -248,7 +248,8 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1]);
+  return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1],
+                            key_ends);  // (nullptr when nothing sweeps: the all-members gather reads the columns)
 }
 
 static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {

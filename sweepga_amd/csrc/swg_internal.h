@@ -264,7 +264,7 @@ struct __attribute__((aligned(32))) swg_key_ends {
   uint64_t key;
   uint32_t start[2];  // [0] query start, [1] target start
   uint32_t end[2];    // [0] query end, [1] target end
-  uint32_t pad[2];
+  uint32_t pad[2];    // with a scaffold stage: [0] matches, [1] block length (else 0)
 };
 
 struct swg_axis_input {

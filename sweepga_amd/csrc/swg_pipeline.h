@@ -25,4 +25,5 @@ int swg_filter_reserve_arena(swg_ctx* ctx, uint64_t n, const swg_records* rec, c
 // axis' order of the mapping sweep): sort A then only needs its passes over the group bits.
 int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                        const uint8_t* keep1, int pos_bits, uint8_t* status_out,
-                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order = nullptr, uint64_t n_alive = ~0ull);
+                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order = nullptr, uint64_t n_alive = ~0ull,
+                       const swg_key_ends* slots = nullptr);

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(EW) void count_status_kernel(uint64_t n, const uint
 
 int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                        const uint8_t* keep1, int pos_bits, uint8_t* status_out,
-                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order, uint64_t n_alive) {
+                       uint32_t* chain_out, swg_stats* stats, const uint32_t* q_order, uint64_t n_alive,
+                       const swg_key_ends* slots) {
   const uint64_t n = r->n;
   hipStream_t st = ctx->stream;
   // chain_out doubles as the anchors' chain-number column (zero = not an anchor); status_out is written in full by
@@ -415,7 +416,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
   ChainBuild B;
   B.want_s_chain = false;  // member_marks derives a member's chain from the labelling arrays
   SWG_TRY(build_chains(ctx, r, alive, keep1, cfg->scaffold_gap, cfg->min_scaffold_length, cfg->min_scaffold_identity,
-                       pos_bits, true, &B, q_order, n_alive));
+                       pos_bits, true, &B, q_order, n_alive, slots));
   if (stats) {
     stats->n_swept = B.m;
     stats->n_chains = B.n_chains_all;

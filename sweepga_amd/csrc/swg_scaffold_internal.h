@@ -135,15 +135,17 @@ struct ChainWork {
 //   chain_predecessors  : sort A over the alive records, members compacted in A order, best-buddy selection -> pred
 //   chain_table_build   : chains = paths of pred; heads, aggregates, all_chains order, span / identity filter -> B.T, B.s_chain
 // n_alive: number of set `alive` flags when the caller knows it (prepare counts them), ~0 otherwise.
+// slots: the 32-byte record slots prepare wrote (matches / block length in their spare words), or nullptr.
 int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
-                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order, uint64_t n_alive);
+                       int pos_bits, ChainBuild* out, ChainWork* work, const uint32_t* q_order, uint64_t n_alive,
+                       const swg_key_ends* slots);
 int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, uint64_t min_len, double min_ident,
                       bool genome_pair_major, ChainBuild* out, const ChainWork& work);
 inline int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, const uint8_t* member, uint64_t max_gap,
                         uint64_t min_len, double min_ident, int pos_bits, bool genome_pair_major, ChainBuild* out,
-                        const uint32_t* q_order = nullptr, uint64_t n_alive = ~0ull) {
+                        const uint32_t* q_order = nullptr, uint64_t n_alive = ~0ull, const swg_key_ends* slots = nullptr) {
   ChainWork W;
-  SWG_TRY(chain_predecessors(ctx, r, alive, member, max_gap, pos_bits, out, &W, q_order, n_alive));
+  SWG_TRY(chain_predecessors(ctx, r, alive, member, max_gap, pos_bits, out, &W, q_order, n_alive, slots));
   if (out->M == 0 || out->m == 0) return SWG_OK;
   return chain_table_build(ctx, r, alive, min_len, min_ident, genome_pair_major, out, W);
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              const uint32_t* __restrict__ ts, const uint32_t* __restrict__ te,
                                                              uint64_t min_block, int keep_self, double min_identity,
                                                              int scoring, uint8_t* __restrict__ alive,
-                                                             swg_key_ends* __restrict__ key_ends,
+                                                             swg_key_ends* __restrict__ key_ends, int slot_payload,
                                                              unsigned long long* __restrict__ scalars) {
   uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
@@ -121,7 +121,10 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
       ke.start[1] = c;
       ke.end[0] = b;
       ke.end[1] = d;
-      ke.pad[0] = ke.pad[1] = 0;
+      // the slot's spare 8 bytes: matches and block length when a scaffold stage follows -- its gathers after sort A then take
+      // everything they need of a record from this one sector
+      ke.pad[0] = slot_payload ? matches[i] : 0u;
+      ke.pad[1] = slot_payload ? block_len[i] : 0u;
       key_ends[i] = ke;
     }
     const uint32_t m1 = a > b ? a : b, m2 = c > d ? c : d;
@@ -1334,7 +1337,7 @@ int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
                                  r->n, r->q_id, r->t_id, r->block_len, r->matches, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
                                  cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
-                                 scalars));
+                                 cfg->scaffold_gap != 0 ? 1 : 0, scalars));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }

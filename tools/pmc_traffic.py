@@ -57,8 +57,8 @@ def collect(d, counter):
 
 def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    # filter calls inside one profiled bench.py run (--steps 1 --warmup 0: timed + un-profiled + statistics = 3)
-    calls = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    # filter calls inside one profiled bench.py run (--steps 1 --warmup 0: all-events pass + timed region + no-events pass + statistics = 4)
+    calls = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
     total = 0.0

@@ -22,7 +22,7 @@ run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = 
     find $OUT/stats_${p}_$SUF -name "*kernel_trace.csv" -delete
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_fetch_${p}_$SUF.log 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_write_${p}_$SUF.log 2>&1
-    python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM 3 > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
+    python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM 4 > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
     find $OUT -name "*kernel_trace.csv" -delete
   done
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1_$SUF -- python3 $R/bench.py --workload $WL --pipeline sweep --steps 1 --warmup 0 $COMMON > $OUT/sq1_$SUF.log 2>&1
