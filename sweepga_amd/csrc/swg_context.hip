@@ -108,6 +108,7 @@ int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64
 
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count) {
   if (count > 64) return swg_set_error(ctx, SWG_ERR_INVALID, "swg_read_scalars: count > 64");
+  ++ctx->n_readbacks;
   SWG_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, d_src, sizeof(uint64_t) * count, hipMemcpyDeviceToHost,
                               ctx->stream));
   SWG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -339,6 +339,7 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   SWG_TRY(swg_filter_reserve_arena(ctx, rec->n, rec, cfg, rec64 != nullptr));
+  const uint64_t readbacks0 = ctx->n_readbacks;
   SWG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc = swg_run_with_arena(ctx, [&]() -> int {
     if (!rec64 || rec->n == 0) return filter_device_body(ctx, rec, cfg, status_out, chain_out, stats);
@@ -380,6 +381,11 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
   });
   if (rc != SWG_OK) return rc;
   SWG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  {
+    static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[swg] filter call over %llu records: %llu scalar read-backs (stream synchronisations)\n",
+                     (unsigned long long)rec->n, (unsigned long long)(ctx->n_readbacks - readbacks0));
+  }
   if (stats) {
     SWG_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

@@ -30,6 +30,7 @@ struct swg_ctx {
   uint64_t* h_scalars = nullptr;  // 64 x u64
   std::string err;
   int num_cu = 256;
+  uint64_t n_readbacks = 0;  // swg_read_scalars calls (each one a stream synchronisation), for SWG_DEBUG
   // per-kernel profiler (swg_profile_*)
   bool prof_on = false;
   std::string prof_only;  // non-empty: only launches with this label are bracketed (swg_profile_select)

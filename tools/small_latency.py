@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import sweepga_amd as sw
 from sweepga_amd import PafFile
-ctx = sw.default_context()
+ctx = sw.default_context()   # run with SWG_DEBUG=1 to have the library print its read-backs per call
 with PafFile(os.path.join(ROOT, "tests", "golden", "syeast.paf.gz")) as pf:
     from sweepga_amd.filter import PackedRecords
     cols = {k: np.ascontiguousarray(pf.column(k)) for k in ("q_id","t_id","q_start","q_end","t_start","t_end","identity","matches","block_len","strand")}
@@ -22,4 +22,8 @@ with PafFile(os.path.join(ROOT, "tests", "golden", "syeast.paf.gz")) as pf:
         t=[]; d=[]
         for _ in range(20):
             t0=time.perf_counter(); f.filter_columns(packed); t.append((time.perf_counter()-t0)*1e3); d.append(f.last_stats.device_ms)
-        print(name, "n", pf.n, "wall ms median", round(float(np.median(t)),3), "device ms median", round(float(np.median(d)),3))
+        ctx.profile_reset(); ctx.profile(True); f.filter_columns(packed); ctx.profile(False)
+        launches = sum(v[0] for v in ctx.profile_table().values())
+        print(name, "n", pf.n, "wall ms median", round(float(np.median(t)),3), "device ms median", round(float(np.median(d)),3),
+              "kernel launches", launches, flush=True)
+        os.environ["SWG_DEBUG"] = "1"   # (read once per process by the library: set before the first call to see the read-back count)
