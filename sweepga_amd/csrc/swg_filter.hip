@@ -593,7 +593,7 @@ extern "C" int swg_warmup(swg_ctx* ctx, uint64_t n_records_hint, uint32_t n_seq_
     // scratch: an input of millions of records grouped by query genome (what aligners write) is filtered in eight ranges
     // (csrc/swg_stream.hip) and needs scratch for one of them -- 25 GB of hipMalloc for 10^8 records took up to 1.3 s on the GPU
     // box; an input that turns out not to be grouped grows the arena inside its call instead
-    const uint64_t scratch_records = n_records_hint >= (uint64_t(4) << 20) ? std::max<uint64_t>(n_records_hint / 6, uint64_t(1) << 21) : n_records_hint;
+    const uint64_t scratch_records = n_records_hint >= (uint64_t(12) << 20) ? std::max<uint64_t>(n_records_hint / 6, uint64_t(6) << 20) : n_records_hint;
     size_t want = (size_t)scratch_records * (with_scaffold ? SWG_ARENA_B_SCAFFOLD : SWG_ARENA_B_SWEEP) + (size_t(8) << 20);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want + io_block_bytes(n_records_hint, n_seq_hint) > free_b / 2)

@@ -237,11 +237,15 @@ int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const 
   const uint64_t n = r->n;
   uint64_t target = chunk_knob ? strtoull(chunk_knob, nullptr, 10) : 0;
   if (!target) {
-    if (n < (uint64_t(4) << 20)) return SWG_OK;  // a few ms of PCIe: nothing to hide the kernels behind
-    // eight ranges per device: a range costs ~2.5 ms of launches and read-backs on top of its share of the kernels (measured:
-    // 16 ranges of 6.25 M records took 67 ms of device time against 23 ms in one piece, and the call became compute-bound),
-    // and the last range's filter + download is what the upload cannot hide
-    target = std::max<uint64_t>(n / (uint64_t)(8 * n_ctx), uint64_t(1) << 21);
+    // A range costs ~2.5 ms of launches and read-backs on top of its share of the kernels (~0.2 ms per 10^6 records) and its
+    // upload takes ~0.75 ms per 10^6 records: only ranges of more than ~5 M records are filtered faster than the next one
+    // arrives (measured: 10^7 records in five ranges of 2 M took 62 ms against 45-55 ms in one piece; 10^8 in 16 ranges of
+    // 6.25 M took 67 ms of device time and the call became compute-bound; in 8 ranges it is copy-bound, 85 against 102 ms).
+    // So: at least 6 M records per range, eight ranges per device when there are enough records, and no streaming at all
+    // below two such ranges per device.
+    constexpr uint64_t MIN_RANGE = 6u << 20;
+    if (n < 2 * MIN_RANGE * (uint64_t)n_ctx) return SWG_OK;
+    target = std::max<uint64_t>(n / (uint64_t)(8 * n_ctx), MIN_RANGE);
   }
   if (!r->seq_genome_last || !r->seq_genome_two || !swg_streamed::same_partition(r)) return SWG_OK;
   std::vector<swg_streamed::Chunk> chunks;
