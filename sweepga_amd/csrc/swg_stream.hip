@@ -243,9 +243,16 @@ int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const 
     // 6.25 M took 67 ms of device time and the call became compute-bound; in 8 ranges it is copy-bound, 85 against 102 ms).
     // So: at least 6 M records per range, eight ranges per device when there are enough records, and no streaming at all
     // below two such ranges per device.
+    // Several devices: the ranges also replace the host-side scatter and merge of the record set (0.4 s per 10^8 records,
+    // csrc/host/shard_host.h), which is worth a few ranges' overhead at any size from a million records per device up.
     constexpr uint64_t MIN_RANGE = 6u << 20;
-    if (n < 2 * MIN_RANGE * (uint64_t)n_ctx) return SWG_OK;
-    target = std::max<uint64_t>(n / (uint64_t)(8 * n_ctx), MIN_RANGE);
+    if (n_ctx == 1) {
+      if (n < 2 * MIN_RANGE) return SWG_OK;
+      target = std::max<uint64_t>(n / 8, MIN_RANGE);
+    } else {
+      if (n < (uint64_t(1) << 20) * (uint64_t)n_ctx) return SWG_OK;
+      target = std::max<uint64_t>(n / (uint64_t)(8 * n_ctx), uint64_t(1) << 20);
+    }
   }
   if (!r->seq_genome_last || !r->seq_genome_two || !swg_streamed::same_partition(r)) return SWG_OK;
   std::vector<swg_streamed::Chunk> chunks;
