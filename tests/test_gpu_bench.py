@@ -158,6 +158,10 @@ def test_two_rank_launch_rehearsal():
     w = run_bench("--gpus", "2", "--rehearse", "--only", *common)
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["_line"]["n_gpus"] == 2
     assert abs(w["value"] - 2 * n / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
+    # ... and the host-buffer leg runs on every rank at once, reported as the slowest rank's time over all ranks' records
+    pc = w["pcie_inclusive"]["default"]
+    assert pc["ranks"] == 2 and pc["ms"] > 0 and abs(pc["value"] - 2 * n / (pc["ms"] * 1e-3)) / pc["value"] < 1e-6
+    assert w["_line"]["pcie_default_ms"] == pytest.approx(pc["ms"], abs=0.01)
 
 
 def test_smoke_entry():

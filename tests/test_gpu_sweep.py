@@ -225,3 +225,32 @@ def test_mapping_filter_no_scaffold(sw, seed):
                                                              nbad=int(bad.size), first=bad[:20].tolist()))
                 assert bad.size == 0, (int(mode), mq, mt, thr, keep_self, bad.size)
                 assert np.array_equal(chain, och)
+
+
+def test_reversed_interval_does_not_depend_on_unrelated_records():
+    """Reversed intervals (start > end) are malformed PAF and not modelled -- but what the filter answers
+    for such a record must not depend on records that have nothing to do with it.  Round 3's shortcut for the unlimited sweep
+    counted only exactly-zero-length records as degenerate, the per-axis path every start >= end: whether a reversed record was
+    kept then depended on whether some OTHER record of the input happened to have zero length."""
+    import sweepga_amd as sw
+    from tests import gen
+    rng = np.random.default_rng(91)
+    rec = gen.random_records(rng, 3_000, n_genomes=3, chrs_per_genome=2, span=300_000, zero_frac=0.0)
+    k = 1234
+    rec.qs[k], rec.qe[k] = rec.qe[k] + 10, rec.qs[k]   # reversed on the query axis
+    cfg = sw.FilterConfig(scaffold_gap=0)              # many:many, no scaffolding: the unlimited sweep decides
+    f = sw.PafFilter(cfg)
+    base, _ = f.filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+    base = base.copy()
+    # the same records plus one zero-length record in a genome pair of its own
+    import copy
+    rec2 = copy.copy(rec)
+    rec2.qname = rec.qname + ["zz#1#chr1"]
+    rec2.tname = rec.tname + ["yy#1#chr1"]
+    for name, val in (("qs", 500), ("qe", 500), ("ts", 700), ("te", 900), ("block_length", 200), ("matches", 180)):
+        setattr(rec2, name, np.append(getattr(rec, name), np.uint64(val)))
+    rec2.identity = np.append(rec.identity, 0.9)
+    rec2.strand = np.append(rec.strand, np.uint8(ord("+")))
+    rec2.rank = np.arange(len(rec2.qname), dtype=np.uint64)
+    more, _ = f.filter_columns(sw.pack_records(gen.records_to_meta(rec2)))
+    assert np.array_equal(more[:len(base)], base)
