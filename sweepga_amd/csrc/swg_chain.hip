@@ -36,7 +36,9 @@ __global__ __launch_bounds__(EW) void sortA_keys_hist_kernel(uint64_t M, const u
                                                              const uint8_t* __restrict__ strand,
                                                              const uint32_t* __restrict__ q_start, uint32_t n_seq,
                                                              int pos_bits, uint64_t* __restrict__ key, swg_radix_plan plan,
-                                                             uint32_t* __restrict__ ghist) {
+                                                             uint32_t* __restrict__ ghist, int drop = 0, int idx_bits = 0) {
+  // drop > 0: sort on the truncated key -- key[a] becomes the WORD ((key >> drop) << idx_bits) | record index
+  // (swg_radix_sort_words; gather_all_words_kernel orders the runs of equal truncated keys), histograms of key >> drop
   __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
   const int npasses = plan.npasses;
   swg_radix_hist_zero(h, npasses);
@@ -49,8 +51,13 @@ __global__ __launch_bounds__(EW) void sortA_keys_hist_kernel(uint64_t M, const u
       const uint32_t i = a_idx ? a_idx[a] : (uint32_t)a;
       const uint64_t g = ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
       k = (g << pos_bits) | q_start[i];
-      key[a] = k;
-      if (idx_out) idx_out[a] = i;
+      if (drop) {
+        k >>= drop;
+        key[a] = (k << idx_bits) | i;
+      } else {
+        key[a] = k;
+        if (idx_out) idx_out[a] = i;
+      }
     }
     swg_radix_hist_add(h, k, in, plan);
   }
@@ -262,6 +269,106 @@ __global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const
   }
   block_boundary_count(pf, gf, blk_cnt + lb);
 }
+// The same after a sort on the TRUNCATED key (swg_radix_sort_words): P[a] = ((key >> drop) << idx_bits) | record index, in
+// (key >> drop, index) order.  Records whose q_start differ only in the low `drop` bits form short runs; each member counts,
+// in LDS (the work-group's 256 words + SWG_RUN_HALO on either side, the halo's low bits gathered only for a run that crosses
+// the block's edge), the members that order before it by (low bits, index) and writes its columns at run start + that rank
+// (begin_gather_words_kernel in swg_sweep.hip is the same idea).  The boundary counts are taken at the positions BEFORE the
+// reordering: a pair / group begins where a run begins, and a run's first position does not move.  A run that reaches beyond
+// the halo raises *long_run (the caller sorts again on the whole key).
+__global__ __launch_bounds__(EW) void gather_all_words_kernel(uint64_t M, const uint64_t* __restrict__ P, int idx_bits, int drop,
+                                                              const uint32_t* __restrict__ q_start,
+                                                              const uint32_t* __restrict__ q_end,
+                                                              const uint32_t* __restrict__ t_start,
+                                                              const uint32_t* __restrict__ t_end,
+                                                              const uint32_t* __restrict__ matches,
+                                                              const uint32_t* __restrict__ block_len, int pos_bits,
+                                                              uint64_t* __restrict__ keyA, uint32_t* __restrict__ idxA,
+                                                              uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
+                                                              uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
+                                                              uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
+                                                              uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt,
+                                                              unsigned long long* __restrict__ long_run) {
+  constexpr int H = SWG_RUN_HALO, W = EW + 2 * H;
+  __shared__ uint64_t l_hi[W];   // key >> drop, + 1 (0: no element at this position)
+  __shared__ uint64_t l_ord[W];  // (low bits of q_start << 32) | record index
+  const uint32_t lb = swg_xcd_block(blockIdx.x, gridDim.x);
+  const uint64_t p0 = (uint64_t)lb * EW;
+  const int t = threadIdx.x;
+  const uint64_t idx_mask = (uint64_t(1) << idx_bits) - 1;
+  const uint32_t low_mask = (1u << drop) - 1u;
+  const uint64_t a = p0 + t;
+  uint64_t hi = 0;
+  uint32_t i = 0, qs = 0, qe = 0, ts = 0, te = 0, mt = 0, bl = 0;
+  if (a < M) {
+    const uint64_t w = P[a];
+    hi = (w >> idx_bits) + 1;  // (+1: a key of 0 is a real key here -- sequence 0 onto itself at coordinate < 2^drop)
+    i = (uint32_t)(w & idx_mask);
+    qs = q_start[i];
+    qe = q_end[i];
+    ts = t_start[i];
+    te = t_end[i];
+    mt = matches[i];
+    bl = block_len[i];
+  }
+  l_hi[H + t] = hi;
+  l_ord[H + t] = ((uint64_t)(qs & low_mask) << 32) | i;
+  if (t < 2 * H) {
+    const bool left = t < H;
+    const int64_t q = left ? (int64_t)p0 - H + t : (int64_t)p0 + EW + (t - H);
+    const int li = left ? t : EW + t;
+    const bool there = q >= 0 && (uint64_t)q < M;
+    l_hi[li] = there ? (P[q] >> idx_bits) + 1 : 0ull;
+    l_ord[li] = there ? (P[q] & idx_mask) : 0ull;  // (index only so far)
+  }
+  __syncthreads();
+  if (t < 2 * H) {
+    const bool left = t < H;
+    const int li = left ? t : EW + t;
+    const uint64_t edge = left ? l_hi[H] : l_hi[H + EW - 1];
+    if (edge != 0 && l_hi[li] == edge) {
+      const uint32_t hid = (uint32_t)l_ord[li];
+      l_ord[li] = ((uint64_t)(q_start[hid] & low_mask) << 32) | hid;
+    }
+  }
+  __syncthreads();
+  bool pf = false, gf = false;
+  if (a < M) {
+    const uint64_t mine = l_ord[H + t];
+    uint32_t before = 0, rank = 0;
+    int j = H + t - 1;
+    for (; j >= 0 && l_hi[j] == hi; --j) {
+      ++before;
+      rank += l_ord[j] < mine ? 1u : 0u;
+    }
+    bool too_long = j < 0 && p0 > (uint64_t)H;  // ran off the left halo with elements still before it
+    int j2 = H + t + 1;
+    for (; j2 < W && l_hi[j2] == hi; ++j2) rank += l_ord[j2] < mine ? 1u : 0u;
+    if (j2 >= W && p0 + EW + H < M) too_long = true;
+    uint64_t np = a;
+    if (too_long)
+      *long_run = 1ull;
+    else
+      np = a - before + rank;
+    const uint64_t kt = hi - 1;  // key >> drop
+    keyA[np] = (kt << drop) | (uint64_t)(qs & low_mask);
+    idxA[np] = i;
+    s_qs[np] = qs;
+    s_qe[np] = qe;
+    s_ts[np] = ts;
+    s_te[np] = te;
+    s_m[np] = mt;
+    s_b[np] = bl;
+    const uint64_t g = kt >> (pos_bits - drop);
+    s_grp[np] = g;
+    const uint64_t hp = l_hi[H + t - 1];  // the element before, at its position before the reordering (0: none)
+    const uint64_t gp = (a && hp) ? (hp - 1) >> (pos_bits - drop) : ~0ull;
+    pf = (gp >> 1) != (g >> 1);
+    gf = gp != g;
+  }
+  block_boundary_count(pf, gf, blk_cnt + lb);
+}
+
 // after the inclusive sum scan of the blocks' counts: dense pair and group ids, group begins.  The flags are recomputed from
 // the sorted keys; a block's 256 prefix counts come from two ballots per wavefront and the wavefronts' totals in LDS.
 __global__ __launch_bounds__(EW) void group_pair_kernel(uint64_t M, const uint64_t* __restrict__ keyA, int pos_bits,
@@ -1933,6 +2040,31 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   SWG_CHECK_ARENA(ctx);
   uint64_t* packedA = nullptr;  // sort A's result as packed words (then B.keyA / B.idxA are written by the gather)
   int packed_idx_bits = 0;
+  int dropA = 0;                // low key bits left out of sort A (swg_radix_sort_words; the gather orders the runs)
+  // keys + histograms + the packed / word sort of the all-members case; drop = 0: the packed sort over the whole key
+  uint32_t* prehistA = nullptr;
+  auto sortA_packed = [&](int drop, int key_bits, int idx_bits) -> int {
+    const bool identity = M == n;
+    const unsigned full = nblk(M), cap = (unsigned)ctx->num_cu * 16;
+    SWG_HIP(ctx, hipMemsetAsync(prehistA, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
+    SWG_LAUNCH(ctx, "sortA_keys_hist", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
+                                      M, identity ? nullptr : B.idxA, nullptr, r->q_id, r->t_id, r->strand, r->q_start, r->n_seq, pos_bits,
+                                      keyA0, drop ? swg_radix_plan_words(key_bits - drop) : swg_radix_plan_packed(key_bits), prehistA, drop,
+                                      idx_bits));
+    SWG_KERNEL_CHECK(ctx);
+    int prc;
+    if (drop)
+      prc = swg_radix_sort_words(ctx, keyA0, key_tmp, M, key_bits - drop, idx_bits, prehistA, &packedA);
+    else
+      prc = swg_radix_sort_packed(ctx, keyA0, identity ? nullptr : B.idxA, key_tmp, M, key_bits, idx_bits, prehistA, &packedA);
+    if (prc == SWG_ERR_UNSUPPORTED) return swg_set_error(ctx, SWG_ERR_HIP, "packed sort declined a shape it accepted");
+    if (prc != SWG_OK) return prc;
+    packed_idx_bits = idx_bits;
+    dropA = drop;
+    B.keyA = packedA == keyA0 ? key_tmp : keyA0;  // the buffer the words are not in takes the unpacked keys
+    return SWG_OK;
+  };
+  int sortA_key_bits = 0;
   if (q_order) {
     // The mapping sweep sorted the same alive records by (query sequence, target genome, q_start, index): dead records
     // first, so the last M entries are the alive ones, and inside every (query, target, strand) group they already stand
@@ -1958,21 +2090,16 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
       const bool packed_sort = all_members && pos_bits >= 8 && swg_radix_sort_packed_applies(M, key_bits, idx_bits);
       const bool identity = M == n;
-      SWG_LAUNCH(ctx, "sortA_keys_hist", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
-                                        M, identity ? nullptr : B.idxA, identity && !packed_sort ? B.idxA : nullptr, r->q_id, r->t_id,
-                                        r->strand, r->q_start, r->n_seq, pos_bits, B.keyA,
-                                        packed_sort ? swg_radix_plan_packed(key_bits) : swg_radix_plan_pairs(0, key_bits), prehist));
-      SWG_KERNEL_CHECK(ctx);
-      int prc = SWG_ERR_UNSUPPORTED;
-      if (packed_sort)
-        prc = swg_radix_sort_packed(ctx, B.keyA, identity ? nullptr : B.idxA, key_tmp, M, key_bits, idx_bits, prehist, &packedA);
-      if (packed_sort && prc == SWG_ERR_UNSUPPORTED) return swg_set_error(ctx, SWG_ERR_HIP, "packed sort declined a shape it accepted");
-      if (prc == SWG_OK) {
-        packed_idx_bits = idx_bits;
-      } else if (prc != SWG_ERR_UNSUPPORTED) {
-        return prc;
+      if (packed_sort) {
+        // a pass fewer when the low bits of q_start can be left to the gather (as in the sweep, swg_sweep.hip)
+        prehistA = prehist;
+        sortA_key_bits = key_bits;
+        SWG_TRY(sortA_packed(swg_radix_drop_bits(M, key_bits, pos_bits, idx_bits, ctx->sort_drop_level), key_bits, idx_bits));
       } else {
-        packedA = nullptr;
+        SWG_LAUNCH(ctx, "sortA_keys_hist", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
+                                          M, identity ? nullptr : B.idxA, identity ? B.idxA : nullptr, r->q_id, r->t_id, r->strand,
+                                          r->q_start, r->n_seq, pos_bits, B.keyA, swg_radix_plan_pairs(0, key_bits), prehist));
+        SWG_KERNEL_CHECK(ctx);
         SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits, prehist));
       }
     } else {
@@ -1986,11 +2113,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits));
     }
   }
-  if (packedA) {
-    B.keyA = packedA == keyA0 ? key_tmp : keyA0;  // the buffer the words are not in takes the unpacked keys (no release then)
-  } else if (B.keyA == keyA0) {
-    swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA)
-  }
+  if (!packedA && B.keyA == keyA0) swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA; with packed words: no release)
   uint64_t m = 0, n_groups = 0;
   uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
   uint64_t* s_grp = nullptr;
@@ -2017,20 +2140,40 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     bps = swg_alloc<unsigned long long>(ctx, m);
     pred = swg_alloc<uint32_t>(ctx, m);
     const uint64_t n_blk = nblk(M);
-    uint64_t* blk_cnt = swg_alloc<uint64_t>(ctx, n_blk);  // per 256-element block: (pair boundaries << 32) | group boundaries
+    // per 256-element block: (pair boundaries << 32) | group boundaries; one more word behind them: the words gather's
+    // "a run was too long" flag, read back together with the scan's total
+    uint64_t* blk_cnt = swg_alloc<uint64_t>(ctx, n_blk + 1);
     SWG_CHECK_ARENA(ctx);
-    if (packedA)
-      SWG_LAUNCH(ctx, "gather_all_packed", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
-                                        M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
-                                        pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt));
-    else
-      SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
-                                                                 r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
-                                                                 blk_cnt));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_inclusive_sum_scan_u64(ctx, blk_cnt, blk_cnt, n_blk));
     uint64_t tot = 0;
-    SWG_TRY(swg_read_scalars(ctx, blk_cnt + (n_blk - 1), &tot, 1));
+    for (;;) {
+      if (packedA && dropA) {
+        SWG_HIP(ctx, hipMemsetAsync(blk_cnt + n_blk, 0, 8, st));
+        SWG_LAUNCH(ctx, "gather_all_words", gather_all_words_kernel<<<nblk(M), EW, 0, st>>>(
+                                          M, packedA, packed_idx_bits, dropA, r->q_start, r->q_end, r->t_start, r->t_end, r->matches,
+                                          r->block_len, pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt,
+                                          reinterpret_cast<unsigned long long*>(blk_cnt + n_blk)));
+      } else if (packedA) {
+        SWG_LAUNCH(ctx, "gather_all_packed", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
+                                          M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
+                                          pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt));
+      } else {
+        SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
+                                                                   r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,
+                                                                   blk_cnt));
+      }
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_inclusive_sum_scan_u64(ctx, blk_cnt, blk_cnt, n_blk));
+      uint64_t h2[2] = {0, 0};
+      SWG_TRY(swg_read_scalars(ctx, blk_cnt + (n_blk - 1), h2, (packedA && dropA) ? 2 : 1));
+      tot = h2[0];
+      if (!(packedA && dropA) || h2[1] == 0) break;
+      // runs of equal truncated keys longer than the gather can order: once more, sorted on the whole key
+      ++ctx->sort_drop_level;
+      static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[swg] sort A: runs of equal q_start >> %d longer than %d: sorting again on the whole key\n", dropA, SWG_RUN_HALO);
+      if (M != n) SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));  // (the failed gather wrote over the list of alive records)
+      SWG_TRY(sortA_packed(0, sortA_key_bits, packed_idx_bits));
+    }
     B.n_pairs = tot >> 32;
     n_groups = tot & 0xffffffffull;
     // the group-head flags as a column are only read by the scan-based reductions of few, long groups (below and in the chain

@@ -339,6 +339,10 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
   if (rec->n && (!status_out || !chain_out)) return swg_set_error(ctx, SWG_ERR_INVALID, "output buffer is NULL");
   SWG_HIP(ctx, hipSetDevice(ctx->device));
   SWG_TRY(swg_filter_reserve_arena(ctx, rec->n, rec, cfg, rec64 != nullptr));
+  // sorts on truncated keys (swg_radix_drop_bits): a context that met runs too long for them stops trying -- for inputs of
+  // about the size that failed (a host filtering the same kind of file again and again pays the failed attempt once)
+  if (ctx->sort_drop_level > 0 && (rec->n < ctx->sort_drop_n / 2 || rec->n > 2 * ctx->sort_drop_n)) ctx->sort_drop_level = 0;
+  const int drop_level0 = ctx->sort_drop_level;
   const uint64_t readbacks0 = ctx->n_readbacks;
   SWG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int rc = swg_run_with_arena(ctx, [&]() -> int {
@@ -380,6 +384,7 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
     return filter_device_body(ctx, &r32, cfg, status_out, chain_out, stats);
   });
   if (rc != SWG_OK) return rc;
+  if (ctx->sort_drop_level > drop_level0) ctx->sort_drop_n = rec->n;
   SWG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   {
     static const bool dbg = getenv("SWG_DEBUG") != nullptr;

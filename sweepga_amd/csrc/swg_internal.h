@@ -31,6 +31,8 @@ struct swg_ctx {
   std::string err;
   int num_cu = 256;
   uint64_t n_readbacks = 0;  // swg_read_scalars calls (each one a stream synchronisation), for SWG_DEBUG
+  int sort_drop_level = 0;   // raised when a sort on a truncated key met runs too long to order in the gather (swg_radix_drop_bits)
+  uint64_t sort_drop_n = 0;  // ... by a call over this many records: a call of a very different size starts from level 0 again
   // per-kernel profiler (swg_profile_*)
   bool prof_on = false;
   std::string prof_only;  // non-empty: only launches with this label are bracketed (swg_profile_select)
@@ -185,6 +187,14 @@ static inline swg_radix_plan swg_radix_plan_pairs(int begin_bit, int end_bit) {
 // into 9-bit digits where that saves a pass (34 remaining bits: 9 + 9 + 8 + 8 instead of five passes), else into 8-bit ones.
 // SWG_SORT_BITS8=1 (test knob): 8-bit digits everywhere.
 swg_radix_plan swg_radix_plan_packed(int key_bits);
+// Sort on a truncated key: words (k << val_bits) | value over all `sorted_bits` bits of k, plain 8-byte passes
+// (swg_sort.hip has the story).  swg_radix_drop_bits: how many low bits of a key of key_bits (the lowest `low_bits` of which
+// are the caller's to order afterwards) to leave out, 0 = take the packed sort.
+swg_radix_plan swg_radix_plan_words(int sorted_bits);
+int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level);
+int swg_radix_sort_words(swg_ctx* ctx, uint64_t* words, uint64_t* scratch, uint64_t n, int sorted_bits, int val_bits,
+                         uint32_t* prehist, uint64_t** out);
+constexpr int SWG_RUN_HALO = 64;  // a gather orders runs of equal truncated keys of up to this many elements (+1)
 #ifdef __HIPCC__
 // Accumulates one key of every lane of the wavefront into the work-group's LDS histograms h[pass][bin] (zero them first,
 // flush them with swg_radix_hist_flush).  High digits are usually the same for a whole wavefront (segment bits): one add

@@ -973,6 +973,109 @@ swg_radix_plan swg_radix_plan_packed(int key_bits) {
   }
   return pl;
 }
+// ---- sort on a truncated key (round 4) --------------------------------------------------------------------------------
+// Words w = (k << val_bits) | value, sorted on ALL `sorted_bits` bits of k by plain 8-byte passes: no pass that reads wider
+// elements, no key bits dropped from the word.  The callers get a pass fewer than swg_radix_sort_packed by leaving the LOW
+// bits of their real key out of k altogether (k = key >> drop) and ordering the short runs of equal k afterwards, where they
+// gather the records anyway (begin_gather_words_kernel, gather_all_words_kernel).
+swg_radix_plan swg_radix_plan_words(int sorted_bits) {
+  static const bool bits8 = getenv("SWG_SORT_BITS8") != nullptr;
+  swg_radix_plan pl{};
+  if (sorted_bits <= 0) return pl;
+  const int q8 = (sorted_bits + 7) / 8, q9 = (sorted_bits + 8) / 9;
+  const int q = (bits8 || q9 == q8) ? q8 : q9;
+  if (q > SWG_RADIX_MAX_PASSES) return pl;
+  // as even as possible, the wider digits on top (see swg_radix_plan_packed)
+  const int base = sorted_bits / q, extra = sorted_bits % q;
+  int at = 0;
+  for (int p = 0; p < q; ++p) {
+    const int b = base + (p >= q - extra ? 1 : 0);
+    pl.shift[p] = (uint8_t)at;
+    pl.bits[p] = (uint8_t)b;
+    at += b;
+  }
+  pl.npasses = q;
+  return pl;
+}
+// rough cost of a plan in ms per 10^8 elements (measured: 0.41 per 8-bit pass, 0.50 per 9-bit pass, 0.43 for the packed
+// sort's first pass): what the choice of `drop` below compares
+static double plan_cost(const swg_radix_plan& pl, bool packed_first) {
+  double c = 0.0;
+  for (int p = 0; p < pl.npasses; ++p) c += (p == 0 && packed_first) ? 0.43 : (pl.bits[p] > 8 ? 0.50 : 0.41);
+  return c;
+}
+// How many low key bits to leave out of the sort (0: none, take the packed sort).  `level`: 0 = up to 10 bits, 1 = up to 7,
+// 2+ = never -- the caller raises it when a run of equal truncated keys turned out longer than its gather can order.
+int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level) {
+  static const char* knob = getenv("SWG_SORT_DROP");  // "0": never (test / A-B knob); "n": at most n bits
+  static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr, force_wide = getenv("SWG_SORT_WIDE") != nullptr,
+                    no_packed = getenv("SWG_SORT_PAIRS") != nullptr;
+  if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || level >= 2) return 0;
+  int dmax = level == 0 ? 10 : 7;
+  if (knob) dmax = std::min(dmax, atoi(knob));
+  if (dmax > low_bits) dmax = low_bits;
+  const double now = plan_cost(swg_radix_plan_packed(key_bits), true);
+  int best = 0;
+  double best_cost = now - 0.2;  // a pass fewer, or nothing
+  for (int d = 1; d <= dmax; ++d) {
+    if (key_bits - d < 1 || key_bits - d + val_bits > 64) continue;
+    const swg_radix_plan pl = swg_radix_plan_words(key_bits - d);
+    if (pl.npasses == 0) continue;
+    const double c = plan_cost(pl, false) + 0.004 * d;
+    if (c < best_cost) {
+      best_cost = c;
+      best = d;
+    }
+  }
+  return best;
+}
+int swg_radix_sort_words(swg_ctx* ctx, uint64_t* words, uint64_t* scratch, uint64_t n, int sorted_bits, int val_bits,
+                         uint32_t* prehist, uint64_t** out) {
+  const swg_radix_plan plan = swg_radix_plan_words(sorted_bits);
+  const int npasses = plan.npasses;
+  if (npasses == 0 || sorted_bits + val_bits > 64 || n < 2 || n >= (uint64_t(1) << 30)) return SWG_ERR_UNSUPPORTED;
+  const uint32_t ntiles = (uint32_t)((n + PK_TILE - 1) / PK_TILE);
+  const uint32_t htiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+  swg_arena_mark mark = swg_arena_save(ctx);
+  uint32_t* ghist = prehist ? prehist : swg_alloc<uint32_t>(ctx, (size_t)OS_MAX_PASSES * SWG_RADIX_BINS);
+  uint32_t* status = swg_alloc<uint32_t>(ctx, (size_t)ntiles * SWG_RADIX_BINS);
+  uint32_t* tickets = swg_alloc<uint32_t>(ctx, OS_MAX_PASSES);
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(tickets, 0, sizeof(uint32_t) * OS_MAX_PASSES, ctx->stream));
+  if (!prehist) {  // digits straight from the words
+    swg_radix_plan wp = plan;
+    for (int p = 0; p < npasses; ++p) wp.shift[p] = (uint8_t)(plan.shift[p] + val_bits);
+    SWG_HIP(ctx, hipMemsetAsync(ghist, 0, sizeof(uint32_t) * OS_MAX_PASSES * SWG_RADIX_BINS, ctx->stream));
+    uint32_t hb = htiles < (uint32_t)ctx->num_cu * 8 ? htiles : (uint32_t)ctx->num_cu * 8;
+    SWG_LAUNCH(ctx, "os_hist", os_hist_kernel<<<hb, OS_THREADS, 0, ctx->stream>>>(words, n, wp, ghist));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  SWG_LAUNCH(ctx, "os_scan_hist", os_scan_hist_kernel<<<npasses, SWG_RADIX_BINS, 0, ctx->stream>>>(ghist));
+  SWG_KERNEL_CHECK(ctx);
+  uint64_t* src = words;
+  uint64_t* dst = scratch;
+  for (int p = 0; p < npasses; ++p) {
+    const int bits = plan.bits[p];
+    const uint32_t mask = (1u << bits) - 1u;
+    const int wshift = val_bits + plan.shift[p];
+    const uint32_t* gb = ghist + (size_t)p * SWG_RADIX_BINS;
+    SWG_HIP(ctx, hipMemsetAsync(status, 0, sizeof(uint32_t) * (size_t)ntiles * (bits == 9 ? P9_BINS : RS_RADIX), ctx->stream));
+    if (bits == 9)
+      SWG_LAUNCH_N(ctx, "os_pass_packed9", n, os_pass_packed9_kernel<uint32_t><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
+                                              src, dst, n, wshift, gb, status, tickets + p));
+    else
+      SWG_LAUNCH_N(ctx, "os_pass_packed", n, os_pass_packed_kernel<uint32_t, false><<<ntiles, PK_THREADS, 0, ctx->stream>>>(
+                                              src, nullptr, dst, n, wshift, mask, val_bits, gb, status, tickets + p));
+    SWG_KERNEL_CHECK(ctx);
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
+  }
+  *out = src;
+  swg_arena_restore(ctx, mark);
+  return SWG_OK;
+}
+
 int swg_radix_sort_pairs(swg_ctx* ctx, uint64_t** keys, uint32_t** vals, uint64_t** keys_alt, uint32_t** vals_alt,
                          uint64_t n, int begin_bit, int end_bit, uint32_t* prehist) {
   if (n <= 1 || end_bit <= begin_bit) return SWG_OK;

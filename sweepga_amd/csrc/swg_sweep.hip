@@ -159,7 +159,9 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
                                                                  const uint8_t* __restrict__ alive, int pos_bits,
                                                                  uint64_t* __restrict__ key,
                                                                  uint32_t* __restrict__ val, swg_radix_plan plan,
-                                                                 uint32_t* __restrict__ ghist) {
+                                                                 uint32_t* __restrict__ ghist, int drop = 0, int idx_bits = 0) {
+  // drop > 0: sort on the truncated key -- key[i] becomes the WORD ((X >> drop) << idx_bits) | i (swg_radix_sort_words) and
+  // the histograms are those of X >> drop.
   // grid-stride over whole work-groups (the trip count is block-uniform); with `ghist` the digit histograms of the sort
   // that follows are accumulated here, while the key is in a register (the sort then skips its own pass over the keys)
   __shared__ uint32_t h[SWG_RADIX_MAX_PASSES][SWG_RADIX_BINS];
@@ -184,8 +186,13 @@ __global__ __launch_bounds__(EW_THREADS) void begin_build_kernel(uint64_t n, con
         }
         k = ((sg + 1) << pos_bits) | start[i];
       }
-      key[i] = k;
-      if (val) val[i] = (uint32_t)i;  // (nullptr: the packed sort takes the identity as read)
+      if (drop) {
+        k >>= drop;
+        key[i] = (k << idx_bits) | i;
+      } else {
+        key[i] = k;
+        if (val) val[i] = (uint32_t)i;  // (nullptr: the packed sort takes the identity as read)
+      }
     }
     if (ghist) swg_radix_hist_add(h, k, in, plan);
   }
@@ -265,6 +272,99 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_
   E[p] = e;
   KEY[p] = k;
   if ((p % TB) == 0) tile_x[p / TB] = s;
+}
+
+// The same after a sort on the TRUNCATED key (swg_radix_sort_words): P[p] = ((X >> drop) << idx_bits) | record index, in
+// (X >> drop, index) order.  Begins whose starts differ only in the low `drop` bits form short runs; each member finds the
+// other members of its run in LDS (the work-group's 256 words plus SWG_RUN_HALO on either side, with the low bits of their
+// starts from the record slots), counts those that order before it by (low bits, index) and writes its begin to
+// run start + that rank: the full (X, index) order, one radix pass cheaper.  A run that reaches beyond the halo cannot be
+// ordered here: *long_run is raised (the positions written are then meaningless but in range) and the caller sorts again,
+// the ordinary way.
+__global__ __launch_bounds__(EW_THREADS) void begin_gather_words_kernel(uint64_t n, const uint64_t* __restrict__ P, int idx_bits,
+                                                                        int drop, const swg_key_ends* __restrict__ packed,
+                                                                        int axis, int pos_bits, uint64_t* __restrict__ S,
+                                                                        uint32_t* __restrict__ I, uint32_t* __restrict__ E,
+                                                                        uint64_t* __restrict__ KEY,
+                                                                        uint64_t* __restrict__ tile_x,
+                                                                        uint8_t* __restrict__ single,
+                                                                        uint32_t* __restrict__ long_run) {
+  constexpr int H = SWG_RUN_HALO, W = EW_THREADS + 2 * H;
+  __shared__ uint64_t l_hi[W];   // X >> drop (0: dead record, or no element at this position)
+  __shared__ uint64_t l_ord[W];  // (low bits of the start << 32) | record index: the order inside a run
+  const uint64_t p0 = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW_THREADS;
+  const int t = threadIdx.x;
+  const uint64_t idx_mask = (uint64_t(1) << idx_bits) - 1;
+  const uint32_t low_mask = (1u << drop) - 1u;
+  // own element
+  const uint64_t p = p0 + t;
+  uint64_t w = 0, hi = 0;
+  uint32_t id = 0, e = 0, low = 0;
+  uint64_t k = 0;
+  if (p < n) {
+    w = P[p];
+    hi = w >> idx_bits;
+    id = (uint32_t)(w & idx_mask);
+    if (hi != 0) {
+      const swg_key_ends ke = packed[id];
+      low = ke.start[axis] & low_mask;
+      e = ke.end[axis];
+      k = ke.key;
+    }
+  }
+  l_hi[H + t] = hi;
+  l_ord[H + t] = ((uint64_t)low << 32) | id;
+  // halo words (their record slots are read below, and only for the elements of a run that crosses the block's edge)
+  if (t < 2 * H) {
+    const bool left = t < H;
+    const int64_t q = left ? (int64_t)p0 - H + t : (int64_t)p0 + EW_THREADS + (t - H);
+    const int li = left ? t : EW_THREADS + t;  // H + EW_THREADS + (t - H)
+    l_hi[li] = (q >= 0 && (uint64_t)q < n) ? (P[q] >> idx_bits) : 0ull;
+    l_ord[li] = (q >= 0 && (uint64_t)q < n) ? (P[q] & idx_mask) : 0ull;  // (index only so far)
+  }
+  __syncthreads();
+  if (t < 2 * H) {
+    const bool left = t < H;
+    const int li = left ? t : EW_THREADS + t;
+    const uint64_t edge = left ? l_hi[H] : l_hi[H + EW_THREADS - 1];
+    if (edge != 0 && l_hi[li] == edge) {
+      const uint32_t hid = (uint32_t)l_ord[li];
+      l_ord[li] = ((uint64_t)(packed[hid].start[axis] & low_mask) << 32) | hid;
+    }
+  }
+  __syncthreads();
+  if (p >= n) return;
+  uint64_t np = p;
+  if (hi != 0) {
+    const uint64_t mine = l_ord[H + t];
+    uint32_t before = 0, rank = 0;
+    int j = H + t - 1;
+    for (; j >= 0 && l_hi[j] == hi; --j) {
+      ++before;
+      rank += l_ord[j] < mine ? 1u : 0u;
+    }
+    bool too_long = j < 0 && p0 > (uint64_t)H;  // ran off the left halo with elements still before it
+    int j2 = H + t + 1;
+    for (; j2 < W && l_hi[j2] == hi; ++j2) rank += l_ord[j2] < mine ? 1u : 0u;
+    if (j2 >= W && p0 + EW_THREADS + H < n) too_long = true;  // ran off the right halo with elements still after it
+    if (too_long) {
+      *long_run = 1u;
+    } else {
+      np = p - before + rank;
+    }
+  }
+  const uint64_t s = hi ? ((hi << drop) | low) : 0ull;
+  S[np] = s;
+  I[np] = id;
+  E[np] = e;
+  KEY[np] = k;
+  if ((np % TB) == 0) tile_x[np / TB] = s;
+  if (hi != 0) {
+    const uint64_t sg = hi >> (pos_bits - drop);
+    const bool prev_same = p > 0 && (l_hi[H + t - 1] >> (pos_bits - drop)) == sg;
+    const bool next_same = p + 1 < n && (l_hi[H + t + 1] >> (pos_bits - drop)) == sg;
+    if (!prev_same && !next_same) single[id] = 1;
+  }
 }
 
 // composite end of a begin with composite start s (0 = dead) and end coordinate e
@@ -1380,6 +1480,48 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     }
     const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
     const bool packed_sort = in.packed && in.pos_bits >= 8 && swg_radix_sort_packed_applies(n, key_bits, idx_bits);
+    // One radix pass fewer: sort on the key without the low `drop` bits of the start coordinate, order the short runs of equal
+    // truncated keys in the gather (begin_gather_words_kernel).  A run longer than the gather can see (dense data, heavy ties)
+    // raises a flag: the context stops trying (for good, after a second failure with fewer bits) and this sort runs again
+    // the ordinary way.
+    const int drop = (packed_sort && prehist) ? swg_radix_drop_bits(n, key_bits, in.pos_bits, idx_bits, ctx->sort_drop_level) : 0;
+    if (drop) {
+      const unsigned full = blocks_for(n, EW_THREADS), cap = (unsigned)ctx->num_cu * 16;
+      SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<full > cap ? cap : full, EW_THREADS, 0, st>>>(
+                                         n, in.seg, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.start, in.alive, in.pos_bits, S, nullptr,
+                                         swg_radix_plan_words(key_bits - drop), prehist, drop, idx_bits));
+      SWG_KERNEL_CHECK(ctx);
+      uint64_t* P = nullptr;
+      const int wrc = swg_radix_sort_words(ctx, S, S2, n, key_bits - drop, idx_bits, prehist, &P);
+      if (wrc != SWG_OK) return wrc == SWG_ERR_UNSUPPORTED ? swg_set_error(ctx, SWG_ERR_HIP, "word sort declined a shape it accepted") : wrc;
+      uint64_t* other = P == S ? S2 : S;
+      const swg_arena_mark third_mark = swg_arena_save(ctx);
+      uint64_t* third = swg_alloc<uint64_t>(ctx, n);
+      uint64_t* d_flag = swg_alloc<uint64_t>(ctx, 1);
+      SWG_CHECK_ARENA(ctx);
+      SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
+      SWG_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, st));
+      SWG_LAUNCH(ctx, "begin_gather_words", begin_gather_words_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+                                         n, P, idx_bits, drop, in.packed, in.packed_end, in.pos_bits, other, I, reinterpret_cast<uint32_t*>(third), KEY,
+                                         tile_x, single, reinterpret_cast<uint32_t*>(d_flag)));
+      SWG_KERNEL_CHECK(ctx);
+      uint64_t long_run = 0;
+      SWG_TRY(swg_read_scalars(ctx, d_flag, &long_run, 1));
+      if ((uint32_t)long_run == 0) {
+        S = other;
+        E = reinterpret_cast<uint32_t*>(third);
+        if (in.sorted_idx_out) {
+          SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+          if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
+        }
+        return SWG_OK;
+      }
+      ++ctx->sort_drop_level;
+      static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[swg] sweep: runs of equal starts >> %d longer than %d: sorting again on the whole key\n", drop, SWG_RUN_HALO);
+      swg_arena_restore(ctx, third_mark);
+      SWG_HIP(ctx, hipMemsetAsync(prehist, 0, sizeof(uint32_t) * SWG_RADIX_MAX_PASSES * SWG_RADIX_BINS, st));
+    }
     {
       const unsigned full = blocks_for(n, EW_THREADS), cap = (unsigned)ctx->num_cu * 16;
       SWG_LAUNCH(ctx, "begin_build", begin_build_kernel<<<(prehist && full > cap) ? cap : full, EW_THREADS, 0, st>>>(
