@@ -5,6 +5,8 @@
 //   chaining    best-buddy predecessor selection (paf_filter.rs:784-851): units cut where no window can straddle,
 //               parallel candidate lists, then the reference's sequential greedy per unit (one lane, one wavefront or
 //               block-speculative, by unit length)
+#include <type_traits>
+
 #include "swg_scaffold_internal.h"
 
 namespace swg_scaf {
@@ -596,12 +598,159 @@ __device__ __forceinline__ void wave_top_kc(uint64_t bd[KC], uint32_t bj[KC]) {
 // is reported as one more than what was seen -- "the window may hold more" -- which at worst lets the selection re-evaluate
 // a window that has nothing left to offer (same result); the window extent then comes from a galloping search.
 constexpr int CW_PER_WAVE = 16;  // consecutive i handled by one wavefront
-// Round 3: the wavefront's KC best live in ONE wave-uniform list (scalar registers) instead of one list per lane.  A batch
-// of 64 elements is evaluated by the lanes; only the elements that beat the list's last entry (a ballot; rare once the list
-// has settled: ~4 ln(window / 4) insertions per element in all) are inserted, one at a time in ascending lane = ascending
-// j order, which is the sequential insertion order of chain_candidates_kernel.  No per-lane lists, no butterfly merge at the
-// end, and the early cut reads the list's last entry directly.  The results of the CW_PER_WAVE elements are parked in
-// lanes 0..15 and stored together (whole lines instead of one 8-byte store per array and element).
+
+// Round 4: the batch loop for gap limits below 2^31 (no wrap-around, the early cut applies), written for the vector unit,
+// which is what bounds this kernel (a wave64 instruction occupies the SIMD for four cycles; the generic loop below spends
+// ~45 vector instructions and two quarter-rate 64-bit multiply-adds per batch):
+//   * the strand is a template argument (two selects per batch gone), so is the width of the distance: a limit of at most
+//     46340 keeps q^2 + r^2 below 2^32 -- 24-bit multiplies, one 32-bit compare against the list's last entry;
+//   * a gap is |a - b| (one v_sad_u32) and passes when it is at most a fifth of the limit, or at most the limit on the gap
+//     side -- the same predicate as paf_filter.rs:798-836 with the value selects folded away (a rejected pair's distance is
+//     never read);
+//   * loads address `uniform base + lane` with the lane offset clamped to the group's end (no exec-mask branch, no 64-bit
+//     address arithmetic per lane); two batches per trip, so the prefetched registers are not moved.
+// The wavefront's list stays wave-uniform (scalar registers), inserted into in ascending lane = ascending j order as before.
+constexpr size_t CAND_PAD = 8192;  // the scan reads up to three batches (768 bytes per array) past a group's end without clamping
+struct CandScan {
+  uint64_t d0, d1, d2, d3;
+  uint32_t j0, j1, j2, j3;
+  uint32_t count, ext, cut_at;
+  bool cut;
+};
+// |a - b| of a per-lane and a wave-uniform value: one instruction (the compiler expands the generic form to min / max / sub)
+__device__ __forceinline__ uint32_t absdiff_vs(uint32_t v, uint32_t s) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(v), "s"(s));
+  return r;
+}
+template <bool MINUS, bool D32>
+__device__ __forceinline__ void cand_scan_fast(uint32_t p, uint32_t e, uint32_t qe_i, uint32_t ts_i, uint32_t te_i, uint32_t bound,
+                                               uint32_t gap, uint32_t fifth, const uint32_t* __restrict__ s_qs,
+                                               const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te, uint32_t lane,
+                                               CandScan& L) {
+  // the list: 32-bit distances with 0xffffffff = empty when they fit (every compare of the insertion on the scalar unit)
+  using DT = typename std::conditional<D32, uint32_t, uint64_t>::type;
+  constexpr DT EMPTY = (DT)~(DT)0;
+  DT sd0 = EMPTY, sd1 = EMPTY, sd2 = EMPTY, sd3 = EMPTY;
+  uint32_t sj0 = NONE, sj1 = NONE, sj2 = NONE, sj3 = NONE;
+  uint32_t count = 0, ext = 0, cut_at = 0;
+  bool cut = false;
+  // (plain locals and one copy of the loop body: lambdas that capture the list by reference end up with the list in scratch
+  // memory, addressed through selected pointers.  Predicates that feed both a ballot and a select are kept apart: combined as
+  // `bool` they are materialised as 0/1 and compared again, two vector instructions each.)
+  const uint32_t* __restrict__ s_r = MINUS ? s_te : s_ts;  // the target coordinate of j that enters d(i, j)
+  const uint32_t r_i = MINUS ? ts_i : te_i;                // ... and that of i
+  // A wave64 vector instruction occupies the SIMD for four cycles and the scalar unit serves a SIMD every fourth cycle: a
+  // batch costs 4 x max(vector, scalar) instructions (SQ counters, profiles/README.md).  Both are kept to the loop's own work:
+  //   * addresses: uniform base (s_qs + p + 1) + a per-lane byte offset that advances by 256 (one vector add for both arrays);
+  //     no clamping -- the arrays are followed by CAND_PAD readable bytes, what lies past the group's end is masked;
+  //   * j itself is a per-lane value (j < e is a vector compare); the scan ends when the window mask is not full, which a
+  //     batch past the group's end also satisfies -- no uniform batch counter in the loop, the window extent is taken from
+  //     the last batch's position;
+  //   * a rejected pair gets the distance "empty" by selects; the list test reads that one value;
+  //   * the number of valid j saturates at KC + 1 (all its readers ask: how many of the KC entries, and were there more),
+  //     so it is counted only until it gets there;
+  //   * the early cut is evaluated by every lane for its own element (two vector instructions) and read from lane 63.
+  const char* pq = reinterpret_cast<const char*>(s_qs + (p + 1u));
+  const char* pr = reinterpret_cast<const char*>(s_r + (p + 1u));
+  uint32_t voff = lane * 4u;
+  uint32_t vj = p + 1u + lane;
+  uint32_t n_qs = *reinterpret_cast<const uint32_t*>(pq + voff);
+  uint32_t n_r = *reinterpret_cast<const uint32_t*>(pr + voff);
+  // the two limits as per-lane values the compiler cannot re-materialise inside the loop (a select takes one scalar operand:
+  // its mask -- both limits would be moved into vector registers again in every batch)
+  uint32_t vgap = gap, vfifth = fifth;
+  asm volatile("" : "+v"(vgap), "+v"(vfifth));
+  if (p + 1u < e) {
+    for (;;) {
+      const uint32_t qs_j = n_qs, r_j = n_r;
+      voff += 256u;  // the next batch is requested before this one is evaluated
+      n_qs = *reinterpret_cast<const uint32_t*>(pq + voff);
+      n_r = *reinterpret_cast<const uint32_t*>(pr + voff);
+      // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
+      const bool in_e = vj < e, in_b = qs_j <= bound;
+      const uint64_t wmask = __builtin_amdgcn_ballot_w64(in_e) & __builtin_amdgcn_ballot_w64(in_b);
+      const uint32_t aq = absdiff_vs(qs_j, qe_i);
+      const bool q_ge = qs_j >= qe_i;
+      const uint32_t lim_q = q_ge ? vgap : vfifth;  // a gap may reach the limit, an overlap a fifth of it
+      const uint32_t ar = absdiff_vs(r_j, r_i);
+      // gap side: plus strand t_start[j] >= t_end[i], minus strand t_start[i] >= t_end[j]
+      const uint32_t lim_r = (MINUS ? r_j <= r_i : r_j >= r_i) ? vgap : vfifth;
+      DT d;
+      uint64_t cutmask;  // (taken before the insertions: they only lower sd3)
+      if constexpr (D32) {
+        // (an accepted gap is below 2^16; a rejected pair's value is not read.  The cut: this lane's query gap squared
+        // reaches the list's last entry -- 65535^2 exceeds every distance and stays below "empty")
+        const uint32_t aqc = min(aq, 65535u);
+        const uint32_t t1 = __umul24(aqc, aqc);
+        d = t1 + __umul24(ar, ar);
+        cutmask = __builtin_amdgcn_ballot_w64(q_ge) & __builtin_amdgcn_ballot_w64(t1 >= sd3);
+      } else {
+        const uint64_t t1 = (uint64_t)aq * aq;
+        d = t1 + (uint64_t)ar * ar;
+        cutmask = __builtin_amdgcn_ballot_w64(q_ge) & __builtin_amdgcn_ballot_w64(t1 >= sd3);  // (a square is never "empty")
+      }
+      d = (aq <= lim_q) ? d : EMPTY;
+      d = (ar <= lim_r) ? d : EMPTY;
+      d = in_e ? d : EMPTY;
+      d = in_b ? d : EMPTY;
+      if (count <= (uint32_t)KC) count += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d != EMPTY));
+      uint64_t cmask = __builtin_amdgcn_ballot_w64(d < sd3);
+      bool c = ((uint32_t)(cutmask >> 32) >> 31) != 0u;
+      if (cmask) {
+        do {
+          const int l = __builtin_ctzll(cmask);
+          DT dl;
+          if constexpr (D32)
+            dl = readlane_u32(d, l);
+          else
+            dl = readlane_u64(d, l);
+          const uint32_t jl = readlane_u32(vj, l);
+          if (dl < sd0) {
+            sd3 = sd2; sj3 = sj2; sd2 = sd1; sj2 = sj1; sd1 = sd0; sj1 = sj0; sd0 = dl; sj0 = jl;
+          } else if (dl < sd1) {
+            sd3 = sd2; sj3 = sj2; sd2 = sd1; sj2 = sj1; sd1 = dl; sj1 = jl;
+          } else if (dl < sd2) {
+            sd3 = sd2; sj3 = sj2; sd2 = dl; sj2 = jl;
+          } else {
+            sd3 = dl; sj3 = jl;
+          }
+          cmask = __builtin_amdgcn_ballot_w64(d < sd3) & ~((2ull << l) - 1ull);  // lanes above l that still beat the list
+        } while (cmask);
+        if (!c && sd3 != EMPTY) {  // the list changed: lane 63's test against the list as it stands now
+          const uint32_t q_last = readlane_u32(qs_j, 63);
+          if (q_last >= qe_i) {
+            const uint64_t qg = (uint64_t)q_last - qe_i;
+            c = (uint64_t)sd3 <= qg * qg;
+          }
+        }
+      }
+      if (wmask != ~0ull) {  // the window ended inside these 64, or the group did (a batch past the group's end is empty)
+        ext = readlane_u32(vj, 0) - (p + 1u) + (uint32_t)__popcll(wmask);
+        break;
+      }
+      // every later element starts at or after this batch's last one: its query gap is at least `qg`; with KC entries held
+      // at distance <= qg^2 no later j can enter the list (d >= qg^2; equal distances keep the smaller j)
+      if (c) {
+        cut_at = readlane_u32(vj, 0) + 64u;
+        cut = cut_at < e;  // (a full batch that ends the group: nothing was cut, the counts are exact)
+        if (!cut) ext = cut_at - (p + 1u);
+        break;
+      }
+      vj += 64u;
+    }
+  }
+  auto wide = [](DT v) { return v == EMPTY ? ~0ull : (uint64_t)v; };
+  L.d0 = wide(sd0); L.d1 = wide(sd1); L.d2 = wide(sd2); L.d3 = wide(sd3);
+  L.j0 = sj0; L.j1 = sj1; L.j2 = sj2; L.j3 = sj3;
+  L.count = min(count, (uint32_t)KC + 1u);
+  L.ext = ext;
+  L.cut_at = cut_at;
+  L.cut = cut;
+}
+
+// MODE 0: any gap limit (the generic loop); 1: limit < 2^31 (cand_scan_fast, 64-bit distances); 2: limit <= 46340 (32-bit)
+template <int MODE>
 __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, const uint32_t* __restrict__ s_gidx,
                                                                    const uint32_t* __restrict__ group_begin,
                                                                    uint32_t n_groups, const uint64_t* __restrict__ s_grp,
@@ -653,6 +802,19 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     uint32_t sj0 = NONE, sj1 = NONE, sj2 = NONE, sj3 = NONE;
     uint32_t count = 0, ext = 0, cut_at = 0;
     bool cut = false;
+    if (MODE != 0) {
+      CandScan L;
+      if (minus)
+        cand_scan_fast<true, MODE == 2>((uint32_t)p, e, qe_i, ts_i, te_i, bound, gap, fifth, s_qs, s_ts, s_te, (uint32_t)lane, L);
+      else
+        cand_scan_fast<false, MODE == 2>((uint32_t)p, e, qe_i, ts_i, te_i, bound, gap, fifth, s_qs, s_ts, s_te, (uint32_t)lane, L);
+      sd0 = L.d0; sd1 = L.d1; sd2 = L.d2; sd3 = L.d3;
+      sj0 = L.j0; sj1 = L.j1; sj2 = L.j2; sj3 = L.j3;
+      count = L.count;
+      ext = L.ext;
+      cut_at = L.cut_at;
+      cut = L.cut;
+    } else {
     // software pipeline: the three coordinates of the NEXT batch are requested before the current one is evaluated (one
     // memory round trip per batch, overlapped with the arithmetic, instead of two dependent ones)
     uint32_t n_qs = 0xffffffffu, n_ts = 0, n_te = 0;
@@ -733,6 +895,7 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
       if (__builtin_amdgcn_readfirstlane(stop)) break;
       j0 += 64;
     }
+    }  // MODE == 0
     if (cut) {
       // Window extent without scanning: the batch before `cut_at` lies inside the window; gallop ahead 64 x 64 elements at
       // a time (one probe per lane), then resolve inside the 64-element block that holds the boundary.
@@ -775,6 +938,25 @@ __global__ __launch_bounds__(EW) void chain_candidates_wave_kernel(uint64_t m, c
     c_n[po] = out_n;
     c_ext[po] = out_ext;
   }
+}
+
+// SWG_CAND_GENERIC=1 (test knob): the generic loop whatever the limit
+template <class G>
+static void launch_candidates_wave(swg_ctx* ctx, hipStream_t st, G grid, uint64_t m, const uint32_t* s_gidx, const uint32_t* group_begin,
+                                   uint32_t n_groups, const uint64_t* s_grp, const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts,
+                                   const uint32_t* s_te, uint64_t max_gap, unsigned long long* c_d, uint32_t* c_j, uint32_t* c_n, uint32_t* c_ext) {
+  static const bool generic = getenv("SWG_CAND_GENERIC") != nullptr;
+  const int mode = (generic || max_gap >= (uint64_t(1) << 31)) ? 0 : (max_gap <= 46340 ? 2 : 1);
+#define SWG_CAND_LAUNCH(MODE)                                                                                                        \
+  SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<MODE><<<grid, EW, 0, st>>>(m, s_gidx, group_begin, n_groups, s_grp, s_qs, \
+                                                                                                    s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext))
+  if (mode == 0)
+    SWG_CAND_LAUNCH(0);
+  else if (mode == 1)
+    SWG_CAND_LAUNCH(1);
+  else
+    SWG_CAND_LAUNCH(2);
+#undef SWG_CAND_LAUNCH
 }
 
 struct SelBlock {
@@ -2365,9 +2547,10 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
         c_n = swg_alloc<uint32_t>(ctx, m);
         c_ext = swg_alloc<uint32_t>(ctx, m);
+        (void)swg_alloc<uint8_t>(ctx, CAND_PAD);  // readable bytes behind the coordinate arrays (cand_scan_fast)
         SWG_CHECK_ARENA(ctx);
-        SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
-                                                     m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+        launch_candidates_wave(ctx, st, nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe,
+                               s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext);
         SWG_KERNEL_CHECK(ctx);
       } else if (n_big) {
         // sparse data with a few long units: their blocks build their candidate lists while they walk, like the chunks (no
@@ -2506,10 +2689,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     uint32_t* c_j = swg_alloc<uint32_t>(ctx, (size_t)KC * m);
     uint32_t* c_n = swg_alloc<uint32_t>(ctx, m);
     uint32_t* c_ext = swg_alloc<uint32_t>(ctx, m);
+    (void)swg_alloc<uint8_t>(ctx, CAND_PAD);  // readable bytes behind the coordinate arrays (cand_scan_fast)
     SWG_CHECK_ARENA(ctx);
     if (long_groups || force_deep)
-      SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<<<nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), EW, 0, st>>>(
-                                                   m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));
+      launch_candidates_wave(ctx, st, nblk((m + CW_PER_WAVE - 1) / CW_PER_WAVE * 64), m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs, s_qe,
+                             s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext);
     else
       SWG_LAUNCH(ctx, "chain_candidates", chain_candidates_kernel<<<nblk(m), EW, 0, st>>>(m, s_gidx, group_begin, (uint32_t)n_groups, s_grp, s_qs,
                                                                               s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext));

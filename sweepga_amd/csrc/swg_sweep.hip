@@ -46,6 +46,10 @@ constexpr int TB = 256;  // begins per tile == threads per workgroup
 constexpr int CC = 256;  // carry-in entries staged per LDS chunk
 constexpr int EW_THREADS = 256;
 constexpr uint64_t DEEP_CARRY_PER_TILE = 64;  // average carry-ins per 256-begin tile from which k = 1 uses 512-begin tiles
+constexpr uint64_t SPARSE_CARRY_PER_TILE = 4;  // ... and below which it uses 128-begin tiles (two-wavefront work-groups: the
+                                               // tile kernel 5.9 -> 5.5 ms on S-pan, routing +0.07; 13 vs 8.3 ms on the deep pair)
+constexpr int TBF = 128;                       // the gathers publish tile-start keys at this granularity; coarser tilings take
+                                               // every 2nd / 4th of them
 
 __device__ __forceinline__ bool prio_less(uint64_t ak, uint64_t as, uint32_t ai, uint64_t bk, uint64_t bs,
                                           uint32_t bi) {
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_kernel(uint64_t n, co
   }
   E[p] = e;
   KEY[p] = k;
-  if ((p % TB) == 0) tile_x[p / TB] = s;
+  if ((p % TBF) == 0) tile_x[p / TBF] = s;
 }
 
 // The same after the packed sort (swg_radix_sort_packed): P[p] = ((X >> 8) << idx_bits) | record index.  The begin's full
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_packed_kernel(uint64_
   I[p] = id;
   E[p] = e;
   KEY[p] = k;
-  if ((p % TB) == 0) tile_x[p / TB] = s;
+  if ((p % TBF) == 0) tile_x[p / TBF] = s;
 }
 
 // The same after a sort on the TRUNCATED key (swg_radix_sort_words): P[p] = ((X >> drop) << idx_bits) | record index, in
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(EW_THREADS) void begin_gather_words_kernel(uint64_t
   I[np] = id;
   E[np] = e;
   KEY[np] = k;
-  if ((np % TB) == 0) tile_x[np / TB] = s;
+  if ((np % TBF) == 0) tile_x[np / TBF] = s;
   if (hi != 0) {
     const uint64_t sg = hi >> (pos_bits - drop);
     const bool prev_same = p > 0 && (l_hi[H + t - 1] >> (pos_bits - drop)) == sg;
@@ -372,11 +376,17 @@ __device__ __forceinline__ uint64_t swg_comp_end(uint64_t s, uint32_t e, int pos
   return s ? ((s >> pos_bits) << pos_bits) | e : 0ull;
 }
 
+// first keys of tiles of `tile` begins, straight from the sorted begins (SWG_TILE_SMALL experiment)
+__global__ __launch_bounds__(EW_THREADS) void tile_x_stride_kernel(uint32_t nt, const uint64_t* __restrict__ S, uint32_t tile,
+                                                                   uint64_t* __restrict__ tile_x) {
+  const uint32_t b = blockIdx.x * EW_THREADS + threadIdx.x;
+  if (b < nt) tile_x[b] = S[(uint64_t)b * tile];
+}
 // first keys of the 512-begin tiles = every second one of the 256-begin tiles
 __global__ __launch_bounds__(EW_THREADS) void tile_x_pairs_kernel(uint32_t ntiles2, const uint64_t* __restrict__ tile_x,
-                                                                  uint64_t* __restrict__ tile_x2) {
+                                                                  uint64_t* __restrict__ tile_x2, uint32_t every = 2) {
   const uint32_t b = blockIdx.x * EW_THREADS + threadIdx.x;
-  if (b < ntiles2) tile_x2[b] = tile_x[2 * (size_t)b];
+  if (b < ntiles2) tile_x2[b] = tile_x[(size_t)every * b];
 }
 
 // ---- routing: carry-ins and end points ----------------------------------------------------------
@@ -410,14 +420,20 @@ __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, con
                                                                  const uint64_t* __restrict__ tile_x2, uint32_t ntiles2, int mode,
                                                                  const unsigned long long* __restrict__ reach, uint32_t stride,
                                                                  uint32_t* __restrict__ te_out,
-                                                                 uint32_t* __restrict__ carry_cnt) {
+                                                                 uint32_t* __restrict__ carry_cnt, uint32_t small_tile = 0,
+                                                                 const uint64_t* __restrict__ tile_xf = nullptr, uint32_t ntilesf = 0) {
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
-  const bool wide = mode == 1 || (mode == 2 && *reach * stride / ntiles >= DEEP_CARRY_PER_TILE);
-  const uint64_t* tx = wide ? tile_x2 : tile_x;
-  const uint32_t nt = wide ? ntiles2 : ntiles;
+  // mode 3 (small_tile != 0): tiles of `small_tile` begins, tile_x2 / ntiles2 describe them (knob).  mode 2: 512-begin tiles
+  // (tile_x2) for deep data, 128-begin tiles (tile_xf) for sparse data, 256 otherwise -- by the estimate
+  // (avg = reach * stride / ntiles, compared without the 64-bit division; every tile size is a power of two: shifts)
+  const uint64_t rs = mode == 2 ? *reach * stride : 0;
+  const bool wide = mode == 1 || mode == 3 || (mode == 2 && rs >= (uint64_t)DEEP_CARRY_PER_TILE * ntiles);
+  const bool fine = mode == 2 && rs < (uint64_t)SPARSE_CARRY_PER_TILE * ntiles;
+  const uint64_t* tx = fine ? tile_xf : wide ? tile_x2 : tile_x;
+  const uint32_t nt = fine ? ntilesf : wide ? ntiles2 : ntiles;
   const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits);
-  const uint32_t tb = (uint32_t)(p / (wide ? 2 * TB : TB));
+  const uint32_t tb = (uint32_t)(p >> (31 - __clz((int)(mode == 3 ? small_tile : fine ? (uint32_t)TBF : (wide ? 2 * TB : TB)))));
   uint32_t te = tb;
   if (s != 0 && e > s) {  // live and not zero-length
     te = last_tile_below(tx, nt, tb, e);
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(EW_THREADS) void route_fill_kernel(
   uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
   if (p >= n) return;
   const uint32_t te = te_in[p];
-  const uint32_t tb = (uint32_t)(p / tile_size);
+  const uint32_t tb = (uint32_t)(p >> (31 - __clz((int)tile_size)));  // (a power of two)
   if (te <= tb) return;
   const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits), k = KEY[p];
   const uint32_t id = I[p];
@@ -526,8 +542,9 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
   __shared__ uint64_t skey[TBT];      // its score key
   __shared__ uint32_t sid[TBT];   // its interval index
   __shared__ uint64_t wmax[TBT / 64];
-  __shared__ uint64_t ls[CCAP], le[CCAP], lkey[CCAP];  // candidate carry-ins
-  __shared__ uint32_t lid[CCAP];
+  constexpr int CC = CCAP < TBT ? CCAP : TBT;  // candidate carry-ins kept in LDS: one per thread at most (small tiles)
+  __shared__ uint64_t ls[CC], le[CC], lkey[CC];  // candidate carry-ins
+  __shared__ uint32_t lid[CC];
   __shared__ uint32_t l_count;
   __shared__ uint64_t r_k[TBT / 64], r_s[TBT / 64], r_e[TBT / 64];
   __shared__ uint32_t r_i[TBT / 64], r_have[TBT / 64];
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
         have_star = true;
       }
   };
-  if (n_carry != 0 && n_carry <= CCAP) {  // block-uniform.  The usual case: the whole list goes to LDS as it is
+  if (n_carry != 0 && n_carry <= (uint32_t)CC) {  // block-uniform.  The usual case: the whole list goes to LDS as it is
     const bool mine = (uint32_t)tid < n_carry;
     uint64_t cs_ = 0, ce_ = 0, ck_ = 0;
     uint32_t ci_ = 0;
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
         const uint32_t id = a.c_id[c];
         if (!have_star || prio_less(k, s, id, star_k, star_s, star_i)) {
           const uint32_t slot = atomicAdd(&l_count, 1u);
-          if (slot < CCAP) {
+          if (slot < (uint32_t)CC) {
             ls[slot] = s;
             le[slot] = e;
             lkey[slot] = k;
@@ -680,9 +697,9 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
   } else if (n_carry != 0) {
     __syncthreads();
   }
-  if (n_carry > CCAP) {
+  if (n_carry > (uint32_t)CC) {
     n_cc = l_count;
-    cc_in_lds = n_cc <= CCAP;  // else: every carry-in is scanned from global memory (a superset is harmless)
+    cc_in_lds = n_cc <= (uint32_t)CC;  // else: every carry-in is scanned from global memory (a superset is harmless)
   }
   const bool cc_complete = cc_in_lds && !have_star;  // the LDS list holds every carry-in of the tile
   const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TBT - 1) / TBT);
@@ -1459,7 +1476,8 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint64_t* S = nullptr;
   uint32_t* I = nullptr;
   uint32_t* E = nullptr;  // end coordinates, in one of the sort's u64 scratch buffers
-  uint64_t *KEY = nullptr, *tile_x = nullptr;
+  uint64_t *KEY = nullptr, *tile_x = nullptr, *tile_xf = nullptr;  // tile-start keys of the 256-begin / TBF-begin tilings
+  const uint32_t ntilesf = (uint32_t)((n + TBF - 1) / TBF);
   uint8_t* single = nullptr;
   auto sort_begins = [&]() -> int {
     S = swg_alloc<uint64_t>(ctx, n);
@@ -1468,6 +1486,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     uint32_t* I2 = swg_alloc<uint32_t>(ctx, n);
     KEY = swg_alloc<uint64_t>(ctx, n);
     tile_x = swg_alloc<uint64_t>(ctx, (size_t)ntiles + 1);
+    tile_xf = swg_alloc<uint64_t>(ctx, (size_t)ntilesf + 1);
     single = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
     // the sort's digit histograms come out of begin_build (when the onesweep path will run: up to 8 passes)
@@ -1503,13 +1522,15 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, st));
       SWG_LAUNCH(ctx, "begin_gather_words", begin_gather_words_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
                                          n, P, idx_bits, drop, in.packed, in.packed_end, in.pos_bits, other, I, reinterpret_cast<uint32_t*>(third), KEY,
-                                         tile_x, single, reinterpret_cast<uint32_t*>(d_flag)));
+                                         tile_xf, single, reinterpret_cast<uint32_t*>(d_flag)));
       SWG_KERNEL_CHECK(ctx);
       uint64_t long_run = 0;
       SWG_TRY(swg_read_scalars(ctx, d_flag, &long_run, 1));
       if ((uint32_t)long_run == 0) {
         S = other;
         E = reinterpret_cast<uint32_t*>(third);
+        SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
+        SWG_KERNEL_CHECK(ctx);
         if (in.sorted_idx_out) {
           SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
           if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
@@ -1543,7 +1564,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       S = other;
       E = reinterpret_cast<uint32_t*>(third);
       SWG_LAUNCH(ctx, "begin_gather_packed", begin_gather_packed_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                          n, P, idx_bits, in.packed, in.packed_end, in.pos_bits, S, I, E, KEY, tile_x, single));
+                                          n, P, idx_bits, in.packed, in.packed_end, in.pos_bits, S, I, E, KEY, tile_xf, single));
       SWG_KERNEL_CHECK(ctx);
     } else if (prc != SWG_ERR_UNSUPPORTED) {
       return prc;
@@ -1551,9 +1572,11 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_TRY(swg_radix_sort_pairs(ctx, &S, &I, &S2, &I2, n, 0, key_bits, prehist));
       E = reinterpret_cast<uint32_t*>(S2);  // the sort's scratch key buffer is free again
       SWG_LAUNCH(ctx, "begin_gather", begin_gather_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                          n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_x, single));
+                                          n, S, I, in.end, in.score_key, in.packed, in.packed_end, in.pos_bits, E, KEY, tile_xf, single));
       SWG_KERNEL_CHECK(ctx);
     }
+    SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
+    SWG_KERNEL_CHECK(ctx);
     if (in.sorted_idx_out) {
       SWG_HIP(ctx, hipMemcpyAsync(in.sorted_idx_out, I, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
       if (in.sorted_idx_valid) *in.sorted_idx_valid = 1;
@@ -1583,15 +1606,21 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* te = swg_alloc<uint32_t>(ctx, n);
   const size_t n_pad = ((size_t)n + 255) & ~size_t(255);  // keeps `ovl` 16-byte aligned for combine's vector loads
   uint8_t* flags = swg_alloc<uint8_t>(ctx, 2 * n_pad);  // top | ovl
-  uint32_t* cnts = swg_alloc<uint32_t>(ctx, 2 * ((size_t)ntiles + 1));  // carry_cnt | carry_cur
+  // SWG_TILE_SMALL=64|128 (experiment knob): k = 1 tiles of that many begins -- a work-group of one or two wavefronts
+  static const int small_knob = getenv("SWG_TILE_SMALL") ? atoi(getenv("SWG_TILE_SMALL")) : 0;
+  const uint32_t small_tile = (k == 1 && ntiles > 1 && (small_knob == 64 || small_knob == 128)) ? (uint32_t)small_knob : 0u;
+  static const bool force512_ = getenv("SWG_TILE_512") != nullptr, force256_ = getenv("SWG_TILE_256") != nullptr;
+  const bool auto_tile = k == 1 && ntiles > 1 && !small_tile && !force512_ && !force256_;  // chosen on the device: 128 / 256 / 512
+  const uint32_t nt_max = small_tile ? (uint32_t)((n + small_tile - 1) / small_tile) : auto_tile ? ntilesf : ntiles;  // finest tiling in use
+  uint32_t* cnts = swg_alloc<uint32_t>(ctx, 2 * ((size_t)nt_max + 1));  // carry_cnt | carry_cur
   uint64_t* d_total = swg_alloc<uint64_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   uint8_t* top = flags;
   uint8_t* ovl = flags + n_pad;
   uint32_t* carry_cnt = cnts;
-  uint32_t* carry_cur = cnts + ((size_t)ntiles + 1);
+  uint32_t* carry_cur = cnts + ((size_t)nt_max + 1);
   SWG_HIP(ctx, hipMemsetAsync(flags, 0, 2 * n_pad, st));
-  SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 2 * ((size_t)ntiles + 1), st));
+  SWG_HIP(ctx, hipMemsetAsync(cnts, 0, sizeof(uint32_t) * 2 * ((size_t)nt_max + 1), st));
   // Deep data (a tile's carry-in list is long: one chromosome pair at depth 165 has ~150 per 256-begin tile): tiles of 512
   // begins -- half as many carry-in entries to route and stage, half as many tiles -- are faster there for k = 1 (S-big1 sweep
   // 9.6 -> 8.8 ms) and slower on sparse data (S-pan's tile kernel 3.0 -> 3.7 ms), so the tiling is chosen by an estimate of
@@ -1604,7 +1633,14 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint64_t* tile_x2 = tile_x;
   uint32_t ntiles2 = ntiles;
   SWG_HIP(ctx, hipMemsetAsync(d_total, 0, 2 * sizeof(uint64_t), st));
-  if (k == 1 && ntiles > 1) {
+  if (small_tile) {
+    mode = 3;
+    ntiles2 = nt_max;
+    tile_x2 = swg_alloc<uint64_t>(ctx, (size_t)ntiles2 + 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "tile_x_stride", tile_x_stride_kernel<<<blocks_for(ntiles2, EW_THREADS), EW_THREADS, 0, st>>>(ntiles2, S, small_tile, tile_x2));
+    SWG_KERNEL_CHECK(ctx);
+  } else if (k == 1 && ntiles > 1) {
     static const bool force512 = getenv("SWG_TILE_512") != nullptr, force256 = getenv("SWG_TILE_256") != nullptr;
     mode = force512 ? 1 : force256 ? 0 : 2;
     if (mode) {
@@ -1622,17 +1658,31 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   }
   SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
                                      n, S, E, in.pos_bits, tile_x, ntiles, tile_x2, ntiles2, mode, reinterpret_cast<unsigned long long*>(d_total + 1),
-                                     EST_STRIDE, te, carry_cnt));
+                                     EST_STRIDE, te, carry_cnt, small_tile, tile_xf, ntilesf));
   SWG_KERNEL_CHECK(ctx);
-  // (scanned over the 256-begin tiling's length either way: the entries past a 512-begin tiling's end are zero)
-  SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)ntiles + 1, d_total));
+  // (scanned over the finest tiling's length either way: the entries past a coarser tiling's end are zero)
+  SWG_TRY(swg_exclusive_scan_u32(ctx, carry_cnt, carry_cnt, (uint64_t)nt_max + 1, d_total));
   uint64_t h2[2] = {0, 0};
   SWG_TRY(swg_read_scalars(ctx, d_total, h2, 2));
   const uint64_t n_carry = h2[0];
-  if (mode == 1 || (mode == 2 && h2[1] * EST_STRIDE / ntiles >= DEEP_CARRY_PER_TILE)) {  // the kernel's rule
+  if (mode == 3) {
+    tile_size = small_tile;
+    tile_x = tile_x2;
+    ntiles = ntiles2;
+  } else if (mode == 2 && h2[1] * EST_STRIDE / ntiles < SPARSE_CARRY_PER_TILE) {  // the kernel's rule (sparse)
+    tile_size = TBF;
+    tile_x = tile_xf;
+    ntiles = ntilesf;
+  } else if (mode == 1 || (mode == 2 && h2[1] * EST_STRIDE / ntiles >= DEEP_CARRY_PER_TILE)) {  // the kernel's rule (deep)
     tile_size = 2 * TB;
     tile_x = tile_x2;
     ntiles = ntiles2;
+  }
+  {
+    static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+    if (dbg && mode == 2)
+      fprintf(stderr, "[swg] sweep: n %llu, estimated carry-ins per 256-begin tile %.2f -> tiles of %u begins, %llu carry-ins\n",
+              (unsigned long long)n, (double)h2[1] * EST_STRIDE / (double)((n + TB - 1) / TB), tile_size, (unsigned long long)n_carry);
   }
   uint64_t* c_s = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_e = swg_alloc<uint64_t>(ctx, n_carry + 1);
@@ -1664,7 +1714,11 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   ta.ovl = ovl;
   ta.tile_done = nullptr;
   if (k == 1) {
-    if (tile_size == (uint32_t)TB)
+    if (tile_size == 64u)
+      SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<64><<<ntiles, 64, 0, st>>>(ta));
+    else if (tile_size == 128u)
+      SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<128><<<ntiles, 128, 0, st>>>(ta));
+    else if (tile_size == (uint32_t)TB)
       SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<TB><<<ntiles, TB, 0, st>>>(ta));
     else
       SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<2 * TB><<<ntiles, 2 * TB, 0, st>>>(ta));
