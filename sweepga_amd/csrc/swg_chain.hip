@@ -617,6 +617,12 @@ struct CandScan {
   uint32_t count, ext, cut_at;
   bool cut;
 };
+// |a - b|, one instruction (the compiler expands the generic form to min / max / sub)
+__device__ __forceinline__ uint32_t absdiff_vv(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // |a - b| of a per-lane and a wave-uniform value: one instruction (the compiler expands the generic form to min / max / sub)
 __device__ __forceinline__ uint32_t absdiff_vs(uint32_t v, uint32_t s) {
   uint32_t r;
@@ -662,6 +668,10 @@ __device__ __forceinline__ void cand_scan_fast(uint32_t p, uint32_t e, uint32_t 
   uint32_t vgap = gap, vfifth = fifth;
   asm volatile("" : "+v"(vgap), "+v"(vfifth));
   if (p + 1u < e) {
+    // (one exit, decided by scalar arithmetic, and the two ways out told apart afterwards: two `break`s with their own
+    // epilogues come out of the compiler as a chain of flag registers and half a dozen branches per batch)
+    uint64_t wmask;
+    uint32_t c;
     for (;;) {
       const uint32_t qs_j = n_qs, r_j = n_r;
       voff += 256u;  // the next batch is requested before this one is evaluated
@@ -669,7 +679,7 @@ __device__ __forceinline__ void cand_scan_fast(uint32_t p, uint32_t e, uint32_t 
       n_r = *reinterpret_cast<const uint32_t*>(pr + voff);
       // sorted by q_start (paf_filter.rs:794-796): the window is a prefix
       const bool in_e = vj < e, in_b = qs_j <= bound;
-      const uint64_t wmask = __builtin_amdgcn_ballot_w64(in_e) & __builtin_amdgcn_ballot_w64(in_b);
+      wmask = __builtin_amdgcn_ballot_w64(in_e) & __builtin_amdgcn_ballot_w64(in_b);
       const uint32_t aq = absdiff_vs(qs_j, qe_i);
       const bool q_ge = qs_j >= qe_i;
       const uint32_t lim_q = q_ge ? vgap : vfifth;  // a gap may reach the limit, an overlap a fifth of it
@@ -696,7 +706,11 @@ __device__ __forceinline__ void cand_scan_fast(uint32_t p, uint32_t e, uint32_t 
       d = in_b ? d : EMPTY;
       if (count <= (uint32_t)KC) count += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d != EMPTY));
       uint64_t cmask = __builtin_amdgcn_ballot_w64(d < sd3);
-      bool c = ((uint32_t)(cutmask >> 32) >> 31) != 0u;
+      {  // lane 63's bit (through an opaque move: the compiler otherwise turns it into a 64-bit sign test on the vector unit)
+        uint32_t hi = (uint32_t)(cutmask >> 32);
+        asm("" : "+s"(hi));
+        c = hi >> 31;
+      }
       if (cmask) {
         do {
           const int l = __builtin_ctzll(cmask);
@@ -721,23 +735,26 @@ __device__ __forceinline__ void cand_scan_fast(uint32_t p, uint32_t e, uint32_t 
           const uint32_t q_last = readlane_u32(qs_j, 63);
           if (q_last >= qe_i) {
             const uint64_t qg = (uint64_t)q_last - qe_i;
-            c = (uint64_t)sd3 <= qg * qg;
+            // (readfirstlane: a 64-bit compare of uniform values is done on the vector unit and would make `c`, and with it
+            // the loop's exit test, a per-lane value)
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((uint64_t)sd3 <= qg * qg ? 1 : 0);
           }
         }
       }
-      if (wmask != ~0ull) {  // the window ended inside these 64, or the group did (a batch past the group's end is empty)
-        ext = readlane_u32(vj, 0) - (p + 1u) + (uint32_t)__popcll(wmask);
-        break;
-      }
-      // every later element starts at or after this batch's last one: its query gap is at least `qg`; with KC entries held
-      // at distance <= qg^2 no later j can enter the list (d >= qg^2; equal distances keep the smaller j)
-      if (c) {
-        cut_at = readlane_u32(vj, 0) + 64u;
-        cut = cut_at < e;  // (a full batch that ends the group: nothing was cut, the counts are exact)
-        if (!cut) ext = cut_at - (p + 1u);
-        break;
-      }
+      // the window ended inside these 64, or the group did (a batch past the group's end is empty); or the cut: every later
+      // element starts at or after this batch's last one, so its query gap is at least `qg`, and with KC entries held at
+      // distance <= qg^2 no later j can enter the list (d >= qg^2; equal distances keep the smaller j)
+      const uint64_t nw = ~wmask;
+      if (((uint32_t)nw | (uint32_t)(nw >> 32) | c) != 0u) break;
       vj += 64u;
+    }
+    const uint32_t j_first = readlane_u32(vj, 0);  // of the last batch
+    if (wmask != ~0ull) {
+      ext = j_first - (p + 1u) + (uint32_t)__popcll(wmask);
+    } else {
+      cut_at = j_first + 64u;
+      cut = cut_at < e;  // (a full batch that ends the group: nothing was cut, the counts are exact)
+      if (!cut) ext = cut_at - (p + 1u);
     }
   }
   auto wide = [](DT v) { return v == EMPTY ? ~0ull : (uint64_t)v; };
@@ -1621,7 +1638,10 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
   constexpr bool spec = SPEC;
   __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this range sees them
   __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end
-  __shared__ uint32_t hcnt[WALK_HASH];
+  __shared__ uint32_t hcnt[WALK_HASH];   // lowest lane naming a j that hashes here
+  __shared__ uint32_t hnum[WALK_HASH];   // ... and how many lanes do
+  __shared__ unsigned long long l_fd[64];  // the lanes' first choices, for the lanes that share a slot with one other lane
+  __shared__ uint32_t l_fj[64];
   const int lane = threadIdx.x;
   const uint64_t INF = ~0ull;
   const uint64_t fifth = max_gap / 5;
@@ -1629,7 +1649,10 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
   const uint32_t fifth32 = fifth > 0xffffffffull ? 0xffffffffu : (uint32_t)fifth;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
-  for (int k = lane; k < WALK_HASH; k += 64) hcnt[k] = 0;
+  for (int k = lane; k < WALK_HASH; k += 64) {
+    hcnt[k] = 0xffffffffu;
+    hnum[k] = 0;
+  }
   wave_lds_sync();
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
@@ -1747,25 +1770,23 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       const uint32_t e_i = cur.ei;  // end of the element's (query, target, strand) group inside the range
       if (FUSED && valid) {
         // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic, selects instead of branches (as in chain_candidates_wave_kernel)
-        const uint32_t qe_i = cur.qe, ts_i = cur.ts, te_i = cur.te;
+        const uint32_t qe_i = cur.qe;
         const bool minus = cur.minus != 0;
         const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // wrapping, as release Rust
         const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
-        for (uint32_t j = i + 1; j < e_i; ++j) {
-          const bool inr = j - base < (uint32_t)BIGW;
-          const uint32_t qs_j = inr ? rq[j % BIGW] : s_qs[j];
-          if (qs_j > bound) break;  // sorted by q_start (paf_filter.rs:794-796)
-          const uint32_t ts_j = inr ? rt[j % BIGW] : s_ts[j], te_j = inr ? re[j % BIGW] : s_te[j];
-          const bool q_ge = qs_j >= qe_i;
-          const uint32_t q_ov = qe_i - qs_j;
-          const bool q_in = q_ge | (q_ov <= fifth32);
-          const uint32_t q_gap = q_ge ? qs_j - qe_i : (q_in ? q_ov : 0u);
-          const uint32_t ra = minus ? ts_i : ts_j, rb = minus ? te_j : te_i;
-          const bool r_ge = ra >= rb;
-          const uint32_t r_ov = rb - ra;
-          const bool r_in = r_ge | (r_ov <= fifth32);
-          const uint32_t r_gap = r_ge ? ra - rb : (r_in ? r_ov : 0u);
-          if (!((q_in | wrap) & (r_in | wrap) & (q_gap <= gap32) & (r_gap <= gap32))) continue;
+        // the target coordinates that enter d(i, j): plus strand t_start[j] against t_end[i], minus strand t_end[j] against
+        // t_start[i] -- chosen once per element (two LDS reads per j instead of three)
+        const uint32_t r_i = minus ? cur.ts : cur.te;
+        const uint32_t* r_ring = minus ? re : rt;
+        const uint32_t* __restrict__ r_mem = minus ? s_te : s_ts;
+        // one j: a gap is |a - b|; it passes when it is at most the limit on the gap side, a fifth of the limit on the
+        // overlap side (the predicate of paf_filter.rs:798-836; with the limit at u64::MAX both bounds are 2^32 - 1:
+        // everything passes)
+        auto consider = [&](uint32_t j, uint32_t qs_j, uint32_t r_j) {
+          const uint32_t q_gap = absdiff_vv(qs_j, qe_i), r_gap = absdiff_vv(r_j, r_i);
+          const uint32_t lim_q = qs_j >= qe_i ? gap32 : fifth32;
+          const uint32_t lim_r = (minus ? r_j <= r_i : r_j >= r_i) ? gap32 : fifth32;
+          if ((q_gap > lim_q) | (r_gap > lim_r)) return;
           const uint64_t d = (uint64_t)q_gap * q_gap + (uint64_t)r_gap * r_gap;  // wrapping, as release Rust
           if (nv <= (uint32_t)KC) ++nv;
           if (d < bd[KC - 1]) {  // insert keeping (d asc, j asc), see chain_candidates_kernel
@@ -1785,7 +1806,28 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
               }
             }
           }
+        };
+        // The window in two stretches: the part inside the ring (nearly always all of it) reads LDS, both coordinates of a
+        // step requested together; what lies beyond reads memory.  One loop with `in the ring ? LDS : memory` per load is
+        // compiled to flat loads of a selected pointer, two dependent ones per step with a full wait each.
+        const uint32_t e_ring = min(e_i, base + (uint32_t)BIGW);
+        uint32_t j = i + 1;
+        bool open = true;  // the window has not ended yet
+        for (; j < e_ring; ++j) {
+          uint32_t qs_j = rq[j % BIGW], r_j = r_ring[j % BIGW];
+          asm volatile("" : "+v"(qs_j), "+v"(r_j));  // both reads issued here, one wait (the second would sink below the test)
+          if (qs_j > bound) {  // sorted by q_start (paf_filter.rs:794-796)
+            open = false;
+            break;
+          }
+          consider(j, qs_j, r_j);
         }
+        if (open)
+          for (; j < e_i; ++j) {
+            const uint32_t qs_j = s_qs[j];
+            if (qs_j > bound) break;
+            consider(j, qs_j, r_mem[j]);
+          }
       }
       // ---- acc bits and the first acceptable candidate
       uint32_t acc = 0;
@@ -1801,12 +1843,32 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           fj = bj[c];
         }
       // ---- lanes that share their j with another lane (hash filter; superset), and lanes that need their whole window
-      uint32_t* slot = &hcnt[fj & (WALK_HASH - 1)];
-      if (fj != NONE) atomicAdd(slot, 1u);
+      // (the slot keeps the LOWEST lane that names a j hashing there: that lane's choice stands unless a lower lane moves to
+      // its j later -- which puts it on the list then --, so only the other lanes of the slot start on the work list; and
+      // when the slot has exactly two lanes, the higher one only if the lower one really blocks it: same j, distance not
+      // larger than its own.  That second test is worth its LDS traffic in the blocks of long units (S-big1 chain_walk_spec
+      // 6.2 -> 5.8 ms: 40 % fewer lanes on the list) and not in the chunks of short ones (S-pan chain_walk 3.2 -> 3.3 ms).)
+      constexpr bool PAIR_TEST = SPEC;
+      const uint32_t hs = fj & (WALK_HASH - 1);
+      if (fj != NONE) {
+        atomicMin(&hcnt[hs], (uint32_t)lane);
+        if (PAIR_TEST) atomicAdd(&hnum[hs], 1u);
+      }
+      if (PAIR_TEST) {
+        l_fd[lane] = fd;
+        l_fj[lane] = fj;
+      }
       wave_lds_sync();
-      const bool shared_j = fj != NONE && *slot > 1u;
+      bool shared_j = false;
+      if (fj != NONE) {
+        const uint32_t low = hcnt[hs];
+        if (low != (uint32_t)lane) shared_j = !PAIR_TEST || hnum[hs] > 2u || (l_fj[low] == fj && (uint64_t)l_fd[low] <= fd);
+      }
       wave_lds_sync();
-      if (fj != NONE) *slot = 0;
+      if (fj != NONE) {
+        hcnt[hs] = 0xffffffffu;
+        if (PAIR_TEST) hnum[hs] = 0;
+      }
       uint64_t work = __ballot(shared_j || (fj == NONE && nv > (uint32_t)KC));
       if (wstats && lane == 0) {  // SWG_WALK_STATS: batches, lanes on the work list
         atomicAdd(&wstats[0], 1ull);
@@ -1921,7 +1983,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           fj = nj;
         }
         if (nj != NONE && nj != old_j) {
-          const uint64_t woken = __ballot(fj == nj) & ~lower & ~(1ull << l);  // higher lanes holding the new j
+          const uint64_t woken = __ballot(fj == nj && fd >= nd) & ~lower & ~(1ull << l);  // higher lanes holding the new j that it blocks
           if (wstats && lane == 0) atomicAdd(&wstats[4], (unsigned long long)__popcll(woken & ~work));
           work |= woken;
         }
