@@ -246,7 +246,8 @@ __global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const
                                                                uint32_t* __restrict__ s_qs, uint32_t* __restrict__ s_qe,
                                                                uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                                uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
-                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt) {
+                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt,
+                                                               const swg_key_ends* __restrict__ slots) {
   const uint32_t lb = swg_xcd_block(blockIdx.x, gridDim.x);
   const uint64_t a = (uint64_t)lb * EW + threadIdx.x;
   bool pf = false, gf = false;
@@ -254,7 +255,23 @@ __global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const
     const uint64_t w = P[a];
     const uint32_t i = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
     const uint64_t hi = w >> idx_bits;  // key >> 8
-    const uint32_t qs = q_start[i], qe = q_end[i], ts = t_start[i], te = t_end[i], mt = matches[i], bl = block_len[i];
+    uint32_t qs, qe, ts, te, mt, bl;
+    if (slots) {  // the record's 32-byte slot (prepare_kernel): one line from L2 instead of six
+      const swg_key_ends ke = slots[i];
+      qs = ke.start[0];
+      ts = ke.start[1];
+      qe = ke.end[0];
+      te = ke.end[1];
+      mt = ke.pad[0];
+      bl = ke.pad[1];
+    } else {
+      qs = q_start[i];
+      qe = q_end[i];
+      ts = t_start[i];
+      te = t_end[i];
+      mt = matches[i];
+      bl = block_len[i];
+    }
     keyA[a] = (hi << 8) | (uint64_t)(qs & 0xffu);
     idxA[a] = i;
     s_qs[a] = qs;
@@ -290,7 +307,10 @@ __global__ __launch_bounds__(EW) void gather_all_words_kernel(uint64_t M, const 
                                                               uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                               uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt,
-                                                              unsigned long long* __restrict__ long_run) {
+                                                              unsigned long long* __restrict__ long_run,
+                                                              const swg_key_ends* __restrict__ slots) {
+  // slots != nullptr: the six columns of a record from its 32-byte slot (prepare_kernel) -- one line from L2 per record
+  // instead of six
   constexpr int H = SWG_RUN_HALO, W = EW + 2 * H;
   __shared__ uint64_t l_hi[W];   // key >> drop, + 1 (0: no element at this position)
   __shared__ uint64_t l_ord[W];  // (low bits of q_start << 32) | record index
@@ -306,12 +326,22 @@ __global__ __launch_bounds__(EW) void gather_all_words_kernel(uint64_t M, const 
     const uint64_t w = P[a];
     hi = (w >> idx_bits) + 1;  // (+1: a key of 0 is a real key here -- sequence 0 onto itself at coordinate < 2^drop)
     i = (uint32_t)(w & idx_mask);
-    qs = q_start[i];
-    qe = q_end[i];
-    ts = t_start[i];
-    te = t_end[i];
-    mt = matches[i];
-    bl = block_len[i];
+    if (slots) {
+      const swg_key_ends ke = slots[i];
+      qs = ke.start[0];
+      ts = ke.start[1];
+      qe = ke.end[0];
+      te = ke.end[1];
+      mt = ke.pad[0];
+      bl = ke.pad[1];
+    } else {
+      qs = q_start[i];
+      qe = q_end[i];
+      ts = t_start[i];
+      te = t_end[i];
+      mt = matches[i];
+      bl = block_len[i];
+    }
   }
   l_hi[H + t] = hi;
   l_ord[H + t] = ((uint64_t)(qs & low_mask) << 32) | i;
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(EW) void gather_all_words_kernel(uint64_t M, const 
     const uint64_t edge = left ? l_hi[H] : l_hi[H + EW - 1];
     if (edge != 0 && l_hi[li] == edge) {
       const uint32_t hid = (uint32_t)l_ord[li];
-      l_ord[li] = ((uint64_t)(q_start[hid] & low_mask) << 32) | hid;
+      l_ord[li] = ((uint64_t)((slots ? slots[hid].start[0] : q_start[hid]) & low_mask) << 32) | hid;
     }
   }
   __syncthreads();
@@ -2395,11 +2425,11 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_LAUNCH(ctx, "gather_all_words", gather_all_words_kernel<<<nblk(M), EW, 0, st>>>(
                                           M, packedA, packed_idx_bits, dropA, r->q_start, r->q_end, r->t_start, r->t_end, r->matches,
                                           r->block_len, pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt,
-                                          reinterpret_cast<unsigned long long*>(blk_cnt + n_blk)));
+                                          reinterpret_cast<unsigned long long*>(blk_cnt + n_blk), slots));
       } else if (packedA) {
         SWG_LAUNCH(ctx, "gather_all_packed", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
                                           M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
-                                          pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt));
+                                          pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt, slots));
       } else {
         SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
                                                                    r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,

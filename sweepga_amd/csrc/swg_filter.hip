@@ -208,15 +208,25 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   if (n == 0) return SWG_OK;
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
-  // score keys and ends are what the mapping-level sweep sorts and ranks by: with both limits infinite (the CLI defaults)
-  // nothing sweeps, and the 16 bytes per record are neither computed nor stored
+  // The 32-byte record slots (both starts, both ends, score key, matches, block length).  The mapping-level sweep sorts and
+  // ranks by them.  With both limits infinite (the CLI defaults) nothing sweeps and the score keys are not computed; the
+  // scaffold stage's gather after its first sort can still take a record's six columns from ONE slot instead of six
+  // scattered 4-byte reads, each of which moves a 128-byte line from L2.  Whether that pays depends on where those reads hit:
+  // the gather walks the records pair by pair, so with ~10^4 records per sequence pair (S-pan) a pair's columns sit in L2 and
+  // the slots only move the cost (gather_all_words 3.3 -> 2.4 ms, prepare 0.8 -> 1.6 ms, 6.4 GB more traffic), while one pair
+  // of 10^7 records (S-big1) has no such locality (1.20 -> 0.31 ms for 0.02 ms more in prepare).  Chosen by the records per
+  // POSSIBLE sequence pair, which is all that is known before the first kernel; SWG_SLOTS=1 / 0 force either (test knobs).
   uint64_t kq0, kt0;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq0, &kt0);
-  swg_key_ends* key_ends = (kq0 == SWG_K_INF && kt0 == SWG_K_INF) ? nullptr : swg_alloc<swg_key_ends>(ctx, n);
+  const bool sweeps = !(kq0 == SWG_K_INF && kt0 == SWG_K_INF);
+  static const int slots_knob = getenv("SWG_SLOTS") ? atoi(getenv("SWG_SLOTS")) : -1;
+  const uint64_t pairs_ub = (uint64_t)r->n_seq * r->n_seq ? (uint64_t)r->n_seq * r->n_seq : 1;
+  const bool deep_pairs = slots_knob >= 0 ? slots_knob != 0 : n / pairs_ub >= (uint64_t(1) << 17);
+  swg_key_ends* key_ends = (sweeps || (cfg->scaffold_gap != 0 && deep_pairs)) ? swg_alloc<swg_key_ends>(ctx, n) : nullptr;
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
-  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, scalars));
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, sweeps, scalars));
   uint64_t h[3];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 3));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
@@ -249,7 +259,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     return SWG_OK;
   }
   return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1],
-                            key_ends);  // (nullptr when nothing sweeps: the all-members gather reads the columns)
+                            key_ends);
 }
 
 static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {

@@ -309,5 +309,5 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
                    const double* identity, int scoring, uint64_t* key_out);
 // Step-1 retain (src/paf_filter.rs:384-388), score keys and the two scalars the pipeline needs, in one pass over
 // the records: scalars[0] = max coordinate, scalars[1] = number of retained records (device u64, pre-zeroed).
-int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends,
+int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
                 unsigned long long* scalars);

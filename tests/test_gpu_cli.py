@@ -80,7 +80,8 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
     assert (tmp_path / "py.paf").read_bytes() == want
 
 
-@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_SORT_PAIRS", "SWG_SORT_BITS8", "SWG_CHAIN_DEEP", "SWG_CHAIN_OLD", "SWG_KN_PLAIN", "SWG_TILE_512"])
+@pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_SORT_PAIRS", "SWG_SORT_BITS8", "SWG_CHAIN_DEEP", "SWG_CHAIN_OLD", "SWG_KN_PLAIN", "SWG_TILE_512",
+                                  "SWG_TILE_256", "SWG_SLOTS", "SWG_CHAIN_DEEP+SWG_CAND_GENERIC"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
     onesweep pass (otherwise only used for n >= 2^30), SWG_SORT_PAIRS=1 keeps the sweep's begins in 12-byte (key, index) pairs
@@ -89,7 +90,11 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     instead of the batch walk, SWG_CHAIN_DEEP=1 the wavefront-per-element candidate kernel of deep
     chaining groups (otherwise only used when groups average more than 8192 mappings), SWG_KN_PLAIN=1 sends every tile of a
     2 <= k < inf sweep through the plain tile kernel (otherwise only the tiles the pruned kernel leaves), SWG_TILE_512=1 gives
-    every k = 1 sweep 512-begin tiles (otherwise only deep data: 64 carry-ins per 256-begin tile on average)."""
+    every k = 1 sweep 512-begin tiles (otherwise only deep data: 64 carry-ins per 256-begin tile on average), SWG_TILE_256=1
+    256-begin tiles (otherwise 128-begin ones on sparse data like this), SWG_SLOTS=1 writes the 32-byte record slots also when
+    nothing sweeps and has the scaffold stage's first gather read them (otherwise only with >= 2^17 records per possible
+    sequence pair), SWG_CAND_GENERIC=1 keeps the deep candidate kernel on its generic batch loop (otherwise only for gap limits
+    of 2^31 and more)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)
@@ -98,7 +103,7 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     for k, flags in enumerate(FLAG_SETS[:5] + [["--num-mappings", "3:2", "--scaffold-jump", "0"]]):
         o1, o2 = tmp_path / f"gpu{k}.paf", tmp_path / f"ref{k}.paf"
         r = subprocess.run([cli, str(paf), "--output-file", str(o1), "--quiet", *flags], capture_output=True, text=True,
-                           env={**os.environ, knob: "1"})
+                           env={**os.environ, **{k1: "1" for k1 in knob.split("+")}})
         assert r.returncode == 0, r.stderr
         subprocess.check_call([ref, str(paf), "--output-file", str(o2), *flags])
         assert o1.read_bytes() == o2.read_bytes(), flags
