@@ -428,6 +428,13 @@ __global__ __launch_bounds__(EW) void chain_ok_kernel(uint64_t m, const uint32_t
 // its members' values in registers: no seeding pass over all elements, no atomics, no pointer-jumping rounds, and the span /
 // identity filter (paf_filter.rs:449-455) is decided right there; only passing heads write aggregates.
 constexpr int LABEL_CAP = (int)(WALK_CHUNK + BIG_UNIT);  // a chunk holds fewer elements than this
+// Round 4: chunks of up to LABEL_FAST elements (nearly all: a chunk is ~WALK_CHUNK elements plus the tail of its last unit)
+// first bring every element's five values into LDS with coalesced loads, and the heads then walk their chains in LDS.  With
+// the values in memory a head's step was five scattered loads issued for the few lanes still walking -- 33 vector-memory
+// instructions per 64 elements, most of them nearly empty, and the texture path was what the kernel waited for (SQ counters).
+// The head of every element goes through LDS as well and is written in element order.  Longer chunks take the old path.
+constexpr int LABEL_FAST = 1536;
+static_assert(LABEL_FAST * (2 + 2 + 5 * 4) >= LABEL_CAP * 2, "the two layouts share one LDS buffer");
 __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, const SpecBlock* __restrict__ chunks,
                                                          const uint32_t* __restrict__ pred,
                                                          const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
@@ -437,7 +444,14 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
                                                          uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
                                                          uint8_t* __restrict__ ok_head, HeadRec* __restrict__ rec,
                                                          unsigned long long* __restrict__ n_heads) {
-  __shared__ uint16_t succ[LABEL_CAP];
+  __shared__ uint32_t lds[LABEL_FAST * 6];  // 36,864 bytes
+  uint16_t* succ = reinterpret_cast<uint16_t*>(lds);            // [LABEL_CAP] (long chunks) / [LABEL_FAST]
+  uint16_t* l_hd = succ + LABEL_FAST;                           // head of every element, relative to the chunk
+  uint32_t* l_qe = lds + LABEL_FAST;                            // (behind the two 16-bit arrays)
+  uint32_t* l_ts = l_qe + LABEL_FAST;
+  uint32_t* l_te = l_ts + LABEL_FAST;
+  uint32_t* l_m = l_te + LABEL_FAST;
+  uint32_t* l_b = l_m + LABEL_FAST;
   constexpr uint16_t NO = 0xffffu;
   uint32_t heads = 0;  // chains headed in this thread's elements (a statistic: all chains, passing the filter or not)
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -446,6 +460,81 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < len; k += EW) succ[k] = NO;
     __syncthreads();
+    if (len <= (uint32_t)LABEL_FAST) {
+      // every load of the chunk is requested before the first value is used (U x 7 per thread): a thread's elements one after
+      // the other would be U memory round trips in a row, per phase
+      constexpr int U = LABEL_FAST / EW;
+      uint32_t r_pr[U], r_qe[U], r_ts[U], r_te[U], r_m[U], r_b[U], r_qs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        const uint32_t p = b + (k < len ? k : 0u);  // (clamped: a read that is not used)
+        r_pr[u] = pred[p];
+        r_qe[u] = s_qe[p];
+        r_ts[u] = s_ts[p];
+        r_te[u] = s_te[p];
+        r_m[u] = s_m[p];
+        r_b[u] = s_b[p];
+        r_qs[u] = s_qs[p];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        if (k < len) {
+          if (r_pr[u] != NONE) succ[r_pr[u] - b] = (uint16_t)k;  // one successor per element: no two writers
+          l_hd[k] = r_pr[u] != NONE ? NO : (uint16_t)k;          // (a member's entry is written by its head below)
+          l_qe[k] = r_qe[u];
+          l_ts[k] = r_ts[u];
+          l_te[k] = r_te[u];
+          l_m[k] = r_m[u];
+          l_b[k] = r_b[u];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        if (k >= len) continue;
+        const uint32_t p = b + k;
+        if (r_pr[u] != NONE) {  // a member: its head writes its label
+          ok_head[p] = 0;
+          continue;
+        }
+        ++heads;
+        uint32_t qe = r_qe[u], ts = r_ts[u], te = r_te[u];
+        uint64_t sm = r_m[u], sb = r_b[u];
+        for (uint16_t nx = succ[k]; nx != NO; nx = succ[nx]) {
+          const uint32_t a = l_qe[nx], t0 = l_ts[nx], t1 = l_te[nx];
+          l_hd[nx] = (uint16_t)k;
+          qe = a > qe ? a : qe;
+          ts = t0 < ts ? t0 : ts;
+          te = t1 > te ? t1 : te;
+          sm += l_m[nx];
+          sb += l_b[nx];
+        }
+        const uint32_t qs0 = r_qs[u];
+        const uint64_t total_length = (uint64_t)qe - (uint64_t)qs0;  // q_max - q_min (the head has the smallest q_start)
+        bool ok = total_length >= min_len;
+        if (ok) {
+          const double wid = chain_weighted_identity(total_length, sm, sb);
+          ok = wid >= min_ident;
+          if (ok) {
+            HeadRec hr;
+            hr.qs = qs0;
+            hr.qe = qe;
+            hr.ts = ts;
+            hr.te = te;
+            hr.wid = wid;
+            hr.grp = s_grp[p];
+            rec[p] = hr;
+          }
+        }
+        ok_head[p] = ok ? 1 : 0;
+      }
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < len; k += EW) hd[b + k] = b + l_hd[k];
+      continue;
+    }
     for (uint32_t k = threadIdx.x; k < len; k += EW) {
       const uint32_t pr = pred[b + k];
       if (pr != NONE) succ[pr - b] = (uint16_t)k;  // one successor per element: no two writers
