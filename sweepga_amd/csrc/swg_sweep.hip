@@ -422,7 +422,8 @@ __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, con
                                                                  uint32_t* __restrict__ te_out,
                                                                  uint32_t* __restrict__ carry_cnt, uint32_t small_tile = 0,
                                                                  const uint64_t* __restrict__ tile_xf = nullptr, uint32_t ntilesf = 0) {
-  uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  // four consecutive begins per thread (one tile: tile sizes are multiples of four): 16-byte loads and one 16-byte store
+  const uint64_t p = ((uint64_t)blockIdx.x * EW_THREADS + threadIdx.x) * 4;
   if (p >= n) return;
   // mode 3 (small_tile != 0): tiles of `small_tile` begins, tile_x2 / ntiles2 describe them (knob).  mode 2: 512-begin tiles
   // (tile_x2) for deep data, 128-begin tiles (tile_xf) for sparse data, 256 otherwise -- by the estimate
@@ -432,14 +433,39 @@ __global__ __launch_bounds__(EW_THREADS) void route_count_kernel(uint64_t n, con
   const bool fine = mode == 2 && rs < (uint64_t)SPARSE_CARRY_PER_TILE * ntiles;
   const uint64_t* tx = fine ? tile_xf : wide ? tile_x2 : tile_x;
   const uint32_t nt = fine ? ntilesf : wide ? ntiles2 : ntiles;
-  const uint64_t s = S[p], e = swg_comp_end(s, E[p], pos_bits);
   const uint32_t tb = (uint32_t)(p >> (31 - __clz((int)(mode == 3 ? small_tile : fine ? (uint32_t)TBF : (wide ? 2 * TB : TB)))));
-  uint32_t te = tb;
-  if (s != 0 && e > s) {  // live and not zero-length
-    te = last_tile_below(tx, nt, tb, e);
-    for (uint32_t b = tb + 1; b <= te; ++b) atomicAdd(&carry_cnt[b], 1u);
+  uint64_t sv[4];
+  uint32_t ev[4], tev[4];
+  const bool whole = p + 4 <= n;
+  if (whole) {
+    const ulonglong2 s01 = *reinterpret_cast<const ulonglong2*>(S + p), s23 = *reinterpret_cast<const ulonglong2*>(S + p + 2);
+    const uint4 e4 = *reinterpret_cast<const uint4*>(E + p);
+    sv[0] = s01.x; sv[1] = s01.y; sv[2] = s23.x; sv[3] = s23.y;
+    ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sv[u] = p + u < n ? S[p + u] : 0ull;
+      ev[u] = p + u < n ? E[p + u] : 0u;
+    }
   }
-  te_out[p] = te;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t s = sv[u], e = swg_comp_end(s, ev[u], pos_bits);
+    uint32_t te = tb;
+    if (s != 0 && e > s) {  // live and not zero-length
+      te = last_tile_below(tx, nt, tb, e);
+      for (uint32_t b = tb + 1; b <= te; ++b) atomicAdd(&carry_cnt[b], 1u);
+    }
+    tev[u] = te;
+  }
+  if (whole) {
+    *reinterpret_cast<uint4*>(te_out + p) = make_uint4(tev[0], tev[1], tev[2], tev[3]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p + u < n) te_out[p + u] = tev[u];
+  }
 }
 
 // Estimate of the carry-in volume (sum over intervals of the tiles they reach into beyond their own) from every
@@ -1656,7 +1682,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_KERNEL_CHECK(ctx);
     }
   }
-  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
+  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for((n + 3) / 4, EW_THREADS), EW_THREADS, 0, st>>>(
                                      n, S, E, in.pos_bits, tile_x, ntiles, tile_x2, ntiles2, mode, reinterpret_cast<unsigned long long*>(d_total + 1),
                                      EST_STRIDE, te, carry_cnt, small_tile, tile_xf, ntilesf));
   SWG_KERNEL_CHECK(ctx);
