@@ -5,6 +5,7 @@
 //   chaining    best-buddy predecessor selection (paf_filter.rs:784-851): units cut where no window can straddle,
 //               parallel candidate lists, then the reference's sequential greedy per unit (one lane, one wavefront or
 //               block-speculative, by unit length)
+#include <cmath>
 #include <type_traits>
 
 #include "swg_scaffold_internal.h"
@@ -2368,7 +2369,18 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         // a pass fewer when the low bits of q_start can be left to the gather (as in the sweep, swg_sweep.hip)
         prehistA = prehist;
         sortA_key_bits = key_bits;
-        SWG_TRY(sortA_packed(swg_radix_drop_bits(M, key_bits, pos_bits, idx_bits, ctx->sort_drop_level), key_bits, idx_bits));
+        // How far the truncation may go follows the density of the keys: with G (query, target, strand) groups at most,
+        // 2^d-wide buckets of q_start hold M * 2^d / (G * 2^pos_bits) records each on average, and the gather orders runs of
+        // up to SWG_RUN_HALO -- buckets of four records on average leave that far away (S-pan: 16 bits, three passes instead of
+        // four; a pair of 10^7 records: 9 bits).  G is only known as an upper bound here (every pair of sequences, both
+        // strands), so a real run that is too long still takes the fall-back below, and the context remembers.
+        static const bool no_dense_cap = getenv("SWG_SORT_DROP10") != nullptr;  // A/B knob: at most 10 bits as before
+        int dcap = 10;
+        if (!no_dense_cap) {
+          const double buckets4 = 4.0 * 2.0 * (double)r->n_seq * (double)r->n_seq * std::ldexp(1.0, pos_bits) / (double)M;
+          dcap = buckets4 >= 65536.0 ? 16 : (buckets4 >= 1024.0 ? (int)std::floor(std::log2(buckets4)) : 10);
+        }
+        SWG_TRY(sortA_packed(swg_radix_drop_bits(M, key_bits, pos_bits, idx_bits, ctx->sort_drop_level, dcap), key_bits, idx_bits));
       } else {
         SWG_LAUNCH(ctx, "sortA_keys_hist", sortA_keys_hist_kernel<<<full > cap ? cap : full, EW, 0, st>>>(
                                           M, identity ? nullptr : B.idxA, identity ? B.idxA : nullptr, r->q_id, r->t_id, r->strand,

@@ -191,7 +191,7 @@ swg_radix_plan swg_radix_plan_packed(int key_bits);
 // (swg_sort.hip has the story).  swg_radix_drop_bits: how many low bits of a key of key_bits (the lowest `low_bits` of which
 // are the caller's to order afterwards) to leave out, 0 = take the packed sort.
 swg_radix_plan swg_radix_plan_words(int sorted_bits);
-int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level);
+int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level, int dmax0 = 10);
 int swg_radix_sort_words(swg_ctx* ctx, uint64_t* words, uint64_t* scratch, uint64_t n, int sorted_bits, int val_bits,
                          uint32_t* prehist, uint64_t** out);
 constexpr int SWG_RUN_HALO = 64;  // a gather orders runs of equal truncated keys of up to this many elements (+1)

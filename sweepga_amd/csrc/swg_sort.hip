@@ -1005,13 +1005,19 @@ static double plan_cost(const swg_radix_plan& pl, bool packed_first) {
   return c;
 }
 // How many low key bits to leave out of the sort (0: none, take the packed sort).  `level`: 0 = up to 10 bits, 1 = up to 7,
-// 2+ = never -- the caller raises it when a run of equal truncated keys turned out longer than its gather can order.
-int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level) {
+// 2+ = never -- the caller raises it when a run of equal truncated keys turned out longer than its gather can order.  A caller
+// that knows its keys are sparse passes a larger first cap (`dmax0` > 10: one more level in front of the two).
+int swg_radix_drop_bits(uint64_t n, int key_bits, int low_bits, int val_bits, int level, int dmax0) {
   static const char* knob = getenv("SWG_SORT_DROP");  // "0": never (test / A-B knob); "n": at most n bits
   static const bool force_fallback = getenv("SWG_SORT_FALLBACK") != nullptr, force_wide = getenv("SWG_SORT_WIDE") != nullptr,
                     no_packed = getenv("SWG_SORT_PAIRS") != nullptr;
-  if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30) || level >= 2) return 0;
-  int dmax = level == 0 ? 10 : 7;
+  if (force_fallback || force_wide || no_packed || n < 2 || n >= (uint64_t(1) << 30)) return 0;
+  int caps[3], nc = 0;
+  if (dmax0 > 10) caps[nc++] = dmax0;
+  caps[nc++] = 10;
+  caps[nc++] = 7;
+  if (level >= nc) return 0;
+  int dmax = caps[level];
   if (knob) dmax = std::min(dmax, atoi(knob));
   if (dmax > low_bits) dmax = low_bits;
   const double now = plan_cost(swg_radix_plan_packed(key_bits), true);
