@@ -105,6 +105,47 @@ __global__ __launch_bounds__(EW) void fwd_extract_kernel(uint64_t nf, const uint
   uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (k < nf) f_pm[k] = (uint32_t)comp[k];
 }
+// The two floating-point tests of the stage as integer thresholds.  Both are monotone in their integer argument --
+//   perpendicular distance  (u64)(deviation as f64 / SQRT_2) <= gap     (inversion capture, paf_filter.rs:570-580)
+//   Euclidean distance      (u64)sqrt((q^2 + t^2) as f64)    <= D       (rescue, paf_filter.rs:686-718)
+// (conversion, division by a positive constant, square root and truncation never decrease) -- so each holds exactly for the
+// arguments up to a largest one, found here by bisection WITH THE SAME OPERATIONS on the same unit; the per-candidate loops
+// then compare integers instead of an f64 division or square root per candidate (S-big1 `inversion` 2.1 -> 1.5 ms, S-pan c5
+// `rescue` 2.61 -> 2.46 ms).  out[0]: largest deviation that passes, out[1]: largest q^2 + t^2.
+__global__ void fp_thresholds_kernel(uint64_t gap, uint64_t D, uint64_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto perp_ok = [&](uint64_t deviation) {
+    const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
+    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
+    return perp <= gap;
+  };
+  auto dist_ok = [&](uint64_t s2) {
+    const double dd = __dsqrt_rn((double)s2);
+    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
+    return dist <= D;
+  };
+  // largest x with ok(x); ok(0) holds (0 <= gap, 0 <= D)
+  uint64_t res[2];
+  for (int which = 0; which < 2; ++which) {
+    auto ok = [&](uint64_t x) { return which == 0 ? perp_ok(x) : dist_ok(x); };
+    uint64_t lo = 0, hi = ~0ull;  // ok(lo); hi: not known
+    if (ok(hi)) {
+      lo = hi;
+    } else {
+      while (hi - lo > 1) {  // ok(lo) && !ok(hi)
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (ok(mid))
+          lo = mid;
+        else
+          hi = mid;
+      }
+    }
+    res[which] = lo;
+  }
+  out[0] = res[0];
+  out[1] = res[1];
+}
+
 // paf_filter.rs:535-597: a '-' record joins the first (lowest-numbered) kept '+' chain of its pair whose
 // diagonal it sits on.  Candidates: chains with q_start <= q_end(rec) + gap (binary search) and
 // q_end + gap >= q_start(rec) (backward scan, stopped by the running maximum).
@@ -121,6 +162,7 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
                                                        const uint32_t* __restrict__ f_pm,
                                                        const uint32_t* __restrict__ f_ts,
                                                        const uint32_t* __restrict__ f_num, uint64_t gap,
+                                                       const uint64_t* __restrict__ fp_thr,
                                                        uint32_t* anchor_num, uint8_t* __restrict__ a_state) {
   uint64_t a = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (a >= M) return;
@@ -162,15 +204,14 @@ __global__ __launch_bounds__(EW) void inversion_kernel(uint64_t M, const uint64_
     c0 = lo;
   }
   uint32_t best = 0;
+  const uint64_t max_dev = fp_thr[0];  // (u64)(deviation / SQRT_2) <= gap  <=>  deviation <= max_dev (fp_thresholds_kernel)
   for (uint32_t c = c0; c < l; ++c) {
     const uint64_t cqe = f_qe[c];
     if ((cqe > ~0ull - gap ? ~0ull : cqe + gap) < qs) continue;  // mapping.query_start > extended_query_end
     const int64_t diag = (int64_t)f_ts[c] - (int64_t)f_qs[c];
     const int64_t dev = (int64_t)tc - (int64_t)qc - diag;
     const uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;
-    const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
-    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
-    if (perp <= gap) {
+    if (deviation <= max_dev) {
       best = f_num[c];
       break;
     }
@@ -300,6 +341,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
                                                     const uint32_t* __restrict__ b_tc,
                                                     const uint32_t* __restrict__ b_idx,
                                                     const uint32_t* __restrict__ b_num, uint64_t D,
+                                                    const uint64_t* __restrict__ fp_thr,
                                                     uint8_t* __restrict__ status, uint32_t* __restrict__ chain) {
   const uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
   // anchors got their status from the coalesced pass in input order; members of span-filtered chains stay DROPPED
@@ -350,6 +392,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
       r = mid;
   }
   uint32_t best_idx = NONE, best_num = 0;
+  const uint64_t max_s2 = fp_thr[1];  // (u64)sqrt((q^2 + t^2) as f64) <= D  <=>  q^2 + t^2 <= max_s2 (fp_thresholds_kernel)
   for (uint64_t j = l; j < slice_end; ++j) {
     const uint64_t bk = b_key[j];
     if (bk > hi) break;
@@ -358,9 +401,7 @@ __global__ __launch_bounds__(EW) void rescue_kernel(uint64_t M, const uint64_t* 
     if (q_diff > D) continue;
     const uint64_t at = b_tc[j];
     const uint64_t t_diff = tc > at ? tc - at : at - tc;
-    const double dd = __dsqrt_rn((double)(q_diff * q_diff + t_diff * t_diff));
-    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
-    if (dist <= D && b_idx[j] < best_idx) {
+    if (q_diff * q_diff + t_diff * t_diff <= max_s2 && b_idx[j] < best_idx) {  // (wrapping sum, as the reference's)
       best_idx = b_idx[j];
       best_num = b_num[j];
     }
@@ -474,6 +515,11 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
     return finish_counts();
   }
 
+  // the stage's two floating-point tests as integer thresholds (one thread, ~130 evaluations)
+  uint64_t* fp_thr = swg_alloc<uint64_t>(ctx, 2);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "fp_thresholds", fp_thresholds_kernel<<<1, 64, 0, st>>>(cfg->scaffold_gap, cfg->scaffold_max_deviation, fp_thr));
+  SWG_KERNEL_CHECK(ctx);
   // ---- inversion capture
   {
     const uint64_t np = B.n_pairs;
@@ -528,7 +574,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       }
       SWG_LAUNCH(ctx, "inversion", inversion_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits,
                                                                 pair_lo, pair_hi, f_qs, f_qe, f_pm, f_ts, f_num,
-                                                                cfg->scaffold_gap, anchor_num, a_state));
+                                                                cfg->scaffold_gap, fp_thr, anchor_num, a_state));
       SWG_KERNEL_CHECK(ctx);
     }
   }
@@ -585,7 +631,7 @@ int swg_scaffold_stage(swg_ctx* ctx, const swg_records* r, const swg_config* cfg
       SWG_KERNEL_CHECK(ctx);
       SWG_LAUNCH(ctx, "rescue", rescue_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, B.a_qe, B.a_ts, B.a_te, B.a_dpair, pos_bits, a_state,
                                                           a_pair_lo, a_pair_hi, b_key, b_tc, b_idx, b_num,
-                                                          cfg->scaffold_max_deviation, status_out, chain_out));
+                                                          cfg->scaffold_max_deviation, fp_thr, status_out, chain_out));
       SWG_KERNEL_CHECK(ctx);
     }
   }
