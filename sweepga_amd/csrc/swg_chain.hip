@@ -29,6 +29,22 @@ __global__ __launch_bounds__(EW) void sortA_keys_kernel(uint64_t M, const uint32
   key[a] = (g << pos_bits) | q_start[i];
 }
 
+// Sort A behind the mapping sweep, as words (round 4): the query axis' order already has every (query, target, strand) group
+// in q_start order, so only the group bits are sorted -- stably -- and q_start is not needed for that: word = (group <<
+// idx_bits) | record index, three gathers instead of four, 8-byte passes instead of 12-byte (key, index) pairs.  The full
+// key is put together again by gatherA_slots_words_kernel, which reads the record's slot anyway.
+__global__ __launch_bounds__(EW) void sortA_words_kernel(uint64_t M, const uint32_t* __restrict__ a_idx,
+                                                         const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                         const uint8_t* __restrict__ strand, uint32_t n_seq, int idx_bits,
+                                                         uint64_t* __restrict__ words,
+                                                         const uint32_t* __restrict__ group32) {  // (optional: the same value, from prepare)
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint32_t i = a_idx[a];
+  const uint64_t g = group32 ? (uint64_t)group32[i] : ((uint64_t)q_id[i] * n_seq + t_id[i]) * 2 + (strand[i] ? 1 : 0);
+  words[a] = (g << idx_bits) | i;
+}
+
 // The same for an ascending (or identity: a_idx == nullptr, then idx_out receives it) index list, with the digit histograms
 // of the sort that follows accumulated on the way (the sort then skips its own pass over the keys, as in the sweep's
 // begin_build).  Grid-stride over whole work-groups.
@@ -111,6 +127,32 @@ __global__ __launch_bounds__(EW) void gatherA_slots_kernel(uint64_t M, const uin
   a_keep[a] = keep1[i] ? 1 : 0;
   const uint64_t pair = keyA[a] >> (pos_bits + 1);
   pair_flag[a] = (a == 0 || (keyA[a - 1] >> (pos_bits + 1)) != pair) ? 1u : 0u;
+}
+
+// ... from sort A's words (sortA_words_kernel): keyA and idxA are written here
+__global__ __launch_bounds__(EW) void gatherA_slots_words_kernel(uint64_t M, const uint64_t* __restrict__ words, int idx_bits,
+                                                                 const swg_key_ends* __restrict__ slots,
+                                                                 const uint8_t* __restrict__ keep1, int pos_bits,
+                                                                 uint64_t* __restrict__ keyA, uint32_t* __restrict__ idxA,
+                                                                 uint32_t* __restrict__ a_qe, uint32_t* __restrict__ a_ts,
+                                                                 uint32_t* __restrict__ a_te, uint32_t* __restrict__ a_m,
+                                                                 uint32_t* __restrict__ a_b, uint8_t* __restrict__ a_keep,
+                                                                 uint32_t* __restrict__ pair_flag) {
+  uint64_t a = (uint64_t)swg_xcd_block(blockIdx.x, gridDim.x) * EW + threadIdx.x;
+  if (a >= M) return;
+  const uint64_t w = words[a];
+  const uint32_t i = (uint32_t)(w & ((uint64_t(1) << idx_bits) - 1));
+  const uint64_t g = w >> idx_bits;  // ((query * n_seq + target) << 1) | strand
+  const swg_key_ends ke = slots[i];
+  keyA[a] = (g << pos_bits) | ke.start[0];
+  idxA[a] = i;
+  a_qe[a] = ke.end[0];
+  a_ts[a] = ke.start[1];
+  a_te[a] = ke.end[1];
+  a_m[a] = ke.pad[0];
+  a_b[a] = ke.pad[1];
+  a_keep[a] = keep1[i] ? 1 : 0;
+  pair_flag[a] = (a == 0 || ((words[a - 1] >> idx_bits) >> 1) != (g >> 1)) ? 1u : 0u;
 }
 
 // dense pair id of every A position: inclusive count of pair heads - 1 (scan result is exclusive)
@@ -2310,6 +2352,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   uint32_t* idx_tmp = swg_alloc<uint32_t>(ctx, M);
   SWG_CHECK_ARENA(ctx);
   uint64_t* packedA = nullptr;  // sort A's result as packed words (then B.keyA / B.idxA are written by the gather)
+  uint64_t* wordsA = nullptr;   // ... as (group, index) words behind the mapping sweep (gatherA_slots_words writes B.keyA / B.idxA)
+  int wordsA_idx_bits = 0;
   int packed_idx_bits = 0;
   int dropA = 0;                // low key bits left out of sort A (swg_radix_sort_words; the gather orders the runs)
   // keys + histograms + the packed / word sort of the all-members case; drop = 0: the packed sort over the whole key
@@ -2341,11 +2385,26 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
     // first, so the last M entries are the alive ones, and inside every (query, target, strand) group they already stand
     // in q_start order with ties in index order -- the order sort A must end in (paf_filter.rs:777).  Stable passes over
     // the group bits alone finish it: 2 radix passes instead of 6 for a 100-genome pangenome.
-    SWG_HIP(ctx, hipMemcpyAsync(B.idxA, q_order + (n - M), M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
-                                                                r->n_seq, pos_bits, B.keyA));
-    SWG_KERNEL_CHECK(ctx);
-    SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
+    static const bool sortA_pairs = getenv("SWG_SORTA_PAIRS") != nullptr;  // test / A-B knob: the (key, index) pairs as before
+    const int idx_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
+    if (slots && !all_members && !sortA_pairs && pair_bits + idx_bits <= 64 && M > 1 && M < (uint64_t(1) << 30) &&
+        swg_radix_plan_words(pair_bits).npasses > 0) {
+      // as words over the group bits alone; the keys come back in gatherA_slots_words (see sortA_words_kernel)
+      SWG_LAUNCH(ctx, "sortA_words", sortA_words_kernel<<<nblk(M), EW, 0, st>>>(M, q_order + (n - M), r->q_id, r->t_id, r->strand, r->n_seq,
+                                                                    idx_bits, keyA0, ctx->call_group32));
+      SWG_KERNEL_CHECK(ctx);
+      const int prc = swg_radix_sort_words(ctx, keyA0, key_tmp, M, pair_bits, idx_bits, nullptr, &wordsA);
+      if (prc == SWG_ERR_UNSUPPORTED) return swg_set_error(ctx, SWG_ERR_HIP, "word sort declined a shape it accepted");
+      if (prc != SWG_OK) return prc;
+      wordsA_idx_bits = idx_bits;
+      B.keyA = wordsA == keyA0 ? key_tmp : keyA0;  // the buffer the words are not in takes the keys
+    } else {
+      SWG_HIP(ctx, hipMemcpyAsync(B.idxA, q_order + (n - M), M * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      SWG_LAUNCH(ctx, "sortA_keys", sortA_keys_kernel<<<nblk(M), EW, 0, st>>>(M, B.idxA, r->q_id, r->t_id, r->strand, r->q_start,
+                                                                  r->n_seq, pos_bits, B.keyA));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, pos_bits, pair_bits + pos_bits));
+    }
   } else {
     if (M != n) SWG_TRY(swg_flags_compact(ctx, alive_scan, B.idxA));  // M == n: the list is the identity, written below
     const int key_bits = pair_bits + pos_bits;
@@ -2395,7 +2454,7 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       SWG_TRY(swg_radix_sort_pairs(ctx, &B.keyA, &B.idxA, &key_tmp, &idx_tmp, M, 0, key_bits));
     }
   }
-  if (!packedA && B.keyA == keyA0) swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA; with packed words: no release)
+  if (!packedA && !wordsA && B.keyA == keyA0) swg_arena_restore(ctx, sort_mark);  // (idxA swaps together with keyA; with packed words: no release)
   uint64_t m = 0, n_groups = 0;
   uint32_t *s_qs = nullptr, *s_qe = nullptr, *s_ts = nullptr, *s_te = nullptr, *s_m = nullptr, *s_b = nullptr;
   uint64_t* s_grp = nullptr;
@@ -2473,8 +2532,12 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
       a_m = swg_alloc<uint32_t>(ctx, M);
       a_b = swg_alloc<uint32_t>(ctx, M);
       SWG_CHECK_ARENA(ctx);
-      SWG_LAUNCH(ctx, "gatherA_slots", gatherA_slots_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, slots, member, pos_bits, B.a_qe, B.a_ts, B.a_te,
-                                                                        a_m, a_b, a_keep, pair_flag));
+      if (wordsA)
+        SWG_LAUNCH(ctx, "gatherA_slots", gatherA_slots_words_kernel<<<nblk(M), EW, 0, st>>>(M, wordsA, wordsA_idx_bits, slots, member, pos_bits, B.keyA,
+                                                                                B.idxA, B.a_qe, B.a_ts, B.a_te, a_m, a_b, a_keep, pair_flag));
+      else
+        SWG_LAUNCH(ctx, "gatherA_slots", gatherA_slots_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, slots, member, pos_bits, B.a_qe, B.a_ts, B.a_te,
+                                                                          a_m, a_b, a_keep, pair_flag));
     } else {
       SWG_LAUNCH(ctx, "gatherA", gatherA_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, member,
                                                             pos_bits, B.a_qe, B.a_ts, B.a_te, a_keep, pair_flag));

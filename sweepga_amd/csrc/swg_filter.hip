@@ -226,7 +226,12 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
-  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, sweeps, scalars));
+  // behind a mapping sweep the scaffold stage's first sort only orders the (query, target, strand) groups (the query axis'
+  // order has the rest): prepare leaves the group of every record as one 4-byte value for it
+  uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
+  SWG_CHECK_ARENA(ctx);
+  ctx->call_group32 = group32;
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, sweeps, scalars, group32));
   uint64_t h[3];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 3));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;

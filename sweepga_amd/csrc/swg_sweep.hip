@@ -103,7 +103,9 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              uint64_t min_block, int keep_self, double min_identity,
                                                              int scoring, uint8_t* __restrict__ alive,
                                                              swg_key_ends* __restrict__ key_ends, int slot_payload,
-                                                             int with_keys, unsigned long long* __restrict__ scalars) {
+                                                             int with_keys, unsigned long long* __restrict__ scalars,
+                                                             const uint8_t* __restrict__ strand, uint32_t n_seq,
+                                                             uint32_t* __restrict__ group32) {
   uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
     // identity == nullptr: RecordMeta.identity as extract_metadata derives it without a dv:f: override -- matches over
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     const uint32_t a = qs[i], b = qe[i], c = ts[i], d = te[i];
     const bool ok = (min_block == 0 || (uint64_t)block_len[i] >= min_block) && (keep_self || q_id[i] != t_id[i]) && id >= min_identity;
     alive[i] = ok ? 1 : 0;
+    // the (query, target, strand) group as one 4-byte value: sort A behind a mapping sweep then gathers one column, not three
+    if (group32) group32[i] = (q_id[i] * n_seq + t_id[i]) * 2u + (strand[i] ? 1u : 0u);
     if (key_ends) {  // nullptr: neither a mapping-level sweep nor a scaffold stage will read the record slots
       swg_key_ends ke;
       ke.key = with_keys ? score_key_of(a, b, id, scoring) : 0ull;  // (no sweep: nobody reads the scores)
@@ -1475,12 +1479,12 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
 }
 
 int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
-                unsigned long long* scalars) {
+                unsigned long long* scalars, uint32_t* group32) {
   if (r->n == 0) return SWG_OK;
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
                                  r->n, r->q_id, r->t_id, r->block_len, r->matches, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
                                  cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
-                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars));
+                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars, r->strand, r->n_seq, group32));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
