@@ -49,6 +49,28 @@ int main() {
       if ((e - b + 7) / 8 > SWG_RADIX_MAX_PASSES) continue;
       bad += check(pl, b, e, 8, "pairs");
     }
+  // word sorts (swg_radix_sort_words): the passes tile the sorted bits; and how many low bits a caller may leave out
+  // (swg_radix_drop_bits): never more than the level's cap or the coordinate's width, a larger first cap only when asked for
+  for (int sb = 1; sb <= 56; ++sb) {
+    const swg_radix_plan pl = swg_radix_plan_words(sb);
+    if (pl.npasses > 0) bad += check(pl, 0, sb, bits8 ? 8 : 9, "words");
+  }
+  if (!getenv("SWG_SORT_DROP")) {
+    const int caps10[4] = {10, 7, 0, 0}, caps16[4] = {16, 10, 7, 0};
+    for (int kb = 20; kb <= 48; ++kb)
+      for (int low = 8; low <= 32; low += 4)
+        for (int level = 0; level < 4; ++level) {
+          const int d10 = swg_radix_drop_bits(100000000ull, kb, low, 27, level), d16 = swg_radix_drop_bits(100000000ull, kb, low, 27, level, 16);
+          if (d10 < 0 || d10 > caps10[level] || d10 > low || d16 < 0 || d16 > caps16[level] || d16 > low || kb - d16 < 1) {
+            printf("drop bits for a %d-bit key (%d low bits), level %d: %d / %d\n", kb, low, level, d10, d16);
+            ++bad;
+          }
+        }
+    if (!bits8 && swg_radix_drop_bits(100000000ull, 43, 28, 27, 0, 16) != 16) {  // S-pan's sort A: 27 bits = three 9-bit passes
+      printf("a 43-bit key with sparse low bits is not cut to 27\n");
+      ++bad;
+    }
+  }
   printf("%d bad, %d widths with 9-bit digits\n", bad, nine);
   return bad ? 1 : 0;
 }
