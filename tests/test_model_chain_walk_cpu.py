@@ -12,3 +12,6 @@ def test_batched_walk_model_equals_sequential_greedy():
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "equal to the sequential greedy" in r.stdout and "whole-window passes" in r.stdout
+    # all three work-list rules (round 3's, and round 4's two shorter lists) are modelled and agree
+    for rule in ("count", "low", "pair"):
+        assert any(line.startswith(rule) and "equal to the sequential greedy" in line for line in r.stdout.splitlines()), r.stdout

@@ -8,6 +8,14 @@ path is hit): acc bits against the scores before the batch, first acceptable can
 lanes that share a j with a lower lane (work list; a lane that moves to a new j wakes the higher lanes holding it), whole
 window for a lane whose KC listed candidates are all refused while its window held more, commit by minimum.
 
+Three rules for who starts on the work list (all must reproduce the sequential greedy):
+  "count": every lane of a hash slot that more than one lane names (round 3);
+  "low":   every lane of a slot except the LOWEST one (round 4, the chunks of short units) -- its choice stands unless a lower
+           lane moves to its j, which wakes it;
+  "pair":  as "low", and in a slot of exactly two lanes the higher one only if the lower one blocks it -- same j, distance
+           not larger (round 4, the blocks of long units).
+With "low" and "pair" a lane that moves wakes only the higher lanes it blocks (same j, distance not smaller than its own).
+
     python3 tools/model_chain_walk.py [cases]
 """
 import random
@@ -32,7 +40,7 @@ def reference(n, valid):
     return pred
 
 
-def batched(n, valid, W, hash_size):
+def batched(n, valid, W, hash_size, rule="count"):
     score = [INF] * n
     pred = [-1] * n
     stats = {"work": 0, "fallback": 0, "moved": 0}
@@ -54,7 +62,24 @@ def batched(n, valid, W, hash_size):
         for l in range(L):
             if fin[l]:
                 cnt[fin[l][1] % hash_size] = cnt.get(fin[l][1] % hash_size, 0) + 1
-        work = set(l for l in range(L) if (fin[l] and cnt[fin[l][1] % hash_size] > 1) or (fin[l] is None and nv[l] > KC))
+        low = {}
+        for l in range(L):
+            if fin[l]:
+                low.setdefault(fin[l][1] % hash_size, l)  # lowest lane of the slot
+
+        def starts(l):
+            if fin[l] is None:
+                return nv[l] > KC
+            h = fin[l][1] % hash_size
+            if rule == "count":
+                return cnt[h] > 1
+            if low[h] == l:
+                return False
+            if rule == "low":
+                return True
+            return cnt[h] > 2 or (fin[low[h]][1] == fin[l][1] and fin[low[h]][0] <= fin[l][0])
+
+        work = set(l for l in range(L) if starts(l))
         committed = 0
 
         def commit(upto):
@@ -91,7 +116,8 @@ def batched(n, valid, W, hash_size):
             fin[l] = new
             if new and new[1] != old_j:
                 stats["moved"] += 1
-                work |= set(k for k in range(l + 1, L) if fin[k] and fin[k][1] == new[1])
+                work |= set(k for k in range(l + 1, L)
+                            if fin[k] and fin[k][1] == new[1] and (rule == "count" or fin[k][0] >= new[0]))
         commit(L)
     return pred, stats
 
@@ -113,19 +139,23 @@ def random_case(rng):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     rng = random.Random(12345)
-    tot = {"work": 0, "fallback": 0, "moved": 0}
+    tot = {rule: {"work": 0, "fallback": 0, "moved": 0} for rule in ("count", "low", "pair")}
     for c in range(cases):
         n, valid = random_case(rng)
         want = reference(n, valid)
         for W in (1, 3, 8, 64):
-            got, st = batched(n, valid, W, rng.choice([1, 4, 256]))
-            if got != want:
-                print("MISMATCH case", c, "W", W, n, valid, want, got)
-                return 1
-            for k in tot:
-                tot[k] += st[k]
-    print(f"{cases} cases x 4 widths equal to the sequential greedy; re-evaluated lanes {tot['work']}, whole-window passes "
-          f"{tot['fallback']}, lanes that moved to a new j {tot['moved']}")
+            hs = rng.choice([1, 4, 256])
+            for rule in ("count", "low", "pair"):
+                got, st = batched(n, valid, W, hs, rule)
+                if got != want:
+                    print("MISMATCH case", c, "W", W, "rule", rule, n, valid, want, got)
+                    return 1
+                for k in st:
+                    tot[rule][k] += st[k]
+    for rule in ("count", "low", "pair"):
+        t = tot[rule]
+        print(f"{rule:5s}: {cases} cases x 4 widths equal to the sequential greedy; re-evaluated lanes {t['work']}, whole-window "
+              f"passes {t['fallback']}, lanes that moved to a new j {t['moved']}")
     return 0
 
 
