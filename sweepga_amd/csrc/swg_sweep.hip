@@ -11,8 +11,11 @@
 //
 //   1. every live interval gets the composite start key X = ((segment+1) << pos_bits) | start;
 //      ONE radix sort of the n begins orders all segments of the axis (dead intervals get X = 0
-//      and fall out in front).  Ends are never sorted.
-//   2. the sorted begins are cut into tiles of TB = 256.  With X_b the first key of tile b:
+//      and fall out in front).  Ends are never sorted.  (Round 4: the sort runs on X without its low
+//      bits where that saves a pass; the gather behind it orders the short runs of equal truncated
+//      keys in LDS -- begin_gather_words_kernel.)
+//   2. the sorted begins are cut into tiles of TB = 256 (k = 1: 128, 256 or 512 begins, chosen on the device from an
+//      estimate of the carry-in volume -- sparse, ordinary, deep data).  With X_b the first key of tile b:
 //        - an interval that begins before tile b and ends after X_b is a *carry-in* of b;
 //        - an interval's end coordinate E is an evaluation point of the last tile with X_b < E
 //          (unless E coincides with the next tile's first key, which is evaluated as a start);
