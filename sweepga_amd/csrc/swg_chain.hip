@@ -290,7 +290,9 @@ __global__ __launch_bounds__(EW) void gather_all_packed_kernel(uint64_t M, const
                                                                uint32_t* __restrict__ s_ts, uint32_t* __restrict__ s_te,
                                                                uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
                                                                uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt,
-                                                               const swg_key_ends* __restrict__ slots) {
+                                                               const swg_key_ends* __restrict__ slots,
+                                                               const uint32_t* __restrict__ slot_flag) {
+  if (slot_flag && *slot_flag == 0) slots = nullptr;  // (wave-uniform; see gather_all_words_kernel)
   const uint32_t lb = swg_xcd_block(blockIdx.x, gridDim.x);
   const uint64_t a = (uint64_t)lb * EW + threadIdx.x;
   bool pf = false, gf = false;
@@ -351,9 +353,11 @@ __global__ __launch_bounds__(EW) void gather_all_words_kernel(uint64_t M, const 
                                                               uint32_t* __restrict__ s_m, uint32_t* __restrict__ s_b,
                                                               uint64_t* __restrict__ s_grp, uint64_t* __restrict__ blk_cnt,
                                                               unsigned long long* __restrict__ long_run,
-                                                              const swg_key_ends* __restrict__ slots) {
+                                                              const swg_key_ends* __restrict__ slots,
+                                                              const uint32_t* __restrict__ slot_flag) {
   // slots != nullptr: the six columns of a record from its 32-byte slot (prepare_kernel) -- one line from L2 per record
-  // instead of six
+  // instead of six.  slot_flag: the slots were only written if *slot_flag != 0 (the input-order probe, swg_filter.hip).
+  if (slot_flag && *slot_flag == 0) slots = nullptr;  // (wave-uniform)
   constexpr int H = SWG_RUN_HALO, W = EW + 2 * H;
   __shared__ uint64_t l_hi[W];   // key >> drop, + 1 (0: no element at this position)
   __shared__ uint64_t l_ord[W];  // (low bits of q_start << 32) | record index
@@ -2492,11 +2496,13 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         SWG_LAUNCH(ctx, "gather_all_words", gather_all_words_kernel<<<nblk(M), EW, 0, st>>>(
                                           M, packedA, packed_idx_bits, dropA, r->q_start, r->q_end, r->t_start, r->t_end, r->matches,
                                           r->block_len, pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt,
-                                          reinterpret_cast<unsigned long long*>(blk_cnt + n_blk), slots));
+                                          reinterpret_cast<unsigned long long*>(blk_cnt + n_blk), slots ? slots : ctx->call_probe_slots,
+                                          slots ? nullptr : ctx->call_probe_flag));
       } else if (packedA) {
         SWG_LAUNCH(ctx, "gather_all_packed", gather_all_packed_kernel<<<nblk(M), EW, 0, st>>>(
                                           M, packedA, packed_idx_bits, r->q_start, r->q_end, r->t_start, r->t_end, r->matches, r->block_len,
-                                          pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt, slots));
+                                          pos_bits, B.keyA, B.idxA, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp, blk_cnt,
+                                          slots ? slots : ctx->call_probe_slots, slots ? nullptr : ctx->call_probe_flag));
       } else {
         SWG_LAUNCH(ctx, "gather_all", gather_all_kernel<<<nblk(M), EW, 0, st>>>(M, B.keyA, B.idxA, r->q_end, r->t_start, r->t_end, r->matches,
                                                                    r->block_len, pos_bits, s_qs, s_qe, s_ts, s_te, s_m, s_b, s_grp,

@@ -206,6 +206,16 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     stats->n_retained = stats->n_swept = stats->n_chains = stats->n_chains_kept = stats->n_out = 0;
   }
   if (n == 0) return SWG_OK;
+  // the per-call pointers the stages below find in the context do not outlive this call (the seams -- swg_merge_chains ... --
+  // run the same stages without them)
+  struct CallScope {
+    swg_ctx* c;
+    ~CallScope() {
+      c->call_probe_slots = nullptr;
+      c->call_probe_flag = nullptr;
+      c->call_group32 = nullptr;
+    }
+  } call_scope{ctx};
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
   // The 32-byte record slots (both starts, both ends, score key, matches, block length).  The mapping-level sweep sorts and
@@ -223,6 +233,18 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   const uint64_t pairs_ub = (uint64_t)r->n_seq * r->n_seq ? (uint64_t)r->n_seq * r->n_seq : 1;
   const bool deep_pairs = slots_knob >= 0 ? slots_knob != 0 : n / pairs_ub >= (uint64_t(1) << 17);
   swg_key_ends* key_ends = (sweeps || (cfg->scaffold_gap != 0 && deep_pairs)) ? swg_alloc<swg_key_ends>(ctx, n) : nullptr;
+  // Shallow pairs, nothing sweeps, a scaffold stage follows: whether the slots pay depends on the ORDER of the input -- records
+  // grouped by sequence pair (what an aligner writes) keep a pair's columns in L2, any other order does not (S-pan shuffled:
+  // 28.8 ms with the column gathers).  That is probed on the device (input_order_probe_kernel); prepare writes the slots and the
+  // all-members gathers read them only if the probe says "not grouped".  Nothing else may read these slots.
+  swg_key_ends* probe_slots = nullptr;
+  uint32_t* probe_flag = nullptr;
+  if (!key_ends && cfg->scaffold_gap != 0 && slots_knob < 0 && n >= 65536) {
+    probe_slots = swg_alloc<swg_key_ends>(ctx, n);
+    probe_flag = swg_alloc<uint32_t>(ctx, 1);
+  }
+  ctx->call_probe_slots = probe_slots;
+  ctx->call_probe_flag = probe_flag;
   unsigned long long* scalars = swg_alloc<unsigned long long>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
@@ -231,7 +253,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   ctx->call_group32 = group32;
-  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends, sweeps, scalars, group32));
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends ? key_ends : probe_slots, sweeps, scalars, group32, probe_flag));
   uint64_t h[3];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 3));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;

@@ -31,6 +31,10 @@ struct swg_ctx {
   std::string err;
   int num_cu = 256;
   uint64_t n_readbacks = 0;  // swg_read_scalars calls (each one a stream synchronisation), for SWG_DEBUG
+  // record slots that prepare writes only if the device-side probe of the input order says so (*flag != 0), for the all-members
+  // gathers of the scaffold stage (swg_filter.hip)
+  const struct swg_key_ends* call_probe_slots = nullptr;
+  const uint32_t* call_probe_flag = nullptr;
   const uint32_t* call_group32 = nullptr;  // the running call's (query, target, strand) group of every record, when prepare wrote it
   int sort_drop_level = 0;   // raised when a sort on a truncated key met runs too long to order in the gather (swg_radix_drop_bits)
   uint64_t sort_drop_n = 0;  // ... by a call over this many records: a call of a very different size starts from level 0 again
@@ -311,4 +315,4 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
 // Step-1 retain (src/paf_filter.rs:384-388), score keys and the two scalars the pipeline needs, in one pass over
 // the records: scalars[0] = max coordinate, scalars[1] = number of retained records (device u64, pre-zeroed).
 int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
-                unsigned long long* scalars, uint32_t* group32 = nullptr);
+                unsigned long long* scalars, uint32_t* group32 = nullptr, uint32_t* probe_flag = nullptr);

@@ -95,6 +95,30 @@ __global__ __launch_bounds__(EW_THREADS) void score_key_kernel(uint64_t n, const
   if (i < n) key[i] = score_key_of(qs[i], qe[i], identity[i], scoring);
 }
 
+// Is the input grouped by sequence pair (as an aligner writes it)?  16,384 sampled records are compared with their successors:
+// in pair-major order nearly all of them share the pair, in random order nearly none.  *flag = 1: not grouped -- the column
+// gathers behind the scaffold stage's first sort then have no locality in L2 (S-pan shuffled: gather_all_words 13.5 ms
+// instead of 3.4) and the record slots are worth writing.  The decision stays on the device: prepare and the gathers read it.
+__global__ __launch_bounds__(256) void input_order_probe_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
+                                                                const uint32_t* __restrict__ t_id, uint32_t* __restrict__ flag) {
+  __shared__ uint32_t same_w[4];
+  uint32_t same = 0;
+  constexpr uint32_t PER_THREAD = 64;
+  if (n >= 2) {
+    uint64_t x = 0x9e3779b97f4a7c15ull * (threadIdx.x + 1);
+    for (uint32_t k = 0; k < PER_THREAD; ++k) {
+      x = x * 6364136223846793005ull + 1442695040888963407ull;
+      const uint64_t i = (x >> 11) % (n - 1);
+      same += (q_id[i] == q_id[i + 1] && t_id[i] == t_id[i + 1]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) same += __shfl_down(same, o, 64);
+  if ((threadIdx.x & 63) == 0) same_w[threadIdx.x >> 6] = same;
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = (n >= 2 && 2 * (same_w[0] + same_w[1] + same_w[2] + same_w[3]) < 256 * PER_THREAD) ? 1u : 0u;
+}
+
 // retain + score key + max coordinate + retained count in one pass (grid-stride, one atomic pair per wave)
 __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const uint32_t* __restrict__ q_id,
                                                              const uint32_t* __restrict__ t_id,
@@ -108,7 +132,9 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              swg_key_ends* __restrict__ key_ends, int slot_payload,
                                                              int with_keys, unsigned long long* __restrict__ scalars,
                                                              const uint8_t* __restrict__ strand, uint32_t n_seq,
-                                                             uint32_t* __restrict__ group32) {
+                                                             uint32_t* __restrict__ group32,
+                                                             const uint32_t* __restrict__ probe_flag) {
+  if (probe_flag && *probe_flag == 0) key_ends = nullptr;  // (wave-uniform) grouped input: the slots are not worth their traffic
   uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
     // identity == nullptr: RecordMeta.identity as extract_metadata derives it without a dv:f: override -- matches over
@@ -1482,12 +1508,16 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
 }
 
 int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
-                unsigned long long* scalars, uint32_t* group32) {
+                unsigned long long* scalars, uint32_t* group32, uint32_t* probe_flag) {
   if (r->n == 0) return SWG_OK;
+  if (probe_flag) {
+    SWG_LAUNCH(ctx, "input_order_probe", input_order_probe_kernel<<<1, 256, 0, ctx->stream>>>(r->n, r->q_id, r->t_id, probe_flag));
+    SWG_KERNEL_CHECK(ctx);
+  }
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
                                  r->n, r->q_id, r->t_id, r->block_len, r->matches, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
                                  cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
-                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars, r->strand, r->n_seq, group32));
+                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars, r->strand, r->n_seq, group32, probe_flag));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
