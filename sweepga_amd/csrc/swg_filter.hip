@@ -14,7 +14,9 @@
 
 namespace {
 
-constexpr size_t SWG_ARENA_B_SWEEP = 96, SWG_ARENA_B_SCAFFOLD = 256;  // scratch bytes per record reserved up front
+// scratch bytes per record reserved up front (the scaffold figure had to follow the input-order probe's slot buffer, 32 B per
+// record: with 256 the first call of a context overflowed and ran twice -- seen as 1.25 launches per call in a 4-call profile)
+constexpr size_t SWG_ARENA_B_SWEEP = 96, SWG_ARENA_B_SCAFFOLD = 296;
 
 constexpr int EW = 256;
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + EW - 1) / EW); }
