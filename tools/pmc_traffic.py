@@ -41,7 +41,13 @@ def short_name(name):
 
 
 def collect(d, counter):
+    """{label: [launches, sum of counter values]} and the launches per pipeline EXECUTION.  Every execution of the filter
+    starts with one `prepare` launch, so the dispatches (in Dispatch_Id order) between two of them are one execution.  A call
+    whose scratch arena overflowed runs its pipeline a second time (run_with_arena: grow, run again), i.e. a profile of c calls
+    can hold c + 1 executions, the first of them cut short; the launches per call are therefore read off the LAST execution
+    (steady state), and the per-call totals are launches-per-call x the average bytes per launch."""
     acc = defaultdict(lambda: [0, 0.0])
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
@@ -49,30 +55,43 @@ def collect(d, counter):
             raw = row["Kernel_Name"]
             if any(t in raw for t in ("at::", "rocprim::", "thrust::", "hipcub::", "c10::")):
                 continue  # torch's kernels (the synthetic record generator), not the library's
-            a = acc[short_name(row["Kernel_Name"])]
+            k = short_name(row["Kernel_Name"])
+            a = acc[k]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
-    return acc
+            rows.append((int(row["Dispatch_Id"]), k))
+    rows.sort()
+    executions, last = 0, defaultdict(int)
+    for _, k in rows:
+        if k == "prepare":
+            executions += 1
+            last = defaultdict(int)
+        last[k] += 1
+    return acc, executions, dict(last)
 
 
 def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     # filter calls inside one profiled bench.py run (--steps 1 --warmup 0: all-events pass + timed region + no-events pass + statistics = 4)
     calls = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    (fe, ex_f, last_f), (wr, ex_w, last_w) = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    executions = max(ex_f, ex_w)
     kernels = {}
     total = 0.0
     for k in sorted(set(fe) | set(wr)):
         f = fe[k][1] / fe[k][0] if fe[k][0] else 0.0
         w = wr[k][1] / wr[k][0] if wr[k][0] else 0.0
         launches = max(fe[k][0], wr[k][0])
+        # launches of one call: those of the last (complete, steady-state) execution; a profile without `prepare` (the seams)
+        # falls back to launches / calls
+        lpc = float(max(last_f.get(k, 0), last_w.get(k, 0))) if executions else launches / calls
         per_launch = (2.0 * f + w) * 1024.0
-        kernels[k] = {"launches_profiled": launches, "launches_per_call": launches / calls, "fetch_size_kb_per_launch": f,
+        kernels[k] = {"launches_profiled": launches, "launches_per_call": lpc, "fetch_size_kb_per_launch": f,
                       "write_size_kb_per_launch": w, "hbm_bytes_per_launch": per_launch,
-                      "hbm_bytes_per_call": per_launch * launches / calls}
-        total += per_launch * launches / calls
-    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "calls_profiled": calls, "hbm_bytes_per_call_all_kernels": total,
-                      "kernels": kernels}, indent=1))
+                      "hbm_bytes_per_call": per_launch * lpc}
+        total += per_launch * lpc
+    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "calls_profiled": calls, "pipeline_executions_profiled": executions,
+                      "hbm_bytes_per_call_all_kernels": total, "kernels": kernels}, indent=1))
 
 
 if __name__ == "__main__":
