@@ -313,8 +313,12 @@ static int validate(swg_ctx* ctx, const swg_records* r, const swg_config* cfg) {
 // slots, packed sort), 204-223 B/record with the scaffold stage.  Reserving that up front avoids the grow-and-rerun path on a
 // context's first call (and, for the streamed host path, any re-allocation between its ranges).
 int swg_filter_reserve_arena(swg_ctx* ctx, uint64_t n, const swg_records* rec, const swg_config* cfg, bool wide) {
-  size_t want = (size_t)n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + (wide ? 24 : 0)) + (size_t(8) << 20) +
-                (wide ? (size_t)rec->n_seq * 8 : 0);
+  // deep sequence pairs (the shape test of filter_device_body): the candidate arrays of the wavefront-per-element lists, 56 B per
+  // record, come on top (the S-big1 profiles showed the first call of a fresh context running twice: 1.25 launches per call)
+  const uint64_t pairs_ub = (uint64_t)rec->n_seq * rec->n_seq ? (uint64_t)rec->n_seq * rec->n_seq : 1;
+  const size_t deep_extra = (cfg->scaffold_gap != 0 && n / pairs_ub >= (uint64_t(1) << 17)) ? 64 : 0;
+  size_t want = (size_t)n * ((cfg->scaffold_gap == 0 ? SWG_ARENA_B_SWEEP : SWG_ARENA_B_SCAFFOLD) + deep_extra + (wide ? 24 : 0)) +
+                (size_t(8) << 20) + (wide ? (size_t)rec->n_seq * 8 : 0);
   if (cfg->scaffold_gap != 0) {
     // the scaffold stage keeps two genome-pair tables (first appearance of a pair under either prefix rule): dense
     // G x G up to 2^14 genomes, else hashed over the pairs that occur (names without '#': every sequence its own genome)
