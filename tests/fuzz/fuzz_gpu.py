@@ -68,10 +68,17 @@ def random_case(rng, extras=True):
     # 2^62: RecordMeta's u64 coordinates through swg_filter64 / swg_filter_multi64 and the per-sequence rebasing
     if extras and rng.random() < 0.12:
         rec, _ = gen.shifted(rec, rng)
+    # --wide-gaps (drawn after everything else, off by default: earlier campaigns keep their cases): gap limits at the borders of
+    # the deep candidate kernel's three loops (<= 46340: 32-bit distances; < 2^31: 64-bit; beyond: the generic loop, where a
+    # limit of u64::MAX wraps like release Rust) -- never drawn by the list above
+    if WIDE_GAPS and kw["scaffold_gap"] != 0 and rng.random() < 0.5:
+        wide = [46_340, 46_341, 2**31 - 1, 2**31, 2**32 + 5, 2**63, 2**64 - 1]
+        kw["scaffold_gap"] = wide[int(rng.integers(0, len(wide)))]  # (by index: rng.choice would round the values to f64)
     return rec, kw, keep_self, scaffolds_only
 
 
 _CTXS = []
+WIDE_GAPS = False
 
 
 def contexts(k):
@@ -127,9 +134,12 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grouped", action="store_true", help="records sorted by query genome; with SWG_STREAM_CHUNK=<small>: the streamed path")
+    ap.add_argument("--wide-gaps", action="store_true", help="half of the scaffolding cases with a gap limit at 46340 / 46341 / 2^31 -+ 1 / "
+                                                                "beyond 2^32 / u64::MAX (combine with SWG_CHAIN_DEEP=1)")
     args = ap.parse_args()
-    global GROUPED
+    global GROUPED, WIDE_GAPS
     GROUPED = args.grouped
+    WIDE_GAPS = args.wide_gaps
     t0 = time.time()
     seed, cases, records, fails = args.seed, 0, 0, 0
     while time.time() - t0 < args.minutes * 60:

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Differential fuzz of the current build against the oracle (run through gpurun from the repo root):
 #   tools/fuzz_campaign.sh <tag> [minutes per leg = 3]
-# Legs: fuzz_gpu.py plain, with SWG_CHAIN_DEEP=1 (and with SWG_CAND_GENERIC=1 on top), with SWG_SORT_PAIRS=1, with SWG_SORT_BITS8=1,
+# Legs: fuzz_gpu.py plain, with SWG_CHAIN_DEEP=1 (and with SWG_CAND_GENERIC=1 on top; and with --wide-gaps: gap limits at the
+# borders of the deep candidate kernel's loops and beyond 2^32 -- added at the very end of round 4, NOT yet run on a GPU), with SWG_SORT_PAIRS=1, with SWG_SORT_BITS8=1,
 # with SWG_CHAIN_OLD=1, with SWG_SORT_DROP=0 (no sorts on truncated keys), with SWG_SLOTS=1 (record slots for the scaffold
 # stage's gather whatever the shape), and on
 # records grouped by query genome with SWG_STREAM_CHUNK=700 (the streamed host path, one context and several; every third
@@ -25,6 +26,7 @@ run gpu_old    SWG_CHAIN_OLD=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN 
 run gpu_nodrop SWG_SORT_DROP=0    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 20
 run gpu_slots  SWG_SLOTS=1        python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 21
 run gpu_deepg  SWG_CHAIN_DEEP=1 SWG_CAND_GENERIC=1 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 22
+run gpu_deepw  SWG_CHAIN_DEEP=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 23 --wide-gaps
 run gpu_stream SWG_STREAM_CHUNK=700 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 19 --grouped
 run seams      X=1                python3 tests/fuzz/fuzz_seams.py --minutes $MIN --seed 15
 run cli        X=1                python3 tests/fuzz/fuzz_cli.py --minutes $MIN --seed 16
