@@ -1040,7 +1040,8 @@ static void launch_candidates_wave(swg_ctx* ctx, hipStream_t st, G grid, uint64_
                                    uint32_t n_groups, const uint64_t* s_grp, const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts,
                                    const uint32_t* s_te, uint64_t max_gap, unsigned long long* c_d, uint32_t* c_j, uint32_t* c_n, uint32_t* c_ext) {
   static const bool generic = getenv("SWG_CAND_GENERIC") != nullptr;
-  const int mode = (generic || max_gap >= (uint64_t(1) << 31)) ? 0 : (max_gap <= 46340 ? 2 : 1);
+  // (the fast loops address a window by a 32-bit byte offset from its first element: up to 2^30 elements)
+  const int mode = (generic || max_gap >= (uint64_t(1) << 31) || m > (uint64_t(1) << 30)) ? 0 : (max_gap <= 46340 ? 2 : 1);
 #define SWG_CAND_LAUNCH(MODE)                                                                                                        \
   SWG_LAUNCH(ctx, "chain_candidates_wave", chain_candidates_wave_kernel<MODE><<<grid, EW, 0, st>>>(m, s_gidx, group_begin, n_groups, s_grp, s_qs, \
                                                                                                     s_qe, s_ts, s_te, max_gap, c_d, c_j, c_n, c_ext))
