@@ -1712,8 +1712,14 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
                                                         const uint32_t* __restrict__ c_j, const uint32_t* __restrict__ c_n,
                                                         unsigned long long* own, unsigned long long* prev,
                                                         uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
-                                                        unsigned long long* __restrict__ wstats) {
+                                                        unsigned long long* __restrict__ wstats,
+                                                        const uint32_t* __restrict__ n_blocks_dev = nullptr) {
   constexpr bool spec = SPEC;
+  // The pair-resident path (swg_pair.hip): the chunk list is made on the device, so its length is read here (n_blocks is
+  // then the list's capacity), and a chunk never leaves one (query, target, strand) group -- the strand comes with the
+  // descriptor (pad) and the group's end is the chunk's: s_grp / s_gidx / group_begin are not read (nullptr).
+  if (n_blocks_dev) n_blocks = min(n_blocks, *n_blocks_dev);
+  const bool pair_desc = s_gidx == nullptr;
   __shared__ unsigned long long ring[BIGW];          // scores of positions [base, base + BIGW) as this range sees them
   __shared__ uint32_t rq[BIGW], rt[BIGW], re[BIGW];  // their q_start, t_start, t_end
   __shared__ uint32_t hcnt[WALK_HASH];   // lowest lane naming a j that hashes here
@@ -1795,7 +1801,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       P.qe = P.ts = P.te = P.minus = 0;
       P.ei = ue;
       if (valid) {
-        if (!spec) {
+        if (!spec && !pair_desc) {
           const uint32_t g = s_gidx[i];
           const uint32_t ge = (g + 1 < n_groups) ? group_begin[g + 1] : m;
           if (ge < P.ei) P.ei = ge;
@@ -1804,7 +1810,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           P.qe = s_qe[i];
           P.ts = s_ts[i];
           P.te = s_te[i];
-          P.minus = (uint32_t)(s_grp[i] & 1ull);
+          P.minus = pair_desc ? D.pad : (uint32_t)(s_grp[i] & 1ull);
         } else {
 #pragma unroll
           for (int c = 0; c < KC; ++c) {
@@ -2010,7 +2016,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
           if (wstats && lane == 0) atomicAdd(&wstats[2], 1ull);  // whole-window passes
           const uint32_t ii = i0 + l;
           const uint64_t qe_l = s_qe[ii], ts_l = s_ts[ii], te_l = s_te[ii];
-          const bool minus_l = (s_grp[ii] & 1ull) != 0;
+          const bool minus_l = pair_desc ? D.pad != 0 : (s_grp[ii] & 1ull) != 0;
           const uint32_t e_l = readlane_u32(e_i, l);
           const uint64_t bound = qe_l + max_gap;
           uint64_t ld = INF;
@@ -3016,6 +3022,20 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
   W.group_begin = group_begin;
   W.pred = pred;
   W.d_tot = d_tot;
+  return SWG_OK;
+}
+
+// The walk over a chunk list made on the device (swg_pair.hip): every chunk lies inside one (query, target, strand) group and
+// carries its strand; `cap_chunks` bounds the list, *n_chunks_dev is its length.  pred must hold NONE for every member.
+int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* desc, const uint32_t* s_qs,
+                     const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, uint64_t max_gap, unsigned long long* bps,
+                     uint32_t* pred) {
+  if (cap_chunks == 0) return SWG_OK;
+  const uint64_t wb = cap_chunks < (uint64_t)ctx->num_cu * 64 ? cap_chunks : (uint64_t)ctx->num_cu * 64;
+  SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, ctx->stream>>>(
+                                    cap_chunks, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
+                                    nullptr, bps, bps, pred, pred, nullptr, n_chunks_dev));
+  SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
 

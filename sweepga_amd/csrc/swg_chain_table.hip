@@ -362,23 +362,7 @@ __global__ __launch_bounds__(EW) void chain_place_kernel(uint64_t nc, const uint
 // (chain_label_kernel for the chunks, chain_ok_kernel for the long units) into the head's slot of a sparse array: one 32-byte
 // sector per passing chain.  chain_columns_kernel then reads one sector per chain (round 3: six scattered 4 / 8-byte columns
 // at the head position, 250 bytes of HBM traffic per chain).
-struct __attribute__((aligned(32))) HeadRec {
-  uint32_t qs, qe, ts, te;
-  double wid;
-  uint64_t grp;  // (query * n_seq + target) * 2 + strand
-};
-
-// weighted identity of a chain (paf_filter.rs:896-913) from its aggregates
-__device__ __forceinline__ double chain_weighted_identity(uint64_t total_length, uint64_t sm, uint64_t sb) {
-  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
-  double lcg = 0.0;
-  if (gap_length > 0) {
-    lcg = swg_log_glibc((double)gap_length);
-    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
-  }
-  const double eff = __dadd_rn((double)sb, lcg);
-  return eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
-}
+// (HeadRec and chain_weighted_identity: swg_scaffold_internal.h)
 // Span / identity filter (paf_filter.rs:449-455) decided at the head, in position order: ok_head[p] = 1 iff p heads a chain
 // that passes.  Most chains are short singletons that fail the span test; only the passing ones are placed, materialised and
 // swept.  The number of all chains (a statistic) is counted on the way.
@@ -443,7 +427,11 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
                                                          const uint64_t* __restrict__ s_grp,
                                                          uint64_t min_len, double min_ident, uint32_t* __restrict__ hd,
                                                          uint8_t* __restrict__ ok_head, HeadRec* __restrict__ rec,
-                                                         unsigned long long* __restrict__ n_heads) {
+                                                         unsigned long long* __restrict__ n_heads,
+                                                         const uint32_t* __restrict__ n_chunks_dev = nullptr) {
+  // (the pair-resident path, swg_pair.hip: the chunk list's length lives on the device and s_grp is nullptr -- a HeadRec's
+  // group is not read there)
+  if (n_chunks_dev) n_chunks = min(n_chunks, *n_chunks_dev);
   __shared__ uint32_t lds[LABEL_FAST * 6];  // 36,864 bytes
   uint16_t* succ = reinterpret_cast<uint16_t*>(lds);            // [LABEL_CAP] (long chunks) / [LABEL_FAST]
   uint16_t* l_hd = succ + LABEL_FAST;                           // head of every element, relative to the chunk
@@ -525,7 +513,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
             hr.ts = ts;
             hr.te = te;
             hr.wid = wid;
-            hr.grp = s_grp[p];
+            hr.grp = s_grp ? s_grp[p] : 0ull;
             rec[p] = hr;
           }
         }
@@ -576,7 +564,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
           hr.ts = ts;
           hr.te = te;
           hr.wid = wid;
-          hr.grp = s_grp[p];
+          hr.grp = s_grp ? s_grp[p] : 0ull;
           rec[p] = hr;
         }
       }
@@ -820,6 +808,20 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
     SWG_LAUNCH(ctx, "survivor_chain", survivor_chain_kernel<<<nblk(m), EW, 0, st>>>(m, hd, ok_head, ch_head, (uint32_t)nc, rank_of, B.s_chain));
     SWG_KERNEL_CHECK(ctx);
   }
+  return SWG_OK;
+}
+
+// chain_label_kernel over a chunk list made on the device (swg_pair.hip).
+int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* chunks, const uint32_t* pred,
+                      const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, const uint32_t* s_m,
+                      const uint32_t* s_b, uint64_t min_len, double min_ident, uint32_t* hd, uint8_t* ok_head, HeadRec* rec,
+                      unsigned long long* n_heads) {
+  if (cap_chunks == 0) return SWG_OK;
+  const uint64_t lb = cap_chunks < (uint64_t)ctx->num_cu * 32 ? cap_chunks : (uint64_t)ctx->num_cu * 32;
+  SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                                             nullptr, min_len, min_ident, hd, ok_head, rec, n_heads,
+                                                                             n_chunks_dev));
+  SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
 

@@ -10,6 +10,7 @@
 #include "swg_internal.h"
 #include "swg_log.h"
 #include "swg_pipeline.h"
+#include "swg_scaffold_internal.h"
 #include "host/rebase.h"
 
 namespace {
@@ -218,6 +219,19 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
       c->call_group32 = nullptr;
     }
   } call_scope{ctx};
+  {
+    // Records grouped by chromosome pair, a scaffold stage, no limit in the mapping-level sweep: the pair-resident stage
+    // (swg_pair.hip) evaluates step 1 itself and takes the unlimited sweep as the identity -- it leaves the call to the
+    // stages below when it meets a retained record that an unlimited sweep would drop (zero length), or anything else it
+    // does not cover.
+    uint64_t kq1, kt1;
+    limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
+    if (cfg->scaffold_gap != 0 && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
+      int taken = 0;
+      SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, nullptr, nullptr, true, status_out, chain_out, stats, &taken));
+      if (taken) return SWG_OK;
+    }
+  }
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);
   uint8_t* keep1 = swg_alloc<uint8_t>(ctx, n);
   // The 32-byte record slots (both starts, both ends, score key, matches, block length).  The mapping-level sweep sorts and

@@ -105,46 +105,7 @@ __global__ __launch_bounds__(EW) void fwd_extract_kernel(uint64_t nf, const uint
   uint64_t k = (uint64_t)blockIdx.x * EW + threadIdx.x;
   if (k < nf) f_pm[k] = (uint32_t)comp[k];
 }
-// The two floating-point tests of the stage as integer thresholds.  Both are monotone in their integer argument --
-//   perpendicular distance  (u64)(deviation as f64 / SQRT_2) <= gap     (inversion capture, paf_filter.rs:570-580)
-//   Euclidean distance      (u64)sqrt((q^2 + t^2) as f64)    <= D       (rescue, paf_filter.rs:686-718)
-// (conversion, division by a positive constant, square root and truncation never decrease) -- so each holds exactly for the
-// arguments up to a largest one, found here by bisection WITH THE SAME OPERATIONS on the same unit; the per-candidate loops
-// then compare integers instead of an f64 division or square root per candidate (S-big1 `inversion` 2.1 -> 1.5 ms, S-pan c5
-// `rescue` 2.61 -> 2.46 ms).  out[0]: largest deviation that passes, out[1]: largest q^2 + t^2.
-__global__ void fp_thresholds_kernel(uint64_t gap, uint64_t D, uint64_t* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  auto perp_ok = [&](uint64_t deviation) {
-    const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
-    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
-    return perp <= gap;
-  };
-  auto dist_ok = [&](uint64_t s2) {
-    const double dd = __dsqrt_rn((double)s2);
-    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
-    return dist <= D;
-  };
-  // largest x with ok(x); ok(0) holds (0 <= gap, 0 <= D)
-  uint64_t res[2];
-  for (int which = 0; which < 2; ++which) {
-    auto ok = [&](uint64_t x) { return which == 0 ? perp_ok(x) : dist_ok(x); };
-    uint64_t lo = 0, hi = ~0ull;  // ok(lo); hi: not known
-    if (ok(hi)) {
-      lo = hi;
-    } else {
-      while (hi - lo > 1) {  // ok(lo) && !ok(hi)
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if (ok(mid))
-          lo = mid;
-        else
-          hi = mid;
-      }
-    }
-    res[which] = lo;
-  }
-  out[0] = res[0];
-  out[1] = res[1];
-}
+// (fp_thresholds_kernel: swg_scaffold_internal.h)
 
 // paf_filter.rs:535-597: a '-' record joins the first (lowest-numbered) kept '+' chain of its pair whose
 // diagonal it sits on.  Candidates: chains with q_start <= q_end(rec) + gap (binary search) and

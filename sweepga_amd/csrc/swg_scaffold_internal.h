@@ -32,6 +32,48 @@ static __global__ __launch_bounds__(EW) void iota_u32_kernel(uint64_t n, uint32_
   if (i < n) p[i] = (uint32_t)i;
 }
 
+// The two floating-point tests of the stage as integer thresholds.  Both are monotone in their integer argument --
+//   perpendicular distance  (u64)(deviation as f64 / SQRT_2) <= gap     (inversion capture, paf_filter.rs:570-580)
+//   Euclidean distance      (u64)sqrt((q^2 + t^2) as f64)    <= D       (rescue, paf_filter.rs:686-718)
+// (conversion, division by a positive constant, square root and truncation never decrease) -- so each holds exactly for the
+// arguments up to a largest one, found here by bisection WITH THE SAME OPERATIONS on the same unit; the per-candidate loops
+// then compare integers instead of an f64 division or square root per candidate (S-big1 `inversion` 2.1 -> 1.5 ms, S-pan c5
+// `rescue` 2.61 -> 2.46 ms).  out[0]: largest deviation that passes, out[1]: largest q^2 + t^2.
+static __global__ void fp_thresholds_kernel(uint64_t gap, uint64_t D, uint64_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto perp_ok = [&](uint64_t deviation) {
+    const double pd = __ddiv_rn((double)deviation, 1.4142135623730951);
+    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
+    return perp <= gap;
+  };
+  auto dist_ok = [&](uint64_t s2) {
+    const double dd = __dsqrt_rn((double)s2);
+    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
+    return dist <= D;
+  };
+  // largest x with ok(x); ok(0) holds (0 <= gap, 0 <= D)
+  uint64_t res[2];
+  for (int which = 0; which < 2; ++which) {
+    auto ok = [&](uint64_t x) { return which == 0 ? perp_ok(x) : dist_ok(x); };
+    uint64_t lo = 0, hi = ~0ull;  // ok(lo); hi: not known
+    if (ok(hi)) {
+      lo = hi;
+    } else {
+      while (hi - lo > 1) {  // ok(lo) && !ok(hi)
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (ok(mid))
+          lo = mid;
+        else
+          hi = mid;
+      }
+    }
+    res[which] = lo;
+  }
+  out[0] = res[0];
+  out[1] = res[1];
+}
+
+
 // genome pair (gq, gt) -> u32, "first appearance" tables of the two prefix rules.  Up to 2^14 genomes: a dense G x G array
 // (one load per lookup).  Beyond (names without '#': every contig its own genome): open addressing over the pairs that
 // actually occur -- their number is bounded by the (query, target) groups the caller has already counted.
@@ -111,6 +153,37 @@ constexpr int BIG_SPAN_SHIFT = 10;  // span_big's granularity = HEAD_SPAN = AGG_
 constexpr uint32_t WALK_CHUNK = 1024;  // a chunk = the units that begin in one WALK_CHUNK-element cell ...
 constexpr uint32_t BIG_UNIT = 8192;    // ... all shorter than this (longer units take the block-speculative path)
 
+// What the chain table needs of a chain that passes the span / identity filter, written ONCE by whoever decides the filter at
+// the chain's head into the head's slot of a sparse array: one 32-byte sector per passing chain.
+struct __attribute__((aligned(32))) HeadRec {
+  uint32_t qs, qe, ts, te;
+  double wid;
+  uint64_t grp;  // (query * n_seq + target) * 2 + strand (not written by the pair-resident path)
+};
+#ifdef __HIPCC__
+// weighted identity of a chain (paf_filter.rs:896-913) from its aggregates
+__device__ __forceinline__ double chain_weighted_identity(uint64_t total_length, uint64_t sm, uint64_t sb) {
+  const uint64_t gap_length = total_length > sb ? total_length - sb : 0;  // saturating_sub
+  double lcg = 0.0;
+  if (gap_length > 0) {
+    lcg = swg_log_glibc((double)gap_length);
+    if (!(lcg > 0.0)) lcg = 0.0;  // .max(0.0)
+  }
+  const double eff = __dadd_rn((double)sb, lcg);
+  return eff > 0.0 ? __ddiv_rn((double)sm, eff) : 0.0;
+}
+#endif
+constexpr uint32_t LABEL_CAP_ELEMS = WALK_CHUNK + BIG_UNIT;  // chain_label_kernel: a chunk holds fewer elements than this
+
+// Chunk-list launchers for the pair-resident path (swg_chain.hip, swg_chain_table.hip)
+int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* desc, const uint32_t* s_qs,
+                     const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, uint64_t max_gap, unsigned long long* bps,
+                     uint32_t* pred);
+int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* chunks, const uint32_t* pred,
+                      const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, const uint32_t* s_m,
+                      const uint32_t* s_b, uint64_t min_len, double min_ident, uint32_t* hd, uint8_t* ok_head, HeadRec* rec,
+                      unsigned long long* n_heads);
+
 
 // What the predecessor selection (swg_chain.hip) hands to the chain table (swg_chain_table.hip): the members of sort A in
 // A order (`s_*`, m entries), their (query, target, strand) groups, and pred[p] = best-buddy predecessor of p (NONE = head).
@@ -156,5 +229,10 @@ inline int build_chains(swg_ctx* ctx, const swg_records* r, const uint8_t* alive
 int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq, const uint32_t* seq_genome2,
                               uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
                               int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out);
+
+// The scaffold stage for inputs grouped by chromosome pair (swg_pair.hip): one work-group per pair, the pair's members sorted
+// inside LDS.  *taken = 0: not applicable -- the caller runs the global-sort stage (swg_scaffold_stage's own path).
+int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive, const uint8_t* member,
+                         bool sweep_assumed_identity, uint8_t* status_out, uint32_t* chain_out, swg_stats* stats, int* taken);
 
 }  // namespace swg_scaf

@@ -1,0 +1,167 @@
+"""The pair-resident scaffold stage (csrc/swg_pair.hip): inputs whose records are grouped by chromosome pair -- what an aligner
+writes -- are chained pair by pair inside LDS.  Status AND chain numbers must equal the CPU oracle's (src/paf_filter.rs:436-747),
+the path must really have been taken (the library's own launch table names its kernels), and SWG_GROUP_FUSED=0 (the global-sort
+stage) must give the same answer.  -m gpu only."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import gen, orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sw():
+    import sweepga_amd
+    sweepga_amd.default_context(0)
+    return sweepga_amd
+
+
+def permute(rec, perm):
+    out = copy.copy(rec)
+    n = len(perm)
+    for k, v in vars(rec).items():
+        if isinstance(v, np.ndarray) and v.shape[:1] == (n,):
+            setattr(out, k, np.ascontiguousarray(v[perm]))
+        elif isinstance(v, list) and len(v) == n:
+            setattr(out, k, [v[i] for i in perm])
+    out.rank = np.arange(n, dtype=rec.rank.dtype)
+    return out
+
+
+def pair_major(rec, rng=None):
+    """Records grouped by (query name, target name), the pairs in a random order, input order kept inside a pair."""
+    pairs = sorted(set(zip(rec.qname, rec.tname)))
+    if rng is not None:
+        rng.shuffle(pairs)
+    pair_of = {p: k for k, p in enumerate(pairs)}
+    key = np.array([pair_of[p] for p in zip(rec.qname, rec.tname)], dtype=np.int64)
+    return permute(rec, np.argsort(key, kind="stable"))
+
+
+def run_both(sw, rec, cfg_kw, keep_self=False, scaffolds_only=False, expect_pair_path=True):
+    kw = {k: (getattr(sw.FilterMode, v) if isinstance(v, str) else v) for k, v in cfg_kw.items()}
+    okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in cfg_kw.items()}
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    ctx = sw.default_context(0)
+    ctx.profile_reset()
+    ctx.profile(True)
+    f = sw.PafFilter(sw.FilterConfig(**kw)).with_keep_self(keep_self).with_scaffolds_only(scaffolds_only)
+    st, ch = f.filter_columns(packed)
+    ctx.profile(False)
+    table = ctx.profile_table()
+    took = "pair_finish" in table
+    ost, och = orc.apply_filters(orc.Config(keep_self=keep_self, scaffolds_only=scaffolds_only, **okw), rec)
+    bad = np.flatnonzero((st != ost) | (ch != och))
+    assert bad.size == 0, (cfg_kw, "pair path" if took else "global path", int(bad.size), bad[:10].tolist(),
+                           st[bad[:10]].tolist(), ost[bad[:10]].tolist(), ch[bad[:10]].tolist(), och[bad[:10]].tolist())
+    if expect_pair_path is not None:
+        assert took == expect_pair_path, (cfg_kw, sorted(table))
+    stats = f.last_stats
+    assert int(stats.n_out) == int((ost != 0).sum())
+    return st, ch, stats
+
+
+CONFIGS = [
+    {},                                                                   # the CLI defaults
+    {"scaffold_gap": 3_000, "min_scaffold_length": 2_000},
+    {"scaffold_gap": 20_000, "min_scaffold_length": 0},
+    {"scaffold_gap": 1_000, "min_scaffold_length": 500, "min_scaffold_identity": 0.85},
+    {"scaffold_gap": 100_000, "min_scaffold_length": 5_000, "min_identity": 0.8, "min_block_length": 300},
+]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_small_pairs_every_class(sw, seed):
+    rng = np.random.default_rng(9100 + seed)
+    n = int(rng.choice([300, 3_000, 20_000, 60_000]))
+    rec = gen.random_records(rng, n, n_genomes=int(rng.integers(2, 5)), chrs_per_genome=int(rng.integers(1, 4)),
+                             span=int(rng.choice([50_000, 400_000, 3_000_000])), minus_frac=float(rng.choice([0.0, 0.2, 0.5, 1.0])),
+                             zero_frac=0.0)
+    rec = pair_major(rec, rng)
+    for cfg in CONFIGS:
+        run_both(sw, rec, cfg)
+    run_both(sw, rec, CONFIGS[1], scaffolds_only=True)
+    run_both(sw, rec, CONFIGS[2], keep_self=True)
+
+
+def test_one_pair_per_size_class(sw):
+    """Pairs of ~900, ~3,500, ~14,000 and ~40,000 records (the four work-group shapes; the last one in several LDS batches)."""
+    rng = np.random.default_rng(77)
+    parts = []
+    for k, n in enumerate([900, 3_500, 14_000, 40_000, 17_000]):
+        r = gen.random_records(rng, n, n_genomes=1, chrs_per_genome=1, span=int(n * 300), minus_frac=0.15, zero_frac=0.0, self_frac=0.0)
+        r.qname = [f"a{k}#1#c" for _ in range(n)]
+        r.tname = [f"b{k}#1#c" for _ in range(n)]
+        parts.append(r)
+    rec = parts[0]
+    for r in parts[1:]:
+        rec = orc.Records(rec.qname + r.qname, rec.tname + r.tname, *[np.concatenate([getattr(rec, c), getattr(r, c)])
+                                                                       for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
+                          np.arange(len(rec) + len(r), dtype=np.uint64))
+    for cfg in ({}, {"scaffold_gap": 5_000, "min_scaffold_length": 3_000}, {"scaffold_gap": 400, "min_scaffold_length": 0}):
+        run_both(sw, rec, cfg)
+
+
+def test_dense_ties_and_equal_starts(sw):
+    """Many records with the same q_start (one bucket of the LDS sort holds them all): order falls to the input index."""
+    rng = np.random.default_rng(5)
+    n = 6_000
+    rec = gen.random_records(rng, n, n_genomes=2, chrs_per_genome=1, span=40_000, zero_frac=0.0)
+    rec.qs[: n // 2] = rec.qs[0]
+    rec.qe[: n // 2] = rec.qs[0] + 500 + (np.arange(n // 2) % 7).astype(np.uint64)
+    rec = pair_major(rec, rng)
+    for cfg in ({}, {"scaffold_gap": 2_000, "min_scaffold_length": 100}):
+        run_both(sw, rec, cfg)
+
+
+def test_numbering_over_genome_and_chromosome_pairs(sw):
+    """chain_N order: genome pair by first appearance (first two '#' parts), chromosome pair inside -- with four-part names where
+    the two prefix rules disagree, pairs without passing chains in between, and both strands opening a pair."""
+    rng = np.random.default_rng(31)
+    rec = gen.random_records(rng, 30_000, n_genomes=4, chrs_per_genome=3, span=600_000, minus_frac=0.4, zero_frac=0.0)
+    ren = {}
+    for nm in sorted(set(rec.qname) | set(rec.tname)):
+        g, h, c = nm.split("#")
+        ren[nm] = f"{g}#{h}#x{int(c[3:]) % 2}#{c}" if g in ("g0", "g1") else nm
+    rec.qname = [ren[x] for x in rec.qname]
+    rec.tname = [ren[x] for x in rec.tname]
+    rec = pair_major(rec, rng)
+    for cfg in ({"scaffold_gap": 10_000, "min_scaffold_length": 4_000}, {}):
+        run_both(sw, rec, cfg)
+
+
+def test_not_grouped_and_degenerate_inputs_take_the_global_path(sw):
+    rng = np.random.default_rng(8)
+    rec = gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.0)
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # pairs interleaved
+    rec = pair_major(gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.02), rng)
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # zero-length records
+
+
+def test_knob_off_gives_the_same_answer(sw):
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import sweepga_amd as sw
+from tests import gen, orc
+from tests.test_gpu_pairs import pair_major
+rng = np.random.default_rng(123)
+rec = pair_major(gen.random_records(rng, 20000, n_genomes=3, chrs_per_genome=2, span=500000, zero_frac=0.0), rng)
+ctx = sw.default_context(0)
+ctx.profile(True)
+st, ch = sw.PafFilter(sw.FilterConfig(scaffold_gap=5000, min_scaffold_length=2000)).filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+assert "pair_finish" not in ctx.profile_table()
+ost, och = orc.apply_filters(orc.Config(scaffold_gap=5000, min_scaffold_length=2000), rec)
+assert np.array_equal(st, ost) and np.array_equal(ch, och)
+print("ok")
+""" % ROOT
+    env = dict(os.environ, SWG_GROUP_FUSED="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
