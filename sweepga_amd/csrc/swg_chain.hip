@@ -1433,7 +1433,13 @@ __global__ __launch_bounds__(EW) void spec_init_kernel(uint32_t n_blocks, const 
                                                        const unsigned long long* __restrict__ ext,
                                                        unsigned long long* __restrict__ own,
                                                        unsigned long long* __restrict__ prev,
-                                                       uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev) {
+                                                       uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
+                                                       const uint32_t* __restrict__ n_dev = nullptr,
+                                                       const uint32_t* __restrict__ gate = nullptr) {
+  // (n_dev: the block list's length lives on the device; gate: a round that follows a round without changes does nothing --
+  // the pair-resident path enqueues its rounds without reading anything back, pair_walk_long_launch)
+  if (gate && *gate == 0) return;
+  if (n_dev) n_blocks = min(n_blocks, *n_dev);
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
     for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
@@ -1447,7 +1453,11 @@ __global__ __launch_bounds__(EW) void spec_init_kernel(uint32_t n_blocks, const 
 __global__ __launch_bounds__(EW) void spec_check_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
                                                         const unsigned long long* __restrict__ prev,
                                                         unsigned long long* __restrict__ ext,
-                                                        uint32_t* __restrict__ changed) {
+                                                        uint32_t* __restrict__ changed,
+                                                        const uint32_t* __restrict__ n_dev = nullptr,
+                                                        const uint32_t* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;
+  if (n_dev) n_blocks = min(n_blocks, *n_dev);
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
     for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
@@ -1462,7 +1472,9 @@ __global__ __launch_bounds__(EW) void spec_check_kernel(uint32_t n_blocks, const
 __global__ __launch_bounds__(EW) void spec_final_kernel(uint32_t n_blocks, const SpecBlock* __restrict__ desc,
                                                         const uint32_t* __restrict__ pred_own,
                                                         const uint32_t* __restrict__ pred_prev,
-                                                        uint32_t* __restrict__ pred) {
+                                                        uint32_t* __restrict__ pred,
+                                                        const uint32_t* __restrict__ n_dev = nullptr) {
+  if (n_dev) n_blocks = min(n_blocks, *n_dev);
   for (uint32_t bk = blockIdx.x; bk < n_blocks; bk += gridDim.x) {
     const SpecBlock D = desc[bk];
     for (uint32_t p = D.bb + threadIdx.x; p < D.be; p += EW) {
@@ -1713,8 +1725,10 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
                                                         unsigned long long* own, unsigned long long* prev,
                                                         uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
                                                         unsigned long long* __restrict__ wstats,
-                                                        const uint32_t* __restrict__ n_blocks_dev = nullptr) {
+                                                        const uint32_t* __restrict__ n_blocks_dev = nullptr,
+                                                        const uint32_t* __restrict__ gate = nullptr) {
   constexpr bool spec = SPEC;
+  if (gate && *gate == 0) return;  // (a speculative round behind a round without changes: pair_walk_long_launch)
   // The pair-resident path (swg_pair.hip): the chunk list is made on the device, so its length is read here (n_blocks is
   // then the list's capacity), and a chunk never leaves one (query, target, strand) group -- the strand comes with the
   // descriptor (pad) and the group's end is the chunk's: s_grp / s_gidx / group_begin are not read (nullptr).
@@ -1742,6 +1756,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
     const SpecBlock D = desc[bk];
     const uint32_t b = D.bb, be = D.be, ue = D.ue;  // i runs over [b, be), j may reach into the next block (< ue)
     if (be <= b || ue - b < 2) continue;
+    if (!SPEC && pair_desc && be - b >= LABEL_CAP_ELEMS) continue;  // a long unit of the pair-resident path: walked in blocks
     auto view_ptr = [&](uint32_t p) -> unsigned long long* { return (spec && p >= be) ? &prev[p] : &own[p]; };
     auto view_load = [&](uint32_t p) -> uint64_t {
       return __hip_atomic_load(view_ptr(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2076,6 +2091,74 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
       cur = nxt;
     }
   }
+}
+
+
+// Pair-resident path: the block plan of the long chunks, made on the device.  One work-group per long chunk: the longest window
+// (how many later members start within q_end + gap: the members are sorted by q_start, a binary search each), the block size S
+// (a multiple of 64, >= longest window + 1, >= 512), the block descriptors appended to one list, `ext` cleared.
+__global__ __launch_bounds__(EW) void pair_long_plan_kernel(uint32_t cap_long, const uint32_t* __restrict__ n_long_dev,
+                                                            const uint32_t* __restrict__ long_list, const SpecBlock* __restrict__ chunks,
+                                                            const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
+                                                            uint64_t max_gap, SpecBlock* __restrict__ desc, uint32_t cap_spec,
+                                                            uint32_t* __restrict__ counters /* [0] n_spec, [1] overflow */,
+                                                            unsigned long long* __restrict__ ext) {
+  __shared__ uint32_t wmaxs[EW / 64];
+  __shared__ uint32_t sh_off;
+  const uint32_t n_long = *n_long_dev < cap_long ? *n_long_dev : cap_long;
+  for (uint32_t c = blockIdx.x; c < n_long; c += gridDim.x) {
+    const SpecBlock D = chunks[long_list[c]];
+    const uint32_t b = D.bb, e = D.be;
+    uint32_t w = 0;
+    for (uint32_t p = b + threadIdx.x; p < e; p += EW) {
+      const uint64_t bound = (uint64_t)s_qe[p] + max_gap;  // wrapping, as release Rust
+      uint32_t lo = p + 1, hi = e;  // first position in (p, e) with q_start > bound
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)s_qs[mid] <= bound)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const uint32_t x = lo - 1 - p;
+      w = x > w ? x : w;
+      ext[p] = ~0ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(w, o, 64);
+      if (t > w) w = t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wmaxs[threadIdx.x >> 6] = w;
+    __syncthreads();
+    for (int k = 0; k < EW / 64; ++k)
+      if (wmaxs[k] > w) w = wmaxs[k];
+    uint32_t S = ((w + 1 + 63) / 64) * 64;
+    if (S < 512) S = 512;
+    const uint32_t nb = (e - b + S - 1) / S;
+    if (threadIdx.x == 0) sh_off = atomicAdd(&counters[0], nb);
+    __syncthreads();
+    const uint32_t off = sh_off;
+    if (off + nb > cap_spec) {
+      if (threadIdx.x == 0) counters[1] = 1;
+      continue;
+    }
+    for (uint32_t k = threadIdx.x; k < nb; k += EW) {
+      SpecBlock d;
+      d.ue = e;
+      d.bb = b + k * S;
+      d.be = d.bb + S < e ? d.bb + S : e;
+      d.pad = D.pad;
+      desc[off + k] = d;
+    }
+  }
+}
+// ... and what the rounds leave behind: a plan that did not fit, or rounds that did not settle, mark the call (the caller's
+// flag word: it then takes the global-sort path)
+__global__ void pair_long_verdict_kernel(const uint32_t* __restrict__ counters, const uint32_t* __restrict__ changed_last,
+                                         uint32_t* __restrict__ flags, uint32_t bit) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && (counters[1] || *changed_last)) atomicOr(flags, bit);
 }
 
 // Chunks of the walk over the units shorter than BIG_UNIT: unit u opens a chunk when it is the first unit to begin in its
@@ -3035,6 +3118,50 @@ int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks
   SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, ctx->stream>>>(
                                     cap_chunks, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
                                     nullptr, bps, bps, pred, pred, nullptr, n_chunks_dev));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+// The long chunks of the pair-resident path (a unit of LABEL_CAP_ELEMS members or more would pin one wavefront for its whole
+// length): cut into blocks and walked block-speculatively like the long units of the global path (above spec_plan_kernel), but
+// with everything decided on the device -- the plan, the list's length, and whether another round is needed: ROUNDS rounds
+// are enqueued, a round behind a round that changed nothing returns at once, and rounds that have not settled by then set
+// `fallback_bit` in *flags.  own / pred double as the walk's own score and predecessor arrays (the long chunks' positions belong
+// to no other chunk).
+int pair_walk_long_launch(swg_ctx* ctx, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list, const SpecBlock* chunks,
+                          uint32_t n_members_cap, const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te,
+                          uint64_t max_gap, unsigned long long* own, uint32_t* pred, uint32_t* flags, uint32_t fallback_bit) {
+  if (cap_long == 0) return SWG_OK;
+  hipStream_t st = ctx->stream;
+  constexpr int ROUNDS = 4;
+  const uint32_t cap_spec = n_members_cap / 512 + cap_long + 1;
+  SpecBlock* desc = swg_alloc<SpecBlock>(ctx, cap_spec);
+  unsigned long long* ext = swg_alloc<unsigned long long>(ctx, n_members_cap);
+  unsigned long long* v_prev = swg_alloc<unsigned long long>(ctx, n_members_cap);
+  uint32_t* p_prev = swg_alloc<uint32_t>(ctx, n_members_cap);
+  uint32_t* counters = swg_alloc<uint32_t>(ctx, 2 + ROUNDS);  // n_spec, overflow, changed[ROUNDS]
+  SWG_CHECK_ARENA(ctx);
+  SWG_HIP(ctx, hipMemsetAsync(counters, 0, (2 + ROUNDS) * sizeof(uint32_t), st));
+  const unsigned pg = cap_long < (uint32_t)ctx->num_cu * 4 ? cap_long : (unsigned)ctx->num_cu * 4;
+  SWG_LAUNCH(ctx, "spec_plan", pair_long_plan_kernel<<<pg, EW, 0, st>>>(cap_long, n_long_dev, long_list, chunks, s_qs, s_qe, max_gap, desc, cap_spec,
+                                                              counters, ext));
+  SWG_KERNEL_CHECK(ctx);
+  const unsigned rblocks = cap_spec < (uint32_t)ctx->num_cu * 8 ? cap_spec : (unsigned)ctx->num_cu * 8;
+  const unsigned wblocks = cap_spec < (uint32_t)ctx->num_cu * 32 ? cap_spec : (unsigned)ctx->num_cu * 32;
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t* gate = r ? counters + 2 + (r - 1) : nullptr;
+    SWG_LAUNCH(ctx, "spec_init", spec_init_kernel<<<rblocks, EW, 0, st>>>(cap_spec, desc, ext, own, v_prev, pred, p_prev, counters, gate));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<256, true, true><<<wblocks, 64, 0, st>>>(
+                                           cap_spec, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
+                                           nullptr, own, v_prev, pred, p_prev, nullptr, counters, gate));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<rblocks, EW, 0, st>>>(cap_spec, desc, v_prev, ext, counters + 2 + r, counters, gate));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  SWG_LAUNCH(ctx, "spec_final", spec_final_kernel<<<rblocks, EW, 0, st>>>(cap_spec, desc, pred, p_prev, pred, counters));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_LAUNCH(ctx, "spec_final", pair_long_verdict_kernel<<<1, 64, 0, st>>>(counters, counters + 2 + (ROUNDS - 1), flags, fallback_bit));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
   uint32_t heads = 0;  // chains headed in this thread's elements (a statistic: all chains, passing the filter or not)
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const uint32_t b = chunks[c].bb, e = chunks[c].be;
-    const uint32_t len = e > b ? e - b : 0;  // 0: a long unit's place holder
+    uint32_t len = e > b ? e - b : 0;  // 0: a long unit's place holder
+    if (len >= (uint32_t)LABEL_CAP) len = 0;  // (pair-resident path: a chunk too long for this LDS layout is pair_label_long's)
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < len; k += EW) succ[k] = NO;
     __syncthreads();
@@ -566,6 +567,88 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
           hr.wid = wid;
           hr.grp = s_grp ? s_grp[p] : 0ull;
           rec[p] = hr;
+        }
+      }
+      ok_head[p] = ok ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
+  if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
+}
+// The same for ONE chunk of any length per work-group (pair-resident path, swg_pair.hip: the long units of dense chromosome
+// pairs): heads by pointer jumping in memory, the aggregates accumulated by atomics in the head's own HeadRec slot (the box in
+// its coordinate fields, the sums of matches / block lengths in the two 8-byte fields), the filter decided by the head.
+__global__ __launch_bounds__(1024) void chain_label_long_kernel(uint32_t cap_long, const uint32_t* __restrict__ n_long_dev,
+                                                                const uint32_t* __restrict__ long_list,
+                                                                const SpecBlock* __restrict__ chunks, const uint32_t* __restrict__ pred,
+                                                                const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
+                                                                const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te,
+                                                                const uint32_t* __restrict__ s_m, const uint32_t* __restrict__ s_b,
+                                                                uint64_t min_len, double min_ident, uint32_t* hd,
+                                                                uint8_t* __restrict__ ok_head, HeadRec* rec,
+                                                                unsigned long long* __restrict__ n_heads) {
+  __shared__ uint32_t changed;
+  const uint32_t n_long = *n_long_dev < cap_long ? *n_long_dev : cap_long;
+  uint32_t heads = 0;
+  for (uint32_t c = blockIdx.x; c < n_long; c += gridDim.x) {
+    const SpecBlock D = chunks[long_list[c]];
+    const uint32_t b = D.bb, e = D.be;
+    for (uint32_t p = b + threadIdx.x; p < e; p += 1024) {
+      const uint32_t pr = pred[p];
+      hd[p] = pr == NONE ? p : pr;
+      if (pr == NONE) {  // a head: its slot starts from its own values
+        HeadRec hr;
+        hr.qs = s_qs[p];
+        hr.qe = s_qe[p];
+        hr.ts = s_ts[p];
+        hr.te = s_te[p];
+        hr.wid = __longlong_as_double((long long)(unsigned long long)s_b[p]);  // sum of block lengths, as bits
+        hr.grp = s_m[p];                                                       // sum of matches
+        rec[p] = hr;
+      }
+    }
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) changed = 0;
+      __syncthreads();
+      bool ch = false;
+      for (uint32_t p = b + threadIdx.x; p < e; p += 1024) {
+        const uint32_t h = __hip_atomic_load(&hd[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t hh = __hip_atomic_load(&hd[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (hh != h) {
+          __hip_atomic_store(&hd[p], hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ch = true;
+        }
+      }
+      if (ch) changed = 1;
+      __syncthreads();
+      if (!changed) break;
+    }
+    for (uint32_t p = b + threadIdx.x; p < e; p += 1024) {
+      const uint32_t h = hd[p];
+      if (h == p) continue;
+      ok_head[p] = 0;
+      atomicMax(&rec[h].qe, s_qe[p]);
+      atomicMin(&rec[h].ts, s_ts[p]);
+      atomicMax(&rec[h].te, s_te[p]);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].wid), (unsigned long long)s_b[p]);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].grp), (unsigned long long)s_m[p]);
+    }
+    __syncthreads();
+    for (uint32_t p = b + threadIdx.x; p < e; p += 1024) {
+      if (hd[p] != p) continue;
+      ++heads;
+      const HeadRec hr = rec[p];
+      const uint64_t sb = (uint64_t)__double_as_longlong(hr.wid), sm = hr.grp;
+      const uint64_t total_length = (uint64_t)hr.qe - (uint64_t)hr.qs;  // q_max - q_min (the head has the smallest q_start)
+      bool ok = total_length >= min_len;
+      if (ok) {
+        const double wid = chain_weighted_identity(total_length, sm, sb);
+        ok = wid >= min_ident;
+        if (ok) {
+          rec[p].wid = wid;
+          rec[p].grp = 0;
         }
       }
       ok_head[p] = ok ? 1 : 0;
@@ -815,13 +898,19 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
 int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* chunks, const uint32_t* pred,
                       const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, const uint32_t* s_m,
                       const uint32_t* s_b, uint64_t min_len, double min_ident, uint32_t* hd, uint8_t* ok_head, HeadRec* rec,
-                      unsigned long long* n_heads) {
+                      unsigned long long* n_heads, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list) {
   if (cap_chunks == 0) return SWG_OK;
   const uint64_t lb = cap_chunks < (uint64_t)ctx->num_cu * 32 ? cap_chunks : (uint64_t)ctx->num_cu * 32;
   SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
                                                                              nullptr, min_len, min_ident, hd, ok_head, rec, n_heads,
                                                                              n_chunks_dev));
   SWG_KERNEL_CHECK(ctx);
+  if (cap_long) {
+    const unsigned lg = cap_long < (uint32_t)ctx->num_cu ? cap_long : (unsigned)ctx->num_cu;
+    SWG_LAUNCH(ctx, "chain_label_long", chain_label_long_kernel<<<lg, 1024, 0, ctx->stream>>>(cap_long, n_long_dev, long_list, chunks, pred, s_qs, s_qe, s_ts,
+                                                                                  s_te, s_m, s_b, min_len, min_ident, hd, ok_head, rec, n_heads));
+    SWG_KERNEL_CHECK(ctx);
+  }
   return SWG_OK;
 }
 

@@ -21,6 +21,8 @@
 // sort key, no compaction), and the host reads back twice: the run list's size, and at the end the statistics together with
 // the "cannot be done here" flag (a unit too long for one chunk, a pair too dense for the LDS batches, a degenerate retained
 // record under an unlimited mapping sweep) that sends the call to the global-sort path instead.
+#include <type_traits>
+
 #include "swg_scaffold_internal.h"
 
 namespace swg_scaf {
@@ -53,7 +55,7 @@ struct PairCounters {
   uint32_t flags;
   uint32_t n_class[4];
   uint32_t n_chunks;
-  uint32_t pad;
+  uint32_t n_long;
   unsigned long long n_alive, n_members, n_heads, n_kept, n_out;
 };
 
@@ -238,11 +240,14 @@ __device__ __forceinline__ void bucket_map_make(BucketMap& B, uint32_t nbk, uint
   }
 }
 __device__ __forceinline__ uint32_t bucket_of(const BucketMap& B, uint32_t st, uint32_t k) {
-  const float f = (float)(k - B.kmin[st]) * B.scale[st];
+  // (selects, not B.x[st]: an array indexed by a run-time value is sent through scratch memory)
+  const uint32_t kmin = st ? B.kmin[1] : B.kmin[0], nb = st ? B.nb[1] : B.nb[0], off = st ? B.off[1] : B.off[0];
+  const float scale = st ? B.scale[1] : B.scale[0];
+  const float f = (float)(k - kmin) * scale;
   uint32_t b = (uint32_t)f;
-  const uint32_t top = B.nb[st] - 1u;
+  const uint32_t top = nb - 1u;
   b = b < top ? b : top;
-  return B.off[st] + b;
+  return off + b;
 }
 
 struct PairSortArgs {
@@ -262,32 +267,497 @@ struct PairSortArgs {
   PairInfo* info;
   SpecBlock* chunks;
   uint32_t cap_chunks;
+  uint32_t* long_list;  // indices (into chunks) of the chunks of LABEL_CAP_ELEMS members and more
+  uint32_t cap_long;
   PairCounters* C;
   PairTable gl_first;
   const uint32_t* seq_genome_last;
 };
 
-// NT threads, CAP = NT * E members per LDS batch, NBK buckets, IT = index type inside the pair (u16 while a run has at most
-// 65,535 records), XL: runs longer than a batch (several batches over coarse bins of the key range, columns gathered).
-template <int NT, int E, int NBK, typename IT, bool XL>
+// What a pair_sort work-group does once its members are in order, shared by the two kernels below.
+//
+// emit_chunks: the chunk list of the walk from the per-cell first unit starts (cellmin; one thread).  The first unit of every
+// cell opens a chunk, and so does the first '-' member; a chunk of LABEL_CAP_ELEMS members or more (a long unit) is also put on
+// the list of the chunks that chain_label_long_kernel labels.
+__device__ void emit_chunks(const PairSortArgs& A, uint32_t a, uint32_t m, uint32_t m_plus, const uint32_t* cellmin, int n_cell) {
+  uint32_t prev = NONE, count = 0, n_long = 0, prev2 = NONE;
+  const bool mp_pending = m_plus > 0 && m_plus < m;
+  auto for_starts = [&](auto&& f) {
+    bool pend = mp_pending;
+    for (int c = 0; c < n_cell; ++c) {
+      const uint32_t v = cellmin[c];
+      if (v == NONE) continue;
+      if (pend && m_plus <= v) {
+        if (m_plus < v) f(m_plus);
+        pend = false;
+      }
+      f(v);
+    }
+    if (pend) f(m_plus);
+  };
+  for_starts([&](uint32_t v) {
+    ++count;
+    if (prev2 != NONE && v - prev2 >= LABEL_CAP_ELEMS) ++n_long;
+    prev2 = v;
+  });
+  if (prev2 != NONE && m - prev2 >= LABEL_CAP_ELEMS) ++n_long;
+  const uint32_t slot = atomicAdd(&A.C->n_chunks, count);
+  uint32_t lslot = n_long ? atomicAdd(&A.C->n_long, n_long) : 0u;
+  if (slot + count > A.cap_chunks || (n_long && lslot + n_long > A.cap_long)) {  // (the capacities are upper bounds: not reached)
+    atomicOr(&A.C->flags, PF_FALLBACK);
+    return;
+  }
+  uint32_t k = 0;
+  auto emit = [&](uint32_t b, uint32_t e) {
+    SpecBlock d;
+    d.bb = a + b;
+    d.be = a + e;
+    d.ue = d.be;
+    d.pad = b >= m_plus ? 1u : 0u;
+    if (e - b >= LABEL_CAP_ELEMS) A.long_list[lslot++] = slot + k;
+    A.chunks[slot + k++] = d;
+  };
+  for_starts([&](uint32_t v) {
+    if (prev != NONE) emit(prev, v);
+    prev = v;
+  });
+  if (prev != NONE) emit(prev, m);
+}
+// unit_starts: the thread's E consecutive positions p0 .. p0 + E of a batch of mb members that begins at pair position
+// `base`; qs / qe are their sorted q_start / q_end.  Position p opens a unit when its q_start lies beyond every earlier q_end
+// of its strand by more than the gap (no window of paf_filter.rs:786-796 can straddle it).  The first unit start of every cell
+// goes into cellmin; *carry_max: running maximum of ((strand << 32) | q_end) over the batches so far.
+template <int NT, int E>
+__device__ __forceinline__ void unit_starts(const uint32_t (&qs)[E], const uint32_t (&qe)[E], uint32_t mb, uint32_t base, uint32_t m_plus,
+                                            uint64_t max_gap, uint64_t* ws64, uint32_t* cellmin, uint64_t* carry_max) {
+  const uint32_t p0 = (uint32_t)threadIdx.x * E;
+  uint64_t tmax = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (p0 + e < mb) {
+      const uint64_t c = ((uint64_t)(base + p0 + e >= m_plus ? 1u : 0u) << 32) | qe[e];
+      tmax = c > tmax ? c : tmax;
+    }
+  uint64_t tot;
+  uint64_t prev = block_excl_max<NT>(tmax, ws64, &tot);
+  prev = prev > *carry_max ? prev : *carry_max;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (p0 + e < mb) {
+      const uint32_t pa = base + p0 + e;
+      uint64_t lim = (prev & 0xffffffffull) + max_gap;
+      if (lim < max_gap) lim = ~0ull;  // saturate
+      if (pa == 0 || pa == m_plus || (uint64_t)qs[e] > lim) atomicMin(&cellmin[pa / PAIR_CELL], pa);
+      const uint64_t c = ((uint64_t)(pa >= m_plus ? 1u : 0u) << 32) | qe[e];
+      prev = c > prev ? c : prev;
+    }
+  *carry_max = tot > *carry_max ? tot : *carry_max;
+}
+// the thread's E consecutive words of an LDS array, as 16-byte reads (4-way bank conflicts instead of 16-way)
+template <int E>
+__device__ __forceinline__ void read_block(const uint32_t* lds, uint32_t (&out)[E]) {
+  static_assert(E % 4 == 0, "whole 16-byte reads");
+  const uint4* v = reinterpret_cast<const uint4*>(lds) + (size_t)threadIdx.x * (E / 4);
+#pragma unroll
+  for (int j = 0; j < E / 4; ++j) {
+    const uint4 x = v[j];
+    out[4 * j] = x.x;
+    out[4 * j + 1] = x.y;
+    out[4 * j + 2] = x.z;
+    out[4 * j + 3] = x.w;
+  }
+}
+
+#ifdef SWG_PAIR_TIMING
+__device__ unsigned long long g_pair_t[16];
+#define PT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_pair_t[k], t_ - pt_last); pt_last = t_; } } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
+// One work-group per pair of at most NT * E records.  Every global load of a phase is requested before the first value is used
+// (a thread's E records one after the other would be E memory round trips in a row -- the work-group is alone on its CU when it
+// uses most of the LDS, nothing else hides them).
+template <int NT, int E, int NBK>
 __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
   constexpr int CAP = NT * E;
-  constexpr int NCELL = XL ? (int)PAIR_XL_CELLS : (CAP + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
-  constexpr int NBIN = XL ? 4096 : 1;       // XL: coarse bins that the batches are made of
-  constexpr int MAXB = XL ? 128 : 1;        // XL: batches per pair at most (2 * PAIR_XL_MAX / CAP + 1 would do)
-  __shared__ uint32_t K[CAP];
-  __shared__ IT I[CAP];
+  constexpr int NCELL = (CAP + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
+  __shared__ __attribute__((aligned(16))) uint32_t K[CAP];
+  __shared__ uint16_t I[CAP];
+  __shared__ uint16_t R[CAP];
   __shared__ uint32_t cnt[NBK];
-  __shared__ uint16_t R[XL ? 1 : CAP];
-  __shared__ uint32_t QE[XL ? CAP : 1];
+  __shared__ uint32_t cellmin[NCELL];
+  __shared__ uint64_t ws64[NT / 64 + 1];
+  __shared__ uint32_t ws[NT / 64 + 1];
+  __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3];
+#ifdef SWG_PAIR_TIMING
+  unsigned long long pt_last = wall_clock64();
+#endif
+  const int tid = threadIdx.x;
+  const uint32_t rk_run = A.list[blockIdx.x];
+  const PairRun run = A.runs[rk_run];
+  const uint32_t a = run.a, n = run.n;
+  if (tid < 4) sh_cnt[tid] = 0;
+  if (tid < 2) {
+    sh_kmin[tid] = 0xffffffffu;
+    sh_kmax[tid] = 0;
+  }
+  if (tid < 3) sh_first[tid] = NONE;
+  for (int c = tid; c < NCELL; c += NT) cellmin[c] = NONE;
+  for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
+  __syncthreads();
+  // ---- step-1 retain, members, the key range per strand
+  const uint32_t q0 = A.q_id[a], t0 = A.t_id[a];
+  const bool self_ok = A.keep_self || q0 != t0;
+  uint32_t qk[E];                                   // q_start of the thread's records (record e: tid + e * NT)
+  uint32_t member_mask = 0, strand_mask = 0, extra_mask = 0;
+  {
+    uint32_t alive_mask = 0, in_mask = 0;
+    // (two halves: sixteen 8-byte identities requested at once, beside everything else, do not fit the register file of a
+    // 1024-thread work-group)
+    auto half = [&](auto off_c) {
+      constexpr int OFF = decltype(off_c)::value, H = E / 2;
+      uint8_t stv[H];
+#pragma unroll
+      for (int e = 0; e < H; ++e) {
+        const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
+        const uint32_t i = a + (li < n ? li : 0u);
+        in_mask |= (li < n ? 1u : 0u) << (OFF + e);
+        stv[e] = A.strand[i];
+        qk[OFF + e] = A.q_start[i];
+      }
+      if (A.alive_in) {
+        uint8_t av[H], mv[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+          const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
+          const uint32_t i = a + (li < n ? li : 0u);
+          av[e] = A.alive_in[i];
+          mv[e] = A.member_in ? A.member_in[i] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+          if (av[e]) alive_mask |= 1u << (OFF + e);
+          if (av[e] && mv[e]) member_mask |= 1u << (OFF + e);
+        }
+      } else {
+        double idv[H];
+        uint32_t blv[H];
+        const bool need_bl = A.min_block != 0 || !A.identity;
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+          const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
+          const uint32_t i = a + (li < n ? li : 0u);
+          blv[e] = need_bl ? A.block_len[i] : 0u;
+          idv[e] = A.identity ? A.identity[i] : (double)A.matches[i];
+        }
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+          // identity == nullptr: matches over max(block length, 1), one IEEE division (src/paf_filter.rs:322)
+          const double id = A.identity ? idv[e] : __ddiv_rn(idv[e], (double)(blv[e] > 1u ? blv[e] : 1u));
+          const bool alive = self_ok && (A.min_block == 0 || (uint64_t)blv[e] >= A.min_block) && id >= A.min_identity;
+          if (alive) {
+            alive_mask |= 1u << (OFF + e);
+            member_mask |= 1u << (OFF + e);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < H; ++e) strand_mask |= (stv[e] ? 1u : 0u) << (OFF + e);
+    };
+    half(std::integral_constant<int, 0>{});
+    asm volatile("" ::: "memory");
+    half(std::integral_constant<int, E / 2>{});
+    alive_mask &= in_mask;
+    member_mask &= in_mask;
+    extra_mask = alive_mask & ~member_mask;
+    uint32_t c_m[2] = {0, 0}, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
+      const uint32_t st = (strand_mask >> e) & 1u;
+      if (li < n) A.code[a + li] = (alive_mask >> e) & 1u ? (uint8_t)((((member_mask >> e) & 1u) ? 1u : 2u) | (st << 2)) : (uint8_t)0;
+      if ((alive_mask >> e) & 1u) {
+        if (fst[2] == NONE) fst[2] = a + li;
+        if ((member_mask >> e) & 1u) {
+#pragma unroll
+          for (uint32_t s2 = 0; s2 < 2; ++s2)  // (no array indexed by a run-time strand: see bucket_of)
+            if (st == s2) {
+              ++c_m[s2];
+              kmin[s2] = qk[e] < kmin[s2] ? qk[e] : kmin[s2];
+              kmax[s2] = qk[e] > kmax[s2] ? qk[e] : kmax[s2];
+              if (fst[s2] == NONE) fst[s2] = a + li;
+            }
+        }
+      }
+    }
+    uint32_t c_x = (uint32_t)__popc(extra_mask);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      c_m[0] += __shfl_xor(c_m[0], o, 64);
+      c_m[1] += __shfl_xor(c_m[1], o, 64);
+      c_x += __shfl_xor(c_x, o, 64);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t x = __shfl_xor(kmin[s], o, 64), y = __shfl_xor(kmax[s], o, 64);
+        kmin[s] = x < kmin[s] ? x : kmin[s];
+        kmax[s] = y > kmax[s] ? y : kmax[s];
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const uint32_t x = __shfl_xor(fst[s], o, 64);
+        fst[s] = x < fst[s] ? x : fst[s];
+      }
+    }
+    if ((tid & 63) == 0) {
+      if (c_m[0]) atomicAdd(&sh_cnt[0], c_m[0]);
+      if (c_m[1]) atomicAdd(&sh_cnt[1], c_m[1]);
+      if (c_x) atomicAdd(&sh_cnt[2], c_x);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        if (c_m[s]) {
+          atomicMin(&sh_kmin[s], kmin[s]);
+          atomicMax(&sh_kmax[s], kmax[s]);
+        }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (fst[s] != NONE) atomicMin(&sh_first[s], fst[s]);
+    }
+  }
+  __syncthreads();
+  const uint32_t m_plus = sh_cnt[0], m = sh_cnt[0] + sh_cnt[1], n_x = sh_cnt[2], M = m + n_x;
+  PT_STAMP(1);
+  if (tid == 0) {
+    PairInfo pi;
+    pi.m = m;
+    pi.m_plus = m_plus;
+    pi.M = M;
+    pi.first_alive = sh_first[2];
+    pi.first_mem[0] = sh_first[0];
+    pi.first_mem[1] = sh_first[1];
+    pi.q = q0;
+    pi.t = t0;
+    A.info[rk_run] = pi;
+    if (sh_first[2] != NONE) {  // the genome pair's first alive record (apply_plane_sweep_to_mappings' group order, :1037-1046)
+      uint32_t* slot = pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]);
+      if (*slot > sh_first[2]) atomicMin(slot, sh_first[2]);
+    }
+    if (M) {
+      atomicAdd(&A.C->n_alive, (unsigned long long)M);
+      atomicAdd(&A.C->n_members, (unsigned long long)m);
+    }
+  }
+  if (M == 0) return;
+  bool degenerate = false;
+  // ---- the alive records that are not members (behind a mapping sweep): kept with the pair for the inversion capture and
+  // the rescue, behind the members, in input order; bit 31 of their index carries the strand
+  if (n_x) {
+    uint32_t done = 0;
+#pragma unroll 1
+    for (int e = 0; e < E; ++e) {
+      if ((uint32_t)e * NT >= n) break;
+      const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
+      const bool x = (extra_mask >> e) & 1u;
+      uint32_t tot;
+      const uint32_t r = block_excl_sum<NT>(x ? 1u : 0u, ws, &tot);
+      if (x) {
+        const uint32_t i = a + li, p = a + m + done + r;
+        const uint32_t qs = qk[e], qe = A.q_end[i], ts = A.t_start[i], te = A.t_end[i];
+        A.s_qs[p] = qs;
+        A.s_qe[p] = qe;
+        A.s_ts[p] = ts;
+        A.s_te[p] = te;
+        A.s_idx[p] = i | (((strand_mask >> e) & 1u) << 31);
+        degenerate |= qs >= qe || ts >= te;
+      }
+      done += tot;
+    }
+  }
+  if (m == 0) {
+    if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
+    return;
+  }
+  // ---- bucket sort of the members by (strand, q_start, index)
+  BucketMap FM;
+  {
+    const uint32_t kmn[2] = {sh_kmin[0], sh_kmin[1]}, kmx[2] = {sh_kmax[0], sh_kmax[1]};
+    bucket_map_make(FM, NBK, m_plus, m - m_plus, kmn, kmx);
+  }
+  uint32_t bk[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if ((member_mask >> e) & 1u) {
+      bk[e] = bucket_of(FM, (strand_mask >> e) & 1u, qk[e]);
+      atomicAdd(&cnt[bk[e]], 1u);
+    }
+  __syncthreads();
+  PT_STAMP(2);
+  {
+    constexpr int PER = NBK / NT;
+    static_assert(NBK % NT == 0 && PER >= 1, "bucket counters per thread");
+    uint32_t c[PER], sum = 0, tot;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      c[j] = cnt[tid * PER + j];
+      sum += c[j];
+    }
+    uint32_t off = block_excl_sum<NT>(sum, ws, &tot);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      cnt[tid * PER + j] = off;
+      off += c[j];
+    }
+  }
+  __syncthreads();
+  PT_STAMP(3);
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if ((member_mask >> e) & 1u) {
+      const uint32_t pos = atomicAdd(&cnt[bk[e]], 1u);  // (unordered inside a bucket; cnt[b] ends as the bucket's end)
+      K[pos] = qk[e];
+      I[pos] = (uint16_t)((uint32_t)tid + (uint32_t)e * NT);
+    }
+  __syncthreads();
+  PT_STAMP(4);
+  {
+    // order inside the buckets: final position = bucket begin + the bucket's elements that order before by (key, index)
+    uint32_t rk[E], rr[E];
+    uint16_t rl[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t pos = (uint32_t)tid + (uint32_t)e * NT;
+      rr[e] = NONE;
+      if (pos < m) {
+        const uint32_t k = K[pos], li = I[pos];
+        const uint32_t b = bucket_of(FM, pos >= m_plus ? 1u : 0u, k);
+        const uint32_t hi = cnt[b], lo = b ? cnt[b - 1] : 0u;
+        uint32_t r = lo;
+        for (uint32_t x = lo; x < hi; ++x) {
+          const uint32_t kx = K[x], lx = I[x];
+          r += (kx < k || (kx == k && lx < li)) ? 1u : 0u;
+        }
+        rk[e] = k;
+        rl[e] = (uint16_t)li;
+        rr[e] = r;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (rr[e] != NONE) {
+        K[rr[e]] = rk[e];
+        I[rr[e]] = rl[e];
+      }
+  }
+  __syncthreads();
+  PT_STAMP(5);
+  // ---- the sorted q_start and record index out; every member's rank
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
+    if (p < m) {
+      const uint32_t li = I[p];
+      A.s_qs[a + p] = K[p];
+      A.s_idx[a + p] = a + li;
+      A.pred[a + p] = NONE;
+      R[li] = (uint16_t)p;
+    }
+  }
+  uint32_t qs_r[E];  // the thread's own E consecutive positions, for the unit cuts
+  read_block<E>(K, qs_r);
+  __syncthreads();
+  PT_STAMP(6);
+  uint16_t rp[E];  // where the thread's records go
+#pragma unroll
+  for (int e = 0; e < E; ++e) rp[e] = R[((uint32_t)tid + (uint32_t)e * NT) < (uint32_t)CAP ? ((uint32_t)tid + (uint32_t)e * NT) : 0u];
+  // ---- the other columns, transposed through LDS: coalesced reads in input order land at their sorted position, coalesced
+  // writes follow
+  auto load_col = [&](const uint32_t* __restrict__ src, uint32_t (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
+      v[e] = src[a + (li < n ? li : 0u)];
+    }
+  };
+  auto put_col = [&](const uint32_t (&v)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((member_mask >> e) & 1u) K[rp[e]] = v[e];
+  };
+  auto store_col = [&](uint32_t* __restrict__ dst) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
+      if (p < m) dst[a + p] = K[p];
+    }
+  };
+  uint64_t carry_max = 0;
+  {
+    uint32_t v[E];
+    load_col(A.q_end, v);
+    put_col(v);
+    __syncthreads();
+    store_col(A.s_qe);
+    uint32_t qe_r[E];
+    read_block<E>(K, qe_r);
+#pragma unroll
+    for (int e = 0; e < E; ++e) degenerate |= (uint32_t)tid * E + e < m && qs_r[e] >= qe_r[e];
+    unit_starts<NT, E>(qs_r, qe_r, m, 0u, m_plus, A.max_gap, ws64, cellmin, &carry_max);  // (its barriers also close the column)
+    __syncthreads();
+  }
+  PT_STAMP(7);
+  {
+    uint32_t v[E], w[E];  // one column goes through LDS while the next one's loads are in flight
+    load_col(A.t_start, w);
+    load_col(A.t_end, v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) degenerate |= ((member_mask >> e) & 1u) && w[e] >= v[e];
+    put_col(w);
+    __syncthreads();
+    store_col(A.s_ts);
+    __syncthreads();
+    PT_STAMP(8);
+    load_col(A.matches, w);
+    put_col(v);
+    __syncthreads();
+    store_col(A.s_te);
+    __syncthreads();
+    PT_STAMP(9);
+    load_col(A.block_len, v);
+    put_col(w);
+    __syncthreads();
+    store_col(A.s_m);
+    __syncthreads();
+    PT_STAMP(10);
+    put_col(v);
+    __syncthreads();
+    store_col(A.s_b);
+  }
+  PT_STAMP(11);
+  if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
+  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, NCELL);  // (cellmin: complete since unit_starts' barrier ... and the later ones)
+  PT_STAMP(12);
+}
+
+// Runs longer than one LDS batch: the key range is cut into coarse bins, consecutive bins are glued into batches of at most CAP
+// members, every batch is bucket-sorted like a small pair (its members picked out of the run by two passes over the run's
+// q_start column), and the other columns are gathered by record index.
+template <int NT, int E, int NBK>
+__global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
+  constexpr int CAP = NT * E;
+  constexpr int NBIN = 4096, MAXB = 128, U = 8;
+  __shared__ __attribute__((aligned(16))) uint32_t K[CAP];
+  __shared__ __attribute__((aligned(16))) uint32_t QE[CAP];
+  __shared__ uint32_t I[CAP];
+  __shared__ uint32_t cnt[NBK];
   __shared__ uint32_t bins[NBIN];
   __shared__ uint32_t b_lo[MAXB + 1];
-  __shared__ uint32_t cellmin[NCELL];
+  __shared__ uint32_t cellmin[PAIR_XL_CELLS];
   __shared__ uint64_t ws64[NT / 64 + 1];
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3], sh_nb, sh_bad;
   const int tid = threadIdx.x;
-  const PairRun run = A.runs[A.list[blockIdx.x]];
+  const uint32_t rk_run = A.list[blockIdx.x];
+  const PairRun run = A.runs[rk_run];
   const uint32_t a = run.a, n = run.n;
   if (tid < 4) sh_cnt[tid] = 0;
   if (tid < 2) {
@@ -296,44 +766,58 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
   }
   if (tid < 3) sh_first[tid] = NONE;
   if (tid == 0) sh_bad = 0;
-  for (int c = tid; c < NCELL; c += NT) cellmin[c] = NONE;
+  for (int c = tid; c < (int)PAIR_XL_CELLS; c += NT) cellmin[c] = NONE;
+  for (int b = tid; b < NBIN; b += NT) bins[b] = 0;
   __syncthreads();
-  // ---- step-1 retain, members, the key range per strand
   const uint32_t q0 = A.q_id[a], t0 = A.t_id[a];
   const bool self_ok = A.keep_self || q0 != t0;
-  uint32_t member_mask = 0;  // (!XL) bit e: record tid + e * NT is a member
+  // ---- step-1 retain, members, the key range per strand (U records per thread requested together)
   {
     uint32_t c_m[2] = {0, 0}, c_x = 0, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
-    int e = 0;
-    for (uint32_t li = tid; li < n; li += NT, ++e) {
-      const uint32_t i = a + li;
-      bool alive;
-      if (A.alive_in) {
-        alive = A.alive_in[i] != 0;
-      } else {
-        double id;
-        if (A.identity) {
-          id = A.identity[i];
-        } else {
-          const uint32_t bl = A.block_len[i];
-          id = __ddiv_rn((double)A.matches[i], (double)(bl > 1u ? bl : 1u));
-        }
-        alive = self_ok && (A.min_block == 0 || (uint64_t)A.block_len[i] >= A.min_block) && id >= A.min_identity;
+    for (uint32_t l0 = 0; l0 < n; l0 += NT * U) {
+      uint8_t stv[U], av[U], mv[U];
+      uint32_t qv[U], blv[U];
+      double idv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t li = l0 + (uint32_t)u * NT + (uint32_t)tid;
+        const uint32_t i = a + (li < n ? li : 0u);
+        stv[u] = A.strand[i];
+        qv[u] = A.q_start[i];
+        av[u] = A.alive_in ? A.alive_in[i] : (uint8_t)1;
+        mv[u] = A.member_in ? A.member_in[i] : (uint8_t)1;
+        blv[u] = (!A.alive_in && (A.min_block != 0 || !A.identity)) ? A.block_len[i] : 0u;
+        idv[u] = A.alive_in ? 1.0 : (A.identity ? A.identity[i] : (double)A.matches[i]);
       }
-      const bool member = alive && (A.member_in ? A.member_in[i] != 0 : true);
-      const uint32_t st = A.strand[i] ? 1u : 0u;
-      A.code[i] = alive ? (uint8_t)((member ? 1u : 2u) | (st << 2)) : (uint8_t)0;
-      if (alive) {
-        if (fst[2] == NONE) fst[2] = i;
-        if (member) {
-          const uint32_t qs = A.q_start[i];
-          ++c_m[st];
-          kmin[st] = qs < kmin[st] ? qs : kmin[st];
-          kmax[st] = qs > kmax[st] ? qs : kmax[st];
-          if (fst[st] == NONE) fst[st] = i;
-          if (!XL) member_mask |= 1u << e;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t li = l0 + (uint32_t)u * NT + (uint32_t)tid;
+        if (li >= n) continue;
+        const uint32_t i = a + li;
+        bool alive;
+        if (A.alive_in) {
+          alive = av[u] != 0;
         } else {
-          ++c_x;
+          const double id = A.identity ? idv[u] : __ddiv_rn(idv[u], (double)(blv[u] > 1u ? blv[u] : 1u));
+          alive = self_ok && (A.min_block == 0 || (uint64_t)blv[u] >= A.min_block) && id >= A.min_identity;
+        }
+        const bool member = alive && mv[u] != 0;
+        const uint32_t st = stv[u] ? 1u : 0u;
+        A.code[i] = alive ? (uint8_t)((member ? 1u : 2u) | (st << 2)) : (uint8_t)0;
+        if (alive) {
+          if (fst[2] == NONE) fst[2] = i;
+          if (member) {
+#pragma unroll
+            for (uint32_t s2 = 0; s2 < 2; ++s2)
+              if (st == s2) {
+                ++c_m[s2];
+                kmin[s2] = qv[u] < kmin[s2] ? qv[u] : kmin[s2];
+                kmax[s2] = qv[u] > kmax[s2] ? qv[u] : kmax[s2];
+                if (fst[s2] == NONE) fst[s2] = i;
+              }
+          } else {
+            ++c_x;
+          }
         }
       }
     }
@@ -381,8 +865,8 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
     pi.first_mem[1] = sh_first[1];
     pi.q = q0;
     pi.t = t0;
-    A.info[A.list[blockIdx.x]] = pi;
-    if (sh_first[2] != NONE) {  // the genome pair's first alive record (apply_plane_sweep_to_mappings' group order, :1037-1046)
+    A.info[rk_run] = pi;
+    if (sh_first[2] != NONE) {
       uint32_t* slot = pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]);
       if (*slot > sh_first[2]) atomicMin(slot, sh_first[2]);
     }
@@ -393,8 +877,6 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
   }
   if (M == 0) return;
   bool degenerate = false;
-  // ---- the alive records that are not members (behind a mapping sweep): kept with the pair for the inversion capture and
-  // the rescue, behind the members, in input order; bit 31 of their index carries the strand
   if (n_x) {
     uint32_t done = 0;
     for (uint32_t l0 = 0; l0 < n; l0 += NT) {
@@ -420,102 +902,94 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
     if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
     return;
   }
-  const uint32_t kmn[2] = {sh_kmin[0], sh_kmin[1]}, kmx[2] = {sh_kmax[0], sh_kmax[1]};
-  // ---- batches (XL: runs of coarse bins of at most CAP members each; otherwise the whole pair is one batch)
-  uint32_t n_batches = 1;
-  BucketMap BM;
-  if (XL) {
-    bucket_map_make(BM, NBIN, m_plus, m - m_plus, kmn, kmx);
-    for (int b = tid; b < NBIN; b += NT) bins[b] = 0;
-    __syncthreads();
-    for (uint32_t li = tid; li < n; li += NT) {
-      const uint8_t code = A.code[a + li];
-      if ((code & 3u) == 1u) atomicAdd(&bins[bucket_of(BM, code >> 2, A.q_start[a + li])], 1u);
+  // a pass over the run's members: f(li, strand, q_start), U records per thread requested together
+  auto for_members = [&](auto&& f) {
+    for (uint32_t l0 = 0; l0 < n; l0 += NT * U) {
+      uint8_t cv[U];
+      uint32_t qv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t li = l0 + (uint32_t)u * NT + (uint32_t)tid;
+        cv[u] = li < n ? A.code[a + li] : (uint8_t)0;
+        qv[u] = A.q_start[a + (li < n ? li : 0u)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((cv[u] & 3u) == 1u) f(l0 + (uint32_t)u * NT + (uint32_t)tid, (uint32_t)(cv[u] >> 2), qv[u]);
     }
-    __syncthreads();
-    if (tid == 0) {  // greedy: a batch is closed when the next bin would not fit
-      uint32_t nb = 0, acc = 0;
-      b_lo[0] = 0;
-      for (uint32_t b = 0; b < (uint32_t)NBIN; ++b) {
-        const uint32_t c = bins[b];
-        if (c > (uint32_t)CAP) sh_bad = 1;  // one bin denser than a batch: not for this path
-        if (acc + c > (uint32_t)CAP && nb + 1 < (uint32_t)MAXB) {
+  };
+  // ---- coarse bins -> batches
+  BucketMap BM;
+  {
+    const uint32_t kmn[2] = {sh_kmin[0], sh_kmin[1]}, kmx[2] = {sh_kmax[0], sh_kmax[1]};
+    bucket_map_make(BM, NBIN, m_plus, m - m_plus, kmn, kmx);
+  }
+  for_members([&](uint32_t, uint32_t st, uint32_t k) { atomicAdd(&bins[bucket_of(BM, st, k)], 1u); });
+  __syncthreads();
+  if (tid == 0) {  // greedy: a batch is closed when the next bin would not fit
+    uint32_t nb = 0, acc = 0;
+    b_lo[0] = 0;
+    for (uint32_t b = 0; b < (uint32_t)NBIN; ++b) {
+      const uint32_t c = bins[b];
+      if (c > (uint32_t)CAP) sh_bad = 1;  // one bin denser than a batch: not for this path
+      if (acc + c > (uint32_t)CAP) {
+        if (nb + 1 < (uint32_t)MAXB) {
           b_lo[++nb] = b;
           acc = 0;
-        } else if (acc + c > (uint32_t)CAP) {
+        } else {
           sh_bad = 1;
         }
-        acc += c;
       }
-      b_lo[++nb] = NBIN;
-      sh_nb = nb;
+      acc += c;
     }
-    __syncthreads();
-    if (sh_bad) {
-      if (tid == 0) atomicOr(&A.C->flags, PF_FALLBACK);
-      return;
-    }
-    n_batches = sh_nb;
+    b_lo[++nb] = NBIN;
+    sh_nb = nb;
   }
-  uint64_t carry_max = 0;  // running maximum of ((strand << 32) | q_end) over the positions before the batch
-  uint32_t base = 0;       // members before the batch
+  __syncthreads();
+  if (sh_bad) {
+    if (tid == 0) atomicOr(&A.C->flags, PF_FALLBACK);
+    return;
+  }
+  const uint32_t n_batches = sh_nb;
+  uint64_t carry_max = 0;
+  uint32_t base = 0;
   for (uint32_t bt = 0; bt < n_batches; ++bt) {
-    const uint32_t bin_lo = XL ? b_lo[bt] : 0u, bin_hi = XL ? b_lo[bt + 1] : 1u;
-    // fine buckets of the batch: XL -- the coarse map refined by a power of two, relative to the batch's first bin
-    int xl_shift = 0;      // fine id = (uint32)(f * 2^12) >> xl_shift, minus the batch's first
-    uint32_t xl_first = 0;
-    BucketMap FM;
-    if (XL) {
-      // f < NBIN = 2^12 has 12 integer bits, so f * 2^12 is exact in the integer part's relation to f: (uint32)(f * 4096) >> 12
-      // == (uint32)f (multiplying a float by a power of two is exact), and the refinement stays monotone
-      const uint32_t span = (bin_hi - bin_lo) << 12;
-      while ((span >> xl_shift) > (uint32_t)NBK) ++xl_shift;
-      xl_first = (bin_lo << 12) >> xl_shift;
-    } else {
-      bucket_map_make(FM, NBK, m_plus, m - m_plus, kmn, kmx);
-    }
-    auto coarse_of = [&](uint32_t st, uint32_t k) -> uint32_t { return bucket_of(BM, st, k); };
-    auto fine_of = [&](uint32_t st, uint32_t k) -> uint32_t {
-      if (XL) {
-        const float f = (float)(k - BM.kmin[st]) * BM.scale[st];
-        const uint32_t top = BM.nb[st] - 1u;
-        uint32_t g = (uint32_t)(f * 4096.0f);
-        const uint32_t cb = g >> 12;
-        if (cb > top) g = (top << 12) | 0xfffu;  // (the clamp of bucket_of, in fine units)
-        g += BM.off[st] << 12;
-        const uint32_t b = (g >> xl_shift) - xl_first;
-        return b < (uint32_t)NBK ? b : (uint32_t)NBK - 1u;
-      }
-      return bucket_of(FM, st, k);
+    const uint32_t bin_lo = b_lo[bt], bin_hi = b_lo[bt + 1];
+    // fine buckets of the batch: the coarse map refined by a power of two, relative to the batch's first bin.  f < NBIN = 2^12
+    // has 12 integer bits and multiplying a float by 2^12 is exact, so (uint32)(f * 4096) >> 12 == (uint32)f: the fine id
+    // names the coarse bin in its high bits and stays monotone in the key.
+    int shift = 0;
+    while ((((bin_hi - bin_lo) << 12) >> shift) > (uint32_t)NBK) ++shift;
+    const uint32_t first = (bin_lo << 12) >> shift;
+    auto fine_of = [&](uint32_t st, uint32_t k, uint32_t* coarse) -> uint32_t {
+      const float f = (float)(k - (st ? BM.kmin[1] : BM.kmin[0])) * (st ? BM.scale[1] : BM.scale[0]);
+      const uint32_t top = (st ? BM.nb[1] : BM.nb[0]) - 1u;
+      uint32_t g = (uint32_t)(f * 4096.0f);
+      if ((g >> 12) > top) g = (top << 12) | 0xfffu;  // (the clamp of bucket_of, in fine units)
+      g += (st ? BM.off[1] : BM.off[0]) << 12;
+      *coarse = g >> 12;
+      const uint32_t b = (g >> shift) - first;
+      return b < (uint32_t)NBK ? b : (uint32_t)NBK - 1u;
     };
     for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
     __syncthreads();
-    // count
-    if (XL) {
-      for (uint32_t li = tid; li < n; li += NT) {
-        const uint8_t code = A.code[a + li];
-        if ((code & 3u) != 1u) continue;
-        const uint32_t k = A.q_start[a + li], st = code >> 2, cb = coarse_of(st, k);
-        if (cb >= bin_lo && cb < bin_hi) atomicAdd(&cnt[fine_of(st, k)], 1u);
-      }
-    } else {
-      int e = 0;
-      for (uint32_t li = tid; li < n; li += NT, ++e)
-        if (member_mask & (1u << e)) atomicAdd(&cnt[fine_of(A.strand[a + li] ? 1u : 0u, A.q_start[a + li])], 1u);
-    }
+    for_members([&](uint32_t, uint32_t st, uint32_t k) {
+      uint32_t cb;
+      const uint32_t fb = fine_of(st, k, &cb);
+      if (cb >= bin_lo && cb < bin_hi) atomicAdd(&cnt[fb], 1u);
+    });
     __syncthreads();
-    // exclusive scan of the bucket counts (NBK / NT consecutive counters per thread)
     uint32_t mb;
     {
       constexpr int PER = NBK / NT;
       static_assert(NBK % NT == 0 && PER >= 1, "bucket counters per thread");
-      uint32_t c[PER], s = 0;
+      uint32_t c[PER], sum = 0;
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
         c[j] = cnt[tid * PER + j];
-        s += c[j];
+        sum += c[j];
       }
-      uint32_t off = block_excl_sum<NT>(s, ws, &mb);
+      uint32_t off = block_excl_sum<NT>(sum, ws, &mb);
 #pragma unroll
       for (int j = 0; j < PER; ++j) {
         cnt[tid * PER + j] = off;
@@ -523,30 +997,16 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
       }
     }
     __syncthreads();
-    // scatter (unordered inside a bucket; cnt[b] ends as the bucket's end)
-    if (XL) {
-      for (uint32_t li = tid; li < n; li += NT) {
-        const uint8_t code = A.code[a + li];
-        if ((code & 3u) != 1u) continue;
-        const uint32_t k = A.q_start[a + li], st = code >> 2, cb = coarse_of(st, k);
-        if (cb >= bin_lo && cb < bin_hi) {
-          const uint32_t pos = atomicAdd(&cnt[fine_of(st, k)], 1u);
-          K[pos] = k;
-          I[pos] = (IT)li;
-        }
+    for_members([&](uint32_t li, uint32_t st, uint32_t k) {
+      uint32_t cb;
+      const uint32_t fb = fine_of(st, k, &cb);
+      if (cb >= bin_lo && cb < bin_hi) {
+        const uint32_t pos = atomicAdd(&cnt[fb], 1u);
+        K[pos] = k;
+        I[pos] = li;
       }
-    } else {
-      int e = 0;
-      for (uint32_t li = tid; li < n; li += NT, ++e)
-        if (member_mask & (1u << e)) {
-          const uint32_t k = A.q_start[a + li];
-          const uint32_t pos = atomicAdd(&cnt[fine_of(A.strand[a + li] ? 1u : 0u, k)], 1u);
-          K[pos] = k;
-          I[pos] = (IT)li;
-        }
-    }
+    });
     __syncthreads();
-    // order inside the buckets: final position = bucket begin + the bucket's elements that order before by (key, index)
     const uint32_t plus_here = m_plus > base ? (m_plus - base < mb ? m_plus - base : mb) : 0u;  // '+' members of the batch
     {
       uint32_t rk[E], rl[E], rr[E];
@@ -555,12 +1015,13 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
         const uint32_t pos = (uint32_t)tid + (uint32_t)e * NT;
         rr[e] = NONE;
         if (pos < mb) {
-          const uint32_t k = K[pos], li = (uint32_t)I[pos];
-          const uint32_t b = fine_of(pos >= plus_here ? 1u : 0u, k);
+          const uint32_t k = K[pos], li = I[pos];
+          uint32_t cb;
+          const uint32_t b = fine_of(pos >= plus_here ? 1u : 0u, k, &cb);
           const uint32_t hi = cnt[b], lo = b ? cnt[b - 1] : 0u;
           uint32_t r = lo;
           for (uint32_t x = lo; x < hi; ++x) {
-            const uint32_t kx = K[x], lx = (uint32_t)I[x];
+            const uint32_t kx = K[x], lx = I[x];
             r += (kx < k || (kx == k && lx < li)) ? 1u : 0u;
           }
           rk[e] = k;
@@ -573,145 +1034,56 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
       for (int e = 0; e < E; ++e)
         if (rr[e] != NONE) {
           K[rr[e]] = rk[e];
-          I[rr[e]] = (IT)rl[e];
+          I[rr[e]] = rl[e];
         }
     }
     __syncthreads();
-    // ---- the sorted q_start and record index out; the other columns in that order
-    for (uint32_t p = tid; p < mb; p += NT) {
-      const uint32_t li = (uint32_t)I[p];
-      A.s_qs[a + base + p] = K[p];
-      A.s_idx[a + base + p] = a + li;
-      A.pred[a + base + p] = NONE;
-      if (!XL) R[li] = (uint16_t)p;
-    }
-    uint32_t qs_r[E], qe_r[E];  // the thread's own E consecutive positions, for the cuts
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t p = (uint32_t)tid * E + e;
-      qs_r[e] = p < mb ? K[p] : 0u;
-    }
-    __syncthreads();
-    if (XL) {
-      for (uint32_t p = tid; p < mb; p += NT) {
-        const uint32_t i = a + (uint32_t)I[p];
-        const uint32_t qe = A.q_end[i], ts = A.t_start[i], te = A.t_end[i];
-        QE[p] = qe;
-        A.s_qe[a + base + p] = qe;
-        A.s_ts[a + base + p] = ts;
-        A.s_te[a + base + p] = te;
-        A.s_m[a + base + p] = A.matches[i];
-        A.s_b[a + base + p] = A.block_len[i];
-        degenerate |= K[p] >= qe || ts >= te;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t p = (uint32_t)tid * E + e;
-        qe_r[e] = p < mb ? QE[p] : 0u;
-      }
-    } else {
-      // transposition through LDS: coalesced reads in input order land at their sorted position, coalesced writes follow
-      auto column = [&](const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ lower, bool keep) {
-        int e = 0;
-        for (uint32_t li = tid; li < n; li += NT, ++e)
-          if (member_mask & (1u << e)) {
-            const uint32_t v = src[a + li];
-            K[R[li]] = v;
-            if (lower) degenerate |= lower[a + li] >= v;  // start >= end (the start was loaded a moment ago: L1)
-          }
-        __syncthreads();
-        for (uint32_t p = tid; p < mb; p += NT) dst[a + p] = K[p];
-        if (keep) {
-#pragma unroll
-          for (int e2 = 0; e2 < E; ++e2) {
-            const uint32_t p = (uint32_t)tid * E + e2;
-            qe_r[e2] = p < mb ? K[p] : 0u;
-          }
-        }
-        __syncthreads();
-      };
-      column(A.q_end, A.s_qe, A.q_start, true);
-      column(A.t_start, A.s_ts, nullptr, false);
-      column(A.t_end, A.s_te, A.t_start, false);
-      column(A.matches, A.s_m, nullptr, false);
-      column(A.block_len, A.s_b, nullptr, false);
-    }
-    // ---- units: position p opens one when its q_start lies beyond every earlier q_end of its strand by more than the gap
-    // (no window of paf_filter.rs:786-796 can straddle it); a chunk = the units that begin in one cell
+    // ---- the batch's columns out, gathered by record index (every load of the thread requested together)
     {
-      uint64_t pre[E], tmax = 0;
+      uint32_t li[E], qe[E], ts[E], te[E], mm[E], bb[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const uint32_t p = (uint32_t)tid * E + e;
-        pre[e] = tmax;
-        if (p < mb) {
-          const uint64_t c = ((uint64_t)(base + p >= m_plus ? 1u : 0u) << 32) | qe_r[e];
-          tmax = c > tmax ? c : tmax;
-        }
+        const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
+        li[e] = p < mb ? I[p] : 0u;
       }
-      uint64_t tot;
-      uint64_t before = block_excl_max<NT>(tmax, ws64, &tot);
-      before = before > carry_max ? before : carry_max;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const uint32_t p = (uint32_t)tid * E + e;
+        const uint32_t i = a + li[e];
+        qe[e] = A.q_end[i];
+        ts[e] = A.t_start[i];
+        te[e] = A.t_end[i];
+        mm[e] = A.matches[i];
+        bb[e] = A.block_len[i];
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
         if (p >= mb) continue;
-        const uint32_t pa = base + p;
-        const uint64_t prev = pre[e] > before ? pre[e] : before;
-        uint64_t lim = (prev & 0xffffffffull) + A.max_gap;
-        if (lim < A.max_gap) lim = ~0ull;  // saturate
-        const bool unit = pa == 0 || pa == m_plus || (uint64_t)qs_r[e] > lim;
-        if (unit) atomicMin(&cellmin[pa / PAIR_CELL], pa);
+        const uint32_t o = a + base + p, qs = K[p];
+        QE[p] = qe[e];
+        A.s_qs[o] = qs;
+        A.s_idx[o] = a + li[e];
+        A.pred[o] = NONE;
+        A.s_qe[o] = qe[e];
+        A.s_ts[o] = ts[e];
+        A.s_te[o] = te[e];
+        A.s_m[o] = mm[e];
+        A.s_b[o] = bb[e];
+        degenerate |= qs >= qe[e] || ts[e] >= te[e];
       }
-      carry_max = tot > carry_max ? tot : carry_max;
+    }
+    __syncthreads();
+    {
+      uint32_t qs_r[E], qe_r[E];
+      read_block<E>(K, qs_r);
+      read_block<E>(QE, qe_r);
+      unit_starts<NT, E>(qs_r, qe_r, mb, base, m_plus, A.max_gap, ws64, cellmin, &carry_max);
     }
     base += mb;
     __syncthreads();
   }
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
-  // ---- the chunk list: the first unit of every cell opens a chunk, and so does the first '-' member
-  if (tid == 0) {
-    uint32_t prev = NONE, count = 0;
-    bool mp_pending = m_plus > 0 && m_plus < m;
-    // two passes over the starts: count, reserve, write
-    auto for_starts = [&](auto&& f) {
-      bool pend = mp_pending;
-      for (int c = 0; c < NCELL; ++c) {
-        const uint32_t v = cellmin[c];
-        if (v == NONE) continue;
-        if (pend && m_plus <= v) {
-          if (m_plus < v) f(m_plus);
-          pend = false;
-        }
-        f(v);
-      }
-      if (pend) f(m_plus);
-    };
-    for_starts([&](uint32_t) { ++count; });
-    const uint32_t slot = atomicAdd(&A.C->n_chunks, count);
-    if (slot + count > A.cap_chunks) {
-      atomicOr(&A.C->flags, PF_FALLBACK);
-    } else {
-      uint32_t k = 0;
-      bool bad = false;
-      auto emit = [&](uint32_t b, uint32_t e) {
-        SpecBlock d;
-        d.bb = a + b;
-        d.be = a + e;
-        d.ue = a + e;
-        d.pad = b >= m_plus ? 1u : 0u;
-        A.chunks[slot + k++] = d;
-        if (e - b >= LABEL_CAP_ELEMS) bad = true;  // a unit too long for the per-chunk labelling
-      };
-      for_starts([&](uint32_t v) {
-        if (prev != NONE) emit(prev, v);
-        prev = v;
-      });
-      if (prev != NONE) emit(prev, m);
-      if (bad) atomicOr(&A.C->flags, PF_FALLBACK);
-    }
-  }
+  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, (int)PAIR_XL_CELLS);
 }
 
 // ---- pair_finish ----------------------------------------------------------------------------------------------------
@@ -741,6 +1113,9 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint64_t ws64[NT / 64 + 1];
   const int tid = threadIdx.x;
+  // a pair_sort work-group gave the call up (a unit too long for a chunk ...): its chunks were not made, so the labels of its
+  // pair do not exist; nothing written from here on is used (the host sees the same flag and runs the global-sort stage)
+  if (A.C->flags & PF_FALLBACK) return;
   const uint32_t rk = A.list[blockIdx.x];
   const PairRun run = A.runs[rk];
   const PairInfo pi = A.info[rk];
@@ -888,11 +1263,12 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
 // member (paf_filter.rs:1037-1046, 1110-1120, 761-770).
 __global__ __launch_bounds__(EW) void pair_key1_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, const PairSum* __restrict__ sum,
                                                        PairTable gl_first, const uint32_t* __restrict__ seq_genome_last,
-                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                       uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                       const PairCounters* __restrict__ C) {
   const uint32_t k = blockIdx.x * EW + threadIdx.x;
   if (k >= n_runs) return;
   uint64_t x = ~0ull;
-  if (sum[k].n_pass) {
+  if (!(C->flags & PF_FALLBACK) && sum[k].n_pass) {
     const uint32_t g = pair_get(gl_first, seq_genome_last[info[k].q], seq_genome_last[info[k].t]);
     x = ((uint64_t)g << 32) | sum[k].minmem;
   }
@@ -901,20 +1277,22 @@ __global__ __launch_bounds__(EW) void pair_key1_kernel(uint32_t n_runs, const Pa
 }
 __global__ __launch_bounds__(EW) void pair_rank1_kernel(uint32_t n_runs, const uint32_t* __restrict__ order, const PairInfo* __restrict__ info,
                                                         const PairSum* __restrict__ sum, const uint32_t* __restrict__ seq_genome_two,
-                                                        PairTable gp2_first, uint32_t* __restrict__ rank1) {
+                                                        PairTable gp2_first, uint32_t* __restrict__ rank1,
+                                                        const PairCounters* __restrict__ C) {
   const uint32_t r = blockIdx.x * EW + threadIdx.x;
   if (r >= n_runs) return;
   const uint32_t k = order[r];
   rank1[k] = r;
-  if (sum[k].n_pass) atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
+  if (!(C->flags & PF_FALLBACK) && sum[k].n_pass) atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
 }
 __global__ __launch_bounds__(EW) void pair_key2_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, const PairSum* __restrict__ sum,
                                                        const uint32_t* __restrict__ rank1, const uint32_t* __restrict__ seq_genome_two,
-                                                       PairTable gp2_first, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                       PairTable gp2_first, uint64_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                       const PairCounters* __restrict__ C) {
   const uint32_t k = blockIdx.x * EW + threadIdx.x;
   if (k >= n_runs) return;
   uint64_t x = ~0ull;
-  if (sum[k].n_pass) x = ((uint64_t)pair_get(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]) << 32) | rank1[k];
+  if (!(C->flags & PF_FALLBACK) && sum[k].n_pass) x = ((uint64_t)pair_get(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]) << 32) | rank1[k];
   key[k] = x;
   val[k] = k;
 }
@@ -933,10 +1311,12 @@ __global__ __launch_bounds__(EW) void pair_base_kernel(uint32_t n_runs, const ui
 constexpr int NUMBER_SMALL = 2048;
 __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, PairSum* __restrict__ sum,
                                                                  PairTable gl_first, const uint32_t* __restrict__ seq_genome_last,
-                                                                 PairTable gp2_first, const uint32_t* __restrict__ seq_genome_two) {
+                                                                 PairTable gp2_first, const uint32_t* __restrict__ seq_genome_two,
+                                                                 const PairCounters* __restrict__ C) {
   __shared__ uint64_t key[NUMBER_SMALL];
   __shared__ uint32_t kept[NUMBER_SMALL];
   const int tid = threadIdx.x;
+  if (C->flags & PF_FALLBACK) return;  // (the sums were not written)
   uint64_t k1[NUMBER_SMALL / 1024];
   uint32_t r1[NUMBER_SMALL / 1024];
 #pragma unroll
@@ -992,7 +1372,8 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
 }
 // chain numbers: pair-local -> global (records of pairs without kept chains hold zeros)
 __global__ __launch_bounds__(EW) void pair_renumber_kernel(uint32_t n_runs, const PairRun* __restrict__ runs, const PairSum* __restrict__ sum,
-                                                           uint32_t* __restrict__ chain) {
+                                                           uint32_t* __restrict__ chain, const PairCounters* __restrict__ C) {
+  if (C->flags & PF_FALLBACK) return;
   for (uint32_t k = blockIdx.x; k < n_runs; k += gridDim.x) {
     const uint32_t base = sum[k].base;
     if (base == 0 || sum[k].n_kept == 0) continue;
@@ -1080,6 +1461,8 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   PairSum* sum = swg_alloc<PairSum>(ctx, n_runs);
   const uint32_t cap_chunks = n / PAIR_CELL + 2 * n_runs + 16;
   SpecBlock* chunks = swg_alloc<SpecBlock>(ctx, cap_chunks);
+  const uint32_t cap_long = n / LABEL_CAP_ELEMS + 1;
+  uint32_t* long_list = swg_alloc<uint32_t>(ctx, cap_long);
   uint64_t* fp_thr = swg_alloc<uint64_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   PairTable gl_first, gp2_first;
@@ -1098,21 +1481,25 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.max_gap = cfg->scaffold_gap;
   SA.runs = runs;
   SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = s_m; SA.s_b = s_b; SA.s_idx = s_idx; SA.pred = pred;
-  SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
-  for (int c = 0; c < 4; ++c) {
+  SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
+  for (int c = 3; c >= 0; --c) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
     if (!ncls[c]) continue;
     SA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 256, uint16_t, false><<<ncls[c], 64, 0, st>>>(SA)); break;
-      case 1: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 1024, uint16_t, false><<<ncls[c], 256, 0, st>>>(SA)); break;
-      case 2: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<1024, 16, 4096, uint16_t, false><<<ncls[c], 1024, 0, st>>>(SA)); break;
-      default: SWG_LAUNCH_N(ctx, "pair_sort_xl", 0, pair_sort_kernel<1024, 8, 4096, uint32_t, true><<<ncls[c], 1024, 0, st>>>(SA)); break;
+      case 0: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 256><<<ncls[c], 64, 0, st>>>(SA)); break;
+      case 1: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 1024><<<ncls[c], 256, 0, st>>>(SA)); break;
+      case 2: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<1024, 16, 4096><<<ncls[c], 1024, 0, st>>>(SA)); break;
+      default: SWG_LAUNCH_N(ctx, "pair_sort_xl", 0, pair_sort_xl_kernel<1024, 8, 4096><<<ncls[c], 1024, 0, st>>>(SA)); break;
     }
     SWG_KERNEL_CHECK(ctx);
   }
   SWG_TRY(pair_walk_launch(ctx, cap_chunks, &C->n_chunks, chunks, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred));
+  const bool long_possible = ncls[2] + ncls[3] > 0;  // (a chunk of LABEL_CAP_ELEMS members needs a pair of at least as many)
+  if (long_possible)
+    SWG_TRY(pair_walk_long_launch(ctx, cap_long, &C->n_long, long_list, chunks, n, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred,
+                                  &C->flags, PF_FALLBACK));
   SWG_TRY(pair_label_launch(ctx, cap_chunks, &C->n_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b, cfg->min_scaffold_length,
-                            cfg->min_scaffold_identity, hd, ok_head, head_rec, &C->n_heads));
+                            cfg->min_scaffold_identity, hd, ok_head, head_rec, &C->n_heads, long_possible ? cap_long : 0u, &C->n_long, long_list));
   PairFinishArgs FA{};
   FA.runs = runs; FA.info = info; FA.sum = sum;
   FA.s_qs = s_qs; FA.s_qe = s_qe; FA.s_ts = s_ts; FA.s_te = s_te; FA.s_idx = s_idx; FA.hd = hd; FA.ok_head = ok_head; FA.rec = head_rec;
@@ -1132,7 +1519,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   // ---- chain_N bases
   if (n_runs <= (uint32_t)NUMBER_SMALL) {
     SWG_LAUNCH(ctx, "pair_number", pair_number_small_kernel<<<1, 1024, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, gp2_first,
-                                                                     r->seq_genome_two));
+                                                                     r->seq_genome_two, C));
     SWG_KERNEL_CHECK(ctx);
   } else {
     uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
@@ -1143,12 +1530,12 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     uint32_t* sizes = swg_alloc<uint32_t>(ctx, n_runs);
     SWG_CHECK_ARENA(ctx);
     const unsigned rb = nblk(n_runs);
-    SWG_LAUNCH(ctx, "pair_number", pair_key1_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, key, val));
+    SWG_LAUNCH(ctx, "pair_number", pair_key1_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, key, val, C));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &key, &val, &key_tmp, &val_tmp, n_runs, 0, 64));
-    SWG_LAUNCH(ctx, "pair_number", pair_rank1_kernel<<<rb, EW, 0, st>>>(n_runs, val, info, sum, r->seq_genome_two, gp2_first, rank1));
+    SWG_LAUNCH(ctx, "pair_number", pair_rank1_kernel<<<rb, EW, 0, st>>>(n_runs, val, info, sum, r->seq_genome_two, gp2_first, rank1, C));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "pair_number", pair_key2_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, rank1, r->seq_genome_two, gp2_first, key, val));
+    SWG_LAUNCH(ctx, "pair_number", pair_key2_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, rank1, r->seq_genome_two, gp2_first, key, val, C));
     SWG_KERNEL_CHECK(ctx);
     SWG_TRY(swg_radix_sort_pairs(ctx, &key, &val, &key_tmp, &val_tmp, n_runs, 0, 64));
     SWG_LAUNCH(ctx, "pair_number", pair_sizes_kernel<<<rb, EW, 0, st>>>(n_runs, val, sum, sizes));
@@ -1159,7 +1546,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   {
     const unsigned gb = n_runs < (unsigned)ctx->num_cu * 16 ? n_runs : (unsigned)ctx->num_cu * 16;
-    SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out));
+    SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C));
     SWG_KERNEL_CHECK(ctx);
   }
   // ---- the flags found on the device, and the statistics
@@ -1172,6 +1559,17 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     swg_arena_restore(ctx, mark0);
     return SWG_OK;
   }
+#ifdef SWG_PAIR_TIMING
+  {
+    unsigned long long ht[16];
+    (void)hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_pair_t), sizeof ht);
+    fprintf(stderr, "[swg] pair_sort phases (100 MHz ticks summed over work-groups):");
+    for (int k = 0; k < 13; ++k) fprintf(stderr, " %d:%llu", k, ht[k]);
+    fprintf(stderr, "\n");
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_t), z, sizeof z);
+  }
+#endif
   if (stats) {
     stats->n_retained = hc[4];
     stats->n_swept = hc[5];

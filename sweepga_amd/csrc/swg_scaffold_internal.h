@@ -179,10 +179,14 @@ constexpr uint32_t LABEL_CAP_ELEMS = WALK_CHUNK + BIG_UNIT;  // chain_label_kern
 int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* desc, const uint32_t* s_qs,
                      const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, uint64_t max_gap, unsigned long long* bps,
                      uint32_t* pred);
+int pair_walk_long_launch(swg_ctx* ctx, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list, const SpecBlock* chunks,
+                          uint32_t n_members_cap, const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te,
+                          uint64_t max_gap, unsigned long long* own, uint32_t* pred, uint32_t* flags, uint32_t fallback_bit);
 int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks_dev, const SpecBlock* chunks, const uint32_t* pred,
                       const uint32_t* s_qs, const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, const uint32_t* s_m,
                       const uint32_t* s_b, uint64_t min_len, double min_ident, uint32_t* hd, uint8_t* ok_head, HeadRec* rec,
-                      unsigned long long* n_heads);
+                      unsigned long long* n_heads, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list);
+// (cap_long / n_long_dev / long_list: the chunks of LABEL_CAP_ELEMS members and more, labelled one work-group each)
 
 
 // What the predecessor selection (swg_chain.hip) hands to the chain table (swg_chain_table.hip): the members of sort A in
