@@ -2109,10 +2109,30 @@ __global__ __launch_bounds__(EW) void pair_long_plan_kernel(uint32_t cap_long, c
   for (uint32_t c = blockIdx.x; c < n_long; c += gridDim.x) {
     const SpecBlock D = chunks[long_list[c]];
     const uint32_t b = D.bb, e = D.be;
-    uint32_t w = 0;
+    // An upper bound of the longest window, one binary search per 64 members instead of one per member: a member's window
+    // ends no later than q_start[last of its 64] + (longest member + gap) reaches, because the members are sorted by q_start.
+    uint32_t ml = 0;
     for (uint32_t p = b + threadIdx.x; p < e; p += EW) {
-      const uint64_t bound = (uint64_t)s_qe[p] + max_gap;  // wrapping, as release Rust
-      uint32_t lo = p + 1, hi = e;  // first position in (p, e) with q_start > bound
+      const uint32_t len = s_qe[p] - s_qs[p];
+      ml = len > ml ? len : ml;
+      ext[p] = ~0ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(ml, o, 64);
+      if (t > ml) ml = t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) wmaxs[threadIdx.x >> 6] = ml;
+    __syncthreads();
+    for (int k = 0; k < EW / 64; ++k)
+      if (wmaxs[k] > ml) ml = wmaxs[k];
+    const uint64_t reach = (uint64_t)ml + (max_gap > (uint64_t(1) << 33) ? (uint64_t(1) << 33) : max_gap);
+    uint32_t w = 0;
+    for (uint32_t p0 = b + threadIdx.x * 64u; p0 < e; p0 += EW * 64u) {
+      const uint32_t last = p0 + 63 < e ? p0 + 63 : e - 1;
+      const uint64_t bound = (uint64_t)s_qs[last] + reach;
+      uint32_t lo = last + 1, hi = e;  // first position in (last, e) with q_start > bound
       while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if ((uint64_t)s_qs[mid] <= bound)
@@ -2120,9 +2140,8 @@ __global__ __launch_bounds__(EW) void pair_long_plan_kernel(uint32_t cap_long, c
         else
           hi = mid;
       }
-      const uint32_t x = lo - 1 - p;
+      const uint32_t x = lo - 1 - p0;
       w = x > w ? x : w;
-      ext[p] = ~0ull;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -29,7 +29,7 @@ namespace swg_scaf {
 namespace {
 
 constexpr uint32_t PAIR_CELL = WALK_CHUNK;        // a chunk = the units that begin in one cell of this many members
-constexpr uint32_t PAIR_S_MAX = 1024, PAIR_M_MAX = 4096, PAIR_L_MAX = 16384, PAIR_XL_MAX = uint32_t(1) << 18;
+constexpr uint32_t PAIR_S_MAX = 1024, PAIR_M_MAX = 4096, PAIR_L_MAX = 32768, PAIR_XL_MAX = uint32_t(1) << 18;
 constexpr uint32_t PAIR_XL_CELLS = PAIR_XL_MAX / PAIR_CELL;
 constexpr uint32_t PF_NOT_GROUPED = 1, PF_RUN_OVERFLOW = 2, PF_TOO_LONG = 4, PF_FALLBACK = 8;
 
@@ -238,6 +238,14 @@ __device__ __forceinline__ void bucket_map_make(BucketMap& B, uint32_t nbk, uint
     const float range = (float)(kmax[s] - kmin[s]) + 1.0f;
     B.scale[s] = (float)B.nb[s] / range;
   }
+  // work-group-uniform values that came out of LDS reads (vector registers): into scalar registers
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    B.kmin[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.kmin[s]);
+    B.scale[s] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(B.scale[s])));
+    B.off[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.off[s]);
+    B.nb[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.nb[s]);
+  }
 }
 __device__ __forceinline__ uint32_t bucket_of(const BucketMap& B, uint32_t st, uint32_t k) {
   // (selects, not B.x[st]: an array indexed by a run-time value is sent through scratch memory)
@@ -374,21 +382,29 @@ __device__ unsigned long long g_pair_t[16];
 #else
 #define PT_STAMP(k) do { } while (0)
 #endif
-// One work-group per pair of at most NT * E records.  Every global load of a phase is requested before the first value is used
-// (a thread's E records one after the other would be E memory round trips in a row -- the work-group is alone on its CU when it
-// uses most of the LDS, nothing else hides them).
-template <int NT, int E, int NBK>
+// One work-group per pair of at most NT * ER records, sorted in batches of at most NT * ES members (one batch when the pair's
+// members fit, which is the rule; otherwise the key range is cut into coarse bins and consecutive bins are glued into batches).
+// A thread OWNS the records tid, tid + NT, ... of the run: it loads their columns (coalesced), drops their keys into the
+// batch's buckets, learns from the ranking where its records ended up (the slot its key was dropped at names the rank:
+// RR), and puts their columns at that place of an LDS buffer that is then written out coalesced -- no gather anywhere.
+// Every global load of a phase is requested before the first value is used (a thread's records one after the other would be
+// as many memory round trips in a row, and the work-group is alone on its CU: nothing else hides them).
+template <int NT, int ES, int ER, int NBK, int NBIN>
 __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
-  constexpr int CAP = NT * E;
-  constexpr int NCELL = (CAP + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
+  constexpr int CAP = NT * ES, NREC = NT * ER, MAXB = 16, H = 8;
+  constexpr int NCELL = (NREC + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
+  static_assert(ER <= 32 && ER % H == 0 && ES % 4 == 0 && NREC <= 65536, "record masks are 32 bits wide, indices 16");
+  static_assert(NBIN >= 2 && NBIN <= 4096, "each strand needs a coarse bin of its own (the members are ordered strand first)");
   __shared__ __attribute__((aligned(16))) uint32_t K[CAP];
   __shared__ uint16_t I[CAP];
-  __shared__ uint16_t R[CAP];
+  __shared__ uint16_t RR[CAP];
   __shared__ uint32_t cnt[NBK];
+  __shared__ uint32_t bins[NBIN];
+  __shared__ uint32_t b_lo[MAXB + 1];
   __shared__ uint32_t cellmin[NCELL];
   __shared__ uint64_t ws64[NT / 64 + 1];
   __shared__ uint32_t ws[NT / 64 + 1];
-  __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3];
+  __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3], sh_nb, sh_bad;
 #ifdef SWG_PAIR_TIMING
   unsigned long long pt_last = wall_clock64();
 #endif
@@ -402,94 +418,102 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
     sh_kmax[tid] = 0;
   }
   if (tid < 3) sh_first[tid] = NONE;
+  if (tid == 0) sh_bad = 0;
   for (int c = tid; c < NCELL; c += NT) cellmin[c] = NONE;
-  for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
+  for (int b = tid; b < NBIN; b += NT) bins[b] = 0;
   __syncthreads();
+  // the thread's records: e-th record = tid + e * NT; every loop over them runs in groups of H whose loads go out together
+  // (the pair's columns as work-group-uniform pointers indexed by a 32-bit offset inside the pair: one scalar base and one
+  // 32-bit register per load, not a 64-bit address pair per column and record)
+  // (a fresh copy of the thread index per phase: the compiler otherwise computes tid + e * NT for every e once, keeps the 16
+  // or 32 values across the whole kernel and ends up spilling them -- they cost one addition each)
+  auto fresh_tid = [&]() -> uint32_t {
+    uint32_t t = (uint32_t)tid;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
+  uint32_t tid_v = (uint32_t)tid, n_v = n;  // (copies that pass through an empty asm per batch: see the batch loop)
+  auto rec_index = [&](int e) -> uint32_t {
+    const uint32_t li = tid_v + (uint32_t)e * NT;
+    return li < n_v ? li : 0u;
+  };
+  const uint32_t* c_qs = A.q_start + a;
+  const uint32_t* c_qe = A.q_end + a;
+  const uint32_t* c_ts = A.t_start + a;
+  const uint32_t* c_te = A.t_end + a;
+  const uint32_t* c_m = A.matches + a;
+  const uint32_t* c_b = A.block_len + a;
+  const uint8_t* c_st = A.strand + a;
+  const double* c_id = A.identity ? A.identity + a : nullptr;
+  const uint8_t* c_alive = A.alive_in ? A.alive_in + a : nullptr;
+  const uint8_t* c_member = A.member_in ? A.member_in + a : nullptr;
+  uint32_t* o_qs = A.s_qs + a;
+  uint32_t* o_qe = A.s_qe + a;
+  uint32_t* o_ts = A.s_ts + a;
+  uint32_t* o_te = A.s_te + a;
+  uint32_t* o_m = A.s_m + a;
+  uint32_t* o_b = A.s_b + a;
+  uint32_t* o_idx = A.s_idx + a;
+  uint32_t* o_pred = A.pred + a;
   // ---- step-1 retain, members, the key range per strand
   const uint32_t q0 = A.q_id[a], t0 = A.t_id[a];
   const bool self_ok = A.keep_self || q0 != t0;
-  uint32_t qk[E];                                   // q_start of the thread's records (record e: tid + e * NT)
   uint32_t member_mask = 0, strand_mask = 0, extra_mask = 0;
   {
     uint32_t alive_mask = 0, in_mask = 0;
-    // (two halves: sixteen 8-byte identities requested at once, beside everything else, do not fit the register file of a
-    // 1024-thread work-group)
-    auto half = [&](auto off_c) {
-      constexpr int OFF = decltype(off_c)::value, H = E / 2;
-      uint8_t stv[H];
+    uint32_t c_m[2] = {0, 0}, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
+#pragma unroll
+    for (int g = 0; g < ER; g += H) {
+      if ((uint32_t)g * NT >= n) continue;  // (block-uniform; `continue`, not `break`: the loop must unroll -- its arrays are registers)
+      uint8_t stv[H], av[H], mv[H];
+      uint32_t qv[H], blv[H];
+      double idv[H];
+      const bool need_bl = !A.alive_in && (A.min_block != 0 || !A.identity);
 #pragma unroll
       for (int e = 0; e < H; ++e) {
-        const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
-        const uint32_t i = a + (li < n ? li : 0u);
-        in_mask |= (li < n ? 1u : 0u) << (OFF + e);
-        stv[e] = A.strand[i];
-        qk[OFF + e] = A.q_start[i];
+        const uint32_t i = rec_index(g + e);
+        stv[e] = c_st[i];
+        qv[e] = c_qs[i];
+        av[e] = c_alive ? c_alive[i] : (uint8_t)1;
+        mv[e] = c_member ? c_member[i] : (uint8_t)1;
+        blv[e] = need_bl ? c_b[i] : 0u;
+        idv[e] = c_alive ? 1.0 : (c_id ? c_id[i] : (double)c_m[i]);
       }
-      if (A.alive_in) {
-        uint8_t av[H], mv[H];
 #pragma unroll
-        for (int e = 0; e < H; ++e) {
-          const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
-          const uint32_t i = a + (li < n ? li : 0u);
-          av[e] = A.alive_in[i];
-          mv[e] = A.member_in ? A.member_in[i] : (uint8_t)1;
-        }
-#pragma unroll
-        for (int e = 0; e < H; ++e) {
-          if (av[e]) alive_mask |= 1u << (OFF + e);
-          if (av[e] && mv[e]) member_mask |= 1u << (OFF + e);
-        }
-      } else {
-        double idv[H];
-        uint32_t blv[H];
-        const bool need_bl = A.min_block != 0 || !A.identity;
-#pragma unroll
-        for (int e = 0; e < H; ++e) {
-          const uint32_t li = (uint32_t)tid + (uint32_t)(OFF + e) * NT;
-          const uint32_t i = a + (li < n ? li : 0u);
-          blv[e] = need_bl ? A.block_len[i] : 0u;
-          idv[e] = A.identity ? A.identity[i] : (double)A.matches[i];
-        }
-#pragma unroll
-        for (int e = 0; e < H; ++e) {
+      for (int e = 0; e < H; ++e) {
+        const uint32_t li = (uint32_t)tid + (uint32_t)(g + e) * NT;
+        if (li >= n) continue;
+        bool alive;
+        if (A.alive_in) {
+          alive = av[e] != 0;
+        } else {
           // identity == nullptr: matches over max(block length, 1), one IEEE division (src/paf_filter.rs:322)
           const double id = A.identity ? idv[e] : __ddiv_rn(idv[e], (double)(blv[e] > 1u ? blv[e] : 1u));
-          const bool alive = self_ok && (A.min_block == 0 || (uint64_t)blv[e] >= A.min_block) && id >= A.min_identity;
-          if (alive) {
-            alive_mask |= 1u << (OFF + e);
-            member_mask |= 1u << (OFF + e);
+          alive = self_ok && (A.min_block == 0 || (uint64_t)blv[e] >= A.min_block) && id >= A.min_identity;
+        }
+        const bool member = alive && mv[e] != 0;
+        const uint32_t st = stv[e] ? 1u : 0u;
+        in_mask |= 1u << (g + e);
+        strand_mask |= st << (g + e);
+        if (alive) {
+          alive_mask |= 1u << (g + e);
+          if (fst[2] == NONE) fst[2] = a + li;
+          if (member) {
+            member_mask |= 1u << (g + e);
+#pragma unroll
+            for (uint32_t s2 = 0; s2 < 2; ++s2)  // (no array indexed by a run-time strand: see bucket_of)
+              if (st == s2) {
+                ++c_m[s2];
+                kmin[s2] = qv[e] < kmin[s2] ? qv[e] : kmin[s2];
+                kmax[s2] = qv[e] > kmax[s2] ? qv[e] : kmax[s2];
+                if (fst[s2] == NONE) fst[s2] = a + li;
+              }
           }
         }
       }
-#pragma unroll
-      for (int e = 0; e < H; ++e) strand_mask |= (stv[e] ? 1u : 0u) << (OFF + e);
-    };
-    half(std::integral_constant<int, 0>{});
-    asm volatile("" ::: "memory");
-    half(std::integral_constant<int, E / 2>{});
-    alive_mask &= in_mask;
-    member_mask &= in_mask;
-    extra_mask = alive_mask & ~member_mask;
-    uint32_t c_m[2] = {0, 0}, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
-      const uint32_t st = (strand_mask >> e) & 1u;
-      if (li < n) A.code[a + li] = (alive_mask >> e) & 1u ? (uint8_t)((((member_mask >> e) & 1u) ? 1u : 2u) | (st << 2)) : (uint8_t)0;
-      if ((alive_mask >> e) & 1u) {
-        if (fst[2] == NONE) fst[2] = a + li;
-        if ((member_mask >> e) & 1u) {
-#pragma unroll
-          for (uint32_t s2 = 0; s2 < 2; ++s2)  // (no array indexed by a run-time strand: see bucket_of)
-            if (st == s2) {
-              ++c_m[s2];
-              kmin[s2] = qk[e] < kmin[s2] ? qk[e] : kmin[s2];
-              kmax[s2] = qk[e] > kmax[s2] ? qk[e] : kmax[s2];
-              if (fst[s2] == NONE) fst[s2] = a + li;
-            }
-        }
-      }
+      asm volatile("" ::: "memory");
     }
+    extra_mask = alive_mask & ~member_mask;
     uint32_t c_x = (uint32_t)__popc(extra_mask);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -497,15 +521,15 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
       c_m[1] += __shfl_xor(c_m[1], o, 64);
       c_x += __shfl_xor(c_x, o, 64);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint32_t x = __shfl_xor(kmin[s], o, 64), y = __shfl_xor(kmax[s], o, 64);
-        kmin[s] = x < kmin[s] ? x : kmin[s];
-        kmax[s] = y > kmax[s] ? y : kmax[s];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint32_t x = __shfl_xor(kmin[s2], o, 64), y = __shfl_xor(kmax[s2], o, 64);
+        kmin[s2] = x < kmin[s2] ? x : kmin[s2];
+        kmax[s2] = y > kmax[s2] ? y : kmax[s2];
       }
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const uint32_t x = __shfl_xor(fst[s], o, 64);
-        fst[s] = x < fst[s] ? x : fst[s];
+      for (int s2 = 0; s2 < 3; ++s2) {
+        const uint32_t x = __shfl_xor(fst[s2], o, 64);
+        fst[s2] = x < fst[s2] ? x : fst[s2];
       }
     }
     if ((tid & 63) == 0) {
@@ -513,20 +537,22 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
       if (c_m[1]) atomicAdd(&sh_cnt[1], c_m[1]);
       if (c_x) atomicAdd(&sh_cnt[2], c_x);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (c_m[s]) {
-          atomicMin(&sh_kmin[s], kmin[s]);
-          atomicMax(&sh_kmax[s], kmax[s]);
+      for (int s2 = 0; s2 < 2; ++s2)
+        if (c_m[s2]) {
+          atomicMin(&sh_kmin[s2], kmin[s2]);
+          atomicMax(&sh_kmax[s2], kmax[s2]);
         }
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        if (fst[s] != NONE) atomicMin(&sh_first[s], fst[s]);
+      for (int s2 = 0; s2 < 3; ++s2)
+        if (fst[s2] != NONE) atomicMin(&sh_first[s2], fst[s2]);
     }
   }
   __syncthreads();
-  const uint32_t m_plus = sh_cnt[0], m = sh_cnt[0] + sh_cnt[1], n_x = sh_cnt[2], M = m + n_x;
+  const uint32_t m_plus = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[0]);
+  const uint32_t m = m_plus + (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[1]);
+  const uint32_t n_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[2]), M = m + n_x;
   PT_STAMP(1);
-  if (tid == 0) {
+  if (tid == NT - 1) {  // (the last wavefront: thread 0's has the chunk list to write at the end)
     PairInfo pi;
     pi.m = m;
     pi.m_plus = m_plus;
@@ -537,10 +563,8 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
     pi.q = q0;
     pi.t = t0;
     A.info[rk_run] = pi;
-    if (sh_first[2] != NONE) {  // the genome pair's first alive record (apply_plane_sweep_to_mappings' group order, :1037-1046)
-      uint32_t* slot = pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]);
-      if (*slot > sh_first[2]) atomicMin(slot, sh_first[2]);
-    }
+    if (sh_first[2] != NONE)  // the genome pair's first alive record (apply_plane_sweep_to_mappings' group order, :1037-1046)
+      atomicMin(pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]), sh_first[2]);
     if (M) {
       atomicAdd(&A.C->n_alive, (unsigned long long)M);
       atomicAdd(&A.C->n_members, (unsigned long long)m);
@@ -553,20 +577,20 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
   if (n_x) {
     uint32_t done = 0;
 #pragma unroll 1
-    for (int e = 0; e < E; ++e) {
+    for (int e = 0; e < ER; ++e) {
       if ((uint32_t)e * NT >= n) break;
       const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
       const bool x = (extra_mask >> e) & 1u;
       uint32_t tot;
       const uint32_t r = block_excl_sum<NT>(x ? 1u : 0u, ws, &tot);
       if (x) {
-        const uint32_t i = a + li, p = a + m + done + r;
-        const uint32_t qs = qk[e], qe = A.q_end[i], ts = A.t_start[i], te = A.t_end[i];
-        A.s_qs[p] = qs;
-        A.s_qe[p] = qe;
-        A.s_ts[p] = ts;
-        A.s_te[p] = te;
-        A.s_idx[p] = i | (((strand_mask >> e) & 1u) << 31);
+        const uint32_t p = m + done + r;
+        const uint32_t qs = c_qs[li], qe = c_qe[li], ts = c_ts[li], te = c_te[li];
+        o_qs[p] = qs;
+        o_qe[p] = qe;
+        o_ts[p] = ts;
+        o_te[p] = te;
+        o_idx[p] = (a + li) | (((strand_mask >> e) & 1u) << 31);
         degenerate |= qs >= qe || ts >= te;
       }
       done += tot;
@@ -576,165 +600,307 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
     if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
     return;
   }
-  // ---- bucket sort of the members by (strand, q_start, index)
-  BucketMap FM;
+  // ---- coarse bins over (strand, q_start); more than one batch only when the members do not fit one
+  BucketMap BM;
   {
     const uint32_t kmn[2] = {sh_kmin[0], sh_kmin[1]}, kmx[2] = {sh_kmax[0], sh_kmax[1]};
-    bucket_map_make(FM, NBK, m_plus, m - m_plus, kmn, kmx);
+    bucket_map_make(BM, NBIN, m_plus, m - m_plus, kmn, kmx);
   }
-  uint32_t bk[E];
+  // the fine bucket of a key inside the batch [bin_lo, bin_hi): the coarse map refined by a power of two.  f < NBIN <= 2^12
+  // has at most 12 integer bits and multiplying a float by 2^12 is exact, so (uint32)(f * 4096) >> 12 == (uint32)f: the fine id
+  // names the coarse bin in its high bits and stays monotone in the key.
+  auto fine_of = [&](uint32_t st, uint32_t k, int shift, uint32_t first, uint32_t* coarse) -> uint32_t {
+    const float f = (float)(k - (st ? BM.kmin[1] : BM.kmin[0])) * (st ? BM.scale[1] : BM.scale[0]);
+    const uint32_t top = (st ? BM.nb[1] : BM.nb[0]) - 1u;
+    uint32_t g = (uint32_t)(f * 4096.0f);
+    if ((g >> 12) > top) g = (top << 12) | 0xfffu;  // (the clamp of bucket_of, in fine units)
+    g += (st ? BM.off[1] : BM.off[0]) << 12;
+    *coarse = g >> 12;
+    const uint32_t b = (g >> shift) - first;
+    return b < (uint32_t)NBK ? b : (uint32_t)NBK - 1u;
+  };
+  uint32_t n_batches = 1;
+  if (m > (uint32_t)CAP) {
 #pragma unroll
-  for (int e = 0; e < E; ++e)
-    if ((member_mask >> e) & 1u) {
-      bk[e] = bucket_of(FM, (strand_mask >> e) & 1u, qk[e]);
-      atomicAdd(&cnt[bk[e]], 1u);
+    for (int g = 0; g < ER; g += H) {
+      if ((uint32_t)g * NT >= n) continue;
+      uint32_t qv[H];
+#pragma unroll
+      for (int e = 0; e < H; ++e) qv[e] = c_qs[rec_index(g + e)];
+#pragma unroll
+      for (int e = 0; e < H; ++e)
+        if ((member_mask >> (g + e)) & 1u) atomicAdd(&bins[bucket_of(BM, (strand_mask >> (g + e)) & 1u, qv[e])], 1u);
+      asm volatile("" ::: "memory");
     }
-  __syncthreads();
-  PT_STAMP(2);
-  {
-    constexpr int PER = NBK / NT;
-    static_assert(NBK % NT == 0 && PER >= 1, "bucket counters per thread");
-    uint32_t c[PER], sum = 0, tot;
+    __syncthreads();
+    {  // bins -> their exclusive prefix sums
+      constexpr int PERB = (NBIN + NT - 1) / NT;
+      uint32_t c[PERB], sum = 0, tot;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      c[j] = cnt[tid * PER + j];
-      sum += c[j];
-    }
-    uint32_t off = block_excl_sum<NT>(sum, ws, &tot);
+      for (int j = 0; j < PERB; ++j) {
+        c[j] = tid * PERB + j < NBIN ? bins[tid * PERB + j] : 0u;
+        sum += c[j];
+      }
+      uint32_t off = block_excl_sum<NT>(sum, ws, &tot);
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      cnt[tid * PER + j] = off;
-      off += c[j];
-    }
-  }
-  __syncthreads();
-  PT_STAMP(3);
-#pragma unroll
-  for (int e = 0; e < E; ++e)
-    if ((member_mask >> e) & 1u) {
-      const uint32_t pos = atomicAdd(&cnt[bk[e]], 1u);  // (unordered inside a bucket; cnt[b] ends as the bucket's end)
-      K[pos] = qk[e];
-      I[pos] = (uint16_t)((uint32_t)tid + (uint32_t)e * NT);
-    }
-  __syncthreads();
-  PT_STAMP(4);
-  {
-    // order inside the buckets: final position = bucket begin + the bucket's elements that order before by (key, index)
-    uint32_t rk[E], rr[E];
-    uint16_t rl[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t pos = (uint32_t)tid + (uint32_t)e * NT;
-      rr[e] = NONE;
-      if (pos < m) {
-        const uint32_t k = K[pos], li = I[pos];
-        const uint32_t b = bucket_of(FM, pos >= m_plus ? 1u : 0u, k);
-        const uint32_t hi = cnt[b], lo = b ? cnt[b - 1] : 0u;
-        uint32_t r = lo;
-        for (uint32_t x = lo; x < hi; ++x) {
-          const uint32_t kx = K[x], lx = I[x];
-          r += (kx < k || (kx == k && lx < li)) ? 1u : 0u;
+      for (int j = 0; j < PERB; ++j)
+        if (tid * PERB + j < NBIN) {
+          bins[tid * PERB + j] = off;
+          off += c[j];
         }
-        rk[e] = k;
-        rl[e] = (uint16_t)li;
-        rr[e] = r;
-      }
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (rr[e] != NONE) {
-        K[rr[e]] = rk[e];
-        I[rr[e]] = rl[e];
+    if (tid == 0) {  // greedy: a batch takes as many bins as fit (a binary search in the prefix sums per batch)
+      uint32_t nb = 0, lo = 0;
+      b_lo[0] = 0;
+      while (lo < (uint32_t)NBIN) {
+        const uint32_t start = bins[lo];
+        uint32_t l = lo + 1, r = NBIN;
+        while (l < r) {
+          const uint32_t mid = l + ((r - l + 1) >> 1);
+          const uint32_t pm = mid < (uint32_t)NBIN ? bins[mid] : m;
+          if (pm - start <= (uint32_t)CAP) l = mid; else r = mid - 1;
+        }
+        const uint32_t p1 = l < (uint32_t)NBIN ? bins[l] : m;
+        if (p1 - start > (uint32_t)CAP || nb + 1 >= (uint32_t)MAXB) {  // one bin denser than a batch: not for this path
+          sh_bad = 1;
+          break;
+        }
+        b_lo[++nb] = l;
+        lo = l;
       }
+      sh_nb = nb;
+    }
+    __syncthreads();
+    if (sh_bad) {
+      if (tid == 0) atomicOr(&A.C->flags, PF_FALLBACK);
+      return;
+    }
+    n_batches = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_nb);
   }
-  __syncthreads();
-  PT_STAMP(5);
-  // ---- the sorted q_start and record index out; every member's rank
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
-    if (p < m) {
-      const uint32_t li = I[p];
-      A.s_qs[a + p] = K[p];
-      A.s_idx[a + p] = a + li;
-      A.pred[a + p] = NONE;
-      R[li] = (uint16_t)p;
-    }
-  }
-  uint32_t qs_r[E];  // the thread's own E consecutive positions, for the unit cuts
-  read_block<E>(K, qs_r);
-  __syncthreads();
-  PT_STAMP(6);
-  uint16_t rp[E];  // where the thread's records go
-#pragma unroll
-  for (int e = 0; e < E; ++e) rp[e] = R[((uint32_t)tid + (uint32_t)e * NT) < (uint32_t)CAP ? ((uint32_t)tid + (uint32_t)e * NT) : 0u];
-  // ---- the other columns, transposed through LDS: coalesced reads in input order land at their sorted position, coalesced
-  // writes follow
-  auto load_col = [&](const uint32_t* __restrict__ src, uint32_t (&v)[E]) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t li = (uint32_t)tid + (uint32_t)e * NT;
-      v[e] = src[a + (li < n ? li : 0u)];
-    }
-  };
-  auto put_col = [&](const uint32_t (&v)[E]) {
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-      if ((member_mask >> e) & 1u) K[rp[e]] = v[e];
-  };
-  auto store_col = [&](uint32_t* __restrict__ dst) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t p = (uint32_t)tid + (uint32_t)e * NT;
-      if (p < m) dst[a + p] = K[p];
-    }
-  };
+  PT_STAMP(2);
   uint64_t carry_max = 0;
-  {
-    uint32_t v[E];
-    load_col(A.q_end, v);
-    put_col(v);
+  uint32_t base = 0;
+  for (uint32_t bt = 0; bt < n_batches; ++bt) {
+    // (the column pointers pass through an empty asm: every batch re-reads the thread's records, and a compiler that sees
+    // the same loads in every iteration lifts all of them out of the loop -- some 200 registers held across it)
+    asm volatile("" : "+s"(c_qs), "+s"(c_qe), "+s"(c_ts), "+s"(c_te), "+s"(c_m), "+s"(c_b), "+v"(tid_v), "+s"(n_v), "+v"(member_mask), "+v"(strand_mask));
+    const uint32_t bin_lo = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt]) : 0u;
+    const uint32_t bin_hi = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt + 1]) : (uint32_t)NBIN;
+    int shift = 0;
+    while ((((bin_hi - bin_lo) << 12) >> shift) > (uint32_t)NBK) ++shift;
+    const uint32_t first = (bin_lo << 12) >> shift;
+    for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
     __syncthreads();
-    store_col(A.s_qe);
-    uint32_t qe_r[E];
-    read_block<E>(K, qe_r);
+    // ---- count: the batch's members among the thread's records, and their buckets
+    uint32_t batch_mask = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) degenerate |= (uint32_t)tid * E + e < m && qs_r[e] >= qe_r[e];
-    unit_starts<NT, E>(qs_r, qe_r, m, 0u, m_plus, A.max_gap, ws64, cellmin, &carry_max);  // (its barriers also close the column)
-    __syncthreads();
-  }
-  PT_STAMP(7);
-  {
-    uint32_t v[E], w[E];  // one column goes through LDS while the next one's loads are in flight
-    load_col(A.t_start, w);
-    load_col(A.t_end, v);
+    for (int g = 0; g < ER; g += H) {
+      if ((uint32_t)g * NT >= n) continue;
+      uint32_t qv[H];
 #pragma unroll
-    for (int e = 0; e < E; ++e) degenerate |= ((member_mask >> e) & 1u) && w[e] >= v[e];
-    put_col(w);
+      for (int e = 0; e < H; ++e) qv[e] = c_qs[rec_index(g + e)];
+#pragma unroll
+      for (int e = 0; e < H; ++e)
+        if ((member_mask >> (g + e)) & 1u) {
+          uint32_t cb;
+          const uint32_t fb = fine_of((strand_mask >> (g + e)) & 1u, qv[e], shift, first, &cb);
+          if (cb >= bin_lo && cb < bin_hi) {
+            batch_mask |= 1u << (g + e);
+            atomicAdd(&cnt[fb], 1u);
+          }
+        }
+      asm volatile("" ::: "memory");  // (keeps the next group's loads behind this group's work: registers)
+    }
     __syncthreads();
-    store_col(A.s_ts);
+    PT_STAMP(3);
+    uint32_t mb;
+    {
+      constexpr int PER = NBK / NT;
+      static_assert(NBK % NT == 0 && PER >= 1, "bucket counters per thread");
+      uint32_t c[PER], sum = 0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        c[j] = cnt[tid * PER + j];
+        sum += c[j];
+      }
+      uint32_t off = block_excl_sum<NT>(sum, ws, &mb);
+      mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        cnt[tid * PER + j] = off;
+        off += c[j];
+      }
+    }
+    __syncthreads();
+    // ---- scatter (unordered inside a bucket; cnt[b] ends as the bucket's end); the thread remembers where each key went
+    uint32_t slotw[ER / 2];  // two 16-bit slots per word: first the slot of the key, after the ranking the record's final place
+#pragma unroll
+    for (int j = 0; j < ER / 2; ++j) slotw[j] = 0;
+    const uint32_t t_sc = fresh_tid();
+#pragma unroll
+    for (int g = 0; g < ER; g += H) {
+      if ((uint32_t)g * NT >= n) continue;
+      uint32_t qv[H];
+#pragma unroll
+      for (int e = 0; e < H; ++e) qv[e] = c_qs[rec_index(g + e)];
+#pragma unroll
+      for (int e = 0; e < H; ++e)
+        if ((batch_mask >> (g + e)) & 1u) {
+          uint32_t cb;
+          const uint32_t fb = fine_of((strand_mask >> (g + e)) & 1u, qv[e], shift, first, &cb);
+          const uint32_t pos = atomicAdd(&cnt[fb], 1u);
+          K[pos] = qv[e];
+          I[pos] = (uint16_t)(t_sc + (uint32_t)(g + e) * NT);
+          slotw[(g + e) / 2] |= pos << (16 * ((g + e) & 1));
+        }
+      asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    PT_STAMP(4);
+    const uint32_t plus_here = m_plus > base ? (m_plus - base < mb ? m_plus - base : mb) : 0u;  // '+' members of the batch
+    {
+      // order inside the buckets: final position = bucket begin + the bucket's elements that order before by (key, index).
+      // The thread's ES slots advance together (one round trip of LDS reads per step, not one per slot and step).
+      // (the slot's record index and its rank share a word: index << 16 | rank, rank 0xffff = an empty slot)
+      uint32_t rk[ES], rp[ES];
+      static_assert(CAP < 0xffff, "ranks are 16 bits wide");
+      const uint32_t t_rk = fresh_tid();
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t pos = t_rk + (uint32_t)e * NT;
+        rk[e] = pos < mb ? K[pos] : 0u;
+        rp[e] = ((pos < mb ? (uint32_t)I[pos] : 0u) << 16) | 0xffffu;
+      }
+      auto count_half = [&](auto off_c) {
+        constexpr int OFF = decltype(off_c)::value, HS = ES / 2;
+        uint32_t lo[HS], hi[HS], longest = 0;
+#pragma unroll
+        for (int e = 0; e < HS; ++e) {
+          const uint32_t pos = t_rk + (uint32_t)(OFF + e) * NT;
+          lo[e] = hi[e] = 0;
+          if (pos < mb) {
+            uint32_t cb;
+            const uint32_t b = fine_of(pos >= plus_here ? 1u : 0u, rk[OFF + e], shift, first, &cb);
+            hi[e] = cnt[b];
+            lo[e] = b ? cnt[b - 1] : 0u;
+            rp[OFF + e] = (rp[OFF + e] & 0xffff0000u) | lo[e];
+            longest = hi[e] - lo[e] > longest ? hi[e] - lo[e] : longest;
+          }
+        }
+        for (uint32_t it = 0; it < longest; ++it) {
+#pragma unroll
+          for (int e = 0; e < HS; ++e) {
+            const uint32_t x = lo[e] + it;
+            if (x < hi[e]) {
+              const uint32_t kx = K[x], lx = I[x];
+              rp[OFF + e] += (kx < rk[OFF + e] || (kx == rk[OFF + e] && lx < (rp[OFF + e] >> 16))) ? 1u : 0u;
+            }
+          }
+        }
+      };
+      count_half(std::integral_constant<int, 0>{});
+      count_half(std::integral_constant<int, ES / 2>{});
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < ES; ++e)
+        if ((rp[e] & 0xffffu) != 0xffffu) {
+          const uint32_t r = rp[e] & 0xffffu;
+          K[r] = rk[e];
+          I[r] = (uint16_t)(rp[e] >> 16);
+          RR[t_rk + (uint32_t)e * NT] = (uint16_t)r;
+        }
+    }
+    __syncthreads();
+    PT_STAMP(5);
+    // ---- the sorted q_start and record index out; where the thread's own records went
+    const uint32_t t_out = fresh_tid();
+#pragma unroll
+    for (int e = 0; e < ES; ++e) {
+      const uint32_t p = t_out + (uint32_t)e * NT;
+      if (p < mb) {
+        o_qs[base + p] = K[p];
+        o_idx[base + p] = a + (uint32_t)I[p];
+        o_pred[base + p] = NONE;
+      }
+    }
+    uint32_t qs_r[ES];  // the thread's own ES consecutive positions, for the unit cuts
+    read_block<ES>(K, qs_r);
+#pragma unroll
+    for (int j = 0; j < ER / 2; ++j) {
+      const uint32_t w = slotw[j];
+      const uint32_t r0 = (batch_mask >> (2 * j)) & 1u ? RR[w & 0xffffu] : 0u, r1 = (batch_mask >> (2 * j + 1)) & 1u ? RR[w >> 16] : 0u;
+      slotw[j] = r0 | (r1 << 16);
+      asm volatile("" : "+v"(slotw[j]));  // (kept packed: the compiler would otherwise carry the 32 places as 32 registers)
+    }
+    __syncthreads();
+    PT_STAMP(6);
+    // ---- the other columns, transposed through LDS: coalesced reads in input order land at their sorted position, coalesced
+    // writes follow
+    auto put_group = [&](int g, const uint32_t (&v)[H]) {
+#pragma unroll
+      for (int e = 0; e < H; ++e)
+        if ((batch_mask >> (g + e)) & 1u) K[(slotw[(g + e) / 2] >> (16 * ((g + e) & 1))) & 0xffffu] = v[e];
+    };
+    auto column = [&](const uint32_t* src, uint32_t* dst) {
+      tid_v = fresh_tid();
+#pragma unroll
+      for (int g = 0; g < ER; g += 2 * H) {
+        if ((uint32_t)g * NT >= n) continue;
+        uint32_t v[H], w[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) v[e] = src[rec_index(g + e)];
+        if (g + H < ER) {
+#pragma unroll
+          for (int e = 0; e < H; ++e) w[e] = src[rec_index(g + H + e)];
+        }
+        put_group(g, v);
+        if (g + H < ER) put_group(g + H, w);
+        asm volatile("" ::: "memory");
+      }
+      __syncthreads();
+      const uint32_t t_st = fresh_tid();
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t p = t_st + (uint32_t)e * NT;
+        if (p < mb) dst[base + p] = K[p];
+      }
+    };
+    column(c_qe, o_qe);
+    {
+      uint32_t qe_r[ES];
+      read_block<ES>(K, qe_r);
+#pragma unroll
+      for (int e = 0; e < ES; ++e) degenerate |= (uint32_t)tid * ES + e < mb && qs_r[e] >= qe_r[e];
+      unit_starts<NT, ES>(qs_r, qe_r, mb, base, m_plus, A.max_gap, ws64, cellmin, &carry_max);  // (its barriers also close the column)
+    }
+    __syncthreads();
+    PT_STAMP(7);
+    column(c_ts, o_ts);
+    uint32_t ts_r[ES];
+    read_block<ES>(K, ts_r);
     __syncthreads();
     PT_STAMP(8);
-    load_col(A.matches, w);
-    put_col(v);
-    __syncthreads();
-    store_col(A.s_te);
+    column(c_te, o_te);
+    {
+      uint32_t te_r[ES];
+      read_block<ES>(K, te_r);
+#pragma unroll
+      for (int e = 0; e < ES; ++e) degenerate |= (uint32_t)tid * ES + e < mb && ts_r[e] >= te_r[e];
+    }
     __syncthreads();
     PT_STAMP(9);
-    load_col(A.block_len, v);
-    put_col(w);
-    __syncthreads();
-    store_col(A.s_m);
+    column(c_m, o_m);
     __syncthreads();
     PT_STAMP(10);
-    put_col(v);
+    column(c_b, o_b);
+    base += mb;
     __syncthreads();
-    store_col(A.s_b);
+    PT_STAMP(11);
   }
-  PT_STAMP(11);
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
-  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, NCELL);  // (cellmin: complete since unit_starts' barrier ... and the later ones)
+  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, NCELL);
   PT_STAMP(12);
 }
 
@@ -755,6 +921,9 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
   __shared__ uint64_t ws64[NT / 64 + 1];
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3], sh_nb, sh_bad;
+#ifdef SWG_PAIR_TIMING
+  unsigned long long pt_last = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const uint32_t rk_run = A.list[blockIdx.x];
   const PairRun run = A.runs[rk_run];
@@ -855,6 +1024,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
   }
   __syncthreads();
   const uint32_t m_plus = sh_cnt[0], m = sh_cnt[0] + sh_cnt[1], n_x = sh_cnt[2], M = m + n_x;
+  PT_STAMP(1);
   if (tid == 0) {
     PairInfo pi;
     pi.m = m;
@@ -926,23 +1096,44 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
   }
   for_members([&](uint32_t, uint32_t st, uint32_t k) { atomicAdd(&bins[bucket_of(BM, st, k)], 1u); });
   __syncthreads();
-  if (tid == 0) {  // greedy: a batch is closed when the next bin would not fit
-    uint32_t nb = 0, acc = 0;
-    b_lo[0] = 0;
-    for (uint32_t b = 0; b < (uint32_t)NBIN; ++b) {
-      const uint32_t c = bins[b];
-      if (c > (uint32_t)CAP) sh_bad = 1;  // one bin denser than a batch: not for this path
-      if (acc + c > (uint32_t)CAP) {
-        if (nb + 1 < (uint32_t)MAXB) {
-          b_lo[++nb] = b;
-          acc = 0;
-        } else {
-          sh_bad = 1;
-        }
-      }
-      acc += c;
+  PT_STAMP(2);
+  {  // bins -> their exclusive prefix sums (NBIN / NT consecutive bins per thread)
+    constexpr int PERB = NBIN / NT;
+    static_assert(NBIN % NT == 0 && PERB >= 1, "bins per thread");
+    uint32_t c[PERB], sum = 0, tot;
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+      c[j] = bins[tid * PERB + j];
+      sum += c[j];
     }
-    b_lo[++nb] = NBIN;
+    uint32_t off = block_excl_sum<NT>(sum, ws, &tot);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+      bins[tid * PERB + j] = off;
+      off += c[j];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // greedy: a batch takes as many bins as fit (a binary search in the prefix sums per batch)
+    uint32_t nb = 0, lo = 0;
+    b_lo[0] = 0;
+    while (lo < (uint32_t)NBIN) {
+      const uint32_t start = bins[lo];
+      uint32_t l = lo + 1, r = NBIN;  // largest hi in (lo, NBIN] with prefix(hi) - prefix(lo) <= CAP; prefix(NBIN) = m
+      while (l < r) {
+        const uint32_t mid = l + ((r - l + 1) >> 1);
+        const uint32_t pm = mid < (uint32_t)NBIN ? bins[mid] : m;
+        if (pm - start <= (uint32_t)CAP) l = mid; else r = mid - 1;
+      }
+      const uint32_t p1 = l < (uint32_t)NBIN ? bins[l] : m;
+      if (p1 - start > (uint32_t)CAP || nb + 1 >= (uint32_t)MAXB) {  // one bin denser than a batch (or too many batches): not for this path
+        sh_bad = 1;
+        break;
+      }
+      b_lo[++nb] = l;
+      lo = l;
+    }
     sh_nb = nb;
   }
   __syncthreads();
@@ -950,6 +1141,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
     if (tid == 0) atomicOr(&A.C->flags, PF_FALLBACK);
     return;
   }
+  PT_STAMP(3);
   const uint32_t n_batches = sh_nb;
   uint64_t carry_max = 0;
   uint32_t base = 0;
@@ -979,6 +1171,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
       if (cb >= bin_lo && cb < bin_hi) atomicAdd(&cnt[fb], 1u);
     });
     __syncthreads();
+    PT_STAMP(4);
     uint32_t mb;
     {
       constexpr int PER = NBK / NT;
@@ -1007,6 +1200,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
       }
     });
     __syncthreads();
+    PT_STAMP(5);
     const uint32_t plus_here = m_plus > base ? (m_plus - base < mb ? m_plus - base : mb) : 0u;  // '+' members of the batch
     {
       uint32_t rk[E], rl[E], rr[E];
@@ -1038,6 +1232,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
         }
     }
     __syncthreads();
+    PT_STAMP(6);
     // ---- the batch's columns out, gathered by record index (every load of the thread requested together)
     {
       uint32_t li[E], qe[E], ts[E], te[E], mm[E], bb[E];
@@ -1073,6 +1268,7 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
       }
     }
     __syncthreads();
+    PT_STAMP(7);
     {
       uint32_t qs_r[E], qe_r[E];
       read_block<E>(K, qs_r);
@@ -1081,9 +1277,11 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
     }
     base += mb;
     __syncthreads();
+    PT_STAMP(8);
   }
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
   if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, (int)PAIR_XL_CELLS);
+  PT_STAMP(9);
 }
 
 // ---- pair_finish ----------------------------------------------------------------------------------------------------
@@ -1107,14 +1305,19 @@ struct PairFinishArgs {
 
 // plane_sweep_both with no limit on either axis (plane_sweep_exact.rs:268-461 with mappings_to_keep = usize::MAX): a sweep
 // over at most one interval returns it; otherwise an interval survives iff it is ever in the tree at a mark_good call, i.e.
-// iff start < end.  The target sweep runs over the query sweep's survivors.
-template <int NT>
+// iff start < end.  The target sweep runs over the query sweep's survivors.  So a chain with both spans positive is always
+// kept, and only a pair that holds a chain with an empty span needs the counts: the sweep below first ranks the chains under
+// "both spans positive", and runs once more under the exact rule if it met such a chain.
+// KP: the kept '+' chains of a pair that are staged in LDS for the inversion capture (a longer list is searched in memory).
+template <int NT, int KP>
 __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
+  constexpr int U = 4;  // positions per thread and round: their loads are requested together
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint64_t ws64[NT / 64 + 1];
+  __shared__ uint32_t l_qs[KP], l_qe[KP], l_ts[KP], l_pm[KP];
   const int tid = threadIdx.x;
-  // a pair_sort work-group gave the call up (a unit too long for a chunk ...): its chunks were not made, so the labels of its
-  // pair do not exist; nothing written from here on is used (the host sees the same flag and runs the global-sort stage)
+  // a pair_sort work-group gave the call up (a pair too dense for the LDS batches ...): nothing written from here on is used
+  // (the host sees the same flag and runs the global-sort stage)
   if (A.C->flags & PF_FALLBACK) return;
   const uint32_t rk = A.list[blockIdx.x];
   const PairRun run = A.runs[rk];
@@ -1128,112 +1331,187 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     if (tid == 0) A.sum[rk] = sm;
     return;
   }
-  // ---- the chains that pass the span / identity filter
-  uint32_t c0 = 0, c1 = 0, cq = 0;
-  for (uint32_t p = tid; p < m; p += NT)
-    if (A.ok_head[a + p]) {
-      const HeadRec hr = A.rec[a + p];
-      if (p < m_plus) ++c0; else ++c1;
-      cq += hr.qs < hr.qe ? 1u : 0u;
+  // ---- the chains that pass the span / identity filter, ranked in position order ('+' chains first); the kept '+' chains
+  // listed for the inversion capture.  exact: 0 = a chain is kept iff both its spans are positive (counts the others);
+  // 1 = the rule above with the counts of the first sweep.
+  uint32_t n_pass0 = 0, n_pass1 = 0, n_q = 0, n_deg = 0, n_kept = 0, kP = 0;
+  bool all_q = false, all_t = false;
+  auto sweep = [&](const bool exact) {
+    uint32_t kept_before = 0, c0 = 0, c1 = 0, cq = 0, cd = 0, cp = 0;
+    for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
+      uint8_t ok[U];
+      HeadRec hr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        if (ok[u]) hr[u] = A.rec[a + p];
+      }
+      uint64_t packed = 0;  // four 16-bit counters: kept chains of row u among the threads before this one
+      bool kept[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        kept[u] = false;
+        if (ok[u]) {
+          const bool hq = hr[u].qs < hr[u].qe, ht = hr[u].ts < hr[u].te;
+          kept[u] = exact ? (all_q || hq) && (all_t || ht) : hq && ht;
+          if (p < m_plus) ++c0; else ++c1;
+          cq += hq ? 1u : 0u;
+          cd += (hq && ht) ? 0u : 1u;
+          cp += (kept[u] && p < m_plus) ? 1u : 0u;
+        }
+        packed |= (uint64_t)(kept[u] ? 1u : 0u) << (16 * u);
+      }
+      // one scan for the four rows (NT <= 1024 < 2^16)
+      uint64_t inc = packed;
+      const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      uint64_t off = 0, tot = 0;
+      if (NT == 64) {
+        tot = __shfl(inc, 63, 64);
+      } else {
+        __syncthreads();
+        if (lane == 63) ws64[w] = inc;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) {
+          const uint64_t x = ws64[k];
+          off += k < w ? x : 0ull;
+          tot += x;
+        }
+      }
+      const uint64_t ex = off + inc - packed;
+      uint32_t row_base = kept_before;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        const uint32_t r = row_base + (uint32_t)((ex >> (16 * u)) & 0xffffu);
+        if (p < m) A.head_num[a + p] = kept[u] ? r : NONE;  // (every position: the members look their head's entry up)
+        if (kept[u] && p < m_plus) {  // '+' chains come first: r is the chain's slot in the list
+          A.f_qs[a + r] = hr[u].qs;
+          A.f_qe[a + r] = hr[u].qe;
+          A.f_ts[a + r] = hr[u].ts;
+          if (r < (uint32_t)KP) {
+            l_qs[r] = hr[u].qs;
+            l_qe[r] = hr[u].qe;
+            l_ts[r] = hr[u].ts;
+          }
+        }
+        row_base += (uint32_t)((tot >> (16 * u)) & 0xffffu);
+      }
+      kept_before = row_base;
     }
-  const uint32_t np0 = block_sum<NT>(c0, ws), np1 = block_sum<NT>(c1, ws), nq = block_sum<NT>(cq, ws);
-  const uint32_t n_ch = np0 + np1;
+    n_kept = kept_before;
+    n_pass0 = block_sum<NT>(c0, ws);
+    n_pass1 = block_sum<NT>(c1, ws);
+    n_q = block_sum<NT>(cq, ws);
+    n_deg = block_sum<NT>(cd, ws);
+    kP = block_sum<NT>(cp, ws);
+  };
+  sweep(false);
+  const uint32_t n_ch = n_pass0 + n_pass1;
   if (n_ch == 0) {
     if (tid == 0) A.sum[rk] = sm;
     return;
   }
-  const bool all_q = n_ch <= 1;
-  const uint32_t nq_eff = all_q ? n_ch : nq;
-  const bool all_t = nq_eff <= 1;
-  // ---- kept chains ranked in position order ('+' chains first); the kept '+' chains listed for the inversion capture
-  uint32_t kept_before = 0, kept_plus = 0;
-  for (uint32_t p0 = 0; p0 < m; p0 += NT) {
-    const uint32_t p = p0 + tid;
-    bool kept = false;
-    HeadRec hr{};
-    if (p < m && A.ok_head[a + p]) {
-      hr = A.rec[a + p];
-      kept = (all_q || hr.qs < hr.qe) && (all_t || hr.ts < hr.te);
-    }
-    uint32_t tot;
-    const uint32_t r = kept_before + block_excl_sum<NT>(kept ? 1u : 0u, ws, &tot);
-    if (p < m && A.ok_head[a + p]) A.head_num[a + p] = kept ? r : NONE;
-    if (kept && p < m_plus) {  // r < kept_plus_total: its slot in the list
-      A.f_qs[a + r] = hr.qs;
-      A.f_qe[a + r] = hr.qe;
-      A.f_ts[a + r] = hr.ts;
-    }
-    kept_before += tot;
-    if (p0 < m_plus) {  // (block-uniform) kept '+' chains so far
-      const uint32_t plus_here = block_sum<NT>((kept && p < m_plus) ? 1u : 0u, ws);
-      kept_plus += plus_here;
-    }
+  if (n_deg) {  // a chain with an empty span: the rule needs the counts
+    all_q = n_ch <= 1;
+    all_t = (all_q ? n_ch : n_q) <= 1;
+    __syncthreads();
+    sweep(true);
   }
-  const uint32_t n_kept = kept_before, kP = kept_plus, kM = n_kept - kP;
+  const uint32_t kM = n_kept - kP;
   // the reference's all_chains order inside the pair: the (query, target, strand) group that appears first in the metadata
   const bool plus_first = pi.first_mem[0] < pi.first_mem[1];
   sm.n_pass = n_ch;
   sm.n_kept = n_kept;
-  sm.minmem = np0 && np1 ? (pi.first_mem[0] < pi.first_mem[1] ? pi.first_mem[0] : pi.first_mem[1]) : (np0 ? pi.first_mem[0] : pi.first_mem[1]);
+  sm.minmem = n_pass0 && n_pass1 ? (pi.first_mem[0] < pi.first_mem[1] ? pi.first_mem[0] : pi.first_mem[1]) : (n_pass0 ? pi.first_mem[0] : pi.first_mem[1]);
   if (tid == 0) A.sum[rk] = sm;
   if (n_kept == 0) return;
-  __syncthreads();  // head_num / f_* of the whole pair are written
+  __syncthreads();  // head_num / the chain list of the whole pair are written
   auto local_number = [&](uint32_t r, bool minus) -> uint32_t {  // 1-based, in the pair's all_chains order
     if (plus_first) return r + 1;
     return minus ? r - kP + 1 : r + kM + 1;
   };
   // ---- anchors: the members of kept chains (paf_filter.rs:517-528)
   uint32_t out = 0;
-  for (uint32_t p = tid; p < m; p += NT) {
-    const uint32_t h = A.hd[a + p];
-    if (!A.ok_head[h]) continue;
-    const uint32_t r = A.head_num[h];
-    if (r == NONE) continue;
-    const uint32_t i = A.s_idx[a + p];
-    A.chain[i] = local_number(r, h - a >= m_plus);
-    A.status[i] = SWG_ST_SCAFFOLD;
-    ++out;
+  for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
+    uint32_t h[U], idx[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      h[u] = p < m ? A.hd[a + p] : a;
+      idx[u] = p < m ? A.s_idx[a + p] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = A.head_num[h[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      if (p < m && r[u] != NONE) {
+        A.chain[idx[u]] = local_number(r[u], h[u] - a >= m_plus);
+        A.status[idx[u]] = SWG_ST_SCAFFOLD;
+        ++out;
+      }
+    }
   }
   // ---- inversion capture (paf_filter.rs:535-597): a '-' record that is not an anchor joins the first kept '+' chain of its
   // pair whose window and diagonal it sits on
   if (!A.scaffolds_only && kP > 0 && M > m_plus) {
+    const bool in_lds = kP <= (uint32_t)KP;
     // running maximum of the chains' ends
     uint64_t carry = 0;
     for (uint32_t c0b = 0; c0b < kP; c0b += NT) {
       const uint32_t c = c0b + tid;
-      const uint64_t v = c < kP ? (uint64_t)A.f_qe[a + c] : 0ull;
+      const uint64_t v = c < kP ? (uint64_t)(in_lds ? l_qe[c] : A.f_qe[a + c]) : 0ull;
       uint64_t tot;
       uint64_t ex = block_excl_max<NT>(v, ws64, &tot);
       ex = ex > carry ? ex : carry;
-      if (c < kP) A.f_pm[a + c] = (uint32_t)(v > ex ? v : ex);
+      if (c < kP) {
+        const uint32_t pm = (uint32_t)(v > ex ? v : ex);
+        if (in_lds) l_pm[c] = pm; else A.f_pm[a + c] = pm;
+      }
       carry = tot > carry ? tot : carry;
     }
-    __syncthreads();  // f_pm, and the anchors' chain numbers
+    __syncthreads();  // the running maxima, and the anchors' chain numbers
+    const uint32_t* __restrict__ c_qs = in_lds ? l_qs : A.f_qs + a;
+    const uint32_t* __restrict__ c_qe = in_lds ? l_qe : A.f_qe + a;
+    const uint32_t* __restrict__ c_ts = in_lds ? l_ts : A.f_ts + a;
+    const uint32_t* __restrict__ c_pm = in_lds ? l_pm : A.f_pm + a;
     const uint64_t gap = A.gap, max_dev = A.fp_thr[0];
     for (uint32_t p = m_plus + tid; p < M; p += NT) {
       const uint32_t iw = A.s_idx[a + p];
       if (p >= m && (iw >> 31) == 0) continue;  // an alive non-member on the '+' strand
       const uint32_t i = iw & 0x7fffffffu;
-      if (A.chain[i]) continue;  // already an anchor
       const uint64_t qs = A.s_qs[a + p], qe = A.s_qe[a + p], ts = A.s_ts[a + p], te = A.s_te[a + p];
+      if (A.chain[i]) continue;  // already an anchor
       const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
       const uint64_t lim = qe > ~0ull - gap ? ~0ull : qe + gap;  // chain.query_start.saturating_sub(gap) <= qe
       uint32_t l = 0, r = kP;  // first chain with q_start > lim
       while (l < r) {
         const uint32_t mid = l + ((r - l) >> 1);
-        if ((uint64_t)A.f_qs[a + mid] <= lim) l = mid + 1; else r = mid;
+        if ((uint64_t)c_qs[mid] <= lim) l = mid + 1; else r = mid;
       }
       uint32_t lo = 0, hi = l;  // first slot whose running maximum of ends reaches the record
       while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        const uint64_t pm = A.f_pm[a + mid];
+        const uint64_t pm = c_pm[mid];
         if ((pm > ~0ull - gap ? ~0ull : pm + gap) < qs) lo = mid + 1; else hi = mid;
       }
       uint32_t best = NONE;
       for (uint32_t c = lo; c < l; ++c) {
-        const uint64_t cqe = A.f_qe[a + c];
+        const uint64_t cqe = c_qe[c];
         if ((cqe > ~0ull - gap ? ~0ull : cqe + gap) < qs) continue;
-        const int64_t diag = (int64_t)A.f_ts[a + c] - (int64_t)A.f_qs[a + c];
+        const int64_t diag = (int64_t)c_ts[c] - (int64_t)c_qs[c];
         const int64_t dev = (int64_t)tc - (int64_t)qc - diag;
         const uint64_t deviation = dev < 0 ? (uint64_t)0 - (uint64_t)dev : (uint64_t)dev;
         if (deviation <= max_dev) {
@@ -1305,6 +1583,47 @@ __global__ __launch_bounds__(EW) void pair_base_kernel(uint32_t n_runs, const ui
                                                        PairSum* __restrict__ sum) {
   const uint32_t r = blockIdx.x * EW + threadIdx.x;
   if (r < n_runs) sum[order[r]].base = bases[r];
+}
+// A moderate number of pairs: the same by counting, one thread per pair, the keys passed through LDS a tile at a time
+// (O(pairs^2) compares, no sort: 10^4 pairs are 10^8 compares).
+constexpr int COUNT_TILE = 1024;
+__global__ __launch_bounds__(EW) void pair_rank_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, const PairInfo* __restrict__ info,
+                                                             const uint32_t* __restrict__ seq_genome_two, PairTable gp2_first,
+                                                             uint32_t* __restrict__ rank1) {
+  __shared__ uint64_t tile[COUNT_TILE];
+  const uint32_t k = blockIdx.x * EW + threadIdx.x;
+  const uint64_t mine = k < n_runs ? key[k] : ~0ull;
+  uint32_t r = 0;
+  for (uint32_t t0 = 0; t0 < n_runs; t0 += COUNT_TILE) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)COUNT_TILE; j += EW) tile[j] = t0 + j < n_runs ? key[t0 + j] : ~0ull;
+    __syncthreads();
+    const uint32_t lim = n_runs - t0 < (uint32_t)COUNT_TILE ? n_runs - t0 : (uint32_t)COUNT_TILE;
+    for (uint32_t j = 0; j < lim; ++j) r += tile[j] < mine ? 1u : 0u;
+  }
+  if (k >= n_runs) return;
+  rank1[k] = r;
+  if (mine != ~0ull) atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
+}
+__global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, PairSum* __restrict__ sum) {
+  __shared__ uint64_t tile[COUNT_TILE];
+  __shared__ uint32_t kept[COUNT_TILE];
+  const uint32_t k = blockIdx.x * EW + threadIdx.x;
+  const uint64_t mine = k < n_runs ? key[k] : ~0ull;
+  uint32_t b = 0;
+  for (uint32_t t0 = 0; t0 < n_runs; t0 += COUNT_TILE) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < (uint32_t)COUNT_TILE; j += EW) {
+      const bool in = t0 + j < n_runs;
+      tile[j] = in ? key[t0 + j] : ~0ull;
+      kept[j] = in ? sum[t0 + j].n_kept : 0u;
+    }
+    __syncthreads();
+    const uint32_t lim = n_runs - t0 < (uint32_t)COUNT_TILE ? n_runs - t0 : (uint32_t)COUNT_TILE;
+    for (uint32_t j = 0; j < lim; ++j) b += tile[j] < mine ? kept[j] : 0u;
+  }
+  __syncthreads();  // (every thread has read the sums of its last tile before any base is written: base and n_kept share a record)
+  if (k < n_runs) sum[k].base = mine != ~0ull ? b : 0u;
 }
 // Few pairs (the usual case for a small input): no sort at all -- a pair's place among the keys is a count, and its base is
 // the sum of the kept chains of the pairs whose key is smaller; one work-group, O(pairs^2) compares from LDS.
@@ -1486,9 +1805,9 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     if (!ncls[c]) continue;
     SA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 256><<<ncls[c], 64, 0, st>>>(SA)); break;
-      case 1: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 1024><<<ncls[c], 256, 0, st>>>(SA)); break;
-      case 2: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<1024, 16, 4096><<<ncls[c], 1024, 0, st>>>(SA)); break;
+      case 0: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA)); break;
+      case 1: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA)); break;
+      case 2: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<1024, 16, 32, 4096, 1024><<<ncls[c], 1024, 0, st>>>(SA)); break;
       default: SWG_LAUNCH_N(ctx, "pair_sort_xl", 0, pair_sort_xl_kernel<1024, 8, 4096><<<ncls[c], 1024, 0, st>>>(SA)); break;
     }
     SWG_KERNEL_CHECK(ctx);
@@ -1510,9 +1829,9 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<64><<<ncls[c], 64, 0, st>>>(FA)); break;
-      case 1: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<256><<<ncls[c], 256, 0, st>>>(FA)); break;
-      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<1024><<<ncls[c], 1024, 0, st>>>(FA)); break;
+      case 0: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<64, 256><<<ncls[c], 64, 0, st>>>(FA)); break;
+      case 1: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<256, 1024><<<ncls[c], 256, 0, st>>>(FA)); break;
+      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096><<<ncls[c], 512, 0, st>>>(FA)); break;
     }
     SWG_KERNEL_CHECK(ctx);
   }
@@ -1520,6 +1839,17 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   if (n_runs <= (uint32_t)NUMBER_SMALL) {
     SWG_LAUNCH(ctx, "pair_number", pair_number_small_kernel<<<1, 1024, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, gp2_first,
                                                                      r->seq_genome_two, C));
+    SWG_KERNEL_CHECK(ctx);
+  } else if (n_runs <= 32768u) {
+    uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
+    uint32_t* val = swg_alloc<uint32_t>(ctx, n_runs);
+    uint32_t* rank1 = swg_alloc<uint32_t>(ctx, n_runs);
+    SWG_CHECK_ARENA(ctx);
+    const unsigned rb = nblk(n_runs);
+    SWG_LAUNCH(ctx, "pair_number", pair_key1_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, key, val, C));
+    SWG_LAUNCH(ctx, "pair_number", pair_rank_count_kernel<<<rb, EW, 0, st>>>(n_runs, key, info, r->seq_genome_two, gp2_first, rank1));
+    SWG_LAUNCH(ctx, "pair_number", pair_key2_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, rank1, r->seq_genome_two, gp2_first, key, val, C));
+    SWG_LAUNCH(ctx, "pair_number", pair_base_count_kernel<<<rb, EW, 0, st>>>(n_runs, key, sum));
     SWG_KERNEL_CHECK(ctx);
   } else {
     uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
