@@ -389,27 +389,47 @@ __device__ unsigned long long g_pair_t[16];
 // RR), and puts their columns at that place of an LDS buffer that is then written out coalesced -- no gather anywhere.
 // Every global load of a phase is requested before the first value is used (a thread's records one after the other would be
 // as many memory round trips in a row, and the work-group is alone on its CU: nothing else hides them).
+// (the LDS of a pair_sort work-group is one raw block that the body carves up: the two bodies -- this one and the one for the
+// longest runs -- share a launch and therefore a block)
+// Compile-time offsets only: a pointer that goes through an integer on its way loses its address space, and every LDS access
+// behind it becomes a flat instruction.
+constexpr size_t lds_align_up(size_t off, size_t align) { return (off + align - 1) / align * align; }
 template <int NT, int ES, int ER, int NBK, int NBIN>
-__global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
+constexpr size_t pair_sort_lds_bytes() {
+  // K, I, RR, cnt, bins, b_lo, cellmin, ws64, ws, 13 scalars -- plus slack for the alignment of each piece
+  return (size_t)NT * ES * 8 + (size_t)NBK * 4 + (size_t)NBIN * 4 + 17 * 4 + (size_t)((NT * ER + PAIR_CELL - 1) / PAIR_CELL) * 4 +
+         (size_t)(NT / 64 + 1) * 12 + 16 * 4 + 128;
+}
+template <int NT, int ES, int ER, int NBK, int NBIN>
+__device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint32_t rk_run, char* lds_raw) {
   constexpr int CAP = NT * ES, NREC = NT * ER, MAXB = 16, H = 8;
   constexpr int NCELL = (NREC + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
   static_assert(ER <= 32 && ER % H == 0 && ES % 4 == 0 && NREC <= 65536, "record masks are 32 bits wide, indices 16");
   static_assert(NBIN >= 2 && NBIN <= 4096, "each strand needs a coarse bin of its own (the members are ordered strand first)");
-  __shared__ __attribute__((aligned(16))) uint32_t K[CAP];
-  __shared__ uint16_t I[CAP];
-  __shared__ uint16_t RR[CAP];
-  __shared__ uint32_t cnt[NBK];
-  __shared__ uint32_t bins[NBIN];
-  __shared__ uint32_t b_lo[MAXB + 1];
-  __shared__ uint32_t cellmin[NCELL];
-  __shared__ uint64_t ws64[NT / 64 + 1];
-  __shared__ uint32_t ws[NT / 64 + 1];
-  __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3], sh_nb, sh_bad;
+  constexpr size_t O_K = 0, O_I = O_K + (size_t)CAP * 4, O_RR = O_I + (size_t)CAP * 2, O_CNT = lds_align_up(O_RR + (size_t)CAP * 2, 4),
+                   O_BINS = O_CNT + (size_t)NBK * 4, O_BLO = O_BINS + (size_t)NBIN * 4, O_CELL = O_BLO + (size_t)(MAXB + 1) * 4,
+                   O_WS64 = lds_align_up(O_CELL + (size_t)NCELL * 4, 8), O_WS = O_WS64 + (size_t)(NT / 64 + 1) * 8,
+                   O_SH = O_WS + (size_t)(NT / 64 + 1) * 4;
+  static_assert(O_SH + 13 * 4 <= pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN>(), "LDS block of the work-group");
+  uint32_t* const K = reinterpret_cast<uint32_t*>(lds_raw + O_K);
+  uint16_t* const I = reinterpret_cast<uint16_t*>(lds_raw + O_I);
+  uint16_t* const RR = reinterpret_cast<uint16_t*>(lds_raw + O_RR);
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds_raw + O_CNT);
+  uint32_t* const bins = reinterpret_cast<uint32_t*>(lds_raw + O_BINS);
+  uint32_t* const b_lo = reinterpret_cast<uint32_t*>(lds_raw + O_BLO);
+  uint32_t* const cellmin = reinterpret_cast<uint32_t*>(lds_raw + O_CELL);
+  uint64_t* const ws64 = reinterpret_cast<uint64_t*>(lds_raw + O_WS64);
+  uint32_t* const ws = reinterpret_cast<uint32_t*>(lds_raw + O_WS);
+  uint32_t* const sh_cnt = reinterpret_cast<uint32_t*>(lds_raw + O_SH);
+  uint32_t* const sh_kmin = sh_cnt + 4;
+  uint32_t* const sh_kmax = sh_cnt + 6;
+  uint32_t* const sh_first = sh_cnt + 8;
+  uint32_t& sh_nb = sh_cnt[11];
+  uint32_t& sh_bad = sh_cnt[12];
 #ifdef SWG_PAIR_TIMING
   unsigned long long pt_last = wall_clock64();
 #endif
   const int tid = threadIdx.x;
-  const uint32_t rk_run = A.list[blockIdx.x];
   const PairRun run = A.runs[rk_run];
   const uint32_t a = run.a, n = run.n;
   if (tid < 4) sh_cnt[tid] = 0;
@@ -683,9 +703,10 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
   uint64_t carry_max = 0;
   uint32_t base = 0;
   for (uint32_t bt = 0; bt < n_batches; ++bt) {
-    // (the column pointers pass through an empty asm: every batch re-reads the thread's records, and a compiler that sees
-    // the same loads in every iteration lifts all of them out of the loop -- some 200 registers held across it)
-    asm volatile("" : "+s"(c_qs), "+s"(c_qe), "+s"(c_ts), "+s"(c_te), "+s"(c_m), "+s"(c_b), "+v"(tid_v), "+s"(n_v), "+v"(member_mask), "+v"(strand_mask));
+    // (the thread index and the run length pass through an empty asm: every batch re-reads the thread's records, and a
+    // compiler that sees the same loads in every iteration lifts all of them out of the loop -- some 200 registers held
+    // across it.  Not the pointers themselves: behind an asm they lose their address space and the loads become flat ones.)
+    asm volatile("" : "+v"(tid_v), "+s"(n_v), "+v"(member_mask), "+v"(strand_mask));
     const uint32_t bin_lo = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt]) : 0u;
     const uint32_t bin_hi = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt + 1]) : (uint32_t)NBIN;
     int shift = 0;
@@ -908,24 +929,37 @@ __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
 // members, every batch is bucket-sorted like a small pair (its members picked out of the run by two passes over the run's
 // q_start column), and the other columns are gathered by record index.
 template <int NT, int E, int NBK>
-__global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
+constexpr size_t pair_sort_xl_lds_bytes() {
+  return (size_t)NT * E * 12 + (size_t)NBK * 4 + 4096 * 4 + 129 * 4 + (size_t)PAIR_XL_CELLS * 4 + (size_t)(NT / 64 + 1) * 12 + 16 * 4 + 128;
+}
+template <int NT, int E, int NBK>
+__device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const uint32_t rk_run, char* lds_raw) {
   constexpr int CAP = NT * E;
   constexpr int NBIN = 4096, MAXB = 128, U = 8;
-  __shared__ __attribute__((aligned(16))) uint32_t K[CAP];
-  __shared__ __attribute__((aligned(16))) uint32_t QE[CAP];
-  __shared__ uint32_t I[CAP];
-  __shared__ uint32_t cnt[NBK];
-  __shared__ uint32_t bins[NBIN];
-  __shared__ uint32_t b_lo[MAXB + 1];
-  __shared__ uint32_t cellmin[PAIR_XL_CELLS];
-  __shared__ uint64_t ws64[NT / 64 + 1];
-  __shared__ uint32_t ws[NT / 64 + 1];
-  __shared__ uint32_t sh_cnt[4], sh_kmin[2], sh_kmax[2], sh_first[3], sh_nb, sh_bad;
+  constexpr size_t O_K = 0, O_QE = O_K + (size_t)CAP * 4, O_I = O_QE + (size_t)CAP * 4, O_CNT = O_I + (size_t)CAP * 4,
+                   O_BINS = O_CNT + (size_t)NBK * 4, O_BLO = O_BINS + (size_t)NBIN * 4, O_CELL = O_BLO + (size_t)(MAXB + 1) * 4,
+                   O_WS64 = lds_align_up(O_CELL + (size_t)PAIR_XL_CELLS * 4, 8), O_WS = O_WS64 + (size_t)(NT / 64 + 1) * 8,
+                   O_SH = O_WS + (size_t)(NT / 64 + 1) * 4;
+  static_assert(O_SH + 13 * 4 <= pair_sort_xl_lds_bytes<NT, E, NBK>(), "LDS block of the work-group");
+  uint32_t* const K = reinterpret_cast<uint32_t*>(lds_raw + O_K);
+  uint32_t* const QE = reinterpret_cast<uint32_t*>(lds_raw + O_QE);
+  uint32_t* const I = reinterpret_cast<uint32_t*>(lds_raw + O_I);
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds_raw + O_CNT);
+  uint32_t* const bins = reinterpret_cast<uint32_t*>(lds_raw + O_BINS);
+  uint32_t* const b_lo = reinterpret_cast<uint32_t*>(lds_raw + O_BLO);
+  uint32_t* const cellmin = reinterpret_cast<uint32_t*>(lds_raw + O_CELL);
+  uint64_t* const ws64 = reinterpret_cast<uint64_t*>(lds_raw + O_WS64);
+  uint32_t* const ws = reinterpret_cast<uint32_t*>(lds_raw + O_WS);
+  uint32_t* const sh_cnt = reinterpret_cast<uint32_t*>(lds_raw + O_SH);
+  uint32_t* const sh_kmin = sh_cnt + 4;
+  uint32_t* const sh_kmax = sh_cnt + 6;
+  uint32_t* const sh_first = sh_cnt + 8;
+  uint32_t& sh_nb = sh_cnt[11];
+  uint32_t& sh_bad = sh_cnt[12];
 #ifdef SWG_PAIR_TIMING
   unsigned long long pt_last = wall_clock64();
 #endif
   const int tid = threadIdx.x;
-  const uint32_t rk_run = A.list[blockIdx.x];
   const PairRun run = A.runs[rk_run];
   const uint32_t a = run.a, n = run.n;
   if (tid < 4) sh_cnt[tid] = 0;
@@ -1284,6 +1318,25 @@ __global__ __launch_bounds__(NT) void pair_sort_xl_kernel(PairSortArgs A) {
   PT_STAMP(9);
 }
 
+template <int NT, int ES, int ER, int NBK, int NBIN>
+__global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
+  __shared__ __attribute__((aligned(16))) char raw[pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN>()];
+  pair_sort_body<NT, ES, ER, NBK, NBIN>(A, A.list[blockIdx.x], raw);
+}
+// The two largest size classes in one launch: the few very long runs first (they last longest), the others fill the chip
+// beside them (launched on their own the long runs keep a handful of CUs busy and the rest of the chip waits).
+constexpr size_t PAIR_BIG_LDS = pair_sort_lds_bytes<1024, 16, 32, 4096, 1024>() > pair_sort_xl_lds_bytes<1024, 8, 4096>()
+                                    ? pair_sort_lds_bytes<1024, 16, 32, 4096, 1024>()
+                                    : pair_sort_xl_lds_bytes<1024, 8, 4096>();
+static_assert(PAIR_BIG_LDS <= 160 * 1024, "LDS of a CU");
+__global__ __launch_bounds__(1024) void pair_sort_big_kernel(PairSortArgs A, const uint32_t* __restrict__ list_xl, uint32_t n_xl) {
+  __shared__ __attribute__((aligned(16))) char raw[PAIR_BIG_LDS];
+  if (blockIdx.x < n_xl)
+    pair_sort_xl_body<1024, 8, 4096>(A, list_xl[blockIdx.x], raw);
+  else
+    pair_sort_body<1024, 16, 32, 4096, 1024>(A, A.list[blockIdx.x - n_xl], raw);
+}
+
 // ---- pair_finish ----------------------------------------------------------------------------------------------------
 struct PairFinishArgs {
   const PairRun* runs;
@@ -1584,46 +1637,40 @@ __global__ __launch_bounds__(EW) void pair_base_kernel(uint32_t n_runs, const ui
   const uint32_t r = blockIdx.x * EW + threadIdx.x;
   if (r < n_runs) sum[order[r]].base = bases[r];
 }
-// A moderate number of pairs: the same by counting, one thread per pair, the keys passed through LDS a tile at a time
-// (O(pairs^2) compares, no sort: 10^4 pairs are 10^8 compares).
-constexpr int COUNT_TILE = 1024;
+// A moderate number of pairs: the same by counting, one wavefront per pair (its lanes stride over the keys; O(pairs^2)
+// compares, no sort: 10^4 pairs are 10^8 compares).
 __global__ __launch_bounds__(EW) void pair_rank_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, const PairInfo* __restrict__ info,
                                                              const uint32_t* __restrict__ seq_genome_two, PairTable gp2_first,
                                                              uint32_t* __restrict__ rank1) {
-  __shared__ uint64_t tile[COUNT_TILE];
-  const uint32_t k = blockIdx.x * EW + threadIdx.x;
-  const uint64_t mine = k < n_runs ? key[k] : ~0ull;
-  uint32_t r = 0;
-  for (uint32_t t0 = 0; t0 < n_runs; t0 += COUNT_TILE) {
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < (uint32_t)COUNT_TILE; j += EW) tile[j] = t0 + j < n_runs ? key[t0 + j] : ~0ull;
-    __syncthreads();
-    const uint32_t lim = n_runs - t0 < (uint32_t)COUNT_TILE ? n_runs - t0 : (uint32_t)COUNT_TILE;
-    for (uint32_t j = 0; j < lim; ++j) r += tile[j] < mine ? 1u : 0u;
-  }
+  const uint32_t k = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (k >= n_runs) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t mine = key[k];
+  uint32_t r = 0;
+  if (mine != ~0ull)
+    for (uint32_t j = lane; j < n_runs; j += 64) r += key[j] < mine ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+  if (lane) return;
   rank1[k] = r;
   if (mine != ~0ull) atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
 }
-__global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, PairSum* __restrict__ sum) {
-  __shared__ uint64_t tile[COUNT_TILE];
-  __shared__ uint32_t kept[COUNT_TILE];
-  const uint32_t k = blockIdx.x * EW + threadIdx.x;
-  const uint64_t mine = k < n_runs ? key[k] : ~0ull;
+__global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, const PairSum* __restrict__ sum,
+                                                             uint32_t* __restrict__ base_out) {
+  const uint32_t k = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (k >= n_runs) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t mine = key[k];
   uint32_t b = 0;
-  for (uint32_t t0 = 0; t0 < n_runs; t0 += COUNT_TILE) {
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < (uint32_t)COUNT_TILE; j += EW) {
-      const bool in = t0 + j < n_runs;
-      tile[j] = in ? key[t0 + j] : ~0ull;
-      kept[j] = in ? sum[t0 + j].n_kept : 0u;
-    }
-    __syncthreads();
-    const uint32_t lim = n_runs - t0 < (uint32_t)COUNT_TILE ? n_runs - t0 : (uint32_t)COUNT_TILE;
-    for (uint32_t j = 0; j < lim; ++j) b += tile[j] < mine ? kept[j] : 0u;
-  }
-  __syncthreads();  // (every thread has read the sums of its last tile before any base is written: base and n_kept share a record)
-  if (k < n_runs) sum[k].base = mine != ~0ull ? b : 0u;
+  if (mine != ~0ull)
+    for (uint32_t j = lane; j < n_runs; j += 64) b += key[j] < mine ? sum[j].n_kept : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+  if (lane == 0) base_out[k] = b;  // (a separate array: the sums are still being read by other wavefronts)
+}
+__global__ __launch_bounds__(EW) void pair_base_store_kernel(uint32_t n_runs, const uint32_t* __restrict__ base_in, PairSum* __restrict__ sum) {
+  const uint32_t k = blockIdx.x * EW + threadIdx.x;
+  if (k < n_runs) sum[k].base = base_in[k];
 }
 // Few pairs (the usual case for a small input): no sort at all -- a pair's place among the keys is a count, and its base is
 // the sum of the kept chains of the pairs whose key is smaller; one work-group, O(pairs^2) compares from LDS.
@@ -1801,15 +1848,18 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.runs = runs;
   SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = s_m; SA.s_b = s_b; SA.s_idx = s_idx; SA.pred = pred;
   SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
-  for (int c = 3; c >= 0; --c) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
+  if (ncls[2] + ncls[3]) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
+    SA.list = class_list + (size_t)2 * cap;
+    SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_big_kernel<<<ncls[2] + ncls[3], 1024, 0, st>>>(SA, class_list + (size_t)3 * cap, ncls[3]));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  for (int c = 1; c >= 0; --c) {
     if (!ncls[c]) continue;
     SA.list = class_list + (size_t)c * cap;
-    switch (c) {
-      case 0: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA)); break;
-      case 1: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA)); break;
-      case 2: SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<1024, 16, 32, 4096, 1024><<<ncls[c], 1024, 0, st>>>(SA)); break;
-      default: SWG_LAUNCH_N(ctx, "pair_sort_xl", 0, pair_sort_xl_kernel<1024, 8, 4096><<<ncls[c], 1024, 0, st>>>(SA)); break;
-    }
+    if (c == 0)
+      SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA));
+    else
+      SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA));
     SWG_KERNEL_CHECK(ctx);
   }
   SWG_TRY(pair_walk_launch(ctx, cap_chunks, &C->n_chunks, chunks, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred));
@@ -1845,11 +1895,12 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     uint32_t* val = swg_alloc<uint32_t>(ctx, n_runs);
     uint32_t* rank1 = swg_alloc<uint32_t>(ctx, n_runs);
     SWG_CHECK_ARENA(ctx);
-    const unsigned rb = nblk(n_runs);
+    const unsigned rb = nblk(n_runs), wb = (n_runs + EW / 64 - 1) / (EW / 64);
     SWG_LAUNCH(ctx, "pair_number", pair_key1_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, key, val, C));
-    SWG_LAUNCH(ctx, "pair_number", pair_rank_count_kernel<<<rb, EW, 0, st>>>(n_runs, key, info, r->seq_genome_two, gp2_first, rank1));
+    SWG_LAUNCH(ctx, "pair_number", pair_rank_count_kernel<<<wb, EW, 0, st>>>(n_runs, key, info, r->seq_genome_two, gp2_first, rank1));
     SWG_LAUNCH(ctx, "pair_number", pair_key2_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, rank1, r->seq_genome_two, gp2_first, key, val, C));
-    SWG_LAUNCH(ctx, "pair_number", pair_base_count_kernel<<<rb, EW, 0, st>>>(n_runs, key, sum));
+    SWG_LAUNCH(ctx, "pair_number", pair_base_count_kernel<<<wb, EW, 0, st>>>(n_runs, key, sum, rank1));
+    SWG_LAUNCH(ctx, "pair_number", pair_base_store_kernel<<<rb, EW, 0, st>>>(n_runs, rank1, sum));
     SWG_KERNEL_CHECK(ctx);
   } else {
     uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
