@@ -481,7 +481,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
   uint32_t member_mask = 0, strand_mask = 0, extra_mask = 0;
   {
     uint32_t alive_mask = 0, in_mask = 0;
-    uint32_t c_m[2] = {0, 0}, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
+    uint32_t n_mem[2] = {0, 0}, kmin[2] = {0xffffffffu, 0xffffffffu}, kmax[2] = {0, 0}, fst[3] = {NONE, NONE, NONE};
 #pragma unroll
     for (int g = 0; g < ER; g += H) {
       if ((uint32_t)g * NT >= n) continue;  // (block-uniform; `continue`, not `break`: the loop must unroll -- its arrays are registers)
@@ -523,7 +523,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
 #pragma unroll
             for (uint32_t s2 = 0; s2 < 2; ++s2)  // (no array indexed by a run-time strand: see bucket_of)
               if (st == s2) {
-                ++c_m[s2];
+                ++n_mem[s2];
                 kmin[s2] = qv[e] < kmin[s2] ? qv[e] : kmin[s2];
                 kmax[s2] = qv[e] > kmax[s2] ? qv[e] : kmax[s2];
                 if (fst[s2] == NONE) fst[s2] = a + li;
@@ -537,8 +537,8 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     uint32_t c_x = (uint32_t)__popc(extra_mask);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      c_m[0] += __shfl_xor(c_m[0], o, 64);
-      c_m[1] += __shfl_xor(c_m[1], o, 64);
+      n_mem[0] += __shfl_xor(n_mem[0], o, 64);
+      n_mem[1] += __shfl_xor(n_mem[1], o, 64);
       c_x += __shfl_xor(c_x, o, 64);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -553,12 +553,12 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       }
     }
     if ((tid & 63) == 0) {
-      if (c_m[0]) atomicAdd(&sh_cnt[0], c_m[0]);
-      if (c_m[1]) atomicAdd(&sh_cnt[1], c_m[1]);
+      if (n_mem[0]) atomicAdd(&sh_cnt[0], n_mem[0]);
+      if (n_mem[1]) atomicAdd(&sh_cnt[1], n_mem[1]);
       if (c_x) atomicAdd(&sh_cnt[2], c_x);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
-        if (c_m[s2]) {
+        if (n_mem[s2]) {
           atomicMin(&sh_kmin[s2], kmin[s2]);
           atomicMax(&sh_kmax[s2], kmax[s2]);
         }
@@ -1850,16 +1850,16 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
   if (ncls[2] + ncls[3]) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
     SA.list = class_list + (size_t)2 * cap;
-    SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_big_kernel<<<ncls[2] + ncls[3], 1024, 0, st>>>(SA, class_list + (size_t)3 * cap, ncls[3]));
+    SWG_LAUNCH_N(ctx, "pair_sort_big", 0, pair_sort_big_kernel<<<ncls[2] + ncls[3], 1024, 0, st>>>(SA, class_list + (size_t)3 * cap, ncls[3]));
     SWG_KERNEL_CHECK(ctx);
   }
   for (int c = 1; c >= 0; --c) {
     if (!ncls[c]) continue;
     SA.list = class_list + (size_t)c * cap;
     if (c == 0)
-      SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA));
+      SWG_LAUNCH_N(ctx, "pair_sort_s", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA));
     else
-      SWG_LAUNCH_N(ctx, "pair_sort", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA));
+      SWG_LAUNCH_N(ctx, "pair_sort_m", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA));
     SWG_KERNEL_CHECK(ctx);
   }
   SWG_TRY(pair_walk_launch(ctx, cap_chunks, &C->n_chunks, chunks, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred));
@@ -1879,8 +1879,8 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<64, 256><<<ncls[c], 64, 0, st>>>(FA)); break;
-      case 1: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<256, 1024><<<ncls[c], 256, 0, st>>>(FA)); break;
+      case 0: SWG_LAUNCH(ctx, "pair_finish_s", pair_finish_kernel<64, 256><<<ncls[c], 64, 0, st>>>(FA)); break;
+      case 1: SWG_LAUNCH(ctx, "pair_finish_m", pair_finish_kernel<256, 1024><<<ncls[c], 256, 0, st>>>(FA)); break;
       default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096><<<ncls[c], 512, 0, st>>>(FA)); break;
     }
     SWG_KERNEL_CHECK(ctx);

@@ -45,10 +45,12 @@ def pair_major(rec, rng=None):
     return permute(rec, np.argsort(key, kind="stable"))
 
 
-def run_both(sw, rec, cfg_kw, keep_self=False, scaffolds_only=False, expect_pair_path=True):
+def run_both(sw, rec, cfg_kw, keep_self=False, scaffolds_only=False, expect_pair_path=True, derived_identity=False):
     kw = {k: (getattr(sw.FilterMode, v) if isinstance(v, str) else v) for k, v in cfg_kw.items()}
     okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in cfg_kw.items()}
     packed = sw.pack_records(gen.records_to_meta(rec))
+    if derived_identity:   # no identity column: matches / max(block length, 1), evaluated on the device (gen's records carry exactly that)
+        packed.cols["identity"] = None
     ctx = sw.default_context(0)
     ctx.profile_reset()
     ctx.profile(True)
@@ -57,7 +59,7 @@ def run_both(sw, rec, cfg_kw, keep_self=False, scaffolds_only=False, expect_pair
     ctx.profile(False)
     table = ctx.profile_table()
     # (a call the pair path starts and then leaves to the global-sort stage -- a condition found on the device -- shows both)
-    took = "pair_finish" in table and not any(k in table for k in ("chain_cuts", "cuts_from_scan", "sortA_keys", "sortA_keys_hist", "sortA_words"))
+    took = "pair_renumber" in table and not any(k in table for k in ("chain_cuts", "cuts_from_scan", "sortA_keys", "sortA_keys_hist", "sortA_words"))
     ost, och = orc.apply_filters(orc.Config(keep_self=keep_self, scaffolds_only=scaffolds_only, **okw), rec)
     bad = np.flatnonzero((st != ost) | (ch != och))
     assert bad.size == 0, (cfg_kw, "pair path" if took else "global path", int(bad.size), bad[:10].tolist(),
@@ -90,6 +92,7 @@ def test_small_pairs_every_class(sw, seed):
         run_both(sw, rec, cfg)
     run_both(sw, rec, CONFIGS[1], scaffolds_only=True)
     run_both(sw, rec, CONFIGS[2], keep_self=True)
+    run_both(sw, rec, CONFIGS[4], derived_identity=True)
 
 
 def test_one_pair_per_size_class(sw):
@@ -110,6 +113,7 @@ def test_one_pair_per_size_class(sw):
                 {"scaffold_gap": 5_000, "min_scaffold_length": 3_000}, {"scaffold_gap": 400, "min_scaffold_length": 0},
                 {"scaffold_gap": 9_000, "min_scaffold_length": 20_000, "min_scaffold_identity": 0.8}):
         run_both(sw, rec, cfg)
+    run_both(sw, rec, {"scaffold_gap": 5_000, "min_scaffold_length": 3_000, "min_identity": 0.8}, derived_identity=True)
 
 
 def test_dense_ties_and_equal_starts(sw):
@@ -160,7 +164,7 @@ rec = pair_major(gen.random_records(rng, 20000, n_genomes=3, chrs_per_genome=2, 
 ctx = sw.default_context(0)
 ctx.profile(True)
 st, ch = sw.PafFilter(sw.FilterConfig(scaffold_gap=5000, min_scaffold_length=2000)).filter_columns(sw.pack_records(gen.records_to_meta(rec)))
-assert "pair_finish" not in ctx.profile_table()
+assert "pair_renumber" not in ctx.profile_table()
 ost, och = orc.apply_filters(orc.Config(scaffold_gap=5000, min_scaffold_length=2000), rec)
 assert np.array_equal(st, ost) and np.array_equal(ch, och)
 print("ok")

@@ -33,6 +33,10 @@ def short_name(name):
         base = "chain_walk_spec"      # blocks of long units, speculative rounds (template <BIGW, FUSED, SPEC>)
     if base == "os_pass_packed" and len(t) >= 2 and t[1] == "true":
         base = "os_pass_packed_first"  # the pass that reads (key, value) pairs and writes packed words
+    if base == "pair_sort" and t:      # pair_sort_kernel<NT, ...>: the small size classes (the large ones: pair_sort_big)
+        base = {"64": "pair_sort_s", "256": "pair_sort_m"}.get(t[0], base)
+    if base == "pair_finish" and t:    # pair_finish_kernel<NT, KP>
+        base = {"64": "pair_finish_s", "256": "pair_finish_m"}.get(t[0], base)
     if base in ("fill_u32", "fill_u64"):
         base = "fill"
     if base == "iota_u32":
@@ -62,8 +66,11 @@ def collect(d, counter):
             rows.append((int(row["Dispatch_Id"]), k))
     rows.sort()
     executions, last = 0, defaultdict(int)
+    # (the pair-resident path starts with pair_boundary and has no prepare; a call it hands over to the global-sort stage has
+    # both, pair_boundary first)
+    first = "pair_boundary" if any(k == "pair_boundary" for _, k in rows) else "prepare"
     for _, k in rows:
-        if k == "prepare":
+        if k == first:
             executions += 1
             last = defaultdict(int)
         last[k] += 1
