@@ -713,8 +713,7 @@ int pair_table_make(swg_ctx* ctx, uint32_t n_genome, uint64_t bound, PairTable* 
   if (g2 <= DENSE_PAIR_LIMIT) {
     t->dense = swg_alloc<uint32_t>(ctx, g2);
     SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "fill", fill_u32_kernel<<<nblk(g2), EW, 0, st>>>(g2, t->dense, NONE));
-    SWG_KERNEL_CHECK(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(t->dense, 0xff, g2 * sizeof(uint32_t), st));  // NONE in every entry
     return SWG_OK;
   }
   uint64_t cap = 1024;

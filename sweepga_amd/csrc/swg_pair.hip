@@ -31,6 +31,7 @@ namespace {
 constexpr uint32_t PAIR_CELL = WALK_CHUNK;        // a chunk = the units that begin in one cell of this many members
 constexpr uint32_t PAIR_S_MAX = 1024, PAIR_M_MAX = 4096, PAIR_L_MAX = 32768, PAIR_XL_MAX = uint32_t(1) << 18;
 constexpr uint32_t PAIR_XL_CELLS = PAIR_XL_MAX / PAIR_CELL;
+constexpr uint32_t PAIR_HASH_MAX = 65536;  // inputs up to this many records find their pairs through a hash table
 constexpr uint32_t PF_NOT_GROUPED = 1, PF_RUN_OVERFLOW = 2, PF_TOO_LONG = 4, PF_FALLBACK = 8;
 
 struct PairRun {
@@ -213,6 +214,56 @@ __global__ __launch_bounds__(256) void pair_runs_kernel(uint32_t n, uint32_t cap
   class_list[(size_t)cls * cap + j] = k;
 }
 
+// ---- inputs that are not grouped by pair (and small ones in general): the pairs through a hash table ----------------------
+// pair_hash: every record's pair is entered into an open-addressing table (key + 1, 0 = empty) and counted; pair_slots: the
+// occupied slots become the pairs -- their sizes, offsets into a list of record indices and size classes; pair_perm: every record drops its index into its pair's part of that list.  The order inside a pair is whatever
+// the atomics make it: pair_sort orders by (strand, q_start, record index) with the record's own index, so it does not matter.
+__global__ __launch_bounds__(256) void pair_hash_kernel(uint32_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                        unsigned long long* __restrict__ table, uint32_t tmask,
+                                                        uint32_t* __restrict__ count, uint32_t* __restrict__ slot_of) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = (((unsigned long long)q_id[i] << 32) | t_id[i]) + 1ull;
+  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & tmask;
+  for (;;) {  // (at most n keys in >= 2 n slots)
+    unsigned long long old = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 0ull) {
+      old = atomicCAS(&table[h], 0ull, key);
+      if (old == 0ull) old = key;
+    }
+    if (old == key) break;
+    h = (h + 1) & tmask;
+  }
+  slot_of[i] = h;
+  atomicAdd(&count[h], 1u);
+}
+__global__ __launch_bounds__(256) void pair_slots_kernel(uint32_t tsize, const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
+                                                         PairRun* __restrict__ runs, uint32_t* __restrict__ class_list, uint32_t cap,
+                                                         PairCounters* __restrict__ C, uint32_t* __restrict__ cursor) {
+  // every occupied slot takes the next pair number and the next stretch of the index list (which pair gets which is left to
+  // the atomics: nothing depends on the order of the pairs)
+  const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t c = h < tsize ? count[h] : 0u;
+  if (!c) return;
+  const uint32_t k = atomicAdd(&C->n_runs, 1u), o = atomicAdd(cursor, c);
+  start[h] = o;
+  PairRun r;
+  r.a = o;
+  r.n = c;
+  runs[k] = r;
+  if (c > PAIR_L_MAX) {
+    atomicOr(&C->flags, PF_TOO_LONG);
+  } else {
+    const int cls = c <= PAIR_S_MAX ? 0 : (c <= PAIR_M_MAX ? 1 : 2);
+    class_list[(size_t)cls * cap + atomicAdd(&C->n_class[cls], 1u)] = k;
+  }
+}
+__global__ __launch_bounds__(256) void pair_perm_kernel(uint32_t n, const uint32_t* __restrict__ slot_of, uint32_t* __restrict__ start,
+                                                        uint32_t* __restrict__ perm) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) perm[atomicAdd(&start[slot_of[i]], 1u)] = i;
+}
+
 // ---- pair_sort ------------------------------------------------------------------------------------------------------
 // Monotone map of a (strand, key) onto buckets: the strand's share of the buckets, inside it a linear map of the key range.
 // Float arithmetic, but monotone in the key whatever the rounding (conversion, multiplication by a positive constant and
@@ -270,6 +321,7 @@ struct PairSortArgs {
   uint64_t max_gap;
   const PairRun* runs;
   const uint32_t* list;
+  const uint32_t* perm;  // inputs not grouped by pair: record indices, pair after pair (runs[] then index this list)
   uint8_t* code;
   uint32_t *s_qs, *s_qe, *s_ts, *s_te, *s_m, *s_b, *s_idx, *pred;
   PairInfo* info;
@@ -394,25 +446,28 @@ __device__ unsigned long long g_pair_t[16];
 // Compile-time offsets only: a pointer that goes through an integer on its way loses its address space, and every LDS access
 // behind it becomes a flat instruction.
 constexpr size_t lds_align_up(size_t off, size_t align) { return (off + align - 1) / align * align; }
-template <int NT, int ES, int ER, int NBK, int NBIN>
+template <int NT, int ES, int ER, int NBK, int NBIN, bool PERM>
 constexpr size_t pair_sort_lds_bytes() {
   // K, I, RR, cnt, bins, b_lo, cellmin, ws64, ws, 13 scalars -- plus slack for the alignment of each piece
-  return (size_t)NT * ES * 8 + (size_t)NBK * 4 + (size_t)NBIN * 4 + 17 * 4 + (size_t)((NT * ER + PAIR_CELL - 1) / PAIR_CELL) * 4 +
+  return (size_t)NT * ES * (PERM ? 10 : 8) + (size_t)NBK * 4 + (size_t)NBIN * 4 + 17 * 4 + (size_t)((NT * ER + PAIR_CELL - 1) / PAIR_CELL) * 4 +
          (size_t)(NT / 64 + 1) * 12 + 16 * 4 + 128;
 }
-template <int NT, int ES, int ER, int NBK, int NBIN>
+// PERM: the pair's records are not a run of the input but the entries [a, a + n) of a list of record indices (inputs that are
+// not grouped by pair: pair_group_*); the index inside the pair gives way to the record's own index everywhere.
+template <int NT, int ES, int ER, int NBK, int NBIN, bool PERM>
 __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint32_t rk_run, char* lds_raw) {
+  using IT = typename std::conditional<PERM, uint32_t, uint16_t>::type;
   constexpr int CAP = NT * ES, NREC = NT * ER, MAXB = 16, H = 8;
   constexpr int NCELL = (NREC + (int)PAIR_CELL - 1) / (int)PAIR_CELL;
   static_assert(ER <= 32 && ER % H == 0 && ES % 4 == 0 && NREC <= 65536, "record masks are 32 bits wide, indices 16");
   static_assert(NBIN >= 2 && NBIN <= 4096, "each strand needs a coarse bin of its own (the members are ordered strand first)");
-  constexpr size_t O_K = 0, O_I = O_K + (size_t)CAP * 4, O_RR = O_I + (size_t)CAP * 2, O_CNT = lds_align_up(O_RR + (size_t)CAP * 2, 4),
+  constexpr size_t O_K = 0, O_I = O_K + (size_t)CAP * 4, O_RR = O_I + (size_t)CAP * sizeof(IT), O_CNT = lds_align_up(O_RR + (size_t)CAP * 2, 4),
                    O_BINS = O_CNT + (size_t)NBK * 4, O_BLO = O_BINS + (size_t)NBIN * 4, O_CELL = O_BLO + (size_t)(MAXB + 1) * 4,
                    O_WS64 = lds_align_up(O_CELL + (size_t)NCELL * 4, 8), O_WS = O_WS64 + (size_t)(NT / 64 + 1) * 8,
                    O_SH = O_WS + (size_t)(NT / 64 + 1) * 4;
-  static_assert(O_SH + 13 * 4 <= pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN>(), "LDS block of the work-group");
+  static_assert(O_SH + 13 * 4 <= pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN, PERM>(), "LDS block of the work-group");
   uint32_t* const K = reinterpret_cast<uint32_t*>(lds_raw + O_K);
-  uint16_t* const I = reinterpret_cast<uint16_t*>(lds_raw + O_I);
+  IT* const I = reinterpret_cast<IT*>(lds_raw + O_I);
   uint16_t* const RR = reinterpret_cast<uint16_t*>(lds_raw + O_RR);
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds_raw + O_CNT);
   uint32_t* const bins = reinterpret_cast<uint32_t*>(lds_raw + O_BINS);
@@ -453,20 +508,23 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     return t;
   };
   uint32_t tid_v = (uint32_t)tid, n_v = n;  // (copies that pass through an empty asm per batch: see the batch loop)
+  // what a column is indexed by: the record's place in the run (the column pointers then start at the run), or its own index
   auto rec_index = [&](int e) -> uint32_t {
     const uint32_t li = tid_v + (uint32_t)e * NT;
-    return li < n_v ? li : 0u;
+    const uint32_t lc = li < n_v ? li : 0u;
+    return PERM ? A.perm[a + lc] : lc;
   };
-  const uint32_t* c_qs = A.q_start + a;
-  const uint32_t* c_qe = A.q_end + a;
-  const uint32_t* c_ts = A.t_start + a;
-  const uint32_t* c_te = A.t_end + a;
-  const uint32_t* c_m = A.matches + a;
-  const uint32_t* c_b = A.block_len + a;
-  const uint8_t* c_st = A.strand + a;
-  const double* c_id = A.identity ? A.identity + a : nullptr;
-  const uint8_t* c_alive = A.alive_in ? A.alive_in + a : nullptr;
-  const uint8_t* c_member = A.member_in ? A.member_in + a : nullptr;
+  const uint32_t cb = PERM ? 0u : a;  // column base
+  const uint32_t* c_qs = A.q_start + cb;
+  const uint32_t* c_qe = A.q_end + cb;
+  const uint32_t* c_ts = A.t_start + cb;
+  const uint32_t* c_te = A.t_end + cb;
+  const uint32_t* c_m = A.matches + cb;
+  const uint32_t* c_b = A.block_len + cb;
+  const uint8_t* c_st = A.strand + cb;
+  const double* c_id = A.identity ? A.identity + cb : nullptr;
+  const uint8_t* c_alive = A.alive_in ? A.alive_in + cb : nullptr;
+  const uint8_t* c_member = A.member_in ? A.member_in + cb : nullptr;
   uint32_t* o_qs = A.s_qs + a;
   uint32_t* o_qe = A.s_qe + a;
   uint32_t* o_ts = A.s_ts + a;
@@ -476,7 +534,8 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
   uint32_t* o_idx = A.s_idx + a;
   uint32_t* o_pred = A.pred + a;
   // ---- step-1 retain, members, the key range per strand
-  const uint32_t q0 = A.q_id[a], t0 = A.t_id[a];
+  const uint32_t r0 = PERM ? A.perm[a] : a;
+  const uint32_t q0 = A.q_id[r0], t0 = A.t_id[r0];
   const bool self_ok = A.keep_self || q0 != t0;
   uint32_t member_mask = 0, strand_mask = 0, extra_mask = 0;
   {
@@ -486,12 +545,12 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     for (int g = 0; g < ER; g += H) {
       if ((uint32_t)g * NT >= n) continue;  // (block-uniform; `continue`, not `break`: the loop must unroll -- its arrays are registers)
       uint8_t stv[H], av[H], mv[H];
-      uint32_t qv[H], blv[H];
+      uint32_t qv[H], blv[H], ixv[H];
       double idv[H];
       const bool need_bl = !A.alive_in && (A.min_block != 0 || !A.identity);
 #pragma unroll
       for (int e = 0; e < H; ++e) {
-        const uint32_t i = rec_index(g + e);
+        const uint32_t i = ixv[e] = rec_index(g + e);
         stv[e] = c_st[i];
         qv[e] = c_qs[i];
         av[e] = c_alive ? c_alive[i] : (uint8_t)1;
@@ -503,6 +562,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       for (int e = 0; e < H; ++e) {
         const uint32_t li = (uint32_t)tid + (uint32_t)(g + e) * NT;
         if (li >= n) continue;
+        const uint32_t gi = PERM ? ixv[e] : a + li;  // the record's own index
         bool alive;
         if (A.alive_in) {
           alive = av[e] != 0;
@@ -517,7 +577,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         strand_mask |= st << (g + e);
         if (alive) {
           alive_mask |= 1u << (g + e);
-          if (fst[2] == NONE) fst[2] = a + li;
+          fst[2] = gi < fst[2] ? gi : fst[2];
           if (member) {
             member_mask |= 1u << (g + e);
 #pragma unroll
@@ -526,7 +586,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
                 ++n_mem[s2];
                 kmin[s2] = qv[e] < kmin[s2] ? qv[e] : kmin[s2];
                 kmax[s2] = qv[e] > kmax[s2] ? qv[e] : kmax[s2];
-                if (fst[s2] == NONE) fst[s2] = a + li;
+                fst[s2] = gi < fst[s2] ? gi : fst[s2];
               }
           }
         }
@@ -605,12 +665,13 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       const uint32_t r = block_excl_sum<NT>(x ? 1u : 0u, ws, &tot);
       if (x) {
         const uint32_t p = m + done + r;
-        const uint32_t qs = c_qs[li], qe = c_qe[li], ts = c_ts[li], te = c_te[li];
+        const uint32_t ri = PERM ? A.perm[a + li] : li;
+        const uint32_t qs = c_qs[ri], qe = c_qe[ri], ts = c_ts[ri], te = c_te[ri];
         o_qs[p] = qs;
         o_qe[p] = qe;
         o_ts[p] = ts;
         o_te[p] = te;
-        o_idx[p] = (a + li) | (((strand_mask >> e) & 1u) << 31);
+        o_idx[p] = (PERM ? ri : a + li) | (((strand_mask >> e) & 1u) << 31);
         degenerate |= qs >= qe || ts >= te;
       }
       done += tot;
@@ -763,9 +824,11 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
 #pragma unroll
     for (int g = 0; g < ER; g += H) {
       if ((uint32_t)g * NT >= n) continue;
-      uint32_t qv[H];
+      uint32_t qv[H], ixv[H];
 #pragma unroll
-      for (int e = 0; e < H; ++e) qv[e] = c_qs[rec_index(g + e)];
+      for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
+#pragma unroll
+      for (int e = 0; e < H; ++e) qv[e] = c_qs[ixv[e]];
 #pragma unroll
       for (int e = 0; e < H; ++e)
         if ((batch_mask >> (g + e)) & 1u) {
@@ -773,7 +836,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
           const uint32_t fb = fine_of((strand_mask >> (g + e)) & 1u, qv[e], shift, first, &cb);
           const uint32_t pos = atomicAdd(&cnt[fb], 1u);
           K[pos] = qv[e];
-          I[pos] = (uint16_t)(t_sc + (uint32_t)(g + e) * NT);
+          I[pos] = (IT)(PERM ? ixv[e] : t_sc + (uint32_t)(g + e) * NT);
           slotw[(g + e) / 2] |= pos << (16 * ((g + e) & 1));
         }
       asm volatile("" ::: "memory");
@@ -784,15 +847,21 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     {
       // order inside the buckets: final position = bucket begin + the bucket's elements that order before by (key, index).
       // The thread's ES slots advance together (one round trip of LDS reads per step, not one per slot and step).
-      // (the slot's record index and its rank share a word: index << 16 | rank, rank 0xffff = an empty slot)
-      uint32_t rk[ES], rp[ES];
+      // (!PERM: the slot's record index and its rank share a word, index << 16 | rank; rank 0xffff = an empty slot)
+      uint32_t rk[ES], rp[ES], ri[PERM ? ES : 1];
       static_assert(CAP < 0xffff, "ranks are 16 bits wide");
       const uint32_t t_rk = fresh_tid();
 #pragma unroll
       for (int e = 0; e < ES; ++e) {
         const uint32_t pos = t_rk + (uint32_t)e * NT;
         rk[e] = pos < mb ? K[pos] : 0u;
-        rp[e] = ((pos < mb ? (uint32_t)I[pos] : 0u) << 16) | 0xffffu;
+        const uint32_t ix = pos < mb ? (uint32_t)I[pos] : 0u;
+        if constexpr (PERM) {
+          ri[e] = ix;
+          rp[e] = 0xffffu;
+        } else {
+          rp[e] = (ix << 16) | 0xffffu;
+        }
       }
       auto count_half = [&](auto off_c) {
         constexpr int OFF = decltype(off_c)::value, HS = ES / 2;
@@ -815,8 +884,10 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
           for (int e = 0; e < HS; ++e) {
             const uint32_t x = lo[e] + it;
             if (x < hi[e]) {
-              const uint32_t kx = K[x], lx = I[x];
-              rp[OFF + e] += (kx < rk[OFF + e] || (kx == rk[OFF + e] && lx < (rp[OFF + e] >> 16))) ? 1u : 0u;
+              const uint32_t kx = K[x], lx = (uint32_t)I[x];
+              uint32_t mine;
+              if constexpr (PERM) mine = ri[OFF + e]; else mine = rp[OFF + e] >> 16;
+              rp[OFF + e] += (kx < rk[OFF + e] || (kx == rk[OFF + e] && lx < mine)) ? 1u : 0u;
             }
           }
         }
@@ -829,7 +900,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         if ((rp[e] & 0xffffu) != 0xffffu) {
           const uint32_t r = rp[e] & 0xffffu;
           K[r] = rk[e];
-          I[r] = (uint16_t)(rp[e] >> 16);
+          if constexpr (PERM) I[r] = ri[e]; else I[r] = (uint16_t)(rp[e] >> 16);
           RR[t_rk + (uint32_t)e * NT] = (uint16_t)r;
         }
     }
@@ -842,7 +913,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       const uint32_t p = t_out + (uint32_t)e * NT;
       if (p < mb) {
         o_qs[base + p] = K[p];
-        o_idx[base + p] = a + (uint32_t)I[p];
+        o_idx[base + p] = PERM ? (uint32_t)I[p] : a + (uint32_t)I[p];
         o_pred[base + p] = NONE;
       }
     }
@@ -1318,15 +1389,15 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
   PT_STAMP(9);
 }
 
-template <int NT, int ES, int ER, int NBK, int NBIN>
+template <int NT, int ES, int ER, int NBK, int NBIN, bool PERM>
 __global__ __launch_bounds__(NT) void pair_sort_kernel(PairSortArgs A) {
-  __shared__ __attribute__((aligned(16))) char raw[pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN>()];
-  pair_sort_body<NT, ES, ER, NBK, NBIN>(A, A.list[blockIdx.x], raw);
+  __shared__ __attribute__((aligned(16))) char raw[pair_sort_lds_bytes<NT, ES, ER, NBK, NBIN, PERM>()];
+  pair_sort_body<NT, ES, ER, NBK, NBIN, PERM>(A, A.list[blockIdx.x], raw);
 }
 // The two largest size classes in one launch: the few very long runs first (they last longest), the others fill the chip
 // beside them (launched on their own the long runs keep a handful of CUs busy and the rest of the chip waits).
-constexpr size_t PAIR_BIG_LDS = pair_sort_lds_bytes<1024, 16, 32, 4096, 1024>() > pair_sort_xl_lds_bytes<1024, 8, 4096>()
-                                    ? pair_sort_lds_bytes<1024, 16, 32, 4096, 1024>()
+constexpr size_t PAIR_BIG_LDS = pair_sort_lds_bytes<1024, 16, 32, 4096, 1024, false>() > pair_sort_xl_lds_bytes<1024, 8, 4096>()
+                                    ? pair_sort_lds_bytes<1024, 16, 32, 4096, 1024, false>()
                                     : pair_sort_xl_lds_bytes<1024, 8, 4096>();
 static_assert(PAIR_BIG_LDS <= 160 * 1024, "LDS of a CU");
 __global__ __launch_bounds__(1024) void pair_sort_big_kernel(PairSortArgs A, const uint32_t* __restrict__ list_xl, uint32_t n_xl) {
@@ -1334,7 +1405,7 @@ __global__ __launch_bounds__(1024) void pair_sort_big_kernel(PairSortArgs A, con
   if (blockIdx.x < n_xl)
     pair_sort_xl_body<1024, 8, 4096>(A, list_xl[blockIdx.x], raw);
   else
-    pair_sort_body<1024, 16, 32, 4096, 1024>(A, A.list[blockIdx.x - n_xl], raw);
+    pair_sort_body<1024, 16, 32, 4096, 1024, false>(A, A.list[blockIdx.x - n_xl], raw);
 }
 
 // ---- pair_finish ----------------------------------------------------------------------------------------------------
@@ -1352,7 +1423,7 @@ struct PairFinishArgs {
   uint32_t* chain;
   int scaffolds_only;
   uint64_t gap;
-  const uint64_t* fp_thr;
+  uint64_t max_dev;  // largest deviation from a chain's diagonal that the inversion capture accepts (pair_max_deviation)
   PairCounters* C;
 };
 
@@ -1540,7 +1611,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     const uint32_t* __restrict__ c_qe = in_lds ? l_qe : A.f_qe + a;
     const uint32_t* __restrict__ c_ts = in_lds ? l_ts : A.f_ts + a;
     const uint32_t* __restrict__ c_pm = in_lds ? l_pm : A.f_pm + a;
-    const uint64_t gap = A.gap, max_dev = A.fp_thr[0];
+    const uint64_t gap = A.gap, max_dev = A.max_dev;
     for (uint32_t p = m_plus + tid; p < M; p += NT) {
       const uint32_t iw = A.s_idx[a + p];
       if (p >= m && (iw >> 31) == 0) continue;  // an alive non-member on the '+' strand
@@ -1655,8 +1726,7 @@ __global__ __launch_bounds__(EW) void pair_rank_count_kernel(uint32_t n_runs, co
   rank1[k] = r;
   if (mine != ~0ull) atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
 }
-__global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, const PairSum* __restrict__ sum,
-                                                             uint32_t* __restrict__ base_out) {
+__global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, const uint64_t* __restrict__ key, PairSum* sum) {
   const uint32_t k = blockIdx.x * (EW / 64) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (k >= n_runs) return;
   const int lane = threadIdx.x & 63;
@@ -1666,16 +1736,12 @@ __global__ __launch_bounds__(EW) void pair_base_count_kernel(uint32_t n_runs, co
     for (uint32_t j = lane; j < n_runs; j += 64) b += key[j] < mine ? sum[j].n_kept : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
-  if (lane == 0) base_out[k] = b;  // (a separate array: the sums are still being read by other wavefronts)
-}
-__global__ __launch_bounds__(EW) void pair_base_store_kernel(uint32_t n_runs, const uint32_t* __restrict__ base_in, PairSum* __restrict__ sum) {
-  const uint32_t k = blockIdx.x * EW + threadIdx.x;
-  if (k < n_runs) sum[k].base = base_in[k];
+  if (lane == 0) sum[k].base = b;  // (a word of its own: the other wavefronts read n_kept)
 }
 // Few pairs (the usual case for a small input): no sort at all -- a pair's place among the keys is a count, and its base is
 // the sum of the kept chains of the pairs whose key is smaller; one work-group, O(pairs^2) compares from LDS.
-constexpr int NUMBER_SMALL = 2048;
-__global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, PairSum* __restrict__ sum,
+constexpr int NUMBER_SMALL = 512;
+__global__ __launch_bounds__(512) void pair_number_small_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, PairSum* __restrict__ sum,
                                                                  PairTable gl_first, const uint32_t* __restrict__ seq_genome_last,
                                                                  PairTable gp2_first, const uint32_t* __restrict__ seq_genome_two,
                                                                  const PairCounters* __restrict__ C) {
@@ -1683,11 +1749,11 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
   __shared__ uint32_t kept[NUMBER_SMALL];
   const int tid = threadIdx.x;
   if (C->flags & PF_FALLBACK) return;  // (the sums were not written)
-  uint64_t k1[NUMBER_SMALL / 1024];
-  uint32_t r1[NUMBER_SMALL / 1024];
+  uint64_t k1[1];
+  uint32_t r1[1];
 #pragma unroll
-  for (int u = 0; u < NUMBER_SMALL / 1024; ++u) {
-    const uint32_t k = (uint32_t)tid + (uint32_t)u * 1024u;
+  for (int u = 0; u < 1; ++u) {
+    const uint32_t k = (uint32_t)tid + (uint32_t)u * 512u;
     uint64_t x = ~0ull;
     if (k < n_runs && sum[k].n_pass)
       x = ((uint64_t)pair_get(gl_first, seq_genome_last[info[k].q], seq_genome_last[info[k].t]) << 32) | sum[k].minmem;
@@ -1699,10 +1765,11 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < NUMBER_SMALL / 1024; ++u) {
-    const uint32_t k = (uint32_t)tid + (uint32_t)u * 1024u;
+  for (int u = 0; u < 1; ++u) {
+    const uint32_t k = (uint32_t)tid + (uint32_t)u * 512u;
     uint32_t r = 0;
     if (k < n_runs && k1[u] != ~0ull) {
+#pragma unroll 8
       for (uint32_t j = 0; j < n_runs; ++j) r += key[j] < k1[u] ? 1u : 0u;  // (the keys of pairs with chains are distinct)
       atomicMin(pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]), r);
     }
@@ -1711,8 +1778,8 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
   __threadfence();
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < NUMBER_SMALL / 1024; ++u) {
-    const uint32_t k = (uint32_t)tid + (uint32_t)u * 1024u;
+  for (int u = 0; u < 1; ++u) {
+    const uint32_t k = (uint32_t)tid + (uint32_t)u * 512u;
     if (k < n_runs && k1[u] != ~0ull) {
       uint32_t* slot = pair_slot(gp2_first, seq_genome_two[info[k].q], seq_genome_two[info[k].t]);
       k1[u] = ((uint64_t)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | r1[u];
@@ -1720,17 +1787,18 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < NUMBER_SMALL / 1024; ++u) {
-    const uint32_t k = (uint32_t)tid + (uint32_t)u * 1024u;
+  for (int u = 0; u < 1; ++u) {
+    const uint32_t k = (uint32_t)tid + (uint32_t)u * 512u;
     if (k < n_runs) key[k] = k1[u];
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < NUMBER_SMALL / 1024; ++u) {
-    const uint32_t k = (uint32_t)tid + (uint32_t)u * 1024u;
+  for (int u = 0; u < 1; ++u) {
+    const uint32_t k = (uint32_t)tid + (uint32_t)u * 512u;
     if (k < n_runs) {
       uint32_t b = 0;
       if (k1[u] != ~0ull)
+#pragma unroll 8
         for (uint32_t j = 0; j < n_runs; ++j) b += key[j] < k1[u] ? kept[j] : 0u;
       sum[k].base = b;
     }
@@ -1738,17 +1806,45 @@ __global__ __launch_bounds__(1024) void pair_number_small_kernel(uint32_t n_runs
 }
 // chain numbers: pair-local -> global (records of pairs without kept chains hold zeros)
 __global__ __launch_bounds__(EW) void pair_renumber_kernel(uint32_t n_runs, const PairRun* __restrict__ runs, const PairSum* __restrict__ sum,
-                                                           uint32_t* __restrict__ chain, const PairCounters* __restrict__ C) {
+                                                           uint32_t* __restrict__ chain, const PairCounters* __restrict__ C,
+                                                           const uint32_t* __restrict__ perm) {
   if (C->flags & PF_FALLBACK) return;
   for (uint32_t k = blockIdx.x; k < n_runs; k += gridDim.x) {
     const uint32_t base = sum[k].base;
     if (base == 0 || sum[k].n_kept == 0) continue;
     const uint32_t a = runs[k].a, n = runs[k].n;
-    for (uint32_t li = threadIdx.x; li < n; li += EW) {
-      const uint32_t c = chain[a + li];
-      if (c) chain[a + li] = c + base;
+    for (uint32_t l0 = 0; l0 < n; l0 += EW * 4) {
+      uint32_t i[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t li = l0 + (uint32_t)u * EW + threadIdx.x;
+        i[u] = li < n ? (perm ? perm[a + li] : a + li) : NONE;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = i[u] != NONE ? chain[i[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c[u]) chain[i[u]] = c[u] + base;
     }
   }
+}
+
+// The inversion capture's floating-point test as an integer threshold: (u64)(deviation as f64 / SQRT_2) <= gap is monotone in the
+// deviation, so it holds exactly up to a largest one, found by bisection with the same IEEE operations (one conversion, one
+// correctly rounded division, one truncation: the host's are the device's; swg_scaffold_internal.h has the device version).
+uint64_t pair_max_deviation(uint64_t gap) {
+  auto ok = [&](uint64_t deviation) {
+    const double pd = (double)deviation / 1.4142135623730951;
+    const uint64_t perp = pd >= 18446744073709551616.0 ? ~0ull : (uint64_t)pd;
+    return perp <= gap;
+  };
+  uint64_t lo = 0, hi = ~0ull;
+  if (ok(hi)) return hi;
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (ok(mid)) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 
 bool pair_path_wanted() {
@@ -1781,23 +1877,45 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   hipStream_t st = ctx->stream;
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
   const swg_arena_mark mark0 = swg_arena_save(ctx);
-  // ---- runs
+  // ---- the pairs: runs of the input (large inputs, grouped by pair as an aligner writes them), or through a hash table
+  // (small inputs, grouped or not)
+  const bool by_hash = n <= PAIR_HASH_MAX;
   const uint32_t cap = n < 65536u ? n : (n / 16 > 65536u ? n / 16 : 65536u);
   uint32_t tsize = 1;
   while (tsize < 2 * cap) tsize <<= 1;
-  PairCounters* C = swg_alloc<PairCounters>(ctx, 1);
-  unsigned long long* bitmap = swg_alloc<unsigned long long>(ctx, (n + 63) / 64 + 1);
-  uint32_t* run_start = swg_alloc<uint32_t>(ctx, cap);
-  unsigned long long* table = swg_alloc<unsigned long long>(ctx, tsize);
+  PairCounters* C = nullptr;
   PairRun* runs = swg_alloc<PairRun>(ctx, cap);
   uint32_t* class_list = swg_alloc<uint32_t>(ctx, (size_t)4 * cap);
-  SWG_CHECK_ARENA(ctx);
-  SWG_HIP(ctx, hipMemsetAsync(C, 0, sizeof(PairCounters), st));
-  SWG_HIP(ctx, hipMemsetAsync(table, 0xff, (size_t)tsize * 8, st));
-  SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, run_start, cap, table, tsize - 1, C));
-  SWG_KERNEL_CHECK(ctx);
-  SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n, cap, run_start, bitmap, runs, class_list, C));
-  SWG_KERNEL_CHECK(ctx);
+  uint32_t* perm = nullptr;
+  if (by_hash) {
+    // one zeroed block: the table's keys, the counts per slot, the counters
+    char* z = static_cast<char*>(swg_arena_alloc(ctx, (size_t)tsize * 12 + sizeof(PairCounters) + 8));
+    uint32_t* slot_of = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* start = swg_alloc<uint32_t>(ctx, tsize);
+    perm = swg_alloc<uint32_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(z);
+    uint32_t* count = reinterpret_cast<uint32_t*>(z + (size_t)tsize * 8);
+    C = reinterpret_cast<PairCounters*>(z + (size_t)tsize * 12);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(z + (size_t)tsize * 12 + sizeof(PairCounters));
+    SWG_HIP(ctx, hipMemsetAsync(z, 0, (size_t)tsize * 12 + sizeof(PairCounters) + 8, st));
+    SWG_LAUNCH(ctx, "pair_hash", pair_hash_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, r->q_id, r->t_id, table, tsize - 1, count, slot_of));
+    SWG_LAUNCH(ctx, "pair_slots", pair_slots_kernel<<<(tsize + 255) / 256, 256, 0, st>>>(tsize, count, start, runs, class_list, cap, C, cursor));
+    SWG_LAUNCH(ctx, "pair_perm", pair_perm_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, slot_of, start, perm));
+    SWG_KERNEL_CHECK(ctx);
+  } else {
+    C = swg_alloc<PairCounters>(ctx, 1);
+    unsigned long long* bitmap = swg_alloc<unsigned long long>(ctx, (n + 63) / 64 + 1);
+    uint32_t* run_start = swg_alloc<uint32_t>(ctx, cap);
+    unsigned long long* table = swg_alloc<unsigned long long>(ctx, tsize);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(C, 0, sizeof(PairCounters), st));
+    SWG_HIP(ctx, hipMemsetAsync(table, 0xff, (size_t)tsize * 8, st));
+    SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, run_start, cap, table, tsize - 1, C));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n, cap, run_start, bitmap, runs, class_list, C));
+    SWG_KERNEL_CHECK(ctx);
+  }
   uint64_t h[4];
   static_assert(sizeof(PairCounters) >= 32, "the first four words are read back");
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(C), h, 3));
@@ -1808,7 +1926,9 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     swg_arena_restore(ctx, mark0);
     return SWG_OK;
   }
-  if (dbg) fprintf(stderr, "[swg] pair path: %u pairs (%u / %u / %u / %u by size class)\n", n_runs, ncls[0], ncls[1], ncls[2], ncls[3]);
+  if (dbg)
+    fprintf(stderr, "[swg] pair path: %u pairs (%u / %u / %u / %u by size class)%s\n", n_runs, ncls[0], ncls[1], ncls[2], ncls[3],
+            by_hash ? ", found through the hash table" : "");
   // ---- scratch, addressed by the pair's offset in the input
   uint8_t* code = swg_alloc<uint8_t>(ctx, n);
   uint32_t* s_qs = swg_alloc<uint32_t>(ctx, n);
@@ -1829,15 +1949,12 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SpecBlock* chunks = swg_alloc<SpecBlock>(ctx, cap_chunks);
   const uint32_t cap_long = n / LABEL_CAP_ELEMS + 1;
   uint32_t* long_list = swg_alloc<uint32_t>(ctx, cap_long);
-  uint64_t* fp_thr = swg_alloc<uint64_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
   PairTable gl_first, gp2_first;
   SWG_TRY(pair_table_make(ctx, r->n_genome_last, n_runs, &gl_first));
   SWG_TRY(pair_table_make(ctx, r->n_genome_two, n_runs, &gp2_first));
   SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, (size_t)n * sizeof(uint32_t), st));
   SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
-  SWG_LAUNCH(ctx, "fp_thresholds", fp_thresholds_kernel<<<1, 64, 0, st>>>(cfg->scaffold_gap, cfg->scaffold_max_deviation, fp_thr));
-  SWG_KERNEL_CHECK(ctx);
   PairSortArgs SA{};
   SA.q_id = r->q_id; SA.t_id = r->t_id; SA.q_start = r->q_start; SA.q_end = r->q_end; SA.t_start = r->t_start; SA.t_end = r->t_end;
   SA.matches = r->matches; SA.block_len = r->block_len; SA.identity = r->identity; SA.strand = r->strand;
@@ -1846,21 +1963,36 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.check_degenerate = sweep_assumed_identity ? 1 : 0;
   SA.max_gap = cfg->scaffold_gap;
   SA.runs = runs;
+  SA.perm = perm;
   SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = s_m; SA.s_b = s_b; SA.s_idx = s_idx; SA.pred = pred;
   SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
-  if (ncls[2] + ncls[3]) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
-    SA.list = class_list + (size_t)2 * cap;
-    SWG_LAUNCH_N(ctx, "pair_sort_big", 0, pair_sort_big_kernel<<<ncls[2] + ncls[3], 1024, 0, st>>>(SA, class_list + (size_t)3 * cap, ncls[3]));
-    SWG_KERNEL_CHECK(ctx);
-  }
-  for (int c = 1; c >= 0; --c) {
-    if (!ncls[c]) continue;
-    SA.list = class_list + (size_t)c * cap;
-    if (c == 0)
-      SWG_LAUNCH_N(ctx, "pair_sort_s", 0, pair_sort_kernel<64, 16, 16, 256, 64><<<ncls[c], 64, 0, st>>>(SA));
-    else
-      SWG_LAUNCH_N(ctx, "pair_sort_m", 0, pair_sort_kernel<256, 16, 16, 1024, 64><<<ncls[c], 256, 0, st>>>(SA));
-    SWG_KERNEL_CHECK(ctx);
+  if (by_hash) {
+    for (int c = 2; c >= 0; --c) {
+      if (!ncls[c]) continue;
+      SA.list = class_list + (size_t)c * cap;
+      if (c == 0)
+        SWG_LAUNCH_N(ctx, "pair_sort_ps", 0, pair_sort_kernel<64, 16, 16, 256, 64, true><<<ncls[c], 64, 0, st>>>(SA));
+      else if (c == 1)
+        SWG_LAUNCH_N(ctx, "pair_sort_pm", 0, pair_sort_kernel<256, 16, 16, 1024, 64, true><<<ncls[c], 256, 0, st>>>(SA));
+      else
+        SWG_LAUNCH_N(ctx, "pair_sort_pl", 0, pair_sort_kernel<1024, 8, 32, 2048, 1024, true><<<ncls[c], 1024, 0, st>>>(SA));
+      SWG_KERNEL_CHECK(ctx);
+    }
+  } else {
+    if (ncls[2] + ncls[3]) {  // the longest pairs first: their chunks open the list the walk's work-groups draw from
+      SA.list = class_list + (size_t)2 * cap;
+      SWG_LAUNCH_N(ctx, "pair_sort_big", 0, pair_sort_big_kernel<<<ncls[2] + ncls[3], 1024, 0, st>>>(SA, class_list + (size_t)3 * cap, ncls[3]));
+      SWG_KERNEL_CHECK(ctx);
+    }
+    for (int c = 1; c >= 0; --c) {
+      if (!ncls[c]) continue;
+      SA.list = class_list + (size_t)c * cap;
+      if (c == 0)
+        SWG_LAUNCH_N(ctx, "pair_sort_s", 0, pair_sort_kernel<64, 16, 16, 256, 64, false><<<ncls[c], 64, 0, st>>>(SA));
+      else
+        SWG_LAUNCH_N(ctx, "pair_sort_m", 0, pair_sort_kernel<256, 16, 16, 1024, 64, false><<<ncls[c], 256, 0, st>>>(SA));
+      SWG_KERNEL_CHECK(ctx);
+    }
   }
   SWG_TRY(pair_walk_launch(ctx, cap_chunks, &C->n_chunks, chunks, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred));
   const bool long_possible = ncls[2] + ncls[3] > 0;  // (a chunk of LABEL_CAP_ELEMS members needs a pair of at least as many)
@@ -1874,7 +2006,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   FA.s_qs = s_qs; FA.s_qe = s_qe; FA.s_ts = s_ts; FA.s_te = s_te; FA.s_idx = s_idx; FA.hd = hd; FA.ok_head = ok_head; FA.rec = head_rec;
   FA.head_num = pred;
   FA.f_qs = s_m; FA.f_qe = s_b; FA.f_ts = reinterpret_cast<uint32_t*>(bps); FA.f_pm = reinterpret_cast<uint32_t*>(bps) + n;
-  FA.status = status_out; FA.chain = chain_out; FA.scaffolds_only = cfg->scaffolds_only; FA.gap = cfg->scaffold_gap; FA.fp_thr = fp_thr; FA.C = C;
+  FA.status = status_out; FA.chain = chain_out; FA.scaffolds_only = cfg->scaffolds_only; FA.gap = cfg->scaffold_gap; FA.max_dev = pair_max_deviation(cfg->scaffold_gap); FA.C = C;
   for (int c = 0; c < 4; ++c) {
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
@@ -1887,7 +2019,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   // ---- chain_N bases
   if (n_runs <= (uint32_t)NUMBER_SMALL) {
-    SWG_LAUNCH(ctx, "pair_number", pair_number_small_kernel<<<1, 1024, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, gp2_first,
+    SWG_LAUNCH(ctx, "pair_number", pair_number_small_kernel<<<1, 512, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, gp2_first,
                                                                      r->seq_genome_two, C));
     SWG_KERNEL_CHECK(ctx);
   } else if (n_runs <= 32768u) {
@@ -1899,8 +2031,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     SWG_LAUNCH(ctx, "pair_number", pair_key1_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, key, val, C));
     SWG_LAUNCH(ctx, "pair_number", pair_rank_count_kernel<<<wb, EW, 0, st>>>(n_runs, key, info, r->seq_genome_two, gp2_first, rank1));
     SWG_LAUNCH(ctx, "pair_number", pair_key2_kernel<<<rb, EW, 0, st>>>(n_runs, info, sum, rank1, r->seq_genome_two, gp2_first, key, val, C));
-    SWG_LAUNCH(ctx, "pair_number", pair_base_count_kernel<<<wb, EW, 0, st>>>(n_runs, key, sum, rank1));
-    SWG_LAUNCH(ctx, "pair_number", pair_base_store_kernel<<<rb, EW, 0, st>>>(n_runs, rank1, sum));
+    SWG_LAUNCH(ctx, "pair_number", pair_base_count_kernel<<<wb, EW, 0, st>>>(n_runs, key, sum));
     SWG_KERNEL_CHECK(ctx);
   } else {
     uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
@@ -1927,7 +2058,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   {
     const unsigned gb = n_runs < (unsigned)ctx->num_cu * 16 ? n_runs : (unsigned)ctx->num_cu * 16;
-    SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C));
+    SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C, perm));
     SWG_KERNEL_CHECK(ctx);
   }
   // ---- the flags found on the device, and the statistics

@@ -144,10 +144,31 @@ def test_numbering_over_genome_and_chromosome_pairs(sw):
         run_both(sw, rec, cfg)
 
 
-def test_not_grouped_and_degenerate_inputs_take_the_global_path(sw):
+def test_small_inputs_need_not_be_grouped(sw):
+    """Up to 65,536 records the pairs are found through a hash table: any record order takes the pair path."""
     rng = np.random.default_rng(8)
-    rec = gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.0)
-    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # pairs interleaved
+    for n in (7, 300, 5_000, 60_000):
+        rec = gen.random_records(rng, n, n_genomes=3, chrs_per_genome=2, span=200_000, zero_frac=0.0)
+        for cfg in ({"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, {}):
+            run_both(sw, rec, cfg)
+        run_both(sw, rec, {"scaffold_gap": 2_000, "min_scaffold_length": 0, "min_identity": 0.8}, derived_identity=True)
+    # one pair of 30,000 records (the 1024-thread shape, several LDS batches) among small ones, records shuffled
+    big = gen.random_records(rng, 30_000, n_genomes=1, chrs_per_genome=1, span=30_000 * 2_000, minus_frac=0.3, zero_frac=0.0, self_frac=0.0)
+    big.qname = ["x#1#c"] * 30_000
+    big.tname = ["y#1#c"] * 30_000
+    small = gen.random_records(rng, 20_000, n_genomes=3, chrs_per_genome=2, span=300_000, zero_frac=0.0)
+    rec = orc.Records(big.qname + small.qname, big.tname + small.tname, *[np.concatenate([getattr(big, c), getattr(small, c)])
+                                                                         for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
+                      np.arange(50_000, dtype=np.uint64))
+    rec = permute(rec, rng.permutation(50_000))
+    for cfg in ({"scaffold_gap": 4_000, "min_scaffold_length": 3_000}, {"scaffold_gap": 700, "min_scaffold_length": 0}):
+        run_both(sw, rec, cfg)
+
+
+def test_large_ungrouped_and_degenerate_inputs_take_the_global_path(sw):
+    rng = np.random.default_rng(9)
+    rec = gen.random_records(rng, 70_000, n_genomes=3, chrs_per_genome=2, span=2_000_000, zero_frac=0.0)
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # pairs interleaved, too many for the table
     rec = pair_major(gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.02), rng)
     run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # zero-length records
 
