@@ -254,3 +254,33 @@ def test_reversed_interval_does_not_depend_on_unrelated_records():
     rec2.rank = np.arange(len(rec2.qname), dtype=np.uint64)
     more, _ = f.filter_columns(sw.pack_records(gen.records_to_meta(rec2)))
     assert np.array_equal(more[:len(base)], base)
+
+
+def test_reversed_interval_against_the_oracle():
+    """The same malformed record held to the ORACLE.  The reference keeps a reversed interval in an unlimited sweep: its End event
+    precedes its Begin event, `remove` finds nothing, and the interval entered later is never taken out of the tree again
+    (src/plane_sweep_exact.rs:300-349) -- the oracle restates that.  The device evaluates the sweep in closed form over
+    [start, end) and counts start >= end as "never active": it DROPS the record.  That is the one documented divergence
+    (DESIGN.md section 4); this test pins both halves of it -- the reversed record's two answers, and that every other record of
+    the input gets the oracle's answer, with and without the scaffold stage behind the sweep."""
+    import sweepga_amd as sw
+    from tests import gen, orc
+    rng = np.random.default_rng(91)
+    rec = gen.random_records(rng, 3_000, n_genomes=3, chrs_per_genome=2, span=300_000, zero_frac=0.0)
+    k = 1234
+    rec.qs[k], rec.qe[k] = rec.qe[k] + 10, rec.qs[k]   # reversed on the query axis
+    others = np.arange(len(rec)) != k
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    # many:many, no scaffolding: the unlimited sweep alone decides
+    st, ch = sw.PafFilter(sw.FilterConfig(scaffold_gap=0)).filter_columns(packed)
+    ost, och = orc.apply_filters(orc.Config(scaffold_gap=0), rec)
+    assert ost[k] == 3 and st[k] == 0            # reference: kept (unassigned); device: dropped
+    assert np.array_equal(st[others], ost[others]) and np.array_equal(ch[others], och[others])
+    # 1:1 on both axes: the reversed record stays in the reference's tree from its start on with the score of a wrapped
+    # length (2^64 - 10: it outranks everything) -- the records of ITS sweep segments may differ, every other segment must not
+    st, _ = sw.PafFilter(sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=0)).filter_columns(packed)
+    ost, _ = orc.apply_filters(orc.Config(mapping_filter_mode=orc.ONE_TO_ONE, scaffold_gap=0), rec)
+    genome = lambda name: name.rsplit("#", 1)[0]
+    seg = np.array([(q == rec.qname[k] and genome(t) == genome(rec.tname[k])) or (t == rec.tname[k] and genome(q) == genome(rec.qname[k]))
+                    for q, t in zip(rec.qname, rec.tname)])
+    assert np.array_equal(st[~seg], ost[~seg])

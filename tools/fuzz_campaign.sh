@@ -18,15 +18,19 @@ run () {  # name, env assignments..., -- command
   echo "$name rc=$? $(tail -1 gpurun_out/${TAG}_$name.log | cut -c1-200)"
 }
 mkdir -p gpurun_out
+# Round 5: the scaffold stage of inputs of up to 65,536 records (every case of fuzz_gpu.py) runs pair-resident (swg_pair.hip)
+# unless SWG_GROUP_FUSED=0: `gpu` / `gpu_wide` are that path, the legs with knobs of the global-sort stage switch it off.
 run gpu        X=1                python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 11
-run gpu_deep   SWG_CHAIN_DEEP=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 12
-run gpu_pairs  SWG_SORT_PAIRS=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 13
-run gpu_bits8  SWG_SORT_BITS8=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 14
-run gpu_old    SWG_CHAIN_OLD=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 18
-run gpu_nodrop SWG_SORT_DROP=0    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 20
-run gpu_slots  SWG_SLOTS=1        python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 21
-run gpu_deepg  SWG_CHAIN_DEEP=1 SWG_CAND_GENERIC=1 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 22
-run gpu_deepw  SWG_CHAIN_DEEP=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 23 --wide-gaps
+run gpu_wide   X=1                python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 26 --wide-gaps
+run gpu_global SWG_GROUP_FUSED=0  python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 27
+run gpu_deep   SWG_GROUP_FUSED=0 SWG_CHAIN_DEEP=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 12
+run gpu_pairs  SWG_GROUP_FUSED=0 SWG_SORT_PAIRS=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 13
+run gpu_bits8  SWG_GROUP_FUSED=0 SWG_SORT_BITS8=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 14
+run gpu_old    SWG_GROUP_FUSED=0 SWG_CHAIN_OLD=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 18
+run gpu_nodrop SWG_GROUP_FUSED=0 SWG_SORT_DROP=0    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 20
+run gpu_slots  SWG_GROUP_FUSED=0 SWG_SLOTS=1        python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 21
+run gpu_deepg  SWG_GROUP_FUSED=0 SWG_CHAIN_DEEP=1 SWG_CAND_GENERIC=1 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 22
+run gpu_deepw  SWG_GROUP_FUSED=0 SWG_CHAIN_DEEP=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 23 --wide-gaps
 run gpu_stream SWG_STREAM_CHUNK=700 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 19 --grouped
 run seams      X=1                python3 tests/fuzz/fuzz_seams.py --minutes $MIN --seed 15
 run cli        X=1                python3 tests/fuzz/fuzz_cli.py --minutes $MIN --seed 16
