@@ -21,6 +21,7 @@
 // sort key, no compaction), and the host reads back twice: the run list's size, and at the end the statistics together with
 // the "cannot be done here" flag (a unit too long for one chunk, a pair too dense for the LDS batches, a degenerate retained
 // record under an unlimited mapping sweep) that sends the call to the global-sort path instead.
+#include <cmath>
 #include <type_traits>
 
 #include "swg_scaffold_internal.h"
@@ -60,6 +61,17 @@ struct PairCounters {
   unsigned long long n_alive, n_members, n_heads, n_kept, n_out;
 };
 
+// A work-group barrier that orders LDS accesses only.  __syncthreads() is a work-group fence in front of s_barrier -- it waits
+// for EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)): for the global stores a phase has just issued to be
+// acknowledged, and for loads requested ahead for the next phase.  The pair kernels only ever exchange data through LDS, so
+// their barriers wait for the LDS queue alone (s_waitcnt lgkmcnt(0), gfx9 encoding) and global memory traffic stays in flight.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- block-wide scans (NT threads; ws: NT / 64 words of LDS scratch per call site) ---------------------------------
 template <int NT>
 __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* ws, uint32_t* total) {
@@ -74,9 +86,9 @@ __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t* ws, uin
     *total = __shfl(inc, 63, 64);
     return inc - v;
   }
-  __syncthreads();
+  lds_barrier();
   if (lane == 63) ws[w] = inc;
-  __syncthreads();
+  lds_barrier();
   uint32_t off = 0, tot = 0;
 #pragma unroll
   for (int k = 0; k < NT / 64; ++k) {
@@ -103,9 +115,9 @@ __device__ __forceinline__ uint64_t block_excl_max(uint64_t v, uint64_t* ws, uin
     *total = __shfl(inc, 63, 64);
     return ex;
   }
-  __syncthreads();
+  lds_barrier();
   if (lane == 63) ws[w] = inc;
-  __syncthreads();
+  lds_barrier();
   uint64_t off = 0, tot = 0;
 #pragma unroll
   for (int k = 0; k < NT / 64; ++k) {
@@ -121,9 +133,9 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* ws) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (NT == 64) return v;
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   uint32_t tot = 0;
 #pragma unroll
   for (int k = 0; k < NT / 64; ++k) tot += ws[k];
@@ -496,7 +508,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
   if (tid == 0) sh_bad = 0;
   for (int c = tid; c < NCELL; c += NT) cellmin[c] = NONE;
   for (int b = tid; b < NBIN; b += NT) bins[b] = 0;
-  __syncthreads();
+  lds_barrier();
   // the thread's records: e-th record = tid + e * NT; every loop over them runs in groups of H whose loads go out together
   // (the pair's columns as work-group-uniform pointers indexed by a 32-bit offset inside the pair: one scalar base and one
   // 32-bit register per load, not a 64-bit address pair per column and record)
@@ -627,7 +639,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         if (fst[s2] != NONE) atomicMin(&sh_first[s2], fst[s2]);
     }
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t m_plus = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[0]);
   const uint32_t m = m_plus + (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[1]);
   const uint32_t n_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_cnt[2]), M = m + n_x;
@@ -713,7 +725,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         if ((member_mask >> (g + e)) & 1u) atomicAdd(&bins[bucket_of(BM, (strand_mask >> (g + e)) & 1u, qv[e])], 1u);
       asm volatile("" ::: "memory");
     }
-    __syncthreads();
+    lds_barrier();
     {  // bins -> their exclusive prefix sums
       constexpr int PERB = (NBIN + NT - 1) / NT;
       uint32_t c[PERB], sum = 0, tot;
@@ -723,7 +735,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         sum += c[j];
       }
       uint32_t off = block_excl_sum<NT>(sum, ws, &tot);
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < PERB; ++j)
         if (tid * PERB + j < NBIN) {
@@ -731,7 +743,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
           off += c[j];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {  // greedy: a batch takes as many bins as fit (a binary search in the prefix sums per batch)
       uint32_t nb = 0, lo = 0;
       b_lo[0] = 0;
@@ -753,7 +765,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       }
       sh_nb = nb;
     }
-    __syncthreads();
+    lds_barrier();
     if (sh_bad) {
       if (tid == 0) atomicOr(&A.C->flags, PF_FALLBACK);
       return;
@@ -767,14 +779,18 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     // (the thread index and the run length pass through an empty asm: every batch re-reads the thread's records, and a
     // compiler that sees the same loads in every iteration lifts all of them out of the loop -- some 200 registers held
     // across it.  Not the pointers themselves: behind an asm they lose their address space and the loads become flat ones.)
-    asm volatile("" : "+v"(tid_v), "+s"(n_v), "+v"(member_mask), "+v"(strand_mask));
+    {
+      uint32_t n_l = n_v;  // (through a vector register: an "s" constraint on a value the compiler may hold in either file is fragile)
+      asm volatile("" : "+v"(tid_v), "+v"(n_l), "+v"(member_mask), "+v"(strand_mask));
+      n_v = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_l);
+    }
     const uint32_t bin_lo = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt]) : 0u;
     const uint32_t bin_hi = n_batches > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)b_lo[bt + 1]) : (uint32_t)NBIN;
     int shift = 0;
     while ((((bin_hi - bin_lo) << 12) >> shift) > (uint32_t)NBK) ++shift;
     const uint32_t first = (bin_lo << 12) >> shift;
     for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
-    __syncthreads();
+    lds_barrier();
     // ---- count: the batch's members among the thread's records, and their buckets
     uint32_t batch_mask = 0;
 #pragma unroll
@@ -795,7 +811,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         }
       asm volatile("" ::: "memory");  // (keeps the next group's loads behind this group's work: registers)
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(3);
     uint32_t mb;
     {
@@ -815,7 +831,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         off += c[j];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- scatter (unordered inside a bucket; cnt[b] ends as the bucket's end); the thread remembers where each key went
     uint32_t slotw[ER / 2];  // two 16-bit slots per word: first the slot of the key, after the ranking the record's final place
 #pragma unroll
@@ -841,7 +857,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         }
       asm volatile("" ::: "memory");
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(4);
     const uint32_t plus_here = m_plus > base ? (m_plus - base < mb ? m_plus - base : mb) : 0u;  // '+' members of the batch
     {
@@ -884,17 +900,21 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
           for (int e = 0; e < HS; ++e) {
             const uint32_t x = lo[e] + it;
             if (x < hi[e]) {
-              const uint32_t kx = K[x], lx = (uint32_t)I[x];
-              uint32_t mine;
-              if constexpr (PERM) mine = ri[OFF + e]; else mine = rp[OFF + e] >> 16;
-              rp[OFF + e] += (kx < rk[OFF + e] || (kx == rk[OFF + e] && lx < mine)) ? 1u : 0u;
+              const uint32_t kx = K[x];
+              uint32_t before = kx < rk[OFF + e] ? 1u : 0u;
+              if (kx == rk[OFF + e]) {  // (a tie on the key: only then is the other element's index read)
+                uint32_t mine;
+                if constexpr (PERM) mine = ri[OFF + e]; else mine = rp[OFF + e] >> 16;
+                before = (uint32_t)I[x] < mine ? 1u : 0u;
+              }
+              rp[OFF + e] += before;
             }
           }
         }
       };
       count_half(std::integral_constant<int, 0>{});
       count_half(std::integral_constant<int, ES / 2>{});
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int e = 0; e < ES; ++e)
         if ((rp[e] & 0xffffu) != 0xffffu) {
@@ -904,7 +924,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
           RR[t_rk + (uint32_t)e * NT] = (uint16_t)r;
         }
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(5);
     // ---- the sorted q_start and record index out; where the thread's own records went
     const uint32_t t_out = fresh_tid();
@@ -926,7 +946,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       slotw[j] = r0 | (r1 << 16);
       asm volatile("" : "+v"(slotw[j]));  // (kept packed: the compiler would otherwise carry the 32 places as 32 registers)
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(6);
     // ---- the other columns, transposed through LDS: coalesced reads in input order land at their sorted position, coalesced
     // writes follow
@@ -951,7 +971,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
         if (g + H < ER) put_group(g + H, w);
         asm volatile("" ::: "memory");
       }
-      __syncthreads();
+      lds_barrier();
       const uint32_t t_st = fresh_tid();
 #pragma unroll
       for (int e = 0; e < ES; ++e) {
@@ -967,12 +987,12 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
       for (int e = 0; e < ES; ++e) degenerate |= (uint32_t)tid * ES + e < mb && qs_r[e] >= qe_r[e];
       unit_starts<NT, ES>(qs_r, qe_r, mb, base, m_plus, A.max_gap, ws64, cellmin, &carry_max);  // (its barriers also close the column)
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(7);
     column(c_ts, o_ts);
     uint32_t ts_r[ES];
     read_block<ES>(K, ts_r);
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(8);
     column(c_te, o_te);
     {
@@ -981,14 +1001,14 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
 #pragma unroll
       for (int e = 0; e < ES; ++e) degenerate |= (uint32_t)tid * ES + e < mb && ts_r[e] >= te_r[e];
     }
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(9);
     column(c_m, o_m);
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(10);
     column(c_b, o_b);
     base += mb;
-    __syncthreads();
+    lds_barrier();
     PT_STAMP(11);
   }
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
@@ -1424,8 +1444,13 @@ struct PairFinishArgs {
   int scaffolds_only;
   uint64_t gap;
   uint64_t max_dev;  // largest deviation from a chain's diagonal that the inversion capture accepts (pair_max_deviation)
+  uint64_t rescue_d;   // scaffold_max_deviation (0: no rescue)
+  uint64_t max_s2;     // largest q^2 + t^2 whose truncated square root is <= rescue_d (pair_max_dist2)
+  uint32_t* anum;      // by member position: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
+  uint32_t* pm;        // by member position: running maximum of q_end inside the strand (the labelling's head array, free by then)
   PairCounters* C;
 };
+constexpr uint32_t NEVER = 0xfffffffeu;  // a member of a chain that passed the span / identity filter but not the scaffold sweep
 
 // plane_sweep_both with no limit on either axis (plane_sweep_exact.rs:268-461 with mappings_to_keep = usize::MAX): a sweep
 // over at most one interval returns it; otherwise an interval survives iff it is ever in the tree at a mark_good call, i.e.
@@ -1519,7 +1544,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
       for (int u = 0; u < U; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         const uint32_t r = row_base + (uint32_t)((ex >> (16 * u)) & 0xffffu);
-        if (p < m) A.head_num[a + p] = kept[u] ? r : NONE;  // (every position: the members look their head's entry up)
+        if (p < m) A.head_num[a + p] = kept[u] ? r : (ok[u] ? NEVER : NONE);  // (every position: the members look their head's entry up)
         if (kept[u] && p < m_plus) {  // '+' chains come first: r is the chain's slot in the list
           A.f_qs[a + r] = hr[u].qs;
           A.f_qe[a + r] = hr[u].qe;
@@ -1581,11 +1606,16 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-      if (p < m && r[u] != NONE) {
-        A.chain[idx[u]] = local_number(r[u], h[u] - a >= m_plus);
+      uint32_t an = 0;
+      if (p < m && r[u] < NEVER) {
+        an = local_number(r[u], h[u] - a >= m_plus);
+        A.chain[idx[u]] = an;
         A.status[idx[u]] = SWG_ST_SCAFFOLD;
         ++out;
+      } else if (r[u] == NEVER) {
+        an = NEVER;
       }
+      if (A.rescue_d && p < m) A.anum[a + p] = an;
     }
   }
   // ---- inversion capture (paf_filter.rs:535-597): a '-' record that is not an anchor joins the first kept '+' chain of its
@@ -1644,8 +1674,76 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         }
       }
       if (best != NONE) {
-        A.chain[i] = local_number(best, false);
+        const uint32_t num = local_number(best, false);
+        A.chain[i] = num;
         A.status[i] = SWG_ST_SCAFFOLD;
+        if (A.rescue_d && p < m) A.anum[a + p] = num;  // an anchor from here on, whatever it was
+        ++out;
+      }
+    }
+  }
+  // ---- rescue (paf_filter.rs:599-732): a record that is neither an anchor nor a member of a swept-away chain is kept when an
+  // anchor of its pair lies within rescue_d of it -- |q centre difference| <= D and floor(sqrt(dq^2 + dt^2)) <= D -- and takes
+  // the chain of the lowest-index such anchor (the reference iterates a HashSet: any in-range anchor; the oracle fixes the
+  // same instance).  The anchors are members, and the members stand sorted by q_start inside each strand: an anchor in range
+  // starts no later than qc + D and ends no earlier than qc - D, so the scan runs from the first member whose running maximum
+  // of ends reaches qc - D to the last one that starts by qc + D.  (Only without alive non-members, i.e. no mapping sweep.)
+  if (!A.scaffolds_only && A.rescue_d && M == m) {
+    __syncthreads();  // every anchor's number is in anum; the head array is free
+    uint64_t carry = 0;
+    for (uint32_t p0 = 0; p0 < m; p0 += NT) {
+      const uint32_t p = p0 + tid;
+      const uint64_t v = p < m ? (((uint64_t)(p >= m_plus ? 1u : 0u) << 32) | A.s_qe[a + p]) : 0ull;
+      uint64_t tot;
+      uint64_t ex = block_excl_max<NT>(v, ws64, &tot);
+      ex = ex > carry ? ex : carry;
+      if (p < m) A.pm[a + p] = (uint32_t)(v > ex ? v : ex);  // (a '-' position's composite outranks every '+' one)
+      carry = tot > carry ? tot : carry;
+    }
+    __syncthreads();
+    const uint64_t D = A.rescue_d, max_s2 = A.max_s2;
+    for (uint32_t p = tid; p < m; p += NT) {
+      if (A.anum[a + p] != 0) continue;
+      const uint64_t qs = A.s_qs[a + p], qe = A.s_qe[a + p], ts = A.s_ts[a + p], te = A.s_te[a + p];
+      const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
+      const uint64_t lo_q = qc > D ? qc - D : 0ull, hi_q = qc + D < qc ? ~0ull : qc + D;
+      uint32_t best_idx = NONE, best_num = 0;
+#pragma unroll 1
+      for (int reg = 0; reg < 2; ++reg) {
+        const uint32_t rb = reg ? m_plus : 0u, re = reg ? m : m_plus;
+        uint32_t l = rb, r = re;  // first member of the strand that starts beyond qc + D
+        while (l < r) {
+          const uint32_t mid = l + ((r - l) >> 1);
+          if ((uint64_t)A.s_qs[a + mid] <= hi_q) l = mid + 1; else r = mid;
+        }
+        const uint32_t hi = l;
+        l = rb;
+        r = hi;  // first member whose running maximum of ends reaches qc - D
+        while (l < r) {
+          const uint32_t mid = l + ((r - l) >> 1);
+          if ((uint64_t)A.pm[a + mid] < lo_q) l = mid + 1; else r = mid;
+        }
+        for (uint32_t j = l; j < hi; ++j) {
+          const uint32_t an = A.anum[a + j];
+          if (an == 0 || an == NEVER) continue;
+          const uint64_t aq = ((uint64_t)A.s_qs[a + j] + (uint64_t)A.s_qe[a + j]) / 2;
+          const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+          if (q_diff > D) continue;
+          const uint64_t at = ((uint64_t)A.s_ts[a + j] + (uint64_t)A.s_te[a + j]) / 2;
+          const uint64_t t_diff = tc > at ? tc - at : at - tc;
+          if (q_diff * q_diff + t_diff * t_diff <= max_s2) {  // (wrapping sum, as the reference's)
+            const uint32_t ix = A.s_idx[a + j];
+            if (ix < best_idx) {
+              best_idx = ix;
+              best_num = an;
+            }
+          }
+        }
+      }
+      if (best_idx != NONE) {
+        const uint32_t i = A.s_idx[a + p];
+        A.status[i] = SWG_ST_RESCUED;
+        A.chain[i] = best_num;
         ++out;
       }
     }
@@ -1847,6 +1945,23 @@ uint64_t pair_max_deviation(uint64_t gap) {
   return lo;
 }
 
+// ... and the rescue's: (u64)sqrt((q^2 + t^2) as f64) <= D holds exactly up to a largest sum (conversion, correctly rounded square
+// root and truncation never decrease)
+uint64_t pair_max_dist2(uint64_t D) {
+  auto ok = [&](uint64_t s2) {
+    const double dd = std::sqrt((double)s2);
+    const uint64_t dist = dd >= 18446744073709551616.0 ? ~0ull : (uint64_t)dd;
+    return dist <= D;
+  };
+  uint64_t lo = 0, hi = ~0ull;
+  if (ok(hi)) return hi;
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (ok(mid)) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 bool pair_path_wanted() {
   static const int knob = getenv("SWG_GROUP_FUSED") ? atoi(getenv("SWG_GROUP_FUSED")) : -1;
   return knob != 0;
@@ -1872,7 +1987,10 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     kt = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
   }
   if (kq != SWG_K_INF || kt != SWG_K_INF) return SWG_OK;
-  if (!cfg->scaffolds_only && cfg->scaffold_max_deviation != 0) return SWG_OK;
+  // a rescue distance: only when every alive record is a member (no mapping sweep in front: the rescue's anchors are then all
+  // in the pair's sorted order)
+  const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
+  if (rescue && (alive || member)) return SWG_OK;
   const uint32_t n = (uint32_t)n64;
   hipStream_t st = ctx->stream;
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
@@ -1943,6 +2061,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   uint8_t* ok_head = swg_alloc<uint8_t>(ctx, n);
   unsigned long long* bps = swg_alloc<unsigned long long>(ctx, n);
   HeadRec* head_rec = swg_alloc<HeadRec>(ctx, n);
+  uint32_t* anum = rescue ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   PairInfo* info = swg_alloc<PairInfo>(ctx, n_runs);
   PairSum* sum = swg_alloc<PairSum>(ctx, n_runs);
   const uint32_t cap_chunks = n / PAIR_CELL + 2 * n_runs + 16;
@@ -2007,6 +2126,10 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   FA.head_num = pred;
   FA.f_qs = s_m; FA.f_qe = s_b; FA.f_ts = reinterpret_cast<uint32_t*>(bps); FA.f_pm = reinterpret_cast<uint32_t*>(bps) + n;
   FA.status = status_out; FA.chain = chain_out; FA.scaffolds_only = cfg->scaffolds_only; FA.gap = cfg->scaffold_gap; FA.max_dev = pair_max_deviation(cfg->scaffold_gap); FA.C = C;
+  FA.rescue_d = rescue ? cfg->scaffold_max_deviation : 0;
+  FA.max_s2 = rescue ? pair_max_dist2(cfg->scaffold_max_deviation) : 0;
+  FA.anum = anum;
+  FA.pm = hd;
   for (int c = 0; c < 4; ++c) {
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;

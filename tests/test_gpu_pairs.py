@@ -77,6 +77,9 @@ CONFIGS = [
     {"scaffold_gap": 20_000, "min_scaffold_length": 0},
     {"scaffold_gap": 1_000, "min_scaffold_length": 500, "min_scaffold_identity": 0.85},
     {"scaffold_gap": 100_000, "min_scaffold_length": 5_000, "min_identity": 0.8, "min_block_length": 300},
+    {"scaffold_gap": 3_000, "min_scaffold_length": 4_000, "scaffold_max_deviation": 5_000},        # rescue around the anchors
+    {"scaffold_gap": 1_000, "min_scaffold_length": 1_500, "scaffold_max_deviation": 100_000},
+    {"scaffold_max_deviation": 20_000},
 ]
 
 
@@ -110,6 +113,7 @@ def test_one_pair_per_size_class(sw):
                                                                        for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
                           np.arange(len(rec) + len(r), dtype=np.uint64))
     for cfg in ({},   # gap 50 kb over records 3 kb apart: every pair is one unit, the long ones walked in speculative blocks
+                {"scaffold_gap": 5_000, "min_scaffold_length": 12_000, "scaffold_max_deviation": 9_000},
                 {"scaffold_gap": 5_000, "min_scaffold_length": 3_000}, {"scaffold_gap": 400, "min_scaffold_length": 0},
                 {"scaffold_gap": 9_000, "min_scaffold_length": 20_000, "min_scaffold_identity": 0.8}):
         run_both(sw, rec, cfg)
