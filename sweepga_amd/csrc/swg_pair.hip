@@ -1446,11 +1446,135 @@ struct PairFinishArgs {
   uint64_t max_dev;  // largest deviation from a chain's diagonal that the inversion capture accepts (pair_max_deviation)
   uint64_t rescue_d;   // scaffold_max_deviation (0: no rescue)
   uint64_t max_s2;     // largest q^2 + t^2 whose truncated square root is <= rescue_d (pair_max_dist2)
+  const uint8_t* kept_in;      // a scaffold sweep with limits ran over the chain table (pair_chains_kernel): kept flag per chain ...
+  const uint32_t* chain_base;  // ... whose entries of pair k start here, in the pair's all_chains order; np[2k], np[2k + 1]: the pair's
+  const uint32_t* np;          //     passing chains per strand
   uint32_t* anum;      // by member position: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
   uint32_t* pm;        // by member position: running maximum of q_end inside the strand (the labelling's head array, free by then)
   PairCounters* C;
 };
 constexpr uint32_t NEVER = 0xfffffffeu;  // a member of a chain that passed the span / identity filter but not the scaffold sweep
+
+// A scaffold sweep with limits (--scaffold-filter 1:1 ...): the chains that pass the span / identity filter go into one chain
+// table for the whole input -- every pair a contiguous stretch in ITS all_chains order (the '+' or the '-' chains first, as the
+// (query, target, strand) groups appear in the metadata; the stretches themselves in whatever order the atomics hand them out:
+// the sweep's segments are the pairs and its index tie-break only ever compares chains of one pair) -- and plane_sweep_both
+// runs over that table on the sweep kernels (swg_sweep_axis).  pair_finish then reads the kept flags back per pair.
+struct PairChainArgs {
+  const PairRun* runs;
+  const uint32_t* list;
+  const PairInfo* info;
+  const uint8_t* ok_head;
+  const HeadRec* rec;
+  uint32_t *T_qs, *T_qe, *T_ts, *T_te;
+  double* T_wid;
+  uint64_t* T_seg;
+  uint32_t *chain_base, *np;
+  unsigned long long* totals;  // [0] chains in the table, [1] largest coordinate
+  const PairCounters* C;
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
+  constexpr int U = 4;
+  __shared__ uint32_t ws[NT / 64 + 1];
+  __shared__ uint64_t ws64[NT / 64 + 1];
+  __shared__ uint32_t sh_base;
+  const int tid = threadIdx.x;
+  if (A.C->flags & PF_FALLBACK) return;
+  const uint32_t rk = A.list[blockIdx.x];
+  const PairRun run = A.runs[rk];
+  const PairInfo pi = A.info[rk];
+  const uint32_t a = run.a, m = pi.m, m_plus = pi.m_plus;
+  uint32_t c0 = 0, c1 = 0, mx = 0;
+  for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
+    uint8_t ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      if (ok[u]) {
+        const HeadRec hr = A.rec[a + p];
+        if (p < m_plus) ++c0; else ++c1;
+        const uint32_t e = hr.qe > hr.te ? hr.qe : hr.te;
+        mx = e > mx ? e : mx;
+      }
+    }
+  }
+  const uint32_t nP = block_sum<NT>(c0, ws), nM = block_sum<NT>(c1, ws);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if ((tid & 63) == 0 && mx) atomicMax(&A.totals[1], (unsigned long long)mx);
+  if (tid == 0) {
+    const uint32_t cb = nP + nM ? (uint32_t)atomicAdd(&A.totals[0], (unsigned long long)(nP + nM)) : 0u;
+    sh_base = cb;
+    A.chain_base[rk] = cb;
+    A.np[2 * rk] = nP;
+    A.np[2 * rk + 1] = nM;
+  }
+  __syncthreads();
+  if (nP + nM == 0) return;
+  const uint32_t cb = sh_base;
+  const bool plus_first = pi.first_mem[0] < pi.first_mem[1];
+  uint32_t before = 0;
+  for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
+    uint8_t ok[U];
+    uint64_t packed = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
+      packed |= (uint64_t)(ok[u] ? 1u : 0u) << (16 * u);
+    }
+    uint64_t inc = packed;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    uint64_t off = 0, tot = 0;
+    if (NT == 64) {
+      tot = __shfl(inc, 63, 64);
+    } else {
+      __syncthreads();
+      if (lane == 63) ws64[w] = inc;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) {
+        const uint64_t x = ws64[k];
+        off += k < w ? x : 0ull;
+        tot += x;
+      }
+    }
+    const uint64_t ex = off + inc - packed;
+    uint32_t row_base = before;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+      if (ok[u]) {
+        const uint32_t c_pos = row_base + (uint32_t)((ex >> (16 * u)) & 0xffffu);  // rank in position order ('+' first)
+        const uint32_t c_all = plus_first ? c_pos : (p >= m_plus ? c_pos - nP : c_pos + nM);
+        const HeadRec hr = A.rec[a + p];
+        const uint32_t c = cb + c_all;
+        A.T_qs[c] = hr.qs;
+        A.T_qe[c] = hr.qe;
+        A.T_ts[c] = hr.ts;
+        A.T_te[c] = hr.te;
+        A.T_wid[c] = hr.wid;
+        A.T_seg[c] = rk;
+      }
+      row_base += (uint32_t)((tot >> (16 * u)) & 0xffffu);
+    }
+    before = row_base;
+  }
+}
 
 // plane_sweep_both with no limit on either axis (plane_sweep_exact.rs:268-461 with mappings_to_keep = usize::MAX): a sweep
 // over at most one interval returns it; otherwise an interval survives iff it is ever in the tree at a mark_good call, i.e.
@@ -1458,12 +1582,17 @@ constexpr uint32_t NEVER = 0xfffffffeu;  // a member of a chain that passed the 
 // kept, and only a pair that holds a chain with an empty span needs the counts: the sweep below first ranks the chains under
 // "both spans positive", and runs once more under the exact rule if it met such a chain.
 // KP: the kept '+' chains of a pair that are staged in LDS for the inversion capture (a longer list is searched in memory).
-template <int NT, int KP>
+template <int NT, int KP, int MAXM>  // MAXM: members of a pair of this size class at most
 __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   constexpr int U = 4;  // positions per thread and round: their loads are requested together
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint64_t ws64[NT / 64 + 1];
-  __shared__ uint32_t l_qs[KP], l_qe[KP], l_ts[KP], l_pm[KP];
+  __shared__ uint32_t l_all[4 * KP];  // the kept '+' chains for the inversion capture, then the rescue's staged members
+  uint32_t* const l_qs = l_all;
+  uint32_t* const l_qe = l_all + KP;
+  uint32_t* const l_ts = l_all + 2 * KP;
+  uint32_t* const l_pm = l_all + 3 * KP;
+  __shared__ uint32_t sh_xr[2 * (MAXM / (KP / 4) + 2)];  // the rescue's tiles: their stretch of the other strand
   const int tid = threadIdx.x;
   // a pair_sort work-group gave the call up (a pair too dense for the LDS batches ...): nothing written from here on is used
   // (the host sees the same flag and runs the global-sort stage)
@@ -1485,8 +1614,37 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   // 1 = the rule above with the counts of the first sweep.
   uint32_t n_pass0 = 0, n_pass1 = 0, n_q = 0, n_deg = 0, n_kept = 0, kP = 0;
   bool all_q = false, all_t = false;
+  const bool given = A.kept_in != nullptr;  // the kept flags come from the sweep over the chain table
+  const uint32_t g_nP = given ? A.np[2 * rk] : 0u, g_nM = given ? A.np[2 * rk + 1] : 0u, g_cb = given ? A.chain_base[rk] : 0u;
+  const bool plus_first0 = pi.first_mem[0] < pi.first_mem[1];
+  // exclusive prefix of four 16-bit counters (one per row of the round) over the threads, and the rows' totals
+  auto row_scan = [&](uint64_t packed, uint64_t* tot_out) -> uint64_t {
+    uint64_t inc = packed;
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    uint64_t off = 0, tot = 0;
+    if (NT == 64) {
+      tot = __shfl(inc, 63, 64);
+    } else {
+      lds_barrier();
+      if (lane == 63) ws64[w] = inc;
+      lds_barrier();
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) {
+        const uint64_t x = ws64[k];
+        off += k < w ? x : 0ull;
+        tot += x;
+      }
+    }
+    *tot_out = tot;
+    return off + inc - packed;
+  };
   auto sweep = [&](const bool exact) {
-    uint32_t kept_before = 0, c0 = 0, c1 = 0, cq = 0, cd = 0, cp = 0;
+    uint32_t kept_before = 0, ok_before = 0, c0 = 0, c1 = 0, cq = 0, cd = 0, cp = 0;
     for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
       uint8_t ok[U];
       HeadRec hr[U];
@@ -1500,45 +1658,46 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         if (ok[u]) hr[u] = A.rec[a + p];
       }
-      uint64_t packed = 0;  // four 16-bit counters: kept chains of row u among the threads before this one
       bool kept[U];
+      if (given) {  // a chain's flag sits at its place in the pair's stretch of the chain table: its rank among the passing chains
+        uint64_t okp = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) okp |= (uint64_t)(ok[u] ? 1u : 0u) << (16 * u);
+        uint64_t tot_ok;
+        const uint64_t ex_ok = row_scan(okp, &tot_ok);
+        uint32_t rb = ok_before;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+          kept[u] = false;
+          if (ok[u]) {
+            const uint32_t c_pos = rb + (uint32_t)((ex_ok >> (16 * u)) & 0xffffu);
+            const uint32_t c_all = plus_first0 ? c_pos : (p >= m_plus ? c_pos - g_nP : c_pos + g_nM);
+            kept[u] = A.kept_in[g_cb + c_all] != 0;
+          }
+          rb += (uint32_t)((tot_ok >> (16 * u)) & 0xffffu);
+        }
+        ok_before = rb;
+      }
+      uint64_t packed = 0;  // four 16-bit counters: kept chains of row u among the threads before this one
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-        kept[u] = false;
+        if (!given) kept[u] = false;
         if (ok[u]) {
           const bool hq = hr[u].qs < hr[u].qe, ht = hr[u].ts < hr[u].te;
-          kept[u] = exact ? (all_q || hq) && (all_t || ht) : hq && ht;
+          if (!given) kept[u] = exact ? (all_q || hq) && (all_t || ht) : hq && ht;
           if (p < m_plus) ++c0; else ++c1;
           cq += hq ? 1u : 0u;
-          cd += (hq && ht) ? 0u : 1u;
+          cd += (given || (hq && ht)) ? 0u : 1u;
           cp += (kept[u] && p < m_plus) ? 1u : 0u;
         }
         packed |= (uint64_t)(kept[u] ? 1u : 0u) << (16 * u);
       }
       // one scan for the four rows (NT <= 1024 < 2^16)
-      uint64_t inc = packed;
-      const int lane = tid & 63, w = tid >> 6;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-      }
-      uint64_t off = 0, tot = 0;
-      if (NT == 64) {
-        tot = __shfl(inc, 63, 64);
-      } else {
-        __syncthreads();
-        if (lane == 63) ws64[w] = inc;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NT / 64; ++k) {
-          const uint64_t x = ws64[k];
-          off += k < w ? x : 0ull;
-          tot += x;
-        }
-      }
-      const uint64_t ex = off + inc - packed;
+      uint64_t tot;
+      const uint64_t ex = row_scan(packed, &tot);
+      (void)0;
       uint32_t row_base = kept_before;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1702,49 +1861,219 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     }
     __syncthreads();
     const uint64_t D = A.rescue_d, max_s2 = A.max_s2;
-    for (uint32_t p = tid; p < m; p += NT) {
-      if (A.anum[a + p] != 0) continue;
-      const uint64_t qs = A.s_qs[a + p], qe = A.s_qe[a + p], ts = A.s_ts[a + p], te = A.s_te[a + p];
-      const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
-      const uint64_t lo_q = qc > D ? qc - D : 0ull, hi_q = qc + D < qc ? ~0ull : qc + D;
-      uint32_t best_idx = NONE, best_num = 0;
-#pragma unroll 1
-      for (int reg = 0; reg < 2; ++reg) {
-        const uint32_t rb = reg ? m_plus : 0u, re = reg ? m : m_plus;
-        uint32_t l = rb, r = re;  // first member of the strand that starts beyond qc + D
-        while (l < r) {
-          const uint32_t mid = l + ((r - l) >> 1);
-          if ((uint64_t)A.s_qs[a + mid] <= hi_q) l = mid + 1; else r = mid;
-        }
-        const uint32_t hi = l;
-        l = rb;
-        r = hi;  // first member whose running maximum of ends reaches qc - D
-        while (l < r) {
-          const uint32_t mid = l + ((r - l) >> 1);
-          if ((uint64_t)A.pm[a + mid] < lo_q) l = mid + 1; else r = mid;
-        }
-        for (uint32_t j = l; j < hi; ++j) {
-          const uint32_t an = A.anum[a + j];
-          if (an == 0 || an == NEVER) continue;
-          const uint64_t aq = ((uint64_t)A.s_qs[a + j] + (uint64_t)A.s_qe[a + j]) / 2;
-          const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
-          if (q_diff > D) continue;
-          const uint64_t at = ((uint64_t)A.s_ts[a + j] + (uint64_t)A.s_te[a + j]) / 2;
-          const uint64_t t_diff = tc > at ? tc - at : at - tc;
-          if (q_diff * q_diff + t_diff * t_diff <= max_s2) {  // (wrapping sum, as the reference's)
-            const uint32_t ix = A.s_idx[a + j];
-            if (ix < best_idx) {
-              best_idx = ix;
-              best_num = an;
-            }
+    // one candidate against the members [rb, re) of one strand, everything read from memory (the exact, slow form: used where
+    // a window reaches beyond what a tile has staged)
+    auto scan_memory = [&](uint32_t rb, uint32_t re, uint64_t qc, uint64_t tc, uint64_t lo_q, uint64_t hi_q, uint32_t& best_idx, uint32_t& best_num) {
+      uint32_t l = rb, r = re;  // first member of the strand that starts beyond qc + D
+      while (l < r) {
+        const uint32_t mid = l + ((r - l) >> 1);
+        if ((uint64_t)A.s_qs[a + mid] <= hi_q) l = mid + 1; else r = mid;
+      }
+      const uint32_t hi = l;
+      l = rb;
+      r = hi;  // first member whose running maximum of ends reaches qc - D
+      while (l < r) {
+        const uint32_t mid = l + ((r - l) >> 1);
+        if ((uint64_t)A.pm[a + mid] < lo_q) l = mid + 1; else r = mid;
+      }
+      for (uint32_t j = l; j < hi; ++j) {
+        const uint32_t an = A.anum[a + j];
+        if (an == 0 || an == NEVER) continue;
+        const uint64_t aq = ((uint64_t)A.s_qs[a + j] + (uint64_t)A.s_qe[a + j]) / 2;
+        const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+        if (q_diff > D) continue;
+        const uint64_t at = ((uint64_t)A.s_ts[a + j] + (uint64_t)A.s_te[a + j]) / 2;
+        const uint64_t t_diff = tc > at ? tc - at : at - tc;
+        if (q_diff * q_diff + t_diff * t_diff <= max_s2) {  // (wrapping sum, as the reference's)
+          const uint32_t ix = A.s_idx[a + j];
+          if (ix < best_idx) {
+            best_idx = ix;
+            best_num = an;
           }
         }
       }
-      if (best_idx != NONE) {
-        const uint32_t i = A.s_idx[a + p];
-        A.status[i] = SWG_ST_RESCUED;
-        A.chain[i] = best_num;
-        ++out;
+    };
+    // Tiles of T consecutive candidates of one strand.  Their windows overlap almost entirely, so the members a tile can reach
+    // are staged in LDS once -- the tile itself with a halo of H members on either side, and the stretch of the OTHER strand's
+    // members that the tile's q range (+- D) can reach -- and every candidate then searches and scans LDS.  A window that
+    // reaches the edge of what is staged (a very long member far to the left, a dense stretch) is evaluated from memory.
+    constexpr uint32_t T = KP / 4, H = KP / 16, SO = T + 2 * H, SX = KP / 8, STG = SO + SX;
+    static_assert(6 * STG <= 4 * KP, "staged members fit the LDS block");
+    uint32_t* const g_qs = l_all;
+    uint32_t* const g_pm = l_all + STG;
+    uint32_t* const g_qc = l_all + 2 * STG;
+    uint32_t* const g_tc = l_all + 3 * STG;
+    uint32_t* const g_an = l_all + 4 * STG;
+    uint32_t* const g_ix = l_all + 5 * STG;
+    auto stage = [&](uint32_t e, uint32_t j) {  // member j of the pair -> staged entry e
+      const uint32_t qs = A.s_qs[a + j], qe = A.s_qe[a + j], ts = A.s_ts[a + j], te = A.s_te[a + j];
+      g_qs[e] = qs;
+      g_pm[e] = A.pm[a + j];
+      g_qc[e] = (uint32_t)(((uint64_t)qs + qe) / 2);
+      g_tc[e] = (uint32_t)(((uint64_t)ts + te) / 2);
+      g_an[e] = A.anum[a + j];
+      g_ix[e] = A.s_idx[a + j];
+    };
+    // one candidate against the staged entries [e0, e1) (sorted by q_start, running maxima of ends in g_pm)
+    auto scan_staged = [&](uint32_t e0, uint32_t e1, uint64_t qc, uint64_t tc, uint64_t lo_q, uint64_t hi_q, uint32_t& best_idx, uint32_t& best_num,
+                           bool* at_left, bool* at_right) {
+      uint32_t l = e0, r = e1;
+      while (l < r) {
+        const uint32_t mid = l + ((r - l) >> 1);
+        if ((uint64_t)g_qs[mid] <= hi_q) l = mid + 1; else r = mid;
+      }
+      const uint32_t hi = l;
+      *at_right = hi == e1;
+      l = e0;
+      r = hi;
+      while (l < r) {
+        const uint32_t mid = l + ((r - l) >> 1);
+        if ((uint64_t)g_pm[mid] < lo_q) l = mid + 1; else r = mid;
+      }
+      *at_left = l == e0 && e0 < hi;
+      for (uint32_t j = l; j < hi; ++j) {
+        const uint32_t an = g_an[j];
+        if (an == 0 || an == NEVER) continue;
+        const uint64_t aq = g_qc[j];
+        const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+        if (q_diff > D) continue;
+        const uint64_t at = g_tc[j];
+        const uint64_t t_diff = tc > at ? tc - at : at - tc;
+        if (q_diff * q_diff + t_diff * t_diff <= max_s2 && g_ix[j] < best_idx) {
+          best_idx = g_ix[j];
+          best_num = an;
+        }
+      }
+    };
+#pragma unroll 1
+    for (int reg = 0; reg < 2; ++reg) {
+      const uint32_t rb = reg ? m_plus : 0u, re = reg ? m : m_plus;  // the candidates' strand
+      const uint32_t xb = reg ? 0u : m_plus, xe = reg ? m_plus : m;  // the other strand
+      // the other strand's stretch of every tile, one wavefront per tile (64 probes per round of the search), all tiles at once
+      __syncthreads();
+      for (uint32_t ti = (uint32_t)tid >> 6; rb + ti * T < re; ti += NT / 64) {
+        const int lane = tid & 63;
+        const uint32_t t0 = rb + ti * T, t1 = t0 + T < re ? t0 + T : re;
+        uint32_t x0 = xb, x1 = xb;
+        if (xb < xe) {
+          const uint64_t q_low = (uint64_t)A.s_qs[a + t0] > D ? (uint64_t)A.s_qs[a + t0] - D : 0ull;
+          const uint64_t pmx = A.pm[a + t1 - 1];
+          const uint64_t q_high = pmx + D < pmx ? ~0ull : pmx + D;
+          auto wave_first = [&](uint32_t lo, uint32_t hi, auto&& pred) -> uint32_t {  // first index in [lo, hi) with pred (monotone), or hi
+            for (;;) {
+              const uint32_t cnt = hi - lo;
+              if (cnt == 0) return lo;
+              if (cnt <= 64) {
+                const bool t = (uint32_t)lane < cnt && pred(lo + lane);
+                const uint64_t mk = __ballot(t);
+                return mk ? lo + (uint32_t)__builtin_ctzll(mk) : hi;
+              }
+              const uint32_t step = (cnt + 63) / 64;
+              uint32_t pos = lo + ((uint32_t)lane + 1) * step;
+              if (pos > hi) pos = hi;
+              const bool t = pred(pos - 1);
+              const uint64_t mk = __ballot(t);
+              if (!mk) return hi;
+              const uint32_t f = (uint32_t)__builtin_ctzll(mk);
+              const uint32_t nlo = lo + f * step;
+              uint32_t nhi = lo + (f + 1) * step;
+              if (nhi > hi) nhi = hi;
+              lo = nlo;
+              hi = nhi - 1;  // the stretch's last element satisfies pred: the first one that does lies in [nlo, nhi - 1]
+            }
+          };
+          x1 = wave_first(xb, xe, [&](uint32_t j) { return (uint64_t)A.s_qs[a + j] > q_high; });
+          x0 = wave_first(xb, x1, [&](uint32_t j) { return (uint64_t)A.pm[a + j] >= q_low; });
+        }
+        if (lane == 0) {
+          sh_xr[2 * ti] = x0;
+          sh_xr[2 * ti + 1] = x1;
+        }
+      }
+      for (uint32_t t0 = rb; t0 < re; t0 += T) {
+        const uint32_t t1 = t0 + T < re ? t0 + T : re;
+        const uint32_t s0 = t0 - rb > H ? t0 - H : rb, s1 = re - t1 > H ? t1 + H : re;
+        __syncthreads();  // (the previous tile's readers are done with the staged entries)
+        const uint32_t ti = (t0 - rb) / T;
+        const uint32_t x0 = sh_xr[2 * ti], x1 = sh_xr[2 * ti + 1];
+        const bool cross_staged = x1 - x0 <= SX;
+        {  // (every load of the thread's entries requested before the first LDS store)
+          constexpr int SE = (int)((SO + NT - 1) / NT), XE = (int)((SX + NT - 1) / NT);
+          uint32_t vq[SE + XE], ve[SE + XE], vt[SE + XE], vu[SE + XE], vp[SE + XE], va[SE + XE], vi[SE + XE];
+#pragma unroll
+          for (int k = 0; k < SE + XE; ++k) {
+            const bool own = k < SE;
+            const uint32_t e = own ? (uint32_t)tid + (uint32_t)k * NT : (uint32_t)tid + (uint32_t)(k - SE) * NT;
+            const bool in = own ? e < s1 - s0 : (cross_staged && e < x1 - x0);
+            const uint32_t j = a + (in ? (own ? s0 + e : x0 + e) : 0u);
+            vq[k] = A.s_qs[j];
+            ve[k] = A.s_qe[j];
+            vt[k] = A.s_ts[j];
+            vu[k] = A.s_te[j];
+            vp[k] = A.pm[j];
+            va[k] = A.anum[j];
+            vi[k] = A.s_idx[j];
+          }
+#pragma unroll
+          for (int k = 0; k < SE + XE; ++k) {
+            const bool own = k < SE;
+            const uint32_t e = own ? (uint32_t)tid + (uint32_t)k * NT : (uint32_t)tid + (uint32_t)(k - SE) * NT;
+            const bool in = own ? e < s1 - s0 : (cross_staged && e < x1 - x0);
+            if (!in) continue;
+            const uint32_t d = own ? e : SO + e;
+            g_qs[d] = vq[k];
+            g_pm[d] = vp[k];
+            g_qc[d] = (uint32_t)(((uint64_t)vq[k] + ve[k]) / 2);
+            g_tc[d] = (uint32_t)(((uint64_t)vt[k] + vu[k]) / 2);
+            g_an[d] = va[k];
+            g_ix[d] = vi[k];
+          }
+        }
+        __syncthreads();
+        for (uint32_t p = t0 + tid; p < t1; p += NT) {
+          const uint32_t e = p - s0;
+          if (g_an[e] != 0) continue;
+          const uint64_t qc = g_qc[e], tc = g_tc[e];
+          const uint64_t lo_q = qc > D ? qc - D : 0ull, hi_q = qc + D < qc ? ~0ull : qc + D;
+          uint32_t best_idx = NONE, best_num = 0;
+          // own strand: the window lies around the candidate's own place -- a few steps right while members start by qc + D, a few
+          // steps left while the running maximum of ends still reaches qc - D
+          const uint32_t ne = s1 - s0;
+          uint32_t hi = e + 1, lo = e;
+          while (hi < ne && (uint64_t)g_qs[hi] <= hi_q) ++hi;
+          while (lo > 0 && (uint64_t)g_pm[lo - 1] >= lo_q) --lo;
+          const bool at_right = hi == ne, at_left = lo == 0;
+          for (uint32_t j = lo; j < hi; ++j) {
+            const uint32_t an = g_an[j];
+            if (an == 0 || an == NEVER) continue;
+            const uint64_t aq = g_qc[j];
+            const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+            if (q_diff > D) continue;
+            const uint64_t at = g_tc[j];
+            const uint64_t t_diff = tc > at ? tc - at : at - tc;
+            if (q_diff * q_diff + t_diff * t_diff <= max_s2 && g_ix[j] < best_idx) {
+              best_idx = g_ix[j];
+              best_num = an;
+            }
+          }
+          if ((at_left && s0 > rb) || (at_right && s1 < re)) {  // the window may go on beyond the staged members
+            best_idx = NONE;
+            best_num = 0;
+            scan_memory(rb, re, qc, tc, lo_q, hi_q, best_idx, best_num);
+          }
+          if (cross_staged) {
+            bool l2, r2;
+            scan_staged(SO, SO + (x1 - x0), qc, tc, lo_q, hi_q, best_idx, best_num, &l2, &r2);
+          } else {
+            scan_memory(xb, xe, qc, tc, lo_q, hi_q, best_idx, best_num);
+          }
+          if (best_idx != NONE) {
+            const uint32_t i = g_ix[e];
+            A.status[i] = SWG_ST_RESCUED;
+            A.chain[i] = best_num;
+            ++out;
+          }
+        }
       }
     }
   }
@@ -1978,7 +2307,6 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   if (!pair_path_wanted()) return SWG_OK;
   const uint64_t n64 = r->n;
   if (n64 < 2 || n64 >= (uint64_t(1) << 31)) return SWG_OK;
-  // covered here: no limit on either axis of the scaffold sweep (the CLI default), no rescue
   uint64_t kq, kt;
   if (cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_ONE) {
     kq = kt = 1;
@@ -1986,7 +2314,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     kq = cfg->scaffold_max_per_query ? cfg->scaffold_max_per_query : SWG_K_INF;
     kt = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
   }
-  if (kq != SWG_K_INF || kt != SWG_K_INF) return SWG_OK;
+  const bool limited = kq != SWG_K_INF || kt != SWG_K_INF;  // the scaffold sweep has limits: it runs over a chain table
   // a rescue distance: only when every alive record is a member (no mapping sweep in front: the rescue's anchors are then all
   // in the pair's sorted order)
   const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
@@ -2120,7 +2448,45 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
                                   &C->flags, PF_FALLBACK));
   SWG_TRY(pair_label_launch(ctx, cap_chunks, &C->n_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b, cfg->min_scaffold_length,
                             cfg->min_scaffold_identity, hd, ok_head, head_rec, &C->n_heads, long_possible ? cap_long : 0u, &C->n_long, long_list));
+  // ---- a scaffold filter with limits: plane_sweep_both over the chain table of the whole input
+  uint8_t* kept_flags = nullptr;
+  uint32_t *chain_base = nullptr, *np_arr = nullptr;
+  if (limited) {
+    PairChainArgs CA{};
+    CA.runs = runs; CA.info = info; CA.ok_head = ok_head; CA.rec = head_rec; CA.C = C;
+    CA.T_qs = swg_alloc<uint32_t>(ctx, n);
+    CA.T_qe = swg_alloc<uint32_t>(ctx, n);
+    CA.T_ts = swg_alloc<uint32_t>(ctx, n);
+    CA.T_te = swg_alloc<uint32_t>(ctx, n);
+    CA.T_wid = swg_alloc<double>(ctx, n);
+    CA.T_seg = swg_alloc<uint64_t>(ctx, n);
+    CA.chain_base = chain_base = swg_alloc<uint32_t>(ctx, n_runs);
+    CA.np = np_arr = swg_alloc<uint32_t>(ctx, (size_t)2 * n_runs);
+    CA.totals = swg_alloc<unsigned long long>(ctx, 2);
+    kept_flags = swg_alloc<uint8_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(CA.totals, 0, 16, st));
+    for (int c = 0; c < 4; ++c) {
+      if (!ncls[c]) continue;
+      CA.list = class_list + (size_t)c * cap;
+      switch (c) {
+        case 0: SWG_LAUNCH(ctx, "pair_chains_s", pair_chains_kernel<64><<<ncls[c], 64, 0, st>>>(CA)); break;
+        case 1: SWG_LAUNCH(ctx, "pair_chains_m", pair_chains_kernel<256><<<ncls[c], 256, 0, st>>>(CA)); break;
+        default: SWG_LAUNCH(ctx, "pair_chains", pair_chains_kernel<512><<<ncls[c], 512, 0, st>>>(CA)); break;
+      }
+      SWG_KERNEL_CHECK(ctx);
+    }
+    uint64_t ht[2];
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(CA.totals), ht, 2));
+    const uint64_t n_table = ht[0];
+    if (n_table) {
+      const int seg_bits = swg_bits_for(n_runs) ? swg_bits_for(n_runs) : 1, pos_bits = swg_bits_for(ht[1]) ? swg_bits_for(ht[1]) : 1;
+      SWG_TRY(scaffold_sweep_segments(ctx, n_table, CA.T_seg, seg_bits, CA.T_qs, CA.T_qe, CA.T_ts, CA.T_te, CA.T_wid, kq, kt,
+                                      cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, kept_flags));
+    }
+  }
   PairFinishArgs FA{};
+  FA.kept_in = kept_flags; FA.chain_base = chain_base; FA.np = np_arr;
   FA.runs = runs; FA.info = info; FA.sum = sum;
   FA.s_qs = s_qs; FA.s_qe = s_qe; FA.s_ts = s_ts; FA.s_te = s_te; FA.s_idx = s_idx; FA.hd = hd; FA.ok_head = ok_head; FA.rec = head_rec;
   FA.head_num = pred;
@@ -2134,9 +2500,9 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH(ctx, "pair_finish_s", pair_finish_kernel<64, 256><<<ncls[c], 64, 0, st>>>(FA)); break;
-      case 1: SWG_LAUNCH(ctx, "pair_finish_m", pair_finish_kernel<256, 1024><<<ncls[c], 256, 0, st>>>(FA)); break;
-      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096><<<ncls[c], 512, 0, st>>>(FA)); break;
+      case 0: SWG_LAUNCH(ctx, "pair_finish_s", pair_finish_kernel<64, 256, (int)PAIR_S_MAX><<<ncls[c], 64, 0, st>>>(FA)); break;
+      case 1: SWG_LAUNCH(ctx, "pair_finish_m", pair_finish_kernel<256, 1024, (int)PAIR_M_MAX><<<ncls[c], 256, 0, st>>>(FA)); break;
+      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096, (int)PAIR_XL_MAX><<<ncls[c], 512, 0, st>>>(FA)); break;
     }
     SWG_KERNEL_CHECK(ctx);
   }

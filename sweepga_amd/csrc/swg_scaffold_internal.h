@@ -234,6 +234,12 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
                               uint32_t n_g2, int mode, uint64_t max_q, uint64_t max_t, double thr, int scoring,
                               int pos_bits, uint8_t* C_kept, uint32_t* C_num, uint64_t* n_kept_out);
 
+// plane_sweep_both over chains in segments (swg_scaffold_sweep.hip): what scaffold_sweep_and_number runs before the numbering,
+// and what the pair-resident path runs over its own chain table when the scaffold filter has limits.
+int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int seg_bits, const uint32_t* qs, const uint32_t* qe,
+                            const uint32_t* ts, const uint32_t* te, const double* wid, uint64_t kq, uint64_t kt, double thr, int scoring,
+                            int pos_bits, uint8_t* kept);
+
 // The scaffold stage for inputs grouped by chromosome pair (swg_pair.hip): one work-group per pair, the pair's members sorted
 // inside LDS.  *taken = 0: not applicable -- the caller runs the global-sort stage (swg_scaffold_stage's own path).
 int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive, const uint8_t* member,

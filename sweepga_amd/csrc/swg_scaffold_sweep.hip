@@ -117,6 +117,42 @@ __global__ __launch_bounds__(EW) void assign_numbers_runs_kernel(uint64_t nc, co
 }
 }  // namespace
 
+// plane_sweep_both (plane_sweep_exact.rs:436-461) over nc chains in segments (one per chromosome pair; seg[c] < 2^seg_bits),
+// index order inside a segment = the reference's order of the pair's chains.  kept[c] = 1 iff chain c survives both axes.
+int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int seg_bits, const uint32_t* qs, const uint32_t* qe,
+                            const uint32_t* ts, const uint32_t* te, const double* wid, uint64_t kq, uint64_t kt, double thr, int scoring,
+                            int pos_bits, uint8_t* kept) {
+  hipStream_t st = ctx->stream;
+  uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
+  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
+  SWG_CHECK_ARENA(ctx);
+  SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
+  swg_axis_input ax;
+  ax.n = nc;
+  ax.seg = seg;
+  ax.seg_bits = seg_bits;
+  ax.pos_bits = pos_bits;
+  ax.score_key = skey;
+  if (kq != SWG_K_INF || kt != SWG_K_INF) {  // a sorting sweep will run: the packed form of its inputs
+    swg_key_ends* slots = swg_alloc<swg_key_ends>(ctx, nc);
+    SWG_CHECK_ARENA(ctx);
+    SWG_LAUNCH(ctx, "chain_slots", chain_slots_kernel<<<nblk(nc), EW, 0, st>>>(nc, skey, qs, qe, ts, te, slots));
+    SWG_KERNEL_CHECK(ctx);
+    ax.packed = slots;
+  }
+  ax.alive = nullptr;
+  ax.start = qs;
+  ax.end = qe;
+  ax.packed_end = 0;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
+  ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
+  ax.start = ts;
+  ax.end = te;
+  ax.packed_end = 1;
+  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
+  return SWG_OK;
+}
+
 // plane_sweep_scaffolds (plane_sweep_scaffold.rs:47-251) + chain numbering.  Chains are given in the
 // reference's all_chains order (their index is the plane sweep's tie-break `idx`).
 // Outputs: C_kept[c] (u8), C_num[c] (1-based position in the reference's output Vec, 0 if dropped).
@@ -138,40 +174,16 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   // restricted to them, which is all the plane sweep's index tie-break needs
   const uint64_t nc = T.nc;
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 1);
-  uint32_t *qid = T.qid, *tid = T.tid, *qs = T.qs, *qe = T.qe, *ts = T.ts, *te = T.te;
-  double* wid = T.wid;
+  uint32_t *qid = T.qid, *tid = T.tid;
   uint64_t* seg = swg_alloc<uint64_t>(ctx, nc);
-  uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
-  uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
   uint8_t* kept = C_kept;
   uint32_t* num = C_num;
   SWG_CHECK_ARENA(ctx);
   SWG_LAUNCH(ctx, "chain_seg", chain_seg_kernel<<<nblk(nc), EW, 0, st>>>(nc, qid, tid, n_seq, seg));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_score_keys(ctx, nc, qs, qe, wid, scoring, skey));
-  swg_axis_input ax;
-  ax.n = nc;
-  ax.seg = seg;
-  ax.seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
-  ax.pos_bits = pos_bits;
-  ax.score_key = skey;
-  if (kq != SWG_K_INF || kt != SWG_K_INF) {  // a sorting sweep will run: the packed form of its inputs
-    swg_key_ends* slots = swg_alloc<swg_key_ends>(ctx, nc);
-    SWG_CHECK_ARENA(ctx);
-    SWG_LAUNCH(ctx, "chain_slots", chain_slots_kernel<<<nblk(nc), EW, 0, st>>>(nc, skey, qs, qe, ts, te, slots));
-    SWG_KERNEL_CHECK(ctx);
-    ax.packed = slots;
-  }
-  ax.alive = nullptr;
-  ax.start = qs;
-  ax.end = qe;
-  ax.packed_end = 0;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
-  ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
-  ax.start = ts;
-  ax.end = te;
-  ax.packed_end = 1;
-  SWG_TRY(swg_sweep_axis(ctx, ax, kt, thr, kept));
+  const int seg_bits = swg_bits_for((uint64_t)n_seq * n_seq);
+  SWG_TRY(scaffold_sweep_segments(ctx, nc, seg, seg_bits, T.qs, T.qe, T.ts, T.te, T.wid, kq, kt, thr, scoring, pos_bits,
+                                  kept));
 
   // ---- numbering -------------------------------------------------------------------------------------
   uint64_t* seg_sorted = swg_alloc<uint64_t>(ctx, nc);
@@ -187,7 +199,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
   SWG_HIP(ctx, hipMemcpyAsync(seg_sorted, seg, nc * 8, hipMemcpyDeviceToDevice, st));
   SWG_LAUNCH(ctx, "iota", iota_u32_kernel<<<nblk(nc), EW, 0, st>>>(nc, c_sorted));
   SWG_KERNEL_CHECK(ctx);
-  SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, ax.seg_bits));
+  SWG_TRY(swg_radix_sort_pairs(ctx, &seg_sorted, &c_sorted, &seg_tmp, &c_tmp, nc, 0, seg_bits));
   SWG_LAUNCH(ctx, "run_flag", run_flag_kernel<<<nblk(nc), EW, 0, st>>>(nc, seg_sorted, run_flag));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_exclusive_scan_u32(ctx, run_flag, run_excl, nc, d_tot));  // total = number of chromosome-pair runs

@@ -80,6 +80,12 @@ CONFIGS = [
     {"scaffold_gap": 3_000, "min_scaffold_length": 4_000, "scaffold_max_deviation": 5_000},        # rescue around the anchors
     {"scaffold_gap": 1_000, "min_scaffold_length": 1_500, "scaffold_max_deviation": 100_000},
     {"scaffold_max_deviation": 20_000},
+    {"scaffold_filter_mode": "OneToOne", "scaffold_gap": 3_000, "min_scaffold_length": 2_000},     # a scaffold sweep with limits
+    {"scaffold_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 1_000, "scaffold_max_deviation": 8_000,
+     "scaffold_overlap_threshold": 0.2},
+    {"scaffold_filter_mode": "OneToMany", "scaffold_max_per_query": 2, "scaffold_max_per_target": 3, "scaffold_gap": 2_000,
+     "min_scaffold_length": 0, "scaffold_max_deviation": 3_000},
+    {"scaffold_filter_mode": "ManyToMany", "scaffold_max_per_target": 1, "scaffold_gap": 10_000, "min_scaffold_length": 3_000},
 ]
 
 
@@ -114,6 +120,7 @@ def test_one_pair_per_size_class(sw):
                           np.arange(len(rec) + len(r), dtype=np.uint64))
     for cfg in ({},   # gap 50 kb over records 3 kb apart: every pair is one unit, the long ones walked in speculative blocks
                 {"scaffold_gap": 5_000, "min_scaffold_length": 12_000, "scaffold_max_deviation": 9_000},
+                {"scaffold_filter_mode": "OneToOne", "scaffold_gap": 6_000, "min_scaffold_length": 8_000, "scaffold_max_deviation": 20_000},
                 {"scaffold_gap": 5_000, "min_scaffold_length": 3_000}, {"scaffold_gap": 400, "min_scaffold_length": 0},
                 {"scaffold_gap": 9_000, "min_scaffold_length": 20_000, "min_scaffold_identity": 0.8}):
         run_both(sw, rec, cfg)
