@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
 ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r04_v7"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
+PROFILE_TAG = "r05_v1"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
 
 # BASELINE.json's metric, verbatim
 BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
@@ -388,6 +388,18 @@ class Runner:
         return out
 
 
+_LIB_SHA = []
+
+
+def LIB_SHA256():
+    """sha256 of the shared library this process runs (tools/pmc_traffic.py stamps the traffic JSON with the same digest)."""
+    if not _LIB_SHA:
+        import hashlib
+        p = os.path.join(ROOT, "sweepga_amd", "libsweepga_gpu.so")
+        _LIB_SHA.append(hashlib.sha256(open(p, "rb").read()).hexdigest() if os.path.exists(p) else None)
+    return _LIB_SHA[0]
+
+
 def roofline(pipeline, n, steps, t, wl="100m"):
     """Dominant kernel of one flag set = the launch label with the most time per step.  One label is one kernel function
     (one rocprof name; tools/pmc_traffic.py maps names to the same labels), so every figure below averages over the SAME
@@ -411,10 +423,14 @@ def roofline(pipeline, n, steps, t, wl="100m"):
     traffic, tnote, total_traffic, tfile = None, None, None, f"profiles/{PROFILE_TAG}_hbm_traffic_{pipeline}_{wl}.json"
     try:
         tj = json.load(open(os.path.join(ROOT, tfile)))
-        if tj.get("n_mappings") != n:
+        if tj.get("lib_sha256") != LIB_SHA256():
+            # counters of another build of the library say nothing about this one's launches: no traffic figure at all
+            tnote = f"{tfile} was collected from library {str(tj.get('lib_sha256'))[:12]}, this run loads {str(LIB_SHA256())[:12]}"
+            tj = {"kernels": {}}
+        elif tj.get("n_mappings") != n:
             tnote = f"{tfile} is for {tj.get('n_mappings')} mappings"
         elif dom_name not in tj["kernels"]:
-            tnote = f"{dom_name} not in {tfile}"
+            tnote = tnote or f"{dom_name} not in {tfile}"
         else:
             k = tj["kernels"][dom_name]
             lpc = k.get("launches_per_call", k["launches_profiled"] / tj.get("calls_profiled", 3))

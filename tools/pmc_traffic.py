@@ -10,6 +10,7 @@ Both counters are in KB per dispatch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) 
 correction, calibrated on os_pass which reads exactly 12 B per pair)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -33,10 +34,16 @@ def short_name(name):
         base = "chain_walk_spec"      # blocks of long units, speculative rounds (template <BIGW, FUSED, SPEC>)
     if base == "os_pass_packed" and len(t) >= 2 and t[1] == "true":
         base = "os_pass_packed_first"  # the pass that reads (key, value) pairs and writes packed words
-    if base == "pair_sort" and t:      # pair_sort_kernel<NT, ...>: the small size classes (the large ones: pair_sort_big)
-        base = {"64": "pair_sort_s", "256": "pair_sort_m"}.get(t[0], base)
-    if base == "pair_finish" and t:    # pair_finish_kernel<NT, KP>
-        base = {"64": "pair_finish_s", "256": "pair_finish_m"}.get(t[0], base)
+    if base == "pair_sort" and t:      # pair_sort_kernel<NT, ES, ER, NBK, NBIN, PERM>: by size class, PERM = through the hash grouping
+        base = "pair_sort_" + ("p" if t[-1] == "true" else "") + {"64": "s", "256": "m", "1024": "l"}.get(t[0], t[0])
+    if base in ("pair_finish", "pair_chains") and t:    # <NT, ...>: 64 / 256 = the small size classes
+        base += {"64": "_s", "256": "_m"}.get(t[0], "")
+    if base in ("pair_key1", "pair_key2", "pair_rank1", "pair_rank_count", "pair_base", "pair_base_count", "pair_sizes", "pair_number_small"):
+        base = "pair_number"          # the chain_N numbering over the pair table: one label in the library
+    if base == "pair_long_plan":
+        base = "spec_plan"
+    if base == "pair_long_verdict":
+        base = "spec_final"
     if base in ("fill_u32", "fill_u64"):
         base = "fill"
     if base == "iota_u32":
@@ -97,7 +104,10 @@ def main():
                       "write_size_kb_per_launch": w, "hbm_bytes_per_launch": per_launch,
                       "hbm_bytes_per_call": per_launch * lpc}
         total += per_launch * lpc
-    print(json.dumps({"_how": __doc__.strip(), "n_mappings": n, "calls_profiled": calls, "pipeline_executions_profiled": executions,
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sweepga_amd", "libsweepga_gpu.so")
+    # the library these counters were taken from: bench.py reports `traffic` only when the library it runs has the same digest
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    print(json.dumps({"_how": __doc__.strip(), "lib_sha256": sha, "n_mappings": n, "calls_profiled": calls, "pipeline_executions_profiled": executions,
                       "hbm_bytes_per_call_all_kernels": total, "kernels": kernels}, indent=1))
 
 

@@ -5,7 +5,8 @@
 #   * rocprofv3 --kernel-trace --stats               -> <tag>_<flags>_<workload>_kernel_stats.csv
 #   * two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, as MI355X_MICROARCH.md prescribes; never combined with other
 #     trace domains) reduced by tools/pmc_traffic.py  -> <tag>_hbm_traffic_<flags>_<workload>.json
-#   * SQ counters of the sweep flags (VALU / LDS activity, waits, LDS bank conflicts, occupancy)  -> <tag>_sq_<workload>.txt
+#   * SQ counters of every flag set (VALU / LDS activity, waits, LDS bank conflicts, occupancy)  -> <tag>_sq_<flags>_<workload>.txt
+# The traffic JSONs and SQ tables carry the sha256 of the libsweepga_gpu.so they were taken from (bench.py checks it).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-rXX}
@@ -13,8 +14,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--only --cpu-sample 0 --no-pcie --e2e 0 --sbig1 0"
-run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = flag sets
-  WL=$1; SUF=$2; NM=$3; PIPES=$4
+run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = flag sets, $5 = flag sets with SQ tables
+  WL=$1; SUF=$2; NM=$3; PIPES=$4; SQPIPES=$5
   for p in $PIPES; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 3 --warmup 1 $COMMON > $OUT/stats_${p}_$SUF.log 2>&1
     f=$(find $OUT/stats_${p}_$SUF -name "*kernel_stats.csv" | head -1)
@@ -25,12 +26,15 @@ run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = 
     python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM 4 > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
     find $OUT -name "*kernel_trace.csv" -delete
   done
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1_$SUF -- python3 $R/bench.py --workload $WL --pipeline sweep --steps 1 --warmup 0 $COMMON > $OUT/sq1_$SUF.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d $OUT/sq2_$SUF -- python3 $R/bench.py --workload $WL --pipeline sweep --steps 1 --warmup 0 $COMMON > $OUT/sq2_$SUF.log 2>&1
-  { echo "# rocprofv3 --pmc SQ counters, per-launch averages (tools/pmc_table.py), sweep flags, workload $SUF"; python3 $R/tools/pmc_table.py $OUT/sq1_$SUF; python3 $R/tools/pmc_table.py $OUT/sq2_$SUF; } > $OUT/${TAG}_sq_$SUF.txt
+  for p in $SQPIPES; do   # SQ counters (VALU / LDS activity, waits, LDS bank conflicts, waves) of every flag set named
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/sq1_${p}_$SUF.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d $OUT/sq2_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/sq2_${p}_$SUF.log 2>&1
+    { echo "# rocprofv3 --pmc SQ counters, per-launch averages (tools/pmc_table.py), $p flags, workload $SUF, library $(sha256sum $R/sweepga_amd/libsweepga_gpu.so | cut -c1-12)"; python3 $R/tools/pmc_table.py $OUT/sq1_${p}_$SUF; python3 $R/tools/pmc_table.py $OUT/sq2_${p}_$SUF; } > $OUT/${TAG}_sq_${p}_$SUF.txt
+    find $OUT -name "*kernel_trace.csv" -delete
+  done
   find $OUT -name "*kernel_trace.csv" -delete
 }
-run_set span 100m 100000000 "default sweep full c5"   # c5 = BASELINE.json configs[4] as written (many:many + scaffold 1:1 + rescue)
-run_set sbig1 sbig1_10m 10000000 "default sweep full"
+run_set span 100m 100000000 "default sweep full c5" "default sweep full c5"   # c5 = BASELINE.json configs[4] as written (many:many + scaffold 1:1 + rescue)
+run_set sbig1 sbig1_10m 10000000 "default sweep full" "default"
 cd $R
 ls -la $OUT | head -60
