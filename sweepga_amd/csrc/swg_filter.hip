@@ -301,6 +301,11 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
+  if (!sweep_is_identity) {  // behind a mapping sweep: the pair-resident stage with the sweep's flags (members = the records it kept)
+    int taken = 0;
+    SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive, keep1, false, status_out, chain_out, stats, &taken));
+    if (taken) return SWG_OK;
+  }
   return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1],
                             key_ends);
 }

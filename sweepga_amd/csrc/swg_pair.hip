@@ -443,8 +443,11 @@ __device__ __forceinline__ void read_block(const uint32_t* lds, uint32_t (&out)[
 #ifdef SWG_PAIR_TIMING
 __device__ unsigned long long g_pair_t[16];
 #define PT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_pair_t[k], t_ - pt_last); pt_last = t_; } } while (0)
+#define FT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_fin_t[k], t_ - pt_last); pt_last = t_; } } while (0)
+__device__ unsigned long long g_fin_t[16];
 #else
 #define PT_STAMP(k) do { } while (0)
+#define FT_STAMP(k) do { } while (0)
 #endif
 // One work-group per pair of at most NT * ER records, sorted in batches of at most NT * ES members (one batch when the pair's
 // members fit, which is the rule; otherwise the key range is cut into coarse bins and consecutive bins are glued into batches).
@@ -1449,8 +1452,7 @@ struct PairFinishArgs {
   const uint8_t* kept_in;      // a scaffold sweep with limits ran over the chain table (pair_chains_kernel): kept flag per chain ...
   const uint32_t* chain_base;  // ... whose entries of pair k start here, in the pair's all_chains order; np[2k], np[2k + 1]: the pair's
   const uint32_t* np;          //     passing chains per strand
-  uint32_t* anum;      // by member position: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
-  uint32_t* pm;        // by member position: running maximum of q_end inside the strand (the labelling's head array, free by then)
+  uint32_t* anum;      // by position in the pair: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
   PairCounters* C;
 };
 constexpr uint32_t NEVER = 0xfffffffeu;  // a member of a chain that passed the span / identity filter but not the scaffold sweep
@@ -1582,7 +1584,7 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
 // kept, and only a pair that holds a chain with an empty span needs the counts: the sweep below first ranks the chains under
 // "both spans positive", and runs once more under the exact rule if it met such a chain.
 // KP: the kept '+' chains of a pair that are staged in LDS for the inversion capture (a longer list is searched in memory).
-template <int NT, int KP, int MAXM>  // MAXM: members of a pair of this size class at most
+template <int NT, int KP>
 __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   constexpr int U = 4;  // positions per thread and round: their loads are requested together
   __shared__ uint32_t ws[NT / 64 + 1];
@@ -1592,8 +1594,10 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   uint32_t* const l_qe = l_all + KP;
   uint32_t* const l_ts = l_all + 2 * KP;
   uint32_t* const l_pm = l_all + 3 * KP;
-  __shared__ uint32_t sh_xr[2 * (MAXM / (KP / 4) + 2)];  // the rescue's tiles: their stretch of the other strand
   const int tid = threadIdx.x;
+#ifdef SWG_PAIR_TIMING
+  unsigned long long pt_last = wall_clock64();
+#endif
   // a pair_sort work-group gave the call up (a pair too dense for the LDS batches ...): nothing written from here on is used
   // (the host sees the same flag and runs the global-sort stage)
   if (A.C->flags & PF_FALLBACK) return;
@@ -1750,6 +1754,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     if (plus_first) return r + 1;
     return minus ? r - kP + 1 : r + kM + 1;
   };
+  FT_STAMP(0);
   // ---- anchors: the members of kept chains (paf_filter.rs:517-528)
   uint32_t out = 0;
   for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
@@ -1777,6 +1782,10 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
       if (A.rescue_d && p < m) A.anum[a + p] = an;
     }
   }
+  if (A.rescue_d) {  // the alive non-members: rescue candidates unless the inversion capture takes them
+    for (uint32_t p = m + (uint32_t)tid; p < M; p += NT) A.anum[a + p] = 0u;
+  }
+  FT_STAMP(1);
   // ---- inversion capture (paf_filter.rs:535-597): a '-' record that is not an anchor joins the first kept '+' chain of its
   // pair whose window and diagonal it sits on
   if (!A.scaffolds_only && kP > 0 && M > m_plus) {
@@ -1836,247 +1845,165 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         const uint32_t num = local_number(best, false);
         A.chain[i] = num;
         A.status[i] = SWG_ST_SCAFFOLD;
-        if (A.rescue_d && p < m) A.anum[a + p] = num;  // an anchor from here on, whatever it was
+        if (A.rescue_d) A.anum[a + p] = num;  // an anchor from here on, whatever it was
         ++out;
       }
     }
   }
+  FT_STAMP(2);
   // ---- rescue (paf_filter.rs:599-732): a record that is neither an anchor nor a member of a swept-away chain is kept when an
   // anchor of its pair lies within rescue_d of it -- |q centre difference| <= D and floor(sqrt(dq^2 + dt^2)) <= D -- and takes
   // the chain of the lowest-index such anchor (the reference iterates a HashSet: any in-range anchor; the oracle fixes the
-  // same instance).  The anchors are members, and the members stand sorted by q_start inside each strand: an anchor in range
-  // starts no later than qc + D and ends no earlier than qc - D, so the scan runs from the first member whose running maximum
-  // of ends reaches qc - D to the last one that starts by qc + D.  (Only without alive non-members, i.e. no mapping sweep.)
-  if (!A.scaffolds_only && A.rescue_d && M == m) {
-    __syncthreads();  // every anchor's number is in anum; the head array is free
-    uint64_t carry = 0;
-    for (uint32_t p0 = 0; p0 < m; p0 += NT) {
-      const uint32_t p = p0 + tid;
-      const uint64_t v = p < m ? (((uint64_t)(p >= m_plus ? 1u : 0u) << 32) | A.s_qe[a + p]) : 0ull;
-      uint64_t tot;
-      uint64_t ex = block_excl_max<NT>(v, ws64, &tot);
-      ex = ex > carry ? ex : carry;
-      if (p < m) A.pm[a + p] = (uint32_t)(v > ex ? v : ex);  // (a '-' position's composite outranks every '+' one)
-      carry = tot > carry ? tot : carry;
-    }
-    __syncthreads();
+  // same instance).  The ANCHORS are what is resident: members of kept chains and whatever the inversion capture took, in
+  // batches of KA (one batch is the rule), binned in LDS by the cell of width D + 1 that their query centre falls in (cell
+  // modulo NB: a counting sort -- count, scan, place).  An anchor within D of a candidate lies in the candidate's cell or a
+  // neighbouring one, so every candidate of the pair -- members in any order, alive non-members behind a mapping sweep --
+  // reads three bins and applies the exact test to what it finds there.  A candidate's best anchor so far survives between
+  // batches in its anum word (bit 31 | record index; never equal to NEVER).
+  if (!A.scaffolds_only && A.rescue_d) {
+    __syncthreads();  // every anchor's number is in anum (marks, inversion capture); the chain list in l_all is done with
     const uint64_t D = A.rescue_d, max_s2 = A.max_s2;
-    // one candidate against the members [rb, re) of one strand, everything read from memory (the exact, slow form: used where
-    // a window reaches beyond what a tile has staged)
-    auto scan_memory = [&](uint32_t rb, uint32_t re, uint64_t qc, uint64_t tc, uint64_t lo_q, uint64_t hi_q, uint32_t& best_idx, uint32_t& best_num) {
-      uint32_t l = rb, r = re;  // first member of the strand that starts beyond qc + D
-      while (l < r) {
-        const uint32_t mid = l + ((r - l) >> 1);
-        if ((uint64_t)A.s_qs[a + mid] <= hi_q) l = mid + 1; else r = mid;
-      }
-      const uint32_t hi = l;
-      l = rb;
-      r = hi;  // first member whose running maximum of ends reaches qc - D
-      while (l < r) {
-        const uint32_t mid = l + ((r - l) >> 1);
-        if ((uint64_t)A.pm[a + mid] < lo_q) l = mid + 1; else r = mid;
-      }
-      for (uint32_t j = l; j < hi; ++j) {
-        const uint32_t an = A.anum[a + j];
-        if (an == 0 || an == NEVER) continue;
-        const uint64_t aq = ((uint64_t)A.s_qs[a + j] + (uint64_t)A.s_qe[a + j]) / 2;
-        const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
-        if (q_diff > D) continue;
-        const uint64_t at = ((uint64_t)A.s_ts[a + j] + (uint64_t)A.s_te[a + j]) / 2;
-        const uint64_t t_diff = tc > at ? tc - at : at - tc;
-        if (q_diff * q_diff + t_diff * t_diff <= max_s2) {  // (wrapping sum, as the reference's)
-          const uint32_t ix = A.s_idx[a + j];
-          if (ix < best_idx) {
-            best_idx = ix;
-            best_num = an;
-          }
-        }
-      }
-    };
-    // Tiles of T consecutive candidates of one strand.  Their windows overlap almost entirely, so the members a tile can reach
-    // are staged in LDS once -- the tile itself with a halo of H members on either side, and the stretch of the OTHER strand's
-    // members that the tile's q range (+- D) can reach -- and every candidate then searches and scans LDS.  A window that
-    // reaches the edge of what is staged (a very long member far to the left, a dense stretch) is evaluated from memory.
-    constexpr uint32_t T = KP / 4, H = KP / 16, SO = T + 2 * H, SX = KP / 8, STG = SO + SX;
-    static_assert(6 * STG <= 4 * KP, "staged members fit the LDS block");
-    uint32_t* const g_qs = l_all;
-    uint32_t* const g_pm = l_all + STG;
-    uint32_t* const g_qc = l_all + 2 * STG;
-    uint32_t* const g_tc = l_all + 3 * STG;
-    uint32_t* const g_an = l_all + 4 * STG;
-    uint32_t* const g_ix = l_all + 5 * STG;
-    auto stage = [&](uint32_t e, uint32_t j) {  // member j of the pair -> staged entry e
-      const uint32_t qs = A.s_qs[a + j], qe = A.s_qe[a + j], ts = A.s_ts[a + j], te = A.s_te[a + j];
-      g_qs[e] = qs;
-      g_pm[e] = A.pm[a + j];
-      g_qc[e] = (uint32_t)(((uint64_t)qs + qe) / 2);
-      g_tc[e] = (uint32_t)(((uint64_t)ts + te) / 2);
-      g_an[e] = A.anum[a + j];
-      g_ix[e] = A.s_idx[a + j];
-    };
-    // one candidate against the staged entries [e0, e1) (sorted by q_start, running maxima of ends in g_pm)
-    auto scan_staged = [&](uint32_t e0, uint32_t e1, uint64_t qc, uint64_t tc, uint64_t lo_q, uint64_t hi_q, uint32_t& best_idx, uint32_t& best_num,
-                           bool* at_left, bool* at_right) {
-      uint32_t l = e0, r = e1;
-      while (l < r) {
-        const uint32_t mid = l + ((r - l) >> 1);
-        if ((uint64_t)g_qs[mid] <= hi_q) l = mid + 1; else r = mid;
-      }
-      const uint32_t hi = l;
-      *at_right = hi == e1;
-      l = e0;
-      r = hi;
-      while (l < r) {
-        const uint32_t mid = l + ((r - l) >> 1);
-        if ((uint64_t)g_pm[mid] < lo_q) l = mid + 1; else r = mid;
-      }
-      *at_left = l == e0 && e0 < hi;
-      for (uint32_t j = l; j < hi; ++j) {
-        const uint32_t an = g_an[j];
-        if (an == 0 || an == NEVER) continue;
-        const uint64_t aq = g_qc[j];
-        const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
-        if (q_diff > D) continue;
-        const uint64_t at = g_tc[j];
-        const uint64_t t_diff = tc > at ? tc - at : at - tc;
-        if (q_diff * q_diff + t_diff * t_diff <= max_s2 && g_ix[j] < best_idx) {
-          best_idx = g_ix[j];
-          best_num = an;
-        }
-      }
-    };
-#pragma unroll 1
-    for (int reg = 0; reg < 2; ++reg) {
-      const uint32_t rb = reg ? m_plus : 0u, re = reg ? m : m_plus;  // the candidates' strand
-      const uint32_t xb = reg ? 0u : m_plus, xe = reg ? m_plus : m;  // the other strand
-      // the other strand's stretch of every tile, one wavefront per tile (64 probes per round of the search), all tiles at once
+    const uint32_t dc = D >= 0xffffffffull ? 0u : (uint32_t)D + 1u;  // cell width (0: one cell holds every 32-bit coordinate)
+    constexpr uint32_t NB = (uint32_t)KP / 4u, KA = (4u * (uint32_t)KP - 2u * NB - 1u) / 3u;
+    static_assert(KA >= (uint32_t)NT * U && NB % NT == 0, "one round of anchors fits a batch; whole bins per thread");
+    uint32_t* const g_qc = l_all;
+    uint32_t* const g_tc = l_all + KA;
+    uint32_t* const g_ix = l_all + 2 * KA;
+    uint32_t* const b_start = l_all + 3 * KA;  // NB + 1
+    uint32_t* const b_cur = b_start + NB + 1;  // NB
+    uint32_t* const c_num = A.f_qe + a;        // (a chain list of the inversion capture: free from here on)
+    auto is_anchor = [](uint32_t an) { return an != 0u && an < 0x80000000u; };
+    auto bin_of = [&](uint32_t qc) -> uint32_t { return (dc ? qc / dc : 0u) % NB; };
+    uint32_t pb = 0, r0 = 0;
+    while (pb < M) {  // (uniform)
+      for (uint32_t b = tid; b < NB; b += NT) b_cur[b] = 0u;
       __syncthreads();
-      for (uint32_t ti = (uint32_t)tid >> 6; rb + ti * T < re; ti += NT / 64) {
-        const int lane = tid & 63;
-        const uint32_t t0 = rb + ti * T, t1 = t0 + T < re ? t0 + T : re;
-        uint32_t x0 = xb, x1 = xb;
-        if (xb < xe) {
-          const uint64_t q_low = (uint64_t)A.s_qs[a + t0] > D ? (uint64_t)A.s_qs[a + t0] - D : 0ull;
-          const uint64_t pmx = A.pm[a + t1 - 1];
-          const uint64_t q_high = pmx + D < pmx ? ~0ull : pmx + D;
-          auto wave_first = [&](uint32_t lo, uint32_t hi, auto&& pred) -> uint32_t {  // first index in [lo, hi) with pred (monotone), or hi
-            for (;;) {
-              const uint32_t cnt = hi - lo;
-              if (cnt == 0) return lo;
-              if (cnt <= 64) {
-                const bool t = (uint32_t)lane < cnt && pred(lo + lane);
-                const uint64_t mk = __ballot(t);
-                return mk ? lo + (uint32_t)__builtin_ctzll(mk) : hi;
+      // the batch: whole rounds of positions from pb on while their anchors fit, counted per bin
+      uint32_t cnt = 0, pe = pb;
+      for (uint32_t p0 = pb; p0 < M; p0 += NT * U) {
+        uint32_t an[U], qs[U], qe[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+          const uint32_t j = a + (p < M ? p : 0u);
+          an[u] = p < M ? A.anum[j] : 0u;
+          qs[u] = A.s_qs[j];
+          qe[u] = A.s_qe[j];
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) mine += is_anchor(an[u]) ? 1u : 0u;
+        const uint32_t rt = block_sum<NT>(mine, ws);
+        if (cnt + rt > KA) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (is_anchor(an[u])) atomicAdd(&b_cur[bin_of((uint32_t)(((uint64_t)qs[u] + qe[u]) / 2))], 1u);
+        cnt += rt;
+        pe = p0 + NT * U < M ? p0 + NT * U : M;
+      }
+      __syncthreads();
+      {  // bin starts
+        constexpr uint32_t BT = NB / NT;
+        uint32_t c[BT], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < BT; ++k) {
+          c[k] = b_cur[(uint32_t)tid * BT + k];
+          sum += c[k];
+        }
+        uint32_t tot;
+        uint32_t run = block_excl_sum<NT>(sum, ws, &tot);
+#pragma unroll
+        for (uint32_t k = 0; k < BT; ++k) {
+          b_start[(uint32_t)tid * BT + k] = run;
+          b_cur[(uint32_t)tid * BT + k] = run;
+          run += c[k];
+        }
+        if (tid == NT - 1) b_start[NB] = run;
+      }
+      __syncthreads();
+      for (uint32_t p0 = pb; p0 < pe; p0 += NT * U) {
+        uint32_t an[U], qs[U], qe[U], ts[U], te[U], ix[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+          const uint32_t j = a + (p < pe ? p : 0u);
+          an[u] = p < pe ? A.anum[j] : 0u;
+          qs[u] = A.s_qs[j];
+          qe[u] = A.s_qe[j];
+          ts[u] = A.s_ts[j];
+          te[u] = A.s_te[j];
+          ix[u] = A.s_idx[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!is_anchor(an[u])) continue;
+          const uint32_t qc = (uint32_t)(((uint64_t)qs[u] + qe[u]) / 2);
+          const uint32_t e = atomicAdd(&b_cur[bin_of(qc)], 1u);
+          g_qc[e] = qc;
+          g_tc[e] = (uint32_t)(((uint64_t)ts[u] + te[u]) / 2);
+          g_ix[e] = ix[u] & 0x7fffffffu;
+          c_num[r0 + e] = an[u];
+        }
+      }
+      __syncthreads();
+      FT_STAMP(3);
+      // every candidate of the pair against the batch
+      for (uint32_t p0 = 0; cnt && p0 < M; p0 += NT * U) {
+        uint32_t an[U], qs[U], qe[U], ts[U], te[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+          const uint32_t j = a + (p < M ? p : 0u);
+          an[u] = A.anum[j];
+          qs[u] = A.s_qs[j];
+          qe[u] = A.s_qe[j];
+          ts[u] = A.s_ts[j];
+          te[u] = A.s_te[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+          const uint32_t st = an[u];
+          if (p >= M || !(st == 0u || (st >= 0x80000000u && st != NEVER))) continue;
+          const uint32_t qc32 = (uint32_t)(((uint64_t)qs[u] + qe[u]) / 2);
+          const uint64_t qc = qc32, tc = ((uint64_t)ts[u] + te[u]) / 2;
+          const uint32_t cell = dc ? qc32 / dc : 0u;
+          uint32_t best_idx = st ? st & 0x7fffffffu : NONE, best_e = NONE;
+#pragma unroll 1
+          for (int d = -1; d <= 1; ++d) {
+            if (d < 0 && cell == 0u) continue;  // (NB >= 3: three different bins; a bin read for a cell beyond the last one is harmless)
+            const uint32_t b = (cell + (uint32_t)d) % NB;
+            const uint32_t k1 = b_start[b + 1];
+            for (uint32_t k = b_start[b]; k < k1; ++k) {
+              const uint64_t aq = g_qc[k];
+              const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
+              if (q_diff > D) continue;
+              const uint64_t at = g_tc[k];
+              const uint64_t t_diff = tc > at ? tc - at : at - tc;
+              if (q_diff * q_diff + t_diff * t_diff > max_s2) continue;  // (wrapping sum, as the reference's)
+              const uint32_t ix = g_ix[k];
+              if (ix < best_idx) {
+                best_idx = ix;
+                best_e = k;
               }
-              const uint32_t step = (cnt + 63) / 64;
-              uint32_t pos = lo + ((uint32_t)lane + 1) * step;
-              if (pos > hi) pos = hi;
-              const bool t = pred(pos - 1);
-              const uint64_t mk = __ballot(t);
-              if (!mk) return hi;
-              const uint32_t f = (uint32_t)__builtin_ctzll(mk);
-              const uint32_t nlo = lo + f * step;
-              uint32_t nhi = lo + (f + 1) * step;
-              if (nhi > hi) nhi = hi;
-              lo = nlo;
-              hi = nhi - 1;  // the stretch's last element satisfies pred: the first one that does lies in [nlo, nhi - 1]
-            }
-          };
-          x1 = wave_first(xb, xe, [&](uint32_t j) { return (uint64_t)A.s_qs[a + j] > q_high; });
-          x0 = wave_first(xb, x1, [&](uint32_t j) { return (uint64_t)A.pm[a + j] >= q_low; });
-        }
-        if (lane == 0) {
-          sh_xr[2 * ti] = x0;
-          sh_xr[2 * ti + 1] = x1;
-        }
-      }
-      for (uint32_t t0 = rb; t0 < re; t0 += T) {
-        const uint32_t t1 = t0 + T < re ? t0 + T : re;
-        const uint32_t s0 = t0 - rb > H ? t0 - H : rb, s1 = re - t1 > H ? t1 + H : re;
-        __syncthreads();  // (the previous tile's readers are done with the staged entries)
-        const uint32_t ti = (t0 - rb) / T;
-        const uint32_t x0 = sh_xr[2 * ti], x1 = sh_xr[2 * ti + 1];
-        const bool cross_staged = x1 - x0 <= SX;
-        {  // (every load of the thread's entries requested before the first LDS store)
-          constexpr int SE = (int)((SO + NT - 1) / NT), XE = (int)((SX + NT - 1) / NT);
-          uint32_t vq[SE + XE], ve[SE + XE], vt[SE + XE], vu[SE + XE], vp[SE + XE], va[SE + XE], vi[SE + XE];
-#pragma unroll
-          for (int k = 0; k < SE + XE; ++k) {
-            const bool own = k < SE;
-            const uint32_t e = own ? (uint32_t)tid + (uint32_t)k * NT : (uint32_t)tid + (uint32_t)(k - SE) * NT;
-            const bool in = own ? e < s1 - s0 : (cross_staged && e < x1 - x0);
-            const uint32_t j = a + (in ? (own ? s0 + e : x0 + e) : 0u);
-            vq[k] = A.s_qs[j];
-            ve[k] = A.s_qe[j];
-            vt[k] = A.s_ts[j];
-            vu[k] = A.s_te[j];
-            vp[k] = A.pm[j];
-            va[k] = A.anum[j];
-            vi[k] = A.s_idx[j];
-          }
-#pragma unroll
-          for (int k = 0; k < SE + XE; ++k) {
-            const bool own = k < SE;
-            const uint32_t e = own ? (uint32_t)tid + (uint32_t)k * NT : (uint32_t)tid + (uint32_t)(k - SE) * NT;
-            const bool in = own ? e < s1 - s0 : (cross_staged && e < x1 - x0);
-            if (!in) continue;
-            const uint32_t d = own ? e : SO + e;
-            g_qs[d] = vq[k];
-            g_pm[d] = vp[k];
-            g_qc[d] = (uint32_t)(((uint64_t)vq[k] + ve[k]) / 2);
-            g_tc[d] = (uint32_t)(((uint64_t)vt[k] + vu[k]) / 2);
-            g_an[d] = va[k];
-            g_ix[d] = vi[k];
-          }
-        }
-        __syncthreads();
-        for (uint32_t p = t0 + tid; p < t1; p += NT) {
-          const uint32_t e = p - s0;
-          if (g_an[e] != 0) continue;
-          const uint64_t qc = g_qc[e], tc = g_tc[e];
-          const uint64_t lo_q = qc > D ? qc - D : 0ull, hi_q = qc + D < qc ? ~0ull : qc + D;
-          uint32_t best_idx = NONE, best_num = 0;
-          // own strand: the window lies around the candidate's own place -- a few steps right while members start by qc + D, a few
-          // steps left while the running maximum of ends still reaches qc - D
-          const uint32_t ne = s1 - s0;
-          uint32_t hi = e + 1, lo = e;
-          while (hi < ne && (uint64_t)g_qs[hi] <= hi_q) ++hi;
-          while (lo > 0 && (uint64_t)g_pm[lo - 1] >= lo_q) --lo;
-          const bool at_right = hi == ne, at_left = lo == 0;
-          for (uint32_t j = lo; j < hi; ++j) {
-            const uint32_t an = g_an[j];
-            if (an == 0 || an == NEVER) continue;
-            const uint64_t aq = g_qc[j];
-            const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
-            if (q_diff > D) continue;
-            const uint64_t at = g_tc[j];
-            const uint64_t t_diff = tc > at ? tc - at : at - tc;
-            if (q_diff * q_diff + t_diff * t_diff <= max_s2 && g_ix[j] < best_idx) {
-              best_idx = g_ix[j];
-              best_num = an;
             }
           }
-          if ((at_left && s0 > rb) || (at_right && s1 < re)) {  // the window may go on beyond the staged members
-            best_idx = NONE;
-            best_num = 0;
-            scan_memory(rb, re, qc, tc, lo_q, hi_q, best_idx, best_num);
-          }
-          if (cross_staged) {
-            bool l2, r2;
-            scan_staged(SO, SO + (x1 - x0), qc, tc, lo_q, hi_q, best_idx, best_num, &l2, &r2);
-          } else {
-            scan_memory(xb, xe, qc, tc, lo_q, hi_q, best_idx, best_num);
-          }
-          if (best_idx != NONE) {
-            const uint32_t i = g_ix[e];
+          if (best_e != NONE) {
+            const uint32_t i = A.s_idx[a + p] & 0x7fffffffu;
             A.status[i] = SWG_ST_RESCUED;
-            A.chain[i] = best_num;
-            ++out;
+            A.chain[i] = c_num[r0 + best_e];
+            A.anum[a + p] = 0x80000000u | best_idx;
+            if (st == 0u) ++out;
           }
         }
       }
+      FT_STAMP(4);
+      __syncthreads();  // (the next batch overwrites the bins)
+      r0 += cnt;
+      pb = pe;
     }
   }
+  FT_STAMP(5);
   out = block_sum<NT>(out, ws);
   if (tid == 0) {
     atomicAdd(&A.C->n_kept, (unsigned long long)n_kept);
@@ -2315,10 +2242,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     kt = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
   }
   const bool limited = kq != SWG_K_INF || kt != SWG_K_INF;  // the scaffold sweep has limits: it runs over a chain table
-  // a rescue distance: only when every alive record is a member (no mapping sweep in front: the rescue's anchors are then all
-  // in the pair's sorted order)
   const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
-  if (rescue && (alive || member)) return SWG_OK;
   const uint32_t n = (uint32_t)n64;
   hipStream_t st = ctx->stream;
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
@@ -2495,14 +2419,13 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   FA.rescue_d = rescue ? cfg->scaffold_max_deviation : 0;
   FA.max_s2 = rescue ? pair_max_dist2(cfg->scaffold_max_deviation) : 0;
   FA.anum = anum;
-  FA.pm = hd;
   for (int c = 0; c < 4; ++c) {
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
     switch (c) {
-      case 0: SWG_LAUNCH(ctx, "pair_finish_s", pair_finish_kernel<64, 256, (int)PAIR_S_MAX><<<ncls[c], 64, 0, st>>>(FA)); break;
-      case 1: SWG_LAUNCH(ctx, "pair_finish_m", pair_finish_kernel<256, 1024, (int)PAIR_M_MAX><<<ncls[c], 256, 0, st>>>(FA)); break;
-      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096, (int)PAIR_XL_MAX><<<ncls[c], 512, 0, st>>>(FA)); break;
+      case 0: SWG_LAUNCH(ctx, "pair_finish_s", pair_finish_kernel<64, 256><<<ncls[c], 64, 0, st>>>(FA)); break;
+      case 1: SWG_LAUNCH(ctx, "pair_finish_m", pair_finish_kernel<256, 1024><<<ncls[c], 256, 0, st>>>(FA)); break;
+      default: SWG_LAUNCH(ctx, "pair_finish", pair_finish_kernel<512, 4096><<<ncls[c], 512, 0, st>>>(FA)); break;
     }
     SWG_KERNEL_CHECK(ctx);
   }
@@ -2569,6 +2492,11 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     fprintf(stderr, "\n");
     unsigned long long z[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_t), z, sizeof z);
+    (void)hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_fin_t), sizeof ht);
+    fprintf(stderr, "[swg] pair_finish phases:");
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%llu", k, ht[k]);
+    fprintf(stderr, "\n");
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_t), z, sizeof z);
   }
 #endif
   if (stats) {

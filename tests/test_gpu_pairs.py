@@ -86,6 +86,15 @@ CONFIGS = [
     {"scaffold_filter_mode": "OneToMany", "scaffold_max_per_query": 2, "scaffold_max_per_target": 3, "scaffold_gap": 2_000,
      "min_scaffold_length": 0, "scaffold_max_deviation": 3_000},
     {"scaffold_filter_mode": "ManyToMany", "scaffold_max_per_target": 1, "scaffold_gap": 10_000, "min_scaffold_length": 3_000},
+    # behind a mapping sweep: the records it dropped are no members, but candidates of the inversion capture and the rescue
+    {"mapping_filter_mode": "OneToOne"},
+    {"mapping_filter_mode": "OneToOne", "scaffold_gap": 4_000, "min_scaffold_length": 2_000, "scaffold_max_deviation": 6_000},
+    {"mapping_filter_mode": "OneToOne", "scaffold_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 1_000,
+     "scaffold_max_deviation": 30_000},
+    {"mapping_filter_mode": "OneToMany", "mapping_max_per_query": 3, "mapping_max_per_target": 2, "scaffold_gap": 2_000,
+     "min_scaffold_length": 500, "scaffold_max_deviation": 2_000, "overlap_threshold": 0.5},
+    {"mapping_filter_mode": "ManyToMany", "mapping_max_per_query": 2, "scaffold_gap": 8_000, "min_scaffold_length": 0,
+     "scaffold_max_deviation": 0},
 ]
 
 
@@ -176,12 +185,14 @@ def test_small_inputs_need_not_be_grouped(sw):
         run_both(sw, rec, cfg)
 
 
-def test_large_ungrouped_and_degenerate_inputs_take_the_global_path(sw):
+def test_large_ungrouped_inputs_take_the_global_path_and_degenerate_ones_the_real_sweep(sw):
     rng = np.random.default_rng(9)
     rec = gen.random_records(rng, 70_000, n_genomes=3, chrs_per_genome=2, span=2_000_000, zero_frac=0.0)
     run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # pairs interleaved, too many for the table
     rec = pair_major(gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.02), rng)
-    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # zero-length records
+    # zero-length records: the unlimited mapping sweep is not the identity, so it runs, and the pair path takes its flags
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=True)
+    assert "kinf_mark" in sw.default_context(0).profile_table() or "kinf_mark_both" in sw.default_context(0).profile_table()
 
 
 def test_knob_off_gives_the_same_answer(sw):
