@@ -219,16 +219,19 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
       c->call_group32 = nullptr;
     }
   } call_scope{ctx};
+  // Records grouped by chromosome pair and a scaffold stage: the pair-resident stage (swg_pair.hip).  Its plan -- the pairs of
+  // the input -- is made first.  Without limits in the mapping-level sweep the stage evaluates step 1 itself and takes the
+  // unlimited sweep as the identity; it leaves the call to the stages below when it meets a retained record that an unlimited
+  // sweep would drop (zero length), or anything else it does not cover.  Behind a mapping sweep it takes the sweep's flags
+  // (further down), and the sweep is told that nobody will ask for its sorted order.
+  swg_scaf::PairPlan pair_plan;
+  if (cfg->scaffold_gap != 0) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
   {
-    // Records grouped by chromosome pair, a scaffold stage, no limit in the mapping-level sweep: the pair-resident stage
-    // (swg_pair.hip) evaluates step 1 itself and takes the unlimited sweep as the identity -- it leaves the call to the
-    // stages below when it meets a retained record that an unlimited sweep would drop (zero length), or anything else it
-    // does not cover.
     uint64_t kq1, kt1;
     limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
-    if (cfg->scaffold_gap != 0 && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
+    if (pair_plan.valid && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
       int taken = 0;
-      SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, nullptr, nullptr, true, status_out, chain_out, stats, &taken));
+      SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, nullptr, nullptr, true, status_out, chain_out, stats, &taken, &pair_plan));
       if (taken) return SWG_OK;
     }
   }
@@ -266,7 +269,8 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_HIP(ctx, hipMemsetAsync(scalars, 0, 8 * sizeof(unsigned long long), st));
   // behind a mapping sweep the scaffold stage's first sort only orders the (query, target, strand) groups (the query axis'
   // order has the rest): prepare leaves the group of every record as one 4-byte value for it
-  uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
+  // (neither when the pair-resident stage is going to run: it sorts inside its pairs)
+  uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && !pair_plan.valid && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   ctx->call_group32 = group32;
   SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends ? key_ends : probe_slots, sweeps, scalars, group32, probe_flag));
@@ -282,7 +286,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
 
   // with scaffolding on, the query axis' sorted order is kept: sort A of the chaining is the same order refined by
   // (target sequence, strand)
-  uint32_t* q_order = cfg->scaffold_gap != 0 ? swg_alloc<uint32_t>(ctx, n) : nullptr;
+  uint32_t* q_order = cfg->scaffold_gap != 0 && !(pair_plan.valid && sweeps) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   int q_order_valid = 0;
   if (!sweep_is_identity) SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid));
@@ -301,9 +305,9 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  if (!sweep_is_identity) {  // behind a mapping sweep: the pair-resident stage with the sweep's flags (members = the records it kept)
+  if (!sweep_is_identity && pair_plan.valid) {  // behind a mapping sweep: with the sweep's flags (members = the records it kept)
     int taken = 0;
-    SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive, keep1, false, status_out, chain_out, stats, &taken));
+    SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive, keep1, false, status_out, chain_out, stats, &taken, &pair_plan));
     if (taken) return SWG_OK;
   }
   return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1],

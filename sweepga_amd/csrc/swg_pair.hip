@@ -150,80 +150,105 @@ __global__ __launch_bounds__(256) void pair_boundary_kernel(uint32_t n, const ui
                                                             uint32_t* __restrict__ run_start, uint32_t cap,
                                                             unsigned long long* __restrict__ table, uint32_t tmask,
                                                             PairCounters* __restrict__ C) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  // a wavefront takes 4 x 64 consecutive records (four bitmap words); every load is requested before the first comparison
+  constexpr int R = 4;
   const int lane = threadIdx.x & 63;
-  uint32_t q = 0, t = 0;
-  bool start = false;
-  if (i < n) {
-    q = q_id[i];
-    t = t_id[i];
-    start = i == 0 || q_id[i - 1] != q || t_id[i - 1] != t;
+  const uint32_t base_i = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (64u * R);
+  if (base_i >= n) return;
+  uint32_t q[R], t[R], pq[R], pt[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint32_t i = base_i + (uint32_t)j * 64u + (uint32_t)lane;
+    q[j] = i < n ? q_id[i] : 0u;
+    t[j] = i < n ? t_id[i] : 0u;
   }
-  const unsigned long long mask = __ballot(start);
-  if (lane == 0 && i < n) bitmap[i >> 6] = mask;
-  if (mask == 0) return;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&C->n_runs, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, 0, 64);
-  if (!start) return;
-  const uint32_t k = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  if (k >= cap) {
-    atomicOr(&C->flags, PF_RUN_OVERFLOW);
-    return;
-  }
-  run_start[k] = i;
-  const unsigned long long key = ((unsigned long long)q << 32) | t;
-  uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & tmask;
-  for (;;) {  // (at most `cap` keys in 2 * cap slots)
-    const unsigned long long old = atomicCAS(&table[h], ~0ull, key);
-    if (old == ~0ull) break;
-    if (old == key) {
-      atomicOr(&C->flags, PF_NOT_GROUPED);
-      break;
+  const uint32_t q_before = base_i ? q_id[base_i - 1] : 0u, t_before = base_i ? t_id[base_i - 1] : 0u;  // (uniform)
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    pq[j] = (uint32_t)__shfl_up((int)q[j], 1, 64);
+    pt[j] = (uint32_t)__shfl_up((int)t[j], 1, 64);
+    const uint32_t lq = j ? (uint32_t)__shfl((int)q[j - 1], 63, 64) : q_before, lt = j ? (uint32_t)__shfl((int)t[j - 1], 63, 64) : t_before;
+    if (lane == 0) {
+      pq[j] = lq;
+      pt[j] = lt;
     }
-    h = (h + 1) & tmask;
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint32_t i = base_i + (uint32_t)j * 64u + (uint32_t)lane;
+    const bool start = i < n && (i == 0 || pq[j] != q[j] || pt[j] != t[j]);
+    const unsigned long long mask = __ballot(start);
+    if (lane == 0 && i < n) bitmap[i >> 6] = mask;
+    if (mask == 0) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&C->n_runs, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (!start) continue;
+    const uint32_t k = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (k >= cap) {
+      atomicOr(&C->flags, PF_RUN_OVERFLOW);
+      continue;
+    }
+    run_start[k] = i;
+    const unsigned long long key = ((unsigned long long)q[j] << 32) | t[j];
+    uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & tmask;
+    for (;;) {  // (at most `cap` keys in 2 * cap slots)
+      const unsigned long long old = atomicCAS(&table[h], ~0ull, key);
+      if (old == ~0ull) break;
+      if (old == key) {
+        atomicOr(&C->flags, PF_NOT_GROUPED);
+        break;
+      }
+      h = (h + 1) & tmask;
+    }
   }
 }
-// Every run's end (the next set bit), its size class, and the per-class lists the work-groups of the later kernels index.
+// Every run's end (the next set bit), its size class, and the per-class lists the work-groups of the later kernels index.  One
+// wavefront per run (64 bitmap words per step), the wavefronts of a fixed grid striding over the runs.
 __global__ __launch_bounds__(256) void pair_runs_kernel(uint32_t n, uint32_t cap, const uint32_t* __restrict__ run_start,
                                                         const unsigned long long* __restrict__ bitmap, PairRun* __restrict__ runs,
                                                         uint32_t* __restrict__ class_list, PairCounters* __restrict__ C) {
-  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
   const uint32_t nr = C->n_runs < cap ? C->n_runs : cap;
-  if (k >= nr) return;
-  const uint32_t a = run_start[k];
   const uint32_t n_words = (n + 63) >> 6;
-  uint32_t end = n;
-  bool too_long = false;
-  if (a + 1 < n) {
-    uint32_t w = (a + 1) >> 6;
-    unsigned long long x = bitmap[w] & (~0ull << ((a + 1) & 63));
-    const uint32_t w_stop = w + PAIR_XL_MAX / 64 + 2;
-    for (;;) {
-      if (x) {
-        end = (w << 6) + (uint32_t)__builtin_ctzll(x);
-        break;
+  for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < nr; k += gridDim.x * 4u) {
+    const uint32_t a = run_start[k];
+    uint32_t end = n;
+    bool too_long = false;
+    if (a + 1 < n) {
+      const uint32_t w0 = (a + 1) >> 6;
+      const uint32_t w_stop = w0 + PAIR_XL_MAX / 64 + 2;
+      const uint32_t limit = n_words < w_stop ? n_words : w_stop;  // words [w0, limit) are looked at
+      bool found = false;
+      for (uint32_t wb = w0; wb < limit; wb += 64) {
+        const uint32_t w = wb + lane;
+        unsigned long long x = w < limit ? bitmap[w] : 0ull;
+        if (w == w0) x &= ~0ull << ((a + 1) & 63);
+        const unsigned long long m = __ballot(x != 0ull);
+        if (m) {
+          const int f = __builtin_ctzll(m);
+          const unsigned long long xf = __shfl(x, f, 64);
+          end = ((wb + (uint32_t)f) << 6) + (uint32_t)__builtin_ctzll(xf);
+          found = true;
+          break;
+        }
       }
-      if (++w >= n_words) break;
-      if (w >= w_stop) {
-        too_long = true;
-        break;
-      }
-      x = bitmap[w];
+      too_long = !found && limit < n_words;  // (otherwise the run goes to the end of the input)
     }
+    if (lane != 0) continue;
+    const uint32_t len = end - a;
+    PairRun r;
+    r.a = a;
+    r.n = len;
+    runs[k] = r;
+    if (too_long || len > PAIR_XL_MAX) {
+      atomicOr(&C->flags, PF_TOO_LONG);
+      continue;
+    }
+    const int cls = len <= PAIR_S_MAX ? 0 : (len <= PAIR_M_MAX ? 1 : (len <= PAIR_L_MAX ? 2 : 3));
+    const uint32_t j = atomicAdd(&C->n_class[cls], 1u);
+    class_list[(size_t)cls * cap + j] = k;
   }
-  const uint32_t len = end - a;
-  PairRun r;
-  r.a = a;
-  r.n = len;
-  runs[k] = r;
-  if (too_long || len > PAIR_XL_MAX) {
-    atomicOr(&C->flags, PF_TOO_LONG);
-    return;
-  }
-  const int cls = len <= PAIR_S_MAX ? 0 : (len <= PAIR_M_MAX ? 1 : (len <= PAIR_L_MAX ? 2 : 3));
-  const uint32_t j = atomicAdd(&C->n_class[cls], 1u);
-  class_list[(size_t)cls * cap + j] = k;
 }
 
 // ---- inputs that are not grouped by pair (and small ones in general): the pairs through a hash table ----------------------
@@ -1864,19 +1889,24 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     __syncthreads();  // every anchor's number is in anum (marks, inversion capture); the chain list in l_all is done with
     const uint64_t D = A.rescue_d, max_s2 = A.max_s2;
     const uint32_t dc = D >= 0xffffffffull ? 0u : (uint32_t)D + 1u;  // cell width (0: one cell holds every 32-bit coordinate)
-    constexpr uint32_t NB = (uint32_t)KP / 4u, KA = (4u * (uint32_t)KP - 2u * NB - 1u) / 3u;
-    static_assert(KA >= (uint32_t)NT * U && NB % NT == 0, "one round of anchors fits a batch; whole bins per thread");
+    // (bin starts and cursors are 16-bit: KA < 2^16; the cursors are bumped by 32-bit atomics on the word that holds two)
+    constexpr uint32_t NB = (uint32_t)KP / 2u, KA = (4u * (uint32_t)KP - NB - 1u) / 3u, BT = NB / NT;
+    static_assert(KA >= (uint32_t)NT * U && KA < 65536u && NB % (2 * NT) == 0, "one round of anchors fits a batch; whole words of bins per thread");
     uint32_t* const g_qc = l_all;
     uint32_t* const g_tc = l_all + KA;
     uint32_t* const g_ix = l_all + 2 * KA;
-    uint32_t* const b_start = l_all + 3 * KA;  // NB + 1
-    uint32_t* const b_cur = b_start + NB + 1;  // NB
+    uint16_t* const b_start = reinterpret_cast<uint16_t*>(l_all + 3 * KA);  // NB + 1
+    uint32_t* const b_cur = l_all + 3 * KA + (NB + 2) / 2;                   // NB / 2 words
+    auto bump = [&](uint32_t b) -> uint32_t {  // the bin's cursor before the bump
+      const uint32_t sh = 16u * (b & 1u);
+      return (atomicAdd(&b_cur[b >> 1], 1u << sh) >> sh) & 0xffffu;
+    };
     uint32_t* const c_num = A.f_qe + a;        // (a chain list of the inversion capture: free from here on)
     auto is_anchor = [](uint32_t an) { return an != 0u && an < 0x80000000u; };
     auto bin_of = [&](uint32_t qc) -> uint32_t { return (dc ? qc / dc : 0u) % NB; };
     uint32_t pb = 0, r0 = 0;
     while (pb < M) {  // (uniform)
-      for (uint32_t b = tid; b < NB; b += NT) b_cur[b] = 0u;
+      for (uint32_t b = tid; b < NB / 2; b += NT) b_cur[b] = 0u;
       __syncthreads();
       // the batch: whole rounds of positions from pb on while their anchors fit, counted per bin
       uint32_t cnt = 0, pe = pb;
@@ -1897,28 +1927,31 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         if (cnt + rt > KA) break;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (is_anchor(an[u])) atomicAdd(&b_cur[bin_of((uint32_t)(((uint64_t)qs[u] + qe[u]) / 2))], 1u);
+          if (is_anchor(an[u])) (void)bump(bin_of((uint32_t)(((uint64_t)qs[u] + qe[u]) / 2)));
         cnt += rt;
         pe = p0 + NT * U < M ? p0 + NT * U : M;
       }
       __syncthreads();
-      {  // bin starts
-        constexpr uint32_t BT = NB / NT;
+      {  // bin starts: BT consecutive bins (BT / 2 words) per thread
         uint32_t c[BT], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < BT; ++k) {
-          c[k] = b_cur[(uint32_t)tid * BT + k];
-          sum += c[k];
+        for (uint32_t k = 0; k < BT; k += 2) {
+          const uint32_t w = b_cur[((uint32_t)tid * BT + k) >> 1];
+          c[k] = w & 0xffffu;
+          c[k + 1] = w >> 16;
+          sum += c[k] + c[k + 1];
         }
         uint32_t tot;
         uint32_t run = block_excl_sum<NT>(sum, ws, &tot);
 #pragma unroll
-        for (uint32_t k = 0; k < BT; ++k) {
-          b_start[(uint32_t)tid * BT + k] = run;
-          b_cur[(uint32_t)tid * BT + k] = run;
-          run += c[k];
+        for (uint32_t k = 0; k < BT; k += 2) {
+          const uint32_t s0 = run, s1 = run + c[k];
+          b_start[(uint32_t)tid * BT + k] = (uint16_t)s0;
+          b_start[(uint32_t)tid * BT + k + 1] = (uint16_t)s1;
+          b_cur[((uint32_t)tid * BT + k) >> 1] = s0 | (s1 << 16);
+          run = s1 + c[k + 1];
         }
-        if (tid == NT - 1) b_start[NB] = run;
+        if (tid == NT - 1) b_start[NB] = (uint16_t)run;
       }
       __syncthreads();
       for (uint32_t p0 = pb; p0 < pe; p0 += NT * U) {
@@ -1938,7 +1971,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         for (int u = 0; u < U; ++u) {
           if (!is_anchor(an[u])) continue;
           const uint32_t qc = (uint32_t)(((uint64_t)qs[u] + qe[u]) / 2);
-          const uint32_t e = atomicAdd(&b_cur[bin_of(qc)], 1u);
+          const uint32_t e = bump(bin_of(qc));
           g_qc[e] = qc;
           g_tc[e] = (uint32_t)(((uint64_t)ts[u] + te[u]) / 2);
           g_ix[e] = ix[u] & 0x7fffffffu;
@@ -2225,30 +2258,18 @@ bool pair_path_wanted() {
 
 }  // namespace
 
-// The scaffold stage for records grouped by chromosome pair.  *taken = 0: not applicable (not grouped, a pair too long, a
-// configuration this path does not cover, or a condition found on the device) -- nothing the caller cannot overwrite was
-// done, and it runs the global-sort path.  alive / member: nullptr = step-1 retain evaluated here / members == alive records.
-int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive, const uint8_t* member,
-                         bool sweep_assumed_identity, uint8_t* status_out, uint32_t* chain_out, swg_stats* stats, int* taken) {
-  *taken = 0;
+// The pairs of the input: runs of equal (q_id, t_id) (large inputs, grouped by pair as an aligner writes them), or through a
+// hash table (small inputs, grouped or not).  valid = 0: the pair-resident stage does not apply.
+int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPlan* plan) {
+  (void)cfg;
+  *plan = PairPlan{};
   if (!pair_path_wanted()) return SWG_OK;
   const uint64_t n64 = r->n;
   if (n64 < 2 || n64 >= (uint64_t(1) << 31)) return SWG_OK;
-  uint64_t kq, kt;
-  if (cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_ONE) {
-    kq = kt = 1;
-  } else {
-    kq = cfg->scaffold_max_per_query ? cfg->scaffold_max_per_query : SWG_K_INF;
-    kt = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
-  }
-  const bool limited = kq != SWG_K_INF || kt != SWG_K_INF;  // the scaffold sweep has limits: it runs over a chain table
-  const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
   const uint32_t n = (uint32_t)n64;
   hipStream_t st = ctx->stream;
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
   const swg_arena_mark mark0 = swg_arena_save(ctx);
-  // ---- the pairs: runs of the input (large inputs, grouped by pair as an aligner writes them), or through a hash table
-  // (small inputs, grouped or not)
   const bool by_hash = n <= PAIR_HASH_MAX;
   const uint32_t cap = n < 65536u ? n : (n / 16 > 65536u ? n / 16 : 65536u);
   uint32_t tsize = 1;
@@ -2281,24 +2302,75 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemsetAsync(C, 0, sizeof(PairCounters), st));
     SWG_HIP(ctx, hipMemsetAsync(table, 0xff, (size_t)tsize * 8, st));
-    SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, run_start, cap, table, tsize - 1, C));
+    SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 1023) / 1024, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, run_start, cap, table, tsize - 1, C));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n, cap, run_start, bitmap, runs, class_list, C));
+    SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 3) / 4 < (uint32_t)ctx->num_cu * 16u ? (cap + 3) / 4 : (uint32_t)ctx->num_cu * 16u, 256, 0, st>>>(n, cap, run_start, bitmap, runs, class_list, C));
     SWG_KERNEL_CHECK(ctx);
   }
   uint64_t h[4];
   static_assert(sizeof(PairCounters) >= 32, "the first four words are read back");
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(C), h, 3));
   const uint32_t n_runs = (uint32_t)h[0], flags = (uint32_t)(h[0] >> 32);
-  const uint32_t ncls[4] = {(uint32_t)h[1], (uint32_t)(h[1] >> 32), (uint32_t)h[2], (uint32_t)(h[2] >> 32)};
   if (flags || n_runs == 0) {
     if (dbg) fprintf(stderr, "[swg] pair path: not applicable (%u runs, flags %u)\n", n_runs, flags);
     swg_arena_restore(ctx, mark0);
     return SWG_OK;
   }
+  plan->valid = 1;
+  plan->by_hash = by_hash;
+  plan->n_runs = n_runs;
+  plan->ncls[0] = (uint32_t)h[1];
+  plan->ncls[1] = (uint32_t)(h[1] >> 32);
+  plan->ncls[2] = (uint32_t)h[2];
+  plan->ncls[3] = (uint32_t)(h[2] >> 32);
+  plan->cap = cap;
+  plan->counters = C;
+  plan->runs = runs;
+  plan->class_list = class_list;
+  plan->perm = perm;
   if (dbg)
-    fprintf(stderr, "[swg] pair path: %u pairs (%u / %u / %u / %u by size class)%s\n", n_runs, ncls[0], ncls[1], ncls[2], ncls[3],
-            by_hash ? ", found through the hash table" : "");
+    fprintf(stderr, "[swg] pair path: %u pairs (%u / %u / %u / %u by size class)%s\n", n_runs, plan->ncls[0], plan->ncls[1], plan->ncls[2],
+            plan->ncls[3], by_hash ? ", found through the hash table" : "");
+  return SWG_OK;
+}
+
+// The scaffold stage for records grouped by chromosome pair.  *taken = 0: not applicable (not grouped, a pair too long, or a
+// condition found on the device) -- nothing the caller cannot overwrite was done, and it runs the global-sort path.
+// alive / member: nullptr = step-1 retain evaluated here / members == alive records.
+int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive, const uint8_t* member,
+                         bool sweep_assumed_identity, uint8_t* status_out, uint32_t* chain_out, swg_stats* stats, int* taken,
+                         const PairPlan* plan_in) {
+  *taken = 0;
+  PairPlan own;
+  if (!plan_in) {
+    SWG_TRY(pair_plan(ctx, r, cfg, &own));
+    plan_in = &own;
+  }
+  if (!plan_in->valid) return SWG_OK;
+  uint64_t kq, kt;
+  if (cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_ONE) {
+    kq = kt = 1;
+  } else {
+    kq = cfg->scaffold_max_per_query ? cfg->scaffold_max_per_query : SWG_K_INF;
+    kt = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
+  }
+  const bool limited = kq != SWG_K_INF || kt != SWG_K_INF;  // the scaffold sweep has limits: it runs over a chain table
+  const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
+  const uint32_t n = (uint32_t)r->n;
+  hipStream_t st = ctx->stream;
+  static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+  const swg_arena_mark mark0 = swg_arena_save(ctx);
+  const bool by_hash = plan_in->by_hash;
+  const uint32_t cap = plan_in->cap, n_runs = plan_in->n_runs;
+  const uint32_t ncls[4] = {plan_in->ncls[0], plan_in->ncls[1], plan_in->ncls[2], plan_in->ncls[3]};
+  PairCounters* C = static_cast<PairCounters*>(plan_in->counters);
+  PairRun* runs = static_cast<PairRun*>(plan_in->runs);
+  uint32_t* class_list = static_cast<uint32_t*>(plan_in->class_list);
+  uint32_t* perm = static_cast<uint32_t*>(plan_in->perm);
+  // (a plan may be used twice -- an unlimited mapping sweep taken as the identity, then the real one: everything but the
+  // pairs' own counts starts from zero)
+  SWG_HIP(ctx, hipMemsetAsync(reinterpret_cast<char*>(C) + offsetof(PairCounters, flags), 0, sizeof(uint32_t), st));
+  SWG_HIP(ctx, hipMemsetAsync(reinterpret_cast<char*>(C) + offsetof(PairCounters, n_chunks), 0, sizeof(PairCounters) - offsetof(PairCounters, n_chunks), st));
   // ---- scratch, addressed by the pair's offset in the input
   uint8_t* code = swg_alloc<uint8_t>(ctx, n);
   uint32_t* s_qs = swg_alloc<uint32_t>(ctx, n);

@@ -241,8 +241,20 @@ int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int 
                             int pos_bits, uint8_t* kept);
 
 // The scaffold stage for inputs grouped by chromosome pair (swg_pair.hip): one work-group per pair, the pair's members sorted
-// inside LDS.  *taken = 0: not applicable -- the caller runs the global-sort stage (swg_scaffold_stage's own path).
+// inside LDS.  pair_plan finds the pairs (runs of the input, or a hash table for small inputs) and reads their number back;
+// valid = 0: not applicable (not grouped, a pair too long ...).  The plan's device arrays live in the caller's arena frame, so
+// it can be made before a mapping sweep (which then knows that nobody will ask for its sorted order) and used after it.
+struct PairPlan {
+  int valid = 0;
+  bool by_hash = false;
+  uint32_t n_runs = 0, ncls[4] = {0, 0, 0, 0}, cap = 0;
+  void *counters = nullptr, *runs = nullptr, *class_list = nullptr, *perm = nullptr;
+};
+int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPlan* plan);
+// *taken = 0: not applicable, or left on a condition found on the device -- the caller runs the global-sort stage
+// (swg_scaffold_stage's own path).  plan: from pair_plan, or nullptr (made here).
 int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive, const uint8_t* member,
-                         bool sweep_assumed_identity, uint8_t* status_out, uint32_t* chain_out, swg_stats* stats, int* taken);
+                         bool sweep_assumed_identity, uint8_t* status_out, uint32_t* chain_out, swg_stats* stats, int* taken,
+                         const PairPlan* plan = nullptr);
 
 }  // namespace swg_scaf
