@@ -1888,7 +1888,10 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   if (!A.scaffolds_only && A.rescue_d) {
     __syncthreads();  // every anchor's number is in anum (marks, inversion capture); the chain list in l_all is done with
     const uint64_t D = A.rescue_d, max_s2 = A.max_s2;
-    const uint32_t dc = D >= 0xffffffffull ? 0u : (uint32_t)D + 1u;  // cell width (0: one cell holds every 32-bit coordinate)
+    // cell width: the power of two from D + 1 up -- a shift, and two centres within D of each other still lie in the same cell
+    // or in neighbouring ones (32: one cell holds every 32-bit coordinate)
+    int cell_sh = 0;
+    while (cell_sh < 32 && (1ull << cell_sh) <= D) ++cell_sh;
     // (bin starts and cursors are 16-bit: KA < 2^16; the cursors are bumped by 32-bit atomics on the word that holds two)
     constexpr uint32_t NB = (uint32_t)KP / 2u, KA = (4u * (uint32_t)KP - NB - 1u) / 3u, BT = NB / NT;
     static_assert(KA >= (uint32_t)NT * U && KA < 65536u && NB % (2 * NT) == 0, "one round of anchors fits a batch; whole words of bins per thread");
@@ -1903,7 +1906,9 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     };
     uint32_t* const c_num = A.f_qe + a;        // (a chain list of the inversion capture: free from here on)
     auto is_anchor = [](uint32_t an) { return an != 0u && an < 0x80000000u; };
-    auto bin_of = [&](uint32_t qc) -> uint32_t { return (dc ? qc / dc : 0u) % NB; };
+    static_assert((NB & (NB - 1u)) == 0u && NB >= 4u, "bins by the cell's low bits");
+    auto cell_of = [&](uint32_t qc) -> uint32_t { return cell_sh < 32 ? qc >> cell_sh : 0u; };
+    auto bin_of = [&](uint32_t qc) -> uint32_t { return cell_of(qc) & (NB - 1u); };
     uint32_t pb = 0, r0 = 0;
     while (pb < M) {  // (uniform)
       for (uint32_t b = tid; b < NB / 2; b += NT) b_cur[b] = 0u;
@@ -2000,14 +2005,9 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
           if (p >= M || !(st == 0u || (st >= 0x80000000u && st != NEVER))) continue;
           const uint32_t qc32 = (uint32_t)(((uint64_t)qs[u] + qe[u]) / 2);
           const uint64_t qc = qc32, tc = ((uint64_t)ts[u] + te[u]) / 2;
-          const uint32_t cell = dc ? qc32 / dc : 0u;
           uint32_t best_idx = st ? st & 0x7fffffffu : NONE, best_e = NONE;
-#pragma unroll 1
-          for (int d = -1; d <= 1; ++d) {
-            if (d < 0 && cell == 0u) continue;  // (NB >= 3: three different bins; a bin read for a cell beyond the last one is harmless)
-            const uint32_t b = (cell + (uint32_t)d) % NB;
-            const uint32_t k1 = b_start[b + 1];
-            for (uint32_t k = b_start[b]; k < k1; ++k) {
+          auto scan = [&](uint32_t k0, uint32_t k1) {
+            for (uint32_t k = k0; k < k1; ++k) {
               const uint64_t aq = g_qc[k];
               const uint64_t q_diff = qc > aq ? qc - aq : aq - qc;
               if (q_diff > D) continue;
@@ -2020,6 +2020,18 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
                 best_e = k;
               }
             }
+          };
+          // the cell's bin and its two neighbours are consecutive bins, i.e. ONE stretch of the binned anchors -- unless the bin
+          // is the first or the last one, where the neighbour wraps around (a bin read for a cell that does not exist is harmless)
+          const uint32_t b = bin_of(qc32);
+          if (b != 0u && b != NB - 1u) {
+            scan(b_start[b - 1], b_start[b + 2]);
+          } else if (b == 0u) {
+            scan(b_start[0], b_start[2]);
+            scan(b_start[NB - 1], b_start[NB]);
+          } else {
+            scan(b_start[NB - 2], b_start[NB]);
+            scan(b_start[0], b_start[1]);
           }
           if (best_e != NONE) {
             const uint32_t i = A.s_idx[a + p] & 0x7fffffffu;
