@@ -2097,12 +2097,14 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
 // Pair-resident path: the block plan of the long chunks, made on the device.  One work-group per long chunk: the longest window
 // (how many later members start within q_end + gap: the members are sorted by q_start, a binary search each), the block size S
 // (a multiple of 64, >= longest window + 1, >= 512), the block descriptors appended to one list, `ext` cleared.
+constexpr uint32_t PAIR_LONG_WINDOW_MAX = 512;
 __global__ __launch_bounds__(EW) void pair_long_plan_kernel(uint32_t cap_long, const uint32_t* __restrict__ n_long_dev,
                                                             const uint32_t* __restrict__ long_list, const SpecBlock* __restrict__ chunks,
                                                             const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
                                                             uint64_t max_gap, SpecBlock* __restrict__ desc, uint32_t cap_spec,
                                                             uint32_t* __restrict__ counters /* [0] n_spec, [1] overflow */,
-                                                            unsigned long long* __restrict__ ext) {
+                                                            unsigned long long* __restrict__ ext, uint32_t* __restrict__ flags,
+                                                            uint32_t fallback_bit) {
   __shared__ uint32_t wmaxs[EW / 64];
   __shared__ uint32_t sh_off;
   const uint32_t n_long = *n_long_dev < cap_long ? *n_long_dev : cap_long;
@@ -2153,6 +2155,13 @@ __global__ __launch_bounds__(EW) void pair_long_plan_kernel(uint32_t cap_long, c
     __syncthreads();
     for (int k = 0; k < EW / 64; ++k)
       if (wmaxs[k] > w) w = wmaxs[k];
+    // a deep unit (hundreds of members inside the gap limit of one): the blocks of the speculative walk would have to be as long
+    // as the windows, and each step a pass over hundreds of candidates -- that is the global-sort stage's case (candidate lists by
+    // a wavefront per member): the call is handed over before any round runs
+    if (w > PAIR_LONG_WINDOW_MAX) {
+      if (threadIdx.x == 0) atomicOr(flags, fallback_bit);
+      continue;
+    }
     uint32_t S = ((w + 1 + 63) / 64) * 64;
     if (S < 512) S = 512;
     const uint32_t nb = (e - b + S - 1) / S;
@@ -3163,7 +3172,7 @@ int pair_walk_long_launch(swg_ctx* ctx, uint32_t cap_long, const uint32_t* n_lon
   SWG_HIP(ctx, hipMemsetAsync(counters, 0, (2 + ROUNDS) * sizeof(uint32_t), st));
   const unsigned pg = cap_long < (uint32_t)ctx->num_cu * 4 ? cap_long : (unsigned)ctx->num_cu * 4;
   SWG_LAUNCH(ctx, "spec_plan", pair_long_plan_kernel<<<pg, EW, 0, st>>>(cap_long, n_long_dev, long_list, chunks, s_qs, s_qe, max_gap, desc, cap_spec,
-                                                              counters, ext));
+                                                              counters, ext, flags, fallback_bit));
   SWG_KERNEL_CHECK(ctx);
   const unsigned rblocks = cap_spec < (uint32_t)ctx->num_cu * 8 ? cap_spec : (unsigned)ctx->num_cu * 8;
   const unsigned wblocks = cap_spec < (uint32_t)ctx->num_cu * 32 ? cap_spec : (unsigned)ctx->num_cu * 32;

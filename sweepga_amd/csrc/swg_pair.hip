@@ -1456,6 +1456,16 @@ __global__ __launch_bounds__(1024) void pair_sort_big_kernel(PairSortArgs A, con
     pair_sort_body<1024, 16, 32, 4096, 1024, false>(A, A.list[blockIdx.x - n_xl], raw);
 }
 
+// A call that is being handed over to the global-sort stage (PF_FALLBACK raised by a pair_sort work-group or by the plan of
+// the long units): the walk and the labelling take their chunk counts from the device, so clearing them makes the kernels
+// still to come return at once instead of walking and labelling 10^8 members for nothing.
+__global__ void pair_gate_kernel(PairCounters* __restrict__ C) {
+  if (threadIdx.x == 0 && (C->flags & PF_FALLBACK)) {
+    C->n_chunks = 0u;
+    C->n_long = 0u;
+  }
+}
+
 // ---- pair_finish ----------------------------------------------------------------------------------------------------
 struct PairFinishArgs {
   const PairRun* runs;
@@ -2328,6 +2338,13 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
     swg_arena_restore(ctx, mark0);
     return SWG_OK;
   }
+  // a few very long pairs (the average beyond the third size class): one work-group per pair would leave most of the chip idle,
+  // and pairs of that size are deep more often than not -- the global-sort stage's case
+  if ((uint64_t)n / n_runs > PAIR_L_MAX) {
+    if (dbg) fprintf(stderr, "[swg] pair path: %u pairs of %llu records on average: left to the global-sort stage\n", n_runs, (unsigned long long)n / n_runs);
+    swg_arena_restore(ctx, mark0);
+    return SWG_OK;
+  }
   plan->valid = 1;
   plan->by_hash = by_hash;
   plan->n_runs = n_runs;
@@ -2449,11 +2466,20 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
       SWG_KERNEL_CHECK(ctx);
     }
   }
+  if (!by_hash) {  // (large inputs only: what a small one walks for nothing is not worth a launch)
+    SWG_LAUNCH(ctx, "pair_gate", pair_gate_kernel<<<1, 64, 0, st>>>(C));
+    SWG_KERNEL_CHECK(ctx);
+  }
   SWG_TRY(pair_walk_launch(ctx, cap_chunks, &C->n_chunks, chunks, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred));
   const bool long_possible = ncls[2] + ncls[3] > 0;  // (a chunk of LABEL_CAP_ELEMS members needs a pair of at least as many)
-  if (long_possible)
+  if (long_possible) {
     SWG_TRY(pair_walk_long_launch(ctx, cap_long, &C->n_long, long_list, chunks, n, s_qs, s_qe, s_ts, s_te, cfg->scaffold_gap, bps, pred,
                                   &C->flags, PF_FALLBACK));
+    if (!by_hash) {
+      SWG_LAUNCH(ctx, "pair_gate", pair_gate_kernel<<<1, 64, 0, st>>>(C));
+      SWG_KERNEL_CHECK(ctx);
+    }
+  }
   SWG_TRY(pair_label_launch(ctx, cap_chunks, &C->n_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b, cfg->min_scaffold_length,
                             cfg->min_scaffold_identity, hd, ok_head, head_rec, &C->n_heads, long_possible ? cap_long : 0u, &C->n_long, long_list));
   // ---- a scaffold filter with limits: plane_sweep_both over the chain table of the whole input

@@ -2,7 +2,10 @@
 """Million-record shapes the bench workload does not have, GPU vs oracle (exact status and chain numbers):
 single giant chromosome pair at high depth, many chromosomes per genome (segments spanning several target sequences),
 thousands of tiny genome pairs, heavy coordinate ties, minus-strand only.  Oracle runs are spread over host threads.
-    python tests/fuzz/fuzz_large.py [--records 1500000]"""
+--pair-major: the same shapes with the records grouped by (query, target) pair, pairs in random order -- what an aligner writes:
+inputs of this size then take the pair-resident scaffold stage through the runs of the input (csrc/swg_pair.hip; without the
+flag the records come in random order, which is the global-sort stage's case), and the launch table must show that it ran.
+    python tests/fuzz/fuzz_large.py [--records 1500000] [--pair-major]"""
 import argparse
 import json
 import os
@@ -25,6 +28,8 @@ SHAPES = [
     dict(name="ties_grid", n_genomes=4, chrs_per_genome=3, span=400_000, max_len=6_000, syntenic_frac=0.7, scale=0.6, grid=500),
     dict(name="minus_only", n_genomes=5, chrs_per_genome=2, span=5_000_000, max_len=10_000, syntenic_frac=0.9, scale=1.0, minus_frac=1.0),
     dict(name="non_pansn_names", n_genomes=8, chrs_per_genome=3, span=1_000_000, max_len=6_000, syntenic_frac=0.6, scale=1.0, pansn=False),
+    # ~39,800 pairs of ~25 records: more pairs than the wavefront-per-key numbering takes (the radix path of pair_number)
+    dict(name="tiny_pairs_40k", n_genomes=200, chrs_per_genome=1, span=200_000, max_len=4_000, syntenic_frac=0.8, scale=0.66),
 ]
 CONFIGS = [
     ("sweep", dict(mapping_filter_mode="OneToOne", scaffold_gap=0)),
@@ -39,7 +44,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=1_500_000)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--pair-major", action="store_true")
     args = ap.parse_args()
+    ctx = sw.default_context(0)
     results, lock = [], threading.Lock()
     jobs = []
     t_all = time.time()
@@ -52,6 +59,9 @@ def main():
         if "grid" in shape:
             for a in (rec.qs, rec.qe, rec.ts, rec.te):
                 a[:] = a // shape["grid"] * shape["grid"]
+        if args.pair_major:
+            from tests.test_gpu_pairs import pair_major
+            rec = pair_major(rec, rng)
         packed = sw.pack_records(gen.records_to_meta(rec))
         for cname, kw in CONFIGS:
             kwg = {k: (getattr(sw.FilterMode, v) if isinstance(v, str) else v) for k, v in kw.items()}
@@ -59,6 +69,15 @@ def main():
             t0 = time.perf_counter()
             st, ch = f.filter_columns(packed)
             gpu_s = time.perf_counter() - t0
+            if args.pair_major and kw.get("scaffold_gap", 1) != 0 and os.environ.get("SWG_GROUP_FUSED", "1") != "0":
+                ctx.profile_reset()
+                ctx.profile(True)
+                f.filter_columns(packed)
+                ctx.profile(False)
+                table = ctx.profile_table()
+                took = "pair_renumber" in table and "chain_cuts" not in table and "cuts_from_scan" not in table
+                print("   path:", shape["name"], cname, "pair-resident" if took else "global-sort (a pair beyond the largest size class, or a condition met on the device)", flush=True)
+                assert took or shape["name"] == "giant_pair_deep", (shape["name"], cname, sorted(table))
             okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in kw.items()}
             jobs.append((shape["name"], cname, rec, orc.Config(**okw), st.copy(), ch.copy(), gpu_s))
         print("generated + filtered", shape["name"], n, flush=True)

@@ -35,3 +35,4 @@ run gpu_stream SWG_STREAM_CHUNK=700 python3 tests/fuzz/fuzz_gpu.py --minutes $MI
 run seams      X=1                python3 tests/fuzz/fuzz_seams.py --minutes $MIN --seed 15
 run cli        X=1                python3 tests/fuzz/fuzz_cli.py --minutes $MIN --seed 16
 run large      X=1                python3 tests/fuzz/fuzz_large.py --seed 17
+run large_pm   X=1                python3 tests/fuzz/fuzz_large.py --seed 24 --pair-major
