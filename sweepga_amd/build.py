@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsweepga_gpu.so")
-SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_chain.hip", "swg_chain_table.hip", "swg_scaffold_sweep.hip", "swg_scaffold.hip", "swg_pair.hip",
+SOURCES = ["swg_context.hip", "swg_sort.hip", "swg_sweep.hip", "swg_filter.hip", "swg_chain.hip", "swg_chain_table.hip", "swg_scaffold_sweep.hip", "swg_scaffold.hip", "swg_pair.hip", "swg_segsort.hip",
            "swg_union_find.hip", "swg_ani.hip", "swg_shard.hip", "swg_stream.hip",
            os.path.join("host", "paf_io.cpp"), os.path.join("host", "tree_filter.cpp"),
            os.path.join("host", "alnstats.cpp")]

@@ -154,7 +154,8 @@ void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, ui
 
 // ---- mapping-level sweep ----------------------------------------------------------------------
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
-                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order, int* q_order_valid) {
+                      const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order, int* q_order_valid,
+                      const void* pair_runs, uint32_t n_pair_runs, const uint64_t* score_key, uint64_t n_alive) {
   const uint64_t n = r->n;
   uint64_t kq, kt;
   limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
@@ -185,6 +186,18 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
   ax.packed_end = 0;
   ax.sorted_idx_out = q_order;
   ax.sorted_idx_valid = q_order ? q_order_valid : nullptr;
+  if (pair_runs && score_key && !key_ends && !q_order) {
+    // the input is grouped by (query, target) pair: a segment of either axis is a handful of whole runs, sorted in LDS
+    uint32_t* run_alive = swg_alloc<uint32_t>(ctx, n_pair_runs);
+    SWG_CHECK_ARENA(ctx);
+    SWG_TRY(swg_seg_run_alive(ctx, pair_runs, n_pair_runs, alive, run_alive));
+    ax.seg_runs = pair_runs;
+    ax.n_seg_runs = n_pair_runs;
+    ax.seg_run_alive = run_alive;
+    ax.n_alive = n_alive;
+    ax.score_key = score_key;
+    ax.packed = nullptr;
+  }
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, cfg->overlap_threshold, keep_q));
   ax.sorted_idx_out = nullptr;
   ax.sorted_idx_valid = nullptr;
@@ -225,11 +238,16 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   // sweep would drop (zero length), or anything else it does not cover.  Behind a mapping sweep it takes the sweep's flags
   // (further down), and the sweep is told that nobody will ask for its sorted order.
   swg_scaf::PairPlan pair_plan;
-  if (cfg->scaffold_gap != 0) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
   {
     uint64_t kq1, kt1;
     limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
-    if (pair_plan.valid && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
+    // (the plan also serves a mapping sweep with limits: its axes sort their begins segment by segment over the plan's runs)
+    if (cfg->scaffold_gap != 0 || (kq1 != SWG_K_INF || kt1 != SWG_K_INF)) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
+  }
+  {
+    uint64_t kq1, kt1;
+    limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
+    if (pair_plan.valid && cfg->scaffold_gap != 0 && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
       int taken = 0;
       SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, nullptr, nullptr, true, status_out, chain_out, stats, &taken, &pair_plan));
       if (taken) return SWG_OK;
@@ -251,7 +269,11 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   static const int slots_knob = getenv("SWG_SLOTS") ? atoi(getenv("SWG_SLOTS")) : -1;
   const uint64_t pairs_ub = (uint64_t)r->n_seq * r->n_seq ? (uint64_t)r->n_seq * r->n_seq : 1;
   const bool deep_pairs = slots_knob >= 0 ? slots_knob != 0 : n / pairs_ub >= (uint64_t(1) << 17);
-  swg_key_ends* key_ends = (sweeps || (cfg->scaffold_gap != 0 && deep_pairs)) ? swg_alloc<swg_key_ends>(ctx, n) : nullptr;
+  // a sweep over a pair-grouped input (the plan's runs; not the small inputs grouped through the hash table) sorts its begins
+  // segment by segment in LDS and reads plain columns: the score keys as 8 bytes per record instead of the 32-byte slots
+  const bool seg_sweep = sweeps && pair_plan.valid && !pair_plan.by_hash;
+  uint64_t* score_col = seg_sweep ? swg_alloc<uint64_t>(ctx, n) : nullptr;
+  swg_key_ends* key_ends = ((sweeps && !seg_sweep) || (cfg->scaffold_gap != 0 && deep_pairs)) ? swg_alloc<swg_key_ends>(ctx, n) : nullptr;
   // Shallow pairs, nothing sweeps, a scaffold stage follows: whether the slots pay depends on the ORDER of the input -- records
   // grouped by sequence pair (what an aligner writes) keep a pair's columns in L2, any other order does not (S-pan shuffled:
   // 28.8 ms with the column gathers).  That is probed on the device (input_order_probe_kernel); prepare writes the slots and the
@@ -273,7 +295,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && !pair_plan.valid && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   ctx->call_group32 = group32;
-  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends ? key_ends : probe_slots, sweeps, scalars, group32, probe_flag));
+  SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends ? key_ends : probe_slots, sweeps, scalars, group32, probe_flag, score_col));
   uint64_t h[3];
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(scalars), h, 3));
   const int pos_bits = swg_bits_for(h[0]) ? swg_bits_for(h[0]) : 1;
@@ -289,7 +311,9 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   uint32_t* q_order = cfg->scaffold_gap != 0 && !(pair_plan.valid && sweeps) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   int q_order_valid = 0;
-  if (!sweep_is_identity) SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid));
+  if (!sweep_is_identity)
+    SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid, seg_sweep ? pair_plan.runs : nullptr,
+                              pair_plan.n_runs, score_col, h[1]));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(keep1) | reinterpret_cast<uintptr_t>(status_out) | reinterpret_cast<uintptr_t>(chain_out);

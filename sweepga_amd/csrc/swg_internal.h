@@ -302,8 +302,18 @@ struct swg_axis_input {
   int packed_end = 0;                    //   which end of `packed` is this axis' end
   uint32_t* sorted_idx_out = nullptr;    // optional [n]: the record indices in (segment, start, index) order, dead first --
   int* sorted_idx_valid = nullptr;       //   *valid = 1 when the begins were sorted (not for k = inf without zero lengths)
+  // optional: the input is grouped by (seg_a, seg_b) pair and these are its runs (device array of {first record, length}); the
+  // begins are then sorted segment by segment in LDS (swg_segsort.hip) instead of by the radix sort.  Needs score_key / end as
+  // plain columns (packed == nullptr), the live records per run and their total.
+  const void* seg_runs = nullptr;
+  uint32_t n_seg_runs = 0;
+  const uint32_t* seg_run_alive = nullptr;
+  uint64_t n_alive = 0;
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
+int swg_seg_run_alive(swg_ctx* ctx, const void* runs, uint32_t n_runs, const uint8_t* alive, uint32_t* run_alive);
+int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
+                        uint32_t ntilesf, uint8_t* single, int* done);
 // Both axes with k = inf in one pass; *done = 0 when zero-length intervals exist (then the per-axis calls are needed).
 int swg_kinf_both(swg_ctx* ctx, uint64_t n, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts, const uint32_t* te,
                   const uint8_t* alive, uint8_t* keep, int* done);
@@ -315,4 +325,4 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
 // Step-1 retain (src/paf_filter.rs:384-388), score keys and the two scalars the pipeline needs, in one pass over
 // the records: scalars[0] = max coordinate, scalars[1] = number of retained records (device u64, pre-zeroed).
 int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
-                unsigned long long* scalars, uint32_t* group32 = nullptr, uint32_t* probe_flag = nullptr);
+                unsigned long long* scalars, uint32_t* group32 = nullptr, uint32_t* probe_flag = nullptr, uint64_t* score_out = nullptr);

@@ -6,9 +6,13 @@
 // target genome), target-axis sweep per (target sequence, query genome), intersection.
 // q_order (optional, [n]): receives the records in the query axis' sorted order (segment = (query sequence, target genome),
 // then q_start, then index; dead records first); *q_order_valid says whether it was produced.
+// pair_runs (optional): the input is grouped by (query, target) pair and these are its runs (swg_scaf::PairPlan): with
+// score_key (8 bytes per record, written by swg_prepare), key_ends == nullptr and no q_order the axes sort their begins segment
+// by segment in LDS (swg_segsort.hip); n_alive = the retained records.
 int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, const uint8_t* alive,
                       const swg_key_ends* key_ends, int pos_bits, uint8_t* keep, uint32_t* q_order = nullptr,
-                      int* q_order_valid = nullptr);
+                      int* q_order_valid = nullptr, const void* pair_runs = nullptr, uint32_t n_pair_runs = 0,
+                      const uint64_t* score_key = nullptr, uint64_t n_alive = 0);
 
 // Streamed host path (csrc/swg_stream.hip): ranges of whole query genomes, uploads overlapped with the filter.  *taken = 0:
 // not applicable (input not grouped by query genome, too small, SWG_STREAM=0), nothing was done; the caller runs its own path.

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
                                                              int with_keys, unsigned long long* __restrict__ scalars,
                                                              const uint8_t* __restrict__ strand, uint32_t n_seq,
                                                              uint32_t* __restrict__ group32,
-                                                             const uint32_t* __restrict__ probe_flag) {
+                                                             const uint32_t* __restrict__ probe_flag,
+                                                             uint64_t* __restrict__ score_out) {
   if (probe_flag && *probe_flag == 0) key_ends = nullptr;  // (wave-uniform) grouped input: the slots are not worth their traffic
   uint32_t mx = 0, cnt = 0, zero = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * EW_THREADS) {
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     alive[i] = ok ? 1 : 0;
     // the (query, target, strand) group as one 4-byte value: sort A behind a mapping sweep then gathers one column, not three
     if (group32) group32[i] = (q_id[i] * n_seq + t_id[i]) * 2u + (strand[i] ? 1u : 0u);
+    if (score_out) score_out[i] = score_key_of(a, b, id, scoring);  // (the segment-resident sort reads plain columns: swg_segsort.hip)
     if (key_ends) {  // nullptr: neither a mapping-level sweep nor a scaffold stage will read the record slots
       swg_key_ends ke;
       ke.key = with_keys ? score_key_of(a, b, id, scoring) : 0ull;  // (no sweep: nobody reads the scores)
@@ -1508,7 +1510,7 @@ int swg_score_keys(swg_ctx* ctx, uint64_t n, const uint32_t* q_start, const uint
 }
 
 int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8_t* alive, swg_key_ends* key_ends, bool with_keys,
-                unsigned long long* scalars, uint32_t* group32, uint32_t* probe_flag) {
+                unsigned long long* scalars, uint32_t* group32, uint32_t* probe_flag, uint64_t* score_out) {
   if (r->n == 0) return SWG_OK;
   if (probe_flag) {
     SWG_LAUNCH(ctx, "input_order_probe", input_order_probe_kernel<<<1, 256, 0, ctx->stream>>>(r->n, r->q_id, r->t_id, probe_flag));
@@ -1517,7 +1519,7 @@ int swg_prepare(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, uint8
   SWG_LAUNCH(ctx, "prepare", prepare_kernel<<<ctx->num_cu * 16, EW_THREADS, 0, ctx->stream>>>(
                                  r->n, r->q_id, r->t_id, r->block_len, r->matches, r->identity, r->q_start, r->q_end, r->t_start, r->t_end,
                                  cfg->min_block_length, cfg->keep_self, cfg->min_identity, cfg->scoring_function, alive, key_ends,
-                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars, r->strand, r->n_seq, group32, probe_flag));
+                                 cfg->scaffold_gap != 0 ? 1 : 0, with_keys ? 1 : 0, scalars, r->strand, r->n_seq, group32, probe_flag, score_out));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
@@ -1552,6 +1554,23 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     tile_xf = swg_alloc<uint64_t>(ctx, (size_t)ntilesf + 1);
     single = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
+    if (in.seg_runs && !in.sorted_idx_out) {
+      // records grouped by (seg_a, seg_b) pair: the begins sorted segment by segment in LDS (swg_segsort.hip); E and KEY in
+      // buffers of their own (the radix path takes them from its scratch)
+      const swg_arena_mark seg_mark = swg_arena_save(ctx);
+      uint32_t* E2 = swg_alloc<uint32_t>(ctx, n);
+      SWG_CHECK_ARENA(ctx);
+      SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
+      int done = 0;
+      SWG_TRY(swg_seg_sort_begins(ctx, in, S, I, E2, KEY, tile_xf, ntilesf, single, &done));
+      if (done) {
+        E = E2;
+        SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
+        SWG_KERNEL_CHECK(ctx);
+        return SWG_OK;
+      }
+      swg_arena_restore(ctx, seg_mark);
+    }
     // the sort's digit histograms come out of begin_build (when the onesweep path will run: up to 8 passes)
     static const bool sort_fallback = getenv("SWG_SORT_FALLBACK") != nullptr;
     uint32_t* prehist = nullptr;

@@ -77,7 +77,7 @@ def main():
                 table = ctx.profile_table()
                 took = "pair_renumber" in table and "chain_cuts" not in table and "cuts_from_scan" not in table
                 print("   path:", shape["name"], cname, "pair-resident" if took else "global-sort (a pair beyond the largest size class, or a condition met on the device)", flush=True)
-                assert took or shape["name"] == "giant_pair_deep", (shape["name"], cname, sorted(table))
+                assert took or shape["name"] in ("giant_pair_deep", "ties_grid"), (shape["name"], cname, sorted(table))  # (deep pairs, heavy ties)
             okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in kw.items()}
             jobs.append((shape["name"], cname, rec, orc.Config(**okw), st.copy(), ch.copy(), gpu_s))
         print("generated + filtered", shape["name"], n, flush=True)
