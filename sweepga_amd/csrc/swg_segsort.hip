@@ -536,28 +536,7 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
       for (int e = 0; e < H; ++e)
         if ((batch_mask >> (g + e)) & 1u) buf[(slotw[(g + e) / 2] >> (16 * ((g + e) & 1))) & 0xffffu] = v[e];
     };
-    // the record indices
-    {
-      tid_v = fresh_tid();
-#pragma unroll
-      for (int g = 0; g < ER; g += H) {
-        if ((uint32_t)g * NT >= m) continue;
-        uint32_t v[H];
-#pragma unroll
-        for (int e = 0; e < H; ++e) v[e] = rec_index(g + e);
-        put_group(g, v, K);
-        asm volatile("" ::: "memory");
-      }
-      lds_barrier();
-      const uint32_t t_st = fresh_tid();
-#pragma unroll
-      for (int e = 0; e < ES; ++e) {
-        const uint32_t p = t_st + (uint32_t)e * NT;
-        if (p < mb) A.I[gbase + p] = K[p];
-      }
-      lds_barrier();
-    }
-    // the ends
+    // the record indices and the ends (two buffers: K, and the room of I and RR, both done with)
     {
       tid_v = fresh_tid();
 #pragma unroll
@@ -568,7 +547,8 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
         for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
 #pragma unroll
         for (int e = 0; e < H; ++e) v[e] = A.end[ixv[e]];
-        put_group(g, v, K);
+        put_group(g, ixv, K);
+        put_group(g, v, B2);
         asm volatile("" ::: "memory");
       }
       lds_barrier();
@@ -576,7 +556,10 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
 #pragma unroll
       for (int e = 0; e < ES; ++e) {
         const uint32_t p = t_st + (uint32_t)e * NT;
-        if (p < mb) A.E[gbase + p] = K[p];
+        if (p < mb) {
+          A.I[gbase + p] = K[p];
+          A.E[gbase + p] = B2[p];
+        }
       }
       lds_barrier();
     }
@@ -750,6 +733,7 @@ __device__ __forceinline__ void seg_sort_xl_body(const SegSortArgs& A, const uin
       A.E[gbase + p] = A.end[id];
       A.KEY[gbase + p] = A.score[id];
       if (((gbase + p) % TBF) == 0u) A.tile_xf[(gbase + p) / TBF] = s;
+      if (n_live == 1u) A.single[id] = 1;  // (a long run with one live record) returned whole by the reference
     }
     __syncthreads();
     base += mb;

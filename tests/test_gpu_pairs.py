@@ -215,3 +215,52 @@ print("ok")
     env = dict(os.environ, SWG_GROUP_FUSED="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_mapping_sweep_sorts_its_begins_segment_by_segment(sw):
+    """A mapping sweep over a pair-grouped input of more than 65,536 records takes the plan's runs: every axis' begins are sorted
+    per (sequence, genome of the other side) segment in LDS (csrc/swg_segsort.hip) -- segments of one run read in place, segments
+    of several runs (genomes with several chromosomes) through a list, dead records (step-1 filters) left out.  Against the
+    oracle, with the launch table showing the path, and SWG_SEG_SORT=0 (the radix sort) giving the same answer."""
+    rng = np.random.default_rng(31)
+    rec = gen.random_records(rng, 90_000, n_genomes=3, chrs_per_genome=3, span=2_000_000, zero_frac=0.0)
+    rec = pair_major(rec, rng)
+    for cfg in ({"mapping_filter_mode": "OneToOne", "scaffold_gap": 0},
+                {"mapping_filter_mode": "OneToOne", "scaffold_gap": 0, "min_identity": 0.85, "min_block_length": 400},
+                {"mapping_filter_mode": "OneToMany", "mapping_max_per_query": 2, "mapping_max_per_target": 3, "scaffold_gap": 0, "overlap_threshold": 0.5},
+                {"mapping_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 2_000, "scaffold_max_deviation": 4_000}):
+        run_both(sw, rec, cfg, expect_pair_path=None)
+        table = sw.default_context(0).profile_table()
+        assert any(k.startswith("seg_sort") for k in table) and "begin_gather_words" not in table and "begin_gather_packed" not in table, sorted(table)
+    # a run of 40,000 records with ONE live record (the longest size class, `single` set there), next to ordinary pairs
+    big = gen.random_records(rng, 40_000, n_genomes=1, chrs_per_genome=1, span=1_000_000, zero_frac=0.0, self_frac=0.0)
+    big.qname = ["x#1#c"] * 40_000
+    big.tname = ["y#1#c"] * 40_000
+    big.identity[:] = 0.5
+    big.matches[:] = (big.block_length * 0.5).astype(big.matches.dtype)
+    big.identity[:] = big.matches / np.maximum(big.block_length, 1)
+    big.identity[12_345] = 1.0
+    big.matches[12_345] = big.block_length[12_345]
+    both = orc.Records(big.qname + rec.qname, big.tname + rec.tname, *[np.concatenate([getattr(big, c), getattr(rec, c)])
+                                                                         for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
+                       np.arange(len(big) + len(rec), dtype=np.uint64))
+    run_both(sw, both, {"mapping_filter_mode": "OneToOne", "scaffold_gap": 0, "min_identity": 0.9}, expect_pair_path=None)
+    assert any(k.startswith("seg_sort") for k in sw.default_context(0).profile_table())
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import sweepga_amd as sw
+from tests import gen, orc
+from tests.test_gpu_pairs import pair_major
+rng = np.random.default_rng(31)
+rec = pair_major(gen.random_records(rng, 90000, n_genomes=3, chrs_per_genome=3, span=2000000, zero_frac=0.0), rng)
+ctx = sw.default_context(0)
+ctx.profile(True)
+st, ch = sw.PafFilter(sw.FilterConfig(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=0)).filter_columns(sw.pack_records(gen.records_to_meta(rec)))
+assert not any(k.startswith("seg_sort") for k in ctx.profile_table())
+ost, och = orc.apply_filters(orc.Config(mapping_filter_mode=int(sw.FilterMode.OneToOne), scaffold_gap=0), rec)
+assert np.array_equal(st, ost) and np.array_equal(ch, och)
+print("ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SWG_SEG_SORT="0"), capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
