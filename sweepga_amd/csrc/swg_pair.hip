@@ -1507,7 +1507,8 @@ struct PairChainArgs {
   double* T_wid;
   uint64_t* T_seg;
   uint32_t *chain_base, *np;
-  unsigned long long* totals;  // [0] chains in the table, [1] largest coordinate
+  PairRun* T_runs;             // the pairs' stretches of the table (those that hold a chain)
+  unsigned long long* totals;  // [0] chains in the table, [1] largest coordinate, [2] stretches
   const PairCounters* C;
 };
 template <int NT>
@@ -1554,6 +1555,12 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
     A.chain_base[rk] = cb;
     A.np[2 * rk] = nP;
     A.np[2 * rk + 1] = nM;
+    if (nP + nM) {  // the pair's stretch of the table: a run of the sweep's input (its begins are sorted segment by segment)
+      PairRun tr;
+      tr.a = cb;
+      tr.n = nP + nM;
+      A.T_runs[atomicAdd(&A.totals[2], 1ull)] = tr;
+    }
   }
   __syncthreads();
   if (nP + nM == 0) return;
@@ -2496,10 +2503,11 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     CA.T_seg = swg_alloc<uint64_t>(ctx, n);
     CA.chain_base = chain_base = swg_alloc<uint32_t>(ctx, n_runs);
     CA.np = np_arr = swg_alloc<uint32_t>(ctx, (size_t)2 * n_runs);
-    CA.totals = swg_alloc<unsigned long long>(ctx, 2);
+    CA.totals = swg_alloc<unsigned long long>(ctx, 3);
+    CA.T_runs = swg_alloc<PairRun>(ctx, n_runs);
     kept_flags = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
-    SWG_HIP(ctx, hipMemsetAsync(CA.totals, 0, 16, st));
+    SWG_HIP(ctx, hipMemsetAsync(CA.totals, 0, 24, st));
     for (int c = 0; c < 4; ++c) {
       if (!ncls[c]) continue;
       CA.list = class_list + (size_t)c * cap;
@@ -2510,13 +2518,13 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
       }
       SWG_KERNEL_CHECK(ctx);
     }
-    uint64_t ht[2];
-    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(CA.totals), ht, 2));
+    uint64_t ht[3];
+    SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(CA.totals), ht, 3));
     const uint64_t n_table = ht[0];
     if (n_table) {
       const int seg_bits = swg_bits_for(n_runs) ? swg_bits_for(n_runs) : 1, pos_bits = swg_bits_for(ht[1]) ? swg_bits_for(ht[1]) : 1;
       SWG_TRY(scaffold_sweep_segments(ctx, n_table, CA.T_seg, seg_bits, CA.T_qs, CA.T_qe, CA.T_ts, CA.T_te, CA.T_wid, kq, kt,
-                                      cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, kept_flags));
+                                      cfg->scaffold_overlap_threshold, cfg->scoring_function, pos_bits, kept_flags, CA.T_runs, (uint32_t)ht[2]));
     }
   }
   PairFinishArgs FA{};

@@ -238,7 +238,7 @@ int scaffold_sweep_and_number(swg_ctx* ctx, const ChainTable& T, uint32_t n_seq,
 // and what the pair-resident path runs over its own chain table when the scaffold filter has limits.
 int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int seg_bits, const uint32_t* qs, const uint32_t* qe,
                             const uint32_t* ts, const uint32_t* te, const double* wid, uint64_t kq, uint64_t kt, double thr, int scoring,
-                            int pos_bits, uint8_t* kept);
+                            int pos_bits, uint8_t* kept, const void* runs = nullptr, uint32_t n_runs = 0);
 
 // The scaffold stage for inputs grouped by chromosome pair (swg_pair.hip): one work-group per pair, the pair's members sorted
 // inside LDS.  pair_plan finds the pairs (runs of the input, or a hash table for small inputs) and reads their number back;

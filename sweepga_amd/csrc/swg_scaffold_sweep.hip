@@ -121,7 +121,7 @@ __global__ __launch_bounds__(EW) void assign_numbers_runs_kernel(uint64_t nc, co
 // index order inside a segment = the reference's order of the pair's chains.  kept[c] = 1 iff chain c survives both axes.
 int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int seg_bits, const uint32_t* qs, const uint32_t* qe,
                             const uint32_t* ts, const uint32_t* te, const double* wid, uint64_t kq, uint64_t kt, double thr, int scoring,
-                            int pos_bits, uint8_t* kept) {
+                            int pos_bits, uint8_t* kept, const void* runs, uint32_t n_runs) {
   hipStream_t st = ctx->stream;
   uint64_t* skey = swg_alloc<uint64_t>(ctx, nc);
   uint8_t* keep_q = swg_alloc<uint8_t>(ctx, nc);
@@ -133,7 +133,19 @@ int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int 
   ax.seg_bits = seg_bits;
   ax.pos_bits = pos_bits;
   ax.score_key = skey;
-  if (kq != SWG_K_INF || kt != SWG_K_INF) {  // a sorting sweep will run: the packed form of its inputs
+  // runs: every segment is one stretch of the table (the pair-resident stage's chain table): the axes sort their begins segment
+  // by segment in LDS (swg_segsort.hip) and read plain columns
+  static const int seg_knob = getenv("SWG_SEG_SORT") ? atoi(getenv("SWG_SEG_SORT")) : -1;
+  uint32_t* run_alive = nullptr;
+  if (runs && n_runs && seg_knob != 0 && nc > 16384) {
+    run_alive = swg_alloc<uint32_t>(ctx, n_runs);
+    SWG_CHECK_ARENA(ctx);
+    SWG_TRY(swg_seg_run_alive(ctx, runs, n_runs, nullptr, run_alive));
+    ax.seg_runs = runs;
+    ax.n_seg_runs = n_runs;
+    ax.seg_run_alive = run_alive;
+    ax.n_alive = nc;
+  } else if (kq != SWG_K_INF || kt != SWG_K_INF) {  // a sorting sweep will run: the packed form of its inputs
     swg_key_ends* slots = swg_alloc<swg_key_ends>(ctx, nc);
     SWG_CHECK_ARENA(ctx);
     SWG_LAUNCH(ctx, "chain_slots", chain_slots_kernel<<<nblk(nc), EW, 0, st>>>(nc, skey, qs, qe, ts, te, slots));
@@ -146,6 +158,10 @@ int scaffold_sweep_segments(swg_ctx* ctx, uint64_t nc, const uint64_t* seg, int 
   ax.packed_end = 0;
   SWG_TRY(swg_sweep_axis(ctx, ax, kq, thr, keep_q));
   ax.alive = keep_q;  // plane_sweep_both: the target sweep sees the query survivors only
+  if (run_alive) {
+    SWG_TRY(swg_seg_run_alive(ctx, runs, n_runs, keep_q, run_alive));
+    ax.n_alive = ~0ull;  // (their number comes back with the segment plan)
+  }
   ax.start = ts;
   ax.end = te;
   ax.packed_end = 1;

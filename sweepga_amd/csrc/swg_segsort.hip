@@ -101,12 +101,18 @@ __global__ __launch_bounds__(256) void run_alive_kernel(uint32_t n_runs, const R
 }
 __global__ __launch_bounds__(EW) void run_key_kernel(uint32_t n_runs, const Run* __restrict__ runs, const uint32_t* __restrict__ seg_a,
                                                      const uint32_t* __restrict__ seg_b, const uint32_t* __restrict__ seg_table,
-                                                     uint32_t seg_mul, int a_bits, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                     uint32_t seg_mul, const uint64_t* __restrict__ seg, int a_bits,
+                                                     uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
   const uint32_t k = blockIdx.x * EW + threadIdx.x;
   if (k >= n_runs) return;
   const uint32_t i = runs[k].a;
-  const uint32_t b = seg_b[i];
-  const uint64_t sg = (uint64_t)seg_a[i] * seg_mul + (seg_table ? seg_table[b] : b);
+  uint64_t sg;
+  if (seg) {
+    sg = seg[i];
+  } else {
+    const uint32_t b = seg_b[i];
+    sg = (uint64_t)seg_a[i] * seg_mul + (seg_table ? seg_table[b] : b);
+  }
   key[k] = (sg << a_bits) | i;  // runs of one segment in ascending input order: the segment's list is then in record index order
   val[k] = k;
 }
@@ -772,11 +778,12 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   *done = 0;
   static const int knob = getenv("SWG_SEG_SORT") ? atoi(getenv("SWG_SEG_SORT")) : -1;
   if (knob == 0) return SWG_OK;
-  if (!in.seg_runs || in.n_seg_runs == 0 || !in.score_key || in.packed || in.seg || !in.seg_run_alive) return SWG_OK;
+  if (!in.seg_runs || in.n_seg_runs == 0 || !in.score_key || in.packed || !in.seg_run_alive) return SWG_OK;
   const uint64_t n = in.n;
   const uint32_t n_runs = in.n_seg_runs;
   const int a_bits = swg_bits_for(n - 1) ? swg_bits_for(n - 1) : 1;
-  if (in.seg_bits + a_bits > 64 || n >= (uint64_t(1) << 31) || in.n_alive > n) return SWG_OK;
+  const bool count_known = in.n_alive != ~0ull;  // (~0: the live records' number is the runs' total, read back with the plan)
+  if (in.seg_bits + a_bits > 64 || n >= (uint64_t(1) << 31) || (count_known && in.n_alive > n)) return SWG_OK;
   hipStream_t st = ctx->stream;
   const Run* runs = static_cast<const Run*>(in.seg_runs);
   const swg_arena_mark mark = swg_arena_save(ctx);
@@ -794,13 +801,13 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   uint32_t* seg_base = swg_alloc<uint32_t>(ctx, n_runs);
   uint32_t* seg_len = swg_alloc<uint32_t>(ctx, n_runs);
   uint32_t* class_list = swg_alloc<uint32_t>(ctx, (size_t)4 * n_runs);
-  uint32_t* perm = swg_alloc<uint32_t>(ctx, in.n_alive + 1);
+  uint32_t* perm = swg_alloc<uint32_t>(ctx, (count_known ? in.n_alive : n) + 1);
   uint64_t* d_tot = swg_alloc<uint64_t>(ctx, 2);
   uint32_t* counters = swg_alloc<uint32_t>(ctx, 8);
   SWG_CHECK_ARENA(ctx);
   SWG_HIP(ctx, hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st));
   SWG_HIP(ctx, hipMemsetAsync(d_tot, 0, 2 * sizeof(uint64_t), st));
-  SWG_LAUNCH(ctx, "seg_run_key", run_key_kernel<<<nblk(n_runs), EW, 0, st>>>(n_runs, runs, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, a_bits, key, val));
+  SWG_LAUNCH(ctx, "seg_run_key", run_key_kernel<<<nblk(n_runs), EW, 0, st>>>(n_runs, runs, in.seg_a, in.seg_b, in.seg_table, in.seg_mul, in.seg, a_bits, key, val));
   SWG_KERNEL_CHECK(ctx);
   SWG_TRY(swg_radix_sort_pairs(ctx, &key, &val, &key2, &val2, n_runs, 0, in.seg_bits + a_bits));
   SWG_LAUNCH(ctx, "seg_flags", seg_flags_kernel<<<nblk(n_runs), EW, 0, st>>>(n_runs, key, val, a_bits, in.seg_run_alive, c, f));
@@ -827,7 +834,8 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   }
   const uint32_t ncls[4] = {(uint32_t)h[2], (uint32_t)(h[2] >> 32), (uint32_t)h[3], (uint32_t)(h[3] >> 32)};
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
-  if (h[0] != in.n_alive) {  // (the caller's count of live records and the runs' disagree: not this path's input)
+  const uint64_t n_alive = count_known ? in.n_alive : h[0];
+  if (h[0] != n_alive || n_alive > n) {  // (the caller's count of live records and the runs' disagree: not this path's input)
     if (dbg) fprintf(stderr, "[swg] segment sort: %llu live records in the runs, %llu expected: the general sort takes the axis\n",
                      (unsigned long long)h[0], (unsigned long long)in.n_alive);
     swg_arena_restore(ctx, mark);
@@ -836,7 +844,7 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   if (dbg)
     fprintf(stderr, "[swg] segment sort: %llu segments over %u runs (%u / %u / %u / %u by size class)\n", (unsigned long long)h[1], n_runs, ncls[0],
             ncls[1], ncls[2], ncls[3]);
-  const uint64_t n_dead = n - in.n_alive;
+  const uint64_t n_dead = n - n_alive;
   // the dead records' places (in front) and every tile start among them: zero
   if (n_dead) {
     SWG_HIP(ctx, hipMemsetAsync(S, 0, n_dead * sizeof(uint64_t), st));
