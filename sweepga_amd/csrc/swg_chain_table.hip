@@ -462,8 +462,8 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
         r_qe[u] = s_qe[p];
         r_ts[u] = s_ts[p];
         r_te[u] = s_te[p];
-        r_m[u] = s_m[p];
-        r_b[u] = s_b[p];
+        r_m[u] = s_m ? s_m[p] : 0u;  // (nullptr: the weighted identity is not asked for -- the pair-resident path without an identity floor)
+        r_b[u] = s_m ? s_b[p] : 0u;
         r_qs[u] = s_qs[p];
       }
 #pragma unroll
@@ -539,11 +539,11 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
       ++heads;
       hd[p] = p;
       uint32_t qe = s_qe[p], ts = s_ts[p], te = s_te[p];
-      uint64_t sm = s_m[p], sb = s_b[p];
+      uint64_t sm = s_m ? s_m[p] : 0u, sb = s_m ? s_b[p] : 0u;
       for (uint16_t nx = succ[k]; nx != NO;) {
         const uint32_t q = b + nx;
         const uint16_t nn = succ[nx];  // requested together with the member's values
-        const uint32_t a = s_qe[q], t0 = s_ts[q], t1 = s_te[q], mm = s_m[q], bb = s_b[q];
+        const uint32_t a = s_qe[q], t0 = s_ts[q], t1 = s_te[q], mm = s_m ? s_m[q] : 0u, bb = s_m ? s_b[q] : 0u;
         hd[q] = p;
         qe = a > qe ? a : qe;
         ts = t0 < ts ? t0 : ts;
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(1024) void chain_label_long_kernel(uint32_t cap_lon
         hr.qe = s_qe[p];
         hr.ts = s_ts[p];
         hr.te = s_te[p];
-        hr.wid = __longlong_as_double((long long)(unsigned long long)s_b[p]);  // sum of block lengths, as bits
-        hr.grp = s_m[p];                                                       // sum of matches
+        hr.wid = __longlong_as_double((long long)(unsigned long long)(s_m ? s_b[p] : 0u));  // sum of block lengths, as bits
+        hr.grp = s_m ? s_m[p] : 0u;                                                         // sum of matches
         rec[p] = hr;
       }
     }
@@ -632,8 +632,10 @@ __global__ __launch_bounds__(1024) void chain_label_long_kernel(uint32_t cap_lon
       atomicMax(&rec[h].qe, s_qe[p]);
       atomicMin(&rec[h].ts, s_ts[p]);
       atomicMax(&rec[h].te, s_te[p]);
-      atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].wid), (unsigned long long)s_b[p]);
-      atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].grp), (unsigned long long)s_m[p]);
+      if (s_m) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].wid), (unsigned long long)s_b[p]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&rec[h].grp), (unsigned long long)s_m[p]);
+      }
     }
     __syncthreads();
     for (uint32_t p = b + threadIdx.x; p < e; p += 1024) {

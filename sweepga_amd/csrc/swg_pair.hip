@@ -1031,10 +1031,12 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     }
     lds_barrier();
     PT_STAMP(9);
-    column(c_m, o_m);
-    lds_barrier();
-    PT_STAMP(10);
-    column(c_b, o_b);
+    if (A.s_m) {  // (nullptr: nobody asks for the chains' weighted identities -- no identity floor, no scaffold filter with limits)
+      column(c_m, o_m);
+      lds_barrier();
+      PT_STAMP(10);
+      column(c_b, o_b);
+    }
     base += mb;
     lds_barrier();
     PT_STAMP(11);
@@ -1400,8 +1402,8 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
         qe[e] = A.q_end[i];
         ts[e] = A.t_start[i];
         te[e] = A.t_end[i];
-        mm[e] = A.matches[i];
-        bb[e] = A.block_len[i];
+        mm[e] = A.s_m ? A.matches[i] : 0u;
+        bb[e] = A.s_m ? A.block_len[i] : 0u;
       }
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -1415,8 +1417,10 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
         A.s_qe[o] = qe[e];
         A.s_ts[o] = ts[e];
         A.s_te[o] = te[e];
-        A.s_m[o] = mm[e];
-        A.s_b[o] = bb[e];
+        if (A.s_m) {
+          A.s_m[o] = mm[e];
+          A.s_b[o] = bb[e];
+        }
         degenerate |= qs >= qe[e] || ts[e] >= te[e];
       }
     }
@@ -2392,6 +2396,10 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   const bool limited = kq != SWG_K_INF || kt != SWG_K_INF;  // the scaffold sweep has limits: it runs over a chain table
   const bool rescue = !cfg->scaffolds_only && cfg->scaffold_max_deviation != 0;
+  // a chain's weighted identity (sums of matches and block lengths over its members) is read by the identity floor and by the
+  // scores of a scaffold sweep with limits; without either the two columns are neither sorted nor summed (an identity is
+  // never negative or NaN, paf_filter.rs:896-913: a floor of zero or less passes every chain)
+  const bool need_wid = limited || !(cfg->min_scaffold_identity <= 0.0);
   const uint32_t n = (uint32_t)r->n;
   hipStream_t st = ctx->stream;
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
@@ -2443,7 +2451,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.max_gap = cfg->scaffold_gap;
   SA.runs = runs;
   SA.perm = perm;
-  SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = s_m; SA.s_b = s_b; SA.s_idx = s_idx; SA.pred = pred;
+  SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = need_wid ? s_m : nullptr; SA.s_b = need_wid ? s_b : nullptr; SA.s_idx = s_idx; SA.pred = pred;
   SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
   if (by_hash) {
     for (int c = 2; c >= 0; --c) {
@@ -2487,7 +2495,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
       SWG_KERNEL_CHECK(ctx);
     }
   }
-  SWG_TRY(pair_label_launch(ctx, cap_chunks, &C->n_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b, cfg->min_scaffold_length,
+  SWG_TRY(pair_label_launch(ctx, cap_chunks, &C->n_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, need_wid ? s_m : nullptr, need_wid ? s_b : nullptr, cfg->min_scaffold_length,
                             cfg->min_scaffold_identity, hd, ok_head, head_rec, &C->n_heads, long_possible ? cap_long : 0u, &C->n_long, long_list));
   // ---- a scaffold filter with limits: plane_sweep_both over the chain table of the whole input
   uint8_t* kept_flags = nullptr;
