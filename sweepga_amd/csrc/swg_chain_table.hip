@@ -524,52 +524,83 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
       for (uint32_t k = threadIdx.x; k < len; k += EW) hd[b + k] = b + l_hd[k];
       continue;
     }
-    for (uint32_t k = threadIdx.x; k < len; k += EW) {
-      const uint32_t pr = pred[b + k];
-      if (pr != NONE) succ[pr - b] = (uint16_t)k;  // one successor per element: no two writers
+    // (longer chunks: the values stay in memory.  The loads of LB elements per thread are requested together -- an element
+    // after the other is a memory round trip each, and a chunk of the pair-resident path is a whole unit of thousands of
+    // elements in ONE work-group: 35 round trips per pass and thread on S-pan, 150 us per chunk, before this was batched)
+    constexpr int LB = 8;
+    for (uint32_t k0 = 0; k0 < len; k0 += EW * LB) {
+      uint32_t pr[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        pr[u] = pred[b + (k < len ? k : 0u)];
+      }
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        if (k < len && pr[u] != NONE) succ[pr[u] - b] = (uint16_t)k;  // one successor per element: no two writers
+      }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < len; k += EW) {
-      const uint32_t p = b + k;
-      if (pred[p] != NONE) {  // a member: its head writes its label
-        ok_head[p] = 0;
-        continue;
+    for (uint32_t k0 = 0; k0 < len; k0 += EW * LB) {
+      uint32_t pr[LB], v_qs[LB], v_qe[LB], v_ts[LB], v_te[LB], v_m[LB], v_b[LB];
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        const uint32_t p = b + (k < len ? k : 0u);
+        pr[u] = pred[p];
+        v_qs[u] = s_qs[p];
+        v_qe[u] = s_qe[p];
+        v_ts[u] = s_ts[p];
+        v_te[u] = s_te[p];
+        v_m[u] = s_m ? s_m[p] : 0u;
+        v_b[u] = s_m ? s_b[p] : 0u;
       }
-      // a head: walk the chain
-      ++heads;
-      hd[p] = p;
-      uint32_t qe = s_qe[p], ts = s_ts[p], te = s_te[p];
-      uint64_t sm = s_m ? s_m[p] : 0u, sb = s_m ? s_b[p] : 0u;
-      for (uint16_t nx = succ[k]; nx != NO;) {
-        const uint32_t q = b + nx;
-        const uint16_t nn = succ[nx];  // requested together with the member's values
-        const uint32_t a = s_qe[q], t0 = s_ts[q], t1 = s_te[q], mm = s_m ? s_m[q] : 0u, bb = s_m ? s_b[q] : 0u;
-        hd[q] = p;
-        qe = a > qe ? a : qe;
-        ts = t0 < ts ? t0 : ts;
-        te = t1 > te ? t1 : te;
-        sm += mm;
-        sb += bb;
-        nx = nn;
-      }
-      const uint32_t qs0 = s_qs[p];
-      const uint64_t total_length = (uint64_t)qe - (uint64_t)qs0;  // q_max - q_min (the head has the smallest q_start)
-      bool ok = total_length >= min_len;
-      if (ok) {
-        const double wid = chain_weighted_identity(total_length, sm, sb);
-        ok = wid >= min_ident;
-        if (ok) {
-          HeadRec hr;
-          hr.qs = qs0;
-          hr.qe = qe;
-          hr.ts = ts;
-          hr.te = te;
-          hr.wid = wid;
-          hr.grp = s_grp ? s_grp[p] : 0ull;
-          rec[p] = hr;
+#pragma unroll
+      for (int u = 0; u < LB; ++u) {
+        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        if (k >= len) continue;
+        const uint32_t p = b + k;
+        if (pr[u] != NONE) {  // a member: its head writes its label
+          ok_head[p] = 0;
+          continue;
         }
+        // a head: walk the chain
+        ++heads;
+        hd[p] = p;
+        uint32_t qe = v_qe[u], ts = v_ts[u], te = v_te[u];
+        uint64_t sm = v_m[u], sb = v_b[u];
+        for (uint16_t nx = succ[k]; nx != NO;) {
+          const uint32_t q = b + nx;
+          const uint16_t nn = succ[nx];  // requested together with the member's values
+          const uint32_t a = s_qe[q], t0 = s_ts[q], t1 = s_te[q], mm = s_m ? s_m[q] : 0u, bb = s_m ? s_b[q] : 0u;
+          hd[q] = p;
+          qe = a > qe ? a : qe;
+          ts = t0 < ts ? t0 : ts;
+          te = t1 > te ? t1 : te;
+          sm += mm;
+          sb += bb;
+          nx = nn;
+        }
+        const uint32_t qs0 = v_qs[u];
+        const uint64_t total_length = (uint64_t)qe - (uint64_t)qs0;  // q_max - q_min (the head has the smallest q_start)
+        bool ok = total_length >= min_len;
+        if (ok) {
+          const double wid = chain_weighted_identity(total_length, sm, sb);
+          ok = wid >= min_ident;
+          if (ok) {
+            HeadRec hr;
+            hr.qs = qs0;
+            hr.qe = qe;
+            hr.ts = ts;
+            hr.te = te;
+            hr.wid = wid;
+            hr.grp = s_grp ? s_grp[p] : 0ull;
+            rec[p] = hr;
+          }
+        }
+        ok_head[p] = ok ? 1 : 0;
       }
-      ok_head[p] = ok ? 1 : 0;
     }
   }
 #pragma unroll
