@@ -1491,6 +1491,8 @@ struct PairFinishArgs {
   const uint8_t* kept_in;      // a scaffold sweep with limits ran over the chain table (pair_chains_kernel): kept flag per chain ...
   const uint32_t* chain_base;  // ... whose entries of pair k start here, in the pair's all_chains order; np[2k], np[2k + 1]: the pair's
   const uint32_t* np;          //     passing chains per strand
+  uint32_t* fin;       // by position in the pair, or nullptr: the record's result -- status << 30 | pair-local chain number -- instead
+                       //   of scattered writes to the output columns (pair_out_kernel brings them to input order through LDS)
   uint32_t* anum;      // by position in the pair: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
   PairCounters* C;
 };
@@ -1809,7 +1811,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     for (int u = 0; u < U; ++u) {
       const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
       h[u] = p < m ? A.hd[a + p] : a;
-      idx[u] = p < m ? A.s_idx[a + p] : 0u;
+      idx[u] = (p < m && !A.fin) ? A.s_idx[a + p] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) r[u] = A.head_num[h[u]];
@@ -1819,17 +1821,22 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
       uint32_t an = 0;
       if (p < m && r[u] < NEVER) {
         an = local_number(r[u], h[u] - a >= m_plus);
-        A.chain[idx[u]] = an;
-        A.status[idx[u]] = SWG_ST_SCAFFOLD;
+        if (!A.fin) {
+          A.chain[idx[u]] = an;
+          A.status[idx[u]] = SWG_ST_SCAFFOLD;
+        }
         ++out;
       } else if (r[u] == NEVER) {
         an = NEVER;
       }
+      if (A.fin && p < m) A.fin[a + p] = (an != 0u && an != NEVER) ? ((uint32_t)SWG_ST_SCAFFOLD << 30) | an : 0u;
       if (A.rescue_d && p < m) A.anum[a + p] = an;
     }
   }
-  if (A.rescue_d) {  // the alive non-members: rescue candidates unless the inversion capture takes them
-    for (uint32_t p = m + (uint32_t)tid; p < M; p += NT) A.anum[a + p] = 0u;
+  // the alive non-members: rescue candidates unless the inversion capture takes them
+  for (uint32_t p = m + (uint32_t)tid; p < M; p += NT) {
+    if (A.rescue_d) A.anum[a + p] = 0u;
+    if (A.fin) A.fin[a + p] = 0u;
   }
   FT_STAMP(1);
   // ---- inversion capture (paf_filter.rs:535-597): a '-' record that is not an anchor joins the first kept '+' chain of its
@@ -1861,7 +1868,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
       if (p >= m && (iw >> 31) == 0) continue;  // an alive non-member on the '+' strand
       const uint32_t i = iw & 0x7fffffffu;
       const uint64_t qs = A.s_qs[a + p], qe = A.s_qe[a + p], ts = A.s_ts[a + p], te = A.s_te[a + p];
-      if (A.chain[i]) continue;  // already an anchor
+      if (A.fin ? A.fin[a + p] != 0u : A.chain[i] != 0u) continue;  // already an anchor
       const uint64_t qc = (qs + qe) / 2, tc = (ts + te) / 2;
       const uint64_t lim = qe > ~0ull - gap ? ~0ull : qe + gap;  // chain.query_start.saturating_sub(gap) <= qe
       uint32_t l = 0, r = kP;  // first chain with q_start > lim
@@ -1889,8 +1896,12 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
       }
       if (best != NONE) {
         const uint32_t num = local_number(best, false);
-        A.chain[i] = num;
-        A.status[i] = SWG_ST_SCAFFOLD;
+        if (A.fin) {
+          A.fin[a + p] = ((uint32_t)SWG_ST_SCAFFOLD << 30) | num;
+        } else {
+          A.chain[i] = num;
+          A.status[i] = SWG_ST_SCAFFOLD;
+        }
         if (A.rescue_d) A.anum[a + p] = num;  // an anchor from here on, whatever it was
         ++out;
       }
@@ -2055,9 +2066,13 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
             scan(b_start[0], b_start[1]);
           }
           if (best_e != NONE) {
-            const uint32_t i = A.s_idx[a + p] & 0x7fffffffu;
-            A.status[i] = SWG_ST_RESCUED;
-            A.chain[i] = c_num[r0 + best_e];
+            if (A.fin) {
+              A.fin[a + p] = ((uint32_t)SWG_ST_RESCUED << 30) | c_num[r0 + best_e];
+            } else {
+              const uint32_t i = A.s_idx[a + p] & 0x7fffffffu;
+              A.status[i] = SWG_ST_RESCUED;
+              A.chain[i] = c_num[r0 + best_e];
+            }
             A.anum[a + p] = 0x80000000u | best_idx;
             if (st == 0u) ++out;
           }
@@ -2245,6 +2260,53 @@ __global__ __launch_bounds__(EW) void pair_renumber_kernel(uint32_t n_runs, cons
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (c[u]) chain[i[u]] = c[u] + base;
+    }
+  }
+}
+
+// The output columns of an input grouped by pair: every record of a run takes its status and its chain number (the pair-local
+// one from pair_finish + the pair's base) from its place in the pair's sorted order, brought back to input order through LDS
+// -- the records of a pair stand anywhere in its run, and 10^8 scattered 1- and 4-byte stores cost a 32-byte sector each.
+// Every record of every run is written (zeros for the dropped and the dead ones): the columns need no clearing beforehand.
+constexpr uint32_t OUT_TILE = 16384;
+constexpr uint32_t OUT_NT = 1024;
+__global__ __launch_bounds__(OUT_NT) void pair_out_kernel(uint32_t n_runs, const PairRun* __restrict__ runs, const PairInfo* __restrict__ info,
+                                                       const PairSum* __restrict__ sum, const uint32_t* __restrict__ s_idx,
+                                                       const uint32_t* __restrict__ fin, uint32_t* __restrict__ chain,
+                                                       uint8_t* __restrict__ status, const PairCounters* __restrict__ C) {
+  __shared__ uint32_t tile[OUT_TILE];
+  if (C->flags & PF_FALLBACK) return;
+  for (uint32_t k = blockIdx.x; k < n_runs; k += gridDim.x) {
+    const uint32_t a = runs[k].a, n = runs[k].n;
+    const uint32_t kept = sum[k].n_kept, base = sum[k].base, M = kept ? info[k].M : 0u;
+    for (uint32_t t0 = 0; t0 < n; t0 += OUT_TILE) {
+      const uint32_t tn = n - t0 < OUT_TILE ? n - t0 : OUT_TILE;
+      if (M) {
+        __syncthreads();  // (the previous tile's readers)
+        for (uint32_t j = threadIdx.x; j < tn; j += OUT_NT) tile[j] = 0u;
+        __syncthreads();
+        for (uint32_t p0 = 0; p0 < M; p0 += OUT_NT * 4) {
+          uint32_t ix[4], v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t p = p0 + (uint32_t)u * OUT_NT + threadIdx.x;
+            ix[u] = p < M ? s_idx[a + p] & 0x7fffffffu : NONE;
+            v[u] = p < M ? fin[a + p] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t o = ix[u] - a - t0;  // (wraps for a record outside the tile)
+            if (ix[u] != NONE && o < tn && v[u]) tile[o] = v[u];
+          }
+        }
+        __syncthreads();
+      }
+      for (uint32_t j = threadIdx.x; j < tn; j += OUT_NT) {
+        const uint32_t v = M ? tile[j] : 0u;
+        const uint32_t num = v & 0x3fffffffu;
+        chain[a + t0 + j] = num ? num + base : 0u;
+        status[a + t0 + j] = (uint8_t)(v >> 30);
+      }
     }
   }
 }
@@ -2440,8 +2502,13 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   PairTable gl_first, gp2_first;
   SWG_TRY(pair_table_make(ctx, r->n_genome_last, n_runs, &gl_first));
   SWG_TRY(pair_table_make(ctx, r->n_genome_two, n_runs, &gp2_first));
-  SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, (size_t)n * sizeof(uint32_t), st));
-  SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+  // (large inputs: pair_out_kernel writes every record of both columns; small ones are written in place, record by record)
+  uint32_t* fin = by_hash ? nullptr : swg_alloc<uint32_t>(ctx, n);
+  SWG_CHECK_ARENA(ctx);
+  if (by_hash) {
+    SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, (size_t)n * sizeof(uint32_t), st));
+    SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
+  }
   PairSortArgs SA{};
   SA.q_id = r->q_id; SA.t_id = r->t_id; SA.q_start = r->q_start; SA.q_end = r->q_end; SA.t_start = r->t_start; SA.t_end = r->t_end;
   SA.matches = r->matches; SA.block_len = r->block_len; SA.identity = r->identity; SA.strand = r->strand;
@@ -2545,6 +2612,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   FA.rescue_d = rescue ? cfg->scaffold_max_deviation : 0;
   FA.max_s2 = rescue ? pair_max_dist2(cfg->scaffold_max_deviation) : 0;
   FA.anum = anum;
+  FA.fin = fin;
   for (int c = 0; c < 4; ++c) {
     if (!ncls[c]) continue;
     FA.list = class_list + (size_t)c * cap;
@@ -2596,7 +2664,11 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   {
     const unsigned gb = n_runs < (unsigned)ctx->num_cu * 16 ? n_runs : (unsigned)ctx->num_cu * 16;
-    SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C, perm));
+    if (fin)  // (one label for both: the chain numbers' last step)
+      SWG_LAUNCH(ctx, "pair_renumber", pair_out_kernel<<<n_runs < (unsigned)ctx->num_cu * 8 ? n_runs : (unsigned)ctx->num_cu * 8, OUT_NT, 0, st>>>(
+                                           n_runs, runs, info, sum, s_idx, fin, chain_out, status_out, C));
+    else
+      SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C, perm));
     SWG_KERNEL_CHECK(ctx);
   }
   // ---- the flags found on the device, and the statistics

@@ -44,6 +44,8 @@ def short_name(name):
         base += {"64": "_s", "256": "_m"}.get(t[0], "")
     if base in ("run_alive", "run_key"):
         base = "seg_" + base
+    if base == "pair_out":             # (large inputs: the numbering's last step also brings the results to input order)
+        base = "pair_renumber"
     if base == "pair_long_plan":
         base = "spec_plan"
     if base == "pair_long_verdict":
