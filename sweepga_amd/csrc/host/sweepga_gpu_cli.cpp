@@ -452,9 +452,22 @@ int main(int argc, char** argv) {
     // itself -- the column (8 of 47 bytes per record) stays on the host
     swg_records rr = *r;
     if (swg_paf_identity_is_derived(paf)) rr.identity = nullptr;
+    // The result columns are not cleared (posix_memalign above): every filter path must write every entry.  SWG_DEBUG checks
+    // that it does: the columns start as 0xff (no status, no chain number of a real result has that byte pattern in every
+    // byte: statuses are 0..3, chain numbers stay below 2^31) and none of it may be left.
+    const bool poison = std::getenv("SWG_DEBUG") != nullptr;
+    if (poison) {
+      std::memset(status.data(), 0xff, n);
+      std::memset(chain.data(), 0xff, n * sizeof(uint32_t));
+    }
     const int rc = ctxs.size() > 1 ? swg_filter_multi(ctxs.data(), (int)ctxs.size(), &rr, &cfg, status.data(), chain.data(), &st)
                                    : swg_filter(ctx, &rr, &cfg, status.data(), chain.data(), &st);
     if (rc != SWG_OK) die(3, std::string("filter failed: ") + swg_last_error(ctx));
+    if (poison) {
+      for (uint64_t i = 0; i < n; ++i)
+        if (status.data()[i] == 0xff || chain.data()[i] == 0xffffffffu)
+          die(3, "internal: the filter left record " + std::to_string(i) + " of the result columns unwritten");
+    }
   }
   const auto t2 = clk::now();
 

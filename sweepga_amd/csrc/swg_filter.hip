@@ -312,7 +312,9 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   SWG_CHECK_ARENA(ctx);
   int q_order_valid = 0;
   if (!sweep_is_identity)
-    SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, key_ends, pos_bits, keep1, q_order, &q_order_valid, seg_sweep ? pair_plan.runs : nullptr,
+    // (the slots carry score keys only when a sweep with limits was expected: `sweeps`.  Without one they were filled for the
+    // scaffold stage's gathers, every key zero -- an unlimited sweep over zero-length records reads none, and gets none)
+    SWG_TRY(swg_mapping_sweep(ctx, r, cfg, alive, sweeps ? key_ends : nullptr, pos_bits, keep1, q_order, &q_order_valid, seg_sweep ? pair_plan.runs : nullptr,
                               pair_plan.n_runs, score_col, h[1]));
 
   if (cfg->scaffold_gap == 0) {  // src/paf_filter.rs:409-434

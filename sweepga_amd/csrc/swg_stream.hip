@@ -123,34 +123,43 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
   size_t issued = 0;
   bool up_failed = false;
   std::atomic<bool> stop{false};
+  hipError_t up_err = hipSuccess;  // what the uploader's failing call returned (HIP's last error is per thread: the filtering
+                                   // thread cannot ask for it); written under mu next to up_failed
   auto uploader = [&]() {
-    bool ok = hipSetDevice(ctx->device) == hipSuccess;
+    hipError_t e = hipSetDevice(ctx->device);
+    auto step = [&](hipError_t x) {  // runs the call only while everything before it succeeded; keeps the first failure
+      if (e == hipSuccess) e = x;
+      return e == hipSuccess;
+    };
     hipStream_t cs = ctx->copy_stream;
-    ok = ok && hipEventRecord(t_first, cs) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_gl, r->seq_genome_last, (size_t)r->n_seq * 4, hipMemcpyHostToDevice, cs) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_g2, r->seq_genome_two, (size_t)r->n_seq * 4, hipMemcpyHostToDevice, cs) == hipSuccess;
-    for (size_t j = 0; j < nc && ok && !stop.load(std::memory_order_relaxed); ++j) {
+    if (e == hipSuccess) step(hipEventRecord(t_first, cs));
+    if (e == hipSuccess) step(hipMemcpyAsync(d_gl, r->seq_genome_last, (size_t)r->n_seq * 4, hipMemcpyHostToDevice, cs));
+    if (e == hipSuccess) step(hipMemcpyAsync(d_g2, r->seq_genome_two, (size_t)r->n_seq * 4, hipMemcpyHostToDevice, cs));
+    for (size_t j = 0; j < nc && e == hipSuccess && !stop.load(std::memory_order_relaxed); ++j) {
       const swg_streamed::Chunk& c = chunks[(size_t)D.mine[j]];
       const uint64_t len = c.hi - c.lo, lo = c.lo, lo_d = D.local_off[j];
-      for (int k = 0; k < 8 && ok; ++k)
-        if (want4[k]) ok = hipMemcpyAsync(d_c4[k] + lo_d, h_c4[k] + lo, len * 4, hipMemcpyHostToDevice, cs) == hipSuccess;
-      if (ok && r->identity) ok = hipMemcpyAsync(d_identity + lo_d, r->identity + lo, len * 8, hipMemcpyHostToDevice, cs) == hipSuccess;
-      if (ok && scaffold) ok = hipMemcpyAsync(d_strand + lo_d, r->strand + lo, len, hipMemcpyHostToDevice, cs) == hipSuccess;
-      if (ok && j + 1 == nc) ok = hipEventRecord(t_last, cs) == hipSuccess;
-      ok = ok && hipEventRecord(up_ev[j], cs) == hipSuccess;
+      for (int k = 0; k < 8 && e == hipSuccess; ++k)
+        if (want4[k]) step(hipMemcpyAsync(d_c4[k] + lo_d, h_c4[k] + lo, len * 4, hipMemcpyHostToDevice, cs));
+      if (e == hipSuccess && r->identity) step(hipMemcpyAsync(d_identity + lo_d, r->identity + lo, len * 8, hipMemcpyHostToDevice, cs));
+      if (e == hipSuccess && scaffold) step(hipMemcpyAsync(d_strand + lo_d, r->strand + lo, len, hipMemcpyHostToDevice, cs));
+      if (e == hipSuccess && j + 1 == nc) step(hipEventRecord(t_last, cs));
+      if (e == hipSuccess) step(hipEventRecord(up_ev[j], cs));
       {
         std::lock_guard<std::mutex> g(mu);
-        if (ok)
+        if (e == hipSuccess) {
           issued = j + 1;
-        else
+        } else {
           up_failed = true;
+          up_err = e;
+        }
       }
       cv.notify_all();
     }
-    if (!ok) {
+    if (e != hipSuccess) {
       {
         std::lock_guard<std::mutex> g(mu);
         up_failed = true;
+        up_err = e;
       }
       cv.notify_all();
     }
@@ -173,7 +182,7 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
       std::unique_lock<std::mutex> g(mu);
       cv.wait(g, [&] { return issued > j || up_failed; });
       if (issued <= j) {
-        rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy of range %zu failed: %s", j, hipGetErrorString(hipGetLastError()));
+        rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy of range %zu failed: %s", j, hipGetErrorString(up_err));
         break;
       }
     }
