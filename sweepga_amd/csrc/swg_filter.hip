@@ -280,7 +280,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   // all-members gathers read them only if the probe says "not grouped".  Nothing else may read these slots.
   swg_key_ends* probe_slots = nullptr;
   uint32_t* probe_flag = nullptr;
-  if (!key_ends && cfg->scaffold_gap != 0 && slots_knob < 0 && n >= 65536) {
+  if (!key_ends && cfg->scaffold_gap != 0 && slots_knob < 0 && n >= 65536 && !pair_plan.valid) {  // (a valid plan: grouped, and the stage is the pair-resident one)
     probe_slots = swg_alloc<swg_key_ends>(ctx, n);
     probe_flag = swg_alloc<uint32_t>(ctx, 1);
   }
