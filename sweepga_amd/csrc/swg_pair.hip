@@ -143,13 +143,15 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* ws) {
 }
 
 // ---- the runs of equal (q_id, t_id) ---------------------------------------------------------------------------------
-// One bit per record (a run begins here), the run starts as an unordered list, and every pair entered into a hash set: a
-// pair that is entered twice has two runs -- the input is not grouped by chromosome pair.
+// pair_boundary: one bit per record (a run begins here) and the number of set bits per 64-record word -- no counter that every
+// wavefront bumps: an input of millions of tiny pairs would serialise on it (a same-address atomic costs ~11 ns: 14 ms for
+// 1.25 M of them, measured).  A prefix sum over the words' counts (swg_exclusive_scan_u32) numbers the runs in input order;
+// pair_starts lists their first records; pair_runs (a thread per run) takes a run's end from its successor's start, files the
+// run under its size class (one atomic per class and work-group) and enters its pair into a hash set: a pair entered twice has
+// two runs -- the input is not grouped by chromosome pair.
 __global__ __launch_bounds__(256) void pair_boundary_kernel(uint32_t n, const uint32_t* __restrict__ q_id,
                                                             const uint32_t* __restrict__ t_id, unsigned long long* __restrict__ bitmap,
-                                                            uint32_t* __restrict__ run_start, uint32_t cap,
-                                                            unsigned long long* __restrict__ table, uint32_t tmask,
-                                                            PairCounters* __restrict__ C) {
+                                                            uint32_t* __restrict__ wcnt) {
   // a wavefront takes 4 x 64 consecutive records (four bitmap words); every load is requested before the first comparison
   constexpr int R = 4;
   const int lane = threadIdx.x & 63;
@@ -178,19 +180,62 @@ __global__ __launch_bounds__(256) void pair_boundary_kernel(uint32_t n, const ui
     const uint32_t i = base_i + (uint32_t)j * 64u + (uint32_t)lane;
     const bool start = i < n && (i == 0 || pq[j] != q[j] || pt[j] != t[j]);
     const unsigned long long mask = __ballot(start);
-    if (lane == 0 && i < n) bitmap[i >> 6] = mask;
-    if (mask == 0) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&C->n_runs, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, 0, 64);
-    if (!start) continue;
-    const uint32_t k = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (k >= cap) {
-      atomicOr(&C->flags, PF_RUN_OVERFLOW);
-      continue;
+    if (lane == 0 && base_i + (uint32_t)j * 64u < n) {
+      bitmap[i >> 6] = mask;
+      wcnt[i >> 6] = (uint32_t)__popcll(mask);
     }
-    run_start[k] = i;
-    const unsigned long long key = ((unsigned long long)q[j] << 32) | t[j];
+  }
+}
+// starts[r] = first record of run r (runs numbered in input order by the prefix sums of the words' counts); starts[n_runs] = n
+__global__ __launch_bounds__(256) void pair_starts_kernel(uint32_t n, uint32_t n_words, const unsigned long long* __restrict__ bitmap,
+                                                          const uint32_t* __restrict__ wpre, const uint64_t* __restrict__ n_runs_dev,
+                                                          uint32_t cap, uint32_t* __restrict__ starts) {
+  const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+  if (w == 0) {
+    const uint64_t nr = *n_runs_dev;
+    if (nr <= cap) starts[nr] = n;
+  }
+  if (w >= n_words) return;
+  unsigned long long m = bitmap[w];
+  uint32_t r = wpre[w];
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    m &= m - 1;
+    if (r < cap) starts[r] = (w << 6) + (uint32_t)b;
+    ++r;
+  }
+}
+__global__ __launch_bounds__(256) void pair_runs_kernel(uint32_t n, uint32_t cap, const uint64_t* __restrict__ n_runs_dev,
+                                                        const uint32_t* __restrict__ starts, const uint32_t* __restrict__ q_id,
+                                                        const uint32_t* __restrict__ t_id, unsigned long long* __restrict__ table,
+                                                        uint32_t tmask, PairRun* __restrict__ runs, uint32_t* __restrict__ class_list,
+                                                        PairCounters* __restrict__ C) {
+  __shared__ uint32_t s_cnt[4][4], s_base[4];
+  const uint64_t nr64 = *n_runs_dev;
+  if (nr64 > cap) {  // more pairs than this path takes (pair_plan's rule): nothing else is looked at
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      C->n_runs = cap + 1u;
+      atomicOr(&C->flags, PF_RUN_OVERFLOW);
+    }
+    return;
+  }
+  const uint32_t nr = (uint32_t)nr64;
+  if (blockIdx.x == 0 && threadIdx.x == 0) C->n_runs = nr;
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int cls = -1;
+  if (k < nr) {
+    const uint32_t a = starts[k], len = starts[k + 1] - a;
+    PairRun r;
+    r.a = a;
+    r.n = len;
+    runs[k] = r;
+    if (len > PAIR_XL_MAX) {
+      atomicOr(&C->flags, PF_TOO_LONG);
+    } else {
+      cls = len <= PAIR_S_MAX ? 0 : (len <= PAIR_M_MAX ? 1 : (len <= PAIR_L_MAX ? 2 : 3));
+    }
+    const unsigned long long key = ((unsigned long long)q_id[a] << 32) | t_id[a];
     uint32_t h = (uint32_t)((key * 0x9e3779b97f4a7c15ull) >> 32) & tmask;
     for (;;) {  // (at most `cap` keys in 2 * cap slots)
       const unsigned long long old = atomicCAS(&table[h], ~0ull, key);
@@ -202,52 +247,25 @@ __global__ __launch_bounds__(256) void pair_boundary_kernel(uint32_t n, const ui
       h = (h + 1) & tmask;
     }
   }
-}
-// Every run's end (the next set bit), its size class, and the per-class lists the work-groups of the later kernels index.  One
-// wavefront per run (64 bitmap words per step), the wavefronts of a fixed grid striding over the runs.
-__global__ __launch_bounds__(256) void pair_runs_kernel(uint32_t n, uint32_t cap, const uint32_t* __restrict__ run_start,
-                                                        const unsigned long long* __restrict__ bitmap, PairRun* __restrict__ runs,
-                                                        uint32_t* __restrict__ class_list, PairCounters* __restrict__ C) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t nr = C->n_runs < cap ? C->n_runs : cap;
-  const uint32_t n_words = (n + 63) >> 6;
-  for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < nr; k += gridDim.x * 4u) {
-    const uint32_t a = run_start[k];
-    uint32_t end = n;
-    bool too_long = false;
-    if (a + 1 < n) {
-      const uint32_t w0 = (a + 1) >> 6;
-      const uint32_t w_stop = w0 + PAIR_XL_MAX / 64 + 2;
-      const uint32_t limit = n_words < w_stop ? n_words : w_stop;  // words [w0, limit) are looked at
-      bool found = false;
-      for (uint32_t wb = w0; wb < limit; wb += 64) {
-        const uint32_t w = wb + lane;
-        unsigned long long x = w < limit ? bitmap[w] : 0ull;
-        if (w == w0) x &= ~0ull << ((a + 1) & 63);
-        const unsigned long long m = __ballot(x != 0ull);
-        if (m) {
-          const int f = __builtin_ctzll(m);
-          const unsigned long long xf = __shfl(x, f, 64);
-          end = ((wb + (uint32_t)f) << 6) + (uint32_t)__builtin_ctzll(xf);
-          found = true;
-          break;
-        }
-      }
-      too_long = !found && limit < n_words;  // (otherwise the run goes to the end of the input)
-    }
-    if (lane != 0) continue;
-    const uint32_t len = end - a;
-    PairRun r;
-    r.a = a;
-    r.n = len;
-    runs[k] = r;
-    if (too_long || len > PAIR_XL_MAX) {
-      atomicOr(&C->flags, PF_TOO_LONG);
-      continue;
-    }
-    const int cls = len <= PAIR_S_MAX ? 0 : (len <= PAIR_M_MAX ? 1 : (len <= PAIR_L_MAX ? 2 : 3));
-    const uint32_t j = atomicAdd(&C->n_class[cls], 1u);
-    class_list[(size_t)cls * cap + j] = k;
+  // the class lists: one atomic per class and work-group
+  unsigned long long mk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mk[c] = __ballot(cls == c);
+    if (lane == 0) s_cnt[wv][c] = (uint32_t)__popcll(mk[c]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    const uint32_t tot = s_cnt[0][c] + s_cnt[1][c] + s_cnt[2][c] + s_cnt[3][c];
+    s_base[c] = tot ? atomicAdd(&C->n_class[c], tot) : 0u;
+  }
+  __syncthreads();
+  if (cls >= 0) {
+    uint32_t o = s_base[cls];
+    for (int w2 = 0; w2 < wv; ++w2) o += s_cnt[w2][cls];
+    const unsigned long long m = cls == 0 ? mk[0] : (cls == 1 ? mk[1] : (cls == 2 ? mk[2] : mk[3]));
+    class_list[(size_t)cls * cap + o + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
   }
 }
 
@@ -284,6 +302,10 @@ __global__ __launch_bounds__(256) void pair_slots_kernel(uint32_t tsize, const u
   if (!c) return;
   const uint32_t k = atomicAdd(&C->n_runs, 1u), o = atomicAdd(cursor, c);
   start[h] = o;
+  if (k >= cap) {  // more pairs than this path takes (pair_plan's rule)
+    atomicOr(&C->flags, PF_RUN_OVERFLOW);
+    return;
+  }
   PairRun r;
   r.a = o;
   r.n = c;
@@ -2268,28 +2290,32 @@ __global__ __launch_bounds__(EW) void pair_renumber_kernel(uint32_t n_runs, cons
 // one from pair_finish + the pair's base) from its place in the pair's sorted order, brought back to input order through LDS
 // -- the records of a pair stand anywhere in its run, and 10^8 scattered 1- and 4-byte stores cost a 32-byte sector each.
 // Every record of every run is written (zeros for the dropped and the dead ones): the columns need no clearing beforehand.
-constexpr uint32_t OUT_TILE = 16384;
-constexpr uint32_t OUT_NT = 1024;
-__global__ __launch_bounds__(OUT_NT) void pair_out_kernel(uint32_t n_runs, const PairRun* __restrict__ runs, const PairInfo* __restrict__ info,
-                                                       const PairSum* __restrict__ sum, const uint32_t* __restrict__ s_idx,
-                                                       const uint32_t* __restrict__ fin, uint32_t* __restrict__ chain,
-                                                       uint8_t* __restrict__ status, const PairCounters* __restrict__ C) {
-  __shared__ uint32_t tile[OUT_TILE];
+// One launch per size class (work-groups of 64 / 256 / 1,024 threads, tiles of 1,024 / 4,096 / 16,384 records): millions of
+// tiny pairs must not each occupy a 1,024-thread work-group.
+template <int NT, uint32_t TILE>
+__global__ __launch_bounds__(NT) void pair_out_kernel(uint32_t n_first, const uint32_t* __restrict__ first, uint32_t n_list,
+                                                      const uint32_t* __restrict__ list, const PairRun* __restrict__ runs,
+                                                      const PairInfo* __restrict__ info, const PairSum* __restrict__ sum,
+                                                      const uint32_t* __restrict__ s_idx, const uint32_t* __restrict__ fin,
+                                                      uint32_t* __restrict__ chain, uint8_t* __restrict__ status,
+                                                      const PairCounters* __restrict__ C) {
+  __shared__ uint32_t tile[TILE];
   if (C->flags & PF_FALLBACK) return;
-  for (uint32_t k = blockIdx.x; k < n_runs; k += gridDim.x) {
+  for (uint32_t kk = blockIdx.x; kk < n_first + n_list; kk += gridDim.x) {  // (`first`: the longest runs of the launch)
+    const uint32_t k = kk < n_first ? first[kk] : list[kk - n_first];
     const uint32_t a = runs[k].a, n = runs[k].n;
     const uint32_t kept = sum[k].n_kept, base = sum[k].base, M = kept ? info[k].M : 0u;
-    for (uint32_t t0 = 0; t0 < n; t0 += OUT_TILE) {
-      const uint32_t tn = n - t0 < OUT_TILE ? n - t0 : OUT_TILE;
+    for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+      const uint32_t tn = n - t0 < TILE ? n - t0 : TILE;
       if (M) {
         __syncthreads();  // (the previous tile's readers)
-        for (uint32_t j = threadIdx.x; j < tn; j += OUT_NT) tile[j] = 0u;
+        for (uint32_t j = threadIdx.x; j < tn; j += NT) tile[j] = 0u;
         __syncthreads();
-        for (uint32_t p0 = 0; p0 < M; p0 += OUT_NT * 4) {
+        for (uint32_t p0 = 0; p0 < M; p0 += NT * 4) {
           uint32_t ix[4], v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const uint32_t p = p0 + (uint32_t)u * OUT_NT + threadIdx.x;
+            const uint32_t p = p0 + (uint32_t)u * NT + threadIdx.x;
             ix[u] = p < M ? s_idx[a + p] & 0x7fffffffu : NONE;
             v[u] = p < M ? fin[a + p] : 0u;
           }
@@ -2301,7 +2327,7 @@ __global__ __launch_bounds__(OUT_NT) void pair_out_kernel(uint32_t n_runs, const
         }
         __syncthreads();
       }
-      for (uint32_t j = threadIdx.x; j < tn; j += OUT_NT) {
+      for (uint32_t j = threadIdx.x; j < tn; j += NT) {
         const uint32_t v = M ? tile[j] : 0u;
         const uint32_t num = v & 0x3fffffffu;
         chain[a + t0 + j] = num ? num + base : 0u;
@@ -2366,9 +2392,13 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
   const swg_arena_mark mark0 = swg_arena_save(ctx);
   const bool by_hash = n <= PAIR_HASH_MAX;
-  const uint32_t cap = n < 65536u ? n : (n / 16 > 65536u ? n / 16 : 65536u);
+  // How many pairs the path takes.  Its bookkeeping is per pair -- a work-group, a handful of counters bumped in one cache line
+  // (~90 ns of same-address atomics per pair), a wavefront per chunk of the walk -- which is nothing next to a pair of thousands
+  // of records and everything next to a pair of ten: beyond ~65,000 pairs per 10^8 records (an average below 1,536 records), or
+  // 8,192 pairs of a small input, the global-sort stage is the faster one (tools/tiny_pairs_probe.py), and it gets the call.
+  const uint32_t cap = by_hash ? (n < 8192u ? n : 8192u) : (n / 1536u > 8192u ? n / 1536u : 8192u);
   uint32_t tsize = 1;
-  while (tsize < 2 * cap) tsize <<= 1;
+  while (tsize < 2 * (by_hash ? n : cap)) tsize <<= 1;  // (the hash grouping enters every record's pair: room for n of them)
   PairCounters* C = nullptr;
   PairRun* runs = swg_alloc<PairRun>(ctx, cap);
   uint32_t* class_list = swg_alloc<uint32_t>(ctx, (size_t)4 * cap);
@@ -2391,15 +2421,22 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
     SWG_KERNEL_CHECK(ctx);
   } else {
     C = swg_alloc<PairCounters>(ctx, 1);
-    unsigned long long* bitmap = swg_alloc<unsigned long long>(ctx, (n + 63) / 64 + 1);
-    uint32_t* run_start = swg_alloc<uint32_t>(ctx, cap);
+    const uint32_t n_words = (n + 63) / 64;
+    unsigned long long* bitmap = swg_alloc<unsigned long long>(ctx, n_words + 1);
+    uint32_t* wcnt = swg_alloc<uint32_t>(ctx, n_words + 1);
+    uint32_t* wpre = swg_alloc<uint32_t>(ctx, n_words + 1);
+    uint32_t* starts = swg_alloc<uint32_t>(ctx, (size_t)cap + 2);
     unsigned long long* table = swg_alloc<unsigned long long>(ctx, tsize);
+    uint64_t* d_nr = swg_alloc<uint64_t>(ctx, 1);
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemsetAsync(C, 0, sizeof(PairCounters), st));
     SWG_HIP(ctx, hipMemsetAsync(table, 0xff, (size_t)tsize * 8, st));
-    SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 1023) / 1024, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, run_start, cap, table, tsize - 1, C));
+    SWG_LAUNCH(ctx, "pair_boundary", pair_boundary_kernel<<<(n + 1023) / 1024, 256, 0, st>>>(n, r->q_id, r->t_id, bitmap, wcnt));
     SWG_KERNEL_CHECK(ctx);
-    SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 3) / 4 < (uint32_t)ctx->num_cu * 16u ? (cap + 3) / 4 : (uint32_t)ctx->num_cu * 16u, 256, 0, st>>>(n, cap, run_start, bitmap, runs, class_list, C));
+    SWG_TRY(swg_exclusive_scan_u32(ctx, wcnt, wpre, n_words, d_nr));
+    SWG_LAUNCH(ctx, "pair_runs", pair_starts_kernel<<<(n_words + 255) / 256, 256, 0, st>>>(n, n_words, bitmap, wpre, d_nr, cap, starts));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "pair_runs", pair_runs_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n, cap, d_nr, starts, r->q_id, r->t_id, table, tsize - 1, runs, class_list, C));
     SWG_KERNEL_CHECK(ctx);
   }
   uint64_t h[4];
@@ -2664,12 +2701,29 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   }
   {
     const unsigned gb = n_runs < (unsigned)ctx->num_cu * 16 ? n_runs : (unsigned)ctx->num_cu * 16;
-    if (fin)  // (one label for both: the chain numbers' last step)
-      SWG_LAUNCH(ctx, "pair_renumber", pair_out_kernel<<<n_runs < (unsigned)ctx->num_cu * 8 ? n_runs : (unsigned)ctx->num_cu * 8, OUT_NT, 0, st>>>(
-                                           n_runs, runs, info, sum, s_idx, fin, chain_out, status_out, C));
-    else
+    if (fin) {  // (one label for all: the chain numbers' last step)
+      const unsigned cu = (unsigned)ctx->num_cu;
+      if (ncls[2] + ncls[3]) {
+        const uint32_t nb = ncls[2] + ncls[3];
+        SWG_LAUNCH(ctx, "pair_renumber", pair_out_kernel<1024, 16384><<<nb < cu * 8 ? nb : cu * 8, 1024, 0, st>>>(
+                                             ncls[3], class_list + (size_t)3 * cap, ncls[2], class_list + (size_t)2 * cap, runs, info, sum, s_idx, fin,
+                                             chain_out, status_out, C));
+        SWG_KERNEL_CHECK(ctx);
+      }
+      if (ncls[1]) {
+        SWG_LAUNCH(ctx, "pair_renumber", pair_out_kernel<256, 4096><<<ncls[1] < cu * 16 ? ncls[1] : cu * 16, 256, 0, st>>>(
+                                             0u, nullptr, ncls[1], class_list + (size_t)1 * cap, runs, info, sum, s_idx, fin, chain_out, status_out, C));
+        SWG_KERNEL_CHECK(ctx);
+      }
+      if (ncls[0]) {
+        SWG_LAUNCH(ctx, "pair_renumber", pair_out_kernel<64, 1024><<<ncls[0] < cu * 64 ? ncls[0] : cu * 64, 64, 0, st>>>(
+                                             0u, nullptr, ncls[0], class_list, runs, info, sum, s_idx, fin, chain_out, status_out, C));
+        SWG_KERNEL_CHECK(ctx);
+      }
+    } else {
       SWG_LAUNCH(ctx, "pair_renumber", pair_renumber_kernel<<<gb, EW, 0, st>>>(n_runs, runs, sum, chain_out, C, perm));
-    SWG_KERNEL_CHECK(ctx);
+      SWG_KERNEL_CHECK(ctx);
+    }
   }
   // ---- the flags found on the device, and the statistics
   uint64_t hc[9];

@@ -171,23 +171,22 @@ __global__ __launch_bounds__(EW) void seg_class_kernel(const uint64_t* __restric
     if (cls == c) class_list[(size_t)c * cap + base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = s;
   }
 }
-// the live records of every run, in input order, at the run's place in its segment's list (one work-group per sorted run)
+// the live records of every run, in input order, at the run's place in its segment's list: one wavefront per sorted run (a
+// ballot per 64 records; millions of tiny runs must not each occupy a work-group and its barriers)
 __global__ __launch_bounds__(256) void seg_perm_kernel(uint32_t n_runs, const Run* __restrict__ runs, const uint32_t* __restrict__ val,
                                                        const uint32_t* __restrict__ off, const uint32_t* __restrict__ f,
                                                        const uint8_t* __restrict__ alive, uint32_t* __restrict__ perm) {
-  __shared__ uint32_t ws[5];
-  for (uint32_t r = blockIdx.x; r < n_runs; r += gridDim.x) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < n_runs; r += gridDim.x * 4u) {
     if (f[r] && (r + 1 == n_runs || f[r + 1])) continue;  // a segment of one run is read in place
     const Run run = runs[val[r]];
     uint32_t dest = off[r];
-    for (uint32_t j0 = 0; j0 < run.n; j0 += 256) {
-      const uint32_t j = j0 + threadIdx.x;
+    for (uint32_t j0 = 0; j0 < run.n; j0 += 64) {
+      const uint32_t j = j0 + lane;
       const bool live = j < run.n && (!alive || alive[run.a + j] != 0);
-      uint32_t tot;
-      const uint32_t e = block_excl_sum<256>(live ? 1u : 0u, ws, &tot);
-      if (live) perm[dest + e] = run.a + j;
-      dest += tot;
-      lds_barrier();  // (ws is reused by the next round)
+      const unsigned long long mk = __ballot(live);
+      if (live) perm[dest + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = run.a + j;
+      dest += (uint32_t)__popcll(mk);
     }
   }
 }
@@ -819,7 +818,7 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   SWG_LAUNCH(ctx, "seg_class", seg_class_kernel<<<nblk(n_runs), EW, 0, st>>>(d_tot + 1, n_runs, seg_a, seg_e, seg_base, seg_len, class_list, counters));
   SWG_KERNEL_CHECK(ctx);
   {
-    const unsigned pb = n_runs < (uint32_t)ctx->num_cu * 16u ? n_runs : (unsigned)ctx->num_cu * 16u;
+    const unsigned pb = (n_runs + 3) / 4 < (uint32_t)ctx->num_cu * 32u ? (n_runs + 3) / 4 : (unsigned)ctx->num_cu * 32u;
     SWG_LAUNCH(ctx, "seg_perm", seg_perm_kernel<<<pb, 256, 0, st>>>(n_runs, runs, val, off, f, in.alive, perm));
     SWG_KERNEL_CHECK(ctx);
   }

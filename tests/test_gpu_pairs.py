@@ -195,6 +195,19 @@ def test_large_ungrouped_inputs_take_the_global_path_and_degenerate_ones_the_rea
     assert "kinf_mark" in sw.default_context(0).profile_table() or "kinf_mark_both" in sw.default_context(0).profile_table()
 
 
+def test_many_tiny_pairs_are_left_to_the_global_path(sw):
+    """The pair path's bookkeeping is per pair (a work-group, a few counters, a wavefront per chunk): inputs of more than 8,192
+    pairs whose average pair is below 1,536 records go to the global-sort stage, large (runs of the input) and small (hash
+    grouping) alike; a few hundred pairs of any size stay."""
+    rng = np.random.default_rng(12)
+    rec = pair_major(gen.random_records(rng, 90_000, n_genomes=40, chrs_per_genome=4, span=300_000, zero_frac=0.0), rng)   # ~25,000 pairs
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)
+    rec = pair_major(gen.random_records(rng, 40_000, n_genomes=30, chrs_per_genome=4, span=300_000, zero_frac=0.0), rng)   # ~14,000 pairs, <= 65,536 records
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)
+    rec = pair_major(gen.random_records(rng, 90_000, n_genomes=5, chrs_per_genome=4, span=300_000, zero_frac=0.0), rng)    # 400 pairs
+    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=True)
+
+
 def test_knob_off_gives_the_same_answer(sw):
     code = r"""
 import numpy as np, sys
