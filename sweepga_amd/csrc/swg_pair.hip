@@ -1536,7 +1536,7 @@ struct PairChainArgs {
   uint64_t* T_seg;
   uint32_t *chain_base, *np;
   PairRun* T_runs;             // the pairs' stretches of the table (those that hold a chain)
-  unsigned long long* totals;  // [0] chains in the table, [1] largest coordinate, [2] stretches
+  unsigned long long* totals;  // [0] chains in the table (low 40 bits) and stretches (above), [1] largest coordinate
   const PairCounters* C;
 };
 template <int NT>
@@ -1578,7 +1578,9 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
   }
   if ((tid & 63) == 0 && mx) atomicMax(&A.totals[1], (unsigned long long)mx);
   if (tid == 0) {
-    const uint32_t cb = nP + nM ? (uint32_t)atomicAdd(&A.totals[0], (unsigned long long)(nP + nM)) : 0u;
+    // (one returning atomic per pair: the chains before this pair's in the low 40 bits, the stretches before it above them)
+    const unsigned long long old = nP + nM ? atomicAdd(&A.totals[0], (unsigned long long)(nP + nM) | (1ull << 40)) : 0ull;
+    const uint32_t cb = (uint32_t)(old & ((1ull << 40) - 1ull));
     sh_base = cb;
     A.chain_base[rk] = cb;
     A.np[2 * rk] = nP;
@@ -1587,7 +1589,7 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
       PairRun tr;
       tr.a = cb;
       tr.n = nP + nM;
-      A.T_runs[atomicAdd(&A.totals[2], 1ull)] = tr;
+      A.T_runs[old >> 40] = tr;
     }
   }
   __syncthreads();
@@ -2632,7 +2634,8 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     }
     uint64_t ht[3];
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(CA.totals), ht, 3));
-    const uint64_t n_table = ht[0];
+    const uint64_t n_table = ht[0] & ((1ull << 40) - 1ull);
+    ht[2] = ht[0] >> 40;  // the stretches
     if (n_table) {
       const int seg_bits = swg_bits_for(n_runs) ? swg_bits_for(n_runs) : 1, pos_bits = swg_bits_for(ht[1]) ? swg_bits_for(ht[1]) : 1;
       SWG_TRY(scaffold_sweep_segments(ctx, n_table, CA.T_seg, seg_bits, CA.T_qs, CA.T_qe, CA.T_ts, CA.T_te, CA.T_wid, kq, kt,
@@ -2665,7 +2668,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     SWG_LAUNCH(ctx, "pair_number", pair_number_small_kernel<<<1, 512, 0, st>>>(n_runs, info, sum, gl_first, r->seq_genome_last, gp2_first,
                                                                      r->seq_genome_two, C));
     SWG_KERNEL_CHECK(ctx);
-  } else if (n_runs <= 32768u) {
+  } else if (n_runs <= 12288u) {  // (a wavefront per key counts the smaller keys: quadratic -- 0.19 ms at 9,900 pairs, 1.45 at 32,000)
     uint64_t* key = swg_alloc<uint64_t>(ctx, n_runs);
     uint32_t* val = swg_alloc<uint32_t>(ctx, n_runs);
     uint32_t* rank1 = swg_alloc<uint32_t>(ctx, n_runs);

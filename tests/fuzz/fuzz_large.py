@@ -28,7 +28,7 @@ SHAPES = [
     dict(name="ties_grid", n_genomes=4, chrs_per_genome=3, span=400_000, max_len=6_000, syntenic_frac=0.7, scale=0.6, grid=500),
     dict(name="minus_only", n_genomes=5, chrs_per_genome=2, span=5_000_000, max_len=10_000, syntenic_frac=0.9, scale=1.0, minus_frac=1.0),
     dict(name="non_pansn_names", n_genomes=8, chrs_per_genome=3, span=1_000_000, max_len=6_000, syntenic_frac=0.6, scale=1.0, pansn=False),
-    # ~39,800 pairs of ~25 records: more pairs than the wavefront-per-key numbering takes (the radix path of pair_number)
+    # ~39,800 pairs of ~25 records: far more pairs than the pair-resident path takes (its rule: pair_plan, swg_pair.hip)
     dict(name="tiny_pairs_40k", n_genomes=200, chrs_per_genome=1, span=200_000, max_len=4_000, syntenic_frac=0.8, scale=0.66),
 ]
 CONFIGS = [
@@ -77,7 +77,8 @@ def main():
                 table = ctx.profile_table()
                 took = "pair_renumber" in table and "chain_cuts" not in table and "cuts_from_scan" not in table
                 print("   path:", shape["name"], cname, "pair-resident" if took else "global-sort (a pair beyond the largest size class, or a condition met on the device)", flush=True)
-                assert took or shape["name"] in ("giant_pair_deep", "ties_grid"), (shape["name"], cname, sorted(table))  # (deep pairs, heavy ties)
+                # (left to the global-sort stage by rule or on the device: deep pairs, heavy ties, thousands of tiny pairs)
+                assert took or shape["name"] in ("giant_pair_deep", "ties_grid", "tiny_pairs", "tiny_pairs_40k"), (shape["name"], cname, sorted(table))
             okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in kw.items()}
             jobs.append((shape["name"], cname, rec, orc.Config(**okw), st.copy(), ch.copy(), gpu_s))
         print("generated + filtered", shape["name"], n, flush=True)
