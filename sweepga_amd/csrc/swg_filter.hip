@@ -394,6 +394,29 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
   return filter_device_any(ctx, rec, nullptr, cfg, status_out, chain_out, stats);
 }
 
+// Which of the value columns a flag set reads at all.  matches / block_len / identity feed (1) the step-1 identity floor and the
+// block-length floor, (2) the score keys of a mapping sweep with limits, (3) a chain's weighted identity: the identity floor of
+// the span / identity filter and the scores of a scaffold sweep with limits.  The CLI defaults use none of them: the host
+// paths then do not send them (25 instead of 33-41 bytes per record through the link), and the device derives an "identity"
+// from whatever the two unsent columns hold -- finite and non-negative whatever it is (u32 / max(u32, 1)), which a floor of
+// zero or less passes; a chain's weighted identity likewise (paf_filter.rs:896-913).  SWG_POISON=1 fills unsent columns
+// with 0xff bytes, so that a test sees a reader that should not be there.
+void swg_value_columns_needed(const swg_config* cfg, bool* identity_value, bool* weighted_identity) {
+  uint64_t kq, kt;
+  limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq, &kt);
+  const bool sweeps = kq != SWG_K_INF || kt != SWG_K_INF;
+  uint64_t sq, sk;
+  if (cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_ONE) {
+    sq = sk = 1;
+  } else {
+    sq = cfg->scaffold_max_per_query ? cfg->scaffold_max_per_query : SWG_K_INF;
+    sk = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
+  }
+  const bool limited = cfg->scaffold_gap != 0 && (sq != SWG_K_INF || sk != SWG_K_INF);
+  *identity_value = sweeps || !(cfg->min_identity <= 0.0);
+  *weighted_identity = cfg->scaffold_gap != 0 && (limited || !(cfg->min_scaffold_identity <= 0.0));
+}
+
 static swg_records narrow_view(const swg_records64* r) {  // everything but the six wide columns
   swg_records v{};
   v.n = r->n;
@@ -562,12 +585,18 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
   int rc = SWG_OK;
   float h2d = 0.f, d2h = 0.f;
+  static const bool poison = getenv("SWG_POISON") != nullptr;
   auto up = [&](const void* src, size_t bytes, size_t slot, bool needed) -> void* {
     char* dst = take(slot);
     if (needed && rc == SWG_OK && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy failed");
+    if (!needed && poison) (void)hipMemsetAsync(dst, 0xff, slot, st);
     return dst;
   };
+  bool id_value, wid_value;
+  swg_value_columns_needed(cfg, &id_value, &wid_value);
+  const bool send_identity = !derived_identity && id_value;             // the caller's identity column
+  const bool send_mb = wid_value || (derived_identity && id_value);     // matches and block_len
   (void)hipEventRecord(e0, st);
   d.q_id = (const uint32_t*)up(rec->q_id, n * 4, col4, true);
   d.t_id = (const uint32_t*)up(rec->t_id, n * 4, col4, true);
@@ -575,12 +604,10 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   d.q_end = (const uint32_t*)up(rec->q_end, n * 4, col4, true);
   d.t_start = (const uint32_t*)up(rec->t_start, n * 4, col4, true);
   d.t_end = (const uint32_t*)up(rec->t_end, n * 4, col4, true);
-  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, scaffold || derived_identity);  // the scaffold stage; a derived identity
-  // block_len: the retain test (vacuous for min_block_length 0; prepare_kernel then never reads it), the scaffold stage, a
-  // derived identity
-  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, scaffold || cfg->min_block_length != 0 || derived_identity);
-  d.identity = (const double*)up(rec->identity, n * 8, col8, !derived_identity);
-  if (derived_identity) d.identity = nullptr;
+  d.matches = (const uint32_t*)up(rec->matches, n * 4, col4, send_mb);
+  d.block_len = (const uint32_t*)up(rec->block_len, n * 4, col4, send_mb || cfg->min_block_length != 0);
+  d.identity = (const double*)up(rec->identity, n * 8, col8, send_identity);
+  if (!send_identity) d.identity = nullptr;  // (derived on the device: from the columns, or -- nobody reading it -- from anything)
   d.strand = (const uint8_t*)up(rec->strand, n, col1, scaffold);         // read by the scaffold stage only
   d.seq_genome_last = (const uint32_t*)up(rec->seq_genome_last, (size_t)rec->n_seq * 4, seqt, true);
   d.seq_genome_two = (const uint32_t*)up(rec->seq_genome_two, (size_t)rec->n_seq * 4, seqt, true);

@@ -14,6 +14,8 @@ int swg_mapping_sweep(swg_ctx* ctx, const swg_records* r, const swg_config* cfg,
                       int* q_order_valid = nullptr, const void* pair_runs = nullptr, uint32_t n_pair_runs = 0,
                       const uint64_t* score_key = nullptr, uint64_t n_alive = 0);
 
+// which value columns (identity / matches + block_len) a flag set reads: csrc/swg_filter.hip
+void swg_value_columns_needed(const swg_config* cfg, bool* identity_value, bool* weighted_identity);
 // Streamed host path (csrc/swg_stream.hip): ranges of whole query genomes, uploads overlapped with the filter.  *taken = 0:
 // not applicable (input not grouped by query genome, too small, SWG_STREAM=0), nothing was done; the caller runs its own path.
 int swg_stream_try(swg_ctx* const* ctxs, int n_ctx, const swg_records* r, const swg_config* cfg, uint8_t* status_out,

@@ -59,8 +59,12 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
   auto fail = [&](int rc) { D.rc = rc; };
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(swg_set_error(ctx, SWG_ERR_HIP, "hipSetDevice failed"));
   const bool scaffold = cfg->scaffold_gap != 0;
-  const bool need_block = scaffold || cfg->min_block_length != 0 || !r->identity;
-  const bool need_matches = scaffold || !r->identity;
+  bool id_value, wid_value;
+  swg_value_columns_needed(cfg, &id_value, &wid_value);  // (swg_filter.hip: the CLI defaults read none of the value columns)
+  const bool send_identity = r->identity != nullptr && id_value;
+  const bool need_matches = wid_value || (!r->identity && id_value);
+  const bool need_block = need_matches || cfg->min_block_length != 0;
+  static const bool poison = getenv("SWG_POISON") != nullptr;
   uint64_t m = 0, longest = 0;
   D.local_off.assign(nc + 1, 0);
   for (size_t j = 0; j < nc; ++j) {
@@ -140,7 +144,12 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
       const uint64_t len = c.hi - c.lo, lo = c.lo, lo_d = D.local_off[j];
       for (int k = 0; k < 8 && e == hipSuccess; ++k)
         if (want4[k]) step(hipMemcpyAsync(d_c4[k] + lo_d, h_c4[k] + lo, len * 4, hipMemcpyHostToDevice, cs));
-      if (e == hipSuccess && r->identity) step(hipMemcpyAsync(d_identity + lo_d, r->identity + lo, len * 8, hipMemcpyHostToDevice, cs));
+      if (e == hipSuccess && send_identity) step(hipMemcpyAsync(d_identity + lo_d, r->identity + lo, len * 8, hipMemcpyHostToDevice, cs));
+      if (e == hipSuccess && poison) {  // (test knob: unsent columns full of 0xff bytes)
+        for (int k = 6; k < 8 && e == hipSuccess; ++k)
+          if (!want4[k]) step(hipMemsetAsync(d_c4[k] + lo_d, 0xff, len * 4, cs));
+        if (e == hipSuccess && !send_identity) step(hipMemsetAsync(d_identity + lo_d, 0xff, len * 8, cs));
+      }
       if (e == hipSuccess && scaffold) step(hipMemcpyAsync(d_strand + lo_d, r->strand + lo, len, hipMemcpyHostToDevice, cs));
       if (e == hipSuccess && j + 1 == nc) step(hipEventRecord(t_last, cs));
       if (e == hipSuccess) step(hipEventRecord(up_ev[j], cs));
@@ -201,7 +210,7 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
     d.t_end = d_c4[5] + lo_d;
     d.matches = d_c4[6] + lo_d;
     d.block_len = d_c4[7] + lo_d;
-    d.identity = r->identity ? d_identity + lo_d : nullptr;
+    d.identity = send_identity ? d_identity + lo_d : nullptr;  // (derived on the device: from the columns, or -- nobody reading it -- from anything)
     d.strand = d_strand + lo_d;
     swg_stats& st = D.cstats[j];
     const double waited = since();

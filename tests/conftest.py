@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The host paths do not send the value columns (identity / matches / block_len) a flag set does not read; under this knob the
+# library fills what it did not send with 0xff bytes, so that every GPU test doubles as a check that nobody reads them anyway.
+os.environ.setdefault("SWG_POISON", "1")
 
 
 def pytest_configure(config):

@@ -18,6 +18,10 @@ CONFIGS = [
     dict(mapping_filter_mode="OneToOne", scaffold_gap=0),        # sweep only: no chain numbers
     dict(mapping_filter_mode="OneToMany", mapping_max_per_query=2, scaffold_gap=10_000, min_scaffold_length=1_000,
          min_block_length=300, min_identity=0.8, scaffold_max_deviation=5_000),
+    # who reads the value columns (the host paths send only what is read): a chain identity floor alone, a block floor alone
+    dict(scaffold_gap=20_000, min_scaffold_length=3_000, min_scaffold_identity=0.93),
+    dict(scaffold_gap=20_000, min_scaffold_length=3_000, min_block_length=1_500),
+    dict(scaffold_gap=0, min_identity=0.9),
 ]
 
 
