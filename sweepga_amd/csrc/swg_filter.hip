@@ -396,10 +396,12 @@ extern "C" int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg
 
 // Which of the value columns a flag set reads at all.  matches / block_len / identity feed (1) the step-1 identity floor and the
 // block-length floor, (2) the score keys of a mapping sweep with limits, (3) a chain's weighted identity: the identity floor of
-// the span / identity filter and the scores of a scaffold sweep with limits.  The CLI defaults use none of them: the host
-// paths then do not send them (25 instead of 33-41 bytes per record through the link), and the device derives an "identity"
-// from whatever the two unsent columns hold -- finite and non-negative whatever it is (u32 / max(u32, 1)), which a floor of
-// zero or less passes; a chain's weighted identity likewise (paf_filter.rs:896-913).  SWG_POISON=1 fills unsent columns
+// the span / identity filter and the scores of a scaffold sweep with limits.  The CLI defaults use none of them: with a DERIVED
+// identity (no identity column from the caller: matches / max(block_len, 1)) the host paths then send neither matches nor
+// block_len (25 instead of 33 bytes per record through the link), and the device derives an "identity" from whatever the two
+// unsent columns hold -- finite and non-negative whatever it is (u32 / max(u32, 1)), which a floor of zero or less passes; a
+// chain's weighted identity likewise (paf_filter.rs:896-913).  A caller's own identity column is always sent: it may hold
+// anything, and a negative or NaN value fails even a floor of zero.  SWG_POISON=1 fills unsent columns
 // with 0xff bytes, so that a test sees a reader that should not be there.
 void swg_value_columns_needed(const swg_config* cfg, bool* identity_value, bool* weighted_identity) {
   uint64_t kq, kt;
@@ -413,8 +415,9 @@ void swg_value_columns_needed(const swg_config* cfg, bool* identity_value, bool*
     sk = cfg->scaffold_max_per_target ? cfg->scaffold_max_per_target : SWG_K_INF;
   }
   const bool limited = cfg->scaffold_gap != 0 && (sq != SWG_K_INF || sk != SWG_K_INF);
-  *identity_value = sweeps || !(cfg->min_identity <= 0.0);
-  *weighted_identity = cfg->scaffold_gap != 0 && (limited || !(cfg->min_scaffold_identity <= 0.0));
+  static const bool send_all = getenv("SWG_SEND_ALL") != nullptr;  // (test knob: every column whatever the flag set)
+  *identity_value = send_all || sweeps || !(cfg->min_identity <= 0.0);
+  *weighted_identity = send_all || (cfg->scaffold_gap != 0 && (limited || !(cfg->min_scaffold_identity <= 0.0)));
 }
 
 static swg_records narrow_view(const swg_records64* r) {  // everything but the six wide columns
@@ -595,7 +598,9 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
   };
   bool id_value, wid_value;
   swg_value_columns_needed(cfg, &id_value, &wid_value);
-  const bool send_identity = !derived_identity && id_value;             // the caller's identity column
+  // the caller's own identity column always goes: whatever it holds (a dv:f: override may be negative or NaN) decides the
+  // step-1 test even against a floor of zero -- only the DERIVED identity is known to pass it
+  const bool send_identity = !derived_identity;
   const bool send_mb = wid_value || (derived_identity && id_value);     // matches and block_len
   (void)hipEventRecord(e0, st);
   d.q_id = (const uint32_t*)up(rec->q_id, n * 4, col4, true);

@@ -61,7 +61,7 @@ void run_device(DeviceRun& D, const swg_records* r, const swg_config* cfg, const
   const bool scaffold = cfg->scaffold_gap != 0;
   bool id_value, wid_value;
   swg_value_columns_needed(cfg, &id_value, &wid_value);  // (swg_filter.hip: the CLI defaults read none of the value columns)
-  const bool send_identity = r->identity != nullptr && id_value;
+  const bool send_identity = r->identity != nullptr;  // (the caller's own column: always -- see swg_value_columns_needed)
   const bool need_matches = wid_value || (!r->identity && id_value);
   const bool need_block = need_matches || cfg->min_block_length != 0;
   static const bool poison = getenv("SWG_POISON") != nullptr;

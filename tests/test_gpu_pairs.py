@@ -208,6 +208,22 @@ def test_many_tiny_pairs_are_left_to_the_global_path(sw):
     run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=True)
 
 
+def test_a_callers_identity_column_is_always_read(sw):
+    """The host paths send only the value columns a flag set reads -- but a caller's OWN identity column may hold anything (a dv:f:
+    override above 1 makes it negative), and a negative or NaN identity fails the step-1 test even against a floor of zero
+    (src/paf_filter.rs:384-388): only the identity DERIVED on the device is known to pass.  Found by the fuzzer."""
+    rng = np.random.default_rng(1307)
+    rec = pair_major(gen.random_records(rng, 9_000, n_genomes=3, chrs_per_genome=2, span=400_000, zero_frac=0.0), rng)
+    rec.identity = rec.identity.copy()
+    rec.identity[::7] = -0.25
+    rec.identity[3::11] = np.nan
+    for cfg in ({}, {"scaffold_gap": 5_000, "min_scaffold_length": 1_000, "scaffold_max_deviation": 3_000},
+                {"scaffold_filter_mode": "OneToMany", "scaffold_max_per_query": 3, "scaffold_max_per_target": 3, "scaffold_gap": 10_000,
+                 "min_scaffold_length": 1_000, "min_block_length": 2_000}):
+        st, ch, stats = run_both(sw, rec, cfg, expect_pair_path=None)
+        assert (st[::7] == 0).all() and (st[3::11] == 0).all()
+
+
 def test_knob_off_gives_the_same_answer(sw):
     code = r"""
 import numpy as np, sys
