@@ -18,6 +18,7 @@ run () {  # name, env assignments..., -- command
   echo "$name rc=$? $(tail -1 gpurun_out/${TAG}_$name.log | cut -c1-200)"
 }
 mkdir -p gpurun_out
+export SWG_POISON=1   # value columns the host paths do not send are filled with 0xff bytes: a reader that should not be there shows
 # Round 5: the scaffold stage of inputs of up to 65,536 records (every case of fuzz_gpu.py) runs pair-resident (swg_pair.hip)
 # unless SWG_GROUP_FUSED=0: `gpu` / `gpu_wide` are that path, the legs with knobs of the global-sort stage switch it off.
 run gpu        X=1                python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 11
