@@ -242,7 +242,8 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     uint64_t kq1, kt1;
     limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
     // (the plan also serves a mapping sweep with limits: its axes sort their begins segment by segment over the plan's runs)
-    if (cfg->scaffold_gap != 0 || (kq1 != SWG_K_INF || kt1 != SWG_K_INF)) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
+    // (... of a large input: the small ones' plan goes through the hash grouping, which only the scaffold stage reads)
+    if (cfg->scaffold_gap != 0 || ((kq1 != SWG_K_INF || kt1 != SWG_K_INF) && n > 65536)) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
   }
   {
     uint64_t kq1, kt1;
