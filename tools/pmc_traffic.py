@@ -44,6 +44,10 @@ def short_name(name):
         base += {"64": "_s", "256": "_m"}.get(t[0], "")
     if base in ("run_alive", "run_key"):
         base = "seg_" + base
+    if base == "assign_numbers_runs":
+        base = "assign_numbers"
+    if base == "pair_starts":          # (the run list's first step, launched under the label of its second)
+        base = "pair_runs"
     if base == "pair_out":             # (large inputs: the numbering's last step also brings the results to input order)
         base = "pair_renumber"
     if base == "pair_long_plan":
