@@ -109,7 +109,9 @@ def _headers():
     return hs
 
 
-COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# SWG_DEFINES (environment): extra compiler flags of an experiment build, e.g. "-DSWG_SEG_TIMING" (part of the stamp: switching
+# it recompiles every object)
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("SWG_DEFINES", "").split()
 STAMP = os.path.join(OBJ_DIR, "compile.stamp")
 
 

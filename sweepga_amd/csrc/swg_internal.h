@@ -38,6 +38,8 @@ struct swg_ctx {
   const uint32_t* call_group32 = nullptr;  // the running call's (query, target, strand) group of every record, when prepare wrote it
   int sort_drop_level = 0;   // raised when a sort on a truncated key met runs too long to order in the gather (swg_radix_drop_bits)
   uint64_t sort_drop_n = 0;  // ... by a call over this many records: a call of a very different size starts from level 0 again
+  uint64_t seg_sweep_deep_n = 0;  // the segment-resident k = 1 sweep met deep data on an axis of this many records: axes of about
+                                  //   that size go straight to the tile kernels (swg_seg_sweep_k1)
   // per-kernel profiler (swg_profile_*)
   bool prof_on = false;
   std::string prof_only;  // non-empty: only launches with this label are bracketed (swg_profile_select)
@@ -314,6 +316,8 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
 int swg_seg_run_alive(swg_ctx* ctx, const void* runs, uint32_t n_runs, const uint8_t* alive, uint32_t* run_alive);
 int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
                         uint32_t ntilesf, uint8_t* single, int* done);
+int swg_seg_sweep_k1(swg_ctx* ctx, const swg_axis_input& in, double thr, uint8_t* keep, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY,
+                     uint64_t* tile_xf, uint8_t* single, uint64_t* nb_left, int* outcome);
 // Both axes with k = inf in one pass; *done = 0 when zero-length intervals exist (then the per-axis calls are needed).
 int swg_kinf_both(swg_ctx* ctx, uint64_t n, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts, const uint32_t* te,
                   const uint8_t* alive, uint8_t* keep, int* done);

@@ -1475,6 +1475,17 @@ __global__ __launch_bounds__(EW_THREADS) void combine_kernel(uint64_t n, const u
   }
 }
 
+// the same over the begins of a compact list (the segment-resident sweep answered every other record): an interval of a segment
+// of more than one live record is kept iff it was the top somewhere and never overlapped one
+__global__ __launch_bounds__(EW_THREADS) void combine_begins_kernel(uint64_t nb, const uint32_t* __restrict__ I, const uint8_t* __restrict__ top,
+                                                                    const uint8_t* __restrict__ ovl, const uint8_t* __restrict__ and_with,
+                                                                    uint8_t* __restrict__ keep) {
+  const uint64_t p = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (p >= nb) return;
+  const uint32_t i = I[p];
+  keep[i] = (top[i] && !ovl[i] && (!and_with || and_with[i])) ? 1 : 0;
+}
+
 inline unsigned blocks_for(uint64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
@@ -1542,7 +1553,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* I = nullptr;
   uint32_t* E = nullptr;  // end coordinates, in one of the sort's u64 scratch buffers
   uint64_t *KEY = nullptr, *tile_x = nullptr, *tile_xf = nullptr;  // tile-start keys of the 256-begin / TBF-begin tilings
-  const uint32_t ntilesf = (uint32_t)((n + TBF - 1) / TBF);
+  uint32_t ntilesf = (uint32_t)((n + TBF - 1) / TBF);
   uint8_t* single = nullptr;
   auto sort_begins = [&]() -> int {
     S = swg_alloc<uint64_t>(ctx, n);
@@ -1684,8 +1695,45 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     return SWG_OK;
   }
 
-  SWG_TRY(sort_begins());
-  uint32_t* te = swg_alloc<uint32_t>(ctx, n);
+  // k = 1 over a pair-grouped input: the sweep of every segment that fits runs in the LDS residency of its sort
+  // (swg_seg_sweep_k1) and answers into `keep`; what is left for the kernels below are the begins of the longest segments.
+  uint64_t nbg = n;      // begins in S / I / E / KEY
+  bool compact = false;  // ... those of the longest segments only, nothing in front of them
+  if (k == 1 && in.seg_runs && !in.sorted_idx_out) {
+    S = swg_alloc<uint64_t>(ctx, n);
+    I = swg_alloc<uint32_t>(ctx, n);
+    uint32_t* E2 = swg_alloc<uint32_t>(ctx, n);
+    KEY = swg_alloc<uint64_t>(ctx, n);
+    tile_x = swg_alloc<uint64_t>(ctx, (size_t)ntiles + 1);
+    tile_xf = swg_alloc<uint64_t>(ctx, (size_t)ntilesf + 1);
+    single = swg_alloc<uint8_t>(ctx, n);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(keep, 0, n, st));
+    int outcome = 0;
+    uint64_t left = 0;
+    SWG_TRY(swg_seg_sweep_k1(ctx, in, thr, keep, S, I, E2, KEY, tile_xf, single, &left, &outcome));
+    if (outcome == 1) {
+      swg_arena_restore(ctx, mark);
+      return SWG_OK;
+    }
+    if (outcome == 2) {
+      E = E2;
+      nbg = left;
+      compact = true;
+      ntiles = (uint32_t)((nbg + TB - 1) / TB);
+      ntilesf = (uint32_t)((nbg + TBF - 1) / TBF);
+      SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
+      SWG_KERNEL_CHECK(ctx);
+    } else {
+      swg_arena_restore(ctx, mark);
+      S = nullptr;
+      I = nullptr;
+      KEY = tile_x = tile_xf = nullptr;
+      single = nullptr;
+    }
+  }
+  if (!compact) SWG_TRY(sort_begins());
+  uint32_t* te = swg_alloc<uint32_t>(ctx, nbg);
   const size_t n_pad = ((size_t)n + 255) & ~size_t(255);  // keeps `ovl` 16-byte aligned for combine's vector loads
   uint8_t* flags = swg_alloc<uint8_t>(ctx, 2 * n_pad);  // top | ovl
   // SWG_TILE_SMALL=64|128 (experiment knob): k = 1 tiles of that many begins -- a work-group of one or two wavefronts
@@ -1693,7 +1741,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   const uint32_t small_tile = (k == 1 && ntiles > 1 && (small_knob == 64 || small_knob == 128)) ? (uint32_t)small_knob : 0u;
   static const bool force512_ = getenv("SWG_TILE_512") != nullptr, force256_ = getenv("SWG_TILE_256") != nullptr;
   const bool auto_tile = k == 1 && ntiles > 1 && !small_tile && !force512_ && !force256_;  // chosen on the device: 128 / 256 / 512
-  const uint32_t nt_max = small_tile ? (uint32_t)((n + small_tile - 1) / small_tile) : auto_tile ? ntilesf : ntiles;  // finest tiling in use
+  const uint32_t nt_max = small_tile ? (uint32_t)((nbg + small_tile - 1) / small_tile) : auto_tile ? ntilesf : ntiles;  // finest tiling in use
   uint32_t* cnts = swg_alloc<uint32_t>(ctx, 2 * ((size_t)nt_max + 1));  // carry_cnt | carry_cur
   uint64_t* d_total = swg_alloc<uint64_t>(ctx, 2);
   SWG_CHECK_ARENA(ctx);
@@ -1726,20 +1774,20 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     static const bool force512 = getenv("SWG_TILE_512") != nullptr, force256 = getenv("SWG_TILE_256") != nullptr;
     mode = force512 ? 1 : force256 ? 0 : 2;
     if (mode) {
-      ntiles2 = (uint32_t)((n + 2 * TB - 1) / (2 * TB));
+      ntiles2 = (uint32_t)((nbg + 2 * TB - 1) / (2 * TB));
       tile_x2 = swg_alloc<uint64_t>(ctx, (size_t)ntiles2 + 1);
       SWG_CHECK_ARENA(ctx);
       SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles2, EW_THREADS), EW_THREADS, 0, st>>>(ntiles2, tile_x, tile_x2));
       SWG_KERNEL_CHECK(ctx);
     }
     if (mode == 2) {
-      SWG_LAUNCH(ctx, "route_estimate", route_estimate_kernel<<<blocks_for((n + EST_STRIDE - 1) / EST_STRIDE, EW_THREADS), EW_THREADS, 0, st>>>(
-                                            n, EST_STRIDE, S, E, in.pos_bits, tile_x, ntiles, reinterpret_cast<unsigned long long*>(d_total + 1)));
+      SWG_LAUNCH(ctx, "route_estimate", route_estimate_kernel<<<blocks_for((nbg + EST_STRIDE - 1) / EST_STRIDE, EW_THREADS), EW_THREADS, 0, st>>>(
+                                            nbg, EST_STRIDE, S, E, in.pos_bits, tile_x, ntiles, reinterpret_cast<unsigned long long*>(d_total + 1)));
       SWG_KERNEL_CHECK(ctx);
     }
   }
-  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for((n + 3) / 4, EW_THREADS), EW_THREADS, 0, st>>>(
-                                     n, S, E, in.pos_bits, tile_x, ntiles, tile_x2, ntiles2, mode, reinterpret_cast<unsigned long long*>(d_total + 1),
+  SWG_LAUNCH(ctx, "route_count", route_count_kernel<<<blocks_for((nbg + 3) / 4, EW_THREADS), EW_THREADS, 0, st>>>(
+                                     nbg, S, E, in.pos_bits, tile_x, ntiles, tile_x2, ntiles2, mode, reinterpret_cast<unsigned long long*>(d_total + 1),
                                      EST_STRIDE, te, carry_cnt, small_tile, tile_xf, ntilesf));
   SWG_KERNEL_CHECK(ctx);
   // (scanned over the finest tiling's length either way: the entries past a coarser tiling's end are zero)
@@ -1764,7 +1812,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     static const bool dbg = getenv("SWG_DEBUG") != nullptr;
     if (dbg && mode == 2)
       fprintf(stderr, "[swg] sweep: n %llu, estimated carry-ins per 256-begin tile %.2f -> tiles of %u begins, %llu carry-ins\n",
-              (unsigned long long)n, (double)h2[1] * EST_STRIDE / (double)((n + TB - 1) / TB), tile_size, (unsigned long long)n_carry);
+              (unsigned long long)nbg, (double)h2[1] * EST_STRIDE / (double)((nbg + TB - 1) / TB), tile_size, (unsigned long long)n_carry);
   }
   uint64_t* c_s = swg_alloc<uint64_t>(ctx, n_carry + 1);
   uint64_t* c_e = swg_alloc<uint64_t>(ctx, n_carry + 1);
@@ -1772,12 +1820,12 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t* c_id = swg_alloc<uint32_t>(ctx, n_carry + 1);
   SWG_CHECK_ARENA(ctx);
   if (n_carry) {
-    SWG_LAUNCH(ctx, "route_fill", route_fill_kernel<<<blocks_for(n, EW_THREADS), EW_THREADS, 0, st>>>(
-                                      n, S, E, in.pos_bits, KEY, I, tile_size, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
+    SWG_LAUNCH(ctx, "route_fill", route_fill_kernel<<<blocks_for(nbg, EW_THREADS), EW_THREADS, 0, st>>>(
+                                      nbg, S, E, in.pos_bits, KEY, I, tile_size, te, carry_cnt, carry_cur, c_s, c_e, c_key, c_id));
     SWG_KERNEL_CHECK(ctx);
   }
   TileArgs ta;
-  ta.n = n;
+  ta.n = nbg;
   ta.S = S;
   ta.E = E;
   ta.pos_bits = in.pos_bits;
@@ -1815,7 +1863,9 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kn_kernel<<<ntiles, TB, 0, st>>>(ta));
   }
   SWG_KERNEL_CHECK(ctx);
-  {
+  if (compact) {  // (the other records' answers are in `keep` already)
+    SWG_LAUNCH(ctx, "combine_begins", combine_begins_kernel<<<blocks_for(nbg, EW_THREADS), EW_THREADS, 0, st>>>(nbg, I, top, ovl, in.and_with, keep));
+  } else {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(in.alive) | reinterpret_cast<uintptr_t>(single) | reinterpret_cast<uintptr_t>(top) |
                            reinterpret_cast<uintptr_t>(ovl) | reinterpret_cast<uintptr_t>(in.and_with) | reinterpret_cast<uintptr_t>(keep);
     SWG_LAUNCH(ctx, "combine", combine_kernel<<<blocks_for((n + 15) / 16, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, top, ovl,

@@ -11,7 +11,7 @@ from tests import orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from model_segment_sweep import segment_sweep  # noqa: E402
+from model_segment_sweep import segment_sweep, segment_sweep_k1_resident  # noqa: E402
 
 
 def random_segment(rng, n, span, grid, malformed=False):
@@ -43,3 +43,25 @@ def test_model_equals_the_oracle(seed):
                 want = orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=k or 2 ** 63, k_t=k or 2 ** 63, thr=thr, scoring=scoring)
                 got = segment_sweep(a, b, score, k, thr)
                 assert got == sorted(want), (seed, n, k, thr, axis, got[:10], sorted(want)[:10])
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_resident_k1_model_equals_the_oracle(seed):
+    """segment_sweep_k1_resident is the executable model of seg_sweep_body (csrc/swg_segsort.hip): batches, carried intervals, one
+    evaluation per interval over the batch's range of positions.  Tiny batches so that every interval is carried somewhere."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([2, 3, 8, 40, 200, 500]))
+    qs, qe, ts, te, ident = random_segment(rng, n, int(rng.choice([50, 1_000, 100_000])), int(rng.choice([1, 1, 10])))
+    scoring = int(rng.choice([orc.LOG_LENGTH_IDENTITY, orc.IDENTITY, orc.LENGTH, orc.LENGTH_IDENTITY]))
+    score = [orc.score(int(qs[i]), int(qe[i]), float(ident[i]), scoring) for i in range(n)]
+    checked = 0
+    for thr in (0.0, 0.3, 0.95, 1.0):
+        for axis, (a, b) in ((0, (qs, qe)), (1, (ts, te))):
+            want = sorted(orc.plane_sweep(axis, qs, qe, ts, te, ident, k_q=1, k_t=1, thr=thr, scoring=scoring))
+            for cap, cmax in ((8, 10 ** 9), (3, 10 ** 9), (64, 10 ** 9), (10 ** 9, 0)):
+                got = segment_sweep_k1_resident(a, b, score, thr, cap, cmax)
+                if got is None:          # (a run of equal starts longer than a batch: the kernel hands the axis back)
+                    continue
+                checked += 1
+                assert got == want, (seed, n, thr, axis, cap, got[:10], want[:10])
+    assert checked
