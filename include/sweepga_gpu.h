@@ -160,8 +160,11 @@ int swg_filter_device(swg_ctx* ctx, const swg_records* rec, const swg_config* cf
  * The device layout stays 32-bit: every coordinate is rebased to the smallest coordinate its sequence has anywhere in the
  * record set (query and target appearances alike).  apply_filters only ever uses differences, orders and midpoints of
  * positions on one sequence, so the results are those of the unrebased records; what has to fit 32 bits is the stretch of
- * each sequence that mappings touch (and every matches / block_length value), otherwise SWG_ERR_RANGE.  start <= end is
- * assumed, as in any PAF.  swg_filter64: host pointers, rebased by host threads, then swg_filter (no extra PCIe bytes);
+ * each sequence that mappings touch (and every matches / block_length value).  A sequence touched over 2^32 bases or more is
+ * rebased per sweep segment instead -- query coordinates to the smallest one of their (query sequence, genome of the target)
+ * segment, target coordinates likewise (src/paf_filter.rs:1037-1100: no step of apply_filters compares coordinates across
+ * those segments) -- so that only the stretch touched by the mappings against ONE genome has to fit; beyond that
+ * SWG_ERR_RANGE.  start <= end is assumed, as in any PAF.  swg_filter64: host pointers, rebased by host threads, then swg_filter (no extra PCIe bytes);
  * swg_filter_device64: device pointers, rebased by two kernels, then the same pipeline as swg_filter_device. */
 typedef struct swg_records64 {
   uint64_t n;
@@ -285,7 +288,8 @@ int swg_paf_open_buffer(const char* text, uint64_t len, int threads, swg_paf** o
 void swg_paf_close(swg_paf* p);
 /* records in input order; pointers are owned by the handle.  A file with a coordinate, matches or block length >= 2^32
  * is parsed once more into 64-bit columns and rebased per sequence as swg_filter64 does: the coordinate columns are
- * then relative to swg_paf_seq_offsets()[sequence id] (NULL for a file that needed no rebasing). */
+ * then relative to swg_paf_seq_offsets()[sequence id] (NULL for a file that needed no rebasing -- and for one with a sequence
+ * touched over 2^32 bases or more, whose columns are relative to one constant per sweep segment, see swg_records64). */
 const swg_records* swg_paf_records(const swg_paf* p);
 /* 1 when every record's identity is matches / max(block_len, 1) -- no dv:f: tag had the last word on any line: a caller may
  * then pass identity = NULL in the records it hands to the filter and save the column's trip over PCIe. */

@@ -648,28 +648,37 @@ int parse_text(swg_paf* p, int threads) {
     }
   });
   lap("name merge + remap");
+  const uint32_t n_last = genome_table(p->names, prefix_last, &p->g_last);
+  const uint32_t n_two = genome_table(p->names, prefix_two, &p->g_two);
   if (wide) {
     const uint32_t n_seq = (uint32_t)(p->names.empty() ? 1 : p->names.size());
     p->seq_offset.assign(n_seq, 0);
     const uint64_t* const c64[6] = {p->wide[0].data(), p->wide[1].data(), p->wide[2].data(),
                                     p->wide[3].data(), p->wide[4].data(), p->wide[5].data()};
     uint32_t* const c32[6] = {p->qs.data(), p->qe.data(), p->ts.data(), p->te.data(), p->matches.data(), p->block.data()};
-    const swg_rebase::Result rr = swg_rebase::columns(n, p->q_id.data(), p->t_id.data(), c64, n_seq, threads, c32, p->seq_offset.data());
+    swg_rebase::Result rr = swg_rebase::columns(n, p->q_id.data(), p->t_id.data(), c64, n_seq, threads, c32, p->seq_offset.data());
+    if (!rr.ok && rr.bad_field < 4 && swg_rebase::axis_tables_fit(n_seq, n_last)) {
+      // a sequence touched over 2^32 bases or more: one constant per sweep segment and axis instead (host/rebase.h, columns_by_axis);
+      // the columns are then relative to constants the handle does not publish (swg_paf_seq_offsets: NULL)
+      const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, p->q_id.data(), p->t_id.data(), c64, n_seq, p->g_last.data(), n_last, threads, c32);
+      if (r2.ok) {
+        rr = r2;
+        p->seq_offset.clear();
+      }
+    }
     if (!rr.ok) {
       const uint64_t k = rr.bad_record;
       if (rr.bad_field >= 4)
         return paf_error(SWG_ERR_RANGE, "%s >= 2^32 on line %llu is not supported", swg_rebase::field_name(rr.bad_field),
                          (unsigned long long)(p->rank[k] + 1));
       const uint32_t sid = rr.bad_field < 2 ? p->q_id[k] : p->t_id[k];
-      return paf_error(SWG_ERR_RANGE, "the mapped stretch of sequence %s spans 2^32 bases or more (%s on line %llu, first mapped base %llu): "
-                       "not supported by the 32-bit device layout", p->names[sid].c_str(), swg_rebase::field_name(rr.bad_field),
-                       (unsigned long long)(p->rank[k] + 1), (unsigned long long)p->seq_offset[sid]);
+      return paf_error(SWG_ERR_RANGE, "the stretch of sequence %s that the mappings against one genome touch spans 2^32 bases or more (%s on "
+                       "line %llu, first mapped base %llu): not supported by the 32-bit device layout", p->names[sid].c_str(),
+                       swg_rebase::field_name(rr.bad_field), (unsigned long long)(p->rank[k] + 1), (unsigned long long)p->seq_offset[sid]);
     }
     for (auto& w : p->wide) w.alloc(0);
     lap("rebase");
   }
-  const uint32_t n_last = genome_table(p->names, prefix_last, &p->g_last);
-  const uint32_t n_two = genome_table(p->names, prefix_two, &p->g_two);
   swg_records& r = p->rec;
   r.n = n;
   r.q_id = p->q_id.data();
@@ -1313,8 +1322,18 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
       a->seq_offset.assign(n_seq, 0);
       const uint64_t* const c64[6] = {in->query_start, in->query_end, in->target_start, in->target_end, in->matches, block64.data()};
       uint32_t* const c32[6] = {a->qs.data(), a->qe.data(), a->ts.data(), a->te.data(), a->matches.data(), a->block.data()};
-      const swg_rebase::Result rr = swg_rebase::columns(n, a->q_id.data(), a->t_id.data(), c64, n_seq, pick_threads(0), c32,
-                                                        a->seq_offset.data());
+      swg_rebase::Result rr = swg_rebase::columns(n, a->q_id.data(), a->t_id.data(), c64, n_seq, pick_threads(0), c32, a->seq_offset.data());
+      if (!rr.ok && rr.bad_field < 4) {  // (see swg_paf_open)
+        std::vector<uint32_t> g_last;
+        const uint32_t n_last = genome_table(a->names, prefix_last, &g_last);
+        if (swg_rebase::axis_tables_fit(n_seq, n_last)) {
+          const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, a->q_id.data(), a->t_id.data(), c64, n_seq, g_last.data(), n_last, pick_threads(0), c32);
+          if (r2.ok) {
+            rr = r2;
+            a->seq_offset.clear();
+          }
+        }
+      }
       if (!rr.ok) {
         const uint64_t k = rr.bad_record;
         const int f = rr.bad_field;

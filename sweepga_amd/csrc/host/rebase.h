@@ -5,7 +5,8 @@
 // from all of a sequence's coordinates -- query and target appearances alike -- changes no result.  The constant is the
 // smallest coordinate the sequence has anywhere in the record set; what must fit 32 bits is then only the stretch of
 // each sequence that mappings touch, not its absolute position.  Host version (threads); the device version of the same
-// two steps is in swg_filter.hip.
+// two steps is in swg_filter.hip.  A sequence whose touched stretch is wider than that gets the finer partition of
+// columns_by_axis (below) before anything is refused.
 #ifndef SWG_HOST_REBASE_H
 #define SWG_HOST_REBASE_H
 
@@ -74,6 +75,58 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
     const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
     for (uint64_t i = b; i < e; ++i) {
       const uint64_t oq = lo[q_id[i]], ot = lo[t_id[i]];
+      const uint64_t v[6] = {c64[0][i] - oq, c64[1][i] - oq, c64[2][i] - ot, c64[3][i] - ot, c64[4] ? c64[4][i] : 0,
+                             c64[5] ? c64[5][i] : 0};
+      for (int f = 0; f < 6; ++f) {
+        if ((v[f] >> 32) && r.ok) {
+          r.ok = false;
+          r.bad_record = i;
+          r.bad_field = f;
+        }
+        if (f < 4 || c64[f]) c32[f][i] = (uint32_t)v[f];
+      }
+    }
+  });
+  for (auto& r : res)
+    if (!r.ok) return r;
+  return Result{};
+}
+
+// The finer partition, for a sequence whose mapped stretch does not fit 32 bits as a whole (round 6).  Nothing in
+// apply_filters ever compares the QUERY coordinates of two records unless they share the query sequence and the genome of the
+// target -- the mapping-level sweep's query-axis segment (src/paf_filter.rs:1037-1100); chains, the scaffold sweep, the inversion
+// capture and the rescue all nest inside one (query, target) pair, which nests inside that segment -- and likewise the TARGET
+// coordinates unless they share the target sequence and the genome of the query.  So the constant may differ from segment to
+// segment: q coordinates are rebased to the smallest one of their (q_id, genome(t_id)) segment, t coordinates to the smallest
+// one of their (t_id, genome(q_id)) segment, and what must fit 32 bits is the stretch of a sequence touched by the mappings
+// against ONE genome.  seq_genome = the records' seq_genome_last table.  Two tables of n_seq * n_genome offsets (the caller
+// checks that this is affordable: axis_tables_fit).  Same result convention as columns(); ids are taken as checked.
+inline bool axis_tables_fit(uint32_t n_seq, uint32_t n_genome) { return (uint64_t)n_seq * n_genome <= (uint64_t(1) << 24); }
+inline Result columns_by_axis(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, const uint64_t* const c64[6], uint32_t n_seq,
+                              const uint32_t* seq_genome, uint32_t n_genome, int threads, uint32_t* const c32[6]) {
+  if (threads < 1) threads = 1;
+  if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
+  const size_t cells = (size_t)n_seq * n_genome;
+  std::vector<uint64_t> lo_q(cells, UINT64_MAX), lo_t(cells, UINT64_MAX);
+  auto amin = [](uint64_t* cell, uint64_t v) {
+    uint64_t cur = __atomic_load_n(cell, __ATOMIC_RELAXED);
+    while (v < cur && !__atomic_compare_exchange_n(cell, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+  };
+  run(threads, [&](int t) {
+    const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
+    for (uint64_t i = b; i < e; ++i) {
+      const size_t cq = (size_t)q_id[i] * n_genome + seq_genome[t_id[i]], ct = (size_t)t_id[i] * n_genome + seq_genome[q_id[i]];
+      amin(&lo_q[cq], c64[0][i] < c64[1][i] ? c64[0][i] : c64[1][i]);
+      amin(&lo_t[ct], c64[2][i] < c64[3][i] ? c64[2][i] : c64[3][i]);
+    }
+  });
+  std::vector<Result> res(threads);
+  run(threads, [&](int t) {
+    Result& r = res[t];
+    const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
+    for (uint64_t i = b; i < e; ++i) {
+      const uint64_t oq = lo_q[(size_t)q_id[i] * n_genome + seq_genome[t_id[i]]], ot = lo_t[(size_t)t_id[i] * n_genome + seq_genome[q_id[i]]];
       const uint64_t v[6] = {c64[0][i] - oq, c64[1][i] - oq, c64[2][i] - ot, c64[3][i] - ot, c64[4] ? c64[4][i] : 0,
                              c64[5] ? c64[5][i] : 0};
       for (int f = 0; f < 6; ++f) {

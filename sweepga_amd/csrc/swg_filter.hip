@@ -133,6 +133,60 @@ __global__ __launch_bounds__(EW) void rebase_kernel(uint64_t n, const uint32_t* 
   if (f >= 0) atomicMin(bad, ((unsigned long long)(i + 1) << 3) | (unsigned)f);
 }
 
+// the same with one constant per sweep segment and axis (host/rebase.h, columns_by_axis): lo_q[(q, genome(t))], lo_t[(t, genome(q))]
+// (only behind seq_lo_kernel: the ids are known to be in range; the genome table's entries are the caller's, checked here)
+__global__ __launch_bounds__(EW) void axis_lo_kernel(uint64_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                     const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
+                                                     const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
+                                                     const uint32_t* __restrict__ seq_genome, uint32_t n_genome,
+                                                     unsigned long long* __restrict__ lo_q, unsigned long long* __restrict__ lo_t) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  const bool in = i < n;
+  if (__ballot(in) == 0) return;
+  uint32_t cq = 0, ct = 0;
+  unsigned long long a = 0, b = 0;
+  bool ok = in;
+  if (in) {
+    const uint32_t q = q_id[i], t = t_id[i], gq = seq_genome[q], gt = seq_genome[t];
+    ok = gq < n_genome && gt < n_genome;
+    if (ok) {
+      cq = q * n_genome + gt;
+      ct = t * n_genome + gq;
+      a = qs[i] < qe[i] ? qs[i] : qe[i];
+      b = ts[i] < te[i] ? ts[i] : te[i];
+    }
+  }
+  seq_min_atomic(lo_q, cq, a, ok);
+  seq_min_atomic(lo_t, ct, b, ok);
+}
+__global__ __launch_bounds__(EW) void axis_rebase_kernel(uint64_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                         const uint64_t* __restrict__ qs, const uint64_t* __restrict__ qe,
+                                                         const uint64_t* __restrict__ ts, const uint64_t* __restrict__ te,
+                                                         const uint64_t* __restrict__ matches, const uint64_t* __restrict__ block,
+                                                         const uint32_t* __restrict__ seq_genome, uint32_t n_genome,
+                                                         const unsigned long long* __restrict__ lo_q, const unsigned long long* __restrict__ lo_t,
+                                                         uint32_t* __restrict__ o_qs, uint32_t* __restrict__ o_qe, uint32_t* __restrict__ o_ts,
+                                                         uint32_t* __restrict__ o_te, unsigned long long* __restrict__ bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * EW + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t q = q_id[i], t = t_id[i], gq = seq_genome[q], gt = seq_genome[t];
+  if (gq >= n_genome || gt >= n_genome) {
+    atomicMin(bad, ((unsigned long long)(i + 1) << 3) | 6u);
+    return;
+  }
+  const unsigned long long oq = lo_q[(size_t)q * n_genome + gt], ot = lo_t[(size_t)t * n_genome + gq];
+  const unsigned long long v[6] = {qs[i] - oq, qe[i] - oq, ts[i] - ot, te[i] - ot, matches[i], block[i]};  // (the last two: rebase_kernel wrote them)
+  o_qs[i] = (uint32_t)v[0];
+  o_qe[i] = (uint32_t)v[1];
+  o_ts[i] = (uint32_t)v[2];
+  o_te[i] = (uint32_t)v[3];
+  int f = -1;
+#pragma unroll
+  for (int k = 5; k >= 0; --k)
+    if (v[k] >> 32) f = k;
+  if (f >= 0) atomicMin(bad, ((unsigned long long)(i + 1) << 3) | (unsigned)f);
+}
+
 void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, uint64_t* kt) {
   // src/paf_filter.rs:1004-1014
   switch (mode) {
@@ -482,6 +536,22 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
     SWG_KERNEL_CHECK(ctx);
     uint64_t hb;
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(bad), &hb, 1));
+    if (hb != ~0ull && (hb & 7) < 4 && swg_rebase::axis_tables_fit(rec->n_seq, rec->n_genome_last)) {
+      // a sequence touched over 2^32 bases or more: the constants per sweep segment -- (sequence, genome of the other side) --
+      // instead (host/rebase.h, columns_by_axis)
+      const size_t cells = (size_t)rec->n_seq * rec->n_genome_last;
+      unsigned long long* lo2 = swg_alloc<unsigned long long>(ctx, 2 * cells + 1);
+      SWG_CHECK_ARENA(ctx);
+      unsigned long long* bad2 = lo2 + 2 * cells;
+      SWG_HIP(ctx, hipMemsetAsync(lo2, 0xff, (2 * cells + 1) * sizeof(unsigned long long), st));
+      SWG_LAUNCH(ctx, "axis_lo", axis_lo_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end, rec64->t_start,
+                                                                     rec64->t_end, rec->seq_genome_last, rec->n_genome_last, lo2, lo2 + cells));
+      SWG_LAUNCH(ctx, "axis_rebase", axis_rebase_kernel<<<nblk(n), EW, 0, st>>>(n, rec64->q_id, rec64->t_id, rec64->q_start, rec64->q_end,
+                                                                             rec64->t_start, rec64->t_end, rec64->matches, rec64->block_len, rec->seq_genome_last,
+                                                                             rec->n_genome_last, lo2, lo2 + cells, c[0], c[1], c[2], c[3], bad2));
+      SWG_KERNEL_CHECK(ctx);
+      SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<uint64_t*>(bad2), &hb, 1));
+    }
     if (hb != ~0ull) {
       static const char* const F[8] = {"query_start", "query_end", "target_start", "target_end", "matches", "block_length", "?", "?"};
       const int f = (int)(hb & 7);
@@ -489,8 +559,8 @@ static int filter_device_any(swg_ctx* ctx, const swg_records* rec, const swg_rec
         return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)((hb >> 3) - 1));
       return swg_set_error(ctx, SWG_ERR_RANGE,
                            f >= 4 ? "record %llu: %s >= 2^32 is not supported"
-                                  : "record %llu: the mapped stretch of its sequence spans 2^32 bases or more (%s): not supported by the "
-                                    "32-bit device layout",
+                                  : "record %llu: the stretch of its sequence that the mappings against one genome touch spans 2^32 bases or "
+                                    "more (%s): not supported by the 32-bit device layout",
                            (unsigned long long)((hb >> 3) - 1), F[f]);
     }
     swg_records r32 = *rec;
@@ -675,11 +745,24 @@ int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cf
   }
   if (!rr.ok && rr.bad_field == 6)
     return swg_set_error(ctx, SWG_ERR_INVALID, "record %llu: sequence id out of range", (unsigned long long)rr.bad_record);
+  if (!rr.ok && rr.bad_field < 4 && swg_rebase::axis_tables_fit(rec->n_seq, rec->n_genome_last)) {
+    // a sequence touched over 2^32 bases or more: the constants per sweep segment -- (sequence, genome of the other side) -- instead
+    for (uint32_t s = 0; s < rec->n_seq; ++s)
+      if (rec->seq_genome_last[s] >= rec->n_genome_last) return swg_set_error(ctx, SWG_ERR_INVALID, "seq_genome_last[%u] out of range", s);
+    try {
+      rr = swg_rebase::columns_by_axis(n, rec->q_id, rec->t_id, c64, rec->n_seq, rec->seq_genome_last, rec->n_genome_last,
+                                       hc ? (int)(hc > 64 ? 64 : hc) : 1, c32);
+    } catch (const std::bad_alloc&) {
+      return swg_set_error(ctx, SWG_ERR_OOM, "out of host memory while rebasing %llu records", (unsigned long long)n);
+    } catch (const std::system_error& e) {
+      return swg_set_error(ctx, SWG_ERR_OOM, "cannot start host threads: %s", e.what());
+    }
+  }
   if (!rr.ok)
     return swg_set_error(ctx, SWG_ERR_RANGE,
                          rr.bad_field >= 4 ? "record %llu: %s >= 2^32 is not supported"
-                                           : "record %llu: the mapped stretch of its sequence spans 2^32 bases or more (%s): not "
-                                             "supported by the 32-bit device layout",
+                                           : "record %llu: the stretch of its sequence that the mappings against one genome touch spans 2^32 "
+                                             "bases or more (%s): not supported by the 32-bit device layout",
                          (unsigned long long)rr.bad_record, swg_rebase::field_name(rr.bad_field));
   v.q_start = c32[0];
   v.q_end = c32[1];

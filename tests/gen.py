@@ -106,3 +106,24 @@ def shifted(rec, rng):
     ot = np.array([off[x] for x in rec.tname], dtype=np.uint64)
     return orc.Records(rec.qname, rec.tname, rec.qs + oq, rec.qe + oq, rec.ts + ot, rec.te + ot, rec.block_length, rec.identity,
                        rec.matches, rec.strand, rec.rank), off
+
+
+def shifted_by_axis(rec, rng):
+    """The same records with the QUERY coordinates moved by a constant per (query sequence, genome of the target) and the TARGET
+    coordinates by a constant per (target sequence, genome of the query) -- the mapping-level sweep's segments
+    (src/paf_filter.rs:1037-1100; genome = the name up to its last '#').  A sequence mapped against several genomes is then touched
+    over far more than 2^32 bases, each of its segments over as few as before."""
+    genome = lambda name: name.rsplit("#", 1)[0] + "#" if "#" in name else name   # noqa: E731
+    pick = lambda: WIDE_OFFSETS[int(rng.integers(0, len(WIDE_OFFSETS)))]            # noqa: E731
+    off_q, off_t = {}, {}
+    oq = np.zeros(len(rec), dtype=np.uint64)
+    ot = np.zeros(len(rec), dtype=np.uint64)
+    for i, (q, t) in enumerate(zip(rec.qname, rec.tname)):
+        kq, kt = (q, genome(t)), (t, genome(q))
+        if kq not in off_q:
+            off_q[kq] = pick()
+        if kt not in off_t:
+            off_t[kt] = pick()
+        oq[i], ot[i] = off_q[kq], off_t[kt]
+    return orc.Records(rec.qname, rec.tname, rec.qs + oq, rec.qe + oq, rec.ts + ot, rec.te + ot, rec.block_length, rec.identity,
+                       rec.matches, rec.strand, rec.rank)

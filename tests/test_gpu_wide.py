@@ -51,13 +51,84 @@ def test_filter64_matches_oracle(sw, seed, cfg_i):
     assert np.array_equal(chain, och), int((chain != och).sum())
 
 
+def test_a_sequence_touched_over_more_than_2_32_bases(sw, tmp_path):
+    """SURVEY H6, RecordMeta's u64 fields (src/paf_filter.rs:58-62): a sequence whose mappings against DIFFERENT genomes lie more
+    than 2^32 bases apart does not fit one constant per sequence; the front ends then rebase per sweep segment -- (sequence, genome
+    of the other side), which every comparison of the filter nests in (tests/test_wide_cpu.py shows the invariance on the
+    oracle).  Status and chain numbers against the oracle on the u64 records: host columns (swg_filter64), device columns
+    (swg_filter_device64) and a PAF through the command line, for the CLI defaults, a scaffold flag set with a rescue, the 1:1
+    sweep alone and the full pipeline behind it."""
+    from sweepga_amd import build
+    from sweepga_amd._lib import SwgRecords, SwgStats
+    rng = np.random.default_rng(4711)
+    rec0 = gen.random_records(rng, 30_000, n_genomes=4, chrs_per_genome=2, span=1_500_000, minus_frac=0.3)
+    rec = gen.shifted_by_axis(rec0, rng)
+    # (the premise: some sequence's query coordinates spread over 2^32 bases or more)
+    spread = {}
+    for q, a, b in zip(rec.qname, rec.qs, rec.qe):
+        lo, hi = spread.get(q, (int(a), int(b)))
+        spread[q] = (min(lo, int(a)), max(hi, int(b)))
+    assert max(hi - lo for lo, hi in spread.values()) >= 2**32
+    packed = sw.pack_records(gen.records_to_meta(rec))
+    assert packed.wide
+    cfgs = [dict(),
+            dict(scaffold_gap=3_000, min_scaffold_length=4_000, scaffold_max_deviation=5_000),
+            dict(mapping_filter_mode="OneToOne", scaffold_gap=0),
+            dict(mapping_filter_mode="OneToOne", scaffold_filter_mode="OneToOne", scaffold_gap=5_000, min_scaffold_length=1_000,
+                 scaffold_max_deviation=30_000)]
+    hip = Hip()
+    try:
+        r = SwgRecords()
+        n = len(rec)
+        r.n = n
+        for k in ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", "matches", "block_len", "strand"):
+            setattr(r, k, hip.up(packed.cols[k]))
+        r.n_seq = packed.n_seq
+        r.seq_genome_last = hip.up(packed.seq_genome_last)
+        r.n_genome_last = packed.n_genome_last
+        r.seq_genome_two = hip.up(packed.seq_genome_two)
+        r.n_genome_two = packed.n_genome_two
+        d_status, d_chain = hip.alloc(n), hip.alloc(4 * n)
+        ctx = sw.default_context()
+        for kw in cfgs:
+            cfg = sw.FilterConfig(**{k: (getattr(sw.FilterMode, v) if isinstance(v, str) else v) for k, v in kw.items()})
+            ocfg = orc.Config(**{k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in kw.items()})
+            ost, och = orc.apply_filters(ocfg, rec)
+            status, chain = sw.PafFilter(cfg).filter_columns(packed)                       # host columns: swg_filter64
+            assert np.array_equal(status, ost) and np.array_equal(chain, och), (kw, int((status != ost).sum()))
+            stats = SwgStats()
+            cc = cfg.to_c(False, False)
+            ctx.check(ctx.lib.swg_filter_device64(ctx.handle, C.byref(r), C.byref(cc), C.c_void_p(d_status), C.c_void_p(d_chain),
+                                                  C.byref(stats)))                        # device columns: two more kernels
+            ctx.synchronize()
+            status, chain = hip.down(d_status, np.uint8, n), hip.down(d_chain, np.uint32, n)
+            assert np.array_equal(status, ost) and np.array_equal(chain, och), (kw, "device", int((status != ost).sum()))
+    finally:
+        hip.free()
+    # the same records as a PAF through the command line, byte for byte against the oracle's CLI (which keeps u64)
+    inp = tmp_path / "wide.paf"
+    inp.write_text(gen.records_to_paf(rng, rec), newline="")
+    for flags in ([], ["--num-mappings", "1:1", "--scaffold-jump", "0"],
+                  ["--num-mappings", "1:1", "--scaffold-filter", "1:1", "--scaffold-dist", "20000"]):
+        a, b = tmp_path / "a.paf", tmp_path / "b.paf"
+        out = subprocess.run([build.CLI, str(inp), "--output-file", str(a), "--quiet", *flags], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        subprocess.check_call([os.path.join(ROOT, "oracle", "sweepga-ref"), str(inp), "--output-file", str(b), *flags])
+        assert a.read_bytes() == b.read_bytes() and a.stat().st_size > 0, flags
+
+
 def test_filter64_range_errors(sw):
+    """What stays refused: ONE sweep segment -- a sequence against one genome -- touched over 2^32 bases or more, and a matches /
+    block length that does not fit 32 bits."""
     from sweepga_amd import RecordMeta, SwgError
     f = sw.PafFilter(sw.FilterConfig())
     a = RecordMeta(0, "g1#1#a", "g2#1#b", 10, 2000, 0, 2000, 2000, 0.9, 1800, 2000, "+")
     far = RecordMeta(1, "g1#1#a", "g2#1#b", 2**32 + 10, 2**32 + 2000, 0, 2000, 2000, 0.9, 1800, 2000, "+")
-    with pytest.raises(SwgError, match="mapped stretch of its sequence spans 2\\^32"):
-        f.filter_columns(sw.pack_records([a, far]))                      # the stretch [10, 2^32 + 2000) does not fit
+    with pytest.raises(SwgError, match="against one genome touch spans 2\\^32"):
+        f.filter_columns(sw.pack_records([a, far]))                      # the stretch [10, 2^32 + 2000) of one segment does not fit
+    far2 = RecordMeta(1, "g1#1#a", "g3#1#b", 2**32 + 10, 2**32 + 2000, 0, 2000, 2000, 0.9, 1800, 2000, "+")
+    st, ch = f.filter_columns(sw.pack_records([a, far2]))                # against another genome: a segment of its own
+    assert len(st) == 2
     big = RecordMeta(0, "g1#1#a", "g2#1#b", 10, 2000, 0, 2000, 2**32, 0.9, 1800, 2**32, "+")
     with pytest.raises(SwgError, match="block_length >= 2\\^32"):
         f.filter_columns(sw.pack_records([big]))

@@ -31,6 +31,25 @@ def test_oracle_is_invariant_under_per_sequence_shifts(seed, cfg_i):
         assert np.array_equal(st0, st1) and np.array_equal(ch0, ch1), (max(off.values()), int((st0 != st1).sum()))
 
 
+@pytest.mark.parametrize("cfg_i", range(len(SCAFFOLD_CFGS)))
+@pytest.mark.parametrize("seed", range(3))
+def test_oracle_is_invariant_under_shifts_per_sweep_segment(seed, cfg_i):
+    """The finer partition (rebase.h, columns_by_axis): query coordinates moved by a constant per (query sequence, genome of the
+    target), target coordinates per (target sequence, genome of the query).  No step of apply_filters compares coordinates
+    across those segments -- the fallback for a sequence that is touched over 2^32 bases or more."""
+    rng = np.random.default_rng(7300 + 10 * cfg_i + seed)
+    n = int(rng.choice([50, 1_000, 6_000]))
+    rec0 = gen.random_records(rng, n, n_genomes=int(rng.integers(2, 5)), chrs_per_genome=int(rng.integers(1, 3)),
+                              span=int(rng.choice([20_000, 300_000])), minus_frac=0.3)
+    rec = gen.shifted_by_axis(rec0, rng)
+    ocfg = _ocfg(cfg_i)
+    for keep_self, scaffolds_only in ((False, False), (True, True)):
+        ocfg.keep_self, ocfg.scaffolds_only = keep_self, scaffolds_only
+        st0, ch0 = orc.apply_filters(ocfg, rec0)
+        st1, ch1 = orc.apply_filters(ocfg, rec)
+        assert np.array_equal(st0, st1) and np.array_equal(ch0, ch1), int((st0 != st1).sum())
+
+
 def test_aln_front_end_rebases_wide_coordinates():
     from sweepga_amd import AlnRecords, SwgError
     qn = ["a x", "a", "b", "b"]
