@@ -52,10 +52,12 @@ REC_COLS = ("q_id", "t_id", "q_start", "q_end", "t_start", "t_end", "identity", 
 SBIG1_LEN = 248_956_422
 
 
-def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pair=False):
+def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pair=False, chroms=1):
     """Synthetic records on the device, group-major order, as an aligner emits pairs.
     S-pan: n_genomes single-chromosome genomes, every ordered non-self pair, lognormal(0.5) group sizes.
-    S-big1 (single_pair): every record maps sequence 0 onto sequence 1 (one query segment, one target segment)."""
+    S-big1 (single_pair): every record maps sequence 0 onto sequence 1 (one query segment, one target segment).
+    chroms > 1: every genome has that many chromosomes (sequence id = genome * chroms + chromosome, of chr_len / chroms bases),
+    homologous chromosomes map onto each other: n_genomes * (n_genomes - 1) * chroms sequence pairs."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     if device.type == "cuda":
@@ -65,15 +67,20 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pai
         q = torch.zeros(n, dtype=torch.int32, device=device)
         t = torch.ones(n, dtype=torch.int32, device=device)
     else:
-        P = n_genomes * (n_genomes - 1)
+        P = n_genomes * (n_genomes - 1) * chroms
         w = torch.exp(0.5 * torch.randn(P, generator=g, device=device, dtype=torch.float64))
         sizes = torch.floor(w / w.sum() * n).to(torch.int64)
         sizes[0] += n - int(sizes.sum())
         pair = torch.repeat_interleave(torch.arange(P, device=device, dtype=torch.int32), sizes)
+        c = pair % chroms
+        pair = torch.div(pair, chroms, rounding_mode="floor")
         q = torch.div(pair, n_genomes - 1, rounding_mode="floor")
         t = pair - q * (n_genomes - 1)
         t = t + (t >= q).to(torch.int32)
-        del pair
+        if chroms > 1:
+            q, t = q * chroms + c, t * chroms + c
+            chr_len = chr_len // chroms
+        del pair, c
     ln = torch.exp(7.6009 + 1.2 * torch.randn(n, generator=g, device=device)).clamp_(100, 500_000).to(torch.int32)
     ln = torch.minimum(ln, torch.tensor(max(chr_len // 2, 100), dtype=torch.int32, device=device))
     room = (chr_len - ln).to(torch.float32)
@@ -92,7 +99,7 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pai
     matches = torch.floor(ident.to(torch.float64) * block.to(torch.float64)).to(torch.int32)
     identity = matches.to(torch.float64) / block.to(torch.float64)
     strand = (torch.rand(n, generator=g, device=device) < 0.1).to(torch.uint8)
-    table = torch.arange(n_genomes, device=device, dtype=torch.int32)
+    table = torch.div(torch.arange(n_genomes * chroms, device=device, dtype=torch.int32), chroms, rounding_mode="floor")
     cols = dict(q_id=q.contiguous(), t_id=t.contiguous(), q_start=qs, q_end=qs + ln, t_start=ts, t_end=ts + ln,
                 identity=identity.contiguous(), matches=matches, block_len=block.contiguous(), strand=strand,
                 seq_genome_last=table, seq_genome_two=table.clone())
@@ -113,7 +120,7 @@ def make_records(lib_mod, cols, n, n_genomes):
     r.n = n
     for k in REC_COLS:
         setattr(r, k, cols[k].data_ptr())
-    r.n_seq = n_genomes
+    r.n_seq = int(cols["seq_genome_last"].numel())   # (n_genomes sequences unless the genomes have several chromosomes)
     r.seq_genome_last = cols["seq_genome_last"].data_ptr()
     r.n_genome_last = n_genomes
     r.seq_genome_two = cols["seq_genome_two"].data_ptr()

@@ -295,6 +295,9 @@ const swg_records* swg_paf_records(const swg_paf* p);
  * then pass identity = NULL in the records it hands to the filter and save the column's trip over PCIe. */
 int swg_paf_identity_is_derived(const swg_paf* p);
 const uint64_t* swg_paf_seq_offsets(const swg_paf* p);
+/* ... a file with a sequence touched over 2^32 bases or more: [n] what was taken off every RECORD's query (axis 0) or target
+ * (axis 1) coordinates (one constant per sweep segment, see swg_records64); NULL otherwise. */
+const uint64_t* swg_paf_record_offsets(const swg_paf* p, int axis);
 /* physical line count (incl. skipped lines) and each record's rank = 0-based line index (src/paf_filter.rs:298) */
 uint64_t swg_paf_num_lines(const swg_paf* p);
 const uint64_t* swg_paf_ranks(const swg_paf* p);
@@ -344,6 +347,7 @@ void swg_aln_close(swg_aln* a);
 /* records in file order (rank k = record k); pointers are owned by the handle */
 const swg_records* swg_aln_records(const swg_aln* a);
 const uint64_t* swg_aln_seq_offsets(const swg_aln* a);
+const uint64_t* swg_aln_record_offsets(const swg_aln* a, int axis);  /* (as swg_paf_record_offsets) */
 uint32_t swg_aln_num_sequences(const swg_aln* a);
 const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id); /* the name after the first-word cut */
 

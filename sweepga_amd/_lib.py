@@ -22,7 +22,7 @@ SYMBOLS = ["swg_abi_version", "swg_create", "swg_destroy", "swg_last_error", "sw
            "swg_parse_ani_method", "swg_parse_identity_value", "swg_paf_ani_input", "swg_ani_median", "swg_paf_ani_stats",
            "swg_filter_multi", "swg_filter_multi64", "swg_memory_info", "swg_reserve", "swg_warmup",
            "swg_aln_open", "swg_aln_close", "swg_aln_records", "swg_aln_num_sequences", "swg_aln_sequence_name",
-           "swg_paf_seq_offsets", "swg_aln_seq_offsets",
+           "swg_paf_seq_offsets", "swg_aln_seq_offsets", "swg_paf_record_offsets", "swg_aln_record_offsets",
            "swg_paf_tree_filter", "swg_free", "swg_stream_plan", "swg_paf_identity_is_derived",
            "swg_alnstats_open", "swg_alnstats_open_buffer", "swg_alnstats_close", "swg_alnstats_get", "swg_alnstats_pair",
            "swg_alnstats_report", "swg_alnstats_compare", "swg_alnstats_last_error"]
@@ -224,6 +224,10 @@ def load():
         f = getattr(lib, name)
         f.restype = C.POINTER(C.c_uint64)
         f.argtypes = [C.c_void_p]
+    for name in ("swg_paf_record_offsets", "swg_aln_record_offsets"):
+        f = getattr(lib, name)
+        f.restype = C.POINTER(C.c_uint64)
+        f.argtypes = [C.c_void_p, C.c_int]
     lib.swg_aln_num_sequences.restype = C.c_uint32
     lib.swg_aln_num_sequences.argtypes = [C.c_void_p]
     lib.swg_aln_sequence_name.restype = C.c_char_p

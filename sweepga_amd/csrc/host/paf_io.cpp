@@ -395,7 +395,8 @@ struct swg_paf {
   Buf<uint64_t> rank, rec_off;
   Buf<uint32_t> rec_len;
   Buf<uint64_t> wide[6];             // q_start, q_end, t_start, t_end, matches, block length of a file with values >= 2^32
-  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing)
+  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing, or per record:)
+  std::vector<uint64_t> rec_off_q, rec_off_t;  // ... off each RECORD's query / target coordinates (rebased per sweep segment)
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
   swg_records rec{};
@@ -660,10 +661,16 @@ int parse_text(swg_paf* p, int threads) {
     if (!rr.ok && rr.bad_field < 4 && swg_rebase::axis_tables_fit(n_seq, n_last)) {
       // a sequence touched over 2^32 bases or more: one constant per sweep segment and axis instead (host/rebase.h, columns_by_axis);
       // the columns are then relative to constants the handle does not publish (swg_paf_seq_offsets: NULL)
-      const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, p->q_id.data(), p->t_id.data(), c64, n_seq, p->g_last.data(), n_last, threads, c32);
+      p->rec_off_q.assign(n, 0);
+      p->rec_off_t.assign(n, 0);
+      const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, p->q_id.data(), p->t_id.data(), c64, n_seq, p->g_last.data(), n_last, threads, c32,
+                                                                p->rec_off_q.data(), p->rec_off_t.data());
       if (r2.ok) {
         rr = r2;
         p->seq_offset.clear();
+      } else {
+        p->rec_off_q.clear();
+        p->rec_off_t.clear();
       }
     }
     if (!rr.ok) {
@@ -839,6 +846,10 @@ void swg_paf_close(swg_paf* p) { delete p; }
 const swg_records* swg_paf_records(const swg_paf* p) { return p ? &p->rec : nullptr; }
 int swg_paf_identity_is_derived(const swg_paf* p) { return p && p->identity_derived ? 1 : 0; }
 const uint64_t* swg_paf_seq_offsets(const swg_paf* p) { return (p && !p->seq_offset.empty()) ? p->seq_offset.data() : nullptr; }
+const uint64_t* swg_paf_record_offsets(const swg_paf* p, int axis) {
+  if (!p || p->rec_off_q.empty()) return nullptr;
+  return axis ? p->rec_off_t.data() : p->rec_off_q.data();
+}
 uint64_t swg_paf_num_lines(const swg_paf* p) { return p ? p->n_lines : 0; }
 const uint64_t* swg_paf_ranks(const swg_paf* p) { return p ? p->rank.data() : nullptr; }
 uint32_t swg_paf_num_sequences(const swg_paf* p) { return p ? (uint32_t)p->names.size() : 0; }
@@ -1222,7 +1233,8 @@ struct swg_aln {
   std::vector<uint8_t> strand;
   std::vector<std::string> names;
   std::vector<uint32_t> g_last, g_two;
-  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing)
+  std::vector<uint64_t> seq_offset;  // what rebasing took off each sequence's coordinates (empty: nothing, or per record:)
+  std::vector<uint64_t> rec_off_q, rec_off_t;  // ... off each RECORD's query / target coordinates (rebased per sweep segment)
   swg_records rec{};
 };
 
@@ -1327,10 +1339,16 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
         std::vector<uint32_t> g_last;
         const uint32_t n_last = genome_table(a->names, prefix_last, &g_last);
         if (swg_rebase::axis_tables_fit(n_seq, n_last)) {
-          const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, a->q_id.data(), a->t_id.data(), c64, n_seq, g_last.data(), n_last, pick_threads(0), c32);
+          a->rec_off_q.assign(n, 0);
+          a->rec_off_t.assign(n, 0);
+          const swg_rebase::Result r2 = swg_rebase::columns_by_axis(n, a->q_id.data(), a->t_id.data(), c64, n_seq, g_last.data(), n_last, pick_threads(0), c32,
+                                                                    a->rec_off_q.data(), a->rec_off_t.data());
           if (r2.ok) {
             rr = r2;
             a->seq_offset.clear();
+          } else {
+            a->rec_off_q.clear();
+            a->rec_off_t.clear();
           }
         }
       }
@@ -1374,6 +1392,10 @@ int swg_aln_open(const swg_aln_input* in, swg_aln** out) {
 void swg_aln_close(swg_aln* a) { delete a; }
 const swg_records* swg_aln_records(const swg_aln* a) { return a ? &a->rec : nullptr; }
 const uint64_t* swg_aln_seq_offsets(const swg_aln* a) { return (a && !a->seq_offset.empty()) ? a->seq_offset.data() : nullptr; }
+const uint64_t* swg_aln_record_offsets(const swg_aln* a, int axis) {
+  if (!a || a->rec_off_q.empty()) return nullptr;
+  return axis ? a->rec_off_t.data() : a->rec_off_q.data();
+}
 uint32_t swg_aln_num_sequences(const swg_aln* a) { return a ? (uint32_t)a->names.size() : 0; }
 const char* swg_aln_sequence_name(const swg_aln* a, uint32_t id) {
   return (a && id < a->names.size()) ? a->names[id].c_str() : nullptr;

@@ -103,7 +103,8 @@ inline Result columns(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, co
 // checks that this is affordable: axis_tables_fit).  Same result convention as columns(); ids are taken as checked.
 inline bool axis_tables_fit(uint32_t n_seq, uint32_t n_genome) { return (uint64_t)n_seq * n_genome <= (uint64_t(1) << 24); }
 inline Result columns_by_axis(uint64_t n, const uint32_t* q_id, const uint32_t* t_id, const uint64_t* const c64[6], uint32_t n_seq,
-                              const uint32_t* seq_genome, uint32_t n_genome, int threads, uint32_t* const c32[6]) {
+                              const uint32_t* seq_genome, uint32_t n_genome, int threads, uint32_t* const c32[6],
+                              uint64_t* rec_off_q = nullptr, uint64_t* rec_off_t = nullptr) {
   if (threads < 1) threads = 1;
   if ((uint64_t)threads > n / 65536 + 1) threads = (int)(n / 65536 + 1);
   const size_t cells = (size_t)n_seq * n_genome;
@@ -127,6 +128,8 @@ inline Result columns_by_axis(uint64_t n, const uint32_t* q_id, const uint32_t* 
     const uint64_t b = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
     for (uint64_t i = b; i < e; ++i) {
       const uint64_t oq = lo_q[(size_t)q_id[i] * n_genome + seq_genome[t_id[i]]], ot = lo_t[(size_t)t_id[i] * n_genome + seq_genome[q_id[i]]];
+      if (rec_off_q) rec_off_q[i] = oq;  // (what was taken off this record's coordinates, for a front end that publishes it)
+      if (rec_off_t) rec_off_t[i] = ot;
       const uint64_t v[6] = {c64[0][i] - oq, c64[1][i] - oq, c64[2][i] - ot, c64[3][i] - ot, c64[4] ? c64[4][i] : 0,
                              c64[5] ? c64[5][i] : 0};
       for (int f = 0; f < 6; ++f) {

@@ -60,14 +60,26 @@ class PafFile:
 
     @property
     def is_rebased(self):
-        """True when the coordinate columns are relative to `seq_offsets` (results of the filter are unaffected)."""
-        return self.seq_offsets is not None
+        """True when the coordinate columns are relative to `seq_offsets` or `record_offsets` (results of the filter are
+        unaffected)."""
+        return self.seq_offsets is not None or self.record_offsets(0) is not None
+
+    def record_offsets(self, axis):
+        """[n] what was taken off every record's query (axis 0) / target (axis 1) coordinates when the file has a sequence that is
+        touched over 2^32 bases or more (rebased per sweep segment), else None (swg_paf_record_offsets)."""
+        ptr = self.lib.swg_paf_record_offsets(self.handle, int(axis))
+        if not ptr:
+            return None
+        return self._view(C.addressof(ptr.contents), np.uint64, self.n)
 
     def absolute(self, name):
         """q_start / q_end / t_start / t_end as u64 in the file's own coordinates (a copy)."""
         if name not in ("q_start", "q_end", "t_start", "t_end"):
             raise ValueError("absolute() is for the four coordinate columns")
         v = self.column(name).astype(np.uint64)
+        per_record = self.record_offsets(0 if name[0] == "q" else 1)
+        if per_record is not None:
+            return v + per_record
         off = self.seq_offsets
         if off is None:
             return v

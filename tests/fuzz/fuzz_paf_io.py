@@ -76,12 +76,12 @@ def main():
         try:
             with PafFile(path, threads=int(rng.integers(1, 4))) as pf:
                 ok = pf.n == n and (pf.ranks == cols["rank"][:n]).all()
-                off = pf.seq_offsets  # a file with values >= 2^32: coordinates relative to the sequence's smallest one
+                # a file with values >= 2^32: coordinates relative to the sequence's smallest one, or (a sequence touched over 2^32
+                # bases or more) to one constant per sweep segment -- absolute() adds back whichever it was
+                off = pf.seq_offsets if pf.seq_offsets is not None else pf.record_offsets(0)
                 for name, key, ids in (("q_start", "qs", "q_id"), ("q_end", "qe", "q_id"), ("t_start", "ts", "t_id"),
                                        ("t_end", "te", "t_id"), ("block_len", "block", None), ("matches", "matches", None)):
-                    col = pf.column(name).astype(np.uint64)
-                    if off is not None and ids is not None:
-                        col = col + off[pf.column(ids)]
+                    col = pf.absolute(name) if ids is not None else pf.column(name).astype(np.uint64)
                     ok = ok and (col == cols[key][:n]).all()
                 if off is not None:
                     ok = ok and any(int(v) > 0xffffffff for k in ("qs", "qe", "ts", "te", "block", "matches") for v in cols[k][:n])

@@ -179,8 +179,9 @@ def test_open_buffer_and_errors(tmp_path):
         assert (pf.n, pf.n_lines) == (9, 12)
     with pytest.raises(SwgError, match="cannot open"):
         PafFile(tmp_path / "missing.paf")
-    # a sequence whose mapped stretch itself spans 2^32 bases, and a match count >= 2^32, are beyond the 32-bit layout
-    with pytest.raises(SwgError, match="sequence q spans 2\\^32 bases or more \\(query_end on line 2"):
+    # a sequence touched over 2^32 bases by the mappings against ONE genome, and a match count >= 2^32, are beyond the 32-bit layout
+    # (against different genomes: rebased per sweep segment, tests/test_gpu_wide.py)
+    with pytest.raises(SwgError, match="sequence q that the mappings against one genome touch spans 2\\^32 bases or more \\(query_end on line 2"):
         PafFile(text="q\t9\t0\t5\t+\tt\t9\t2\t6\t3\t4\t0\nq\t9\t1\t4294967296\t+\tt\t9\t2\t6\t3\t4\t0\n")
     with pytest.raises(SwgError, match="matches >= 2\\^32 on line 1"):
         PafFile(text="q\t9\t0\t5\t+\tt\t9\t2\t6\t4294967296\t4\t0\n")

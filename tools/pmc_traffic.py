@@ -40,7 +40,7 @@ def short_name(name):
         base += {"64": "_s", "256": "_m"}.get(t[0], "")
     if base in ("pair_key1", "pair_key2", "pair_rank1", "pair_rank_count", "pair_base", "pair_base_count", "pair_sizes", "pair_number_small"):
         base = "pair_number"          # the chain_N numbering over the pair table: one label in the library
-    if base == "seg_sort" and t:       # seg_sort_kernel<NT, ...> (the large class and the longest segments: seg_sort_big)
+    if base in ("seg_sort", "seg_sweep") and t:   # seg_sort_kernel<NT, ...> / seg_sweep_kernel<NT, ...> (the large class and the longest segments: *_big)
         base += {"64": "_s", "256": "_m"}.get(t[0], "")
     if base in ("run_alive", "run_key"):
         base = "seg_" + base
