@@ -70,7 +70,10 @@ def gen_shard(torch, n, n_genomes, seed, device, chr_len=150_000_000, single_pai
         P = n_genomes * (n_genomes - 1) * chroms
         w = torch.exp(0.5 * torch.randn(P, generator=g, device=device, dtype=torch.float64))
         sizes = torch.floor(w / w.sum() * n).to(torch.int64)
-        sizes[0] += n - int(sizes.sum())
+        if chroms > 1:   # (the flooring's remainder one record per pair: on ONE pair of a 7.5 Mbp chromosome it would be a deep pair of its own)
+            sizes[: n - int(sizes.sum())] += 1
+        else:            # (S-pan as every round measured it)
+            sizes[0] += n - int(sizes.sum())
         pair = torch.repeat_interleave(torch.arange(P, device=device, dtype=torch.int32), sizes)
         c = pair % chroms
         pair = torch.div(pair, chroms, rounding_mode="floor")

@@ -707,10 +707,8 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     A.info[rk_run] = pi;
     if (sh_first[2] != NONE)  // the genome pair's first alive record (apply_plane_sweep_to_mappings' group order, :1037-1046)
       atomicMin(pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]), sh_first[2]);
-    if (M) {
-      atomicAdd(&A.C->n_alive, (unsigned long long)M);
-      atomicAdd(&A.C->n_members, (unsigned long long)m);
-    }
+    // (the alive records' and the members' totals: summed over `info` by pair_totals_kernel -- a counter that every pair bumps
+    // serialises on its cache line: 4.5 of 6.8 ms of the small pairs' sort at 198,000 pairs)
   }
   if (M == 0) return;
   bool degenerate = false;
@@ -1217,10 +1215,8 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
       uint32_t* slot = pair_slot(A.gl_first, A.seq_genome_last[q0], A.seq_genome_last[t0]);
       if (*slot > sh_first[2]) atomicMin(slot, sh_first[2]);
     }
-    if (M) {
-      atomicAdd(&A.C->n_alive, (unsigned long long)M);
-      atomicAdd(&A.C->n_members, (unsigned long long)m);
-    }
+    // (the alive records' and the members' totals: summed over `info` by pair_totals_kernel -- a counter that every pair bumps
+    // serialises on its cache line: 4.5 of 6.8 ms of the small pairs' sort at 198,000 pairs)
   }
   if (M == 0) return;
   bool degenerate = false;
@@ -1485,6 +1481,35 @@ __global__ __launch_bounds__(1024) void pair_sort_big_kernel(PairSortArgs A, con
 // A call that is being handed over to the global-sort stage (PF_FALLBACK raised by a pair_sort work-group or by the plan of
 // the long units): the walk and the labelling take their chunk counts from the device, so clearing them makes the kernels
 // still to come return at once instead of walking and labelling 10^8 members for nothing.
+// The statistics' totals over the pairs, once per call: alive records, members, kept chains, records in the output.
+__global__ __launch_bounds__(1024) void pair_totals_kernel(uint32_t n_runs, const PairInfo* __restrict__ info, const PairSum* __restrict__ sum,
+                                                           const uint32_t* __restrict__ n_out_pair, PairCounters* __restrict__ C) {
+  __shared__ unsigned long long part[16][4];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  const bool finished = !(C->flags & PF_FALLBACK);  // (else the sums were not written)
+  for (uint32_t k = blockIdx.x * 1024u + threadIdx.x; k < n_runs; k += gridDim.x * 1024u) {
+    const PairInfo pi = info[k];
+    v[0] += pi.M;
+    v[1] += pi.m;
+    if (finished) {
+      v[2] += pi.M ? sum[k].n_kept : 0u;
+      v[3] += n_out_pair[k];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = v[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; ++w) t += part[w][threadIdx.x];
+    unsigned long long* dst = threadIdx.x == 0 ? &C->n_alive : threadIdx.x == 1 ? &C->n_members : threadIdx.x == 2 ? &C->n_kept : &C->n_out;
+    if (t) atomicAdd(dst, t);  // (a few dozen work-groups; the counters start from zero with every call)
+  }
+}
 __global__ void pair_gate_kernel(PairCounters* __restrict__ C) {
   if (threadIdx.x == 0 && (C->flags & PF_FALLBACK)) {
     C->n_chunks = 0u;
@@ -1516,6 +1541,7 @@ struct PairFinishArgs {
   uint32_t* fin;       // by position in the pair, or nullptr: the record's result -- status << 30 | pair-local chain number -- instead
                        //   of scattered writes to the output columns (pair_out_kernel brings them to input order through LDS)
   uint32_t* anum;      // by position in the pair: the anchor's (pair-local) chain number, 0 = a rescue candidate, NEVER = never rescued
+  uint32_t* n_out_pair;  // [pairs, zeroed] the pair's records in the output
   PairCounters* C;
 };
 constexpr uint32_t NEVER = 0xfffffffeu;  // a member of a chain that passed the span / identity filter but not the scaffold sweep
@@ -1535,11 +1561,14 @@ struct PairChainArgs {
   double* T_wid;
   uint64_t* T_seg;
   uint32_t *chain_base, *np;
+  uint32_t *cnt, *has, *stretch;  // per pair: its chains in the table, whether it has any; the exclusive prefix sums of `has`
   PairRun* T_runs;             // the pairs' stretches of the table (those that hold a chain)
-  unsigned long long* totals;  // [0] chains in the table (low 40 bits) and stretches (above), [1] largest coordinate
+  unsigned long long* totals;  // [0] chains in the table, [1] largest coordinate, [2] stretches
   const PairCounters* C;
 };
-template <int NT>
+// PHASE 0 counts a pair's passing chains; the host's prefix sums over the pairs place the stretches (a returning atomic per
+// pair on one counter serialises: 9.3 ms at 396,000 pairs); PHASE 1 fills the pair's stretch.
+template <int NT, int PHASE>
 __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
   constexpr int U = 4;
   __shared__ uint32_t ws[NT / 64 + 1];
@@ -1551,50 +1580,53 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
   const PairRun run = A.runs[rk];
   const PairInfo pi = A.info[rk];
   const uint32_t a = run.a, m = pi.m, m_plus = pi.m_plus;
-  uint32_t c0 = 0, c1 = 0, mx = 0;
-  for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
-    uint8_t ok[U];
+  if (PHASE == 0) {
+    uint32_t c0 = 0, c1 = 0, mx = 0;
+    for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
+      uint8_t ok[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-      ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
-    }
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-      if (ok[u]) {
-        const HeadRec hr = A.rec[a + p];
-        if (p < m_plus) ++c0; else ++c1;
-        const uint32_t e = hr.qe > hr.te ? hr.qe : hr.te;
-        mx = e > mx ? e : mx;
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        if (ok[u]) {
+          const HeadRec hr = A.rec[a + p];
+          if (p < m_plus) ++c0; else ++c1;
+          const uint32_t e = hr.qe > hr.te ? hr.qe : hr.te;
+          mx = e > mx ? e : mx;
+        }
       }
     }
-  }
-  const uint32_t nP = block_sum<NT>(c0, ws), nM = block_sum<NT>(c1, ws);
+    const uint32_t nP = block_sum<NT>(c0, ws), nM = block_sum<NT>(c1, ws);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = __shfl_xor(mx, o, 64);
-    mx = t > mx ? t : mx;
-  }
-  if ((tid & 63) == 0 && mx) atomicMax(&A.totals[1], (unsigned long long)mx);
-  if (tid == 0) {
-    // (one returning atomic per pair: the chains before this pair's in the low 40 bits, the stretches before it above them)
-    const unsigned long long old = nP + nM ? atomicAdd(&A.totals[0], (unsigned long long)(nP + nM) | (1ull << 40)) : 0ull;
-    const uint32_t cb = (uint32_t)(old & ((1ull << 40) - 1ull));
-    sh_base = cb;
-    A.chain_base[rk] = cb;
-    A.np[2 * rk] = nP;
-    A.np[2 * rk + 1] = nM;
-    if (nP + nM) {  // the pair's stretch of the table: a run of the sweep's input (its begins are sorted segment by segment)
-      PairRun tr;
-      tr.a = cb;
-      tr.n = nP + nM;
-      A.T_runs[old >> 40] = tr;
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(mx, o, 64);
+      mx = t > mx ? t : mx;
     }
+    // (the largest coordinate only ever grows: a look first keeps all but a few atomics off the counter)
+    if ((tid & 63) == 0 && (unsigned long long)mx > __hip_atomic_load(&A.totals[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(&A.totals[1], (unsigned long long)mx);
+    if (tid == 0) {
+      A.np[2 * rk] = nP;
+      A.np[2 * rk + 1] = nM;
+      A.cnt[rk] = nP + nM;
+      A.has[rk] = nP + nM ? 1u : 0u;
+    }
+    return;
   }
-  __syncthreads();
+  const uint32_t nP = A.np[2 * rk], nM = A.np[2 * rk + 1];
   if (nP + nM == 0) return;
-  const uint32_t cb = sh_base;
+  const uint32_t cb = A.chain_base[rk];
+  if (tid == 0) {  // the pair's stretch of the table: a run of the sweep's input (its begins are sorted segment by segment)
+    PairRun tr;
+    tr.a = cb;
+    tr.n = nP + nM;
+    A.T_runs[A.stretch[rk]] = tr;
+  }
+  (void)sh_base;
   const bool plus_first = pi.first_mem[0] < pi.first_mem[1];
   uint32_t before = 0;
   for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
@@ -2110,10 +2142,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   }
   FT_STAMP(5);
   out = block_sum<NT>(out, ws);
-  if (tid == 0) {
-    atomicAdd(&A.C->n_kept, (unsigned long long)n_kept);
-    if (out) atomicAdd(&A.C->n_out, (unsigned long long)out);
-  }
+  if (tid == 0) A.n_out_pair[rk] = out;  // (summed by pair_totals_kernel, with the pairs' kept chains)
 }
 
 // ---- chain_N bases ----------------------------------------------------------------------------------------------------
@@ -2394,11 +2423,16 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
   const swg_arena_mark mark0 = swg_arena_save(ctx);
   const bool by_hash = n <= PAIR_HASH_MAX;
-  // How many pairs the path takes.  Its bookkeeping is per pair -- a work-group, a handful of counters bumped in one cache line
-  // (~90 ns of same-address atomics per pair), a wavefront per chunk of the walk -- which is nothing next to a pair of thousands
-  // of records and everything next to a pair of ten: beyond ~65,000 pairs per 10^8 records (an average below 1,536 records), or
-  // 8,192 pairs of a small input, the global-sort stage is the faster one (tools/tiny_pairs_probe.py), and it gets the call.
-  const uint32_t cap = by_hash ? (n < 8192u ? n : 8192u) : (n / 1536u > 8192u ? n / 1536u : 8192u);
+  // How many pairs the path takes.  Its cost per pair -- a work-group per kernel, a returning atomic for the pair's chunks --
+  // is nothing next to a pair of thousands of records and everything next to a pair of ten.  Measured on 10^8 records of 100
+  // genomes x C chromosomes (round 6, tools/order_shapes.py; default / --scaffold-filter 1:1 flags, pair path against the
+  // global-sort stage): C = 20 (198,000 pairs of 505) 11.9 / 17.2 against 17.7 / 25.1 ms; C = 40 (252 records) 13.4 / 19.5
+  // against 17.8 / 25.2; C = 60 (168) 17.1 / 24.5 against 18.9 / 27.1; C = 100 (101) 26.1 against 19.7.  So: pairs of 192 records
+  // or more on average (round 5 drew the line at 1,536: its pair kernels bumped five statistics counters of ONE cache line
+  // per pair, ~25 ns of serialised same-address atomics each -- now summed per pair afterwards, pair_totals_kernel), or any
+  // 8,192 pairs.  SWG_PAIR_MIN_AVG overrides the average (experiments).
+  static const uint32_t per_pair = getenv("SWG_PAIR_MIN_AVG") && atoi(getenv("SWG_PAIR_MIN_AVG")) > 0 ? (uint32_t)atoi(getenv("SWG_PAIR_MIN_AVG")) : 192u;
+  const uint32_t cap = by_hash ? (n < 8192u ? n : 8192u) : (n / per_pair > 8192u ? n / per_pair : 8192u);
   uint32_t tsize = 1;
   while (tsize < 2 * (by_hash ? n : cap)) tsize <<= 1;  // (the hash grouping enters every record's pair: room for n of them)
   PairCounters* C = nullptr;
@@ -2533,6 +2567,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   uint32_t* anum = rescue ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   PairInfo* info = swg_alloc<PairInfo>(ctx, n_runs);
   PairSum* sum = swg_alloc<PairSum>(ctx, n_runs);
+  uint32_t* n_out_pair = swg_alloc<uint32_t>(ctx, n_runs);
   const uint32_t cap_chunks = n / PAIR_CELL + 2 * n_runs + 16;
   SpecBlock* chunks = swg_alloc<SpecBlock>(ctx, cap_chunks);
   const uint32_t cap_long = n / LABEL_CAP_ELEMS + 1;
@@ -2548,6 +2583,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     SWG_HIP(ctx, hipMemsetAsync(chain_out, 0, (size_t)n * sizeof(uint32_t), st));
     SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
   }
+  SWG_HIP(ctx, hipMemsetAsync(n_out_pair, 0, (size_t)n_runs * sizeof(uint32_t), st));
   PairSortArgs SA{};
   SA.q_id = r->q_id; SA.t_id = r->t_id; SA.q_start = r->q_start; SA.q_end = r->q_end; SA.t_start = r->t_start; SA.t_end = r->t_end;
   SA.matches = r->matches; SA.block_len = r->block_len; SA.identity = r->identity; SA.strand = r->strand;
@@ -2619,23 +2655,41 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     CA.np = np_arr = swg_alloc<uint32_t>(ctx, (size_t)2 * n_runs);
     CA.totals = swg_alloc<unsigned long long>(ctx, 3);
     CA.T_runs = swg_alloc<PairRun>(ctx, n_runs);
+    CA.cnt = swg_alloc<uint32_t>(ctx, n_runs);
+    CA.has = swg_alloc<uint32_t>(ctx, n_runs);
+    CA.stretch = swg_alloc<uint32_t>(ctx, n_runs);
     kept_flags = swg_alloc<uint8_t>(ctx, n);
     SWG_CHECK_ARENA(ctx);
     SWG_HIP(ctx, hipMemsetAsync(CA.totals, 0, 24, st));
-    for (int c = 0; c < 4; ++c) {
-      if (!ncls[c]) continue;
-      CA.list = class_list + (size_t)c * cap;
-      switch (c) {
-        case 0: SWG_LAUNCH(ctx, "pair_chains_s", pair_chains_kernel<64><<<ncls[c], 64, 0, st>>>(CA)); break;
-        case 1: SWG_LAUNCH(ctx, "pair_chains_m", pair_chains_kernel<256><<<ncls[c], 256, 0, st>>>(CA)); break;
-        default: SWG_LAUNCH(ctx, "pair_chains", pair_chains_kernel<512><<<ncls[c], 512, 0, st>>>(CA)); break;
+    SWG_HIP(ctx, hipMemsetAsync(CA.cnt, 0, (size_t)n_runs * sizeof(uint32_t), st));   // (a call given up on the device leaves them unwritten)
+    SWG_HIP(ctx, hipMemsetAsync(CA.has, 0, (size_t)n_runs * sizeof(uint32_t), st));
+    for (int phase = 0; phase < 2; ++phase) {
+      for (int c = 0; c < 4; ++c) {
+        if (!ncls[c]) continue;
+        CA.list = class_list + (size_t)c * cap;
+        if (phase == 0) {
+          switch (c) {
+            case 0: SWG_LAUNCH(ctx, "pair_chains_s", pair_chains_kernel<64, 0><<<ncls[c], 64, 0, st>>>(CA)); break;
+            case 1: SWG_LAUNCH(ctx, "pair_chains_m", pair_chains_kernel<256, 0><<<ncls[c], 256, 0, st>>>(CA)); break;
+            default: SWG_LAUNCH(ctx, "pair_chains", pair_chains_kernel<512, 0><<<ncls[c], 512, 0, st>>>(CA)); break;
+          }
+        } else {
+          switch (c) {
+            case 0: SWG_LAUNCH(ctx, "pair_chains_s", pair_chains_kernel<64, 1><<<ncls[c], 64, 0, st>>>(CA)); break;
+            case 1: SWG_LAUNCH(ctx, "pair_chains_m", pair_chains_kernel<256, 1><<<ncls[c], 256, 0, st>>>(CA)); break;
+            default: SWG_LAUNCH(ctx, "pair_chains", pair_chains_kernel<512, 1><<<ncls[c], 512, 0, st>>>(CA)); break;
+          }
+        }
+        SWG_KERNEL_CHECK(ctx);
       }
-      SWG_KERNEL_CHECK(ctx);
+      if (phase == 0) {  // where every pair's stretch of the table begins, and which stretch it is
+        SWG_TRY(swg_exclusive_scan_u32(ctx, CA.cnt, chain_base, n_runs, reinterpret_cast<uint64_t*>(CA.totals)));
+        SWG_TRY(swg_exclusive_scan_u32(ctx, CA.has, CA.stretch, n_runs, reinterpret_cast<uint64_t*>(CA.totals + 2)));
+      }
     }
     uint64_t ht[3];
     SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(CA.totals), ht, 3));
-    const uint64_t n_table = ht[0] & ((1ull << 40) - 1ull);
-    ht[2] = ht[0] >> 40;  // the stretches
+    const uint64_t n_table = ht[0];
     if (n_table) {
       const int seg_bits = swg_bits_for(n_runs) ? swg_bits_for(n_runs) : 1, pos_bits = swg_bits_for(ht[1]) ? swg_bits_for(ht[1]) : 1;
       SWG_TRY(scaffold_sweep_segments(ctx, n_table, CA.T_seg, seg_bits, CA.T_qs, CA.T_qe, CA.T_ts, CA.T_te, CA.T_wid, kq, kt,
@@ -2652,6 +2706,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   FA.rescue_d = rescue ? cfg->scaffold_max_deviation : 0;
   FA.max_s2 = rescue ? pair_max_dist2(cfg->scaffold_max_deviation) : 0;
   FA.anum = anum;
+  FA.n_out_pair = n_out_pair;
   FA.fin = fin;
   for (int c = 0; c < 4; ++c) {
     if (!ncls[c]) continue;
@@ -2729,6 +2784,8 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     }
   }
   // ---- the flags found on the device, and the statistics
+  SWG_LAUNCH(ctx, "pair_totals", pair_totals_kernel<<<(n_runs + 4095) / 4096 < 64u ? (n_runs + 4095) / 4096 : 64u, 1024, 0, st>>>(n_runs, info, sum, n_out_pair, C));
+  SWG_KERNEL_CHECK(ctx);
   uint64_t hc[9];
   static_assert(sizeof(PairCounters) == 72, "PairCounters is read back as nine words");
   SWG_TRY(swg_read_scalars(ctx, reinterpret_cast<const uint64_t*>(C), hc, 9));

@@ -208,6 +208,22 @@ def test_many_tiny_pairs_are_left_to_the_global_path(sw):
     run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=True)
 
 
+def test_many_pairs_of_a_few_hundred_records_take_the_pair_path(sw):
+    """100 genomes x 20 chromosomes is 198,000 homologous chromosome pairs of ~500 records per 10^8: round 5 left anything beyond
+    n / 1,536 pairs to the global-sort stage (17.7 ms against the 11.9 ms the pair path takes since its per-pair counters are
+    summed afterwards instead of bumped).  Here: 9,000 pairs of ~210 records -- beyond 8,192 pairs and beyond n / 1,536."""
+    rng = np.random.default_rng(13)
+    n_pairs, per = 9_000, 210
+    rec = gen.random_records(rng, n_pairs * per, n_genomes=1, chrs_per_genome=1, span=400_000, zero_frac=0.01, self_frac=0.0)
+    pid = np.arange(len(rec)) // per
+    rec.qname = [f"g{p // 90}#1#c{p % 90}" for p in pid]
+    rec.tname = [f"h{p // 90}#1#c{p % 90}" for p in pid]
+    for cfg in ({"scaffold_gap": 3_000, "min_scaffold_length": 1_000, "scaffold_max_deviation": 2_000},
+                {"scaffold_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 1_000}):
+        st, ch, stats = run_both(sw, rec, cfg, expect_pair_path=True)
+        assert int(stats.n_retained) == len(rec)   # (the totals come from pair_totals_kernel)
+
+
 def test_a_callers_identity_column_is_always_read(sw):
     """The host paths send only the value columns a flag set reads -- but a caller's OWN identity column may hold anything (a dv:f:
     override above 1 makes it negative), and a negative or NaN identity fails the step-1 test even against a floor of zero
