@@ -607,6 +607,80 @@ def _r(x, nd=4):
     return round(x, nd) if isinstance(x, float) else x
 
 
+def shapes_leg(torch, sw, lib_mod, ctx, device, n, seed, steps=3, parity_genomes=5):
+    """The default flags on record sets away from the bench workload's order and shape: S-pan's records
+    shuffled; by query sequence in query order with the targets interleaved (what wfmash writes); 100 genomes x 20 chromosomes
+    (198,000 homologous chromosome pairs per 10^8 records, pair-major).  One time per shape, and parity against the oracle on
+    the records of a few whole genome pairs (a genome pair's answers do not depend on the rest of the input; chain numbers are
+    compared as a partition)."""
+    import numpy as np
+    from tests import orc
+    cfg = make_config(sw, "default")
+    ccfg = cfg.to_c()
+    ocfg = _oracle_config(cfg)
+    out = {}
+
+    def run(tag, cols, G, names, genome_of_seq):
+        rec = make_records(lib_mod, cols, n, G)
+        status = torch.zeros(n, dtype=torch.uint8, device=device)
+        chain = torch.zeros(n, dtype=torch.int32, device=device)
+        ctx.profile_reset()
+        best = None
+        for it in range(steps + 1):
+            torch.cuda.synchronize()
+            if it == steps:
+                ctx.profile(True)
+            t0 = time.perf_counter()
+            ctx.check(ctx.lib.swg_filter_device(ctx.handle, C.byref(rec), C.byref(ccfg), status.data_ptr(), chain.data_ptr(), None))
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            if 0 < it < steps:
+                best = dt if best is None else min(best, dt)
+        ctx.profile(False)
+        table = ctx.profile_table()
+        path = "pair-resident" if "pair_renumber" in table and not any(k in table for k in ("chain_cuts", "cuts_from_scan", "sortA_keys", "sortA_keys_hist", "sortA_words")) else "global sorts"
+        # parity: every record between the first `parity_genomes` genomes (20 ordered genome pairs), in the order they have in this input
+        gq = genome_of_seq[cols["q_id"].long()]
+        gt = genome_of_seq[cols["t_id"].long()]
+        sel = (gq < parity_genomes) & (gt < parity_genomes) & (gq != gt)
+        idx = torch.nonzero(sel, as_tuple=False).flatten()
+        h = {k: np.ascontiguousarray(cols[k][idx].cpu().numpy()) for k in REC_COLS}
+        u = lambda a: np.ascontiguousarray(a.astype(np.uint64))   # noqa: E731
+        orec = orc.Records([names[i] for i in h["q_id"]], [names[i] for i in h["t_id"]], u(h["q_start"]), u(h["q_end"]), u(h["t_start"]),
+                           u(h["t_end"]), u(h["block_len"]), np.ascontiguousarray(h["identity"]), u(h["matches"]),
+                           np.where(h["strand"] == 0, ord("+"), ord("-")).astype(np.uint8), u(np.arange(len(idx))))
+        ost, och = orc.apply_filters(ocfg, orec)
+        gst, gch = status[idx].cpu().numpy(), chain[idx].cpu().numpy()
+        ok = bool(np.array_equal(gst, ost)) and bool(orc.same_chain_partition(gch, och))
+        top = sorted(table.items(), key=lambda kv: -kv[1][1])[:6]
+        out[tag] = {"ms_per_step": best * 1e3, "path": path, "parity": {"mappings_checked": int(len(idx)), "ok": ok},
+                    "kernels_ms": {k: round(v[1], 3) for k, v in top}}
+        del status, chain
+
+    cols, _ = gen_shard(torch, n, 100, seed, device)
+    table1 = cols["seq_genome_last"].long()
+    names1 = span_names(100)
+    key = cols["q_id"].to(torch.int64) * (1 << 32) + cols["q_start"].to(torch.int64)
+    order = torch.argsort(key, stable=True)
+    del key
+    by_q = {k: (cols[k][order].contiguous() if k in REC_COLS else cols[k]) for k in cols}
+    del order
+    run("by_query", by_q, 100, names1, table1)
+    del by_q
+    perm = torch.randperm(n, device=device)
+    shuf = {k: (cols[k][perm].contiguous() if k in REC_COLS else cols[k]) for k in cols}
+    del perm, cols
+    run("shuffled", shuf, 100, names1, table1)
+    del shuf
+    torch.cuda.empty_cache()
+    cols, _ = gen_shard(torch, n, 100, seed, device, chroms=20)
+    names20 = [f"g{i // 20:03d}#1#chr{i % 20 + 1}" for i in range(100 * 20)]
+    run("multichrom", cols, 100, names20, cols["seq_genome_last"].long())
+    del cols
+    torch.cuda.empty_cache()
+    return out
+
+
 def summary_line(out, detail_path):
     """The one stdout line (< 4 KB): contract keys, the headline's roofline and CPU baselines, and ONE scalar per other leg.
     Per-kernel tables, counts, notes and samples are in the detail file (`--detail`, default gpurun_out/bench_detail.json)."""
@@ -642,6 +716,11 @@ def summary_line(out, detail_path):
             pa = e.get("parity")
             if pa:
                 par[f"sbig1_{p}"] = {"checked": pa["mappings_checked"], "ok": bool(pa["status_equal"] and pa["chain_equal"] is not False)}
+    sh = out.get("shapes")
+    if sh:
+        for tag, e in sh.items():   # shuffled_default_ms, by_query_default_ms, multichrom_default_ms
+            line[f"{tag}_default_ms"] = _r(e["ms_per_step"])
+            par[f"{tag}_default"] = {"checked": e["parity"]["mappings_checked"], "ok": bool(e["parity"]["ok"])}
     pc = out.get("pcie_inclusive")
     if pc:
         for p, e in pc.items():
@@ -742,6 +821,7 @@ def main():
     ap.add_argument("--parity-mappings", type=int, default=-1,
                     help="mappings of the timed workload checked against the oracle on all host threads "
                          "(-1 = auto: 2M (sweep) / 0.5M (scaffold flag sets) per host thread, up to the whole shard; 0 = skip)")
+    ap.add_argument("--shapes", type=int, default=1, help="1: the default flags on other orders / shapes of the records (shapes_leg); 0 = skip")
     ap.add_argument("--sbig1", type=int, default=10_000_000, help="mappings of the S-big1 leg (configs[2]); 0 = skip")
     ap.add_argument("--sbig1-parity-sweep", type=int, default=1_000_000)
     ap.add_argument("--sbig1-parity-scaffold", type=int, default=200_000)
@@ -941,6 +1021,7 @@ def main():
         del run, cols
         if rank == 0 and world == 1:
             torch.cuda.empty_cache()
+            out["shapes"] = shapes_leg(torch, sw, _lib, ctx, device, n, args.seed) if (args.shapes and args.workload == "span" and not args.shuffle and not args.only) else None
             out["sbig1"] = sbig1_leg(torch, sw, _lib, ctx, device, args) if args.sbig1 > 0 else None
             out["end_to_end"] = end_to_end(args.e2e, args.e2e_ref, args.threads) if args.e2e > 0 else None
 
