@@ -187,6 +187,8 @@ __global__ __launch_bounds__(EW) void axis_rebase_kernel(uint64_t n, const uint3
   if (f >= 0) atomicMin(bad, ((unsigned long long)(i + 1) << 3) | (unsigned)f);
 }
 
+__global__ void call_begin_kernel() {}
+
 void limits_from_mode(int mode, uint64_t max_q, uint64_t max_t, uint64_t* kq, uint64_t* kt) {
   // src/paf_filter.rs:1004-1014
   switch (mode) {
@@ -276,6 +278,15 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     stats->n_retained = stats->n_swept = stats->n_chains = stats->n_chains_kept = stats->n_out = 0;
   }
   if (n == 0) return SWG_OK;
+  {
+    // SWG_CALL_MARKER=1 (tools/profile_round.sh): an empty launch opens every call, so that a kernel trace can be cut into calls
+    // whatever path each of them takes (tools/pmc_traffic.py)
+    static const bool marker = getenv("SWG_CALL_MARKER") != nullptr;
+    if (marker) {
+      SWG_LAUNCH(ctx, "call_begin", call_begin_kernel<<<1, 64, 0, st>>>());
+      SWG_KERNEL_CHECK(ctx);
+    }
+  }
   // the per-call pointers the stages below find in the context do not outlive this call (the seams -- swg_merge_chains ... --
   // run the same stages without them)
   struct CallScope {
@@ -292,19 +303,39 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   // sweep would drop (zero length), or anything else it does not cover.  Behind a mapping sweep it takes the sweep's flags
   // (further down), and the sweep is told that nobody will ask for its sorted order.
   swg_scaf::PairPlan pair_plan;
+  // (a context whose calls of about this size came back from the pair-resident stage on the device's word twice in a row --
+  // deep long units, dense LDS batches, degenerate records: the whole stage run for nothing each time -- stops trying; a call of
+  // another size, or one the stage finishes, starts afresh.  ADVICE round 5.)
+  auto about_n = [&](int kind) { return n >= ctx->pair_fallback_n[kind] / 2 && n <= ctx->pair_fallback_n[kind] * 2; };
+  for (int kind = 0; kind < 2; ++kind)
+    if (ctx->pair_fallback_count[kind] && !about_n(kind)) ctx->pair_fallback_count[kind] = 0;
+  const bool identity_try_off = ctx->pair_fallback_count[0] >= 2;  // (the attempt before any sweep)
+  const bool pair_stage_off = ctx->pair_fallback_count[1] >= 2;    // (the attempt behind the sweep: then neither is made)
+  auto pair_stage = [&](const uint8_t* alive_in, const uint8_t* member_in, bool assumed_identity, int* taken) -> int {
+    SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive_in, member_in, assumed_identity, status_out, chain_out, stats, taken, &pair_plan));
+    const int kind = assumed_identity ? 0 : 1;
+    if (*taken) {
+      ctx->pair_fallback_count[kind] = 0;
+    } else {  // (a valid plan and no result: handed back)
+      ctx->pair_fallback_count[kind] = ctx->pair_fallback_count[kind] && about_n(kind) ? ctx->pair_fallback_count[kind] + 1 : 1;
+      ctx->pair_fallback_n[kind] = n;
+    }
+    return SWG_OK;
+  };
   {
     uint64_t kq1, kt1;
     limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
+    const bool sweeps1 = kq1 != SWG_K_INF || kt1 != SWG_K_INF;
     // (the plan also serves a mapping sweep with limits: its axes sort their begins segment by segment over the plan's runs)
     // (... of a large input: the small ones' plan goes through the hash grouping, which only the scaffold stage reads)
-    if (cfg->scaffold_gap != 0 || ((kq1 != SWG_K_INF || kt1 != SWG_K_INF) && n > 65536)) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
+    if ((cfg->scaffold_gap != 0 && !pair_stage_off) || (sweeps1 && n > 65536)) SWG_TRY(swg_scaf::pair_plan(ctx, r, cfg, &pair_plan));
   }
   {
     uint64_t kq1, kt1;
     limits_from_mode(cfg->mapping_filter_mode, cfg->mapping_max_per_query, cfg->mapping_max_per_target, &kq1, &kt1);
-    if (pair_plan.valid && cfg->scaffold_gap != 0 && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
+    if (pair_plan.valid && !pair_stage_off && !identity_try_off && cfg->scaffold_gap != 0 && kq1 == SWG_K_INF && kt1 == SWG_K_INF) {
       int taken = 0;
-      SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, nullptr, nullptr, true, status_out, chain_out, stats, &taken, &pair_plan));
+      SWG_TRY(pair_stage(nullptr, nullptr, true, &taken));
       if (taken) return SWG_OK;
     }
   }
@@ -335,7 +366,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   // all-members gathers read them only if the probe says "not grouped".  Nothing else may read these slots.
   swg_key_ends* probe_slots = nullptr;
   uint32_t* probe_flag = nullptr;
-  if (!key_ends && cfg->scaffold_gap != 0 && slots_knob < 0 && n >= 65536 && !pair_plan.valid) {  // (a valid plan: grouped, and the stage is the pair-resident one)
+  if (!key_ends && cfg->scaffold_gap != 0 && slots_knob < 0 && n >= 65536 && !(pair_plan.valid && !pair_stage_off)) {  // (a valid plan: grouped, and the stage is the pair-resident one)
     probe_slots = swg_alloc<swg_key_ends>(ctx, n);
     probe_flag = swg_alloc<uint32_t>(ctx, 1);
   }
@@ -347,7 +378,7 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   // behind a mapping sweep the scaffold stage's first sort only orders the (query, target, strand) groups (the query axis'
   // order has the rest): prepare leaves the group of every record as one 4-byte value for it
   // (neither when the pair-resident stage is going to run: it sorts inside its pairs)
-  uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && !pair_plan.valid && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
+  uint32_t* group32 = (sweeps && cfg->scaffold_gap != 0 && !(pair_plan.valid && !pair_stage_off) && (uint64_t)r->n_seq * r->n_seq * 2 < (uint64_t(1) << 32)) ? swg_alloc<uint32_t>(ctx, n) : nullptr;
   SWG_CHECK_ARENA(ctx);
   ctx->call_group32 = group32;
   SWG_TRY(swg_prepare(ctx, r, cfg, alive, key_ends ? key_ends : probe_slots, sweeps, scalars, group32, probe_flag, score_col));
@@ -386,9 +417,9 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
     }
     return SWG_OK;
   }
-  if (!sweep_is_identity && pair_plan.valid) {  // behind a mapping sweep: with the sweep's flags (members = the records it kept)
+  if (!sweep_is_identity && pair_plan.valid && !pair_stage_off) {  // behind a mapping sweep: with the sweep's flags (members = the records it kept)
     int taken = 0;
-    SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive, keep1, false, status_out, chain_out, stats, &taken, &pair_plan));
+    SWG_TRY(pair_stage(alive, keep1, false, &taken));
     if (taken) return SWG_OK;
   }
   return swg_scaffold_stage(ctx, r, cfg, alive, keep1, pos_bits, status_out, chain_out, stats, q_order_valid ? q_order : nullptr, h[1],

@@ -38,6 +38,10 @@ struct swg_ctx {
   const uint32_t* call_group32 = nullptr;  // the running call's (query, target, strand) group of every record, when prepare wrote it
   int sort_drop_level = 0;   // raised when a sort on a truncated key met runs too long to order in the gather (swg_radix_drop_bits)
   uint64_t sort_drop_n = 0;  // ... by a call over this many records: a call of a very different size starts from level 0 again
+  uint64_t pair_fallback_n[2] = {0, 0};   // the pair-resident scaffold stage handed a call of this many records back on a condition found
+  int pair_fallback_count[2] = {0, 0};    //   on the device (deep long units, dense LDS batches, a degenerate record), so many times in a
+                                          //   row: from the second time on, calls of about that size do not try it (swg_filter.hip).  [0]: the
+                                          //   attempt that takes an unlimited mapping sweep as the identity, [1]: the one behind a real sweep
   uint64_t seg_sweep_deep_n = 0;  // the segment-resident k = 1 sweep met deep data on an axis of this many records: axes of about
                                   //   that size go straight to the tile kernels (swg_seg_sweep_k1)
   // per-kernel profiler (swg_profile_*)

@@ -309,3 +309,28 @@ print("ok")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SWG_SEG_SORT="0"), capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_a_context_stops_trying_what_the_device_keeps_handing_back(sw):
+    """a workload the pair-resident stage always hands back on the device's word pays the whole stage for nothing
+    on every call.  Here: a retained zero-length record under the CLI defaults -- the attempt that takes the unlimited sweep as
+    the identity is handed back, the real sweep runs, the stage runs again behind it.  The context remembers: from the third
+    call of about that size on the first attempt is not made (ONE pair_sort launch per call instead of two); a call of another
+    size starts afresh.  Same answers throughout."""
+    rng = np.random.default_rng(21)
+    rec = pair_major(gen.random_records(rng, 80_000, n_genomes=3, chrs_per_genome=2, span=2_000_000, zero_frac=0.01), rng)
+    cfg = {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}
+    ctx = sw.default_context(0)
+    sorts = []
+    for _ in range(4):
+        run_both(sw, rec, cfg, expect_pair_path=True)
+        t = ctx.profile_table()
+        sorts.append(sum(v[0] for k, v in t.items() if k.startswith("pair_sort_m") or k.startswith("pair_sort_s") or k == "pair_sort_big"))
+    assert sorts[0] == sorts[1] and sorts[2] == sorts[3] and sorts[2] < sorts[0], sorts
+    other = pair_major(gen.random_records(rng, 300_000, n_genomes=3, chrs_per_genome=2, span=2_000_000, zero_frac=0.01), rng)
+    more = []
+    for _ in range(3):                                   # another size: both attempts again, twice
+        run_both(sw, other, cfg, expect_pair_path=True)
+        t = ctx.profile_table()
+        more.append(sum(v[0] for k, v in t.items() if k.startswith("pair_sort_m") or k.startswith("pair_sort_s") or k == "pair_sort_big"))
+    assert more[0] == more[1] and more[2] < more[0], more

@@ -46,3 +46,35 @@ def test_launches_per_call_come_from_the_last_execution(tmp_path):
     assert k["gather_all_words"]["hbm_bytes_per_launch"] == (2 * 100.0 + 50.0) * 1024
     want = sum(v["hbm_bytes_per_launch"] * v["launches_per_call"] for v in k.values())
     assert abs(j["hbm_bytes_per_call_all_kernels"] - want) < 1e-6
+
+
+def test_mixed_call_shapes_and_the_collection_time_stamp(tmp_path):
+    """A trace may mix call shapes: a call starts with pair_boundary (large inputs), pair_hash (small ones) or
+    prepare (no pair plan), and the prepare of a call that the pair path handed over to the global-sort stage is not a new call:
+    with SWG_CALL_MARKER=1 (tools/profile_round.sh) every call opens with the empty launch `call_begin`, and the trace is cut there.  The
+    JSON is stamped with the digest profile_round.sh left next to the counters when it collected them, and only when both passes
+    carry the same one."""
+    ns = "void swg_scaf::(anonymous namespace)::"
+    a = "void (anonymous namespace)::"
+    big = [(ns + "pair_boundary_kernel(unsigned int)", 8.0), (ns + "pair_sort_big_kernel(int)", 50.0)]
+    handed = [(ns + "pair_boundary_kernel(unsigned int)", 8.0), (ns + "pair_sort_big_kernel(int)", 50.0), (a + "prepare_kernel(unsigned long)", 10.0),
+              (a + "gather_all_words_kernel(unsigned long)", 100.0)]
+    small = [(ns + "pair_hash_kernel(unsigned int)", 1.0), (ns + "pair_sort_kernel<64, 16, 16, 256, 64, true>(int)", 2.0)]
+    plain = [(a + "prepare_kernel(unsigned long)", 10.0), (a + "gather_all_words_kernel(unsigned long)", 100.0)]
+    mark = [(a + "call_begin_kernel()", 0.0)]
+    seq = mark + big + mark + handed + mark + small + mark + plain + mark + big
+    fe, wr = str(tmp_path / "fetch"), str(tmp_path / "write")
+    _write(fe, "FETCH_SIZE", seq)
+    _write(wr, "WRITE_SIZE", seq)
+    run = lambda: json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), fe, wr, "1000", "5"],   # noqa: E731
+                                            capture_output=True, text=True, check=True).stdout)
+    j = run()
+    assert j["pipeline_executions_profiled"] == 5                       # (the handed-over call's prepare opens no sixth)
+    assert j["kernels"]["pair_sort_big"]["launches_per_call"] == 1.0 and j["kernels"]["prepare"]["launches_per_call"] == 0.0
+    assert "call_begin" not in j["kernels"]
+    assert j["lib_sha256"] is None                                      # nothing was left at collection time: not stamped
+    for d, digest in ((fe, "ab" * 32), (wr, "ab" * 32)):
+        open(os.path.join(d, "lib_sha256.txt"), "w").write(digest + "  libsweepga_gpu.so\n")
+    assert run()["lib_sha256"] == "ab" * 32
+    open(os.path.join(wr, "lib_sha256.txt"), "w").write("cd" * 32 + "  libsweepga_gpu.so\n")
+    assert run()["lib_sha256"] is None                                  # the two passes ran different libraries

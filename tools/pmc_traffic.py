@@ -10,7 +10,6 @@ Both counters are in KB per dispatch; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) 
 correction, calibrated on os_pass which reads exactly 12 B per pair)."""
 import csv
 import glob
-import hashlib
 import json
 import os
 import re
@@ -83,14 +82,25 @@ def collect(d, counter):
             rows.append((int(row["Dispatch_Id"]), k))
     rows.sort()
     executions, last = 0, defaultdict(int)
-    # (the pair-resident path starts with pair_boundary and has no prepare; a call it hands over to the global-sort stage has
-    # both, pair_boundary first)
-    first = "pair_boundary" if any(k == "pair_boundary" for _, k in rows) else "prepare"
+    # A call starts with pair_boundary (large inputs: the pair plan), pair_hash (small ones) or prepare (no plan at all); a call
+    # the pair-resident path hands over to the global-sort stage has pair_boundary / pair_hash AND, later, prepare -- that
+    # prepare is not a new call.  (A trace may mix call shapes.)
+    # With SWG_CALL_MARKER=1 (tools/profile_round.sh sets it) every call opens with the empty launch `call_begin`: unambiguous.
+    # Without it, the heuristic above -- which takes a call without a plan for a hand-over when it follows one with a plan.
+    marked = any(k == "call_begin" for _, k in rows)
+    by_plan = False
     for _, k in rows:
-        if k == first:
+        if marked:
+            start = k == "call_begin"
+        else:
+            start = k in ("pair_boundary", "pair_hash") or (k == "prepare" and not (by_plan and "prepare" not in last))
+        if start:
             executions += 1
             last = defaultdict(int)
+            by_plan = k != "prepare"
         last[k] += 1
+    acc.pop("call_begin", None)
+    last.pop("call_begin", None)
     return acc, executions, dict(last)
 
 
@@ -114,9 +124,15 @@ def main():
                       "write_size_kb_per_launch": w, "hbm_bytes_per_launch": per_launch,
                       "hbm_bytes_per_call": per_launch * lpc}
         total += per_launch * lpc
-    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sweepga_amd", "libsweepga_gpu.so")
-    # the library these counters were taken from: bench.py reports `traffic` only when the library it runs has the same digest
-    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    # the library these counters were taken FROM: tools/profile_round.sh leaves its sha256 in both counter directories when it
+    # collects them (lib_sha256.txt); without that, or when the two passes ran different libraries, nothing is stamped and
+    # bench.py reports no `traffic` (it only does when the library it runs has the stamped digest)
+    def stamp(d):
+        try:
+            return open(os.path.join(d, "lib_sha256.txt")).read().split()[0]
+        except (OSError, IndexError):
+            return None
+    sha = stamp(fetch_dir) if stamp(fetch_dir) and stamp(fetch_dir) == stamp(write_dir) else None
     print(json.dumps({"_how": __doc__.strip(), "lib_sha256": sha, "n_mappings": n, "calls_profiled": calls, "pipeline_executions_profiled": executions,
                       "hbm_bytes_per_call_all_kernels": total, "kernels": kernels}, indent=1))
 

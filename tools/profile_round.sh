@@ -13,16 +13,19 @@ TAG=${1:-rXX}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export SWG_CALL_MARKER=1   # an empty launch opens every filter call: tools/pmc_traffic.py cuts the traces there
 COMMON="--only --cpu-sample 0 --no-pcie --e2e 0 --sbig1 0"
 run_set () {  # $1 = workload flag value, $2 = file suffix, $3 = mappings, $4 = flag sets, $5 = flag sets with SQ tables
   WL=$1; SUF=$2; NM=$3; PIPES=$4; SQPIPES=$5
   for p in $PIPES; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 3 --warmup 1 $COMMON > $OUT/stats_${p}_$SUF.log 2>&1
     f=$(find $OUT/stats_${p}_$SUF -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && cp $f $OUT/${TAG}_${p}_${SUF}_kernel_stats.csv
+    [ -n "$f" ] && { echo "# library $(sha256sum $R/sweepga_amd/libsweepga_gpu.so | cut -c1-64)" > $OUT/${TAG}_${p}_${SUF}_kernel_stats.csv; cat $f >> $OUT/${TAG}_${p}_${SUF}_kernel_stats.csv; }
     find $OUT/stats_${p}_$SUF -name "*kernel_trace.csv" -delete
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_fetch_${p}_$SUF.log 2>&1
+    sha256sum $R/sweepga_amd/libsweepga_gpu.so > $OUT/pmc_fetch_${p}_$SUF/lib_sha256.txt   # (the library the counters were taken from: pmc_traffic.py stamps its JSON with it)
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_${p}_$SUF -- python3 $R/bench.py --workload $WL --pipeline $p --steps 1 --warmup 0 $COMMON > $OUT/pmc_write_${p}_$SUF.log 2>&1
+    sha256sum $R/sweepga_amd/libsweepga_gpu.so > $OUT/pmc_write_${p}_$SUF/lib_sha256.txt
     python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_${p}_$SUF $OUT/pmc_write_${p}_$SUF $NM 4 > $OUT/${TAG}_hbm_traffic_${p}_$SUF.json
     find $OUT -name "*kernel_trace.csv" -delete
   done
