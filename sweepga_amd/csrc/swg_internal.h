@@ -318,8 +318,19 @@ struct swg_axis_input {
 };
 int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double thr, uint8_t* keep);
 int swg_seg_run_alive(swg_ctx* ctx, const void* runs, uint32_t n_runs, const uint8_t* alive, uint32_t* run_alive);
+// what swg_seg_sort_begins leaves behind for the streaming sweep over its output (device pointers into the arena: valid until the
+// caller restores its mark)
+struct swg_seg_plan_view {
+  int valid = 0;
+  const uint32_t *seg_a = nullptr, *seg_e = nullptr, *class_list = nullptr;
+  uint32_t* counters = nullptr;
+  uint32_t n_runs = 0, ncls[4] = {0, 0, 0, 0};
+  uint64_t n_dead = 0;
+};
 int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
-                        uint32_t ntilesf, uint8_t* single, int* done);
+                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view = nullptr);
+int swg_seg_stream_sweep_k1(swg_ctx* ctx, const swg_seg_plan_view& v, const uint64_t* S, const uint32_t* I, const uint32_t* E, const uint64_t* KEY,
+                            int pos_bits, double thr, const uint8_t* and_with, uint8_t* keep, uint64_t n, int* done);
 int swg_seg_sweep_k1(swg_ctx* ctx, const swg_axis_input& in, double thr, uint8_t* keep, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY,
                      uint64_t* tile_xf, uint8_t* single, uint64_t* nb_left, int* outcome);
 // Both axes with k = inf in one pass; *done = 0 when zero-length intervals exist (then the per-axis calls are needed).

@@ -684,6 +684,295 @@ __device__ __forceinline__ bool seg_overlap_exceeds(uint32_t as, uint32_t ae, ui
   return __ddiv_rn(ol, ml) > thr;
 }
 
+
+// ---- one batch of the k = 1 sweep, shared by the fused body (seg_sweep_body) and the streaming one (seg_stream_body) -----------
+// The batch's intervals sit in LDS in (start, record index) order: the nc carried ones in front, then mb new ones -- start K, end
+// EP.x (EP.y is filled here: the running maximum of the ends), score key KEY, ID (what rec_of turns into the record's index),
+// fresh flags TOPF / OVLF for the new ones.  The batch answers for the positions [s_first, s_next) (last: no bound above);
+// intervals that reach beyond are carried over in front of the next batch (nc on return), the others' flags go to `keep`.
+// false: the data is deep (counters[4] |= 2) -- the caller gives the call up.  Leaves through a barrier.
+// (the LDS arrays as parameters of their own: a pointer that travels through a struct in memory loses its address space, and
+// every access behind it becomes a flat instruction)
+__device__ __forceinline__ uint32_t swg_fresh_tid() {
+  uint32_t t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+template <int NT, int ES, int CMAX, int EVL, int N_LONG, typename IDT, class RecOf>
+__device__ __forceinline__ bool sweep_batch(uint32_t* const K, uint2* const EP, uint64_t* const KEY, IDT* const ID, uint8_t* const TOPF,
+                                            uint8_t* const OVLF, uint16_t* const ev_list /*[EVL] a round's listed slots*/,
+                                            uint16_t* const ev_long /*[N_LONG] those with long windows*/, uint32_t* const ws,
+                                            uint32_t* const sh /*[5] deep, [6] a round's long windows, [7] a round's listed intervals*/,
+                                            uint32_t& nc, const uint32_t mb, const bool last, uint32_t& s_first, const uint32_t s_next,
+                                            const double thr, const uint8_t* __restrict__ and_with, uint8_t* __restrict__ keep,
+                                            uint32_t* __restrict__ counters, RecOf&& rec_of) {
+  constexpr int CAP = NT * ES;
+  const int tid = threadIdx.x;
+  const bool ovl_on = thr < 1.0;
+  {
+    const uint32_t nb = nc + mb;
+    // ---- the running maximum of the ends (an interval that is never active does not raise it)
+    {
+      const uint32_t q0 = swg_fresh_tid() * ES;
+      uint32_t run[ES], tmax = 0;
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t q = q0 + e;
+        const uint32_t s = q < nb ? K[q] : 0u, en = q < nb ? EP[q].x : 0u;
+        if (q < nb && en <= s && en) EP[q].x = 0u;  // never active: end 0 from here on (no position lies below it)
+        tmax = (en > s && en > tmax) ? en : tmax;
+        run[e] = tmax;
+      }
+      const uint32_t before = swg_lds::block_excl_max_u32<NT>(tmax, ws);
+#pragma unroll
+      for (int e = 0; e < ES; ++e)
+        if (q0 + e < nb) EP[q0 + e].y = run[e] > before ? run[e] : before;
+    }
+    lds_barrier();
+    // ---- the sweep of the batch's range of positions [s_first, s_next): one evaluation per interval t, over the part [a, b) of
+    // its span that lies in the range.  Among the intervals that intersect [a, b) -- a window of slots: from the first slot whose
+    // running maximum of ends exceeds a to the last slot that starts before b -- the BETTER ones (score key, then slot) are
+    // walked in start order with the position `reach` up to which they cover [a, b) without a gap; every gap [g, h) is a stretch
+    // where t is the top of the active set: t is marked, and every other interval active somewhere in [g, h) is tested against
+    // it (overlap fraction above the threshold -> the sticky `overlapped`).  (g is an event position: t's start, the range's first
+    // position or a better interval's end; the active set only changes at event positions.)
+    // Everything here is bound by instruction issue (one work-group of 16 wavefronts on the CU, and a wavefront pays for every
+    // path one of its lanes takes), so the work is sorted before it is done:
+    //   classify   one thread per slot: an interval with nobody else in [a, b) -- no earlier interval reaches a (the running
+    //              maximum in front of the slot), no later one begins before b (the next slot's start) -- is the top there,
+    //              settled on the spot; the others go onto a list (the bucket counters' room)
+    //   evaluate   one thread per listed interval: the lanes are full again
+    {
+      constexpr int ROUND = ES < EVL / NT ? ES : EVL / NT;  // slots per thread and round
+      constexpr int EV_STEPS = 12;
+      static_assert(ROUND >= 1 && CAP < 65536, "a round's slots (16 bits each) fit the bucket counters' room");
+      const uint32_t lane = (uint32_t)tid & 63u;
+      // (the work-group waits for its slowest thread at the next barrier, and window lengths are heavy-tailed -- a long
+      // interval's window holds every begin inside its span, an interval in the shadow of a long one every slot back to it: a
+      // thread gives up beyond EV_STEPS window slots and leaves the interval to a whole wavefront, evaluate_long)
+      auto evaluate = [&](const uint32_t t) {
+        const uint32_t s = K[t], en = EP[t].x;
+        const uint64_t kx = KEY[t];
+        const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
+        uint32_t lo = t, hi = t;
+        while (lo > 0 && EP[lo - 1].y > a_ && t - lo <= (uint32_t)EV_STEPS) --lo;
+        while (hi + 1 < nb && K[hi + 1] < b_ && hi - lo <= (uint32_t)EV_STEPS) ++hi;
+        if (hi - lo > (uint32_t)EV_STEPS) {
+          const uint32_t at = atomicAdd(&sh[6], 1u);
+          if (at < (uint32_t)N_LONG) ev_long[at] = (uint16_t)t; else sh[5] = 1u;  // (more long intervals than the list holds: deep data)
+          return;
+        }
+        const uint32_t ts = s, te = en;
+        auto stretch = [&](const uint32_t g, const uint32_t h) {
+          TOPF[t] = 1;
+          if (!ovl_on) return;
+          for (uint32_t x = lo; x <= hi; ++x) {
+            const uint32_t ex = EP[x].x, sx = K[x];
+            if (x != t && ex > g && sx < h && seg_overlap_exceeds(sx, ex, ts, te, thr)) OVLF[x] = 1;
+          }
+        };
+        uint32_t reach = a_;
+        for (uint32_t j = lo; j <= hi && reach < b_; ++j) {
+          const uint32_t ej = EP[j].x;
+          const uint64_t kj = KEY[j];
+          if (j != t && ej > reach && (kj < kx || (kj == kx && j < t))) {  // (an interval that is never active has end 0 here)
+            const uint32_t sj = K[j];
+            if (sj > reach) stretch(reach, sj < b_ ? sj : b_);
+            reach = ej;
+          }
+        }
+        if (reach < b_) stretch(reach, b_);
+      };
+      // the same by a whole wavefront, 64 window slots per step (every lane is passed the same t)
+      auto evaluate_long = [&](const uint32_t t, uint32_t* rounds) {
+        const uint32_t s = K[t], en = EP[t].x;
+        const uint64_t kx = KEY[t];
+        const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
+        uint32_t lo = t, hi = t;
+        for (;;) {  // backwards while the running maximum in front of the slot exceeds a
+          const int j = (int)lo - 1 - (int)lane;
+          const unsigned long long stop = ~__ballot(j >= 0 && EP[j >= 0 ? j : 0].y > a_);
+          const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+          lo -= c;
+          ++*rounds;
+          if (c < 64u) break;
+        }
+        for (;;) {  // forwards while the next slot starts before b
+          const uint32_t j = hi + 1u + lane;
+          const unsigned long long stop = ~__ballot(j < nb && K[j < nb ? j : 0u] < b_);
+          const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+          hi += c;
+          ++*rounds;
+          if (c < 64u) break;
+        }
+        const uint32_t ts = s, te = en;
+        auto stretch = [&](const uint32_t g, const uint32_t h) {
+          if (lane == 0) TOPF[t] = 1;
+          if (!ovl_on) return;
+          for (uint32_t x0 = lo; x0 <= hi; x0 += 64u) {
+            const uint32_t x = x0 + lane;
+            if (x <= hi && x != t) {
+              const uint32_t ex = EP[x].x, sx = K[x];
+              if (ex > g && sx < h && seg_overlap_exceeds(sx, ex, ts, te, thr)) OVLF[x] = 1;
+            }
+            ++*rounds;
+          }
+        };
+        uint32_t reach = a_;
+        for (uint32_t j0 = lo; j0 <= hi && reach < b_; j0 += 64u) {
+          const uint32_t j = j0 + lane;
+          const bool in = j <= hi && j != t;
+          const uint32_t jc = in ? j : t;
+          const uint32_t ej = EP[jc].x, sj = K[jc];
+          const uint64_t kj = KEY[jc];
+          const bool isb = in && ej > a_ && (kj < kx || (kj == kx && j < t));
+          // the position the better intervals in front of this lane's slot reach (the sequential walk's `reach` there)
+          uint32_t inc = isb ? ej : 0u;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc = y > inc ? y : inc;
+          }
+          uint32_t before = __shfl_up(inc, 1, 64);
+          if (lane == 0) before = 0u;
+          before = before > reach ? before : reach;
+          unsigned long long gaps = __ballot(isb && ej > before && sj > before && before < b_);
+          while (gaps) {
+            const int l = __builtin_ctzll(gaps);
+            gaps &= gaps - 1ull;
+            const uint32_t g = (uint32_t)__shfl((int)before, l, 64), h0 = (uint32_t)__shfl((int)sj, l, 64);
+            stretch(g, h0 < b_ ? h0 : b_);
+          }
+          const uint32_t all = (uint32_t)__shfl((int)inc, 63, 64);
+          reach = all > reach ? all : reach;
+          ++*rounds;
+        }
+        if (reach < b_) stretch(reach, b_);
+      };
+#pragma unroll 1
+      for (int e0 = 0; e0 < ES; e0 += ROUND) {
+        if ((uint32_t)e0 * NT >= nb) break;  // (uniform)
+        if (tid == 0) {
+          sh[6] = 0u;
+          sh[7] = 0u;
+        }
+        lds_barrier();
+        // classify
+        {
+          const uint32_t t_ev = swg_fresh_tid();
+          uint32_t ent[ROUND];
+          uint32_t n_ev = 0;
+#pragma unroll
+          for (int e = 0; e < ROUND; ++e) {
+            const uint32_t p = t_ev + (uint32_t)(e0 + e) * NT;
+            const bool in = e0 + e < ES && p < nb;
+            const uint32_t pc = in ? p : 0u;
+            const uint32_t s = K[pc], en = EP[pc].x;
+            const uint32_t k_next = pc + 1 < nb ? K[pc + 1] : 0xffffffffu;
+            const uint32_t pm_prev = pc ? EP[pc - 1].y : 0u;
+            const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
+            const bool has = in && en > s && b_ > a_;
+            const bool alone = pm_prev <= a_ && (pc + 1 >= nb || k_next >= b_);
+            if (has && alone) TOPF[p] = 1;
+            ent[e] = (has && !alone) ? p : NONE;
+            n_ev += ent[e] != NONE ? 1u : 0u;
+          }
+          // the wavefront's intervals onto the list: one atomic per wavefront
+          uint32_t inc = n_ev;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t x = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += x;
+          }
+          uint32_t base = 0;
+          if (lane == 63u && inc) base = atomicAdd(&sh[7], inc);
+          base = (uint32_t)__shfl((int)base, 63, 64) + inc - n_ev;
+#pragma unroll
+          for (int e = 0; e < ROUND; ++e)
+            if (ent[e] != NONE) ev_list[base++] = (uint16_t)ent[e];
+        }
+        lds_barrier();
+        // evaluate
+        {
+          const uint32_t n_list = sh[7];
+          for (uint32_t i = swg_fresh_tid(); i < n_list; i += NT) evaluate(ev_list[i]);
+        }
+        lds_barrier();
+        {
+          const uint32_t n_long = sh[6] < (uint32_t)N_LONG ? sh[6] : (uint32_t)N_LONG;
+          uint32_t rounds = 0;
+          for (uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6); i < n_long; i += NT / 64) {
+            evaluate_long((uint32_t)__builtin_amdgcn_readfirstlane((int)ev_long[i]), &rounds);
+            if (rounds > SWEEP_BUDGET) {
+              sh[5] = 1u;
+              break;
+            }
+          }
+        }
+      }
+    }
+    lds_barrier();
+    if (sh[5]) {
+      if (tid == 0) atomicOr(&counters[4], 2u);
+      return false;
+    }
+    // ---- retire (the flag goes to the record) or carry over
+    {
+      const uint32_t q0 = swg_fresh_tid() * ES;
+      uint32_t ck[ES], ce[ES], cw[ES], cf[ES];  // (cw: the interval's ID, cf: its flags so far)
+      uint64_t cs[ES];
+      uint32_t cmask = 0;
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t q = q0 + e;
+        ck[e] = ce[e] = cw[e] = cf[e] = 0;
+        cs[e] = 0;
+        if (q >= nb) continue;
+        const uint32_t s = K[q], en = EP[q].x, f = (TOPF[q] ? F_TOP : 0u) | (OVLF[q] ? F_OVL : 0u), place = ID[q];
+        if (!last && en > s && en > s_next) {  // (reaches into the next batch's range)
+          cmask |= 1u << e;
+          ck[e] = s;
+          ce[e] = en;
+          cw[e] = place;
+          cf[e] = f;
+          cs[e] = KEY[q];
+        } else {
+          const uint32_t ix = rec_of(place);
+          keep[ix] = ((f & F_TOP) && !(f & F_OVL) && (!and_with || and_with[ix])) ? 1 : 0;
+        }
+      }
+      if (!last) {
+        uint32_t tot;
+        lds_barrier();
+        const uint32_t at = block_excl_sum<NT>((uint32_t)__popc(cmask), ws, &tot);
+        lds_barrier();
+        tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot);
+        if (tot > (uint32_t)CMAX) {
+          if (tid == 0) {
+            atomicOr(&counters[4], 2u);
+            atomicAdd(&counters[7], 1u);
+          }
+          return false;
+        }
+#pragma unroll
+        for (int e = 0; e < ES; ++e)
+          if ((cmask >> e) & 1u) {
+            const uint32_t d = at + (uint32_t)__popc(cmask & ((1u << e) - 1u));
+            K[d] = ck[e];
+            EP[d].x = ce[e];
+            KEY[d] = cs[e];
+            ID[d] = (IDT)cw[e];
+            TOPF[d] = (uint8_t)(cf[e] & F_TOP);
+            OVLF[d] = (uint8_t)(cf[e] & F_OVL);
+          }
+        nc = tot;
+      }
+    }
+    s_first = s_next;
+    lds_barrier();
+  }
+  return true;
+}
 template <int NT, int ES, int NBK>
 constexpr size_t seg_sweep_lds_bytes() {
   // K, EP, KEY, ID, F per slot; bucket counters; b_lo, ws, scalars; slack for the alignment of each piece
@@ -955,279 +1244,12 @@ __device__ __forceinline__ void seg_sweep_body(const SegSweepArgs& A, const uint
     }
     lds_barrier();
     ST_STAMP(6);
-    const uint32_t nb = nc + mb;
-    // ---- the running maximum of the ends (an interval that is never active does not raise it)
     {
-      const uint32_t q0 = fresh_tid() * ES;
-      uint32_t run[ES], tmax = 0;
-#pragma unroll
-      for (int e = 0; e < ES; ++e) {
-        const uint32_t q = q0 + e;
-        const uint32_t s = q < nb ? K[q] : 0u, en = q < nb ? EP[q].x : 0u;
-        if (q < nb && en <= s && en) EP[q].x = 0u;  // never active: end 0 from here on (no position lies below it)
-        tmax = (en > s && en > tmax) ? en : tmax;
-        run[e] = tmax;
-      }
-      const uint32_t before = swg_lds::block_excl_max_u32<NT>(tmax, ws);
-#pragma unroll
-      for (int e = 0; e < ES; ++e)
-        if (q0 + e < nb) EP[q0 + e].y = run[e] > before ? run[e] : before;
+      const uint32_t s_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[4]);  // (the last batch: no bound)
+      if (!sweep_batch<NT, ES, CMAX, 2 * NBK, N_LONG>(K, EP, KEY, ID, TOPF, OVLF, reinterpret_cast<uint16_t*>(cnt), reinterpret_cast<uint16_t*>(lds_raw + O_LONG), ws,
+                                                      sh, nc, mb, last, s_first, s_next, A.thr, A.and_with, A.keep, A.counters, rec_of_place))
+        return;
     }
-    lds_barrier();
-    ST_STAMP(7);
-    const uint32_t s_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[4]);
-    // ---- the sweep of the batch's range of positions [s_first, s_next): one evaluation per interval t, over the part [a, b) of
-    // its span that lies in the range.  Among the intervals that intersect [a, b) -- a window of slots: from the first slot whose
-    // running maximum of ends exceeds a to the last slot that starts before b -- the BETTER ones (score key, then slot) are
-    // walked in start order with the position `reach` up to which they cover [a, b) without a gap; every gap [g, h) is a stretch
-    // where t is the top of the active set: t is marked, and every other interval active somewhere in [g, h) is tested against
-    // it (overlap fraction above the threshold -> the sticky `overlapped`).  (g is an event position: t's start, the range's first
-    // position or a better interval's end; the active set only changes at event positions.)
-    // Everything here is bound by instruction issue (one work-group of 16 wavefronts on the CU, and a wavefront pays for every
-    // path one of its lanes takes), so the work is sorted before it is done:
-    //   classify   one thread per slot: an interval with nobody else in [a, b) -- no earlier interval reaches a (the running
-    //              maximum in front of the slot), no later one begins before b (the next slot's start) -- is the top there,
-    //              settled on the spot; the others go onto a list (the bucket counters' room)
-    //   evaluate   one thread per listed interval: the lanes are full again
-    uint16_t* const ev_list = reinterpret_cast<uint16_t*>(cnt);  // [2 * NBK] slots
-    uint16_t* const ev_long = reinterpret_cast<uint16_t*>(lds_raw + O_LONG);  // [N_LONG] slots of the intervals with long windows
-    {
-      constexpr int ROUND = ES < 2 * NBK / NT ? ES : 2 * NBK / NT;  // slots per thread and round
-      constexpr int EV_STEPS = 12;
-      static_assert(ROUND >= 1 && CAP < 65536, "a round's slots (16 bits each) fit the bucket counters' room");
-      const uint32_t lane = (uint32_t)tid & 63u;
-      // (the work-group waits for its slowest thread at the next barrier, and window lengths are heavy-tailed -- a long
-      // interval's window holds every begin inside its span, an interval in the shadow of a long one every slot back to it: a
-      // thread gives up beyond EV_STEPS window slots and leaves the interval to a whole wavefront, evaluate_long)
-      auto evaluate = [&](const uint32_t t) {
-        const uint32_t s = K[t], en = EP[t].x;
-        const uint64_t kx = KEY[t];
-        const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
-        uint32_t lo = t, hi = t;
-        while (lo > 0 && EP[lo - 1].y > a_ && t - lo <= (uint32_t)EV_STEPS) --lo;
-        while (hi + 1 < nb && K[hi + 1] < b_ && hi - lo <= (uint32_t)EV_STEPS) ++hi;
-        if (hi - lo > (uint32_t)EV_STEPS) {
-          const uint32_t at = atomicAdd(&sh[6], 1u);
-          if (at < (uint32_t)N_LONG) ev_long[at] = (uint16_t)t; else sh[5] = 1u;  // (more long intervals than the list holds: deep data)
-          return;
-        }
-        const uint32_t ts = s, te = en;
-        auto stretch = [&](const uint32_t g, const uint32_t h) {
-          TOPF[t] = 1;
-          if (!ovl_on) return;
-          for (uint32_t x = lo; x <= hi; ++x) {
-            const uint32_t ex = EP[x].x, sx = K[x];
-            if (x != t && ex > g && sx < h && seg_overlap_exceeds(sx, ex, ts, te, A.thr)) OVLF[x] = 1;
-          }
-        };
-        uint32_t reach = a_;
-        for (uint32_t j = lo; j <= hi && reach < b_; ++j) {
-          const uint32_t ej = EP[j].x;
-          const uint64_t kj = KEY[j];
-          if (j != t && ej > reach && (kj < kx || (kj == kx && j < t))) {  // (an interval that is never active has end 0 here)
-            const uint32_t sj = K[j];
-            if (sj > reach) stretch(reach, sj < b_ ? sj : b_);
-            reach = ej;
-          }
-        }
-        if (reach < b_) stretch(reach, b_);
-      };
-      // the same by a whole wavefront, 64 window slots per step (every lane is passed the same t)
-      auto evaluate_long = [&](const uint32_t t, uint32_t* rounds) {
-        const uint32_t s = K[t], en = EP[t].x;
-        const uint64_t kx = KEY[t];
-        const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
-        uint32_t lo = t, hi = t;
-        for (;;) {  // backwards while the running maximum in front of the slot exceeds a
-          const int j = (int)lo - 1 - (int)lane;
-          const unsigned long long stop = ~__ballot(j >= 0 && EP[j >= 0 ? j : 0].y > a_);
-          const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-          lo -= c;
-          ++*rounds;
-          if (c < 64u) break;
-        }
-        for (;;) {  // forwards while the next slot starts before b
-          const uint32_t j = hi + 1u + lane;
-          const unsigned long long stop = ~__ballot(j < nb && K[j < nb ? j : 0u] < b_);
-          const uint32_t c = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
-          hi += c;
-          ++*rounds;
-          if (c < 64u) break;
-        }
-        const uint32_t ts = s, te = en;
-        auto stretch = [&](const uint32_t g, const uint32_t h) {
-          if (lane == 0) TOPF[t] = 1;
-          if (!ovl_on) return;
-          for (uint32_t x0 = lo; x0 <= hi; x0 += 64u) {
-            const uint32_t x = x0 + lane;
-            if (x <= hi && x != t) {
-              const uint32_t ex = EP[x].x, sx = K[x];
-              if (ex > g && sx < h && seg_overlap_exceeds(sx, ex, ts, te, A.thr)) OVLF[x] = 1;
-            }
-            ++*rounds;
-          }
-        };
-        uint32_t reach = a_;
-        for (uint32_t j0 = lo; j0 <= hi && reach < b_; j0 += 64u) {
-          const uint32_t j = j0 + lane;
-          const bool in = j <= hi && j != t;
-          const uint32_t jc = in ? j : t;
-          const uint32_t ej = EP[jc].x, sj = K[jc];
-          const uint64_t kj = KEY[jc];
-          const bool isb = in && ej > a_ && (kj < kx || (kj == kx && j < t));
-          // the position the better intervals in front of this lane's slot reach (the sequential walk's `reach` there)
-          uint32_t inc = isb ? ej : 0u;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(inc, d, 64);
-            if (lane >= (uint32_t)d) inc = y > inc ? y : inc;
-          }
-          uint32_t before = __shfl_up(inc, 1, 64);
-          if (lane == 0) before = 0u;
-          before = before > reach ? before : reach;
-          unsigned long long gaps = __ballot(isb && ej > before && sj > before && before < b_);
-          while (gaps) {
-            const int l = __builtin_ctzll(gaps);
-            gaps &= gaps - 1ull;
-            const uint32_t g = (uint32_t)__shfl((int)before, l, 64), h0 = (uint32_t)__shfl((int)sj, l, 64);
-            stretch(g, h0 < b_ ? h0 : b_);
-          }
-          const uint32_t all = (uint32_t)__shfl((int)inc, 63, 64);
-          reach = all > reach ? all : reach;
-          ++*rounds;
-        }
-        if (reach < b_) stretch(reach, b_);
-      };
-#pragma unroll 1
-      for (int e0 = 0; e0 < ES; e0 += ROUND) {
-        if ((uint32_t)e0 * NT >= nb) break;  // (uniform)
-        if (tid == 0) {
-          sh[6] = 0u;
-          sh[7] = 0u;
-        }
-        lds_barrier();
-        // classify
-        {
-          const uint32_t t_ev = fresh_tid();
-          uint32_t ent[ROUND];
-          uint32_t n_ev = 0;
-#pragma unroll
-          for (int e = 0; e < ROUND; ++e) {
-            const uint32_t p = t_ev + (uint32_t)(e0 + e) * NT;
-            const bool in = e0 + e < ES && p < nb;
-            const uint32_t pc = in ? p : 0u;
-            const uint32_t s = K[pc], en = EP[pc].x;
-            const uint32_t k_next = pc + 1 < nb ? K[pc + 1] : 0xffffffffu;
-            const uint32_t pm_prev = pc ? EP[pc - 1].y : 0u;
-            const uint32_t a_ = s > s_first ? s : s_first, b_ = (last || en < s_next) ? en : s_next;
-            const bool has = in && en > s && b_ > a_;
-            const bool alone = pm_prev <= a_ && (pc + 1 >= nb || k_next >= b_);
-            if (has && alone) TOPF[p] = 1;
-            ent[e] = (has && !alone) ? p : NONE;
-            n_ev += ent[e] != NONE ? 1u : 0u;
-          }
-          // the wavefront's intervals onto the list: one atomic per wavefront
-          uint32_t inc = n_ev;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t x = __shfl_up(inc, d, 64);
-            if (lane >= (uint32_t)d) inc += x;
-          }
-          uint32_t base = 0;
-          if (lane == 63u && inc) base = atomicAdd(&sh[7], inc);
-          base = (uint32_t)__shfl((int)base, 63, 64) + inc - n_ev;
-#pragma unroll
-          for (int e = 0; e < ROUND; ++e)
-            if (ent[e] != NONE) ev_list[base++] = (uint16_t)ent[e];
-        }
-        lds_barrier();
-        ST_STAMP(11);
-        // evaluate
-        {
-          const uint32_t n_list = sh[7];
-#ifdef SWG_SEG_TIMING
-          if (tid == 0) atomicAdd(&g_seg_t[15], (unsigned long long)n_list);
-#endif
-          for (uint32_t i = fresh_tid(); i < n_list; i += NT) evaluate(ev_list[i]);
-        }
-        lds_barrier();
-        ST_STAMP(12);
-        {
-          const uint32_t n_long = sh[6] < (uint32_t)N_LONG ? sh[6] : (uint32_t)N_LONG;
-#ifdef SWG_SEG_TIMING
-          if (tid == 0) atomicAdd(&g_seg_t[13], (unsigned long long)n_long);
-#endif
-          uint32_t rounds = 0;
-          for (uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6); i < n_long; i += NT / 64) {
-            evaluate_long((uint32_t)__builtin_amdgcn_readfirstlane((int)ev_long[i]), &rounds);
-            if (rounds > SWEEP_BUDGET) {
-              sh[5] = 1u;
-              break;
-            }
-          }
-        }
-        ST_STAMP(10);
-      }
-    }
-    lds_barrier();
-    ST_STAMP(8);
-    if (sh[5]) {
-      if (tid == 0) atomicOr(&A.counters[4], 2u);
-      return;
-    }
-    // ---- retire (the flag goes to the record) or carry over
-    {
-      const uint32_t q0 = fresh_tid() * ES;
-      uint32_t ck[ES], ce[ES], cw[ES];  // (cw: list place | flags << 16)
-      uint64_t cs[ES];
-      uint32_t cmask = 0;
-#pragma unroll
-      for (int e = 0; e < ES; ++e) {
-        const uint32_t q = q0 + e;
-        ck[e] = ce[e] = cw[e] = 0;
-        cs[e] = 0;
-        if (q >= nb) continue;
-        const uint32_t s = K[q], en = EP[q].x, f = (TOPF[q] ? F_TOP : 0u) | (OVLF[q] ? F_OVL : 0u), place = ID[q];
-        if (!last && en > s && en > s_next) {  // (reaches into the next batch's range)
-          cmask |= 1u << e;
-          ck[e] = s;
-          ce[e] = en;
-          cw[e] = place | (f << 16);
-          cs[e] = KEY[q];
-        } else {
-          const uint32_t ix = rec_of_place(place);
-          A.keep[ix] = ((f & F_TOP) && !(f & F_OVL) && (!A.and_with || A.and_with[ix])) ? 1 : 0;
-        }
-      }
-      if (!last) {
-        uint32_t tot;
-        lds_barrier();
-        const uint32_t at = block_excl_sum<NT>((uint32_t)__popc(cmask), ws, &tot);
-        lds_barrier();
-        tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot);
-        if (tot > (uint32_t)CMAX) {
-          if (tid == 0) {
-            atomicOr(&A.counters[4], 2u);
-            atomicAdd(&A.counters[7], 1u);
-          }
-          return;
-        }
-#pragma unroll
-        for (int e = 0; e < ES; ++e)
-          if ((cmask >> e) & 1u) {
-            const uint32_t d = at + (uint32_t)__popc(cmask & ((1u << e) - 1u));
-            K[d] = ck[e];
-            EP[d].x = ce[e];
-            KEY[d] = cs[e];
-            ID[d] = (uint16_t)cw[e];
-            TOPF[d] = (uint8_t)((cw[e] >> 16) & F_TOP);
-            OVLF[d] = (uint8_t)((cw[e] >> 16) & F_OVL);
-          }
-        nc = tot;
-      }
-    }
-    s_first = s_next;
-    lds_barrier();
     ST_STAMP(9);
   }
 }
@@ -1246,6 +1268,126 @@ __global__ __launch_bounds__(1024) void seg_sweep_big_kernel(SegSweepArgs W, Seg
     seg_sort_xl_body(A, list_xl[blockIdx.x], raw);
   else
     seg_sweep_body<1024, 6, 32, 2048, 1024, 512>(W, W.list[blockIdx.x - n_xl], raw);
+}
+
+
+// ---- the k = 1 sweep of a segment over its SORTED begins, streamed through LDS (round 6; the default behind seg_sort) -------------
+// seg_sort leaves every segment's begins in (start, record index) order in memory -- S, I, E, KEY -- for the tile kernels
+// (swg_sweep.hip), which cut the whole axis into tiles of 128 begins and need every interval that reaches into a tile routed
+// to it first.  A segment's sweep needs none of that: a work-group takes the segment's stretch through LDS chunk by chunk
+// (coalesced loads), the intervals that reach beyond a chunk's positions carried over in front of the next one, and evaluates
+// each chunk with sweep_batch -- the same code the fused kernel runs behind its own sort (seg_sweep_body), but with nothing in
+// LDS except the sweep's own state: several work-groups share a CU, and a segment of any length streams through.  keep[] is
+// written directly (the other axis' result folded in); deep data raises counters[4] bit 1 and the axis goes on to the tile
+// kernels with the arrays it already has.
+struct SegStreamArgs {
+  const uint32_t *seg_a, *seg_e;
+  const uint32_t* class_list;  // [4][n_runs]
+  uint32_t n_runs;
+  uint32_t n_cls[4];
+  const uint64_t* S;  // composite: (segment + 1) << pos_bits | start
+  const uint32_t* I;
+  const uint32_t* E;
+  const uint64_t* KEY;
+  uint32_t n_dead;
+  uint32_t pos_mask;  // the start's bits of S
+  const uint8_t* and_with;
+  uint8_t* keep;
+  double thr;
+  uint32_t* counters;
+};
+template <int NT, int ES>
+constexpr size_t seg_stream_lds_bytes() {
+  // K, EP, KEY, ID, two flag bytes and a list entry per slot; the long windows' list; ws, scalars; slack
+  return (size_t)NT * ES * (4 + 8 + 8 + 4 + 2 + 2 + 1) + (size_t)(NT / 64 + 1) * 4 + 16 * 4 + 64;
+}
+template <int NT, int ES, int CMAX>
+__device__ __forceinline__ void seg_stream_body(const SegStreamArgs& A, const uint32_t sg, char* lds_raw) {
+  constexpr int CAP = NT * ES, CAPN = CAP - CMAX, N_LONG = CAP / 2;
+  static_assert(CMAX < CAP && CAP % 4 == 0, "room for the new intervals of a chunk");
+  constexpr size_t O_K = 0, O_EP = O_K + (size_t)CAP * 4, O_KEY = O_EP + (size_t)CAP * 8, O_ID = O_KEY + (size_t)CAP * 8, O_F = O_ID + (size_t)CAP * 4,
+                   O_LIST = O_F + (size_t)CAP * 2, O_LONG = O_LIST + (size_t)CAP * 2, O_WS = lds_align_up(O_LONG + (size_t)N_LONG * 2, 4),
+                   O_SH = O_WS + (size_t)(NT / 64 + 1) * 4;
+  static_assert(O_SH + 8 * 4 <= seg_stream_lds_bytes<NT, ES>(), "LDS block of the work-group");
+  uint32_t* const K = reinterpret_cast<uint32_t*>(lds_raw + O_K);
+  uint2* const EP = reinterpret_cast<uint2*>(lds_raw + O_EP);
+  uint64_t* const KEY = reinterpret_cast<uint64_t*>(lds_raw + O_KEY);
+  uint32_t* const ID = reinterpret_cast<uint32_t*>(lds_raw + O_ID);  // the record's own index
+  uint8_t* const TOPF = reinterpret_cast<uint8_t*>(lds_raw + O_F);
+  uint8_t* const OVLF = TOPF + CAP;
+  uint16_t* const ev_list = reinterpret_cast<uint16_t*>(lds_raw + O_LIST);
+  uint16_t* const ev_long = reinterpret_cast<uint16_t*>(lds_raw + O_LONG);
+  uint32_t* const ws = reinterpret_cast<uint32_t*>(lds_raw + O_WS);
+  uint32_t* const sh = reinterpret_cast<uint32_t*>(lds_raw + O_SH);  // [4] the chunk's intervals that start with the next chunk, [5] deep, [6], [7]: sweep_batch's
+  const int tid = threadIdx.x;
+  const uint32_t a = A.seg_a[sg], n_live = A.seg_e[sg] - a;
+  const size_t base = (size_t)A.n_dead + a;
+  if (n_live <= 1u) {  // returned whole by the reference (plane_sweep_exact.rs:274-276)
+    if (tid == 0 && n_live) {
+      const uint32_t ix = A.I[base];
+      A.keep[ix] = (!A.and_with || A.and_with[ix]) ? 1 : 0;
+    }
+    return;
+  }
+  if (tid == 0) sh[5] = 0u;
+  uint32_t nc = 0, s_first = 0, pos = 0;
+  while (pos < n_live) {
+    const uint32_t take = n_live - pos < (uint32_t)CAPN ? n_live - pos : (uint32_t)CAPN;
+    bool last = pos + take == n_live;
+    // the chunk must not end inside a run of equal starts: its intervals that start where the NEXT chunk starts are left to it
+    const uint32_t s_after = last ? 0u : (uint32_t)A.S[base + pos + take] & A.pos_mask;
+    if (tid == 0) sh[4] = 0u;
+    lds_barrier();
+    uint32_t tail = 0;
+    const uint32_t t_ld = swg_fresh_tid();
+#pragma unroll
+    for (int e = 0; e < ES; ++e) {
+      const uint32_t j = t_ld + (uint32_t)e * NT;
+      if (j < take) {
+        const size_t g = base + pos + j;
+        const uint32_t st = (uint32_t)A.S[g] & A.pos_mask;
+        K[nc + j] = st;
+        EP[nc + j].x = A.E[g];
+        KEY[nc + j] = A.KEY[g];
+        ID[nc + j] = A.I[g];
+        TOPF[nc + j] = 0;
+        OVLF[nc + j] = 0;
+        tail += (!last && st == s_after) ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tail += __shfl_xor(tail, o, 64);
+    if ((tid & 63) == 0 && tail) atomicAdd(&sh[4], tail);
+    lds_barrier();
+    const uint32_t n_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[4]);
+    if (n_tail >= take) {  // a run of equal starts longer than a chunk: the tile kernels' case
+      if (tid == 0) atomicOr(&A.counters[4], 2u);
+      return;
+    }
+    const uint32_t mb = take - n_tail;
+    const uint32_t s_next = s_after;
+    if (!sweep_batch<NT, ES, CMAX, CAP, N_LONG>(K, EP, KEY, ID, TOPF, OVLF, ev_list, ev_long, ws, sh, nc, mb, last, s_first, s_next, A.thr, A.and_with,
+                                                A.keep, A.counters, [](uint32_t ix) { return ix; }))
+      return;
+    pos += mb;
+  }
+}
+// the segments of more than SEG_S_MAX places, the longest ones first (blockIdx -> class 3, 2, 1)
+template <int NT, int ES, int CMAX>
+__global__ __launch_bounds__(NT) void seg_stream_kernel(SegStreamArgs A) {
+  __shared__ __attribute__((aligned(16))) char raw[seg_stream_lds_bytes<NT, ES>()];
+  uint32_t b = blockIdx.x;
+  int c = 3;
+  while (c > 1 && b >= A.n_cls[c]) {
+    b -= A.n_cls[c];
+    --c;
+  }
+  seg_stream_body<NT, ES, CMAX>(A, A.class_list[(size_t)c * A.n_runs + b], raw);
+}
+template <int NT, int ES>
+__global__ __launch_bounds__(NT) void seg_stream_small_kernel(SegStreamArgs A) {
+  __shared__ __attribute__((aligned(16))) char raw[seg_stream_lds_bytes<NT, ES>()];
+  seg_stream_body<NT, ES, 0>(A, A.class_list[blockIdx.x], raw);
 }
 
 }  // namespace
@@ -1374,9 +1516,10 @@ int seg_flags_read(swg_ctx* ctx, const SegPlan& P, uint32_t* flags) {
 // The axis' sorted begins from the runs of a pair-grouped input.  *done = 0: not applicable here, or a segment too dense for
 // the LDS batches -- the caller sorts the general way (nothing it cannot overwrite was written).
 int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
-                        uint32_t ntilesf, uint8_t* single, int* done) {
+                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view) {
   using namespace swg_seg;
   *done = 0;
+  if (view) *view = swg_seg_plan_view{};
   static const int knob = getenv("SWG_SEG_SORT") ? atoi(getenv("SWG_SEG_SORT")) : -1;
   if (knob == 0) return SWG_OK;
   if (!in.seg_runs || in.n_seg_runs == 0 || !in.score_key || in.packed || !in.seg_run_alive) return SWG_OK;
@@ -1424,10 +1567,66 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   // the dense-bin flag: read with the caller's next read-back would be cheaper, but the caller must know before it routes
   uint32_t fl = 0;
   SWG_TRY(seg_flags_read(ctx, P, &fl));
-  swg_arena_restore(ctx, mark);
+  if (fl || !view) swg_arena_restore(ctx, mark);
   if (fl) {
     static const bool dbg = getenv("SWG_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[swg] segment sort: a coarse bin denser than an LDS batch: the general sort takes the axis\n");
+    return SWG_OK;
+  }
+  if (view) {  // (the plan stays in the arena for the caller's streaming sweep: it restores its own mark)
+    view->valid = 1;
+    view->seg_a = P.seg_a;
+    view->seg_e = P.seg_e;
+    view->class_list = P.class_list;
+    view->counters = P.counters;
+    view->n_runs = n_runs;
+    for (int c = 0; c < 4; ++c) view->ncls[c] = P.ncls[c];
+    view->n_dead = n_dead;
+  }
+  *done = 1;
+  return SWG_OK;
+}
+
+// The k = 1 sweep of every segment over the begins swg_seg_sort_begins left sorted (seg_stream_body).  `keep` must be zero.
+// *done = 0: deep data (or a run of equal starts longer than a chunk) -- the caller goes on with the tile kernels over the same
+// arrays; `keep` then holds garbage.
+int swg_seg_stream_sweep_k1(swg_ctx* ctx, const swg_seg_plan_view& v, const uint64_t* S, const uint32_t* I, const uint32_t* E, const uint64_t* KEY,
+                            int pos_bits, double thr, const uint8_t* and_with, uint8_t* keep, uint64_t n, int* done) {
+  using namespace swg_seg;
+  *done = 0;
+  // Off unless SWG_SEG_STREAM=1 (read at every call).  Measured on 10^8 records, sweep flags (round 6, profiles/README.md): on
+  // segments of thousands of records the streamed sweep equals the routing + tile kernels it replaces (S-pan 13.4 against 13.6 ms,
+  // 100 genomes x 5 chromosomes 11.7 against 12.3), on segments of a few hundred it loses badly (100 x 20: 17.1 against 12.3 -- a
+  // work-group per segment again).  Exact either way (tests/test_gpu_segsweep.py).
+  const char* knob_s = getenv("SWG_SEG_STREAM");
+  const int knob = knob_s ? atoi(knob_s) : 0;  // (2: also where the context remembers deep data -- tests)
+  if (knob < 1 || !v.valid) return SWG_OK;
+  // deep data last time, on a call of about this size: the tile kernels' case (remembered like the sort's dropped bits)
+  if (knob != 2 && ctx->seg_sweep_deep_n && n >= ctx->seg_sweep_deep_n / 2 && n <= ctx->seg_sweep_deep_n * 2) return SWG_OK;
+  hipStream_t st = ctx->stream;
+  SegStreamArgs A{};
+  A.seg_a = v.seg_a; A.seg_e = v.seg_e; A.class_list = v.class_list; A.n_runs = v.n_runs;
+  for (int c = 0; c < 4; ++c) A.n_cls[c] = v.ncls[c];
+  A.S = S; A.I = I; A.E = E; A.KEY = KEY; A.n_dead = (uint32_t)v.n_dead; A.pos_mask = pos_bits >= 32 ? 0xffffffffu : (1u << pos_bits) - 1u; A.and_with = and_with; A.keep = keep; A.thr = thr; A.counters = v.counters;
+  const uint32_t n_big = v.ncls[1] + v.ncls[2] + v.ncls[3];
+  if (n_big) {
+    SWG_LAUNCH(ctx, "seg_stream", seg_stream_kernel<512, 4, 256><<<n_big, 512, 0, st>>>(A));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  if (v.ncls[0]) {
+    SWG_LAUNCH(ctx, "seg_stream_s", seg_stream_small_kernel<64, 16><<<v.ncls[0], 64, 0, st>>>(A));
+    SWG_KERNEL_CHECK(ctx);
+  }
+  uint32_t fl = 0;
+  {
+    SegPlan P{};
+    P.counters = v.counters;
+    SWG_TRY(seg_flags_read(ctx, P, &fl));
+  }
+  if (fl) {
+    ctx->seg_sweep_deep_n = n;
+    static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[swg] streaming segment sweep: deep data: the axis goes on to the tile kernels\n");
     return SWG_OK;
   }
   *done = 1;

@@ -1555,6 +1555,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint64_t *KEY = nullptr, *tile_x = nullptr, *tile_xf = nullptr;  // tile-start keys of the 256-begin / TBF-begin tilings
   uint32_t ntilesf = (uint32_t)((n + TBF - 1) / TBF);
   uint8_t* single = nullptr;
+  swg_seg_plan_view seg_view;  // k = 1 over the plan's runs: the segments of the sorted begins, for the streaming sweep
   auto sort_begins = [&]() -> int {
     S = swg_alloc<uint64_t>(ctx, n);
     I = swg_alloc<uint32_t>(ctx, n);
@@ -1573,7 +1574,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_CHECK_ARENA(ctx);
       SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
       int done = 0;
-      SWG_TRY(swg_seg_sort_begins(ctx, in, S, I, E2, KEY, tile_xf, ntilesf, single, &done));
+      SWG_TRY(swg_seg_sort_begins(ctx, in, S, I, E2, KEY, tile_xf, ntilesf, single, &done, k == 1 ? &seg_view : nullptr));
       if (done) {
         E = E2;
         SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
@@ -1733,6 +1734,17 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     }
   }
   if (!compact) SWG_TRY(sort_begins());
+  if (k == 1 && seg_view.valid && !compact) {
+    // the begins were sorted segment by segment: every segment's sweep streams through LDS (swg_seg_stream_sweep_k1) and answers
+    // into `keep`; on deep data it declines and the tile kernels below take the axis over the same arrays
+    SWG_HIP(ctx, hipMemsetAsync(keep, 0, n, st));
+    int swept = 0;
+    SWG_TRY(swg_seg_stream_sweep_k1(ctx, seg_view, S, I, E, KEY, in.pos_bits, thr, in.and_with, keep, n, &swept));
+    if (swept) {
+      swg_arena_restore(ctx, mark);
+      return SWG_OK;
+    }
+  }
   uint32_t* te = swg_alloc<uint32_t>(ctx, nbg);
   const size_t n_pad = ((size_t)n + 255) & ~size_t(255);  // keeps `ovl` 16-byte aligned for combine's vector loads
   uint8_t* flags = swg_alloc<uint8_t>(ctx, 2 * n_pad);  // top | ovl

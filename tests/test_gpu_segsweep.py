@@ -170,3 +170,35 @@ print("ok")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SWG_SEG_SWEEP="0"), capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_the_streamed_sweep_over_the_sorted_begins(sw):
+    """SWG_SEG_STREAM=1 (opt-in, csrc/swg_segsort.hip seg_stream_body): behind seg_sort, every segment's sorted begins stream
+    through LDS chunk by chunk with the intervals that reach further carried along -- sweep_batch, the code the fused kernel
+    runs -- instead of the carry-in routing and the tile kernels.  Segments of every size (one chunk, several chunks, the
+    longest class), dead records, all thresholds, the scaffold stage behind it; deep data goes on to the tile kernels over the
+    same arrays."""
+    os.environ["SWG_SEG_SWEEP"] = "0"
+    os.environ["SWG_SEG_STREAM"] = "2"      # (2: tried even where an earlier test left the context remembering deep data of this size)
+    try:
+        rng = np.random.default_rng(811)
+        rec = gen.random_records(rng, 150_000, n_genomes=2, chrs_per_genome=2, span=40_000_000, zero_frac=0.02, self_frac=0.0)   # ~37,000 per segment: many chunks
+        small = gen.random_records(rng, 40_000, n_genomes=3, chrs_per_genome=8, span=2_000_000, zero_frac=0.02)
+        small.qname = [x.replace("g", "s") for x in small.qname]
+        small.tname = [x.replace("g", "s") for x in small.tname]
+        both = orc.Records(rec.qname + small.qname, rec.tname + small.tname,
+                           *[np.concatenate([getattr(rec, c), getattr(small, c)]) for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
+                           np.arange(len(rec) + len(small), dtype=np.uint64))
+        both.qs = both.qs // 64 * 64
+        both.qe = np.maximum(both.qe, both.qs)
+        both = pair_major(both, rng)
+        for cfg in (dict(SWEEP, overlap_threshold=0.0), dict(SWEEP, overlap_threshold=0.95, min_identity=0.8, min_block_length=300), dict(SWEEP, overlap_threshold=1.0),
+                    {"mapping_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 2_000, "scaffold_max_deviation": 4_000}):
+            table = sweep_vs_oracle(sw, both, cfg)
+            assert names_of(table, "seg_stream") and names_of(table, "seg_sort") and not names_of(table, "sweep_tile") and not names_of(table, "route_"), sorted(table)
+        deep = pair_major(gen.random_records(rng, 70_000, n_genomes=2, chrs_per_genome=1, span=40_000, max_len=4_000, zero_frac=0.0, self_frac=0.0), rng)
+        table = sweep_vs_oracle(sw, deep, dict(SWEEP, overlap_threshold=0.9))
+        assert names_of(table, "seg_stream") and "sweep_tile_k1" in table, sorted(table)
+    finally:
+        os.environ["SWG_SEG_SWEEP"] = "1"
+        del os.environ["SWG_SEG_STREAM"]
