@@ -41,6 +41,8 @@ def short_name(name):
         base = "pair_number"          # the chain_N numbering over the pair table: one label in the library
     if base in ("seg_sort", "seg_sweep") and t:   # seg_sort_kernel<NT, ...> / seg_sweep_kernel<NT, ...> (the large class and the longest segments: *_big)
         base += {"64": "_s", "256": "_m"}.get(t[0], "")
+    if base == "seg_stream_small":
+        base = "seg_stream_s"
     if base in ("run_alive", "run_key"):
         base = "seg_" + base
     if base == "assign_numbers_runs":
