@@ -327,8 +327,10 @@ struct swg_seg_plan_view {
   uint32_t n_runs = 0, ncls[4] = {0, 0, 0, 0};
   uint64_t n_dead = 0;
 };
+// tile_flag (zero before, or nullptr): the sort settles the lone intervals itself -- single[record] = 1 for those that are kept --
+// and flags every other begin's sorted position for the tile kernels (SegSortArgs)
 int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
-                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view = nullptr);
+                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view = nullptr, uint8_t* tile_flag = nullptr);
 int swg_seg_stream_sweep_k1(swg_ctx* ctx, const swg_seg_plan_view& v, const uint64_t* S, const uint32_t* I, const uint32_t* E, const uint64_t* KEY,
                             int pos_bits, double thr, const uint8_t* and_with, uint8_t* keep, uint64_t n, int* done);
 int swg_seg_sweep_k1(swg_ctx* ctx, const swg_axis_input& in, double thr, uint8_t* keep, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY,

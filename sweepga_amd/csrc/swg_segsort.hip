@@ -185,26 +185,33 @@ struct SegSortArgs {
   uint64_t* tile_xf;
   uint8_t* single;
   uint32_t* counters;
+  // optional (finite k): the intervals that overlap no other interval of their segment are settled here -- they are in the top k
+  // wherever they are active and never overlapped (plane_sweep_exact.rs:197-352) -- and the ones that are never active
+  // (start >= end) as well; tile_flag[sorted position] = 1 for every OTHER begin, the ones the caller compacts for the tile
+  // kernels.  The kept lone ones are marked in `single` (the caller's combine keeps those whatever the tile kernels say).
+  uint8_t* tile_flag;
 };
 
 constexpr size_t lds_align_up(size_t off, size_t align) { return (off + align - 1) / align * align; }
 template <int NT, int ES, int ER, int NBK, int NBIN>
 constexpr size_t seg_sort_lds_bytes() {
-  return (size_t)NT * ES * 8 + (size_t)NBK * 4 + (size_t)NBIN * 4 + 17 * 4 + (size_t)(NT / 64 + 1) * 4 + 16 * 4 + 64;
+  return (size_t)NT * ES * 8 + (size_t)NBK * 4 + (size_t)NBIN * 4 + 17 * 4 + (size_t)(NT / 64 + 1) * 4 + 16 * 4 + (size_t)NT * 4 + 64;
 }
 
 // One work-group per segment of at most NT * ER live records, sorted in batches of at most NT * ES (one batch when they fit).
 // The scheme and its idioms are pair_sort_body's (swg_pair.hip): a thread OWNS the records tid, tid + NT, ... of the segment's
 // list, drops their keys into the batch's buckets, learns from the ranking where they ended up and puts their columns there.
-template <int NT, int ES, int ER, int NBK, int NBIN>
+template <int NT, int ES, int ER, int NBK, int NBIN, bool LONE>
 __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32_t sg, char* lds_raw) {
   constexpr int CAP = NT * ES, MAXB = 16, H = 8;
   static_assert(ER <= 32 && ER % H == 0 && ES % 4 == 0 && NT * ER <= 65536 && CAP < 0xffff, "record masks are 32 bits wide, indices and ranks 16");
   static_assert(NBIN >= 1 && NBIN <= 4096 && NBK % NT == 0, "bins, bucket counters per thread");
   constexpr size_t O_K = 0, O_I = O_K + (size_t)CAP * 4, O_RR = O_I + (size_t)CAP * 2, O_CNT = lds_align_up(O_RR + (size_t)CAP * 2, 4),
                    O_BINS = O_CNT + (size_t)NBK * 4, O_BLO = O_BINS + (size_t)NBIN * 4, O_WS = O_BLO + (size_t)(MAXB + 1) * 4,
-                   O_SH = O_WS + (size_t)(NT / 64 + 1) * 4;
-  static_assert(O_SH + 8 * 4 <= seg_sort_lds_bytes<NT, ES, ER, NBK, NBIN>(), "LDS block of the work-group");
+                   O_SH = O_WS + (size_t)(NT / 64 + 1) * 4, O_LONE = O_SH + 8 * 4;
+  static_assert(O_LONE + (size_t)NT * 4 <= seg_sort_lds_bytes<NT, ES, ER, NBK, NBIN>() && ES <= 16, "LDS block of the work-group");
+  uint16_t* const LBIT = reinterpret_cast<uint16_t*>(lds_raw + O_LONE);  // [NT] bit e: the thread's e-th consecutive position is a lone interval
+  uint16_t* const LKEEP = LBIT + NT;                                       // ... and kept (it is active somewhere)
   uint32_t* const K = reinterpret_cast<uint32_t*>(lds_raw + O_K);
   uint16_t* const I = reinterpret_cast<uint16_t*>(lds_raw + O_I);
   uint16_t* const RR = reinterpret_cast<uint16_t*>(lds_raw + O_RR);
@@ -260,7 +267,9 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
       for (int e = 0; e < H; ++e) {
         const uint32_t li = (uint32_t)tid + (uint32_t)(g + e) * NT;
         if (li >= m || !av[e]) continue;
-        if (n_live == 1u) A.single[ixv[e]] = 1;  // returned whole by the reference (plane_sweep_exact.rs:274-276)
+        if (n_live == 1u) {  // returned whole by the reference (plane_sweep_exact.rs:274-276)
+          A.single[ixv[e]] = 1;
+        }
         in_mask |= 1u << (g + e);
         kmin = qv[e] < kmin ? qv[e] : kmin;
         kmax = qv[e] > kmax ? qv[e] : kmax;
@@ -326,6 +335,7 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
     n_batches = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[2]);
   }
   uint32_t base = 0;
+  uint32_t carry_end = 0;  // (lone intervals) the largest end of the batches so far
   for (uint32_t bt = 0; bt < n_batches; ++bt) {
     {  // (see pair_sort_body: keeps the loads of every batch inside the loop)
       uint32_t m_l = m_v;
@@ -338,28 +348,42 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
     while ((((bin_hi - bin_lo) << 12) >> shift) > (uint32_t)NBK) ++shift;
     const uint32_t first = (bin_lo << 12) >> shift;
     for (int b = tid; b < NBK; b += NT) cnt[b] = 0;
+    if (tid == 0) sh[4] = 0xffffffffu;
     lds_barrier();
-    // ---- count
+    // ---- count (and, for the lone intervals, the first start of the batches behind this one)
     uint32_t batch_mask = 0;
+    {
+      uint32_t s_after = 0xffffffffu;
 #pragma unroll
-    for (int g = 0; g < ER; g += H) {
-      if ((uint32_t)g * NT >= m) continue;
-      uint32_t ixv[H], qv[H];
+      for (int g = 0; g < ER; g += H) {
+        if ((uint32_t)g * NT >= m) continue;
+        uint32_t ixv[H], qv[H];
 #pragma unroll
-      for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
+        for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
 #pragma unroll
-      for (int e = 0; e < H; ++e) qv[e] = A.start[ixv[e]];
+        for (int e = 0; e < H; ++e) qv[e] = A.start[ixv[e]];
 #pragma unroll
-      for (int e = 0; e < H; ++e)
-        if ((in_mask >> (g + e)) & 1u) {
-          uint32_t cb;
-          const uint32_t fb = fine_of(qv[e], shift, first, &cb);
-          if (cb >= bin_lo && cb < bin_hi) {
-            batch_mask |= 1u << (g + e);
-            atomicAdd(&cnt[fb], 1u);
+        for (int e = 0; e < H; ++e)
+          if ((in_mask >> (g + e)) & 1u) {
+            uint32_t cb;
+            const uint32_t fb = fine_of(qv[e], shift, first, &cb);
+            if (cb >= bin_lo && cb < bin_hi) {
+              batch_mask |= 1u << (g + e);
+              atomicAdd(&cnt[fb], 1u);
+            } else if (LONE && cb >= bin_hi) {
+              s_after = qv[e] < s_after ? qv[e] : s_after;
+            }
           }
+        asm volatile("" ::: "memory");
+      }
+      if (LONE && bt + 1 < n_batches) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t x = __shfl_xor(s_after, o, 64);
+          s_after = x < s_after ? x : s_after;
         }
-      asm volatile("" ::: "memory");
+        if ((tid & 63) == 0 && s_after != 0xffffffffu) atomicMin(&sh[4], s_after);
+      }
     }
     lds_barrier();
     const uint32_t mb = swg_lds::bucket_offsets<NT, NBK>(cnt, ws);
@@ -395,18 +419,8 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
       uint32_t cb;
       return fine_of(key, shift, first, &cb);
     });
-    // ---- the composite starts out; where the thread's own records went
+    // ---- where the thread's own records went
     const uint32_t gbase = A.n_dead + A.out_a[sg] + base;
-    const uint32_t t_out = fresh_tid();
-#pragma unroll
-    for (int e = 0; e < ES; ++e) {
-      const uint32_t p = t_out + (uint32_t)e * NT;
-      if (p < mb) {
-        const uint64_t s = seg_part | K[p];
-        A.S[gbase + p] = s;
-        if (((gbase + p) % TBF) == 0u) A.tile_xf[(gbase + p) / TBF] = s;
-      }
-    }
     swg_lds::slots_to_ranks<ER>(slotw, batch_mask, RR);
     lds_barrier();
     // ---- the other columns, transposed through LDS
@@ -415,6 +429,119 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
       for (int e = 0; e < H; ++e)
         if ((batch_mask >> (g + e)) & 1u) buf[(slotw[(g + e) / 2] >> (16 * ((g + e) & 1))) & 0xffffu] = v[e];
     };
+    if constexpr (LONE) {
+    // the ends, into the room of I and RR (both done with) while K still holds the sorted starts
+    {
+      tid_v = fresh_tid();
+#pragma unroll
+      for (int g = 0; g < ER; g += H) {
+        if ((uint32_t)g * NT >= m) continue;
+        uint32_t ixv[H], v[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
+#pragma unroll
+        for (int e = 0; e < H; ++e) v[e] = A.end[ixv[e]];
+        put_group(g, v, B2);
+        asm volatile("" ::: "memory");
+      }
+      lds_barrier();
+    }
+    {
+      // the lone intervals of the batch: no earlier interval of the segment reaches the start (the running maximum of the ends in
+      // front of it, the batches so far included), no later one begins before the end (the next position's start; behind the
+      // batch's last position the first start of the batches to come).  A thread takes ES consecutive positions.
+      const uint32_t q0 = fresh_tid() * ES;
+      const uint32_t s_after = bt + 1 < n_batches ? sh[4] : 0xffffffffu;
+      uint32_t ks[ES + 1], es[ES], tmax = 0;
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        ks[e] = q0 + e < mb ? K[q0 + e] : 0xffffffffu;
+        es[e] = q0 + e < mb ? B2[q0 + e] : 0u;
+      }
+      ks[ES] = q0 + ES < mb ? K[q0 + ES] : s_after;
+#pragma unroll
+      for (int e = 0; e < ES; ++e)
+        if (q0 + e < mb && es[e] > ks[e] && es[e] > tmax) tmax = es[e];
+      uint32_t before = swg_lds::block_excl_max_u32<NT>(tmax, ws);
+      before = before > carry_end ? before : carry_end;
+      uint32_t lone = 0, lkeep = 0;
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        if (q0 + e >= mb) continue;
+        const bool active = es[e] > ks[e];
+        const uint32_t next = q0 + e + 1 < mb ? ks[e + 1] : s_after;
+        const bool alone = before <= ks[e] && next >= es[e];
+        if (!active || alone) lone |= 1u << e;
+        if (active && alone) lkeep |= 1u << e;
+        if (active && es[e] > before) before = es[e];
+      }
+      LBIT[tid] = (uint16_t)lone;
+      LKEEP[tid] = (uint16_t)lkeep;
+      // (the batches so far: the largest end of all -- every thread ends with the batch's through the last thread's `before`)
+      lds_barrier();
+      if (tid == NT - 1) ws[NT / 64] = before;
+      lds_barrier();
+      {
+        const uint32_t all = ws[NT / 64];
+        // (the last thread holds positions beyond mb when the batch is short: its `before` is still the batch's maximum, the
+        // running maximum in front of them)
+        carry_end = all > carry_end ? all : carry_end;
+      }
+    }
+    // ---- the composite starts out (and which of them go on to the tile kernels)
+    const uint32_t t_out = fresh_tid();
+#pragma unroll
+    for (int e = 0; e < ES; ++e) {
+      const uint32_t p = t_out + (uint32_t)e * NT;
+      if (p < mb) {
+        const uint64_t s = seg_part | K[p];
+        A.S[gbase + p] = s;
+        if (((gbase + p) % TBF) == 0u) A.tile_xf[(gbase + p) / TBF] = s;
+        A.tile_flag[gbase + p] = ((LBIT[p / ES] >> (p % ES)) & 1u) ? 0 : 1;
+      }
+    }
+    lds_barrier();
+    // the record indices (K is free now)
+    {
+      tid_v = fresh_tid();
+#pragma unroll
+      for (int g = 0; g < ER; g += H) {
+        if ((uint32_t)g * NT >= m) continue;
+        uint32_t ixv[H];
+#pragma unroll
+        for (int e = 0; e < H; ++e) ixv[e] = rec_index(g + e);
+        put_group(g, ixv, K);
+        asm volatile("" ::: "memory");
+      }
+      lds_barrier();
+      const uint32_t t_st = fresh_tid();
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t p = t_st + (uint32_t)e * NT;
+        if (p < mb) {
+          const uint32_t ix = K[p];
+          A.I[gbase + p] = ix;
+          A.E[gbase + p] = B2[p];
+          if ((LKEEP[p / ES] >> (p % ES)) & 1u) A.single[ix] = 1;  // (kept whatever the tile kernels say: combine)
+        }
+      }
+      lds_barrier();
+    }
+    } else {
+    // ---- the composite starts out
+    {
+      const uint32_t t_out = fresh_tid();
+#pragma unroll
+      for (int e = 0; e < ES; ++e) {
+        const uint32_t p = t_out + (uint32_t)e * NT;
+        if (p < mb) {
+          const uint64_t s = seg_part | K[p];
+          A.S[gbase + p] = s;
+          if (((gbase + p) % TBF) == 0u) A.tile_xf[(gbase + p) / TBF] = s;
+        }
+      }
+      lds_barrier();
+    }
     // the record indices and the ends (two buffers: K, and the room of I and RR, both done with)
     {
       tid_v = fresh_tid();
@@ -441,6 +568,7 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
         }
       }
       lds_barrier();
+    }
     }
     // the score keys (8 bytes: the two halves through two buffers)
     {
@@ -473,10 +601,10 @@ __device__ __forceinline__ void seg_sort_body(const SegSortArgs& A, const uint32
     lds_barrier();
   }
 }
-template <int NT, int ES, int ER, int NBK, int NBIN>
+template <int NT, int ES, int ER, int NBK, int NBIN, bool LONE>
 __global__ __launch_bounds__(NT) void seg_sort_kernel(SegSortArgs A) {
   __shared__ __attribute__((aligned(16))) char raw[seg_sort_lds_bytes<NT, ES, ER, NBK, NBIN>()];
-  seg_sort_body<NT, ES, ER, NBK, NBIN>(A, A.list[blockIdx.x], raw);
+  seg_sort_body<NT, ES, ER, NBK, NBIN, LONE>(A, A.list[blockIdx.x], raw);
 }
 
 // Segments beyond SEG_L_MAX places: key-range batches of at most XCAP (coarse bins glued greedily), every batch picked out of
@@ -611,8 +739,12 @@ __device__ __forceinline__ void seg_sort_xl_body(const SegSortArgs& A, const uin
       A.I[gbase + p] = id;
       A.E[gbase + p] = A.end[id];
       A.KEY[gbase + p] = A.score[id];
+      if (A.tile_flag) A.tile_flag[gbase + p] = 1;  // (the longest segments: not looked at for lone intervals)
       if (((gbase + p) % TBF) == 0u) A.tile_xf[(gbase + p) / TBF] = s;
-      if (n_live == 1u) A.single[id] = 1;  // (a long run with one live record) returned whole by the reference
+      if (n_live == 1u) {  // (a long run with one live record) returned whole by the reference
+        A.single[id] = 1;
+        if (A.tile_flag) A.tile_flag[gbase + p] = 0;
+      }
     }
     __syncthreads();
     base += mb;
@@ -621,12 +753,13 @@ __device__ __forceinline__ void seg_sort_xl_body(const SegSortArgs& A, const uin
 }
 constexpr size_t SEG_BIG_LDS = seg_sort_lds_bytes<1024, 16, 32, 4096, 1024>() > SEG_XL_LDS ? seg_sort_lds_bytes<1024, 16, 32, 4096, 1024>() : SEG_XL_LDS;
 static_assert(SEG_BIG_LDS <= 160 * 1024, "LDS of a CU");
+template <bool LONE>
 __global__ __launch_bounds__(1024) void seg_sort_big_kernel(SegSortArgs A, const uint32_t* __restrict__ list_xl, uint32_t n_xl) {
   __shared__ __attribute__((aligned(16))) char raw[SEG_BIG_LDS];
   if (blockIdx.x < n_xl)
     seg_sort_xl_body(A, list_xl[blockIdx.x], raw);
   else
-    seg_sort_body<1024, 16, 32, 4096, 1024>(A, A.list[blockIdx.x - n_xl], raw);
+    seg_sort_body<1024, 16, 32, 4096, 1024, LONE>(A, A.list[blockIdx.x - n_xl], raw);
 }
 
 
@@ -1516,7 +1649,7 @@ int seg_flags_read(swg_ctx* ctx, const SegPlan& P, uint32_t* flags) {
 // The axis' sorted begins from the runs of a pair-grouped input.  *done = 0: not applicable here, or a segment too dense for
 // the LDS batches -- the caller sorts the general way (nothing it cannot overwrite was written).
 int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uint32_t* I, uint32_t* E, uint64_t* KEY, uint64_t* tile_xf,
-                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view) {
+                        uint32_t ntilesf, uint8_t* single, int* done, swg_seg_plan_view* view, uint8_t* tile_flag) {
   using namespace swg_seg;
   *done = 0;
   if (view) *view = swg_seg_plan_view{};
@@ -1549,19 +1682,29 @@ int swg_seg_sort_begins(swg_ctx* ctx, const swg_axis_input& in, uint64_t* S, uin
   A.out_a = P.seg_a;
   A.pos_bits = in.pos_bits; A.n_dead = (uint32_t)n_dead; A.S = S; A.I = I; A.E = E; A.KEY = KEY; A.tile_xf = tile_xf; A.single = single;
   A.counters = P.counters;
+  A.tile_flag = tile_flag;  // (zero before -- the dead records' places stay so)
   if (P.ncls[2] + P.ncls[3]) {  // (the longest segments first in the same launch)
     A.list = P.class_list + (size_t)2 * n_runs;
-    SWG_LAUNCH(ctx, "seg_sort_big", seg_sort_big_kernel<<<P.ncls[2] + P.ncls[3], 1024, 0, st>>>(A, P.class_list + (size_t)3 * n_runs, P.ncls[3]));
+    if (tile_flag)
+      SWG_LAUNCH(ctx, "seg_sort_big", seg_sort_big_kernel<true><<<P.ncls[2] + P.ncls[3], 1024, 0, st>>>(A, P.class_list + (size_t)3 * n_runs, P.ncls[3]));
+    else
+      SWG_LAUNCH(ctx, "seg_sort_big", seg_sort_big_kernel<false><<<P.ncls[2] + P.ncls[3], 1024, 0, st>>>(A, P.class_list + (size_t)3 * n_runs, P.ncls[3]));
     SWG_KERNEL_CHECK(ctx);
   }
   if (P.ncls[1]) {
     A.list = P.class_list + (size_t)1 * n_runs;
-    SWG_LAUNCH(ctx, "seg_sort_m", seg_sort_kernel<256, 16, 16, 1024, 64><<<P.ncls[1], 256, 0, st>>>(A));
+    if (tile_flag)
+      SWG_LAUNCH(ctx, "seg_sort_m", seg_sort_kernel<256, 16, 16, 1024, 64, true><<<P.ncls[1], 256, 0, st>>>(A));
+    else
+      SWG_LAUNCH(ctx, "seg_sort_m", seg_sort_kernel<256, 16, 16, 1024, 64, false><<<P.ncls[1], 256, 0, st>>>(A));
     SWG_KERNEL_CHECK(ctx);
   }
   if (P.ncls[0]) {
     A.list = P.class_list;
-    SWG_LAUNCH(ctx, "seg_sort_s", seg_sort_kernel<64, 16, 16, 256, 64><<<P.ncls[0], 64, 0, st>>>(A));
+    if (tile_flag)
+      SWG_LAUNCH(ctx, "seg_sort_s", seg_sort_kernel<64, 16, 16, 256, 64, true><<<P.ncls[0], 64, 0, st>>>(A));
+    else
+      SWG_LAUNCH(ctx, "seg_sort_s", seg_sort_kernel<64, 16, 16, 256, 64, false><<<P.ncls[0], 64, 0, st>>>(A));
     SWG_KERNEL_CHECK(ctx);
   }
   // the dense-bin flag: read with the caller's next read-back would be cheaper, but the caller must know before it routes

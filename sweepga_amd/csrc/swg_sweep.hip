@@ -1475,6 +1475,19 @@ __global__ __launch_bounds__(EW_THREADS) void combine_kernel(uint64_t n, const u
   }
 }
 
+// the begins at the listed sorted positions, side by side again
+__global__ __launch_bounds__(EW_THREADS) void begin_compact_kernel(uint64_t m, const uint32_t* __restrict__ list, const uint64_t* __restrict__ S,
+                                                                   const uint32_t* __restrict__ I, const uint32_t* __restrict__ E,
+                                                                   const uint64_t* __restrict__ KEY, uint64_t* __restrict__ S2,
+                                                                   uint32_t* __restrict__ I2, uint32_t* __restrict__ E2, uint64_t* __restrict__ KEY2) {
+  const uint64_t j = (uint64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t p = list[j];
+  S2[j] = S[p];
+  I2[j] = I[p];
+  E2[j] = E[p];
+  KEY2[j] = KEY[p];
+}
 // the same over the begins of a compact list (the segment-resident sweep answered every other record): an interval of a segment
 // of more than one live record is kept iff it was the top somewhere and never overlapped one
 __global__ __launch_bounds__(EW_THREADS) void combine_begins_kernel(uint64_t nb, const uint32_t* __restrict__ I, const uint8_t* __restrict__ top,
@@ -1556,6 +1569,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   uint32_t ntilesf = (uint32_t)((n + TBF - 1) / TBF);
   uint8_t* single = nullptr;
   swg_seg_plan_view seg_view;  // k = 1 over the plan's runs: the segments of the sorted begins, for the streaming sweep
+  uint8_t* tile_flag = nullptr;  // the segment sorts settled the lone intervals: the sorted positions that still need the tile kernels
   auto sort_begins = [&]() -> int {
     S = swg_alloc<uint64_t>(ctx, n);
     I = swg_alloc<uint32_t>(ctx, n);
@@ -1573,8 +1587,21 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       uint32_t* E2 = swg_alloc<uint32_t>(ctx, n);
       SWG_CHECK_ARENA(ctx);
       SWG_HIP(ctx, hipMemsetAsync(single, 0, n, st));
+      // SWG_SEG_LONE=1 (opt-in, read at every call), finite k: the sort also settles the intervals that overlap nobody in their
+      // segment -- they are kept whatever k is -- and only the others are compacted for the routing and the tile kernels.
+      // Measured on S-pan (round 6, profiles/README.md): 56 % of the begins are settled that way and the tile kernel's time falls
+      // from 5.6 to 3.2 ms, but the classification inside the sort (+1.2 ms) and the compaction (+1.7 ms) take it back: 13.8
+      // against 13.6 ms.  Exact either way (tests/test_gpu_segsweep.py).
+      const char* lone_s = getenv("SWG_SEG_LONE");
+      const char* stream_s = getenv("SWG_SEG_STREAM");
+      if (k != SWG_K_INF && lone_s && atoi(lone_s) == 1 && !(stream_s && atoi(stream_s) >= 1)) {
+        tile_flag = swg_alloc<uint8_t>(ctx, n);
+        SWG_CHECK_ARENA(ctx);
+        SWG_HIP(ctx, hipMemsetAsync(tile_flag, 0, n, st));
+      }
       int done = 0;
-      SWG_TRY(swg_seg_sort_begins(ctx, in, S, I, E2, KEY, tile_xf, ntilesf, single, &done, k == 1 ? &seg_view : nullptr));
+      SWG_TRY(swg_seg_sort_begins(ctx, in, S, I, E2, KEY, tile_xf, ntilesf, single, &done, k == 1 ? &seg_view : nullptr, tile_flag));
+      if (!done) tile_flag = nullptr;
       if (done) {
         E = E2;
         SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
@@ -1700,6 +1727,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
   // (swg_seg_sweep_k1) and answers into `keep`; what is left for the kernels below are the begins of the longest segments.
   uint64_t nbg = n;      // begins in S / I / E / KEY
   bool compact = false;  // ... those of the longest segments only, nothing in front of them
+  bool lone_mode = false;  // ... those that overlap another interval of their segment (the others are settled: `single`)
   if (k == 1 && in.seg_runs && !in.sorted_idx_out) {
     S = swg_alloc<uint64_t>(ctx, n);
     I = swg_alloc<uint32_t>(ctx, n);
@@ -1734,6 +1762,54 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     }
   }
   if (!compact) SWG_TRY(sort_begins());
+  if (tile_flag && !compact) {
+    // the begins that overlap another interval of their segment, compacted (order kept): all the routing and the tile kernels see
+    swg_flag_scan fs;
+    uint64_t* d_left = swg_alloc<uint64_t>(ctx, 1);
+    SWG_CHECK_ARENA(ctx);
+    SWG_HIP(ctx, hipMemsetAsync(d_left, 0, sizeof(uint64_t), st));
+    SWG_TRY(swg_flags_count(ctx, tile_flag, n, &fs, d_left));
+    uint64_t left = 0;
+    SWG_TRY(swg_read_scalars(ctx, d_left, &left, 1));
+    static const bool dbg = getenv("SWG_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[swg] sweep: %llu of %llu begins overlap another interval of their segment and go to the tile kernels\n", (unsigned long long)left, (unsigned long long)n);
+    lone_mode = true;  // (the kept lone intervals are in `single`: the full combine below merges them with the tile kernels' flags)
+    uint32_t* list = swg_alloc<uint32_t>(ctx, left + 1);
+    uint64_t* S2 = swg_alloc<uint64_t>(ctx, left);
+    uint32_t* I2 = swg_alloc<uint32_t>(ctx, left);
+    uint32_t* E3 = swg_alloc<uint32_t>(ctx, left);
+    uint64_t* KEY2 = swg_alloc<uint64_t>(ctx, left);
+    SWG_CHECK_ARENA(ctx);
+    if (left == 0) {  // nothing overlaps anything: the kept records are exactly the marked ones
+      const size_t n_pad0 = ((size_t)n + 255) & ~size_t(255);
+      uint8_t* zero = swg_alloc<uint8_t>(ctx, 2 * n_pad0);
+      SWG_CHECK_ARENA(ctx);
+      SWG_HIP(ctx, hipMemsetAsync(zero, 0, 2 * n_pad0, st));
+      const uintptr_t ptrs0 = reinterpret_cast<uintptr_t>(in.alive) | reinterpret_cast<uintptr_t>(single) | reinterpret_cast<uintptr_t>(zero) |
+                              reinterpret_cast<uintptr_t>(in.and_with) | reinterpret_cast<uintptr_t>(keep);
+      SWG_LAUNCH(ctx, "combine", combine_kernel<<<blocks_for((n + 15) / 16, EW_THREADS), EW_THREADS, 0, st>>>(n, in.alive, single, zero, zero + n_pad0, in.and_with,
+                                                                                                   keep, (ptrs0 & 15) == 0));
+      SWG_KERNEL_CHECK(ctx);
+      swg_arena_restore(ctx, mark);
+      return SWG_OK;
+    }
+    SWG_TRY(swg_flags_compact(ctx, fs, list));
+    SWG_LAUNCH(ctx, "begin_compact", begin_compact_kernel<<<blocks_for(left, EW_THREADS), EW_THREADS, 0, st>>>(left, list, S, I, E, KEY, S2, I2, E3, KEY2));
+    SWG_KERNEL_CHECK(ctx);
+    S = S2;
+    I = I2;
+    E = E3;
+    KEY = KEY2;
+    nbg = left;
+    compact = true;
+    seg_view.valid = 0;  // (the streaming sweep reads the segments' own stretches: not these)
+    ntiles = (uint32_t)((nbg + TB - 1) / TB);
+    ntilesf = (uint32_t)((nbg + TBF - 1) / TBF);
+    SWG_LAUNCH(ctx, "tile_x_stride", tile_x_stride_kernel<<<blocks_for(ntilesf, EW_THREADS), EW_THREADS, 0, st>>>(ntilesf, S, TBF, tile_xf));
+    SWG_KERNEL_CHECK(ctx);
+    SWG_LAUNCH(ctx, "tile_x_pairs", tile_x_pairs_kernel<<<blocks_for(ntiles, EW_THREADS), EW_THREADS, 0, st>>>(ntiles, tile_xf, tile_x, TB / TBF));
+    SWG_KERNEL_CHECK(ctx);
+  }
   if (k == 1 && seg_view.valid && !compact) {
     // the begins were sorted segment by segment: every segment's sweep streams through LDS (swg_seg_stream_sweep_k1) and answers
     // into `keep`; on deep data it declines and the tile kernels below take the axis over the same arrays
@@ -1875,7 +1951,7 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
     SWG_LAUNCH(ctx, "sweep_tile_kn", sweep_tile_kn_kernel<<<ntiles, TB, 0, st>>>(ta));
   }
   SWG_KERNEL_CHECK(ctx);
-  if (compact) {  // (the other records' answers are in `keep` already)
+  if (compact && !lone_mode) {  // (the other records' answers are in `keep` already)
     SWG_LAUNCH(ctx, "combine_begins", combine_begins_kernel<<<blocks_for(nbg, EW_THREADS), EW_THREADS, 0, st>>>(nbg, I, top, ovl, in.and_with, keep));
   } else {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(in.alive) | reinterpret_cast<uintptr_t>(single) | reinterpret_cast<uintptr_t>(top) |

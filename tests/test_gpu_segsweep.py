@@ -202,3 +202,40 @@ def test_the_streamed_sweep_over_the_sorted_begins(sw):
     finally:
         os.environ["SWG_SEG_SWEEP"] = "1"
         del os.environ["SWG_SEG_STREAM"]
+
+
+def test_lone_intervals_settled_inside_the_segment_sort(sw):
+    """SWG_SEG_LONE=1 (opt-in): while a segment's sorted starts and ends are in LDS, seg_sort marks the intervals that overlap no
+    other interval of their segment -- kept whatever the limit is -- and only the others are compacted for the routing and the
+    tile kernels.  k = 1 and k = 2 / 3, every threshold kind, dead and zero-length records, segments of one record, segments of
+    several batches and the longest class; an input where nothing overlaps (no tile kernel at all)."""
+    os.environ["SWG_SEG_SWEEP"] = "0"
+    os.environ["SWG_SEG_LONE"] = "1"
+    try:
+        rng = np.random.default_rng(812)
+        rec = gen.random_records(rng, 150_000, n_genomes=2, chrs_per_genome=2, span=40_000_000, zero_frac=0.02, self_frac=0.0)
+        small = gen.random_records(rng, 40_000, n_genomes=3, chrs_per_genome=8, span=2_000_000, zero_frac=0.02)
+        small.qname = [x.replace("g", "s") for x in small.qname]
+        small.tname = [x.replace("g", "s") for x in small.tname]
+        one = gen.random_records(rng, 300, n_genomes=1, chrs_per_genome=1, span=1_000_000, zero_frac=0.3, self_frac=0.0)   # segments of ONE record
+        one.qname = [f"o{i}#1#c" for i in range(len(one))]
+        one.tname = [f"p{i}#1#c" for i in range(len(one))]
+        parts = (rec, small, one)
+        both = orc.Records(sum((r.qname for r in parts), []), sum((r.tname for r in parts), []),
+                           *[np.concatenate([getattr(r, c) for r in parts]) for c in ("qs", "qe", "ts", "te", "block_length", "identity", "matches", "strand")],
+                           np.arange(sum(len(r) for r in parts), dtype=np.uint64))
+        both.qs = both.qs // 64 * 64
+        both.qe = np.maximum(both.qe, both.qs)
+        both = pair_major(both, rng)
+        for cfg in (dict(SWEEP, overlap_threshold=0.0), dict(SWEEP, overlap_threshold=0.95, min_identity=0.8, min_block_length=300), dict(SWEEP, overlap_threshold=1.0),
+                    {"mapping_filter_mode": "OneToMany", "mapping_max_per_query": 2, "mapping_max_per_target": 3, "scaffold_gap": 0, "overlap_threshold": 0.5},
+                    {"mapping_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 2_000, "scaffold_max_deviation": 4_000}):
+            table = sweep_vs_oracle(sw, both, cfg)
+            assert "begin_compact" in table and names_of(table, "seg_sort"), sorted(table)
+        # nothing overlaps anything: every interval is settled by the sort
+        sparse = pair_major(gen.random_records(rng, 70_000, n_genomes=2, chrs_per_genome=1, span=2_000_000_000, max_len=300, zero_frac=0.01, self_frac=0.0, syntenic_frac=0.0), rng)
+        table = sweep_vs_oracle(sw, sparse, dict(SWEEP))
+        assert names_of(table, "seg_sort"), sorted(table)
+    finally:
+        os.environ["SWG_SEG_SWEEP"] = "1"
+        del os.environ["SWG_SEG_LONE"]
