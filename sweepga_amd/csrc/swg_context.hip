@@ -249,6 +249,9 @@ void swg_destroy(swg_ctx* ctx) {
   if (ctx->io_block) (void)hipFree(ctx->io_block);
   std::free(ctx->narrow_host);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->ring) (void)hipHostFree(ctx->ring);
+  for (auto& e : ctx->ring_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (auto& p : ctx->prof_pending_list) {

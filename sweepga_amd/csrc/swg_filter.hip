@@ -12,6 +12,7 @@
 #include "swg_pipeline.h"
 #include "swg_scaffold_internal.h"
 #include "host/rebase.h"
+#include "host/threads.h"
 
 namespace {
 
@@ -734,6 +735,171 @@ extern "C" int swg_filter(swg_ctx* ctx, const swg_records* rec, const swg_config
     if (hipStreamSynchronize(st) != hipSuccess && rc == SWG_OK)
       rc = swg_set_error(ctx, SWG_ERR_HIP, "stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
     if (rc == SWG_OK) (void)hipEventElapsedTime(&d2h, e0, e1);
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  if (stats && rc == SWG_OK) {
+    *stats = local;
+    stats->h2d_ms = h2d;
+    stats->d2h_ms = d2h;
+  }
+  return rc;
+}
+
+// ---- a shard of swg_filter_multi picked out of the caller's columns ("hipMemcpyAsync from pinned memory on per-
+// device streams") ---------------------------------------------------------------------------------------------------------------
+// The shard's records are idx[0 .. m) of the caller's host columns, ascending.  Round 2-5 copied them into pageable columns of
+// their own first (host/shard_host.h scatter: ~50 fresh bytes per record, 0.41 s of page faults per 10^8 records) and uploaded
+// those.  Here host threads gather chunk after chunk into the slots of a small pinned ring that stays with the context, every
+// slot goes to the device on the copy stream as soon as it is full (only the columns the flag set reads), and a slot is
+// gathered into again when its copy is through -- the gathering of chunk c + 1 runs beside the copy of chunk c.
+namespace {
+constexpr int RING_SLOTS = 3;
+constexpr uint64_t RING_CHUNK_MAX = uint64_t(1) << 20;  // records per slot
+inline uint64_t ring_chunk() {  // SWG_RING_CHUNK (test knob): fewer records per slot, so that a small input wraps around the ring
+  static const uint64_t v = [] {
+    const char* e = getenv("SWG_RING_CHUNK");
+    const long long x = e ? atoll(e) : 0;
+    return x >= 256 && (uint64_t)x < RING_CHUNK_MAX ? (uint64_t)x : RING_CHUNK_MAX;
+  }();
+  return v;
+}
+}
+int swg_filter_gathered(swg_ctx* ctx, const swg_records* rec, const uint32_t* idx, uint64_t m, const swg_config* cfg, uint8_t* status_sub,
+                        uint32_t* chain_sub, swg_stats* stats, int threads) {
+  SWG_TRY(validate(ctx, rec, cfg));
+  if (m == 0) {
+    if (stats) *stats = swg_stats{};
+    return SWG_OK;
+  }
+  if (m >= (uint64_t(1) << 31)) return swg_set_error(ctx, SWG_ERR_RANGE, "more than 2^31-1 records in a shard");
+  SWG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (!ctx->copy_stream) SWG_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  hipStream_t cs = ctx->copy_stream;
+  const uint64_t RING_CHUNK = ring_chunk();
+  const size_t slot_bytes = (size_t)RING_CHUNK_MAX * (8 * 4 + 8 + 1);
+  if (!ctx->ring) {
+    void* hp = nullptr;
+    SWG_HIP(ctx, hipHostMalloc(&hp, slot_bytes * RING_SLOTS, hipHostMallocDefault));
+    ctx->ring = static_cast<char*>(hp);
+    ctx->ring_slot_bytes = slot_bytes;
+    for (int k = 0; k < RING_SLOTS; ++k) SWG_HIP(ctx, hipEventCreateWithFlags(&ctx->ring_ev[k], hipEventDisableTiming));
+  }
+  const bool scaffold = cfg->scaffold_gap != 0;
+  const bool derived_identity = rec->identity == nullptr;
+  bool id_value, wid_value;
+  swg_value_columns_needed(cfg, &id_value, &wid_value);
+  const bool send_identity = !derived_identity;
+  const bool send_mb = wid_value || (derived_identity && id_value);
+  const bool send_block = send_mb || cfg->min_block_length != 0;
+  // the device block: swg_filter's layout
+  const size_t col4 = ((m * 4 + 255) & ~size_t(255)), col8 = ((m * 8 + 255) & ~size_t(255)), col1 = ((m + 255) & ~size_t(255)),
+               seqt = (((size_t)rec->n_seq * 4 + 255) & ~size_t(255));
+  SWG_TRY(io_block_reserve(ctx, io_block_bytes(m, rec->n_seq)));
+  char* blk = ctx->io_block;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = blk + off;
+    off += bytes;
+    return p;
+  };
+  char* d_col[10];  // q_id, t_id, q_start, q_end, t_start, t_end, matches, block_len (4 bytes), identity (8), strand (1)
+  for (int c = 0; c < 8; ++c) d_col[c] = take(col4);
+  d_col[8] = take(col8);
+  d_col[9] = take(col1);
+  char* d_gl = take(seqt);
+  char* d_g2 = take(seqt);
+  uint8_t* d_status = (uint8_t*)take(col1);
+  uint32_t* d_chain = (uint32_t*)take(col4);
+  const void* h_col[10] = {rec->q_id, rec->t_id, rec->q_start, rec->q_end, rec->t_start, rec->t_end, rec->matches, rec->block_len, rec->identity, rec->strand};
+  const bool need[10] = {true, true, true, true, true, true, send_mb, send_block, send_identity, scaffold};
+  static const bool poison = getenv("SWG_POISON") != nullptr;
+  if (poison)
+    for (int c = 6; c < 10; ++c)
+      if (!need[c]) SWG_HIP(ctx, hipMemsetAsync(d_col[c], 0xff, c == 8 ? col8 : (c == 9 ? col1 : col4), cs));
+  SWG_HIP(ctx, hipMemcpyAsync(d_gl, rec->seq_genome_last, (size_t)rec->n_seq * 4, hipMemcpyHostToDevice, cs));
+  SWG_HIP(ctx, hipMemcpyAsync(d_g2, rec->seq_genome_two, (size_t)rec->n_seq * 4, hipMemcpyHostToDevice, cs));
+  if (threads < 1) threads = 1;
+  (void)hipEventRecord(ctx->ev0, cs);
+  int rc = SWG_OK;
+  const uint64_t n_chunks = (m + RING_CHUNK - 1) / RING_CHUNK;
+  for (uint64_t ch = 0; ch < n_chunks && rc == SWG_OK; ++ch) {
+    const int k = (int)(ch % RING_SLOTS);
+    const uint64_t c0 = ch * RING_CHUNK, cnt = m - c0 < RING_CHUNK ? m - c0 : RING_CHUNK;
+    if (ch >= (uint64_t)RING_SLOTS && hipEventSynchronize(ctx->ring_ev[k]) != hipSuccess) {  // the slot's last copy is through
+      rc = swg_set_error(ctx, SWG_ERR_HIP, "waiting for a staging slot failed");
+      break;
+    }
+    char* slot = ctx->ring + (size_t)k * slot_bytes;
+    // the slot's columns side by side: RING_CHUNK * {4 x 8, 8, 1}
+    char* s_col[10];
+    for (int c = 0; c < 8; ++c) s_col[c] = slot + (size_t)c * RING_CHUNK * 4;
+    s_col[8] = slot + (size_t)8 * RING_CHUNK * 4;
+    s_col[9] = s_col[8] + (size_t)RING_CHUNK * 8;
+    try {
+      const int tt = (uint64_t)threads > cnt / 16384 + 1 ? (int)(cnt / 16384 + 1) : threads;
+      swg_host::run(tt, [&](int t) {
+        const uint64_t b = cnt * (uint64_t)t / tt, e = cnt * (uint64_t)(t + 1) / tt;
+        const uint32_t* ix = idx + c0;
+        for (int c = 0; c < 8; ++c) {
+          if (!need[c]) continue;
+          const uint32_t* src = static_cast<const uint32_t*>(h_col[c]);
+          uint32_t* dst = reinterpret_cast<uint32_t*>(s_col[c]);
+          for (uint64_t j = b; j < e; ++j) dst[j] = src[ix[j]];
+        }
+        if (need[8]) {
+          const double* src = static_cast<const double*>(h_col[8]);
+          double* dst = reinterpret_cast<double*>(s_col[8]);
+          for (uint64_t j = b; j < e; ++j) dst[j] = src[ix[j]];
+        }
+        if (need[9]) {
+          const uint8_t* src = static_cast<const uint8_t*>(h_col[9]);
+          uint8_t* dst = reinterpret_cast<uint8_t*>(s_col[9]);
+          for (uint64_t j = b; j < e; ++j) dst[j] = src[ix[j]];
+        }
+      });
+    } catch (const std::system_error& e) {
+      rc = swg_set_error(ctx, SWG_ERR_OOM, "cannot start host threads: %s", e.what());
+      break;
+    } catch (const std::bad_alloc&) {
+      rc = swg_set_error(ctx, SWG_ERR_OOM, "out of host memory while staging a shard");
+      break;
+    }
+    for (int c = 0; c < 10 && rc == SWG_OK; ++c) {
+      if (!need[c]) continue;
+      const size_t w = c == 8 ? 8 : (c == 9 ? 1 : 4);
+      if (hipMemcpyAsync(d_col[c] + c0 * w, s_col[c], cnt * w, hipMemcpyHostToDevice, cs) != hipSuccess)
+        rc = swg_set_error(ctx, SWG_ERR_HIP, "H2D copy of a staged chunk failed");
+    }
+    (void)hipEventRecord(ctx->ring_ev[k], cs);
+  }
+  (void)hipEventRecord(ctx->ev1, cs);
+  float h2d = 0.f, d2h = 0.f;
+  if (rc == SWG_OK && hipEventSynchronize(ctx->ev1) == hipSuccess) (void)hipEventElapsedTime(&h2d, ctx->ev0, ctx->ev1);  // (the columns are complete: the filter's stream may start)
+  if (rc != SWG_OK) {
+    (void)hipStreamSynchronize(cs);
+    return rc;
+  }
+  swg_records d = *rec;
+  d.n = m;
+  d.q_id = (const uint32_t*)d_col[0]; d.t_id = (const uint32_t*)d_col[1]; d.q_start = (const uint32_t*)d_col[2]; d.q_end = (const uint32_t*)d_col[3];
+  d.t_start = (const uint32_t*)d_col[4]; d.t_end = (const uint32_t*)d_col[5]; d.matches = (const uint32_t*)d_col[6]; d.block_len = (const uint32_t*)d_col[7];
+  d.identity = send_identity ? (const double*)d_col[8] : nullptr;
+  d.strand = (const uint8_t*)d_col[9];
+  d.seq_genome_last = (const uint32_t*)d_gl;
+  d.seq_genome_two = (const uint32_t*)d_g2;
+  swg_stats local{};
+  rc = swg_filter_device(ctx, &d, cfg, d_status, d_chain, &local);
+  if (rc == SWG_OK) {
+    (void)hipEventRecord(ctx->ev0, st);
+    if (hipMemcpyAsync(status_sub, d_status, m, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (scaffold && hipMemcpyAsync(chain_sub, d_chain, m * 4, hipMemcpyDeviceToHost, st) != hipSuccess))
+      rc = swg_set_error(ctx, SWG_ERR_HIP, "D2H copy failed");
+    (void)hipEventRecord(ctx->ev1, st);
+    if (!scaffold) std::memset(chain_sub, 0, m * sizeof(uint32_t));
+    if (hipStreamSynchronize(st) != hipSuccess && rc == SWG_OK) rc = swg_set_error(ctx, SWG_ERR_HIP, "stream synchronize failed");
+    if (rc == SWG_OK) (void)hipEventElapsedTime(&d2h, ctx->ev0, ctx->ev1);
   } else {
     (void)hipStreamSynchronize(st);
   }

@@ -24,6 +24,11 @@ struct swg_ctx {
   // demand, so a host that filters file after file pays no hipMalloc / hipFree in steady state
   char* io_block = nullptr;
   size_t io_cap = 0;
+  // pinned staging ring of swg_filter_gathered (records picked out of the caller's columns chunk by chunk on their way to the
+  // device): RING_SLOTS slots of ring_slot_bytes, one event per slot (the slot's last copy); allocated on first use
+  char* ring = nullptr;
+  size_t ring_slot_bytes = 0;
+  hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* narrow_host = nullptr;  // swg_filter64: the rebased 32-bit columns (host side, malloc), released by swg_narrow_release
   size_t narrow_cap = 0;            //   in words
   // pinned host scratch for small read-backs
@@ -251,6 +256,11 @@ int swg_narrow_coords(swg_ctx* ctx, uint64_t n, const uint64_t* s0, const uint64
 int swg_rebase_host(swg_ctx* ctx, const swg_records64* rec, const swg_config* cfg, swg_records* out);
 void swg_narrow_release(swg_ctx* ctx);  // after the call that used them (keeps at most 256 MB with the context)
 int swg_read_scalars(swg_ctx* ctx, const uint64_t* d_src, uint64_t* h_dst, int count);
+// apply_filters over the records idx[0 .. m) (ascending) of the caller's host columns: gathered chunk by chunk into a pinned ring,
+// uploaded on the copy stream behind the gathering, filtered, results into status_sub / chain_sub [m] (swg_filter.hip; the shards
+// of swg_filter_multi when the input is not grouped by query genome)
+int swg_filter_gathered(swg_ctx* ctx, const swg_records* rec, const uint32_t* idx, uint64_t m, const swg_config* cfg, uint8_t* status_sub,
+                        uint32_t* chain_sub, swg_stats* stats, int threads);
 
 static inline int swg_bits_for(uint64_t max_value) {  // bits needed to represent max_value
   int b = 0;

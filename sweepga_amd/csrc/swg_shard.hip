@@ -9,6 +9,8 @@
 // That is exact when the reference's two genome-prefix rules (last '#' vs first two '#' parts) induce the same
 // partition of the sequences; otherwise the call falls back to one device.
 #include <algorithm>
+#include <cstdlib>
+#include <thread>
 #include <new>
 #include <system_error>
 #include <vector>
@@ -45,13 +47,16 @@ extern "C" int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_recor
     const int rc = swg_stream_try(ctxs, n_ctx, r, cfg, status_out, chain_out, stats, &taken);
     if (rc != SWG_OK || taken) return rc;
   }
-  // ---- plan + scatter on host threads (csrc/host/shard_host.h)
+  // ---- plan + the shards' index lists on host threads (csrc/host/shard_host.h); the records themselves go from the caller's
+  // columns to every device through its context's pinned ring (swg_filter_gathered).  SWG_MULTI_SCATTER=1: rounds 2-5's way --
+  // every shard copied into host columns of its own first (a comparison knob)
+  static const bool copy_first = getenv("SWG_MULTI_SCATTER") != nullptr;
   swg_shard::Plan P;
   std::vector<swg_shard::Shard> sh;
   try {
     if (!swg_shard::make_plan(*r, *cfg, n_ctx, swg_shard::default_threads(n), &P))
       return swg_set_error(ctx0, SWG_ERR_INVALID, "sequence id out of range (record %llu)", (unsigned long long)P.bad_record);
-    swg_shard::scatter(*r, P, &sh);
+    if (copy_first) swg_shard::scatter(*r, P, &sh); else swg_shard::scatter_indices(P, &sh);
   } catch (const std::bad_alloc&) {
     return swg_set_error(ctx0, SWG_ERR_OOM, "out of host memory while sharding %llu records", (unsigned long long)n);
   } catch (const std::system_error& e) {
@@ -63,8 +68,16 @@ extern "C" int swg_filter_multi(swg_ctx* const* ctxs, int n_ctx, const swg_recor
     swg_shard::run(n_ctx, [&](int s) {
       swg_shard::Shard& S = sh[s];
       if (S.m == 0) return;
-      const swg_records sub = S.view(*r);
-      S.rc = swg_filter(ctxs[s], &sub, cfg, S.status.data(), S.chain.data(), &S.stats);
+      if (copy_first) {
+        const swg_records sub = S.view(*r);
+        S.rc = swg_filter(ctxs[s], &sub, cfg, S.status.data(), S.chain.data(), &S.stats);
+      } else {
+        // (host threads of this device's gathering: the machine's threads shared out among the devices, at most 8 each)
+        unsigned hc = std::thread::hardware_concurrency();
+        int per = hc ? (int)(hc / (unsigned)n_ctx) : 1;
+        per = per < 1 ? 1 : (per > 8 ? 8 : per);
+        S.rc = swg_filter_gathered(ctxs[s], r, S.idx.data(), S.m, cfg, S.status.data(), S.chain.data(), &S.stats, per);
+      }
     });
   } catch (const std::system_error& e) {
     return swg_set_error(ctx0, SWG_ERR_OOM, "cannot start host threads: %s", e.what());

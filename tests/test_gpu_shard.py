@@ -103,3 +103,36 @@ def test_cli_devices_flag_byte_identical(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "gpu.paf").read_bytes() == (tmp_path / "ref.paf").read_bytes()
+
+
+def test_the_pinned_ring_wraps_around(tmp_path):
+    """swg_filter_multi on an input that is not grouped by query genome: every shard's records are gathered from the caller's
+    columns into a pinned ring of three slots and uploaded slot by slot (swg_filter_gathered).  With SWG_RING_CHUNK=2048 a shard of
+    ~30,000 records takes 15 chunks -- every slot re-used several times -- and SWG_POISON fills what the flag set does not send;
+    SWG_MULTI_SCATTER=1 (the shards copied into host columns first, rounds 2-5) must give the same answer."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import sweepga_amd as sw
+from tests import gen
+rng = np.random.default_rng(77)
+rec = gen.random_records(rng, 90_000, n_genomes=6, chrs_per_genome=2, span=800_000)
+packed = sw.pack_records(gen.records_to_meta(rec))
+ctxs = [sw.Context(0) for _ in range(3)]
+for kw in (dict(), dict(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=0),
+           dict(mapping_filter_mode=sw.FilterMode.OneToOne, scaffold_filter_mode=sw.FilterMode.OneToOne, scaffold_gap=20_000, min_scaffold_length=3_000,
+                scaffold_max_deviation=15_000, min_identity=0.75)):
+    f = sw.PafFilter(sw.FilterConfig(**kw), ctx=ctxs[0])
+    want_st, want_ch = f.filter_columns(packed)
+    got_st, got_ch = f.filter_columns_multi(packed, ctxs)
+    assert np.array_equal(got_st, want_st) and np.array_equal(got_ch, want_ch), kw
+print("ok")
+""" % root
+    for env in (dict(SWG_RING_CHUNK="2048", SWG_POISON="1"), dict(SWG_MULTI_SCATTER="1")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, cwd=root)
+        assert out.returncode == 0 and "ok" in out.stdout, (env, out.stderr[-2000:])
