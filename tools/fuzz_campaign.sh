@@ -37,3 +37,10 @@ run seams      X=1                python3 tests/fuzz/fuzz_seams.py --minutes $MI
 run cli        X=1                python3 tests/fuzz/fuzz_cli.py --minutes $MIN --seed 16
 run large      X=1                python3 tests/fuzz/fuzz_large.py --seed 17
 run large_pm   X=1                python3 tests/fuzz/fuzz_large.py --seed 24 --pair-major
+# Round 6: the three opt-in ways of the k = 1 sweep over a pair-major input (fused with the segment sort, streamed behind it, lone
+# intervals settled inside it), and the pinned ring of swg_filter_multi wrapping around (every gpu leg runs swg_filter_multi on
+# ungrouped records: here with 512 records per slot)
+run large_fused  SWG_SEG_SWEEP=1  python3 tests/fuzz/fuzz_large.py --seed 28 --pair-major
+run large_stream SWG_SEG_STREAM=1 python3 tests/fuzz/fuzz_large.py --seed 29 --pair-major
+run large_lone   SWG_SEG_LONE=1   python3 tests/fuzz/fuzz_large.py --seed 30 --pair-major
+run gpu_ring   SWG_RING_CHUNK=512 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 31
