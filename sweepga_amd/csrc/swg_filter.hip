@@ -338,6 +338,37 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
       int taken = 0;
       SWG_TRY(pair_stage(nullptr, nullptr, true, &taken));
       if (taken) return SWG_OK;
+    } else if (!pair_plan.valid && pair_plan.not_grouped && !pair_stage_off && !identity_try_off && cfg->scaffold_gap != 0 && kq1 == SWG_K_INF &&
+               kt1 == SWG_K_INF) {
+      // a large input whose pairs are interleaved (one query after the other with the targets mixed: what wfmash writes): grouped
+      // on the device -- a stable sort of the record indices by pair, one gather into a pair-major copy -- and the pair-resident
+      // stage over the copy (swg_pair.hip, pair_group_records)
+      const swg_arena_mark gm = swg_arena_save(ctx);
+      swg_records copy;
+      uint32_t* perm = nullptr;
+      int ok = 0;
+      SWG_TRY(swg_scaf::pair_group_records(ctx, r, &copy, &perm, &ok));
+      if (ok) {
+        swg_scaf::PairPlan plan2;
+        SWG_TRY(swg_scaf::pair_plan(ctx, &copy, cfg, &plan2));
+        if (plan2.valid) {
+          plan2.orig = perm;
+          uint8_t* st2 = swg_alloc<uint8_t>(ctx, n);
+          uint32_t* ch2 = swg_alloc<uint32_t>(ctx, n);
+          SWG_CHECK_ARENA(ctx);
+          int taken = 0;
+          SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, &copy, cfg, nullptr, nullptr, true, st2, ch2, stats, &taken, &plan2));
+          if (taken) {
+            ctx->pair_fallback_count[0] = 0;
+            SWG_TRY(swg_scaf::pair_ungroup_results(ctx, n, perm, st2, ch2, status_out, chain_out));
+            return SWG_OK;
+          }
+        }
+        // (handed back, or the copy's pairs are too many or too small for the stage as well: remembered like any other hand-over)
+        ctx->pair_fallback_count[0] = ctx->pair_fallback_count[0] && about_n(0) ? ctx->pair_fallback_count[0] + 1 : 1;
+        ctx->pair_fallback_n[0] = n;
+      }
+      swg_arena_restore(ctx, gm);
     }
   }
   uint8_t* alive = swg_alloc<uint8_t>(ctx, n);

@@ -381,6 +381,7 @@ struct PairSortArgs {
   const PairRun* runs;
   const uint32_t* list;
   const uint32_t* perm;  // inputs not grouped by pair: record indices, pair after pair (runs[] then index this list)
+  const uint32_t* orig;  // the records are a pair-major copy: the caller's index of every record (first appearances are reported in those)
   uint8_t* code;
   uint32_t *s_qs, *s_qe, *s_ts, *s_te, *s_m, *s_b, *s_idx, *pred;
   PairInfo* info;
@@ -699,6 +700,11 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     pi.m = m;
     pi.m_plus = m_plus;
     pi.M = M;
+    if (A.orig) {  // (a pair-major copy: first appearances in the caller's own record indices -- ascending inside the pair)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (sh_first[j] != NONE) sh_first[j] = A.orig[sh_first[j]];
+    }
     pi.first_alive = sh_first[2];
     pi.first_mem[0] = sh_first[0];
     pi.first_mem[1] = sh_first[1];
@@ -1205,6 +1211,11 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
     pi.m = m;
     pi.m_plus = m_plus;
     pi.M = M;
+    if (A.orig) {  // (a pair-major copy: first appearances in the caller's own record indices -- ascending inside the pair)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (sh_first[j] != NONE) sh_first[j] = A.orig[sh_first[j]];
+    }
     pi.first_alive = sh_first[2];
     pi.first_mem[0] = sh_first[0];
     pi.first_mem[1] = sh_first[1];
@@ -2408,6 +2419,95 @@ bool pair_path_wanted() {
   return knob != 0;
 }
 
+// ---- large inputs that are not grouped by pair: grouped on the device (round 6) -------------------------------------------------
+// The reference groups records in whatever order they come (IndexMap by (query, target, strand), src/paf_filter.rs:761-770).  The
+// pair-resident stage wants a pair's records side by side; what an aligner like wfmash writes is one query after the other with
+// the targets mixed.  So: key = q_id * n_seq + t_id per record, a stable radix sort of (key, index) -- inside a pair the records
+// keep their order, which every tie-break of the stage relies on --, ONE gather of the ten columns into a pair-major copy, the
+// stage over the copy, and the results scattered back.  What orders PAIRS by first appearance (the chain numbers) is reported
+// in the caller's indices (PairSortArgs.orig).
+__global__ __launch_bounds__(256) void pair_group_key_kernel(uint32_t n, const uint32_t* __restrict__ q_id, const uint32_t* __restrict__ t_id,
+                                                             uint32_t n_seq, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  key[i] = (uint64_t)q_id[i] * n_seq + t_id[i];
+  val[i] = i;
+}
+__global__ __launch_bounds__(256) void pair_group_gather_kernel(uint32_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ q_id,
+                                                                const uint32_t* __restrict__ t_id, const uint32_t* __restrict__ qs,
+                                                                const uint32_t* __restrict__ qe, const uint32_t* __restrict__ ts,
+                                                                const uint32_t* __restrict__ te, const uint32_t* __restrict__ m,
+                                                                const uint32_t* __restrict__ b, const double* __restrict__ id,
+                                                                const uint8_t* __restrict__ strand, uint32_t* __restrict__ o_q,
+                                                                uint32_t* __restrict__ o_t, uint32_t* __restrict__ o_qs, uint32_t* __restrict__ o_qe,
+                                                                uint32_t* __restrict__ o_ts, uint32_t* __restrict__ o_te, uint32_t* __restrict__ o_m,
+                                                                uint32_t* __restrict__ o_b, double* __restrict__ o_id, uint8_t* __restrict__ o_st) {
+  const uint32_t j = swg_xcd_block(blockIdx.x, gridDim.x) * 256u + threadIdx.x;  // (neighbouring blocks read neighbouring records: one L2)
+  if (j >= n) return;
+  const uint32_t i = perm[j];
+  o_q[j] = q_id[i];
+  o_t[j] = t_id[i];
+  o_qs[j] = qs[i];
+  o_qe[j] = qe[i];
+  o_ts[j] = ts[i];
+  o_te[j] = te[i];
+  o_m[j] = m[i];
+  o_b[j] = b[i];
+  if (id) o_id[j] = id[i];
+  o_st[j] = strand[i];
+}
+__global__ __launch_bounds__(256) void pair_ungroup_kernel(uint32_t n, const uint32_t* __restrict__ perm, const uint8_t* __restrict__ st,
+                                                           const uint32_t* __restrict__ ch, uint8_t* __restrict__ status_out,
+                                                           uint32_t* __restrict__ chain_out) {
+  const uint32_t j = swg_xcd_block(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = perm[j];
+  status_out[i] = st[j];
+  chain_out[i] = ch[j];
+}
+
+}  // namespace
+
+int pair_group_records(swg_ctx* ctx, const swg_records* r, swg_records* copy, uint32_t** perm_out, int* ok) {
+  *ok = 0;
+  static const bool off = getenv("SWG_PAIR_GROUP") && atoi(getenv("SWG_PAIR_GROUP")) == 0;
+  const uint64_t n64 = r->n;
+  if (off || !pair_path_wanted() || n64 < 2 || n64 >= (uint64_t(1) << 31)) return SWG_OK;
+  const int key_bits = swg_bits_for((uint64_t)r->n_seq * r->n_seq - 1) ? swg_bits_for((uint64_t)r->n_seq * r->n_seq - 1) : 1;
+  if (key_bits > 24) return SWG_OK;  // (three 12-byte passes at most: beyond that the global-sort stage is the cheaper way)
+  const uint32_t n = (uint32_t)n64;
+  hipStream_t st = ctx->stream;
+  uint64_t* key = swg_alloc<uint64_t>(ctx, n);
+  uint64_t* key2 = swg_alloc<uint64_t>(ctx, n);
+  uint32_t* val = swg_alloc<uint32_t>(ctx, n);
+  uint32_t* val2 = swg_alloc<uint32_t>(ctx, n);
+  uint32_t* c4[8];
+  for (auto& p : c4) p = swg_alloc<uint32_t>(ctx, n);
+  double* c_id = r->identity ? swg_alloc<double>(ctx, n) : nullptr;
+  uint8_t* c_st = swg_alloc<uint8_t>(ctx, n);
+  SWG_CHECK_ARENA(ctx);
+  SWG_LAUNCH(ctx, "pair_group_key", pair_group_key_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, r->q_id, r->t_id, r->n_seq, key, val));
+  SWG_KERNEL_CHECK(ctx);
+  SWG_TRY(swg_radix_sort_pairs(ctx, &key, &val, &key2, &val2, n, 0, key_bits));
+  SWG_LAUNCH(ctx, "pair_group_gather", pair_group_gather_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, val, r->q_id, r->t_id, r->q_start, r->q_end, r->t_start, r->t_end,
+                                                                                       r->matches, r->block_len, r->identity, r->strand, c4[0], c4[1], c4[2],
+                                                                                       c4[3], c4[4], c4[5], c4[6], c4[7], c_id, c_st));
+  SWG_KERNEL_CHECK(ctx);
+  *copy = *r;
+  copy->q_id = c4[0]; copy->t_id = c4[1]; copy->q_start = c4[2]; copy->q_end = c4[3]; copy->t_start = c4[4]; copy->t_end = c4[5];
+  copy->matches = c4[6]; copy->block_len = c4[7]; copy->identity = c_id; copy->strand = c_st;
+  *perm_out = val;
+  *ok = 1;
+  return SWG_OK;
+}
+int pair_ungroup_results(swg_ctx* ctx, uint64_t n, const uint32_t* perm, const uint8_t* st, const uint32_t* ch, uint8_t* status_out, uint32_t* chain_out) {
+  SWG_LAUNCH(ctx, "pair_ungroup", pair_ungroup_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((uint32_t)n, perm, st, ch, status_out, chain_out));
+  SWG_KERNEL_CHECK(ctx);
+  return SWG_OK;
+}
+
+namespace {
+
 }  // namespace
 
 // The pairs of the input: runs of equal (q_id, t_id) (large inputs, grouped by pair as an aligner writes them), or through a
@@ -2481,6 +2581,7 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
   const uint32_t n_runs = (uint32_t)h[0], flags = (uint32_t)(h[0] >> 32);
   if (flags || n_runs == 0) {
     if (dbg) fprintf(stderr, "[swg] pair path: not applicable (%u runs, flags %u)\n", n_runs, flags);
+    plan->not_grouped = !by_hash && (flags & (PF_NOT_GROUPED | PF_RUN_OVERFLOW)) && !(flags & PF_TOO_LONG);
     swg_arena_restore(ctx, mark0);
     return SWG_OK;
   }
@@ -2593,6 +2694,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.max_gap = cfg->scaffold_gap;
   SA.runs = runs;
   SA.perm = perm;
+  SA.orig = plan_in->orig;
   SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = need_wid ? s_m : nullptr; SA.s_b = need_wid ? s_b : nullptr; SA.s_idx = s_idx; SA.pred = pred;
   SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
   if (by_hash) {

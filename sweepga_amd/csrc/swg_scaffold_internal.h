@@ -249,7 +249,16 @@ struct PairPlan {
   bool by_hash = false;
   uint32_t n_runs = 0, ncls[4] = {0, 0, 0, 0}, cap = 0;
   void *counters = nullptr, *runs = nullptr, *class_list = nullptr, *perm = nullptr;
+  bool not_grouped = false;        // why a plan over the runs of a large input is not valid: a pair has two runs, or there are more
+                                   //   runs than pairs the path takes (both: what a grouping of the records by pair would cure)
+  const uint32_t* orig = nullptr;  // the records are a pair-major COPY of the caller's: the caller's index of every record (ascending
+                                   //   inside a pair), for everything that orders pairs by first appearance (pair_group_records)
 };
+// Large inputs that are not grouped by (query, target) pair: a stable sort of the record indices by pair and a pair-major copy
+// of the columns, on the device (swg_pair.hip).  *ok = 0: not applicable (too many sequences for the sort key).  copy / perm live
+// in the caller's arena frame.
+int pair_group_records(swg_ctx* ctx, const swg_records* r, swg_records* copy, uint32_t** perm, int* ok);
+int pair_ungroup_results(swg_ctx* ctx, uint64_t n, const uint32_t* perm, const uint8_t* st, const uint32_t* ch, uint8_t* status_out, uint32_t* chain_out);
 int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPlan* plan);
 // *taken = 0: not applicable, or left on a condition found on the device -- the caller runs the global-sort stage
 // (swg_scaffold_stage's own path).  plan: from pair_plan, or nullptr (made here).

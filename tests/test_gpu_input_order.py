@@ -1,7 +1,7 @@
-"""The input-order probe (input_order_probe_kernel, swg_filter.hip): with the CLI defaults and shallow sequence pairs the library
-decides on the device whether the records are grouped by sequence pair; if they are not, prepare writes the 32-byte record slots
-and the scaffold stage's first gather reads them.  Both orders of the same records must give the oracle's answer (status and
-chain numbers are per record, so the shuffled run's results are the grouped run's, permuted)."""
+"""Both orders of the same records -- grouped by sequence pair and shuffled -- must give the oracle's answer, status and chain
+numbers.  Since round 6 a shuffled input of this size is grouped on the device and runs pair-resident (pair_group_records,
+swg_pair.hip); with SWG_PAIR_GROUP=0 it takes the global-sort stage, where the input-order probe (input_order_probe_kernel,
+swg_filter.hip) decides on the device whether prepare writes the 32-byte record slots for the scaffold stage's first gather."""
 import numpy as np
 import pytest
 
@@ -41,3 +41,14 @@ def test_default_flags_on_grouped_and_shuffled_input(order):
         ost, och = orc.apply_filters(orc.Config(**okw), rec)
         assert np.array_equal(st, ost), (order, cfg_kw, int((st != ost).sum()))
         assert np.array_equal(ch, och), (order, cfg_kw, int((ch != och).sum()))
+
+
+def test_shuffled_input_on_the_global_sort_stage():
+    """The same shuffled records with the device-side grouping switched off: the global-sort stage and its input-order probe."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_input_order import test_default_flags_on_grouped_and_shuffled_input as t; t('shuffled'); print('ok')" % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SWG_PAIR_GROUP="0"), capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

@@ -185,10 +185,22 @@ def test_small_inputs_need_not_be_grouped(sw):
         run_both(sw, rec, cfg)
 
 
-def test_large_ungrouped_inputs_take_the_global_path_and_degenerate_ones_the_real_sweep(sw):
+def test_large_ungrouped_inputs_are_grouped_on_the_device_and_degenerate_ones_take_the_real_sweep(sw):
+    """More than 65,536 records with the pairs interleaved (here: in random order): round 5 left them to the global-sort stage;
+    since round 6 the record indices are sorted by pair on the device (stable: a pair keeps its order), the columns gathered
+    into a pair-major copy, and the pair-resident stage runs over the copy -- with the pairs' first appearances, which order
+    the chain numbers, reported in the caller's record indices (pair_group_records)."""
     rng = np.random.default_rng(9)
     rec = gen.random_records(rng, 70_000, n_genomes=3, chrs_per_genome=2, span=2_000_000, zero_frac=0.0)
-    run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=False)   # pairs interleaved, too many for the table
+    for cfg in ({"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, {},
+                {"scaffold_filter_mode": "OneToOne", "scaffold_gap": 5_000, "min_scaffold_length": 1_000, "scaffold_max_deviation": 8_000},
+                {"scaffold_gap": 100_000, "min_scaffold_length": 5_000, "min_identity": 0.8, "min_block_length": 300}):
+        run_both(sw, rec, cfg, expect_pair_path=True)
+        assert "pair_group_gather" in sw.default_context(0).profile_table()
+    # by query sequence in query order, the targets mixed (what wfmash writes), without an identity column
+    by_q = permute(rec, np.lexsort((rec.qs, np.array(rec.qname))))
+    run_both(sw, by_q, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000, "scaffold_max_deviation": 2_000}, expect_pair_path=True, derived_identity=True)
+    assert "pair_group_gather" in sw.default_context(0).profile_table()
     rec = pair_major(gen.random_records(rng, 5_000, n_genomes=3, chrs_per_genome=2, zero_frac=0.02), rng)
     # zero-length records: the unlimited mapping sweep is not the identity, so it runs, and the pair path takes its flags
     run_both(sw, rec, {"scaffold_gap": 3_000, "min_scaffold_length": 1_000}, expect_pair_path=True)
