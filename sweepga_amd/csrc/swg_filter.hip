@@ -310,8 +310,15 @@ static int filter_device_body(swg_ctx* ctx, const swg_records* r, const swg_conf
   auto about_n = [&](int kind) { return n >= ctx->pair_fallback_n[kind] / 2 && n <= ctx->pair_fallback_n[kind] * 2; };
   for (int kind = 0; kind < 2; ++kind)
     if (ctx->pair_fallback_count[kind] && !about_n(kind)) ctx->pair_fallback_count[kind] = 0;
-  const bool identity_try_off = ctx->pair_fallback_count[0] >= 2;  // (the attempt before any sweep)
-  const bool pair_stage_off = ctx->pair_fallback_count[1] >= 2;    // (the attempt behind the sweep: then neither is made)
+  // (off: not tried -- but every 16th call of that size is, for the next input of that size may be of another kind; a hand-over
+  // then keeps the verdict, a finished call clears it)
+  auto off = [&](int kind) {
+    if (ctx->pair_fallback_count[kind] < 2) return false;
+    if (++ctx->pair_fallback_skips[kind] % 16 == 0) return false;
+    return true;
+  };
+  const bool identity_try_off = off(0);  // (the attempt before any sweep)
+  const bool pair_stage_off = off(1);    // (the attempt behind the sweep: then neither is made)
   auto pair_stage = [&](const uint8_t* alive_in, const uint8_t* member_in, bool assumed_identity, int* taken) -> int {
     SWG_TRY(swg_scaf::scaffold_stage_pairs(ctx, r, cfg, alive_in, member_in, assumed_identity, status_out, chain_out, stats, taken, &pair_plan));
     const int kind = assumed_identity ? 0 : 1;

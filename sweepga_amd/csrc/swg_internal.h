@@ -44,6 +44,7 @@ struct swg_ctx {
   int sort_drop_level = 0;   // raised when a sort on a truncated key met runs too long to order in the gather (swg_radix_drop_bits)
   uint64_t sort_drop_n = 0;  // ... by a call over this many records: a call of a very different size starts from level 0 again
   uint64_t pair_fallback_n[2] = {0, 0};   // the pair-resident scaffold stage handed a call of this many records back on a condition found
+  int pair_fallback_skips[2] = {0, 0};    // calls that did not try since (every 16th does: the next input of that size may be another kind)
   int pair_fallback_count[2] = {0, 0};    //   on the device (deep long units, dense LDS batches, a degenerate record), so many times in a
                                           //   row: from the second time on, calls of about that size do not try it (swg_filter.hip).  [0]: the
                                           //   attempt that takes an unlimited mapping sweep as the identity, [1]: the one behind a real sweep

@@ -46,7 +46,6 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--pair-major", action="store_true")
     args = ap.parse_args()
-    ctx = sw.default_context(0)
     results, lock = [], threading.Lock()
     jobs = []
     t_all = time.time()
@@ -63,9 +62,12 @@ def main():
             from tests.test_gpu_pairs import pair_major
             rec = pair_major(rec, rng)
         packed = sw.pack_records(gen.records_to_meta(rec))
+        # (a context of its own per shape: a context remembers what the device handed back on calls of about this size -- deep pairs,
+        # heavy ties -- and the next shape is of the same size)
+        ctx = sw.Context(0)
         for cname, kw in CONFIGS:
             kwg = {k: (getattr(sw.FilterMode, v) if isinstance(v, str) else v) for k, v in kw.items()}
-            f = sw.PafFilter(sw.FilterConfig(**kwg))
+            f = sw.PafFilter(sw.FilterConfig(**kwg), ctx=ctx)
             t0 = time.perf_counter()
             st, ch = f.filter_columns(packed)
             gpu_s = time.perf_counter() - t0
@@ -81,6 +83,7 @@ def main():
                 assert took or shape["name"] in ("giant_pair_deep", "ties_grid", "tiny_pairs", "tiny_pairs_40k"), (shape["name"], cname, sorted(table))
             okw = {k: (int(getattr(sw.FilterMode, v)) if isinstance(v, str) else v) for k, v in kw.items()}
             jobs.append((shape["name"], cname, rec, orc.Config(**okw), st.copy(), ch.copy(), gpu_s))
+        ctx.close()
         print("generated + filtered", shape["name"], n, flush=True)
 
     def worker():
