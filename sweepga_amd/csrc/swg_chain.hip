@@ -1670,6 +1670,13 @@ __global__ __launch_bounds__(64) void spec_round_kernel(uint32_t n_blocks, const
 }
 
 
+// SWG_WALK_PLAIN=1: the fused walk builds its candidate lists with the per-lane loop for every gap limit (A/B knob and the
+// other half of the tests of the packed-key loop)
+static int walk_plain_knob() {
+  const char* e = getenv("SWG_WALK_PLAIN");
+  return e && e[0] == '1';
+}
+
 // ---- the walk: the reference's greedy, 64 elements per step -----------------------------------------------------------
 // One wavefront walks a range [bb, be) of consecutive elements in order (chain_walk_kernel), 64 at a time, lane l holding
 // element i0 + l.  The sequential rule (paf_filter.rs:790-831) -- i takes the first j of its (d, j)-ordered valid list
@@ -1726,7 +1733,8 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
                                                         uint32_t* __restrict__ pred_own, uint32_t* __restrict__ pred_prev,
                                                         unsigned long long* __restrict__ wstats,
                                                         const uint32_t* __restrict__ n_blocks_dev = nullptr,
-                                                        const uint32_t* __restrict__ gate = nullptr) {
+                                                        const uint32_t* __restrict__ gate = nullptr,
+                                                        int walk_plain_lists = 0) {
   constexpr bool spec = SPEC;
   if (gate && *gate == 0) return;  // (a speculative round behind a round without changes: pair_walk_long_launch)
   // The pair-resident path (swg_pair.hip): the chunk list is made on the device, so its length is read here (n_blocks is
@@ -1747,6 +1755,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
   const uint32_t fifth32 = fifth > 0xffffffffull ? 0xffffffffu : (uint32_t)fifth;
   const bool wrap = max_gap == ~0ull;  // `max_gap + 1` (= reject) wraps to 0 in release Rust
   const bool can_cut = max_gap < (uint64_t(1) << 31);  // accepted gaps < 2^31: d cannot wrap and grows with the query gap
+  const bool fast_keys = max_gap <= (uint64_t(1) << 22) && !walk_plain_lists;  // the candidates as packed keys (see the batch loop)
   for (int k = lane; k < WALK_HASH; k += 64) {
     hcnt[k] = 0xffffffffu;
     hnum[k] = 0;
@@ -1867,7 +1876,71 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         bj[c] = cur.bj[c];
       }
       const uint32_t e_i = cur.ei;  // end of the element's (query, target, strand) group inside the range
-      if (FUSED && valid) {
+      bool listed = false;  // (wave-uniform) the part of the windows inside the ring went through the packed-key loop
+      uint32_t j_next = i + 1;
+      bool open_next = valid;
+      if (FUSED && fast_keys) {
+        // The windows' part inside the ring, for gap limits up to 2^22 (the CLI's 50,000 among them): ONE loop for the
+        // wavefront, as long as its longest window, without a branch in its body.  A candidate is one 64-bit key --
+        // bit 62 | d << 16 | (j - i), d = q_gap^2 + r_gap^2 < 2^45 -- and the keys are read as doubles: positive normal
+        // numbers order like their bit patterns, so v_min_f64 / v_max_f64 are the 64-bit integer minimum and maximum in one
+        // instruction each, and keeping the KC smallest keys in order is a chain of KC min / max pairs (no compare, no
+        // select, no "does it enter the list" branch); a rejected pair is +infinity.  Keys are distinct ((j - i) is), so
+        // the list is the (d, j)-ordered list of paf_filter.rs:798-836 exactly.  The per-lane loop this replaces spent
+        // ~40 scalar and branch instructions per step on exec-mask bookkeeping and ~20 vector ones per insertion.
+        const uint32_t qe_i = cur.qe;
+        const bool minus = cur.minus != 0;
+        const uint64_t bound64 = (uint64_t)qe_i + max_gap;  // (no wrap: max_gap <= 2^22)
+        const uint32_t bound = bound64 > 0xffffffffull ? 0xffffffffu : (uint32_t)bound64;
+        const uint32_t r_i = minus ? cur.ts : cur.te;
+        const uint32_t* r_ring = minus ? re : rt;
+        const uint32_t e_ring = min(e_i, base + (uint32_t)BIGW);
+        constexpr uint64_t KEY_INF = 0x7ff0000000000000ull, KEY_BIT = 1ull << 62;
+        double kb[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) kb[c] = __longlong_as_double((long long)KEY_INF);
+        uint32_t j = i + 1, cnt = 0;
+        bool open = valid;
+        for (;;) {
+          const bool in = open && j < e_ring;
+          if (!__any(in)) break;
+          const uint32_t sl = j % BIGW;
+          uint32_t qs_j = rq[sl], r_j = r_ring[sl];
+          asm volatile("" : "+v"(qs_j), "+v"(r_j));  // both reads issued here, one wait
+          const bool inw = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796)
+          open = open && !(in && qs_j > bound);
+          const uint32_t q_gap = absdiff_vv(qs_j, qe_i), r_gap = absdiff_vv(r_j, r_i);
+          // (at q_gap == 0 / r_gap == 0 either limit passes: the sides need no "or equal")
+          const uint32_t lim_q = qs_j < qe_i ? fifth32 : gap32;
+          const uint32_t lim_r = ((r_j > r_i) != minus) ? gap32 : fifth32;
+          const bool ok = inw && q_gap <= lim_q && r_gap <= lim_r;
+          const uint32_t qa = q_gap << 8, ra = r_gap << 8;  // (their squares: the gaps' squares << 16; garbage when !ok)
+          uint64_t key = (uint64_t)qa * qa + ((uint64_t)ra * ra + (KEY_BIT | (uint64_t)(j - i)));
+          key = ok ? key : KEY_INF;
+          cnt += ok ? 1u : 0u;
+          j += in ? 1u : 0u;
+          double t = __longlong_as_double((long long)key);
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {  // (the list entry is updated in place: no register copies at the loop's back edge)
+            double hi = t;
+            if (c + 1 < KC) asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(kb[c]), "v"(t));
+            asm("v_min_f64 %0, %0, %1" : "+v"(kb[c]) : "v"(t));
+            t = hi;
+          }
+        }
+        nv = cnt < (uint32_t)KC + 1u ? cnt : (uint32_t)KC + 1u;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const uint64_t bits = (uint64_t)__double_as_longlong(kb[c]);
+          const bool none = bits == KEY_INF;
+          bd[c] = none ? INF : (bits & ~KEY_BIT) >> 16;
+          bj[c] = none ? NONE : i + (uint32_t)(bits & 0xffffu);
+        }
+        listed = true;
+        j_next = j;
+        open_next = open;
+      }
+      if (FUSED && valid && (!listed || (open_next && j_next < e_i))) {
         // d(i, j) of paf_filter.rs:798-836 in 32-bit arithmetic, selects instead of branches (as in chain_candidates_wave_kernel)
         const uint32_t qe_i = cur.qe;
         const bool minus = cur.minus != 0;
@@ -1909,8 +1982,8 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         // The window in two stretches: the part inside the ring (nearly always all of it) reads LDS, both coordinates of a
         // step requested together; what lies beyond reads memory.  One loop with `in the ring ? LDS : memory` per load is
         // compiled to flat loads of a selected pointer, two dependent ones per step with a full wait each.
-        const uint32_t e_ring = min(e_i, base + (uint32_t)BIGW);
-        uint32_t j = i + 1;
+        const uint32_t e_ring = listed ? j_next : min(e_i, base + (uint32_t)BIGW);  // (listed: only what lies beyond the ring is left)
+        uint32_t j = j_next;
         bool open = true;  // the window has not ended yet
         for (; j < e_ring; ++j) {
           uint32_t qs_j = rq[j % BIGW], r_j = r_ring[j % BIGW];
@@ -2866,11 +2939,12 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         if (lists_all)
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, bps, bps, pred, pred, wstats));
+                                            (uint32_t)n_groups, max_gap, c_d, c_j, c_n, bps, bps, pred, pred, wstats, nullptr, nullptr, walk_plain_knob()));
         else
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
-                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, bps, bps, pred, pred, wstats));
+                                            (uint32_t)n_groups, max_gap, nullptr, nullptr, nullptr, bps, bps, pred, pred, wstats, nullptr, nullptr,
+                                            walk_plain_knob()));
         SWG_KERNEL_CHECK(ctx);
       }
       if (n_big) {
@@ -2934,7 +3008,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
 #define SWG_WALK_SPEC(W, F)                                                                                                       \
   SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<W, F, true><<<wblocks, 64, 0, st>>>(                                         \
                                          (uint32_t)n_spec, desc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin, \
-                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr))
+                                         (uint32_t)n_groups, max_gap, c_d, c_j, c_n, v_own, v_prev, p_own, p_prev, wstats ? wstats + 8 : nullptr, \
+                                         nullptr, nullptr, walk_plain_knob()))
           if (!lists_all) {
             if (ring <= 256)
               SWG_WALK_SPEC(256, true);
@@ -3145,7 +3220,7 @@ int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks
   const uint64_t wb = cap_chunks < (uint64_t)ctx->num_cu * 64 ? cap_chunks : (uint64_t)ctx->num_cu * 64;
   SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, ctx->stream>>>(
                                     cap_chunks, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
-                                    nullptr, bps, bps, pred, pred, nullptr, n_chunks_dev));
+                                    nullptr, bps, bps, pred, pred, nullptr, n_chunks_dev, nullptr, walk_plain_knob()));
   SWG_KERNEL_CHECK(ctx);
   return SWG_OK;
 }
@@ -3182,7 +3257,7 @@ int pair_walk_long_launch(swg_ctx* ctx, uint32_t cap_long, const uint32_t* n_lon
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "chain_walk_spec", chain_walk_kernel<256, true, true><<<wblocks, 64, 0, st>>>(
                                            cap_spec, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
-                                           nullptr, own, v_prev, pred, p_prev, nullptr, counters, gate));
+                                           nullptr, own, v_prev, pred, p_prev, nullptr, counters, gate, walk_plain_knob()));
     SWG_KERNEL_CHECK(ctx);
     SWG_LAUNCH(ctx, "spec_check", spec_check_kernel<<<rblocks, EW, 0, st>>>(cap_spec, desc, v_prev, ext, counters + 2 + r, counters, gate));
     SWG_KERNEL_CHECK(ctx);

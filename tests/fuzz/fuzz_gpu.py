@@ -72,7 +72,7 @@ def random_case(rng, extras=True):
     # the deep candidate kernel's three loops (<= 46340: 32-bit distances; < 2^31: 64-bit; beyond: the generic loop, where a
     # limit of u64::MAX wraps like release Rust) -- never drawn by the list above
     if WIDE_GAPS and kw["scaffold_gap"] != 0 and rng.random() < 0.5:
-        wide = [46_340, 46_341, 2**31 - 1, 2**31, 2**32 + 5, 2**63, 2**64 - 1]
+        wide = [46_340, 46_341, 2**31 - 1, 2**31, 2**32 + 5, 2**63, 2**64 - 1, 2**22, 2**22 + 1]
         kw["scaffold_gap"] = wide[int(rng.integers(0, len(wide)))]  # (by index: rng.choice would round the values to f64)
     return rec, kw, keep_self, scaffolds_only
 

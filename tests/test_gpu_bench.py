@@ -50,10 +50,13 @@ def test_stdout_line_is_small_and_complete(line):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_unprofiled", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_all_cores",
               "sweep_ms_per_step", "full_ms_per_step", "c5_ms_per_step", "sbig1_sweep_ms", "sbig1_default_ms", "sbig1_full_ms", "pcie_default_ms",
-              "pcie_sweep_ms", "parity", "parity_ok", "detail"):
+              "pcie_sweep_ms", "by_query_default_ms", "shuffled_default_ms", "multichrom_default_ms", "parity", "parity_ok", "detail"):
         assert k in ln, k
     assert ln["value"] == pytest.approx(d["value"], rel=1e-6) and ln["ms_per_step"] == pytest.approx(d["ms_per_step"], abs=1e-3)
-    assert ln["parity_ok"] is True and len(ln["parity"]) == 7 and ln["parity"]["span_c5"]["ok"] is True
+    assert ln["parity_ok"] is True and len(ln["parity"]) == 10 and ln["parity"]["span_c5"]["ok"] is True
+    # the reordered inputs: every record's answer as in the pair-major run, besides the oracle on a few genome pairs
+    assert ln["parity"]["by_query_default"]["same_as_grouped"] is True and ln["parity"]["shuffled_default"]["same_as_grouped"] is True
+    assert ln["parity"]["multichrom_default"]["ok"] is True
     assert ln["parity"]["span_c5"]["checked"] == n
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "pipeline_frac"):
         assert k in ln["roofline"], k

@@ -83,7 +83,7 @@ def test_filter_paf_native_matches_oracle_and_python_mirror(tmp_path, suffix, th
 
 
 @pytest.mark.parametrize("knob", ["SWG_SORT_FALLBACK", "SWG_SORT_WIDE", "SWG_SORT_PAIRS", "SWG_SORT_BITS8", "SWG_CHAIN_DEEP", "SWG_CHAIN_OLD", "SWG_KN_PLAIN", "SWG_TILE_512",
-                                  "SWG_TILE_256", "SWG_SLOTS", "SWG_CHAIN_DEEP+SWG_CAND_GENERIC", "SWG_SORTA_PAIRS", "SWG_SORT_DROP10"])
+                                  "SWG_TILE_256", "SWG_SLOTS", "SWG_CHAIN_DEEP+SWG_CAND_GENERIC", "SWG_SORTA_PAIRS", "SWG_SORT_DROP10", "SWG_WALK_PLAIN"])
 def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     """SWG_SORT_FALLBACK=1 forces the three-kernel radix sort, SWG_SORT_WIDE=1 the 64-bit look-back words of the
     onesweep pass (otherwise only used for n >= 2^30), SWG_SORT_PAIRS=1 keeps the sweep's begins in 12-byte (key, index) pairs
@@ -98,7 +98,8 @@ def test_cli_with_other_sort_paths(bins, tmp_path, knob):
     sequence pair), SWG_CAND_GENERIC=1 keeps the deep candidate kernel on its generic batch loop (otherwise only for gap limits
     of 2^31 and more), SWG_SORTA_PAIRS=1 sorts A behind a mapping sweep as 12-byte (key, index) pairs (otherwise 8-byte (group, index)
     words, the keys rebuilt from the record slots), SWG_SORT_DROP10=1 caps sort A's truncation at 10 bits (otherwise up to 16 on
-    sparse keys)."""
+    sparse keys), SWG_WALK_PLAIN=1 has the fused walk build its candidate lists lane by lane (otherwise only for gap limits beyond
+    2^22; below, the wavefront's windows go through one loop on packed keys)."""
     cli, ref = bins
     rng = np.random.default_rng(99)
     rec = gen.random_records(rng, 60_000, n_genomes=3, chrs_per_genome=2, span=1_000_000)

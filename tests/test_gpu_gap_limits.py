@@ -1,5 +1,6 @@
 """Gap limits at the borders of the chaining kernels' arithmetic (src/paf_filter.rs:786-839): 46340 / 46341 (q^2 + r^2 below /
-beyond 2^32), 2^31 -+ 1 (the early cut of the deep candidate scan), 2^32 + 5 and 2^63 (beyond any 32-bit coordinate: the limit
+beyond 2^32), 2^22 and 2^22 + 1 (the last limit whose candidates the fused walk keeps as packed 64-bit keys, and the first
+that takes its per-lane lists; SWG_WALK_PLAIN=1: those lists for every limit), 2^31 -+ 1 (the early cut of the deep candidate scan), 2^32 + 5 and 2^63 (beyond any 32-bit coordinate: the limit
 cannot bind), u64::MAX (`max_gap + 1` wraps to 0 in release Rust: an overlap beyond a fifth of the limit is distance 0).  One
 deep chromosome pair per strand with records placed exactly at, one short of and one beyond every border, against the oracle,
 under every path that evaluates d(i, j): the pair-resident walk (default), and the global-sort stage with its per-lane lists,
@@ -14,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GAPS = [46_340, 46_341, 2**31 - 1, 2**31, 2**32 + 5, 2**63, 2**64 - 1, 50_000]
+GAPS = [46_340, 46_341, 2**22, 2**22 + 1, 2**31 - 1, 2**31, 2**32 + 5, 2**63, 2**64 - 1, 50_000]
 
 
 def border_records(seed=5):
@@ -35,7 +36,7 @@ def border_records(seed=5):
             t0 = min(max(t0, 0), 4_200_000_000)
             rows.append((pair, int(qs[k]), int(qs[k] + ln[k]), t0, t0 + int(ln[k]), st))
         base = 50_000_000
-        for G in (46_340, 46_341, 2**31 - 1, 2**31, 50_000):
+        for G in (46_340, 46_341, 2**22, 2**22 + 1, 2**31 - 1, 2**31, 50_000):
             for st in ("+", "-"):
                 for dq, dt in ((G - 1, G - 1), (G, G), (G + 1, G), (G, G + 1), (G, 0), (0, G), (G + 1, 0)):
                     a_qs, a_qe = base, base + 1_000
@@ -100,7 +101,9 @@ print("ok", len(rec))
 
 @pytest.mark.parametrize("name,env,pairs,deep", [
     ("pair_path", {}, True, False),
+    ("pair_path_plain_lists", {"SWG_WALK_PLAIN": "1"}, True, False),
     ("global_path", {"SWG_GROUP_FUSED": "0"}, False, False),
+    ("global_path_plain_lists", {"SWG_GROUP_FUSED": "0", "SWG_WALK_PLAIN": "1"}, False, False),
     ("deep_candidates", {"SWG_GROUP_FUSED": "0", "SWG_CHAIN_DEEP": "1"}, False, True),
     ("deep_candidates_generic", {"SWG_GROUP_FUSED": "0", "SWG_CHAIN_DEEP": "1", "SWG_CAND_GENERIC": "1"}, False, True),
 ])
