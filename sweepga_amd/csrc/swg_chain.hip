@@ -1899,26 +1899,35 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
         double kb[KC];
 #pragma unroll
         for (int c = 0; c < KC; ++c) kb[c] = __longlong_as_double((long long)KEY_INF);
-        uint32_t j = i + 1, cnt = 0;
+        // (the loop's own variables: `off` = j - i, `sl` = the ring slot's byte offset, both advanced only while the lane is
+        // inside its window; the two limits sit in vector registers, the key's bit 62 in the addend's high word)
+        uint32_t off = 1, cnt = 0, sl = ((i + 1) % BIGW) * 4u;
+        const uint32_t off_end = e_ring > i ? e_ring - i : 0u;  // j < e_ring  <=>  off < off_end
+        uint32_t gap_v = gap32, fifth_v = fifth32, key_hi = (uint32_t)(KEY_BIT >> 32);
+        asm volatile("" : "+v"(gap_v), "+v"(fifth_v), "+v"(key_hi));
+        const char* const rq_b = reinterpret_cast<const char*>(rq);
+        const char* const rr_b = reinterpret_cast<const char*>(r_ring);
         bool open = valid;
         for (;;) {
-          const bool in = open && j < e_ring;
-          if (!__any(in)) break;
-          const uint32_t sl = j % BIGW;
-          uint32_t qs_j = rq[sl], r_j = r_ring[sl];
+          const bool in = open && off < off_end;
+          if (__ballot(in) == 0ull) break;
+          uint32_t qs_j = *reinterpret_cast<const uint32_t*>(rq_b + sl), r_j = *reinterpret_cast<const uint32_t*>(rr_b + sl);
           asm volatile("" : "+v"(qs_j), "+v"(r_j));  // both reads issued here, one wait
           const bool inw = in && qs_j <= bound;  // sorted by q_start (paf_filter.rs:794-796)
           open = open && !(in && qs_j > bound);
           const uint32_t q_gap = absdiff_vv(qs_j, qe_i), r_gap = absdiff_vv(r_j, r_i);
           // (at q_gap == 0 / r_gap == 0 either limit passes: the sides need no "or equal")
-          const uint32_t lim_q = qs_j < qe_i ? fifth32 : gap32;
-          const uint32_t lim_r = ((r_j > r_i) != minus) ? gap32 : fifth32;
+          const uint32_t lim_q = qs_j < qe_i ? fifth_v : gap_v;
+          const uint32_t lim_r = ((r_j > r_i) != minus) ? gap_v : fifth_v;
           const bool ok = inw && q_gap <= lim_q && r_gap <= lim_r;
           const uint32_t qa = q_gap << 8, ra = r_gap << 8;  // (their squares: the gaps' squares << 16; garbage when !ok)
-          uint64_t key = (uint64_t)qa * qa + ((uint64_t)ra * ra + (KEY_BIT | (uint64_t)(j - i)));
+          const uint64_t add = ((uint64_t)key_hi << 32) | off;
+          uint64_t key = (uint64_t)qa * qa + ((uint64_t)ra * ra + add);
           key = ok ? key : KEY_INF;
           cnt += ok ? 1u : 0u;
-          j += in ? 1u : 0u;
+          const uint32_t step = in ? 1u : 0u;
+          off += step;
+          sl = (sl + (step << 2)) & (BIGW * 4u - 1u);
           double t = __longlong_as_double((long long)key);
 #pragma unroll
           for (int c = 0; c < KC; ++c) {  // (the list entry is updated in place: no register copies at the loop's back edge)
@@ -1928,6 +1937,7 @@ __global__ __launch_bounds__(64) void chain_walk_kernel(uint32_t n_blocks, const
             t = hi;
           }
         }
+        const uint32_t j = i + off;
         nv = cnt < (uint32_t)KC + 1u ? cnt : (uint32_t)KC + 1u;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {

@@ -418,8 +418,13 @@ constexpr int LABEL_CAP = (int)(WALK_CHUNK + BIG_UNIT);  // a chunk holds fewer 
 // instructions per 64 elements, most of them nearly empty, and the texture path was what the kernel waited for (SQ counters).
 // The head of every element goes through LDS as well and is written in element order.  Longer chunks take the old path.
 constexpr int LABEL_FAST = 1536;
-static_assert(LABEL_FAST * (2 + 2 + 5 * 4) >= LABEL_CAP * 2, "the two layouts share one LDS buffer");
-__global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, const SpecBlock* __restrict__ chunks,
+constexpr int LABEL_NT = 512;
+static_assert(LABEL_FAST * (2 + 2 + 3 * 4) >= LABEL_CAP * 2, "the two layouts share one LDS buffer");
+// NT threads per chunk; MB: the matches / block-length columns exist (a weighted identity is asked for).  Round 6: 512 threads
+// with three elements each instead of 256 with six (114 registers, 36 KB of LDS: four work-groups of four wavefronts per CU,
+// and the kernel waited for its loads 76 % of the time) and no LDS for the two columns nobody reads under the CLI defaults.
+template <int NT, bool MB>
+__global__ __launch_bounds__(NT) void chain_label_kernel(uint32_t n_chunks, const SpecBlock* __restrict__ chunks,
                                                          const uint32_t* __restrict__ pred,
                                                          const uint32_t* __restrict__ s_qs, const uint32_t* __restrict__ s_qe,
                                                          const uint32_t* __restrict__ s_ts, const uint32_t* __restrict__ s_te,
@@ -432,14 +437,15 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
   // (the pair-resident path, swg_pair.hip: the chunk list's length lives on the device and s_grp is nullptr -- a HeadRec's
   // group is not read there)
   if (n_chunks_dev) n_chunks = min(n_chunks, *n_chunks_dev);
-  __shared__ uint32_t lds[LABEL_FAST * 6];  // 36,864 bytes
+  __shared__ uint32_t lds[LABEL_FAST * (MB ? 6 : 4)];  // 36,864 / 24,576 bytes
   uint16_t* succ = reinterpret_cast<uint16_t*>(lds);            // [LABEL_CAP] (long chunks) / [LABEL_FAST]
   uint16_t* l_hd = succ + LABEL_FAST;                           // head of every element, relative to the chunk
   uint32_t* l_qe = lds + LABEL_FAST;                            // (behind the two 16-bit arrays)
   uint32_t* l_ts = l_qe + LABEL_FAST;
   uint32_t* l_te = l_ts + LABEL_FAST;
-  uint32_t* l_m = l_te + LABEL_FAST;
-  uint32_t* l_b = l_m + LABEL_FAST;
+  uint32_t* l_m = MB ? l_te + LABEL_FAST : nullptr;
+  uint32_t* l_b = MB ? l_m + LABEL_FAST : nullptr;
+  if (!MB) s_m = s_b = nullptr;
   constexpr uint16_t NO = 0xffffu;
   uint32_t heads = 0;  // chains headed in this thread's elements (a statistic: all chains, passing the filter or not)
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -447,16 +453,17 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
     uint32_t len = e > b ? e - b : 0;  // 0: a long unit's place holder
     if (len >= (uint32_t)LABEL_CAP) len = 0;  // (pair-resident path: a chunk too long for this LDS layout is pair_label_long's)
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < len; k += EW) succ[k] = NO;
+    for (uint32_t k = threadIdx.x; k < len; k += NT) succ[k] = NO;
     __syncthreads();
     if (len <= (uint32_t)LABEL_FAST) {
       // every load of the chunk is requested before the first value is used (U x 7 per thread): a thread's elements one after
       // the other would be U memory round trips in a row, per phase
-      constexpr int U = LABEL_FAST / EW;
+      constexpr int U = LABEL_FAST / NT;
+      static_assert(LABEL_FAST % NT == 0, "whole rounds");
       uint32_t r_pr[U], r_qe[U], r_ts[U], r_te[U], r_m[U], r_b[U], r_qs[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = (uint32_t)u * NT + threadIdx.x;
         const uint32_t p = b + (k < len ? k : 0u);  // (clamped: a read that is not used)
         r_pr[u] = pred[p];
         r_qe[u] = s_qe[p];
@@ -468,21 +475,23 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = (uint32_t)u * NT + threadIdx.x;
         if (k < len) {
           if (r_pr[u] != NONE) succ[r_pr[u] - b] = (uint16_t)k;  // one successor per element: no two writers
           l_hd[k] = r_pr[u] != NONE ? NO : (uint16_t)k;          // (a member's entry is written by its head below)
           l_qe[k] = r_qe[u];
           l_ts[k] = r_ts[u];
           l_te[k] = r_te[u];
-          l_m[k] = r_m[u];
-          l_b[k] = r_b[u];
+          if constexpr (MB) {
+            l_m[k] = r_m[u];
+            l_b[k] = r_b[u];
+          }
         }
       }
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t k = (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = (uint32_t)u * NT + threadIdx.x;
         if (k >= len) continue;
         const uint32_t p = b + k;
         if (r_pr[u] != NONE) {  // a member: its head writes its label
@@ -498,8 +507,10 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
           qe = a > qe ? a : qe;
           ts = t0 < ts ? t0 : ts;
           te = t1 > te ? t1 : te;
-          sm += l_m[nx];
-          sb += l_b[nx];
+          if constexpr (MB) {
+            sm += l_m[nx];
+            sb += l_b[nx];
+          }
         }
         const uint32_t qs0 = r_qs[u];
         const uint64_t total_length = (uint64_t)qe - (uint64_t)qs0;  // q_max - q_min (the head has the smallest q_start)
@@ -521,32 +532,32 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
         ok_head[p] = ok ? 1 : 0;
       }
       __syncthreads();
-      for (uint32_t k = threadIdx.x; k < len; k += EW) hd[b + k] = b + l_hd[k];
+      for (uint32_t k = threadIdx.x; k < len; k += NT) hd[b + k] = b + l_hd[k];
       continue;
     }
     // (longer chunks: the values stay in memory.  The loads of LB elements per thread are requested together -- an element
     // after the other is a memory round trip each, and a chunk of the pair-resident path is a whole unit of thousands of
     // elements in ONE work-group: 35 round trips per pass and thread on S-pan, 150 us per chunk, before this was batched)
-    constexpr int LB = 8;
-    for (uint32_t k0 = 0; k0 < len; k0 += EW * LB) {
+    constexpr int LB = 2048 / NT;  // (as many loads in flight per work-group as before)
+    for (uint32_t k0 = 0; k0 < len; k0 += NT * LB) {
       uint32_t pr[LB];
 #pragma unroll
       for (int u = 0; u < LB; ++u) {
-        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = k0 + (uint32_t)u * NT + threadIdx.x;
         pr[u] = pred[b + (k < len ? k : 0u)];
       }
 #pragma unroll
       for (int u = 0; u < LB; ++u) {
-        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = k0 + (uint32_t)u * NT + threadIdx.x;
         if (k < len && pr[u] != NONE) succ[pr[u] - b] = (uint16_t)k;  // one successor per element: no two writers
       }
     }
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < len; k0 += EW * LB) {
+    for (uint32_t k0 = 0; k0 < len; k0 += NT * LB) {
       uint32_t pr[LB], v_qs[LB], v_qe[LB], v_ts[LB], v_te[LB], v_m[LB], v_b[LB];
 #pragma unroll
       for (int u = 0; u < LB; ++u) {
-        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = k0 + (uint32_t)u * NT + threadIdx.x;
         const uint32_t p = b + (k < len ? k : 0u);
         pr[u] = pred[p];
         v_qs[u] = s_qs[p];
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(EW) void chain_label_kernel(uint32_t n_chunks, cons
       }
 #pragma unroll
       for (int u = 0; u < LB; ++u) {
-        const uint32_t k = k0 + (uint32_t)u * EW + threadIdx.x;
+        const uint32_t k = k0 + (uint32_t)u * NT + threadIdx.x;
         if (k >= len) continue;
         const uint32_t p = b + k;
         if (pr[u] != NONE) {  // a member: its head writes its label
@@ -795,7 +806,11 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   bool generic = true;
   if (W.n_chunks) {
     const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
-    SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
+    if (s_m)
+      SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, true><<<(unsigned)lb, LABEL_NT, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
+                                                                        s_m, s_b, s_grp, min_len, min_ident, hd, ok_head, head_rec, n_heads));
+    else
+      SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, false><<<(unsigned)lb, LABEL_NT, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
                                                                         s_m, s_b, s_grp, min_len, min_ident, hd, ok_head, head_rec, n_heads));
     SWG_KERNEL_CHECK(ctx);
     only = W.big_member;
@@ -933,12 +948,17 @@ int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunk
                       unsigned long long* n_heads, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list) {
   if (cap_chunks == 0) return SWG_OK;
   const uint64_t lb = cap_chunks < (uint64_t)ctx->num_cu * 32 ? cap_chunks : (uint64_t)ctx->num_cu * 32;
-  SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<<<(unsigned)lb, EW, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+  if (s_m)
+    SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, true><<<(unsigned)lb, LABEL_NT, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
+                                                                             nullptr, min_len, min_ident, hd, ok_head, rec, n_heads,
+                                                                             n_chunks_dev));
+  else
+    SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, false><<<(unsigned)lb, LABEL_NT, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
                                                                              nullptr, min_len, min_ident, hd, ok_head, rec, n_heads,
                                                                              n_chunks_dev));
   SWG_KERNEL_CHECK(ctx);
   if (cap_long) {
-    const unsigned lg = cap_long < (uint32_t)ctx->num_cu ? cap_long : (unsigned)ctx->num_cu;
+    const unsigned lg = cap_long < (uint32_t)ctx->num_cu * 2 ? cap_long : (unsigned)ctx->num_cu * 2;  // (32 registers: two work-groups of 1,024 per CU)
     SWG_LAUNCH(ctx, "chain_label_long", chain_label_long_kernel<<<lg, 1024, 0, ctx->stream>>>(cap_long, n_long_dev, long_list, chunks, pred, s_qs, s_qe, s_ts,
                                                                                   s_te, s_m, s_b, min_len, min_ident, hd, ok_head, rec, n_heads));
     SWG_KERNEL_CHECK(ctx);
