@@ -529,7 +529,9 @@ __global__ __launch_bounds__(NT) void chain_label_kernel(uint32_t n_chunks, cons
             rec[p] = hr;
           }
         }
-        ok_head[p] = ok ? 1 : 0;
+        // (pair-resident path, s_grp == nullptr: bits 1 and 2 say whether the chain's query / target span is positive -- what
+        // pair_finish's closed-form sweep asks of a passing chain, so that it ranks the chains without reading their records)
+        ok_head[p] = ok ? (uint8_t)(s_grp ? 1u : 1u | (qs0 < qe ? 2u : 0u) | (ts < te ? 4u : 0u)) : (uint8_t)0;
       }
       __syncthreads();
       for (uint32_t k = threadIdx.x; k < len; k += NT) hd[b + k] = b + l_hd[k];
@@ -610,7 +612,9 @@ __global__ __launch_bounds__(NT) void chain_label_kernel(uint32_t n_chunks, cons
             rec[p] = hr;
           }
         }
-        ok_head[p] = ok ? 1 : 0;
+        // (pair-resident path, s_grp == nullptr: bits 1 and 2 say whether the chain's query / target span is positive -- what
+        // pair_finish's closed-form sweep asks of a passing chain, so that it ranks the chains without reading their records)
+        ok_head[p] = ok ? (uint8_t)(s_grp ? 1u : 1u | (qs0 < qe ? 2u : 0u) | (ts < te ? 4u : 0u)) : (uint8_t)0;
       }
     }
   }
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(1024) void chain_label_long_kernel(uint32_t cap_lon
           rec[p].grp = 0;
         }
       }
-      ok_head[p] = ok ? 1 : 0;
+      ok_head[p] = ok ? (uint8_t)(1u | (hr.qs < hr.qe ? 2u : 0u) | (hr.ts < hr.te ? 4u : 0u)) : (uint8_t)0;  // (span bits: see chain_label_kernel)
     }
   }
 #pragma unroll

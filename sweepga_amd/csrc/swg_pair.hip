@@ -387,6 +387,7 @@ struct PairSortArgs {
   PairInfo* info;
   SpecBlock* chunks;
   uint32_t cap_chunks;
+  int chunks_by_place;  // the runs are in input order (a plan over runs): a pair's chunks go to slots that follow from its place
   uint32_t* long_list;  // indices (into chunks) of the chunks of LABEL_CAP_ELEMS members and more
   uint32_t cap_long;
   PairCounters* C;
@@ -399,7 +400,13 @@ struct PairSortArgs {
 // emit_chunks: the chunk list of the walk from the per-cell first unit starts (cellmin; one thread).  The first unit of every
 // cell opens a chunk, and so does the first '-' member; a chunk of LABEL_CAP_ELEMS members or more (a long unit) is also put on
 // the list of the chunks that chain_label_long_kernel labels.
-__device__ void emit_chunks(const PairSortArgs& A, uint32_t a, uint32_t m, uint32_t m_plus, const uint32_t* cellmin, int n_cell) {
+// Round 6: a pair's chunks take a stretch of the list that follows from its place in the input -- slot a / PAIR_CELL + 2 * (the
+// run's index): runs are in input order, a pair of n records has at most n / PAIR_CELL + 2 chunks, and the next pair's stretch
+// begins at least that far on -- instead of a returning atomic on one counter at the end of every pair's work-group (its round
+// trip was most of the 5.8 us a pair spent here, alone on its CU).  The list is zeroed per call and the kernels that walk it skip
+// empty descriptors; its length is its capacity.  (Inputs grouped through the hash table -- at most 65,536 records -- number
+// their pairs by atomics: no order to rely on, the counter stays.)
+__device__ void emit_chunks(const PairSortArgs& A, uint32_t rk_run, uint32_t a, uint32_t m, uint32_t m_plus, const uint32_t* cellmin, int n_cell) {
   uint32_t prev = NONE, count = 0, n_long = 0, prev2 = NONE;
   const bool mp_pending = m_plus > 0 && m_plus < m;
   auto for_starts = [&](auto&& f) {
@@ -421,7 +428,7 @@ __device__ void emit_chunks(const PairSortArgs& A, uint32_t a, uint32_t m, uint3
     prev2 = v;
   });
   if (prev2 != NONE && m - prev2 >= LABEL_CAP_ELEMS) ++n_long;
-  const uint32_t slot = atomicAdd(&A.C->n_chunks, count);
+  const uint32_t slot = A.chunks_by_place ? a / PAIR_CELL + 2u * rk_run : atomicAdd(&A.C->n_chunks, count);
   uint32_t lslot = n_long ? atomicAdd(&A.C->n_long, n_long) : 0u;
   if (slot + count > A.cap_chunks || (n_long && lslot + n_long > A.cap_long)) {  // (the capacities are upper bounds: not reached)
     atomicOr(&A.C->flags, PF_FALLBACK);
@@ -1068,7 +1075,7 @@ __device__ __forceinline__ void pair_sort_body(const PairSortArgs& A, const uint
     PT_STAMP(11);
   }
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
-  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, NCELL);
+  if (tid == 0) emit_chunks(A, rk_run, a, m, m_plus, cellmin, NCELL);
   PT_STAMP(12);
 }
 
@@ -1466,7 +1473,7 @@ __device__ __forceinline__ void pair_sort_xl_body(const PairSortArgs& A, const u
     PT_STAMP(8);
   }
   if (A.check_degenerate && __any(degenerate) && (tid & 63) == 0) atomicOr(&A.C->flags, PF_FALLBACK);
-  if (tid == 0) emit_chunks(A, a, m, m_plus, cellmin, (int)PAIR_XL_CELLS);
+  if (tid == 0) emit_chunks(A, rk_run, a, m, m_plus, cellmin, (int)PAIR_XL_CELLS);
   PT_STAMP(9);
 }
 
@@ -1772,11 +1779,6 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-        if (ok[u]) hr[u] = A.rec[a + p];
-      }
       bool kept[U];
       if (given) {  // a chain's flag sits at its place in the pair's stretch of the chain table: its rank among the passing chains
         uint64_t okp = 0;
@@ -1804,7 +1806,7 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         if (!given) kept[u] = false;
         if (ok[u]) {
-          const bool hq = hr[u].qs < hr[u].qe, ht = hr[u].ts < hr[u].te;
+          const bool hq = (ok[u] & 2u) != 0, ht = (ok[u] & 4u) != 0;  // (the labelling left the two span tests in the flag byte)
           if (!given) kept[u] = exact ? (all_q || hq) && (all_t || ht) : hq && ht;
           if (p < m_plus) ++c0; else ++c1;
           cq += hq ? 1u : 0u;
@@ -1812,6 +1814,12 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
           cp += (kept[u] && p < m_plus) ? 1u : 0u;
         }
         packed |= (uint64_t)(kept[u] ? 1u : 0u) << (16 * u);
+      }
+      // the records of the kept '+' chains (the list of the inversion capture): requested here, used behind the scan
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
+        if (kept[u] && p < m_plus) hr[u] = A.rec[a + p];
       }
       // one scan for the four rows (NT <= 1024 < 2^16)
       uint64_t tot;
@@ -2674,7 +2682,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   PairInfo* info = swg_alloc<PairInfo>(ctx, n_runs);
   PairSum* sum = swg_alloc<PairSum>(ctx, n_runs);
   uint32_t* n_out_pair = swg_alloc<uint32_t>(ctx, n_runs);
-  const uint32_t cap_chunks = n / PAIR_CELL + 2 * n_runs + 16;
+  const uint32_t cap_chunks = n / PAIR_CELL + 2 * n_runs + 16;  // (emit_chunks: a pair's stretch of the list follows from its place)
   SpecBlock* chunks = swg_alloc<SpecBlock>(ctx, cap_chunks);
   const uint32_t cap_long = n / LABEL_CAP_ELEMS + 1;
   uint32_t* long_list = swg_alloc<uint32_t>(ctx, cap_long);
@@ -2690,6 +2698,10 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
     SWG_HIP(ctx, hipMemsetAsync(status_out, 0, n, st));
   }
   SWG_HIP(ctx, hipMemsetAsync(n_out_pair, 0, (size_t)n_runs * sizeof(uint32_t), st));
+  if (!by_hash) {  // (emit_chunks: fixed slots, the list's length is its capacity)
+    SWG_HIP(ctx, hipMemsetAsync(chunks, 0, (size_t)cap_chunks * sizeof(SpecBlock), st));
+    SWG_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&C->n_chunks), (int)cap_chunks, 1, st));
+  }
   PairSortArgs SA{};
   SA.q_id = r->q_id; SA.t_id = r->t_id; SA.q_start = r->q_start; SA.q_end = r->q_end; SA.t_start = r->t_start; SA.t_end = r->t_end;
   SA.matches = r->matches; SA.block_len = r->block_len; SA.identity = r->identity; SA.strand = r->strand;
@@ -2701,7 +2713,7 @@ int scaffold_stage_pairs(swg_ctx* ctx, const swg_records* r, const swg_config* c
   SA.perm = perm;
   SA.orig = plan_in->orig;
   SA.code = code; SA.s_qs = s_qs; SA.s_qe = s_qe; SA.s_ts = s_ts; SA.s_te = s_te; SA.s_m = need_wid ? s_m : nullptr; SA.s_b = need_wid ? s_b : nullptr; SA.s_idx = s_idx; SA.pred = pred;
-  SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
+  SA.info = info; SA.chunks = chunks; SA.cap_chunks = cap_chunks; SA.chunks_by_place = by_hash ? 0 : 1; SA.long_list = long_list; SA.cap_long = cap_long; SA.C = C; SA.gl_first = gl_first; SA.seq_genome_last = r->seq_genome_last;
   if (by_hash) {
     for (int c = 2; c >= 0; --c) {
       if (!ncls[c]) continue;
