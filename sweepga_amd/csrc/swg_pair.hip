@@ -2526,7 +2526,6 @@ namespace {
 // The pairs of the input: runs of equal (q_id, t_id) (large inputs, grouped by pair as an aligner writes them), or through a
 // hash table (small inputs, grouped or not).  valid = 0: the pair-resident stage does not apply.
 int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPlan* plan) {
-  (void)cfg;
   *plan = PairPlan{};
   if (!pair_path_wanted()) return SWG_OK;
   const uint64_t n64 = r->n;
@@ -2536,15 +2535,26 @@ int pair_plan(swg_ctx* ctx, const swg_records* r, const swg_config* cfg, PairPla
   static const bool dbg = getenv("SWG_DEBUG") != nullptr;
   const swg_arena_mark mark0 = swg_arena_save(ctx);
   const bool by_hash = n <= PAIR_HASH_MAX;
-  // How many pairs the path takes.  Its cost per pair -- a work-group per kernel, a returning atomic for the pair's chunks --
-  // is nothing next to a pair of thousands of records and everything next to a pair of ten.  Measured on 10^8 records of 100
-  // genomes x C chromosomes (round 6, tools/order_shapes.py; default / --scaffold-filter 1:1 flags, pair path against the
-  // global-sort stage): C = 20 (198,000 pairs of 505) 11.9 / 17.2 against 17.7 / 25.1 ms; C = 40 (252 records) 13.4 / 19.5
-  // against 17.8 / 25.2; C = 60 (168) 17.1 / 24.5 against 18.9 / 27.1; C = 100 (101) 26.1 against 19.7.  So: pairs of 192 records
-  // or more on average (round 5 drew the line at 1,536: its pair kernels bumped five statistics counters of ONE cache line
-  // per pair, ~25 ns of serialised same-address atomics each -- now summed per pair afterwards, pair_totals_kernel), or any
-  // 8,192 pairs.  SWG_PAIR_MIN_AVG overrides the average (experiments).
-  static const uint32_t per_pair = getenv("SWG_PAIR_MIN_AVG") && atoi(getenv("SWG_PAIR_MIN_AVG")) > 0 ? (uint32_t)atoi(getenv("SWG_PAIR_MIN_AVG")) : 192u;
+  // How many pairs the path takes.  Its cost per pair -- a work-group per kernel -- is nothing next to a pair of thousands of
+  // records and everything next to a pair of ten.  Measured on 10^8 records of 100 genomes x C chromosomes (round 6,
+  // tools/order_shapes.py <n> <flags> <C,...>, pair path against the global-sort stage).  CLI defaults: C = 20 (198,000 pairs of
+  // 505 records) 8.5 against 17.7 ms, C = 40 (252) 10.7 / 17.2, C = 60 (168) 13.1 / 18.4, C = 100 (101) 17.7 / 19.4, C = 200 (50)
+  // 29.4 / 22.1.  With a scaffold filter that has limits, a rescue or a mapping sweep in front (their per-pair kernels: the
+  // segment sorts, pair_chains, the rescue's bins): C = 60 24.5 / 27.1, C = 100 31.4 / 27.5 (c5), 47.2 / 39.4 (full).  So: pairs of
+  // 96 records or more on average under the plain flags, 192 otherwise, or any 8,192 pairs.  (Round 5 drew the line at 1,536: its
+  // pair kernels bumped five statistics counters of ONE cache line per pair -- now summed afterwards, pair_totals_kernel -- and
+  // took a returning atomic per pair for the chunk list -- now slots that follow from the pair's place, emit_chunks.)
+  // SWG_PAIR_MIN_AVG overrides the average (experiments).
+  bool plain = cfg != nullptr;
+  if (cfg) {
+    const bool sf_limited = cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_ONE || cfg->scaffold_filter_mode == SWG_MODE_ONE_TO_MANY ||
+                            cfg->scaffold_max_per_query != 0 || cfg->scaffold_max_per_target != 0;
+    const bool mf_limited = cfg->mapping_filter_mode == SWG_MODE_ONE_TO_ONE || cfg->mapping_filter_mode == SWG_MODE_ONE_TO_MANY ||
+                            cfg->mapping_max_per_query != 0 || cfg->mapping_max_per_target != 0;
+    plain = !sf_limited && !mf_limited && (cfg->scaffolds_only || cfg->scaffold_max_deviation == 0);
+  }
+  static const uint32_t per_pair_env = getenv("SWG_PAIR_MIN_AVG") && atoi(getenv("SWG_PAIR_MIN_AVG")) > 0 ? (uint32_t)atoi(getenv("SWG_PAIR_MIN_AVG")) : 0u;
+  const uint32_t per_pair = per_pair_env ? per_pair_env : (plain ? 96u : 192u);
   const uint32_t cap = by_hash ? (n < 8192u ? n : 8192u) : (n / per_pair > 8192u ? n / per_pair : 8192u);
   uint32_t tsize = 1;
   while (tsize < 2 * (by_hash ? n : cap)) tsize <<= 1;  // (the hash grouping enters every record's pair: room for n of them)

@@ -1,6 +1,7 @@
 """The default flags on S-pan's records in orders and shapes away from the bench workload (one line each: ms per call, the path
 taken, the longest kernels): pair-major (the bench), shuffled, by query in query order with the targets interleaved (what wfmash
-writes), and 100 genomes x 20 chromosomes (198,000 sequence pairs).  Through gpurun:  python3 tools/order_shapes.py [mappings]"""
+writes), and 100 genomes x 20 chromosomes (198,000 sequence pairs).  Through gpurun:  python3 tools/order_shapes.py [mappings]
+[flag sets] [chromosome counts: only those shapes]"""
 import ctypes as C
 import os
 import sys
@@ -44,6 +45,13 @@ def run(tag, cols, G):
         print(tag, p, round(best * 1e3, 2), "ms", path, "kept", int((status != 0).sum()), [(k, v[0], round(v[1], 2)) for k, v in top], flush=True)
 
 
+if len(sys.argv) > 3:   # only the many-pairs shapes: 100 genomes x C chromosomes for every C named (how the admission rule is measured:
+    for c in (int(x) for x in sys.argv[3].split(",")):   # run once as it is and once with SWG_PAIR_MIN_AVG=1 / =100000)
+        cols, _ = bench.gen_shard(torch, n, 100, 2025, device, chroms=c)
+        run(f"100x{c}", cols, 100)
+        del cols
+        torch.cuda.empty_cache()
+    sys.exit(0)
 cols, _ = bench.gen_shard(torch, n, 100, 2025, device)
 run("pair-major", cols, 100)
 key = cols["q_id"].to(torch.int64) * (1 << 32) + cols["q_start"].to(torch.int64)
