@@ -595,6 +595,12 @@ __device__ __forceinline__ bool overlap_exceeds(uint64_t as, uint64_t ae, uint64
 constexpr int CCAP = 128;     // candidate carry-ins kept in LDS (17 KB per work-group in all: 8 resident per CU)
 constexpr int STAR_MIN = 32;  // fewer carry-ins than this: no pruning (nothing to gain on sparse data)
 
+#ifdef SWG_TILE_TIMING  // (a build knob, SWG_DEFINES of sweepga_amd/build.py) the phases of sweep_tile_k1 in 100 MHz ticks, summed over tiles
+__device__ unsigned long long g_tile_t[8];
+#define TT_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_tile_t[k], t_ - tt_last); tt_last = t_; } } while (0)
+#else
+#define TT_STAMP(k) do { } while (0)
+#endif
 template <int TBT>
 __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
   __shared__ uint64_t sx[TBT];    // composite start of begin q
@@ -612,6 +618,9 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
 
   const uint32_t tile_id = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SWG_TILE_TIMING
+  unsigned long long tt_last = wall_clock64();
+#endif
   const uint64_t p = (uint64_t)tile_id * TBT + tid;
   const bool valid = p < a.n;
   uint64_t X = ~0ull, EE = 0, KEY = 0;
@@ -765,8 +774,10 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
   const bool cc_complete = cc_in_lds && !have_star;  // the LDS list holds every carry-in of the tile
   const uint32_t n_batches = 2 + (cc_in_lds ? (n_cc ? 1u : 0u) : (c_end - c_begin + TBT - 1) / TBT);
   const bool pass2 = a.thr < 1.0;
+  TT_STAMP(0);  // loads, prefix maxima, carry-ins
 
   for (uint32_t batch = 0; batch < n_batches; ++batch) {
+    if (batch) TT_STAMP(batch < 3 ? batch : 3);  // 1: the start points, 2: the tile's own ends, 3: the carry-ins' ends
     // ---- this thread's evaluation point: coordinate PX, last own begin at or before it Q0
     bool eval;
     uint64_t PX;
@@ -908,6 +919,7 @@ __global__ __launch_bounds__(TBT) void sweep_tile_k1_kernel(TileArgs a) {
       }
     }
   }
+  TT_STAMP(4);  // the last batch
 }
 
 // ---- 2 <= k < inf ---------------------------------------------------------------------------------------------------
@@ -1940,6 +1952,16 @@ int swg_sweep_axis(swg_ctx* ctx, const swg_axis_input& in, uint64_t k, double th
       SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<TB><<<ntiles, TB, 0, st>>>(ta));
     else
       SWG_LAUNCH(ctx, "sweep_tile_k1", sweep_tile_k1_kernel<2 * TB><<<ntiles, 2 * TB, 0, st>>>(ta));
+#ifdef SWG_TILE_TIMING
+    {
+      (void)hipStreamSynchronize(st);
+      unsigned long long ht[8], z[8] = {0};
+      (void)hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_tile_t), sizeof ht);
+      fprintf(stderr, "[swg] sweep_tile_k1 phases (%u tiles of %u; 100 MHz ticks summed over tiles): loads+carry %llu, starts %llu, own ends %llu, carried ends %llu, last %llu\n",
+              (unsigned)ntiles, (unsigned)tile_size, ht[0], ht[1], ht[2], ht[3], ht[4]);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_t), z, sizeof z);
+    }
+#endif
   } else {
     static const bool no_prune = getenv("SWG_KN_PLAIN") != nullptr;  // test knob: every tile through the plain kernel
     if (k <= (uint64_t)KSTAR_MAX && !no_prune) {
