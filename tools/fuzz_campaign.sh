@@ -32,7 +32,7 @@ run gpu_nodrop SWG_GROUP_FUSED=0 SWG_SORT_DROP=0    python3 tests/fuzz/fuzz_gpu.
 run gpu_slots  SWG_GROUP_FUSED=0 SWG_SLOTS=1        python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 21
 run gpu_deepg  SWG_GROUP_FUSED=0 SWG_CHAIN_DEEP=1 SWG_CAND_GENERIC=1 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 22
 run gpu_deepw  SWG_GROUP_FUSED=0 SWG_CHAIN_DEEP=1    python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 23 --wide-gaps
-run gpu_plain  SWG_WALK_PLAIN=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 31
+run gpu_plain  SWG_WALK_PLAIN=1   python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 32
 run gpu_stream SWG_STREAM_CHUNK=700 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 19 --grouped
 run seams      X=1                python3 tests/fuzz/fuzz_seams.py --minutes $MIN --seed 15
 run cli        X=1                python3 tests/fuzz/fuzz_cli.py --minutes $MIN --seed 16
@@ -44,4 +44,5 @@ run large_pm   X=1                python3 tests/fuzz/fuzz_large.py --seed 24 --p
 run large_fused  SWG_SEG_SWEEP=1  python3 tests/fuzz/fuzz_large.py --seed 28 --pair-major
 run large_stream SWG_SEG_STREAM=1 python3 tests/fuzz/fuzz_large.py --seed 29 --pair-major
 run large_lone   SWG_SEG_LONE=1   python3 tests/fuzz/fuzz_large.py --seed 30 --pair-major
+run large_plain  SWG_WALK_PLAIN=1  python3 tests/fuzz/fuzz_large.py --seed 33 --pair-major   # (the fused walk's per-lane lists on chunks of thousands of members)
 run gpu_ring   SWG_RING_CHUNK=512 python3 tests/fuzz/fuzz_gpu.py --minutes $MIN --seed 31
