@@ -1707,10 +1707,11 @@ __global__ __launch_bounds__(NT) void pair_chains_kernel(PairChainArgs A) {
 // "both spans positive", and runs once more under the exact rule if it met such a chain.
 // KP: the kept '+' chains of a pair that are staged in LDS for the inversion capture (a longer list is searched in memory).
 template <int NT, int KP>
-__global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
+__global__ __launch_bounds__(NT, NT >= 512 ? 4 : 1) void pair_finish_kernel(PairFinishArgs A) {  // (large class: two work-groups per CU)
   constexpr int U = 4;  // positions per thread and round: their loads are requested together
   __shared__ uint32_t ws[NT / 64 + 1];
   __shared__ uint64_t ws64[NT / 64 + 1];
+  __shared__ uint64_t ws64n[2 * (NT / 64 + 1)];  // (the ranking's scan of two packed words)
   __shared__ uint32_t l_all[4 * KP];  // the kept '+' chains for the inversion capture, then the rescue's staged members
   uint32_t* const l_qs = l_all;
   uint32_t* const l_qe = l_all + KP;
@@ -1769,40 +1770,90 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
     *tot_out = tot;
     return off + inc - packed;
   };
+  // the same for G packed words at once (4 G rows of a round: one pair of barriers whatever G is)
+  auto row_scan_n = [&](auto g_c, const uint64_t (&packed)[decltype(g_c)::value], uint64_t (&ex)[decltype(g_c)::value],
+                        uint64_t (&tot)[decltype(g_c)::value]) {
+    constexpr int G = decltype(g_c)::value;
+    uint64_t inc[G];
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int g = 0; g < G; ++g) inc[g] = packed[g];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint64_t t = __shfl_up(inc[g], d, 64);
+        if (lane >= d) inc[g] += t;
+      }
+    }
+    if (NT == 64) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        tot[g] = __shfl(inc[g], 63, 64);
+        ex[g] = inc[g] - packed[g];
+      }
+      return;
+    }
+    lds_barrier();
+    if (lane == 63) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) ws64n[g * (NT / 64 + 1) + w] = inc[g];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      uint64_t off = 0, t = 0;
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) {
+        const uint64_t x = ws64n[g * (NT / 64 + 1) + k];
+        off += k < w ? x : 0ull;
+        t += x;
+      }
+      tot[g] = t;
+      ex[g] = off + inc[g] - packed[g];
+    }
+  };
+  // Round 6: the large class ranks 8 rows of NT positions per round instead of 4 (half the rounds, half the barriers, twice the
+  // loads in flight: a pair of 10,000 members was five rounds of dependent flag load -> scan -> store)
+  constexpr int US = NT >= 512 ? 8 : 4;  // rows per round
+  constexpr int GS = US / 4;             // packed words per scan
   auto sweep = [&](const bool exact) {
     uint32_t kept_before = 0, ok_before = 0, c0 = 0, c1 = 0, cq = 0, cd = 0, cp = 0;
-    for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
-      uint8_t ok[U];
-      HeadRec hr[U];
+    for (uint32_t p0 = 0; p0 < m; p0 += NT * US) {
+      uint8_t ok[US];
+      uint32_t h_qs[US], h_qe[US], h_ts[US];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < US; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         ok[u] = p < m ? A.ok_head[a + p] : (uint8_t)0;
       }
-      bool kept[U];
+      bool kept[US];
       if (given) {  // a chain's flag sits at its place in the pair's stretch of the chain table: its rank among the passing chains
-        uint64_t okp = 0;
+        uint64_t okp[GS], ex_ok[GS], tot_ok[GS];
 #pragma unroll
-        for (int u = 0; u < U; ++u) okp |= (uint64_t)(ok[u] ? 1u : 0u) << (16 * u);
-        uint64_t tot_ok;
-        const uint64_t ex_ok = row_scan(okp, &tot_ok);
+        for (int g = 0; g < GS; ++g) okp[g] = 0;
+#pragma unroll
+        for (int u = 0; u < US; ++u) okp[u / 4] |= (uint64_t)(ok[u] ? 1u : 0u) << (16 * (u % 4));
+        row_scan_n(std::integral_constant<int, GS>{}, okp, ex_ok, tot_ok);
         uint32_t rb = ok_before;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < US; ++u) {
           const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
           kept[u] = false;
           if (ok[u]) {
-            const uint32_t c_pos = rb + (uint32_t)((ex_ok >> (16 * u)) & 0xffffu);
+            const uint32_t c_pos = rb + (uint32_t)((ex_ok[u / 4] >> (16 * (u % 4))) & 0xffffu);
             const uint32_t c_all = plus_first0 ? c_pos : (p >= m_plus ? c_pos - g_nP : c_pos + g_nM);
             kept[u] = A.kept_in[g_cb + c_all] != 0;
           }
-          rb += (uint32_t)((tot_ok >> (16 * u)) & 0xffffu);
+          rb += (uint32_t)((tot_ok[u / 4] >> (16 * (u % 4))) & 0xffffu);
         }
         ok_before = rb;
       }
-      uint64_t packed = 0;  // four 16-bit counters: kept chains of row u among the threads before this one
+      uint64_t packed[GS], ex[GS], tot[GS];  // 16-bit counters: kept chains of row u among the threads before this one
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int g = 0; g < GS; ++g) packed[g] = 0;
+#pragma unroll
+      for (int u = 0; u < US; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
         if (!given) kept[u] = false;
         if (ok[u]) {
@@ -1813,35 +1864,39 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
           cd += (given || (hq && ht)) ? 0u : 1u;
           cp += (kept[u] && p < m_plus) ? 1u : 0u;
         }
-        packed |= (uint64_t)(kept[u] ? 1u : 0u) << (16 * u);
+        packed[u / 4] |= (uint64_t)(kept[u] ? 1u : 0u) << (16 * (u % 4));
       }
       // the records of the kept '+' chains (the list of the inversion capture): requested here, used behind the scan
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < US; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-        if (kept[u] && p < m_plus) hr[u] = A.rec[a + p];
+        h_qs[u] = h_qe[u] = h_ts[u] = 0;
+        if (kept[u] && p < m_plus) {
+          const HeadRec* hp = A.rec + a + p;
+          h_qs[u] = hp->qs;
+          h_qe[u] = hp->qe;
+          h_ts[u] = hp->ts;
+        }
       }
-      // one scan for the four rows (NT <= 1024 < 2^16)
-      uint64_t tot;
-      const uint64_t ex = row_scan(packed, &tot);
-      (void)0;
+      // one scan for the rows (NT <= 1024 < 2^16)
+      row_scan_n(std::integral_constant<int, GS>{}, packed, ex, tot);
       uint32_t row_base = kept_before;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < US; ++u) {
         const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
-        const uint32_t r = row_base + (uint32_t)((ex >> (16 * u)) & 0xffffu);
+        const uint32_t r = row_base + (uint32_t)((ex[u / 4] >> (16 * (u % 4))) & 0xffffu);
         if (p < m) A.head_num[a + p] = kept[u] ? r : (ok[u] ? NEVER : NONE);  // (every position: the members look their head's entry up)
         if (kept[u] && p < m_plus) {  // '+' chains come first: r is the chain's slot in the list
-          A.f_qs[a + r] = hr[u].qs;
-          A.f_qe[a + r] = hr[u].qe;
-          A.f_ts[a + r] = hr[u].ts;
+          A.f_qs[a + r] = h_qs[u];
+          A.f_qe[a + r] = h_qe[u];
+          A.f_ts[a + r] = h_ts[u];
           if (r < (uint32_t)KP) {
-            l_qs[r] = hr[u].qs;
-            l_qe[r] = hr[u].qe;
-            l_ts[r] = hr[u].ts;
+            l_qs[r] = h_qs[u];
+            l_qe[r] = h_qe[u];
+            l_ts[r] = h_ts[u];
           }
         }
-        row_base += (uint32_t)((tot >> (16 * u)) & 0xffffu);
+        row_base += (uint32_t)((tot[u / 4] >> (16 * (u % 4))) & 0xffffu);
       }
       kept_before = row_base;
     }
@@ -1880,18 +1935,18 @@ __global__ __launch_bounds__(NT) void pair_finish_kernel(PairFinishArgs A) {
   FT_STAMP(0);
   // ---- anchors: the members of kept chains (paf_filter.rs:517-528)
   uint32_t out = 0;
-  for (uint32_t p0 = 0; p0 < m; p0 += NT * U) {
-    uint32_t h[U], idx[U], r[U];
+  for (uint32_t p0 = 0; p0 < m; p0 += NT * US) {
+    uint32_t h[US], idx[US], r[US];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < US; ++u) {
       const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
       h[u] = p < m ? A.hd[a + p] : a;
       idx[u] = (p < m && !A.fin) ? A.s_idx[a + p] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = A.head_num[h[u]];
+    for (int u = 0; u < US; ++u) r[u] = A.head_num[h[u]];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < US; ++u) {
       const uint32_t p = p0 + (uint32_t)u * NT + (uint32_t)tid;
       uint32_t an = 0;
       if (p < m && r[u] < NEVER) {
