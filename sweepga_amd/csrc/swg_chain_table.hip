@@ -620,7 +620,16 @@ __global__ __launch_bounds__(NT) void chain_label_kernel(uint32_t n_chunks, cons
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
-  if ((threadIdx.x & 63) == 0 && heads) atomicAdd(n_heads, (unsigned long long)heads);
+  // one atomic per work-group (a statistic on ONE address: per wavefront it was 65,536 serialised atomics per call, and what
+  // made a finer grid -- better balance over chunks of uneven length -- slower instead of faster)
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = heads;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t all = 0;
+    for (int w = 0; w < NT / 64; ++w) all += lds[w];
+    if (all) atomicAdd(n_heads, (unsigned long long)all);
+  }
 }
 // The same for ONE chunk of any length per work-group (pair-resident path, swg_pair.hip: the long units of dense chromosome
 // pairs): heads by pointer jumping in memory, the aggregates accumulated by atomics in the head's own HeadRec slot (the box in
@@ -809,7 +818,8 @@ int chain_table_build(swg_ctx* ctx, const swg_records* r, const uint8_t* alive, 
   const uint8_t* span = nullptr;  // ... and the 1024-element spans that hold any of it
   bool generic = true;
   if (W.n_chunks) {
-    const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * 32 ? W.n_chunks : (uint64_t)ctx->num_cu * 32;
+    static const uint64_t lper = getenv("SWG_LABEL_BLOCKS") ? (uint64_t)atoi(getenv("SWG_LABEL_BLOCKS")) : 128;  // (work-groups per CU in the grid)
+    const uint64_t lb = W.n_chunks < (uint64_t)ctx->num_cu * lper ? W.n_chunks : (uint64_t)ctx->num_cu * lper;
     if (s_m)
       SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, true><<<(unsigned)lb, LABEL_NT, 0, st>>>((uint32_t)W.n_chunks, W.chunks, pred, s_qs, s_qe, s_ts, s_te,
                                                                         s_m, s_b, s_grp, min_len, min_ident, hd, ok_head, head_rec, n_heads));
@@ -951,7 +961,8 @@ int pair_label_launch(swg_ctx* ctx, uint32_t cap_chunks, const uint32_t* n_chunk
                       const uint32_t* s_b, uint64_t min_len, double min_ident, uint32_t* hd, uint8_t* ok_head, HeadRec* rec,
                       unsigned long long* n_heads, uint32_t cap_long, const uint32_t* n_long_dev, const uint32_t* long_list) {
   if (cap_chunks == 0) return SWG_OK;
-  const uint64_t lb = cap_chunks < (uint64_t)ctx->num_cu * 32 ? cap_chunks : (uint64_t)ctx->num_cu * 32;
+  static const uint64_t lper = getenv("SWG_LABEL_BLOCKS") ? (uint64_t)atoi(getenv("SWG_LABEL_BLOCKS")) : 128;  // (work-groups per CU in the grid)
+  const uint64_t lb = cap_chunks < (uint64_t)ctx->num_cu * lper ? cap_chunks : (uint64_t)ctx->num_cu * lper;
   if (s_m)
     SWG_LAUNCH(ctx, "chain_label", chain_label_kernel<LABEL_NT, true><<<(unsigned)lb, LABEL_NT, 0, ctx->stream>>>(cap_chunks, chunks, pred, s_qs, s_qe, s_ts, s_te, s_m, s_b,
                                                                              nullptr, min_len, min_ident, hd, ok_head, rec, n_heads,
