@@ -182,7 +182,22 @@ __global__ __launch_bounds__(EW_THREADS) void prepare_kernel(uint64_t n, const u
     cnt += __shfl_down(cnt, o, 64);
     zero += __shfl_down(zero, o, 64);
   }
+  // one set of atomics per work-group (the three scalars share a cache line: per wavefront these were 49,152 serialised
+  // atomics at the end of a kernel that streams 4 GB)
+  __shared__ uint32_t w_mx[EW_THREADS / 64], w_cnt[EW_THREADS / 64], w_zero[EW_THREADS / 64];
   if ((threadIdx.x & 63) == 0) {
+    w_mx[threadIdx.x >> 6] = mx;
+    w_cnt[threadIdx.x >> 6] = cnt;
+    w_zero[threadIdx.x >> 6] = zero;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < EW_THREADS / 64; ++w) {
+      mx = w_mx[w] > mx ? w_mx[w] : mx;
+      cnt += w_cnt[w];
+      zero += w_zero[w];
+    }
     atomicMax(&scalars[0], (unsigned long long)mx);
     atomicAdd(&scalars[1], (unsigned long long)cnt);
     if (zero) atomicAdd(&scalars[2], (unsigned long long)zero);
