@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_SWEEP = 33   # 4 x u32 coords + f64 identity + 2 x u32 segment ids in, 1 B flag out
 ALGO_BYTES_FULL = 47    # + u32 matches, u32 block_len, u8 strand in; u32 chain id, u8 status out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_TAG = "r06_v4"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
+PROFILE_TAG = "r06_v5"     # profiles/<tag>_hbm_traffic_<pipeline>_<100m|sbig1_10m>.json: rocprofv3 PMC bytes per launch
 
 # BASELINE.json's metric, verbatim
 BASELINE_METRIC = "PAF mappings/sec through plane-sweep+scaffold filter, 1/2/4/8 MI355X"
